@@ -1,0 +1,188 @@
+"""ORACLE (test infrastructure only - never imported by the product path).
+
+CPU fp32 restatement of the reference's OWN numerics on the training-step path:
+  * DDPM scheduler pieces the step uses (3P diffusers DDPMScheduler, restated; main.py:326)
+  * compute_snr / compute_diffusion_loss            (trainer/loss.py:83-106, 127-170)
+  * DAAM stack + token-attention loss               (trainer/ti_cross_attn_loss.py:239-268,
+                                                     trainer/loss.py:10-80)
+  * DistributionLoss std / covariance regularisers  (trainer/loss.py:254-297)
+  * L1 penalty                                      (main.py:353-356)
+  * AdamW step (torch.optim.AdamW defaults)         (trainer/optimizer.py:18)
+  * LR schedules                                    (main.py:236-240, 268-291)
+
+Pinned against the reference's own functions imported in this container with stub modules
+for its missing third-party imports: tests/golden/*.pt are produced by oracle/gen_golden.py
+and checked by tests/test_oracle_golden.py.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------ scheduler (3P, restated)
+
+def ddpm_alphas_cumprod(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012):
+    """diffusers DDPMScheduler(beta_schedule="scaled_linear") as used by SD1.5/SDXL."""
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+    return torch.cumprod(1.0 - betas, dim=0)
+
+
+def add_noise(alphas_cumprod, x0, noise, timesteps):
+    """DDPMScheduler.add_noise: sqrt(abar_t) x0 + sqrt(1-abar_t) eps   (main.py:326)."""
+    a = alphas_cumprod[timesteps] ** 0.5
+    s = (1.0 - alphas_cumprod[timesteps]) ** 0.5
+    shape = (-1,) + (1,) * (x0.dim() - 1)
+    return a.view(shape) * x0 + s.view(shape) * noise
+
+
+def get_velocity(alphas_cumprod, sample, noise, timesteps):
+    a = alphas_cumprod[timesteps] ** 0.5
+    s = (1.0 - alphas_cumprod[timesteps]) ** 0.5
+    shape = (-1,) + (1,) * (sample.dim() - 1)
+    return a.view(shape) * noise - s.view(shape) * sample
+
+
+# ------------------------------------------------------------------ diffusion loss
+
+def compute_snr(alphas_cumprod, timesteps):
+    """loss.py:83-106: (sqrt(abar)/sqrt(1-abar))^2 gathered at the timesteps, fp32."""
+    alpha = (alphas_cumprod ** 0.5)[timesteps].float()
+    sigma = ((1.0 - alphas_cumprod) ** 0.5)[timesteps].float()
+    return (alpha / sigma) ** 2
+
+
+def diffusion_loss(pred, noise, noisy_latent, mask, alphas_cumprod, timesteps, snr_gamma=5.0,
+                   prediction_type="epsilon"):
+    """loss.py:127-170.  gamma None/0: mean_b( mean_chw(e)_b / (mbar_b / mean_b mbar) ).
+    gamma>0: w_b = min(snr_b,gamma)/snr_b (+1 for v-pred), w <- w/mean(w), loss = mean_b(mean_chw(e)_b*w_b).
+    The reference's trailing "mask modulation" lines (loss.py:165-168) run on an already 1-D loss, so
+    dim=list(range(1,1))=[] reduces over everything: the divisor is exactly 1 and the final mean is
+    the batch mean - restated as such and pinned by tests/golden/diffusion_loss.pt."""
+    if prediction_type == "epsilon":
+        target = noise
+    elif prediction_type == "v_prediction":
+        target = get_velocity(alphas_cumprod, noisy_latent, noise, timesteps)
+    else:
+        raise ValueError(f"Unknown prediction type {prediction_type}")
+    e = (pred - target).pow(2) * mask
+    per_sample = e.flatten(1).mean(dim=1)
+    if snr_gamma is None or snr_gamma == 0.0:
+        mm = mask.flatten(1).mean(dim=1)
+        mm = mm / mm.mean()
+        return (per_sample / mm).mean()
+    snr = compute_snr(alphas_cumprod, timesteps)
+    w = torch.minimum(snr, torch.full_like(snr, float(snr_gamma))) / snr
+    if prediction_type == "v_prediction":
+        w = w + 1
+    w = w / w.mean()
+    return (per_sample * w).mean()
+
+
+# ------------------------------------------------------------------ DAAM stack + token attention loss
+
+def daam_stack(scores, img_ratio):
+    """ti_cross_attn_loss.py:239-268: each [B,N,77] -> [B,h,w,77] (w=round(sqrt(N*ratio)),
+    h=round(w/ratio)); maps larger than the smallest are bicubic-resized to it; stacked on dim 0."""
+    maps = []
+    min_px, min_shape = float("inf"), None
+    for s in scores:
+        b, n, c = s.shape
+        w = round(math.sqrt(n * img_ratio))
+        h = round(w / img_ratio)
+        m = s.reshape(b, h, w, c)
+        maps.append(m)
+        if h * w < min_px:
+            min_px, min_shape = h * w, (h, w)
+    out = []
+    for m in maps:
+        if m.shape[1] * m.shape[2] != min_px:
+            m = F.interpolate(m.permute(0, 3, 1, 2), size=min_shape, mode="bicubic").permute(0, 2, 3, 1)
+        out.append(m)
+    return torch.stack(out, dim=0)
+
+
+def token_attention_loss(attention_maps, masks, token_id_lists, train_ids):
+    """loss.py:10-80.  attention_maps [L,B,h,w,77] (daam_stack output), masks [B,4,H,W],
+    token_id_lists[b] = tokenizer.encode(caption_b) (BOS ... EOS), train_ids = TI token ids."""
+    masks = masks[:, 0].float()
+    L, B, h, w, T = attention_maps.shape
+    masks = F.interpolate(masks.unsqueeze(1), size=(h, w)).squeeze(1)  # nearest
+    att_l2, heat, hmask = [], [], []
+    for b, ids in enumerate(token_id_lists):
+        mean_att = attention_maps[:, b, :, :, 1:len(ids) - 1].mean(dim=[0, 1, 2])
+        att_l2.append((torch.relu(mean_att) ** 2).mean())
+        try:
+            pos = [ids.index(t) for t in train_ids]
+        except ValueError:
+            continue
+        heat.append(torch.stack([attention_maps[:, b, :, :, p].mean(dim=0).float() for p in pos]))
+        hmask.append(torch.stack([masks[b] for _ in pos]))
+    if not heat:
+        return torch.tensor(0.0)
+    heat = torch.stack(heat)      # [B', n_tok, h, w]
+    hmask = torch.stack(hmask)
+    token_var = heat.mean(dim=[2, 3]).var(dim=1)
+    r0 = 5.0 * torch.stack(att_l2).mean()
+    r1 = 1.0 * (torch.relu(heat * hmask) ** 2).mean()
+    r2 = 2.0 * (torch.relu(heat * (1 - hmask) + 10) ** 2).mean()
+    r3 = 1.0 * token_var.mean()
+    return r0 + r1 + r2 + r3
+
+
+# ------------------------------------------------------------------ TI regularisers
+
+class DistributionStats:
+    """loss.py:254-297 (DistributionLoss): statistics of the pretrained token table."""
+
+    def __init__(self, table):
+        t = table.float()
+        self.target_stds_mean = t.std(-1).mean()
+        self.target_stds_var = t.std(-1).std() ** 2 / t.std(-1).mean()
+        adj = t - t.mean(0)
+        self.target_cov = adj.T @ adj / (t.shape[0] - 1)
+
+    def std_loss(self, rows):
+        return ((self.target_stds_mean - rows.std(-1)) ** 2 / self.target_stds_var).mean()
+
+    def cov_loss(self, rows):
+        r = rows.float()
+        adj = r - r.mean(0)
+        cov = adj.T @ adj / (r.shape[0] - 1)
+        return torch.norm(self.target_cov - cov, p="fro") / (r.shape[1] ** 2)
+
+
+def l1_penalty(params, weight):
+    """main.py:353-356."""
+    return weight * sum(p.abs().sum() for p in params) / sum(p.numel() for p in params)
+
+
+# ------------------------------------------------------------------ optimiser + schedules
+
+def adamw_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    """torch.optim.AdamW (decoupled decay), single-tensor form; step is 1-based AFTER increment.
+    In-place on p, m, v."""
+    p.mul_(1.0 - lr * weight_decay)
+    m.mul_(beta1).add_(g, alpha=1.0 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1.0 - beta2)
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+def lr_schedule(global_step, step_in_epoch, epoch, steps_per_epoch, num_train_epochs, *, unet_lr,
+                unet_lr_warmup_steps, ti_lr, freeze_ti_after_completion_f=0.7,
+                freeze_unet_before_completion_f=0.0, is_lora=True, disable_ti=False):
+    """main.py:236-240,265-291.  Returns (lr_unet, lr_ti, completion_f)."""
+    base = 2.0e-4 if (is_lora and disable_ti) else 5.0e-5
+    if not is_lora:
+        base = 1.0e-5
+    completion_f = (epoch + step_in_epoch / steps_per_epoch) / num_train_epochs
+    lr_ti = ti_lr * (1 - completion_f) ** 1.7
+    if completion_f > freeze_ti_after_completion_f:
+        lr_ti = 0.0
+    lr_unet = base * (unet_lr / base) ** (global_step / unet_lr_warmup_steps)
+    if completion_f < freeze_unet_before_completion_f:
+        lr_unet = 0.0
+    return lr_unet, lr_ti, completion_f
