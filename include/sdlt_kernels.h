@@ -1,0 +1,212 @@
+/* C-ABI of the MI355X (gfx950) LoRA / textual-inversion training-step kernels.
+ *
+ * The reference (edenartlab/sd-lora-trainer) is pure Python and has no FFI; the seams this library
+ * sits behind are the duck-typed third-party interfaces listed in SURVEY.md 8b.  Each entry point
+ * below names the reference call site whose arithmetic it replaces (paths under /root/reference).
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions: every pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm on the host side:
+ * tensor.data_ptr()); kernels are enqueued on `stream` (a hipStream_t passed as void*), never allocate,
+ * never synchronise; return 0 on success or a negative SDLT_ERR_* code, with a human-readable message
+ * available from sdlt_last_error().  bf16 tensors are passed as raw 16-bit storage.  Activations are
+ * NHWC / token-major: a [B,C,H,W] feature map is the row-major matrix [B*H*W, C].
+ */
+#ifndef SDLT_KERNELS_H
+#define SDLT_KERNELS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* sdlt_last_error(void);
+int sdlt_abi_version(void);
+int sdlt_struct_size(int which); /* 0 gemm, 1 lora_grad_desc, 2 attn, 3 groupnorm, 4 shadow_desc */
+
+/* ------------------------------------------------------------------------------------------------
+ * sdlt_gemm_bf16 : C = alpha*(X.W^T [+ X2.W2^T] [+ s*(X.Adown^T).Bup^T]) + bias + rowbias + R
+ * Replaces: every nn.Linear / nn.Conv2d (3x3, 1x1) of the UNet forward and their dX backward
+ * (main.py:329-336 -> diffusers UNet2DConditionModel), with the peft LoRA adapter of
+ * trainer/optimizer.py:84-95 fused in (y = base(x) + (alpha/r) * B(A(x))).
+ * mode 0: X is a plain row-major [M,K] matrix (ldx).
+ * mode 1: implicit 3x3 convolution: X is an NHWC activation [B,Hin,Win,(ldx)], K = 9*Cin with
+ *         k = tap*Cin + ci, M = B*Hout*Wout.  stride in {1,2}; ups=2 reads a virtually nearest-2x
+ *         upsampled input; flip=1 mirrors the taps (dX of a stride-1 conv); tr=1 is the transposed
+ *         stride-2 form (dX of a stride-2 conv).  `zero` = >=128 B of zeros (out-of-image taps).
+ * K, K2 multiples of 64; lora_R (padded rank) in {0,16,32,64}; Adown [lora_R,K], Bup [N,lora_R].
+ * T_out (optional) receives s*X.Adown^T as bf16 [M,lora_R] (needed by the LoRA weight gradients).
+ * tile: 0 = auto, 1 = 128x128, 2 = 64x128, 3 = 64x64 (rows x cols of C per workgroup).
+ */
+typedef struct sdlt_gemm_params {
+  const void* X; int64_t ldx;
+  const void* W; int64_t ldw;
+  int32_t M, N, K;
+  const void* X2; int64_t ldx2;
+  const void* W2; int64_t ldw2;
+  int32_t K2;
+  int32_t mode;
+  int32_t Hin, Win, Cin, Hout, Wout, stride, ups, flip, tr;
+  const void* zero;
+  const void* Adown; int64_t ld_adown;
+  const void* Bup; int64_t ld_bup;
+  void* T_out; int64_t ld_t;
+  int32_t lora_R;
+  float lora_scale;
+  float alpha;
+  const float* bias;
+  const void* rowbias; int64_t ld_rowbias; int32_t rows_per_batch;
+  const void* R; int64_t ldr;
+  void* C; int64_t ldc;
+  int32_t out_fp32;
+  int32_t tile;
+  void* Ct; int64_t ldct;     /* optional transposed bf16 copy: Ct[n*ldct + m] */
+} sdlt_gemm_params;
+int sdlt_gemm_bf16(const sdlt_gemm_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optional transposed copy of C written by the sdlt_gemm_bf16 epilogue: set via sdlt_gemm_params.Ct
+ * (bf16 [N, ldct], Ct[n][m] = C[m][n]).  The attention kernels contract over tokens and want their
+ * operands token-contiguous; producing the transposed copy in the projection GEMM removes every
+ * in-kernel transpose.
+ */
+
+/* ------------------------------------------------------------------------------------------------
+ * sdlt_lora_grad_grouped : all LoRA weight gradients of one backward pass in ONE launch.
+ *   problem i:  out[c][r] or out[r][c] (+)= sum_m P[m][c] * Q[m][r]        (fp32 out, bf16 in)
+ *   dBup  = (dY)^T . (s*T)   : P = dY [M,N],  Q = s*T [M,Rp]  (T_out of the forward GEMM), out [N,R]
+ *   dAdown= (s*U)^T . X      : P = X  [M,K],  Q = s*U [M,Rp]  (T_out of the dX GEMM),     out [R,K]
+ * conv=1 gathers P rows like sdlt_gemm_bf16 mode 1 (forward geometry), for the 3x3 LoRA-down conv.
+ * Replaces autograd's per-adapter dA/dB matmuls behind loss.backward() (main.py:363) for the
+ * adapters created at trainer/optimizer.py:86-95.  One workgroup = one problem x 128 columns.
+ */
+typedef struct sdlt_lora_grad_desc {
+  const void* P; int64_t ldp;
+  const void* Q; int64_t ldq;
+  float* out;
+  int32_t M, Cw, R, Rp;          /* R = real rank (columns of Q used), Rp = padded rank in {16,32,64} */
+  int32_t rank_major;            /* 1: out[r*Cw + c]   0: out[c*R + r] */
+  int32_t accumulate;            /* 1: out += result (gradient accumulation) */
+  int32_t conv, Hin, Win, Cin, Hout, Wout, stride;
+  const void* zero;
+  int32_t first_block;           /* id of this problem's first workgroup in the launch */
+  int32_t pad_;
+} sdlt_lora_grad_desc;
+int sdlt_lora_grad_grouped(const sdlt_lora_grad_desc* descs_dev, const int32_t* block_desc_dev,
+                           int32_t n_blocks, int32_t Rp, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * sdlt_attn_fwd / sdlt_attn_bwd : multi-head softmax attention, flash style (no score matrix in HBM).
+ * Replaces F.scaled_dot_product_attention in the reference's DAAMLossAttnProcessor2_0.__call__
+ * (trainer/ti_cross_attn_loss.py:197-199), diffusers' AttnProcessor2_0 for attn1, and their backward.
+ * Q,dO,O,dQ: [B*Nqp, ld] token-major, head h in columns [h*d,(h+1)*d); K,V,dK,dV: [B*Nkp, ld].
+ * Nq/Nk = valid rows per batch, Nqp/Nkp = allocated rows per batch (multiples of 8; pad rows are
+ * masked).  Kt/Vt/Qt/dOt are the transposed copies [H*d, B*N?p].  L = log-sum-exp [B,H,Nq] fp32
+ * (written by fwd, read by bwd), D = rowsum(dO*O) [B,H,Nq] fp32 scratch (written by bwd).
+ * qsplit>1 splits the dK/dV reduction over query ranges (cross-attention: few keys, many queries),
+ * accumulating in dK32/dV32 fp32 [B*Nkp, ld32] scratch before the bf16 store.  causal: CLIP.
+ */
+typedef struct sdlt_attn_params {
+  const void* Q; int64_t ldq;
+  const void* K; int64_t ldk;
+  const void* V; int64_t ldv;
+  const void* Kt; int64_t ldkt;
+  const void* Vt; int64_t ldvt;
+  const void* Qt; int64_t ldqt;
+  const void* dOt; int64_t lddot;
+  void* O; int64_t ldo;
+  float* L;
+  const void* dO; int64_t lddo;
+  float* D;
+  void* dQ; int64_t lddq;
+  void* dK; int64_t lddk;
+  void* dV; int64_t lddv;
+  float* dK32; float* dV32; int64_t ld32;
+  int32_t B, H, Nq, Nk, Nqp, Nkp, d;
+  float scale;
+  int32_t qsplit;
+  int32_t causal;
+} sdlt_attn_params;
+int sdlt_attn_fwd(const sdlt_attn_params* p, void* stream);
+int sdlt_attn_bwd(const sdlt_attn_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * sdlt_groupnorm_fwd / _bwd : GroupNorm(32 groups) [+ SiLU] over an NHWC activation, and its dX.
+ * Replaces ResnetBlock2D.norm1/norm2 (+nonlinearity), Transformer2DModel.norm and conv_norm_out of
+ * the diffusers UNet reached from main.py:329-336.  The input may be the channel concatenation of two
+ * tensors (x1: C1 channels, x2: C-C1 channels) - the up-block skip concat is never materialised.
+ * stats [B,32,2] fp32 (sum, sumsq) is written by fwd and consumed by bwd; bstats is bwd scratch.
+ * bwd: dx = dres + dGN(dy) where dy is the gradient w.r.t. the (optionally SiLU'd) output.
+ */
+typedef struct sdlt_groupnorm_params {
+  const void* x1; int64_t ldx1; int32_t C1;
+  const void* x2; int64_t ldx2;
+  int32_t B, HW, C;
+  const float* gamma; const float* beta; float eps;
+  int32_t silu;
+  void* y; int64_t ldy;
+  float* stats;
+  const void* dy; int64_t lddy;
+  const void* dres; int64_t lddres;
+  void* dx; int64_t lddx;
+  float* bstats;
+} sdlt_groupnorm_params;
+int sdlt_groupnorm_fwd(const sdlt_groupnorm_params* p, void* stream);
+int sdlt_groupnorm_bwd(const sdlt_groupnorm_params* p, void* stream);
+
+/* LayerNorm over the last dim of [M,C] and its dX (dx = dres + dLN(dy)); stats [M,2] = (mean, rstd).
+ * Replaces BasicTransformerBlock.norm1/2/3 and the CLIP LayerNorms. */
+int sdlt_layernorm_fwd(const void* x, int64_t ldx, int32_t M, int32_t C, const float* gamma, const float* beta,
+                       float eps, void* y, int64_t ldy, float* stats, void* stream);
+int sdlt_layernorm_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy, int32_t M, int32_t C,
+                       const float* gamma, const float* stats, const void* dres, int64_t lddres, void* dx,
+                       int64_t lddx, void* stream);
+
+/* GEGLU (diffusers FeedForward, activation_fn="geglu"): in [M, 2*Ch] = (h | g), out = h * gelu(g). */
+int sdlt_geglu_fwd(const void* in, int64_t ldin, int32_t M, int32_t Ch, void* out, int64_t ldout, void* stream);
+int sdlt_geglu_bwd(const void* in, int64_t ldin, const void* dout, int64_t lddout, int32_t M, int32_t Ch, void* din,
+                   int64_t lddin, void* stream);
+
+/* Contiguous bf16 maps: op 0 silu, 1 dy*silu'(x), 2 x+dy, 3 gelu, 4 dy*gelu'(x), 5 quick_gelu, 6 dy*quick_gelu'(x). */
+int sdlt_map_bf16(int32_t op, const void* x, const void* dy, void* y, int64_t n, void* stream);
+
+/* diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): out[r] = [cos(t_r f) | sin(t_r f)] (bf16). */
+int sdlt_timestep_embedding(const float* t, int32_t rows, int32_t dim, void* out, int64_t ldo, void* stream);
+
+/* DDPMScheduler.add_noise (main.py:326) fused with NCHW fp32 -> NHWC bf16 (channels padded with zeros to Cpad). */
+int sdlt_add_noise_nhwc(const float* x0, const float* noise, const int64_t* timesteps, const float* alphas_cumprod,
+                        int32_t B, int32_t C, int32_t HW, int32_t Cpad, void* out_nhwc, float* noisy_nchw, void* stream);
+
+/* compute_diffusion_loss + compute_snr (trainer/loss.py:127-170, 83-106) forward AND d(loss)/d(pred).
+ * pred: NHWC fp32 [B*HW, ldp]; noise/noisy/mask: NCHW fp32; dpred: NHWC bf16 [B*HW, Cpad]; sums: [B,2] scratch. */
+int sdlt_masked_mse_fwd_bwd(const float* pred, int64_t ldp, const float* noise, const float* noisy, const float* mask,
+                            const int64_t* timesteps, const float* alphas_cumprod, int32_t B, int32_t C, int32_t HW,
+                            int32_t Cpad, float snr_gamma, int32_t v_prediction, float loss_scale, float* sums,
+                            float* loss_out, void* dpred, void* stream);
+
+/* torch.optim.AdamW step (trainer/optimizer.py:18,113-150; stepped optimizer.py:270-275) over a flat fp32 arena,
+ * with the L1 penalty of main.py:353-356 folded in as a subgradient.  hyper (device fp32[9]):
+ * lr, beta1, beta2, eps, weight_decay, 1-beta1^t, 1-beta2^t, l1 coefficient, grad scale.  l1_sum (optional) <- sum|p|. */
+int sdlt_adamw_fused(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float* l1_sum, void* stream);
+
+/* bf16 compute copies of the fp32 LoRA arena, in both orientations (dst [rows, ld], dstT [cols, ldT]). */
+typedef struct sdlt_shadow_desc {
+  int64_t offset;      /* element offset of the tensor in the fp32 arena */
+  int64_t src_ld;      /* row stride of the tensor inside the arena (elements) */
+  int32_t rows, cols;
+  void* dst; int64_t ld;
+  void* dstT; int64_t ldT;
+} sdlt_shadow_desc;
+int sdlt_lora_shadow_refresh(const sdlt_shadow_desc* descs_dev, const int32_t* block_desc_dev, const int32_t* block_first_dev,
+                             int32_t n_blocks, const float* arena, void* stream);
+
+/* out[M,C] = a + b on strided 2-D bf16 views (gradient fan-in of the UNet skip connections). */
+int sdlt_add2d(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int32_t M, int32_t C, void* stream);
+
+/* dX of nearest-2x upsampling: out[b,h,w,:] = sum of the 2x2 block of in [B,2H,2W,C]. */
+int sdlt_sum2x2(const void* in, int32_t B, int32_t H, int32_t W, int32_t C, void* out, void* stream);
+/* out[b,c] = sum_r x[b*R + r, c]  (fp32) - gradient of the per-batch time-embedding bias. */
+int sdlt_colsum(const void* x, int64_t ldx, int32_t B, int32_t R, int32_t C, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -53,7 +53,7 @@ CONFIGS = {
     ),
     # tiny topologies with the same wiring, for fast CPU tests of host logic
     "tiny15": dict(
-        block_out_channels=(32, 64, 64),
+        block_out_channels=(64, 128, 128),
         down_has_attn=(True, True, False),
         up_has_attn=(False, True, True),
         layers_per_block=1,
@@ -66,12 +66,12 @@ CONFIGS = {
         scaling_factor=0.18215,
     ),
     "tinyxl": dict(
-        block_out_channels=(32, 64, 128),
+        block_out_channels=(64, 128, 128),
         down_has_attn=(False, True, True),
         up_has_attn=(True, True, False),
         layers_per_block=1,
         transformer_layers=(1, 1, 2),
-        heads=(1, 1, 2),                 # head_dim 64 like SDXL
+        heads=(1, 2, 2),                 # head_dim 64 like SDXL
         cross_dim=64,
         linear_proj=True,
         addition=True, addition_time_embed_dim=32, proj_class_in=64 + 6 * 32,

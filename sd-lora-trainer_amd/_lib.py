@@ -1,0 +1,143 @@
+"""ctypes binding of libsdlt_kernels.so (include/sdlt_kernels.h).
+
+The product path has NO fallback: if the HIP library is missing or a kernel returns an error this
+module raises.  torch is imported first so the library binds to the libamdhip64 that PyTorch-ROCm
+already loaded (one HIP runtime per process -> shared streams and graph capture).
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be loaded before the HIP library, see above)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdlt_kernels.so")
+
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class GemmParams(C.Structure):
+    _fields_ = [
+        ("X", vp), ("ldx", i64), ("W", vp), ("ldw", i64),
+        ("M", i32), ("N", i32), ("K", i32),
+        ("X2", vp), ("ldx2", i64), ("W2", vp), ("ldw2", i64),
+        ("K2", i32), ("mode", i32),
+        ("Hin", i32), ("Win", i32), ("Cin", i32), ("Hout", i32), ("Wout", i32),
+        ("stride", i32), ("ups", i32), ("flip", i32), ("tr", i32),
+        ("zero", vp),
+        ("Adown", vp), ("ld_adown", i64), ("Bup", vp), ("ld_bup", i64),
+        ("T_out", vp), ("ld_t", i64),
+        ("lora_R", i32), ("lora_scale", f32), ("alpha", f32),
+        ("bias", vp),
+        ("rowbias", vp), ("ld_rowbias", i64), ("rows_per_batch", i32),
+        ("R", vp), ("ldr", i64),
+        ("C", vp), ("ldc", i64),
+        ("out_fp32", i32), ("tile", i32),
+        ("Ct", vp), ("ldct", i64),
+    ]
+
+
+class LoraGradDesc(C.Structure):
+    _fields_ = [
+        ("P", vp), ("ldp", i64), ("Q", vp), ("ldq", i64), ("out", vp),
+        ("M", i32), ("Cw", i32), ("R", i32), ("Rp", i32),
+        ("rank_major", i32), ("accumulate", i32),
+        ("conv", i32), ("Hin", i32), ("Win", i32), ("Cin", i32), ("Hout", i32), ("Wout", i32), ("stride", i32),
+        ("zero", vp),
+        ("first_block", i32), ("pad_", i32),
+    ]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [
+        ("Q", vp), ("ldq", i64), ("K", vp), ("ldk", i64), ("V", vp), ("ldv", i64),
+        ("Kt", vp), ("ldkt", i64), ("Vt", vp), ("ldvt", i64), ("Qt", vp), ("ldqt", i64), ("dOt", vp), ("lddot", i64),
+        ("O", vp), ("ldo", i64), ("L", vp),
+        ("dO", vp), ("lddo", i64), ("D", vp),
+        ("dQ", vp), ("lddq", i64), ("dK", vp), ("lddk", i64), ("dV", vp), ("lddv", i64),
+        ("dK32", vp), ("dV32", vp), ("ld32", i64),
+        ("B", i32), ("H", i32), ("Nq", i32), ("Nk", i32), ("Nqp", i32), ("Nkp", i32), ("d", i32),
+        ("scale", f32), ("qsplit", i32), ("causal", i32),
+    ]
+
+
+class GroupNormParams(C.Structure):
+    _fields_ = [
+        ("x1", vp), ("ldx1", i64), ("C1", i32),
+        ("x2", vp), ("ldx2", i64),
+        ("B", i32), ("HW", i32), ("C", i32),
+        ("gamma", vp), ("beta", vp), ("eps", f32),
+        ("silu", i32),
+        ("y", vp), ("ldy", i64),
+        ("stats", vp),
+        ("dy", vp), ("lddy", i64),
+        ("dres", vp), ("lddres", i64),
+        ("dx", vp), ("lddx", i64),
+        ("bstats", vp),
+    ]
+
+
+class ShadowDesc(C.Structure):
+    _fields_ = [("offset", i64), ("src_ld", i64), ("rows", i32), ("cols", i32), ("dst", vp), ("ld", i64), ("dstT", vp), ("ldT", i64)]
+
+
+# every symbol include/sdlt_kernels.h declares (tests/test_capi_symbols.py cross-checks this list with the header)
+SYMBOLS = {
+    "sdlt_last_error": (C.c_char_p, []),
+    "sdlt_abi_version": (i32, []),
+    "sdlt_struct_size": (i32, [i32]),
+    "sdlt_add2d": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, vp]),
+    "sdlt_gemm_bf16": (i32, [C.POINTER(GemmParams), vp]),
+    "sdlt_lora_grad_grouped": (i32, [vp, vp, i32, i32, vp]),
+    "sdlt_attn_fwd": (i32, [C.POINTER(AttnParams), vp]),
+    "sdlt_attn_bwd": (i32, [C.POINTER(AttnParams), vp]),
+    "sdlt_groupnorm_fwd": (i32, [C.POINTER(GroupNormParams), vp]),
+    "sdlt_groupnorm_bwd": (i32, [C.POINTER(GroupNormParams), vp]),
+    "sdlt_layernorm_fwd": (i32, [vp, i64, i32, i32, vp, vp, f32, vp, i64, vp, vp]),
+    "sdlt_layernorm_bwd": (i32, [vp, i64, vp, i64, i32, i32, vp, vp, vp, i64, vp, i64, vp]),
+    "sdlt_geglu_fwd": (i32, [vp, i64, i32, i32, vp, i64, vp]),
+    "sdlt_geglu_bwd": (i32, [vp, i64, vp, i64, i32, i32, vp, i64, vp]),
+    "sdlt_map_bf16": (i32, [i32, vp, vp, vp, i64, vp]),
+    "sdlt_timestep_embedding": (i32, [vp, i32, i32, vp, i64, vp]),
+    "sdlt_add_noise_nhwc": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+    "sdlt_masked_mse_fwd_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, f32, vp, vp, vp, vp]),
+    "sdlt_adamw_fused": (i32, [vp, vp, vp, vp, i64, vp, vp, vp]),
+    "sdlt_lora_shadow_refresh": (i32, [vp, vp, vp, i32, vp, vp]),
+    "sdlt_sum2x2": (i32, [vp, i32, i32, i32, i32, vp, vp]),
+    "sdlt_colsum": (i32, [vp, i64, i32, i32, i32, vp, vp]),
+}
+
+_lib = None
+
+
+class KernelLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises KernelLibraryError - never falls back to anything."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KernelLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU / PyTorch fallback for the training step.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise KernelLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    for which, cls in enumerate((GemmParams, LoraGradDesc, AttnParams, GroupNormParams, ShadowDesc)):
+        if lib.sdlt_struct_size(which) != C.sizeof(cls):
+            raise KernelLibraryError(f"struct layout mismatch for {cls.__name__}: C {lib.sdlt_struct_size(which)} vs ctypes {C.sizeof(cls)}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().sdlt_last_error()
+        raise KernelLibraryError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")

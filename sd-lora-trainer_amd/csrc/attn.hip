@@ -1,0 +1,493 @@
+// Flash-style multi-head attention forward / backward on MFMA (gfx950), used for both the UNet
+// self-attention (attn1) and the 77-token cross-attention (attn2) of every BasicTransformerBlock,
+// and for the CLIP text encoders (causal flag).
+//
+// Replaces F.scaled_dot_product_attention inside diffusers' AttnProcessor2_0 and the reference's own
+// DAAMLossAttnProcessor2_0.__call__ (trainer/ti_cross_attn_loss.py:197-199) together with its autograd
+// backward.  (The head-summed raw-score side output of ti_cross_attn_loss.py:201-212 is one dense GEMM,
+// sum_h Q_h K_h^T = Q K^T, and goes through sdlt_gemm_bf16.)
+//
+// Layout contract: Q/K/V/O/dO/dQ/dK/dV are token-major [B*N, C] with head h in columns [h*d,(h+1)*d).
+// Operands that an MFMA must contract over the TOKEN axis are also supplied transposed ([C, B*N],
+// written by the producing GEMM's epilogue, see sdlt_gemm_bf16 Ct) so every LDS tile is filled with
+// plain 16-byte copies and read with ds_read_b128 - no in-kernel transposes.
+//
+// MFMA chaining without cross-lane traffic: all products are computed "swapped" (D[i][j] with j the
+// row that owns the softmax statistics), and the tile rows fed as the MFMA A operand are PERMUTED
+// (row i of a 16-row fragment <-> token (i/4)*8 + half*4 + i%4 of a 32-token block) so that the two
+// 16x16 accumulators of a 32-token block are, per lane, exactly the 8 consecutive tokens the next
+// 16x16x32 MFMA wants as its B operand.
+#include "common.h"
+#include "../../include/sdlt_kernels.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int TSTR = 64 * 2 + 16;  // bytes per row of a transposed [DP][64-token] tile
+
+__device__ __forceinline__ bf16x8 pack8(const float* a, const float* b) {
+  union { uint4 u; bf16x8 v; } c;
+  c.u.x = pack2bf(a[0], a[1]); c.u.y = pack2bf(a[2], a[3]);
+  c.u.z = pack2bf(b[0], b[1]); c.u.w = pack2bf(b[2], b[3]);
+  return c.v;
+}
+__device__ __forceinline__ bf16x8 ld_frag_global(const bf16_t* p, bool ok) {
+  union { uint4 u; bf16x8 v; } c;
+  c.u = ok ? *(const uint4*)p : make_uint4(0, 0, 0, 0);
+  return c.v;
+}
+__device__ __forceinline__ int prow(int i, int half) { return ((i >> 2) << 3) + half * 4 + (i & 3); }
+
+// natural tile: dst[row][DP] (row stride NSTR bytes) <- src[(row0+row)*ld + col0 + c], rows >= nrows or c >= d zero-filled
+template <int DP>
+__device__ __forceinline__ void load_tile_nat(char* dst, const bf16_t* src, int64_t ld, int64_t row0, int nrows, int col0, int d) {
+  constexpr int NSTR = DP * 2 + 16, CH = DP / 8;
+  for (int c = threadIdx.x; c < 64 * CH; c += 256) {
+    int row = c / CH, ch = c - row * CH;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < nrows && ch * 8 < d) v = *(const uint4*)(src + (row0 + row) * ld + col0 + ch * 8);
+    *(uint4*)(dst + row * NSTR + ch * 16) = v;
+  }
+}
+// transposed tile: dst[dd][64] (row stride TSTR) <- srcT[(col0+dd)*ldT + t0 + t], dd >= d or t >= ntok zero-filled
+template <int DP>
+__device__ __forceinline__ void load_tile_tr(char* dst, const bf16_t* srcT, int64_t ldT, int col0, int d, int64_t t0, int ntok) {
+  for (int c = threadIdx.x; c < DP * 8; c += 256) {
+    int dd = c >> 3, ch = c & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (dd < d && ch * 8 < ntok) v = *(const uint4*)(srcT + (int64_t)(col0 + dd) * ldT + t0 + ch * 8);
+    *(uint4*)(dst + dd * TSTR + ch * 16) = v;
+  }
+}
+
+// =============================================================================== forward
+template <int DP>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const sdlt_attn_params p) {
+  constexpr int NSTR = DP * 2 + 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vt = smem + 64 * NSTR;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
+  const int d = p.d, hc = h * d;
+  const int q = q0 + wave * 16 + i;
+  bf16x8 qf[DP / 32];
+#pragma unroll
+  for (int kk = 0; kk < DP / 32; ++kk) {
+    int col = kk * 32 + g * 8;
+    qf[kk] = ld_frag_global((const bf16_t*)p.Q + ((int64_t)b * p.Nqp + q) * p.ldq + hc + col, q < p.Nq && col < d);
+  }
+  float m = -1e30f, lsum = 0.f;
+  f32x4 o[DP / 16];
+#pragma unroll
+  for (int df = 0; df < DP / 16; ++df) o[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float sl2 = p.scale * LOG2E;
+  const int kend = p.causal ? min(p.Nk, q0 + 64) : p.Nk;
+
+  for (int k0 = 0; k0 < kend; k0 += 64) {
+    __syncthreads();
+    const int nk = min(64, p.Nkp - k0);
+    load_tile_nat<DP>(Ks, (const bf16_t*)p.K, p.ldk, (int64_t)b * p.Nkp + k0, nk, hc, d);
+    load_tile_tr<DP>(Vt, (const bf16_t*)p.Vt, p.ldvt, hc, d, (int64_t)b * p.Nkp + k0, nk);
+    __syncthreads();
+    f32x4 s[4];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf) {
+      s[kf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int krow = (kf >> 1) * 32 + prow(i, kf & 1);
+#pragma unroll
+      for (int kk = 0; kk < DP / 32; ++kk) {
+        bf16x8 kfr = *(const bf16x8*)(Ks + krow * NSTR + (kk * 32 + g * 8) * 2);
+        s[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[kk], s[kf], 0, 0, 0);
+      }
+    }
+    float tmax = -1e30f;
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int key = k0 + (kf >> 1) * 32 + g * 8 + (kf & 1) * 4 + r;
+        float v = s[kf][r] * sl2;
+        if (key >= p.Nk || (p.causal && key > q)) v = -1e30f;
+        s[kf][r] = v;
+        tmax = fmaxf(tmax, v);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float mn = fmaxf(m, tmax);
+    const float alpha = exp2f(m - mn);
+    m = mn;
+    float rs = 0.f;
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float pv = exp2f(s[kf][r] - mn);
+        s[kf][r] = pv;
+        rs += pv;
+      }
+    lsum = lsum * alpha + rs;
+#pragma unroll
+    for (int df = 0; df < DP / 16; ++df) o[df] *= alpha;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float a4[4] = {s[2 * kb][0], s[2 * kb][1], s[2 * kb][2], s[2 * kb][3]};
+      float b4[4] = {s[2 * kb + 1][0], s[2 * kb + 1][1], s[2 * kb + 1][2], s[2 * kb + 1][3]};
+      bf16x8 pf = pack8(a4, b4);
+#pragma unroll
+      for (int df = 0; df < DP / 16; ++df) {
+        bf16x8 vf = *(const bf16x8*)(Vt + (df * 16 + i) * TSTR + (kb * 32 + g * 8) * 2);
+        o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[df], 0, 0, 0);
+      }
+    }
+  }
+  lsum += __shfl_xor(lsum, 16, 64);
+  lsum += __shfl_xor(lsum, 32, 64);
+  if (q < p.Nqp) {   // pad rows get finite values too, so no consumer ever reads uninitialised memory
+    const float inv = 1.f / lsum;
+    if (g == 0 && p.L && q < p.Nq) p.L[((int64_t)b * p.H + h) * p.Nq + q] = (m + log2f(lsum)) / LOG2E;
+#pragma unroll
+    for (int df = 0; df < DP / 16; ++df) {
+      int col = df * 16 + g * 4;
+      if (col < d) {
+        uint2 w;
+        w.x = pack2bf(o[df][0] * inv, o[df][1] * inv);
+        w.y = pack2bf(o[df][2] * inv, o[df][3] * inv);
+        *(uint2*)((bf16_t*)p.O + ((int64_t)b * p.Nqp + q) * p.ldo + hc + col) = w;
+      }
+    }
+  }
+}
+
+// =============================================================================== backward prep: D[b,h,q] = sum_d dO*O
+__global__ void attn_prep_kernel(const bf16_t* O, int64_t ldo, const bf16_t* dO, int64_t lddo, int B, int H, int Nq, int Nqp, int d, float* D) {
+  // one 8-lane group per (b,q,h); lane handles 8-element chunks
+  const int64_t total = (int64_t)B * Nqp * H;
+  const int sub = threadIdx.x & 7;
+  for (int64_t idx = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 3; idx < total; idx += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+    int h = idx % H;
+    int64_t row = idx / H;  // b*Nqp + q
+    const int b = row / Nqp, q = row - (int64_t)b * Nqp;
+    if (q >= Nq) continue;   // uniform within the 8-lane group
+    float acc = 0.f;
+    for (int c = sub * 8; c < d; c += 64) {
+      uint4 a = *(const uint4*)(O + row * ldo + h * d + c);
+      uint4 g = *(const uint4*)(dO + row * lddo + h * d + c);
+      const uint32_t* ap = (const uint32_t*)&a;
+      const uint32_t* gp = (const uint32_t*)&g;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc += bf2f(ap[j] & 0xffff) * bf2f(gp[j] & 0xffff) + bf2f(ap[j] >> 16) * bf2f(gp[j] >> 16);
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (sub == 0) D[((int64_t)b * H + h) * Nq + q] = acc;
+  }
+}
+
+// =============================================================================== backward dQ (per 64-query tile)
+template <int DP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const sdlt_attn_params p) {
+  constexpr int NSTR = DP * 2 + 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = Ks + 64 * NSTR;
+  char* Kt = Vs + 64 * NSTR;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
+  const int d = p.d, hc = h * d;
+  const int q = q0 + wave * 16 + i;
+  const bool qok = q < p.Nq;
+  bf16x8 qf[DP / 32], gf[DP / 32];
+#pragma unroll
+  for (int kk = 0; kk < DP / 32; ++kk) {
+    int col = kk * 32 + g * 8;
+    qf[kk] = ld_frag_global((const bf16_t*)p.Q + ((int64_t)b * p.Nqp + q) * p.ldq + hc + col, qok && col < d);
+    gf[kk] = ld_frag_global((const bf16_t*)p.dO + ((int64_t)b * p.Nqp + q) * p.lddo + hc + col, qok && col < d);
+  }
+  const float Lq = qok ? p.L[((int64_t)b * p.H + h) * p.Nq + q] * LOG2E : 0.f;
+  const float Dq = qok ? p.D[((int64_t)b * p.H + h) * p.Nq + q] : 0.f;
+  f32x4 dq[DP / 16];
+#pragma unroll
+  for (int df = 0; df < DP / 16; ++df) dq[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float sl2 = p.scale * LOG2E;
+  const int kend = p.causal ? min(p.Nk, q0 + 64) : p.Nk;
+
+  for (int k0 = 0; k0 < kend; k0 += 64) {
+    __syncthreads();
+    const int nk = min(64, p.Nkp - k0);
+    load_tile_nat<DP>(Ks, (const bf16_t*)p.K, p.ldk, (int64_t)b * p.Nkp + k0, nk, hc, d);
+    load_tile_nat<DP>(Vs, (const bf16_t*)p.V, p.ldv, (int64_t)b * p.Nkp + k0, nk, hc, d);
+    load_tile_tr<DP>(Kt, (const bf16_t*)p.Kt, p.ldkt, hc, d, (int64_t)b * p.Nkp + k0, nk);
+    __syncthreads();
+    f32x4 s[4], dp[4];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf) {
+      s[kf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dp[kf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int krow = (kf >> 1) * 32 + prow(i, kf & 1);
+#pragma unroll
+      for (int kk = 0; kk < DP / 32; ++kk) {
+        bf16x8 kfr = *(const bf16x8*)(Ks + krow * NSTR + (kk * 32 + g * 8) * 2);
+        s[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[kk], s[kf], 0, 0, 0);
+        bf16x8 vfr = *(const bf16x8*)(Vs + krow * NSTR + (kk * 32 + g * 8) * 2);
+        dp[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, gf[kk], dp[kf], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int key = k0 + (kf >> 1) * 32 + g * 8 + (kf & 1) * 4 + r;
+        bool ok = qok && key < p.Nk && !(p.causal && key > q);
+        float pv = ok ? exp2f(s[kf][r] * sl2 - Lq) : 0.f;
+        s[kf][r] = pv * (dp[kf][r] - Dq) * p.scale;  // dS
+      }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float a4[4] = {s[2 * kb][0], s[2 * kb][1], s[2 * kb][2], s[2 * kb][3]};
+      float b4[4] = {s[2 * kb + 1][0], s[2 * kb + 1][1], s[2 * kb + 1][2], s[2 * kb + 1][3]};
+      bf16x8 dsf = pack8(a4, b4);
+#pragma unroll
+      for (int df = 0; df < DP / 16; ++df) {
+        bf16x8 ktf = *(const bf16x8*)(Kt + (df * 16 + i) * TSTR + (kb * 32 + g * 8) * 2);
+        dq[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dq[df], 0, 0, 0);
+      }
+    }
+  }
+  if (q < p.Nqp) {   // pad rows: dq == 0
+#pragma unroll
+    for (int df = 0; df < DP / 16; ++df) {
+      int col = df * 16 + g * 4;
+      if (col < d) {
+        uint2 w;
+        w.x = pack2bf(dq[df][0], dq[df][1]);
+        w.y = pack2bf(dq[df][2], dq[df][3]);
+        *(uint2*)((bf16_t*)p.dQ + ((int64_t)b * p.Nqp + q) * p.lddq + hc + col) = w;
+      }
+    }
+  }
+}
+
+// =============================================================================== backward dK,dV (per 64-key tile, optional query split)
+template <int DP>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const sdlt_attn_params p) {
+  constexpr int NSTR = DP * 2 + 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qs = smem;
+  char* Gs = Qs + 64 * NSTR;            // dO natural
+  char* Qt = Gs + 64 * NSTR;            // [DP][64 q]
+  char* Gt = Qt + DP * TSTR;            // dO^T
+  float* Ls = (float*)(Gt + DP * TSTR); // [64]
+  float* Ds = Ls + 64;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int ktile = blockIdx.x / p.qsplit, split = blockIdx.x - ktile * p.qsplit;
+  const int k0 = ktile * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
+  const int d = p.d, hc = h * d;
+  const int key = k0 + wave * 16 + i;
+  const bool kok = key < p.Nk;
+  bf16x8 kf[DP / 32], vf[DP / 32];
+#pragma unroll
+  for (int kk = 0; kk < DP / 32; ++kk) {
+    int col = kk * 32 + g * 8;
+    kf[kk] = ld_frag_global((const bf16_t*)p.K + ((int64_t)b * p.Nkp + key) * p.ldk + hc + col, kok && col < d);
+    vf[kk] = ld_frag_global((const bf16_t*)p.V + ((int64_t)b * p.Nkp + key) * p.ldv + hc + col, kok && col < d);
+  }
+  f32x4 dk[DP / 16], dv[DP / 16];
+#pragma unroll
+  for (int df = 0; df < DP / 16; ++df) {
+    dk[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dv[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const float sl2 = p.scale * LOG2E;
+  const int nqt = (p.Nq + 63) / 64;
+  const int per = (nqt + p.qsplit - 1) / p.qsplit;
+  int qt_lo = split * per, qt_hi = min(nqt, qt_lo + per);
+  if (p.causal) qt_lo = max(qt_lo, ktile);  // queries before this key tile never see it
+
+  for (int qt = qt_lo; qt < qt_hi; ++qt) {
+    const int q0 = qt * 64;
+    __syncthreads();
+    const int nq = min(64, p.Nqp - q0);
+    load_tile_nat<DP>(Qs, (const bf16_t*)p.Q, p.ldq, (int64_t)b * p.Nqp + q0, nq, hc, d);
+    load_tile_nat<DP>(Gs, (const bf16_t*)p.dO, p.lddo, (int64_t)b * p.Nqp + q0, nq, hc, d);
+    load_tile_tr<DP>(Qt, (const bf16_t*)p.Qt, p.ldqt, hc, d, (int64_t)b * p.Nqp + q0, nq);
+    load_tile_tr<DP>(Gt, (const bf16_t*)p.dOt, p.lddot, hc, d, (int64_t)b * p.Nqp + q0, nq);
+    if (threadIdx.x < 64) {
+      int qq = q0 + threadIdx.x;
+      Ls[threadIdx.x] = qq < p.Nq ? p.L[((int64_t)b * p.H + h) * p.Nq + qq] * LOG2E : 0.f;
+      Ds[threadIdx.x] = qq < p.Nq ? p.D[((int64_t)b * p.H + h) * p.Nq + qq] : 0.f;
+    }
+    __syncthreads();
+    f32x4 s[4], dp[4];
+#pragma unroll
+    for (int qf = 0; qf < 4; ++qf) {
+      s[qf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dp[qf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int qrow = (qf >> 1) * 32 + prow(i, qf & 1);
+#pragma unroll
+      for (int kk = 0; kk < DP / 32; ++kk) {
+        bf16x8 qfr = *(const bf16x8*)(Qs + qrow * NSTR + (kk * 32 + g * 8) * 2);
+        s[qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kk], s[qf], 0, 0, 0);
+        bf16x8 gfr = *(const bf16x8*)(Gs + qrow * NSTR + (kk * 32 + g * 8) * 2);
+        dp[qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gfr, vf[kk], dp[qf], 0, 0, 0);
+      }
+    }
+    // s[qf][r] = S[q = q0 + (qf>>1)*32 + g*8 + (qf&1)*4 + r][key]
+#pragma unroll
+    for (int qf = 0; qf < 4; ++qf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int ql = (qf >> 1) * 32 + g * 8 + (qf & 1) * 4 + r;
+        int qq = q0 + ql;
+        bool ok = kok && qq < p.Nq && !(p.causal && key > qq);
+        float pv = ok ? exp2f(s[qf][r] * sl2 - Ls[ql]) : 0.f;
+        s[qf][r] = pv;
+        dp[qf][r] = pv * (dp[qf][r] - Ds[ql]) * p.scale;
+      }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float a4[4] = {s[2 * qb][0], s[2 * qb][1], s[2 * qb][2], s[2 * qb][3]};
+      float b4[4] = {s[2 * qb + 1][0], s[2 * qb + 1][1], s[2 * qb + 1][2], s[2 * qb + 1][3]};
+      bf16x8 pf = pack8(a4, b4);
+      float c4[4] = {dp[2 * qb][0], dp[2 * qb][1], dp[2 * qb][2], dp[2 * qb][3]};
+      float e4[4] = {dp[2 * qb + 1][0], dp[2 * qb + 1][1], dp[2 * qb + 1][2], dp[2 * qb + 1][3]};
+      bf16x8 dsf = pack8(c4, e4);
+#pragma unroll
+      for (int df = 0; df < DP / 16; ++df) {
+        bf16x8 gtf = *(const bf16x8*)(Gt + (df * 16 + i) * TSTR + (qb * 32 + g * 8) * 2);
+        dv[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gtf, pf, dv[df], 0, 0, 0);
+        bf16x8 qtf = *(const bf16x8*)(Qt + (df * 16 + i) * TSTR + (qb * 32 + g * 8) * 2);
+        dk[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf, dk[df], 0, 0, 0);
+      }
+    }
+  }
+  if (key < p.Nkp) {   // pad rows [Nk, Nkp) receive zeros (their accumulators are zero: p == 0 there)
+    const int64_t row = (int64_t)b * p.Nkp + key;
+#pragma unroll
+    for (int df = 0; df < DP / 16; ++df) {
+      int col = df * 16 + g * 4;
+      if (col < d) {
+        if (p.qsplit > 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            atomicAdd(p.dK32 + row * p.ld32 + hc + col + r, dk[df][r]);
+            atomicAdd(p.dV32 + row * p.ld32 + hc + col + r, dv[df][r]);
+          }
+        } else {
+          uint2 w;
+          w.x = pack2bf(dk[df][0], dk[df][1]); w.y = pack2bf(dk[df][2], dk[df][3]);
+          *(uint2*)((bf16_t*)p.dK + row * p.lddk + hc + col) = w;
+          w.x = pack2bf(dv[df][0], dv[df][1]); w.y = pack2bf(dv[df][2], dv[df][3]);
+          *(uint2*)((bf16_t*)p.dV + row * p.lddv + hc + col) = w;
+        }
+      }
+    }
+  }
+}
+
+// fp32 [rows, C] (ld32) -> bf16 [rows, C] (ld) after the atomics of the query-split path
+__global__ void cvt_f32_bf16_kernel(const float* in, int64_t ldi, bf16_t* out, int64_t ldo, int rows, int C) {
+  const int nch = C >> 2;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < (int64_t)rows * nch; t += (int64_t)gridDim.x * blockDim.x) {
+    int r = t / nch, c = (t - (int64_t)r * nch) * 4;
+    float4 v = *(const float4*)(in + r * ldi + c);
+    uint2 w;
+    w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+    *(uint2*)(out + r * ldo + c) = w;
+  }
+}
+
+int attn_dp(int d) {
+  if (d <= 0 || (d % 8)) return -1;
+  if (d <= 64) return 64;
+  if (d <= 96) return 96;
+  if (d <= 128) return 128;
+  if (d <= 160) return 160;
+  return -1;
+}
+
+int attn_check(const sdlt_attn_params& p, const char* fn) {
+  if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0 || p.Nkp < p.Nk || attn_dp(p.d) < 0)
+    SDLT_FAIL(SDLT_ERR_SHAPE, "%s: B=%d H=%d Nq=%d Nk=%d Nkp=%d d=%d (d %% 8 == 0, d <= 160)", fn, p.B, p.H, p.Nq, p.Nk, p.Nkp, p.d);
+  if (p.Nqp < p.Nq || (p.Nkp % 8) || (p.Nqp % 8)) SDLT_FAIL(SDLT_ERR_ALIGN, "%s: Nqp/Nkp (padded rows per batch) must be multiples of 8 and >= Nq/Nk", fn);
+  if ((p.ldq % 8) || (p.ldk % 8) || (p.ldv % 8)) SDLT_FAIL(SDLT_ERR_ALIGN, "%s: ld %% 8", fn);
+  return SDLT_OK;
+}
+
+template <typename F>
+int set_smem(F f, int bytes) {
+  // one attribute call per kernel instantiation, keyed by function pointer
+  static const void* done[32];
+  static int ndone = 0;
+  for (int i = 0; i < ndone; ++i)
+    if (done[i] == (const void*)f) return 0;
+  hipError_t e = hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (ndone < 32) done[ndone++] = (const void*)f;
+  return e == hipSuccess ? 0 : -1;
+}
+
+#define ATTN_DISPATCH(DPV, KERNEL, GRID, SMEM)                                                  \
+  switch (DPV) {                                                                                \
+    case 64: set_smem(KERNEL<64>, SMEM(64)); hipLaunchKernelGGL(KERNEL<64>, GRID, dim3(256), SMEM(64), s, p); break;     \
+    case 96: set_smem(KERNEL<96>, SMEM(96)); hipLaunchKernelGGL(KERNEL<96>, GRID, dim3(256), SMEM(96), s, p); break;     \
+    case 128: set_smem(KERNEL<128>, SMEM(128)); hipLaunchKernelGGL(KERNEL<128>, GRID, dim3(256), SMEM(128), s, p); break; \
+    default: set_smem(KERNEL<160>, SMEM(160)); hipLaunchKernelGGL(KERNEL<160>, GRID, dim3(256), SMEM(160), s, p); break; \
+  }
+
+}  // namespace
+
+extern "C" int sdlt_attn_fwd(const sdlt_attn_params* pp, void* stream) {
+  const sdlt_attn_params& p = *pp;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = attn_check(p, "sdlt_attn_fwd");
+  if (rc) return rc;
+  if (!p.Vt || (p.ldvt % 8) || (p.ldo % 4)) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_attn_fwd: needs V^T (ld %% 8) and ldo %% 4");
+  const int dp = attn_dp(p.d);
+  dim3 grid((p.Nq + 63) / 64, p.H, p.B);
+#define SMEM_FWD(D_) (64 * ((D_) * 2 + 16) + (D_) * TSTR)
+  ATTN_DISPATCH(dp, attn_fwd_kernel, grid, SMEM_FWD)
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+
+extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
+  const sdlt_attn_params& p = *pp;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = attn_check(p, "sdlt_attn_bwd");
+  if (rc) return rc;
+  if (!p.Kt || !p.Qt || !p.dOt || !p.L || !p.D || !p.O || !p.dO || !p.dQ)
+    SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_attn_bwd: missing operand (K^T, Q^T, dO^T, L, D, O, dO, dQ are required)");
+  if ((p.ldkt % 8) || (p.ldqt % 8) || (p.lddot % 8) || (p.lddo % 8) || (p.ldo % 8) || (p.lddq % 4))
+    SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_attn_bwd: ld alignment");
+  if (p.qsplit < 1) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_attn_bwd: qsplit=%d", p.qsplit);
+  if (!p.dK || !p.dV || (p.lddk % 4) || (p.lddv % 4) || (p.qsplit > 1 && (!p.dK32 || !p.dV32 || (p.ld32 % 4))))
+    SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_attn_bwd: dK/dV outputs for qsplit=%d", p.qsplit);
+  const int dp = attn_dp(p.d);
+  {
+    int64_t groups = (int64_t)p.B * p.Nqp * p.H;
+    int blocks = (int)((groups * 8 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(attn_prep_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)p.O, p.ldo, (const bf16_t*)p.dO, p.lddo, p.B, p.H, p.Nq, p.Nqp, p.d, p.D);
+  }
+  dim3 gq((p.Nq + 63) / 64, p.H, p.B);
+#define SMEM_DQ(D_) (2 * 64 * ((D_) * 2 + 16) + (D_) * TSTR)
+  ATTN_DISPATCH(dp, attn_bwd_dq_kernel, gq, SMEM_DQ)
+  if (p.qsplit > 1) {
+    hipMemsetAsync(p.dK32, 0, sizeof(float) * (size_t)p.B * p.Nkp * p.ld32, s);
+    hipMemsetAsync(p.dV32, 0, sizeof(float) * (size_t)p.B * p.Nkp * p.ld32, s);
+  }
+  dim3 gk(((p.Nk + 63) / 64) * p.qsplit, p.H, p.B);
+#define SMEM_DKV(D_) (2 * 64 * ((D_) * 2 + 16) + 2 * (D_) * TSTR + 512)
+  ATTN_DISPATCH(dp, attn_bwd_dkdv_kernel, gk, SMEM_DKV)
+  if (p.qsplit > 1) {
+    int C = p.H * p.d, rows = p.B * p.Nkp;
+    int blocks = (int)(((int64_t)rows * C / 4 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cvt_f32_bf16_kernel, dim3(blocks), dim3(256), 0, s, p.dK32, p.ld32, (bf16_t*)p.dK, p.lddk, rows, C);
+    hipLaunchKernelGGL(cvt_f32_bf16_kernel, dim3(blocks), dim3(256), 0, s, p.dV32, p.ld32, (bf16_t*)p.dV, p.lddv, rows, C);
+  }
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}

@@ -1,0 +1,69 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the LoRA/TI training step.
+// wave = 64 lanes everywhere; no other architecture is targeted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short bf16_t;  // raw storage type used in signatures
+
+#define SDLT_OK 0
+#define SDLT_ERR_SHAPE (-1)
+#define SDLT_ERR_ALIGN (-2)
+#define SDLT_ERR_LAUNCH (-3)
+#define SDLT_ERR_UNSUPPORTED (-4)
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even fp32 -> bf16 (NaN preserved as quiet NaN)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// d/dx silu(x) = s + x*s*(1-s), s = sigmoid(x)
+__device__ __forceinline__ float dsilu_f(float x) {
+  float s = 1.0f / (1.0f + __expf(-x));
+  return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// async global -> LDS copy of 16 B per lane; LDS destination = lds_base (wave-uniform) + lane*16
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
+void sdlt_set_error(const char* fmt, ...);
+#define SDLT_FAIL(code, ...)      \
+  do {                            \
+    sdlt_set_error(__VA_ARGS__);  \
+    return (code);                \
+  } while (0)
+#define SDLT_CHECK_LAUNCH()                                                      \
+  do {                                                                           \
+    hipError_t e_ = hipGetLastError();                                           \
+    if (e_ != hipSuccess) SDLT_FAIL(SDLT_ERR_LAUNCH, "%s: %s", __func__, hipGetErrorString(e_)); \
+  } while (0)

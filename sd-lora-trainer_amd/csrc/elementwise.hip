@@ -1,0 +1,367 @@
+// HBM-bound element-wise / small kernels of the training step (gfx950): GEGLU, SiLU, timestep
+// sinusoids, DDPM add-noise (+ NCHW->NHWC), masked-MSE loss fwd+bwd, fused AdamW(+L1), LoRA bf16
+// shadow refresh, 2x2 sum (dX of nearest upsampling), column sums.
+#include "common.h"
+#include "../../include/sdlt_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ void load8(const bf16_t* p, float* v) {
+  uint4 u = *(const uint4*)p;
+  v[0] = bf2f(u.x & 0xffff); v[1] = bf2f(u.x >> 16);
+  v[2] = bf2f(u.y & 0xffff); v[3] = bf2f(u.y >> 16);
+  v[4] = bf2f(u.z & 0xffff); v[5] = bf2f(u.z >> 16);
+  v[6] = bf2f(u.w & 0xffff); v[7] = bf2f(u.w >> 16);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float* v) {
+  uint4 u;
+  u.x = pack2bf(v[0], v[1]); u.y = pack2bf(v[2], v[3]);
+  u.z = pack2bf(v[4], v[5]); u.w = pack2bf(v[6], v[7]);
+  *(uint4*)p = u;
+}
+
+// ------------------------------------------------------------------ GEGLU (diffusers GEGLU: h * gelu(g))
+__global__ void geglu_fwd_kernel(const bf16_t* in, int64_t ldin, int M, int Ch, bf16_t* out, int64_t ldout) {
+  const int nch = Ch >> 3;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)M * nch; i += (int64_t)gridDim.x * blockDim.x) {
+    int m = i / nch, c = (i - (int64_t)m * nch) * 8;
+    float h[8], g[8];
+    load8(in + m * ldin + c, h);
+    load8(in + m * ldin + Ch + c, g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] *= gelu_f(g[j]);
+    store8(out + m * ldout + c, h);
+  }
+}
+__global__ void geglu_bwd_kernel(const bf16_t* in, int64_t ldin, const bf16_t* dout, int64_t lddout, int M, int Ch,
+                                 bf16_t* din, int64_t lddin) {
+  const int nch = Ch >> 3;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)M * nch; i += (int64_t)gridDim.x * blockDim.x) {
+    int m = i / nch, c = (i - (int64_t)m * nch) * 8;
+    float h[8], g[8], d[8], dh[8], dg[8];
+    load8(in + m * ldin + c, h);
+    load8(in + m * ldin + Ch + c, g);
+    load8(dout + m * lddout + c, d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dh[j] = d[j] * gelu_f(g[j]); dg[j] = d[j] * h[j] * dgelu_f(g[j]); }
+    store8(din + m * lddin + c, dh);
+    store8(din + m * lddin + Ch + c, dg);
+  }
+}
+
+// ------------------------------------------------------------------ generic unary / binary maps on contiguous bf16
+// op 0: y = silu(x)            op 1: y = dy * silu'(x)    op 2: y = x + dy (add)
+// op 3: y = gelu(x)            op 4: y = dy * gelu'(x)
+// op 5: y = x*sigmoid(1.702x) (CLIP quick_gelu)           op 6: y = dy * quick_gelu'(x)
+__global__ void map_kernel(int op, const bf16_t* x, const bf16_t* dy, bf16_t* y, int64_t n8) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float a[8], b[8];
+    load8(x + i * 8, a);
+    if (dy) load8(dy + i * 8, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = a[j];
+      switch (op) {
+        case 0: v = silu_f(v); break;
+        case 1: v = b[j] * dsilu_f(v); break;
+        case 2: v = v + b[j]; break;
+        case 3: v = gelu_f(v); break;
+        case 4: v = b[j] * dgelu_f(v); break;
+        case 5: v = v / (1.f + __expf(-1.702f * v)); break;
+        case 6: { float s = 1.f / (1.f + __expf(-1.702f * v)); v = b[j] * (s + 1.702f * v * s * (1.f - s)); } break;
+      }
+      a[j] = v;
+    }
+    store8(y + i * 8, a);
+  }
+}
+
+// ------------------------------------------------------------------ timestep sinusoid (diffusers Timesteps, flip_sin_to_cos, shift 0)
+// out[row, 0:half] = cos(t*f_i), out[row, half:dim] = sin(t*f_i), f_i = exp(-ln(10000) * i / half)
+__global__ void timestep_embed_kernel(const float* t, int rows, int dim, bf16_t* out, int64_t ldo) {
+  int half = dim >> 1;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * half; i += gridDim.x * blockDim.x) {
+    int r = i / half, k = i - r * half;
+    float f = expf(-9.210340371976184f * (float)k / (float)half);
+    float a = t[r] * f;
+    out[r * ldo + k] = f2bf(cosf(a));
+    out[r * ldo + half + k] = f2bf(sinf(a));
+  }
+}
+
+// ------------------------------------------------------------------ DDPM add_noise, NCHW fp32 -> NHWC bf16 padded to Cpad channels
+// noisy = sqrt(abar_t) x0 + sqrt(1-abar_t) eps     (main.py:326 -> diffusers DDPMScheduler.add_noise)
+__global__ void add_noise_kernel(const float* x0, const float* noise, const int64_t* ts, const float* acp, int B, int C,
+                                 int HW, int Cpad, bf16_t* out, float* noisy_nchw) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * HW * Cpad; i += gridDim.x * blockDim.x) {
+    int c = i % Cpad, p = (i / Cpad) % HW, b = i / (Cpad * HW);
+    float v = 0.f;
+    if (c < C) {
+      float a = acp[ts[b]];
+      int64_t src = ((int64_t)b * C + c) * HW + p;
+      v = sqrtf(a) * x0[src] + sqrtf(1.f - a) * noise[src];
+      if (noisy_nchw) noisy_nchw[src] = v;
+    }
+    out[i] = f2bf(v);
+  }
+}
+
+// ------------------------------------------------------------------ masked MSE (+min-SNR weights) fwd + bwd
+// reference: trainer/loss.py:127-170 (compute_diffusion_loss) + :83-106 (compute_snr).
+// pred is the conv_out result, NHWC fp32 [B*HW, ldp] (channels 0..C-1); noise/noisy/mask NCHW fp32.
+// pass 1 (grid B): sums[b] = {sum_chw e, mean_chw mask}
+__global__ __launch_bounds__(256) void mse_reduce_kernel(const float* pred, int64_t ldp, const float* noise, const float* noisy,
+                                                          const float* mask, const int64_t* ts, const float* acp, int C, int HW,
+                                                          int vpred, float* sums) {
+  __shared__ float sh[8];
+  const int b = blockIdx.x;
+  float a = acp[ts[b]], sa = sqrtf(a), ss = sqrtf(1.f - a);
+  float se = 0.f, sm = 0.f;
+  for (int i = threadIdx.x; i < C * HW; i += blockDim.x) {
+    int c = i / HW, p = i - c * HW;
+    int64_t src = ((int64_t)b * C + c) * HW + p;
+    float tgt = vpred ? sa * noise[src] - ss * noisy[src] : noise[src];
+    float d = pred[((int64_t)b * HW + p) * ldp + c] - tgt;
+    float mk = mask[src];
+    se += d * d * mk; sm += mk;
+  }
+  se = wave_sum(se); sm = wave_sum(sm);
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sh[wave * 2] = se; sh[wave * 2 + 1] = sm; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float e = 0.f, m = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { e += sh[w * 2]; m += sh[w * 2 + 1]; }
+    sums[b * 2] = e / (float)(C * HW);
+    sums[b * 2 + 1] = m / (float)(C * HW);
+  }
+}
+// per-sample coefficient coef_b such that loss = mean_b(coef_b * mean_chw(e)_b)
+__device__ __forceinline__ float mse_coef(int b, int B, const float* sums, const int64_t* ts, const float* acp, float gamma, int vpred) {
+  if (gamma > 0.f) {
+    float wsum = 0.f, wb = 0.f;
+    for (int i = 0; i < B; ++i) {
+      float a = acp[ts[i]];
+      float al = sqrtf(a), sg = sqrtf(1.f - a);
+      float snr = (al / sg) * (al / sg);
+      float w = fminf(snr, gamma) / snr + (vpred ? 1.f : 0.f);
+      wsum += w;
+      if (i == b) wb = w;
+    }
+    return wb / (wsum / (float)B);
+  }
+  float msum = 0.f;
+  for (int i = 0; i < B; ++i) msum += sums[i * 2 + 1];
+  return 1.f / (sums[b * 2 + 1] / (msum / (float)B));
+}
+// pass 2: loss scalar (block 0, thread 0) and dpred as bf16 NHWC padded to Cpad (input of conv_out's dX GEMM)
+__global__ void mse_grad_kernel(const float* pred, int64_t ldp, const float* noise, const float* noisy, const float* mask,
+                                const int64_t* ts, const float* acp, int B, int C, int HW, int Cpad, float gamma, int vpred,
+                                float loss_scale, const float* sums, float* loss_out, bf16_t* dpred) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float l = 0.f;
+    for (int b = 0; b < B; ++b) l += mse_coef(b, B, sums, ts, acp, gamma, vpred) * sums[b * 2];
+    loss_out[0] = l / (float)B;
+  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * HW * Cpad; i += gridDim.x * blockDim.x) {
+    int c = i % Cpad, p = (i / Cpad) % HW, b = i / (Cpad * HW);
+    float g = 0.f;
+    if (c < C) {
+      float a = acp[ts[b]], sa = sqrtf(a), ss = sqrtf(1.f - a);
+      int64_t src = ((int64_t)b * C + c) * HW + p;
+      float tgt = vpred ? sa * noise[src] - ss * noisy[src] : noise[src];
+      float d = pred[((int64_t)b * HW + p) * ldp + c] - tgt;
+      float coef = mse_coef(b, B, sums, ts, acp, gamma, vpred);
+      g = loss_scale * coef * 2.f * d * mask[src] / ((float)B * (float)(C * HW));
+    }
+    dpred[i] = f2bf(g);
+  }
+}
+
+// ------------------------------------------------------------------ fused AdamW (+ L1 subgradient), fp32 master params
+// reference: torch.optim.AdamW built at trainer/optimizer.py:18 / :113-150, stepped at optimizer.py:270-275,
+// L1 penalty main.py:353-356 (grad of l1w * sum|p| / N is l1w*sign(p)/N, folded in here).
+// hyper (device, fp32): [0] lr  [1] beta1  [2] beta2  [3] eps  [4] weight_decay  [5] 1-beta1^t  [6] 1-beta2^t
+//                       [7] l1 coefficient (= l1_penalty * loss_scale / N_total)  [8] grad scale
+__global__ void adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float* l1_partial) {
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2 = hyper[6],
+              l1c = hyper[7], gs = hyper[8];
+  const float rs2 = rsqrtf(bc2), step = lr / bc1;
+  float l1 = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float pi = p[i];
+    l1 += fabsf(pi);
+    float gi = g[i] * gs + l1c * (pi > 0.f ? 1.f : (pi < 0.f ? -1.f : 0.f));
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    pi = pi * (1.f - lr * wd) - step * mi / (sqrtf(vi) * rs2 + eps);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+  if (l1_partial) {
+    l1 = wave_sum(l1);
+    if ((threadIdx.x & 63) == 0) atomicAdd(l1_partial, l1);
+  }
+}
+
+// ------------------------------------------------------------------ LoRA bf16 shadows (both orientations) from the fp32 arena
+// one descriptor per parameter tensor [rows, cols] (row-major in the arena):
+//   dst  [rows_pad?, ld ]  <- same orientation        dstT [cols, ldT] <- transposed
+__global__ void shadow_kernel(const sdlt_shadow_desc* descs, const int32_t* block_desc, const int32_t* block_first,
+                              const float* arena) {
+  const sdlt_shadow_desc d = descs[block_desc[blockIdx.x]];
+  const int64_t n = (int64_t)d.rows * d.cols;
+  const int64_t start = (int64_t)(blockIdx.x - block_first[block_desc[blockIdx.x]]) * 4096;
+  for (int64_t i = start + threadIdx.x; i < start + 4096 && i < n; i += blockDim.x) {
+    int r = i / d.cols, c = i - (int64_t)r * d.cols;
+    bf16_t v = f2bf(arena[d.offset + (int64_t)r * d.src_ld + c]);
+    if (d.dst) ((bf16_t*)d.dst)[(int64_t)r * d.ld + c] = v;
+    if (d.dstT) ((bf16_t*)d.dstT)[(int64_t)c * d.ldT + r] = v;
+  }
+}
+
+// ------------------------------------------------------------------ out = a + b on strided [M,C] views
+__global__ void add2d_kernel(const bf16_t* a, int64_t lda, const bf16_t* b, int64_t ldb, bf16_t* out, int64_t ldo, int M, int C) {
+  const int nch = C >> 3;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)M * nch; i += (int64_t)gridDim.x * blockDim.x) {
+    int m = i / nch, c = (i - (int64_t)m * nch) * 8;
+    float x[8], y[8];
+    load8(a + m * lda + c, x);
+    load8(b + m * ldb + c, y);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] += y[j];
+    store8(out + m * ldo + c, x);
+  }
+}
+
+// ------------------------------------------------------------------ dX of nearest-2x upsampling: sum of each 2x2 block
+__global__ void sum2x2_kernel(const bf16_t* in, int B, int H, int W, int C, bf16_t* out) {
+  const int nch = C >> 3;
+  const int64_t total = (int64_t)B * H * W * nch;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (i % nch) * 8;
+    int64_t pix = i / nch;
+    int w = pix % W, h = (pix / W) % H, b = pix / ((int64_t)W * H);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        float v[8];
+        load8(in + (((int64_t)b * 2 * H + 2 * h + dy) * 2 * W + 2 * w + dx) * C + c, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += v[j];
+      }
+    store8(out + pix * C + c, acc);
+  }
+}
+
+// ------------------------------------------------------------------ column sums per batch: out[b, c] = sum_r x[b*R + r, c]  (fp32 out)
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* x, int64_t ldx, int R, int C, float* out) {
+  // grid (C/64, B); same 8 rows x 64 channels wave footprint as the norms
+  __shared__ float sh[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, c0 = blockIdx.x * 64 + (lane & 7) * 8;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int r = wave * 8 + (lane >> 3); r < R; r += 32) {
+    float v[8];
+    load8(x + ((int64_t)b * R + r) * ldx + c0, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] += v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) s[j] += __shfl_xor(s[j], o, 64);
+  if ((lane >> 3) == 0)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sh[wave][(lane & 7) * 8 + j] = s[j];
+  __syncthreads();
+  if (threadIdx.x < 64) out[(int64_t)b * C + blockIdx.x * 64 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+inline int grid_for(int64_t work_items, int block = 256) {
+  int64_t g = (work_items + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace
+
+extern "C" int sdlt_geglu_fwd(const void* in, int64_t ldin, int32_t M, int32_t Ch, void* out, int64_t ldout, void* stream) {
+  if (M <= 0 || Ch <= 0 || (Ch % 8) || (ldin % 8) || (ldout % 8)) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_geglu_fwd: M=%d Ch=%d", M, Ch);
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(grid_for((int64_t)M * Ch / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ldin, M, Ch, (bf16_t*)out, ldout);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+extern "C" int sdlt_geglu_bwd(const void* in, int64_t ldin, const void* dout, int64_t lddout, int32_t M, int32_t Ch, void* din,
+                              int64_t lddin, void* stream) {
+  if (M <= 0 || Ch <= 0 || (Ch % 8) || (ldin % 8) || (lddout % 8) || (lddin % 8)) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_geglu_bwd: M=%d Ch=%d", M, Ch);
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid_for((int64_t)M * Ch / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ldin, (const bf16_t*)dout, lddout, M, Ch, (bf16_t*)din, lddin);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+extern "C" int sdlt_map_bf16(int32_t op, const void* x, const void* dy, void* y, int64_t n, void* stream) {
+  if (n <= 0 || (n % 8) || op < 0 || op > 6) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_map_bf16: op=%d n=%lld (n %% 8 == 0)", op, (long long)n);
+  if ((op == 1 || op == 2 || op == 4 || op == 6) && !dy) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_map_bf16: op %d needs dy", op);
+  hipLaunchKernelGGL(map_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, op, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)y, n / 8);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+extern "C" int sdlt_timestep_embedding(const float* t, int32_t rows, int32_t dim, void* out, int64_t ldo, void* stream) {
+  if (rows <= 0 || dim <= 0 || (dim & 1)) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_timestep_embedding: rows=%d dim=%d", rows, dim);
+  hipLaunchKernelGGL(timestep_embed_kernel, dim3(grid_for((int64_t)rows * dim / 2)), dim3(256), 0, (hipStream_t)stream, t, rows, dim, (bf16_t*)out, ldo);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+extern "C" int sdlt_add_noise_nhwc(const float* x0, const float* noise, const int64_t* timesteps, const float* alphas_cumprod,
+                                   int32_t B, int32_t C, int32_t HW, int32_t Cpad, void* out_nhwc, float* noisy_nchw, void* stream) {
+  if (B <= 0 || C <= 0 || HW <= 0 || Cpad < C) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_add_noise_nhwc: B=%d C=%d HW=%d Cpad=%d", B, C, HW, Cpad);
+  hipLaunchKernelGGL(add_noise_kernel, dim3(grid_for((int64_t)B * HW * Cpad)), dim3(256), 0, (hipStream_t)stream, x0, noise, timesteps, alphas_cumprod, B, C, HW, Cpad, (bf16_t*)out_nhwc, noisy_nchw);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+extern "C" int sdlt_masked_mse_fwd_bwd(const float* pred, int64_t ldp, const float* noise, const float* noisy, const float* mask,
+                                       const int64_t* timesteps, const float* alphas_cumprod, int32_t B, int32_t C, int32_t HW,
+                                       int32_t Cpad, float snr_gamma, int32_t v_prediction, float loss_scale, float* sums,
+                                       float* loss_out, void* dpred, void* stream) {
+  if (B <= 0 || B > 1024 || C <= 0 || HW <= 0 || Cpad < C) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_masked_mse_fwd_bwd: B=%d C=%d HW=%d Cpad=%d", B, C, HW, Cpad);
+  if (v_prediction && !noisy) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_masked_mse_fwd_bwd: v-prediction needs the noisy latent");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(mse_reduce_kernel, dim3(B), dim3(256), 0, s, pred, ldp, noise, noisy, mask, timesteps, alphas_cumprod, C, HW, v_prediction, sums);
+  hipLaunchKernelGGL(mse_grad_kernel, dim3(grid_for((int64_t)B * HW * Cpad)), dim3(256), 0, s, pred, ldp, noise, noisy, mask, timesteps, alphas_cumprod, B, C, HW, Cpad, snr_gamma, v_prediction, loss_scale, sums, loss_out, (bf16_t*)dpred);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+extern "C" int sdlt_adamw_fused(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float* l1_sum,
+                                void* stream) {
+  if (n <= 0) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_adamw_fused: n=%lld", (long long)n);
+  hipStream_t s = (hipStream_t)stream;
+  if (l1_sum) hipMemsetAsync(l1_sum, 0, sizeof(float), s);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, g, m, v, n, hyper, l1_sum);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+extern "C" int sdlt_lora_shadow_refresh(const sdlt_shadow_desc* descs_dev, const int32_t* block_desc_dev, const int32_t* block_first_dev,
+                                        int32_t n_blocks, const float* arena, void* stream) {
+  if (n_blocks <= 0) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_lora_shadow_refresh: n_blocks=%d", n_blocks);
+  hipLaunchKernelGGL(shadow_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, block_desc_dev, block_first_dev, arena);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+extern "C" int sdlt_add2d(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int32_t M, int32_t C, void* stream) {
+  if (M <= 0 || C <= 0 || (C % 8) || (lda % 8) || (ldb % 8) || (ldo % 8)) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_add2d: M=%d C=%d", M, C);
+  hipLaunchKernelGGL(add2d_kernel, dim3(grid_for((int64_t)M * C / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (bf16_t*)out, ldo, M, C);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+extern "C" int sdlt_sum2x2(const void* in, int32_t B, int32_t H, int32_t W, int32_t C, void* out, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8)) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_sum2x2: B=%d H=%d W=%d C=%d", B, H, W, C);
+  hipLaunchKernelGGL(sum2x2_kernel, dim3(grid_for((int64_t)B * H * W * C / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, B, H, W, C, (bf16_t*)out);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+extern "C" int sdlt_colsum(const void* x, int64_t ldx, int32_t B, int32_t R, int32_t C, float* out, void* stream) {
+  if (B <= 0 || R <= 0 || C <= 0 || (C % 64) || (ldx % 8)) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_colsum: B=%d R=%d C=%d", B, R, C);
+  hipLaunchKernelGGL(colsum_kernel, dim3(C / 64, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, R, C, out);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}

@@ -1,0 +1,396 @@
+// bf16 MFMA GEMM family for the UNet training step (gfx950).
+//
+//   C[M,N] = alpha * ( sum_seg  X_seg[M,K_seg] . W_seg[N,K_seg]^T  +  s * (X.Adown^T) . Bup^T )
+//            + bias[n] + rowbias[m / rows_per_batch, n] + R[m,n]
+//
+// * every operand is K-contiguous ("NT" form).  Frozen weights are kept in HBM in BOTH orientations
+//   (W [N,K] for forward, W^T [K,N] for dX) - 288 GB makes that free - so forward and backward are
+//   the same kernel.
+// * X rows can be gathered on the fly: MODE 1 turns the kernel into an implicit-GEMM 3x3 convolution
+//   over an NHWC activation (K = 9*Cin, k = tap*Cin + ci), incl. stride 2, nearest-2x upsampled input,
+//   tap flip (dX of a stride-1 conv) and the transposed stride-2 form (dX of a downsampling conv).
+//   Out-of-image taps read a zero page.
+// * rank-r LoRA is fused: the LoRA-down product T = X.Adown^T is accumulated by the same K loop on
+//   16 extra MFMA columns, scaled, rounded to bf16, and applied with one 16x16x16 MFMA per tile pair
+//   (the 16x16 accumulator layout IS the 16x16x16 B-operand layout, so no cross-lane movement).
+//   Replaces peft's three launches per adapted layer (reference: trainer/optimizer.py:84-95).
+// * tile BMxBNx64, 4 waves (2x2), mfma_f32_16x16x32_bf16, operands swapped (W is the MFMA "A" operand)
+//   so each lane ends with 4 consecutive n of one row m -> 8-byte epilogue accesses.
+// * global->LDS via global_load_lds (16 B/lane, no VGPR round trip), LDS image XOR-swizzled through
+//   the per-lane SOURCE address (chunk ^= row&7) -> conflict-free ds_read_b128; double-buffered,
+//   one barrier per K step, next tile's DMA in flight under the MFMAs.
+#include "common.h"
+#include "../../include/sdlt_kernels.h"
+
+namespace {
+
+constexpr int BK = 64;         // bf16 elements per K step (128 B rows in LDS)
+constexpr int ROW_BYTES = 128;
+
+struct ConvGeom {
+  int Hin, Win, Cin, Hout, Wout, stride, ups, flip, tr;
+};
+
+template <int MI, int NI, int MODE, int R16>
+__global__ __launch_bounds__(256) void gemm_kernel(const sdlt_gemm_params p) {
+  constexpr int BM = 2 * MI * 16, BN = 2 * NI * 16;
+  constexpr int XT = BM * ROW_BYTES, WT = BN * ROW_BYTES, AT = (R16 ? R16 * 16 : 0) * ROW_BYTES;
+  constexpr int STAGE = XT + WT + AT;
+  constexpr int TROW = R16 ? (R16 * 16 + 4) : 4;  // bf16 elements per Tsh row (+4 pad)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* tsh = smem + 2 * STAGE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  // XCD-aware remap: consecutive tile ids (sharing an X panel) land on the same XCD/L2.
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = nbm * nbn, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int bn = bid % nbn, bm = bid / nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  // ---------------- per-lane staging geometry (fixed rows, fixed swizzled chunk) ----------------
+  const int srow = lane >> 3;                       // row within an 8-row DMA piece
+  const int schunk = (lane & 7) ^ (srow & 7);       // source chunk so that LDS holds chunk^(row&7)
+  constexpr int XI = BM / 32, WI = BN / 32;         // DMA pieces per wave
+  const bf16_t* xptr[XI];
+  int xb[XI], xh[XI], xw[XI];                       // conv: decoded output pixel (b<0 => row invalid)
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    int m = m0 + (wave + 4 * i) * 8 + srow;
+    if (MODE == 0) {
+      int mc = m < p.M ? m : p.M - 1;
+      xptr[i] = (const bf16_t*)p.X + (size_t)mc * p.ldx + schunk * 8;
+      xb[i] = xh[i] = xw[i] = 0;
+    } else {
+      if (m < p.M) {
+        int hw = p.Hout * p.Wout;
+        xb[i] = m / hw;
+        int rem = m - xb[i] * hw;
+        xh[i] = rem / p.Wout;
+        xw[i] = rem - xh[i] * p.Wout;
+      } else {
+        xb[i] = -1; xh[i] = xw[i] = 0;
+      }
+      xptr[i] = nullptr;
+    }
+  }
+  const bf16_t* wptr[WI];
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    int n = n0 + (wave + 4 * i) * 8 + srow;
+    int nc = n < p.N ? n : p.N - 1;
+    wptr[i] = (const bf16_t*)p.W + (size_t)nc * p.ldw + schunk * 8;
+  }
+  const bf16_t* x2ptr[XI];
+  const bf16_t* w2ptr[WI];
+  if (p.K2 > 0) {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      int m = m0 + (wave + 4 * i) * 8 + srow;
+      int mc = m < p.M ? m : p.M - 1;
+      x2ptr[i] = (const bf16_t*)p.X2 + (size_t)mc * p.ldx2 + schunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      int n = n0 + (wave + 4 * i) * 8 + srow;
+      int nc = n < p.N ? n : p.N - 1;
+      w2ptr[i] = (const bf16_t*)p.W2 + (size_t)nc * p.ldw2 + schunk * 8;
+    }
+  }
+  // LoRA-down tile: R16*16 rows -> R16*2 pieces, taken by waves 0..(R16*2-1) round robin
+  const bf16_t* aptr = nullptr;
+  if (R16) {
+    // piece index handled by this wave in round j: wave + 4*j  (< R16*2)
+    aptr = (const bf16_t*)p.Adown + schunk * 8;
+  }
+
+  const int nk1 = p.K / BK, nk2 = p.K2 / BK, nk = nk1 + nk2;
+
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * STAGE;
+    if (kt < nk1) {
+      const int k0 = kt * BK;
+      if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) glds16(xptr[i] + k0, base + (wave + 4 * i) * 1024);
+      } else {
+        const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const int oy = p.flip ? 1 - dy : dy - 1, ox = p.flip ? 1 - dx : dx - 1;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+          const bf16_t* src = (const bf16_t*)p.zero + schunk * 8;
+          if (xb[i] >= 0) {
+            int hi, wi;
+            bool ok;
+            if (p.tr) {
+              int ny = xh[i] + oy, nx = xw[i] + ox;
+              ok = ny >= 0 && nx >= 0 && !(ny & 1) && !(nx & 1);
+              hi = ny >> 1; wi = nx >> 1;
+              ok = ok && hi < p.Hin && wi < p.Win;
+            } else {
+              hi = xh[i] * p.stride + oy; wi = xw[i] * p.stride + ox;
+              ok = hi >= 0 && wi >= 0 && hi < p.Hin * p.ups && wi < p.Win * p.ups;
+              if (p.ups == 2) { hi >>= 1; wi >>= 1; }
+            }
+            if (ok) src = (const bf16_t*)p.X + ((size_t)(xb[i] * p.Hin + hi) * p.Win + wi) * p.ldx + ci0 + schunk * 8;
+          }
+          glds16(src, base + (wave + 4 * i) * 1024);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < WI; ++i) glds16(wptr[i] + k0, base + XT + (wave + 4 * i) * 1024);
+      if (R16) {
+#pragma unroll
+        for (int j = 0; j < (R16 * 2 + 3) / 4; ++j) {
+          int piece = wave + 4 * j;
+          if (piece < R16 * 2)
+            glds16(aptr + (size_t)(piece * 8 + srow) * p.ld_adown + k0, base + XT + WT + piece * 1024);
+        }
+      }
+    } else {
+      const int k0 = (kt - nk1) * BK;
+#pragma unroll
+      for (int i = 0; i < XI; ++i) glds16(x2ptr[i] + k0, base + (wave + 4 * i) * 1024);
+#pragma unroll
+      for (int i = 0; i < WI; ++i) glds16(w2ptr[i] + k0, base + XT + (wave + 4 * i) * 1024);
+    }
+  };
+
+  // ---------------- accumulators ----------------
+  f32x4 acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+#pragma unroll
+    for (int b = 0; b < MI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int TMI = MI / 2;  // T fragments per wave (the two wn waves split the wave-row's mi)
+  f32x4 tacc[R16 ? R16 : 1][TMI];
+#pragma unroll
+  for (int a = 0; a < (R16 ? R16 : 1); ++a)
+#pragma unroll
+    for (int b = 0; b < TMI; ++b) tacc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fk = lane >> 4;
+  // byte offset of this lane's fragment chunk inside a 16-row block, for kk = 0/1
+  const int foff0 = frow * ROW_BYTES + (((0 * 4 + fk) ^ (frow & 7)) << 4);
+  const int foff1 = frow * ROW_BYTES + (((1 * 4 + fk) ^ (frow & 7)) << 4);
+
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    const char* base = smem + (kt & 1) * STAGE;
+    const char* xs = base + (wm * MI * 16) * ROW_BYTES;
+    const char* ws = base + XT + (wn * NI * 16) * ROW_BYTES;
+    const char* as = base + XT + WT;
+    const bool lora_step = R16 && kt < nk1;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int fo = kk ? foff1 : foff0;
+      bf16x8 xf[MI], wf[NI];
+#pragma unroll
+      for (int b = 0; b < MI; ++b) xf[b] = *(const bf16x8*)(xs + b * 16 * ROW_BYTES + fo);
+#pragma unroll
+      for (int a = 0; a < NI; ++a) wf[a] = *(const bf16x8*)(ws + a * 16 * ROW_BYTES + fo);
+#pragma unroll
+      for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+      if (R16) {
+        if (lora_step) {
+#pragma unroll
+          for (int j = 0; j < R16; ++j) {
+            bf16x8 af = *(const bf16x8*)(as + j * 16 * ROW_BYTES + fo);
+#pragma unroll
+            for (int b = 0; b < TMI; ++b) {
+              // re-read the X fragment by address: indexing xf[] with the runtime wn would spill it
+              bf16x8 xt = *(const bf16x8*)(xs + (wn * TMI + b) * 16 * ROW_BYTES + fo);
+              tacc[j][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xt, tacc[j][b], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---------------- fused LoRA-up ----------------
+  if (R16) {
+    // tacc[j][b][r] = T[m = wm*MI*16 + (wn*TMI+b)*16 + (lane&15)][rank = j*16 + (lane>>4)*4 + r]
+#pragma unroll
+    for (int j = 0; j < R16; ++j)
+#pragma unroll
+      for (int b = 0; b < TMI; ++b) {
+        int ml = wm * MI * 16 + (wn * TMI + b) * 16 + frow;
+        uint2 v;
+        v.x = pack2bf(tacc[j][b][0] * p.lora_scale, tacc[j][b][1] * p.lora_scale);
+        v.y = pack2bf(tacc[j][b][2] * p.lora_scale, tacc[j][b][3] * p.lora_scale);
+        *(uint2*)(tsh + ((size_t)ml * TROW + j * 16 + fk * 4) * 2) = v;
+      }
+    __syncthreads();
+    if (p.T_out != nullptr && bn == 0) {
+      // [BM rows][R] bf16 -> global, 8 B per lane
+      constexpr int CH = R16 * 4;  // 8-byte chunks per row
+      for (int c = tid; c < BM * CH; c += 256) {
+        int ml = c / CH, cc = c - ml * CH;
+        int m = m0 + ml;
+        if (m < p.M) *(uint2*)((bf16_t*)p.T_out + (size_t)m * p.ld_t + cc * 4) = *(const uint2*)(tsh + ((size_t)ml * TROW + cc * 4) * 2);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < R16; ++j) {
+      s16x4 tf[MI];
+#pragma unroll
+      for (int b = 0; b < MI; ++b) {
+        int ml = wm * MI * 16 + b * 16 + frow;
+        tf[b] = *(const s16x4*)(tsh + ((size_t)ml * TROW + j * 16 + fk * 4) * 2);
+      }
+#pragma unroll
+      for (int a = 0; a < NI; ++a) {
+        int n = n0 + wn * NI * 16 + a * 16 + frow;
+        int nc = n < p.N ? n : p.N - 1;
+        s16x4 bf = *(const s16x4*)((const bf16_t*)p.Bup + (size_t)nc * p.ld_bup + j * 16 + fk * 4);
+#pragma unroll
+        for (int b = 0; b < MI; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bf, tf[b], acc[a][b], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---------------- epilogue ----------------
+  // acc[a][b][r] = C[m = m0 + wm*MI*16 + b*16 + (lane&15)][n = n0 + wn*NI*16 + a*16 + (lane>>4)*4 + r]
+  const bool vec_ok = ((p.ldc & 3) == 0) && (p.R == nullptr || (p.ldr & 3) == 0) &&
+                      (p.rowbias == nullptr || (p.ld_rowbias & 3) == 0);
+#pragma unroll
+  for (int b = 0; b < MI; ++b) {
+    const int m = m0 + wm * MI * 16 + b * 16 + frow;
+    if (m >= p.M) continue;
+    const int brow = p.rowbias ? m / p.rows_per_batch : 0;
+#pragma unroll
+    for (int a = 0; a < NI; ++a) {
+      const int n = n0 + wn * NI * 16 + a * 16 + fk * 4;
+      if (n >= p.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] * p.alpha;
+      if (vec_ok && n + 3 < p.N) {
+        if (p.bias) {
+          float4 bv = *(const float4*)(p.bias + n);
+          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+        }
+        if (p.rowbias) {
+          uint2 rb = *(const uint2*)((const bf16_t*)p.rowbias + (size_t)brow * p.ld_rowbias + n);
+          v[0] += bf2f(rb.x & 0xffff); v[1] += bf2f(rb.x >> 16); v[2] += bf2f(rb.y & 0xffff); v[3] += bf2f(rb.y >> 16);
+        }
+        if (p.R) {
+          uint2 rv = *(const uint2*)((const bf16_t*)p.R + (size_t)m * p.ldr + n);
+          v[0] += bf2f(rv.x & 0xffff); v[1] += bf2f(rv.x >> 16); v[2] += bf2f(rv.y & 0xffff); v[3] += bf2f(rv.y >> 16);
+        }
+        if (p.Ct) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ((bf16_t*)p.Ct)[(size_t)(n + r) * p.ldct + m] = f2bf(v[r]);
+        }
+        if (p.out_fp32) {
+          *(float4*)((float*)p.C + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          uint2 o;
+          o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+          *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r >= p.N) break;
+          float x = v[r];
+          if (p.bias) x += p.bias[n + r];
+          if (p.rowbias) x += bf2f(((const bf16_t*)p.rowbias)[(size_t)brow * p.ld_rowbias + n + r]);
+          if (p.R) x += bf2f(((const bf16_t*)p.R)[(size_t)m * p.ldr + n + r]);
+          if (p.Ct) ((bf16_t*)p.Ct)[(size_t)(n + r) * p.ldct + m] = f2bf(x);
+          if (p.out_fp32) ((float*)p.C)[(size_t)m * p.ldc + n + r] = x;
+          else ((bf16_t*)p.C)[(size_t)m * p.ldc + n + r] = f2bf(x);
+        }
+      }
+    }
+  }
+}
+
+template <int MI, int NI, int MODE, int R16>
+int launch(const sdlt_gemm_params& p, hipStream_t stream) {
+  constexpr int BM = 2 * MI * 16, BN = 2 * NI * 16;
+  constexpr int STAGE = (BM + BN + R16 * 16) * ROW_BYTES;
+  constexpr int TSH = R16 ? BM * (R16 * 16 + 4) * 2 : 0;
+  const int smem = 2 * STAGE + TSH;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_kernel<MI, NI, MODE, R16>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  hipLaunchKernelGGL((gemm_kernel<MI, NI, MODE, R16>), dim3(nbm * nbn), dim3(256), smem, stream, p);
+  return SDLT_OK;
+}
+
+template <int MODE, int R16>
+int dispatch_tile(const sdlt_gemm_params& p, hipStream_t s) {
+  int tile = p.tile;
+  if (tile == 0) {
+    // heuristic: largest tile that still gives >= ~1.5 waves of workgroups over the 256 CUs
+    auto nwg = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+    if (nwg(128, 128) >= 384) tile = 1;
+    else if (nwg(64, 128) >= 320) tile = 2;
+    else tile = 3;
+  }
+  switch (tile) {
+    case 1: return launch<4, 4, MODE, R16>(p, s);
+    case 2: return launch<2, 4, MODE, R16>(p, s);
+    case 3: return launch<2, 2, MODE, R16>(p, s);
+  }
+  SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: tile id %d", p.tile);
+}
+
+}  // namespace
+
+extern "C" int sdlt_gemm_bf16(const sdlt_gemm_params* pp, void* stream) {
+  const sdlt_gemm_params& p = *pp;
+  hipStream_t s = (hipStream_t)stream;
+  if (p.M <= 0 || p.N <= 0) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: M=%d N=%d", p.M, p.N);
+  if (p.K <= 0 || (p.K % BK) || (p.K2 % BK) || p.K2 < 0)
+    SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: K=%d K2=%d must be positive multiples of 64", p.K, p.K2);
+  if ((p.ldx % 8) || (p.ldw % 8) || (p.K2 && ((p.ldx2 % 8) || (p.ldw2 % 8))))
+    SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_gemm_bf16: operand rows must be 16-byte aligned (ld %% 8)");
+  if (((uintptr_t)p.X | (uintptr_t)p.W | (uintptr_t)p.X2 | (uintptr_t)p.W2 | (uintptr_t)p.Adown) & 15)
+    SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_gemm_bf16: operand base pointers must be 16-byte aligned");
+  if (p.mode == 1) {
+    if (!p.zero) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: conv mode needs a zero page");
+    if (p.Cin % BK || p.K != 9 * p.Cin) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: conv needs Cin%%64==0 and K==9*Cin (Cin=%d K=%d)", p.Cin, p.K);
+    if (p.K2) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: conv + second segment");
+    if (p.M % (p.Hout * p.Wout)) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: conv M %% (Hout*Wout)");
+  } else if (p.mode != 0) {
+    SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: mode %d", p.mode);
+  }
+  int r16 = 0;
+  if (p.lora_R) {
+    if (p.lora_R != 16 && p.lora_R != 32 && p.lora_R != 64) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: padded LoRA rank %d (16/32/64)", p.lora_R);
+    if (p.K2) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: LoRA + second segment");
+    if ((p.ld_adown % 8) || (p.ld_bup % 4) || (p.T_out && (p.ld_t % 4))) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_gemm_bf16: LoRA operand alignment");
+    r16 = p.lora_R / 16;
+  }
+  int rc;
+#define DISPATCH(MODE_)                                                 \
+  switch (r16) {                                                        \
+    case 0: rc = dispatch_tile<MODE_, 0>(p, s); break;                  \
+    case 1: rc = dispatch_tile<MODE_, 1>(p, s); break;                  \
+    case 2: rc = dispatch_tile<MODE_, 2>(p, s); break;                  \
+    default: rc = dispatch_tile<MODE_, 4>(p, s); break;                 \
+  }
+  if (p.mode == 0) { DISPATCH(0) } else { DISPATCH(1) }
+#undef DISPATCH
+  if (rc != SDLT_OK) return rc;
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}

@@ -1,0 +1,377 @@
+// GroupNorm(32)+SiLU and LayerNorm, forward and dX backward, for NHWC / token-major bf16
+// activations (gfx950).  HBM-bound: every kernel moves 16 B per lane, a wave covers 8 rows x 64
+// channels (128-B lines), and each thread keeps a FIXED 8-channel column so gamma/beta/mean/rstd
+// live in registers for the whole row loop.
+//
+// Replaces (reference call sites, all reached from main.py:329-336 through diffusers):
+//   ResnetBlock2D.norm1/norm2 + SiLU, Transformer2DModel.norm, conv_norm_out  -> groupnorm
+//   BasicTransformerBlock.norm1/2/3 (and CLIP LayerNorms)                     -> layernorm
+// gamma/beta are frozen in the reference (main.py:109-114), so only dX is produced.
+#include "common.h"
+#include "../../include/sdlt_kernels.h"
+
+namespace {
+
+constexpr int G = 32;
+
+__device__ __forceinline__ void load8(const bf16_t* p, float* v) {
+  uint4 u = *(const uint4*)p;
+  v[0] = bf2f(u.x & 0xffff); v[1] = bf2f(u.x >> 16);
+  v[2] = bf2f(u.y & 0xffff); v[3] = bf2f(u.y >> 16);
+  v[4] = bf2f(u.z & 0xffff); v[5] = bf2f(u.z >> 16);
+  v[6] = bf2f(u.w & 0xffff); v[7] = bf2f(u.w >> 16);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float* v) {
+  uint4 u;
+  u.x = pack2bf(v[0], v[1]); u.y = pack2bf(v[2], v[3]);
+  u.z = pack2bf(v[4], v[5]); u.w = pack2bf(v[6], v[7]);
+  *(uint4*)p = u;
+}
+
+// row pointer for channel c of row r of the (possibly two-tensor, channel-concatenated) input
+struct CatIn {
+  const bf16_t* x1; int64_t ld1; int C1;
+  const bf16_t* x2; int64_t ld2;
+  __device__ __forceinline__ const bf16_t* at(int64_t row, int c) const {
+    return c < C1 ? x1 + row * ld1 + c : x2 + row * ld2 + (c - C1);
+  }
+};
+
+// ---------------------------------------------------------------------------------- GroupNorm
+// grid (C/64, rowsplit, B), block 256 = 4 waves; thread: fixed chunk c0 = bx*64 + (lane&7)*8,
+// rows r = ry*32.. step gridDim.y*32, sub-row = wave*8 + lane/8.
+// stats[b][g] = {sum, sumsq} accumulated with atomics (zeroed by the entry point).
+__global__ __launch_bounds__(256) void gn_stats_kernel(CatIn in, int HW, int C, float* stats) {
+  __shared__ float sg[G * 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.x * 64 + (lane & 7) * 8;
+  const int cpg = C / G;
+  if (tid < G * 2) sg[tid] = 0.f;
+  __syncthreads();
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+  for (int r = blockIdx.y * 32 + wave * 8 + (lane >> 3); r < HW; r += gridDim.y * 32) {
+    float v[8];
+    load8(in.at((int64_t)b * HW + r, c0), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
+  }
+  // lanes with the same (lane&7) hold the same channels: reduce over lane>>3 (xor 8,16,32)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) { s[j] += __shfl_xor(s[j], o, 64); q[j] += __shfl_xor(q[j], o, 64); }
+  }
+  if ((lane >> 3) == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int g = (c0 + j) / cpg;
+      atomicAdd(&sg[g * 2], s[j]);
+      atomicAdd(&sg[g * 2 + 1], q[j]);
+    }
+  }
+  __syncthreads();
+  if (tid < G * 2) {
+    int g = tid >> 1;
+    int glo = (blockIdx.x * 64) / cpg, ghi = (blockIdx.x * 64 + 63) / cpg;
+    if (g >= glo && g <= ghi) atomicAdd(&stats[(b * G) * 2 + tid], sg[tid]);
+  }
+}
+
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(CatIn in, int HW, int C, const float* stats,
+                                                        const float* gamma, const float* beta, float eps,
+                                                        bf16_t* y, int64_t ldy) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.x * 64 + (lane & 7) * 8;
+  const int cpg = C / G;
+  const float inv_n = 1.0f / ((float)HW * (float)cpg);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int g = (c0 + j) / cpg;
+    float mean = stats[(b * G + g) * 2] * inv_n;
+    float var = fmaxf(stats[(b * G + g) * 2 + 1] * inv_n - mean * mean, 0.f);
+    float rstd = rsqrtf(var + eps);
+    sc[j] = rstd * gamma[c0 + j];
+    sh[j] = beta[c0 + j] - mean * sc[j];
+  }
+  for (int r = blockIdx.y * 32 + wave * 8 + (lane >> 3); r < HW; r += gridDim.y * 32) {
+    float v[8];
+    int64_t row = (int64_t)b * HW + r;
+    load8(in.at(row, c0), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float z = v[j] * sc[j] + sh[j];
+      v[j] = SILU ? silu_f(z) : z;
+    }
+    store8(y + row * ldy + c0, v);
+  }
+}
+
+// backward pass 1: per (b,g): s1 = sum(dz*gamma), s2 = sum(dz*gamma*xhat)
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(CatIn in, const bf16_t* dy, int64_t lddy, int HW, int C,
+                                                            const float* stats, const float* gamma, const float* beta,
+                                                            float eps, float* bstats) {
+  __shared__ float sg[G * 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.x * 64 + (lane & 7) * 8;
+  const int cpg = C / G;
+  const float inv_n = 1.0f / ((float)HW * (float)cpg);
+  if (tid < G * 2) sg[tid] = 0.f;
+  __syncthreads();
+  float mean[8], rstd[8], gm[8], bt[8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int g = (c0 + j) / cpg;
+    mean[j] = stats[(b * G + g) * 2] * inv_n;
+    float var = fmaxf(stats[(b * G + g) * 2 + 1] * inv_n - mean[j] * mean[j], 0.f);
+    rstd[j] = rsqrtf(var + eps);
+    gm[j] = gamma[c0 + j]; bt[j] = beta[c0 + j];
+    s1[j] = s2[j] = 0.f;
+  }
+  for (int r = blockIdx.y * 32 + wave * 8 + (lane >> 3); r < HW; r += gridDim.y * 32) {
+    float v[8], d[8];
+    int64_t row = (int64_t)b * HW + r;
+    load8(in.at(row, c0), v);
+    load8(dy + row * lddy + c0, d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float xh = (v[j] - mean[j]) * rstd[j];
+      float dz = d[j];
+      if (SILU) dz *= dsilu_f(xh * gm[j] + bt[j]);
+      float dxh = dz * gm[j];
+      s1[j] += dxh; s2[j] += dxh * xh;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+  }
+  if ((lane >> 3) == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int g = (c0 + j) / cpg;
+      atomicAdd(&sg[g * 2], s1[j]);
+      atomicAdd(&sg[g * 2 + 1], s2[j]);
+    }
+  }
+  __syncthreads();
+  if (tid < G * 2) {
+    int g = tid >> 1;
+    int glo = (blockIdx.x * 64) / cpg, ghi = (blockIdx.x * 64 + 63) / cpg;
+    if (g >= glo && g <= ghi) atomicAdd(&bstats[(b * G) * 2 + tid], sg[tid]);
+  }
+}
+
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(CatIn in, const bf16_t* dy, int64_t lddy, int HW, int C,
+                                                            const float* stats, const float* bstats, const float* gamma,
+                                                            const float* beta, float eps, const bf16_t* dres, int64_t lddres,
+                                                            bf16_t* dx, int64_t lddx) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.x * 64 + (lane & 7) * 8;
+  const int cpg = C / G;
+  const float inv_n = 1.0f / ((float)HW * (float)cpg);
+  float mean[8], rstd[8], gm[8], bt[8], m1[8], m2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int g = (c0 + j) / cpg;
+    mean[j] = stats[(b * G + g) * 2] * inv_n;
+    float var = fmaxf(stats[(b * G + g) * 2 + 1] * inv_n - mean[j] * mean[j], 0.f);
+    rstd[j] = rsqrtf(var + eps);
+    gm[j] = gamma[c0 + j]; bt[j] = beta[c0 + j];
+    m1[j] = bstats[(b * G + g) * 2] * inv_n;
+    m2[j] = bstats[(b * G + g) * 2 + 1] * inv_n;
+  }
+  for (int r = blockIdx.y * 32 + wave * 8 + (lane >> 3); r < HW; r += gridDim.y * 32) {
+    float v[8], d[8], o[8];
+    int64_t row = (int64_t)b * HW + r;
+    load8(in.at(row, c0), v);
+    load8(dy + row * lddy + c0, d);
+    if (dres) load8(dres + row * lddres + c0, o);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float xh = (v[j] - mean[j]) * rstd[j];
+      float dz = d[j];
+      if (SILU) dz *= dsilu_f(xh * gm[j] + bt[j]);
+      float dxh = dz * gm[j];
+      o[j] += rstd[j] * (dxh - m1[j] - xh * m2[j]);
+    }
+    store8(dx + row * lddx + c0, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------- LayerNorm
+// one wave per row; lane handles chunks lane, lane+64, ... (C/8 chunks; C <= 2048)
+constexpr int LN_MAXCH = 4;
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, int64_t ldx, int M, int C, const float* gamma,
+                                                      const float* beta, float eps, bf16_t* y, int64_t ldy, float* stats) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = C >> 3;
+  float v[LN_MAXCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    int ch = lane + i * 64;
+    if (ch < nch) {
+      load8(x + (int64_t)row * ldx + ch * 8, v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[i][j];
+    }
+  }
+  float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    int ch = lane + i * 64;
+    if (ch < nch) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float d = v[i][j] - mean; q += d * d; }
+    }
+  }
+  float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0 && stats) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    int ch = lane + i * 64;
+    if (ch < nch) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * gamma[ch * 8 + j] + beta[ch * 8 + j];
+      store8(y + (int64_t)row * ldy + ch * 8, o);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* x, int64_t ldx, const bf16_t* dy, int64_t lddy, int M,
+                                                      int C, const float* gamma, const float* stats, const bf16_t* dres,
+                                                      int64_t lddres, bf16_t* dx, int64_t lddx) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = C >> 3;
+  const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+  float xh[LN_MAXCH][8], dxh[LN_MAXCH][8];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    int ch = lane + i * 64;
+    if (ch < nch) {
+      float v[8], d[8];
+      load8(x + (int64_t)row * ldx + ch * 8, v);
+      load8(dy + (int64_t)row * lddy + ch * 8, d);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xh[i][j] = (v[j] - mean) * rstd;
+        dxh[i][j] = d[j] * gamma[ch * 8 + j];
+        s1 += dxh[i][j]; s2 += dxh[i][j] * xh[i][j];
+      }
+    }
+  }
+  s1 = wave_sum(s1) / (float)C;
+  s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    int ch = lane + i * 64;
+    if (ch < nch) {
+      float o[8];
+      if (dres) load8(dres + (int64_t)row * lddres + ch * 8, o);
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += rstd * (dxh[i][j] - s1 - xh[i][j] * s2);
+      store8(dx + (int64_t)row * lddx + ch * 8, o);
+    }
+  }
+}
+
+int gn_check(const sdlt_groupnorm_params& p, const char* fn) {
+  if (p.B <= 0 || p.HW <= 0 || p.C <= 0 || (p.C % 64)) SDLT_FAIL(SDLT_ERR_SHAPE, "%s: B=%d HW=%d C=%d (C %% 64 == 0 required)", fn, p.B, p.HW, p.C);
+  if (p.x2 ? ((p.C1 % 8) || p.C1 <= 0 || p.C1 >= p.C || (p.ldx2 % 8)) : (p.C1 != p.C)) SDLT_FAIL(SDLT_ERR_SHAPE, "%s: concat split C1=%d of C=%d", fn, p.C1, p.C);
+  if ((p.ldx1 % 8)) SDLT_FAIL(SDLT_ERR_ALIGN, "%s: ldx %% 8", fn);
+  return SDLT_OK;
+}
+
+dim3 gn_grid(const sdlt_groupnorm_params& p) {
+  int cb = p.C / 64;
+  int want = 2048 / (cb * p.B);                 // ~8 workgroups per CU in total
+  int maxsplit = (p.HW + 31) / 32;
+  int rs = want < 1 ? 1 : (want > maxsplit ? maxsplit : want);
+  return dim3(cb, rs, p.B);
+}
+
+}  // namespace
+
+extern "C" int sdlt_groupnorm_fwd(const sdlt_groupnorm_params* pp, void* stream) {
+  const sdlt_groupnorm_params& p = *pp;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = gn_check(p, "sdlt_groupnorm_fwd");
+  if (rc) return rc;
+  if (p.ldy % 8) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_groupnorm_fwd: ldy %% 8");
+  CatIn in{(const bf16_t*)p.x1, p.ldx1, p.C1, (const bf16_t*)p.x2, p.ldx2};
+  hipMemsetAsync(p.stats, 0, sizeof(float) * p.B * G * 2, s);
+  dim3 grid = gn_grid(p);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, s, in, p.HW, p.C, p.stats);
+  if (p.silu)
+    hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(256), 0, s, in, p.HW, p.C, p.stats, p.gamma, p.beta, p.eps, (bf16_t*)p.y, p.ldy);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(256), 0, s, in, p.HW, p.C, p.stats, p.gamma, p.beta, p.eps, (bf16_t*)p.y, p.ldy);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+
+extern "C" int sdlt_groupnorm_bwd(const sdlt_groupnorm_params* pp, void* stream) {
+  const sdlt_groupnorm_params& p = *pp;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = gn_check(p, "sdlt_groupnorm_bwd");
+  if (rc) return rc;
+  if ((p.lddy % 8) || (p.lddx % 8) || (p.dres && (p.lddres % 8))) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_groupnorm_bwd: ld %% 8");
+  CatIn in{(const bf16_t*)p.x1, p.ldx1, p.C1, (const bf16_t*)p.x2, p.ldx2};
+  hipMemsetAsync(p.bstats, 0, sizeof(float) * p.B * G * 2, s);
+  dim3 grid = gn_grid(p);
+  if (p.silu) {
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.gamma, p.beta, p.eps, p.bstats);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.bstats, p.gamma, p.beta, p.eps, (const bf16_t*)p.dres, p.lddres, (bf16_t*)p.dx, p.lddx);
+  } else {
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.gamma, p.beta, p.eps, p.bstats);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.bstats, p.gamma, p.beta, p.eps, (const bf16_t*)p.dres, p.lddres, (bf16_t*)p.dx, p.lddx);
+  }
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+
+extern "C" int sdlt_layernorm_fwd(const void* x, int64_t ldx, int32_t M, int32_t C, const float* gamma, const float* beta,
+                                  float eps, void* y, int64_t ldy, float* stats, void* stream) {
+  if (M <= 0 || C <= 0 || (C % 8) || C > LN_MAXCH * 512) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_layernorm_fwd: M=%d C=%d (C%%8==0, C<=%d)", M, C, LN_MAXCH * 512);
+  if ((ldx % 8) || (ldy % 8)) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_layernorm_fwd: ld %% 8");
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, M, C, gamma, beta, eps, (bf16_t*)y, ldy, stats);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+
+extern "C" int sdlt_layernorm_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy, int32_t M, int32_t C,
+                                  const float* gamma, const float* stats, const void* dres, int64_t lddres, void* dx,
+                                  int64_t lddx, void* stream) {
+  if (M <= 0 || C <= 0 || (C % 8) || C > LN_MAXCH * 512) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_layernorm_bwd: M=%d C=%d", M, C);
+  if ((ldx % 8) || (lddy % 8) || (lddx % 8) || (dres && (lddres % 8))) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_layernorm_bwd: ld %% 8");
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, M, C, gamma, stats, (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}

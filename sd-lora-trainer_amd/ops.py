@@ -1,0 +1,371 @@
+"""Tensor-level wrappers over the C-ABI (include/sdlt_kernels.h).  PyTorch is plumbing here: it owns
+the device memory and the stream; all arithmetic happens in libsdlt_kernels.so.
+
+Conventions: activations are 2-D bf16 matrices [rows, C] with unit column stride and an
+arbitrary row stride (views of wider buffers are fine); "NHWC" means rows = B*H*W.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, f"need a 2-D row-major view, got {tuple(t.shape)} strides {t.stride()}"
+    return t.stride(0)
+
+
+def _chk2(t, dtype=BF16):
+    assert t.is_cuda and t.dtype == dtype, f"expected cuda {dtype}, got {t.device} {t.dtype}"
+    return t
+
+
+_zero_pages = {}
+
+
+def zero_page(device):
+    z = _zero_pages.get(device)
+    if z is None:
+        z = torch.zeros(256, dtype=BF16, device=device)
+        _zero_pages[device] = z
+    return z
+
+
+class ConvGeom:
+    """Geometry of an implicit 3x3 convolution over an NHWC activation (sdlt_gemm_bf16 mode 1)."""
+    __slots__ = ("B", "Hin", "Win", "Cin", "Hout", "Wout", "stride", "ups", "flip", "tr")
+
+    def __init__(self, B, Hin, Win, Cin, Hout, Wout, stride=1, ups=1, flip=0, tr=0):
+        self.B, self.Hin, self.Win, self.Cin, self.Hout, self.Wout = B, Hin, Win, Cin, Hout, Wout
+        self.stride, self.ups, self.flip, self.tr = stride, ups, flip, tr
+
+
+def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
+         residual=None, alpha=1.0, Ct=None, tile=0):
+    """out[M,N] = alpha*(X.W^T [+ X2.W2^T] [+ s*(X.Adown^T).Bup^T]) + bias + rowbias[m//rows_per_batch] + residual.
+    lora = (Adown [Rp,K], Bup [N,Rp], scale, T_out [M,Rp] or None).  out dtype bf16 or fp32.  Ct: optional
+    transposed bf16 copy [N, >=M].  conv: ConvGeom -> X is the NHWC activation [B*Hin*Win, Cin]."""
+    lib = _lib.load()
+    p = _lib.GemmParams()
+    _chk2(X), _chk2(W)
+    p.X, p.ldx, p.W, p.ldw = _p(X), _ld(X), _p(W), _ld(W)
+    N, K = W.shape
+    if conv is None:
+        M = X.shape[0]
+        assert X.shape[1] == K, (X.shape, W.shape)
+        p.mode = 0
+    else:
+        M = conv.B * conv.Hout * conv.Wout
+        assert K == 9 * conv.Cin and X.shape[1] == conv.Cin and X.shape[0] == conv.B * conv.Hin * conv.Win
+        p.mode = 1
+        p.Hin, p.Win, p.Cin, p.Hout, p.Wout = conv.Hin, conv.Win, conv.Cin, conv.Hout, conv.Wout
+        p.stride, p.ups, p.flip, p.tr = conv.stride, conv.ups, conv.flip, conv.tr
+        p.zero = _p(zero_page(X.device))
+    p.M, p.N, p.K = M, N, K
+    if X2 is not None:
+        _chk2(X2), _chk2(W2)
+        assert X2.shape[0] == M and W2.shape[0] == N and X2.shape[1] == W2.shape[1]
+        p.X2, p.ldx2, p.W2, p.ldw2, p.K2 = _p(X2), _ld(X2), _p(W2), _ld(W2), X2.shape[1]
+    if lora is not None:
+        Adown, Bup, scale, T_out = lora
+        _chk2(Adown), _chk2(Bup)
+        Rp = Adown.shape[0]
+        assert Adown.shape[1] == K and tuple(Bup.shape) == (N, Rp), (Adown.shape, Bup.shape, N, K)
+        p.Adown, p.ld_adown, p.Bup, p.ld_bup = _p(Adown), _ld(Adown), _p(Bup), _ld(Bup)
+        p.lora_R, p.lora_scale = Rp, float(scale)
+        if T_out is not None:
+            _chk2(T_out)
+            assert tuple(T_out.shape) == (M, Rp)
+            p.T_out, p.ld_t = _p(T_out), _ld(T_out)
+    p.alpha = float(alpha)
+    if bias is not None:
+        _chk2(bias, F32)
+        assert bias.numel() == N
+        p.bias = _p(bias)
+    if rowbias is not None:
+        _chk2(rowbias)
+        assert rowbias.shape[1] == N and rows_per_batch > 0
+        p.rowbias, p.ld_rowbias, p.rows_per_batch = _p(rowbias), _ld(rowbias), rows_per_batch
+    if residual is not None:
+        _chk2(residual)
+        assert tuple(residual.shape) == (M, N)
+        p.R, p.ldr = _p(residual), _ld(residual)
+    assert out.is_cuda and tuple(out.shape) == (M, N) and out.dtype in (BF16, F32)
+    p.C, p.ldc, p.out_fp32 = _p(out), _ld(out), int(out.dtype == F32)
+    if Ct is not None:
+        _chk2(Ct)
+        assert Ct.shape[0] == N and Ct.shape[1] >= M
+        p.Ct, p.ldct = _p(Ct), _ld(Ct)
+    p.tile = tile
+    _lib.check(lib.sdlt_gemm_bf16(C.byref(p), _stream()), "sdlt_gemm_bf16")
+    return out
+
+
+class LoraGradPlan:
+    """Device-resident descriptor table for sdlt_lora_grad_grouped (built once, replayed every step)."""
+
+    def __init__(self, problems, Rp, device):
+        # problems: list of dict(P, Q, out, M, Cw, R, rank_major, conv=None|ConvGeom)
+        descs = (_lib.LoraGradDesc * len(problems))()
+        block_desc = []
+        self.keep = []
+        nb = 0
+        for i, pr in enumerate(problems):
+            d = descs[i]
+            P, Q, out = pr["P"], pr["Q"], pr["out"]
+            _chk2(P), _chk2(Q), _chk2(out, F32)
+            d.P, d.ldp, d.Q, d.ldq, d.out = P.data_ptr(), _ld(P), Q.data_ptr(), _ld(Q), out.data_ptr()
+            d.M, d.Cw, d.R, d.Rp = pr["M"], pr["Cw"], pr["R"], Rp
+            assert Q.shape[1] == Rp and Q.shape[0] == pr["M"] and out.numel() == pr["Cw"] * pr["R"] and out.is_contiguous()
+            d.rank_major, d.accumulate = int(pr["rank_major"]), 0
+            cv = pr.get("conv")
+            if cv is not None:
+                d.conv, d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.stride = 1, cv.Hin, cv.Win, cv.Cin, cv.Hout, cv.Wout, cv.stride
+                assert pr["Cw"] == 9 * cv.Cin and pr["M"] == cv.B * cv.Hout * cv.Wout
+                d.zero = zero_page(device).data_ptr()
+            else:
+                assert P.shape[0] == pr["M"] and P.shape[1] == pr["Cw"]
+            d.first_block = nb
+            blocks = (pr["Cw"] + 127) // 128
+            block_desc += [i] * blocks
+            nb += blocks
+            self.keep += [P, Q, out]
+        self.n_blocks, self.Rp = nb, Rp
+        raw = bytes(descs)
+        self.descs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self.block_desc_dev = torch.tensor(block_desc, dtype=torch.int32, device=device)
+        self._accum_off = _lib.LoraGradDesc.accumulate.offset
+        self._stride = C.sizeof(_lib.LoraGradDesc)
+
+    def set_accumulate(self, flag):
+        v = self.descs_dev.view(-1, self._stride)[:, self._accum_off:self._accum_off + 4]
+        v.copy_(torch.tensor([int(flag), 0, 0, 0], dtype=torch.uint8, device=v.device).expand_as(v))
+
+    def run(self):
+        lib = _lib.load()
+        _lib.check(lib.sdlt_lora_grad_grouped(_p(self.descs_dev), _p(self.block_desc_dev), self.n_blocks, self.Rp, _stream()),
+                   "sdlt_lora_grad_grouped")
+
+
+def _attn_params(Q, K, V, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=False):
+    p = _lib.AttnParams()
+    for t in (Q, K, V):
+        _chk2(t)
+    p.Q, p.ldq, p.K, p.ldk, p.V, p.ldv = _p(Q), _ld(Q), _p(K), _ld(K), _p(V), _ld(V)
+    p.B, p.H, p.Nq, p.Nk, p.Nqp, p.Nkp, p.d = B, H, Nq, Nk, Nqp, Nkp, d
+    p.scale, p.qsplit, p.causal = float(scale), 1, int(causal)
+    return p
+
+
+def attn_fwd(Q, K, V, Vt, O, L, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=False):
+    lib = _lib.load()
+    p = _attn_params(Q, K, V, B=B, H=H, Nq=Nq, Nk=Nk, Nqp=Nqp, Nkp=Nkp, d=d, scale=scale, causal=causal)
+    _chk2(Vt), _chk2(O), _chk2(L, F32)
+    p.Vt, p.ldvt, p.O, p.ldo, p.L = _p(Vt), _ld(Vt), _p(O), _ld(O), _p(L)
+    _lib.check(lib.sdlt_attn_fwd(C.byref(p), _stream()), "sdlt_attn_fwd")
+    return O
+
+
+def attn_bwd(Q, K, V, Kt, Qt, O, L, dO, dOt, D, dQ, dK, dV, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=False,
+             qsplit=1, dK32=None, dV32=None):
+    lib = _lib.load()
+    p = _attn_params(Q, K, V, B=B, H=H, Nq=Nq, Nk=Nk, Nqp=Nqp, Nkp=Nkp, d=d, scale=scale, causal=causal)
+    for t in (Kt, Qt, O, dO, dOt, dQ, dK, dV):
+        _chk2(t)
+    _chk2(L, F32), _chk2(D, F32)
+    p.Kt, p.ldkt, p.Qt, p.ldqt, p.dOt, p.lddot = _p(Kt), _ld(Kt), _p(Qt), _ld(Qt), _p(dOt), _ld(dOt)
+    p.O, p.ldo, p.L, p.dO, p.lddo, p.D = _p(O), _ld(O), _p(L), _p(dO), _ld(dO), _p(D)
+    p.dQ, p.lddq, p.dK, p.lddk, p.dV, p.lddv = _p(dQ), _ld(dQ), _p(dK), _ld(dK), _p(dV), _ld(dV)
+    p.qsplit = qsplit
+    if qsplit > 1:
+        _chk2(dK32, F32), _chk2(dV32, F32)
+        p.dK32, p.dV32, p.ld32 = _p(dK32), _p(dV32), _ld(dK32)
+    _lib.check(lib.sdlt_attn_bwd(C.byref(p), _stream()), "sdlt_attn_bwd")
+
+
+def _gn_params(x1, x2, B, HW, gamma, beta, eps, silu, stats):
+    p = _lib.GroupNormParams()
+    _chk2(x1), _chk2(gamma, F32), _chk2(beta, F32), _chk2(stats, F32)
+    C1 = x1.shape[1]
+    Ctot = C1 + (x2.shape[1] if x2 is not None else 0)
+    assert gamma.numel() == Ctot and x1.shape[0] == B * HW and stats.numel() >= B * 64
+    p.x1, p.ldx1, p.C1 = _p(x1), _ld(x1), C1
+    if x2 is not None:
+        _chk2(x2)
+        p.x2, p.ldx2 = _p(x2), _ld(x2)
+    p.B, p.HW, p.C = B, HW, Ctot
+    p.gamma, p.beta, p.eps, p.silu, p.stats = _p(gamma), _p(beta), float(eps), int(silu), _p(stats)
+    return p
+
+
+def groupnorm_fwd(x1, x2, y, stats, *, B, HW, gamma, beta, eps, silu):
+    lib = _lib.load()
+    p = _gn_params(x1, x2, B, HW, gamma, beta, eps, silu, stats)
+    _chk2(y)
+    p.y, p.ldy = _p(y), _ld(y)
+    _lib.check(lib.sdlt_groupnorm_fwd(C.byref(p), _stream()), "sdlt_groupnorm_fwd")
+    return y
+
+
+def groupnorm_bwd(x1, x2, dy, dx, stats, bstats, *, B, HW, gamma, beta, eps, silu, dres=None):
+    lib = _lib.load()
+    p = _gn_params(x1, x2, B, HW, gamma, beta, eps, silu, stats)
+    _chk2(dy), _chk2(dx), _chk2(bstats, F32)
+    p.dy, p.lddy, p.dx, p.lddx, p.bstats = _p(dy), _ld(dy), _p(dx), _ld(dx), _p(bstats)
+    if dres is not None:
+        _chk2(dres)
+        p.dres, p.lddres = _p(dres), _ld(dres)
+    _lib.check(lib.sdlt_groupnorm_bwd(C.byref(p), _stream()), "sdlt_groupnorm_bwd")
+    return dx
+
+
+def layernorm_fwd(x, y, stats, *, gamma, beta, eps=1e-5):
+    lib = _lib.load()
+    _chk2(x), _chk2(y), _chk2(stats, F32), _chk2(gamma, F32), _chk2(beta, F32)
+    M, Cc = x.shape
+    _lib.check(lib.sdlt_layernorm_fwd(_p(x), _ld(x), M, Cc, _p(gamma), _p(beta), float(eps), _p(y), _ld(y), _p(stats), _stream()),
+               "sdlt_layernorm_fwd")
+    return y
+
+
+def layernorm_bwd(x, dy, dx, stats, *, gamma, dres=None):
+    lib = _lib.load()
+    _chk2(x), _chk2(dy), _chk2(dx), _chk2(stats, F32), _chk2(gamma, F32)
+    M, Cc = x.shape
+    _lib.check(lib.sdlt_layernorm_bwd(_p(x), _ld(x), _p(dy), _ld(dy), M, Cc, _p(gamma), _p(stats), _p(dres),
+                                      _ld(dres) if dres is not None else 0, _p(dx), _ld(dx), _stream()), "sdlt_layernorm_bwd")
+    return dx
+
+
+def geglu_fwd(inp, out):
+    lib = _lib.load()
+    _chk2(inp), _chk2(out)
+    M, C2 = inp.shape
+    _lib.check(lib.sdlt_geglu_fwd(_p(inp), _ld(inp), M, C2 // 2, _p(out), _ld(out), _stream()), "sdlt_geglu_fwd")
+    return out
+
+
+def geglu_bwd(inp, dout, din):
+    lib = _lib.load()
+    _chk2(inp), _chk2(dout), _chk2(din)
+    M, C2 = inp.shape
+    _lib.check(lib.sdlt_geglu_bwd(_p(inp), _ld(inp), _p(dout), _ld(dout), M, C2 // 2, _p(din), _ld(din), _stream()), "sdlt_geglu_bwd")
+    return din
+
+
+MAP_SILU, MAP_DSILU, MAP_ADD, MAP_GELU, MAP_DGELU, MAP_QGELU, MAP_DQGELU = range(7)
+
+
+def map_bf16(op, x, dy, y):
+    lib = _lib.load()
+    _chk2(x), _chk2(y)
+    assert x.is_contiguous() and y.is_contiguous() and (dy is None or dy.is_contiguous())
+    _lib.check(lib.sdlt_map_bf16(op, _p(x), _p(dy), _p(y), x.numel(), _stream()), "sdlt_map_bf16")
+    return y
+
+
+def timestep_embedding(t, out):
+    """t fp32 [rows], out bf16 [rows, dim] = [cos | sin]."""
+    lib = _lib.load()
+    _chk2(t, F32), _chk2(out)
+    _lib.check(lib.sdlt_timestep_embedding(_p(t), out.shape[0], out.shape[1], _p(out), _ld(out), _stream()), "sdlt_timestep_embedding")
+    return out
+
+
+def add_noise_nhwc(x0, noise, timesteps, alphas_cumprod, out, noisy_nchw=None):
+    lib = _lib.load()
+    B, Cc, H, W = x0.shape
+    _chk2(x0, F32), _chk2(noise, F32), _chk2(alphas_cumprod, F32), _chk2(out)
+    assert timesteps.dtype == torch.int64 and x0.is_contiguous() and noise.is_contiguous() and out.is_contiguous()
+    _lib.check(lib.sdlt_add_noise_nhwc(_p(x0), _p(noise), _p(timesteps), _p(alphas_cumprod), B, Cc, H * W, out.shape[1], _p(out),
+                                       _p(noisy_nchw), _stream()), "sdlt_add_noise_nhwc")
+    return out
+
+
+def masked_mse_fwd_bwd(pred, noise, noisy, mask, timesteps, alphas_cumprod, sums, loss_out, dpred, *, snr_gamma, v_prediction=False,
+                       loss_scale=1.0):
+    lib = _lib.load()
+    B, Cc, H, W = noise.shape
+    _chk2(pred, F32), _chk2(noise, F32), _chk2(mask, F32), _chk2(sums, F32), _chk2(loss_out, F32), _chk2(dpred)
+    assert mask.is_contiguous() and noise.is_contiguous() and dpred.is_contiguous()
+    _lib.check(lib.sdlt_masked_mse_fwd_bwd(_p(pred), _ld(pred), _p(noise), _p(noisy), _p(mask), _p(timesteps), _p(alphas_cumprod),
+                                           B, Cc, H * W, dpred.shape[1], float(snr_gamma or 0.0), int(v_prediction), float(loss_scale),
+                                           _p(sums), _p(loss_out), _p(dpred), _stream()), "sdlt_masked_mse_fwd_bwd")
+
+
+def adamw_fused(p, g, m, v, hyper, l1_sum=None):
+    lib = _lib.load()
+    for t in (p, g, m, v, hyper):
+        _chk2(t, F32)
+        assert t.is_contiguous()
+    _lib.check(lib.sdlt_adamw_fused(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _p(l1_sum), _stream()), "sdlt_adamw_fused")
+
+
+class ShadowPlan:
+    """Descriptor table for sdlt_lora_shadow_refresh: fp32 arena tensors -> bf16 compute copies."""
+
+    def __init__(self, entries, device):
+        # entries: list of (offset, rows, cols, src_ld, dst or None, dstT or None)
+        descs = (_lib.ShadowDesc * len(entries))()
+        block_desc, block_first = [], []
+        nb = 0
+        self.keep = []
+        for i, (off, rows, cols, src_ld, dst, dstT) in enumerate(entries):
+            d = descs[i]
+            d.offset, d.rows, d.cols, d.src_ld = off, rows, cols, src_ld
+            if dst is not None:
+                _chk2(dst)
+                d.dst, d.ld = dst.data_ptr(), _ld(dst)
+            if dstT is not None:
+                _chk2(dstT)
+                d.dstT, d.ldT = dstT.data_ptr(), _ld(dstT)
+            block_first.append(nb)
+            blocks = (rows * cols + 4095) // 4096
+            block_desc += [i] * blocks
+            nb += blocks
+            self.keep += [dst, dstT]
+        self.n_blocks = nb
+        self.descs_dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(device)
+        self.block_desc_dev = torch.tensor(block_desc, dtype=torch.int32, device=device)
+        self.block_first_dev = torch.tensor(block_first, dtype=torch.int32, device=device)
+
+    def run(self, arena):
+        lib = _lib.load()
+        _chk2(arena, F32)
+        _lib.check(lib.sdlt_lora_shadow_refresh(_p(self.descs_dev), _p(self.block_desc_dev), _p(self.block_first_dev), self.n_blocks,
+                                                _p(arena), _stream()), "sdlt_lora_shadow_refresh")
+
+
+def add2d(a, b, out):
+    lib = _lib.load()
+    _chk2(a), _chk2(b), _chk2(out)
+    M, Cc = a.shape
+    _lib.check(lib.sdlt_add2d(_p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out), M, Cc, _stream()), "sdlt_add2d")
+    return out
+
+
+def sum2x2(inp, out, *, B, H, W):
+    lib = _lib.load()
+    _chk2(inp), _chk2(out)
+    assert inp.is_contiguous() and out.is_contiguous()
+    _lib.check(lib.sdlt_sum2x2(_p(inp), B, H, W, inp.shape[1], _p(out), _stream()), "sdlt_sum2x2")
+    return out
+
+
+def colsum(x, out, *, B, R):
+    lib = _lib.load()
+    _chk2(x), _chk2(out, F32)
+    _lib.check(lib.sdlt_colsum(_p(x), _ld(x), B, R, x.shape[1], _p(out), _stream()), "sdlt_colsum")
+    return out

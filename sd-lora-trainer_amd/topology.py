@@ -1,0 +1,178 @@
+"""Static description of the two UNet2DConditionModel topologies the reference trains (SD1.5 / SDXL;
+/root/reference trainer/models.py:15-32 loads them through diffusers `from_single_file`), in diffusers
+state-dict naming, plus the analytical FLOP census the benchmark's roofline figure uses.
+
+`tiny15` / `tinyxl` keep the exact wiring at toy sizes (channels still multiples of 64) for fast tests.
+"""
+import math
+from collections import OrderedDict
+
+CONFIGS = {
+    "sd15": dict(block_out_channels=(320, 640, 1280, 1280), down_has_attn=(True, True, True, False),
+                 up_has_attn=(False, True, True, True), layers_per_block=2, transformer_layers=(1, 1, 1, 1),
+                 heads=(8, 8, 8, 8), cross_dim=768, linear_proj=False, addition=False, in_channels=4, out_channels=4,
+                 scaling_factor=0.18215),
+    "sdxl": dict(block_out_channels=(320, 640, 1280), down_has_attn=(False, True, True), up_has_attn=(True, True, False),
+                 layers_per_block=2, transformer_layers=(1, 2, 10), heads=(5, 10, 20), cross_dim=2048, linear_proj=True,
+                 addition=True, addition_time_embed_dim=256, proj_class_in=2816, in_channels=4, out_channels=4,
+                 scaling_factor=0.13025),
+    "tiny15": dict(block_out_channels=(64, 128, 128), down_has_attn=(True, True, False), up_has_attn=(False, True, True),
+                   layers_per_block=1, transformer_layers=(1, 1, 1), heads=(2, 2, 2), cross_dim=64, linear_proj=False,
+                   addition=False, in_channels=4, out_channels=4, scaling_factor=0.18215),
+    "tinyxl": dict(block_out_channels=(64, 128, 128), down_has_attn=(False, True, True), up_has_attn=(True, True, False),
+                   layers_per_block=1, transformer_layers=(1, 1, 2), heads=(1, 2, 2), cross_dim=64, linear_proj=True,
+                   addition=True, addition_time_embed_dim=32, proj_class_in=64 + 6 * 32, in_channels=4, out_channels=4,
+                   scaling_factor=0.13025),
+}
+TIME_DIM_MULT = 4
+LORA_TARGET_SUFFIXES = ("to_k", "to_q", "to_v", "to_out.0", "conv2")  # trainer/optimizer.py:84
+
+
+def _walk(cfg, on_resnet, on_transformer, on_conv, on_linear, on_norm):
+    """Calls the visitors in diffusers module order; shared by param_shapes() and flops()."""
+    boc = cfg["block_out_channels"]
+    c0, L = boc[0], cfg["layers_per_block"]
+    tdim = c0 * TIME_DIM_MULT
+    on_conv("conv_in", cfg["in_channels"], c0, 3, 0)
+    on_linear("time_embedding.linear_1", c0, tdim, True, None)
+    on_linear("time_embedding.linear_2", tdim, tdim, True, None)
+    if cfg["addition"]:
+        on_linear("add_embedding.linear_1", cfg["proj_class_in"], tdim, True, None)
+        on_linear("add_embedding.linear_2", tdim, tdim, True, None)
+    out_c, lvl = c0, 0
+    for i, c in enumerate(boc):
+        in_c, out_c = out_c, c
+        for j in range(L):
+            on_resnet(f"down_blocks.{i}.resnets.{j}", in_c if j == 0 else out_c, out_c, lvl)
+            if cfg["down_has_attn"][i]:
+                on_transformer(f"down_blocks.{i}.attentions.{j}", out_c, cfg["transformer_layers"][i], cfg["heads"][i], lvl)
+        if i != len(boc) - 1:
+            on_conv(f"down_blocks.{i}.downsamplers.0.conv", out_c, out_c, 3, lvl + 1)
+            lvl += 1
+    cm = boc[-1]
+    on_resnet("mid_block.resnets.0", cm, cm, lvl)
+    on_transformer("mid_block.attentions.0", cm, cfg["transformer_layers"][-1], cfg["heads"][-1], lvl)
+    on_resnet("mid_block.resnets.1", cm, cm, lvl)
+    rev, rev_l, rev_h = list(reversed(boc)), list(reversed(cfg["transformer_layers"])), list(reversed(cfg["heads"]))
+    out_c = rev[0]
+    for i in range(len(boc)):
+        prev, out_c = out_c, rev[i]
+        in_c = rev[min(i + 1, len(boc) - 1)]
+        for j in range(L + 1):
+            skip = in_c if j == L else out_c
+            on_resnet(f"up_blocks.{i}.resnets.{j}", (prev if j == 0 else out_c) + skip, out_c, lvl)
+            if cfg["up_has_attn"][i]:
+                on_transformer(f"up_blocks.{i}.attentions.{j}", out_c, rev_l[i], rev_h[i], lvl)
+        if i != len(boc) - 1:
+            lvl -= 1
+            on_conv(f"up_blocks.{i}.upsamplers.0.conv", out_c, out_c, 3, lvl)
+    on_norm("conv_norm_out", c0)
+    on_conv("conv_out", c0, cfg["out_channels"], 3, 0)
+
+
+def param_shapes(cfg):
+    """OrderedDict diffusers-name -> shape."""
+    P = OrderedDict()
+    tdim = cfg["block_out_channels"][0] * TIME_DIM_MULT
+
+    def lin(n, i, o, bias, lvl):
+        P[n + ".weight"] = (o, i)
+        if bias:
+            P[n + ".bias"] = (o,)
+
+    def conv(n, i, o, k, lvl):
+        P[n + ".weight"] = (o, i, k, k)
+        P[n + ".bias"] = (o,)
+
+    def norm(n, c):
+        P[n + ".weight"] = (c,)
+        P[n + ".bias"] = (c,)
+
+    def resnet(n, i, o, lvl):
+        norm(n + ".norm1", i)
+        conv(n + ".conv1", i, o, 3, lvl)
+        lin(n + ".time_emb_proj", tdim, o, True, None)
+        norm(n + ".norm2", o)
+        conv(n + ".conv2", o, o, 3, lvl)
+        if i != o:
+            conv(n + ".conv_shortcut", i, o, 1, lvl)
+
+    def transformer(n, c, nlayers, heads, lvl):
+        norm(n + ".norm", c)
+        (lin if cfg["linear_proj"] else (lambda a, b, d, e, f: conv(a, b, d, 1, f)))(n + ".proj_in", c, c, True, lvl)
+        for k in range(nlayers):
+            b = f"{n}.transformer_blocks.{k}"
+            norm(b + ".norm1", c)
+            for a, kvd in (("attn1", c), ("attn2", cfg["cross_dim"])):
+                lin(f"{b}.{a}.to_q", c, c, False, lvl)
+                lin(f"{b}.{a}.to_k", kvd, c, False, lvl)
+                lin(f"{b}.{a}.to_v", kvd, c, False, lvl)
+                lin(f"{b}.{a}.to_out.0", c, c, True, lvl)
+                if a == "attn1":
+                    norm(b + ".norm2", c)
+            norm(b + ".norm3", c)
+            lin(b + ".ff.net.0.proj", c, 8 * c, True, lvl)
+            lin(b + ".ff.net.2", 4 * c, c, True, lvl)
+        (lin if cfg["linear_proj"] else (lambda a, b, d, e, f: conv(a, b, d, 1, f)))(n + ".proj_out", c, c, True, lvl)
+
+    _walk(cfg, resnet, transformer, conv, lin, norm)
+    return P
+
+
+def lora_targets(cfg):
+    shapes = param_shapes(cfg)
+    return [n[:-7] for n in shapes if n.endswith(".weight") and any(n[:-7].endswith("." + s) for s in LORA_TARGET_SUFFIXES)]
+
+
+def fwd_flops(cfg, B, H, W, rank=16, n_ctx=77):
+    """2*MAC count of every GEMM / conv / attention matmul of one UNet forward (incl. LoRA and the DAAM score
+    GEMMs of the hooked cross-attentions), latent size HxW.  Reproduces SURVEY.md Appendix B:
+    SDXL 128x128 B=1 r=16 -> 6.832 TFLOP."""
+    tot = {"conv3": 0.0, "proj": 0.0, "attn_proj": 0.0, "attn_core": 0.0, "ff": 0.0, "lora": 0.0, "daam": 0.0}
+
+    def px(lvl):
+        return B * (H >> lvl) * (W >> lvl)
+
+    def conv(n, i, o, k, lvl):
+        key = "conv3" if k == 3 else "proj"
+        tot[key] += 2.0 * px(lvl) * i * o * k * k
+
+    def lin(n, i, o, bias, lvl):
+        if lvl is None:
+            tot["proj"] += 2.0 * B * i * o
+        else:
+            tot["proj"] += 2.0 * px(lvl) * i * o
+
+    def norm(n, c):
+        pass
+
+    def resnet(n, i, o, lvl):
+        conv(n, i, o, 3, lvl)
+        conv(n, o, o, 3, lvl)
+        tot["lora"] += 2.0 * px(lvl) * rank * (9 * o + o)
+        tot["proj"] += 2.0 * B * (cfg["block_out_channels"][0] * TIME_DIM_MULT) * o
+        if i != o:
+            conv(n, i, o, 1, lvl)
+
+    def transformer(n, c, nlayers, heads, lvl):
+        N = px(lvl)
+        tot["proj"] += 2 * 2.0 * N * c * c
+        hooked = not n.startswith("mid_block")
+        for _ in range(nlayers):
+            tot["attn_proj"] += 2.0 * N * c * c * 4            # attn1 q,k,v,out
+            tot["attn_proj"] += 2.0 * N * c * c * 2            # attn2 q,out
+            tot["attn_proj"] += 2.0 * B * n_ctx * cfg["cross_dim"] * c * 2
+            tot["lora"] += 2.0 * N * rank * 2 * c * 6 + 2.0 * B * n_ctx * rank * (cfg["cross_dim"] + c) * 2
+            per_b = N // B
+            tot["attn_core"] += 4.0 * B * per_b * per_b * c + 4.0 * B * per_b * n_ctx * c
+            if hooked:
+                tot["daam"] += 2.0 * N * n_ctx * c
+            tot["ff"] += 2.0 * N * c * 8 * c + 2.0 * N * 4 * c * c
+
+    _walk(cfg, resnet, transformer, conv, lin, norm)
+    tot["total"] = sum(tot.values())
+    return tot
+
+
+def n_params(cfg):
+    return sum(math.prod(s) for s in param_shapes(cfg).values())

@@ -1,0 +1,618 @@
+"""UNet2DCondition (SD1.5 / SDXL) with rank-r LoRA adapters as an explicit forward/backward plan over
+the HIP kernels of libsdlt_kernels.so.
+
+This is the drop-in for the model call of the reference's training step
+(/root/reference main.py:329-336: `unet(noisy_latent, timesteps, encoder_hidden_states=..., added_cond_kwargs=...)`
+with the peft adapters of trainer/optimizer.py:84-95 and the DAAM hooks of trainer/ti_cross_attn_loss.py:336-364)
+and for `loss.backward()` (main.py:363) restricted to what the reference actually trains: LoRA A/B and the
+gradient w.r.t. the text conditioning (which carries the textual-inversion gradient).
+
+MI355X-first choices:
+  * no autograd tape, no tracing compiler: the topology is static, so every layer owns persistent buffers
+    (activations are kept, never recomputed - 288 GB HBM) and an explicit backward; the whole step is
+    captured once into a hipGraph and replayed.
+  * NHWC / token-major bf16 activations: a feature map IS the [B*H*W, C] matrix the transformer blocks use,
+    3x3 convs are implicit GEMMs, the up-block skip concat is never materialised.
+  * frozen weights are stored in both orientations (W for forward, W^T for dX).
+  * every LoRA weight gradient of the step is produced by ONE grouped launch at the end of backward.
+
+Weight names follow the diffusers state dict so real checkpoints and the kohya exporter line up.
+"""
+import math
+
+import torch
+
+from . import ops as _ops
+from .topology import CONFIGS, TIME_DIM_MULT, lora_targets, param_shapes  # noqa: F401
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _pad_to(x, m):
+    return (x + m - 1) // m * m
+
+
+class Runtime:
+    """Execution context shared by all layers: device, batch, activation dtype and the op table."""
+
+    def __init__(self, device, B, act_dtype=BF16, ops=None):
+        self.device, self.B, self.act = torch.device(device), B, act_dtype
+        self.ops = ops if ops is not None else _ops
+        self.lora_problems = []      # filled by layers on their first backward
+        self.daam = []               # (name, scores fp32 [B, N, 80]) of hooked attn2 layers, reference order
+
+    def empty(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or self.act, device=self.device)
+
+    def zeros(self, *shape, dtype=None):
+        return torch.zeros(*shape, dtype=dtype or self.act, device=self.device)
+
+
+class _Module:
+    def __init__(self, rt, name):
+        self.rt, self.name, self._b = rt, name, {}
+
+    def buf(self, key, *shape, dtype=None, zero=False):
+        t = self._b.get(key)
+        if t is None:
+            t = (self.rt.zeros if zero else self.rt.empty)(*shape, dtype=dtype)
+            self._b[key] = t
+        return t
+
+
+# ---------------------------------------------------------------------------------------- LoRA arena
+
+class LoraArena:
+    """Flat fp32 master copy of every LoRA A/B (plus grads and AdamW moments) and the bf16 compute copies."""
+
+    def __init__(self, rt, rank, alpha_multiplier=1.0):
+        self.rt, self.rank = rt, rank
+        self.Rp = 16 if rank <= 16 else (32 if rank <= 32 else 64)
+        assert rank <= 64, "LoRA rank > 64 not supported by the fused kernels"
+        self.scale = (rank * alpha_multiplier) / rank  # peft: lora_alpha / r, lora_alpha = r * multiplier (optimizer.py:88)
+        self.entries = []   # dict(name, kind, offA, offB, N, K, conv)
+        self.n = 0
+        self._shadow_entries = []
+        self.params = self.grads = self.m = self.v = None
+
+    def add(self, name, N, K, conv_cin=None):
+        r, Rp, rt = self.rank, self.Rp, self.rt
+        e = dict(name=name, N=N, K=K, conv_cin=conv_cin, offA=self.n, offB=self.n + r * K)
+        self.n += r * K + N * r
+        e["A_s"] = rt.zeros(Rp, K)          # LoRA-down, forward orientation   [Rp, K]
+        e["B_s"] = rt.zeros(N, Rp)          # LoRA-up                          [N, Rp]
+        e["Bt_s"] = rt.zeros(Rp, N)         # backward LoRA-down operand       [Rp, N]
+        if conv_cin is None:
+            e["At_s"] = rt.zeros(K, Rp)     # backward LoRA-up operand         [K, Rp]
+        else:
+            e["Ab_s"] = rt.zeros(conv_cin, 9 * 64)  # dX weights of the 3x3 LoRA-down conv: [Cin, tap*64 + rank]
+        self.entries.append(e)
+        return e
+
+    def finalize(self):
+        rt = self.rt
+        self.params = rt.zeros(self.n, dtype=F32)
+        self.grads = rt.zeros(self.n, dtype=F32)
+        self.m = rt.zeros(self.n, dtype=F32)
+        self.v = rt.zeros(self.n, dtype=F32)
+        sh = []
+        r = self.rank
+        for e in self.entries:
+            N, K = e["N"], e["K"]
+            if e["conv_cin"] is None:
+                sh.append((e["offA"], r, K, K, e["A_s"], e["At_s"]))   # (offset, rows, cols, src_ld, dst, dstT)
+            else:
+                cin = e["conv_cin"]
+                sh.append((e["offA"], r, K, K, e["A_s"], None))
+                for tap in range(9):   # A[:, tap, :] ([r, Cin], row stride 9*Cin) -> Ab[ci, tap*64 + rank]
+                    sh.append((e["offA"] + tap * cin, r, cin, K, None, e["Ab_s"][:, tap * 64: tap * 64 + 64]))
+            sh.append((e["offB"], N, r, r, e["B_s"], e["Bt_s"]))
+            e["A"] = self.params[e["offA"]: e["offA"] + r * K].view(r, K)
+            e["B"] = self.params[e["offB"]: e["offB"] + N * r].view(N, r)
+            e["gA"] = self.grads[e["offA"]: e["offA"] + r * K].view(r, K)
+            e["gB"] = self.grads[e["offB"]: e["offB"] + N * r].view(N, r)
+        self._shadow_plan = rt.ops.ShadowPlan(sh, rt.device)
+
+    def refresh_shadows(self):
+        self._shadow_plan.run(self.params)
+
+    # ---- host-side (load / export) in the reference's layouts -------------------------------
+    def load(self, lora_dict):
+        """lora_dict: module -> (A, B) in peft layout (conv: A [r,Cin,3,3], B [Cout,r,1,1])."""
+        for e in self.entries:
+            A, B = lora_dict[e["name"]]
+            if A.dim() == 4:
+                A = A.permute(0, 2, 3, 1).reshape(A.shape[0], -1)   # [r, (tap, ci)]
+                B = B.reshape(B.shape[0], -1)
+            e["A"].copy_(A.to(self.rt.device, F32))
+            e["B"].copy_(B.to(self.rt.device, F32))
+        self.refresh_shadows()
+
+    def export(self, which="params"):
+        out = {}
+        for e in self.entries:
+            A, B = (e["A"], e["B"]) if which == "params" else (e["gA"], e["gB"])
+            A, B = A.detach().float().cpu(), B.detach().float().cpu()
+            if e["conv_cin"] is not None:
+                r = A.shape[0]
+                A = A.reshape(r, 3, 3, e["conv_cin"]).permute(0, 3, 1, 2).contiguous()
+                B = B.reshape(B.shape[0], r, 1, 1)
+            out[e["name"]] = (A, B)
+        return out
+
+
+# ---------------------------------------------------------------------------------------- leaf layers
+
+class Linear(_Module):
+    """y = x W^T + b (+ LoRA) (+ residual);  dx = dy W (+ LoRA) (+ dres)."""
+
+    def __init__(self, rt, name, sd, arena=None, need_dx=True):
+        super().__init__(rt, name)
+        w = sd[name + ".weight"]
+        if w.dim() == 4:   # 1x1 conv stored [Cout, Cin, 1, 1]
+            w = w.reshape(w.shape[0], w.shape[1])
+        self.N, self.K = w.shape
+        self.W = w.to(rt.device, rt.act).contiguous()
+        self.Wt = w.t().to(rt.device, rt.act).contiguous() if need_dx else None
+        b = sd.get(name + ".bias")
+        self.bias = b.to(rt.device, F32).contiguous() if b is not None else None
+        self.lora = arena.add(name, self.N, self.K) if arena is not None else None
+        self.arena = arena
+
+    def forward(self, x, *, residual=None, Ct=None, key="y", out=None, train=True):
+        M = x.shape[0]
+        y = out if out is not None else self.buf(key, M, self.N)
+        lora = None
+        if self.lora is not None:
+            T = self.buf("T", M, self.arena.Rp) if train else None
+            lora = (self.lora["A_s"], self.lora["B_s"], self.arena.scale, T)
+            self._x = x
+        self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, residual=residual, Ct=Ct)
+        return y
+
+    def backward(self, dy, *, dres=None, Ct=None, key="dx", out=None):
+        M = dy.shape[0]
+        dx = out if out is not None else self.buf(key, M, self.K)
+        lora = None
+        if self.lora is not None:
+            U = self.buf("U", M, self.arena.Rp)
+            lora = (self.lora["Bt_s"], self.lora["At_s"], self.arena.scale, U)
+            if not getattr(self, "_registered", False):
+                r = self.arena.rank
+                self.rt.lora_problems += [
+                    dict(P=dy, Q=self._b["T"], out=self.lora["gB"], M=M, Cw=self.N, R=r, rank_major=False),
+                    dict(P=self._x, Q=U, out=self.lora["gA"], M=M, Cw=self.K, R=r, rank_major=True)]
+                self._registered = True
+        self.rt.ops.gemm(dy, self.Wt, dx, lora=lora, residual=dres, Ct=Ct)
+        return dx
+
+
+class Conv3x3(_Module):
+    """3x3 conv (pad 1) on NHWC activations as an implicit GEMM; optional stride 2 / nearest-2x upsampled input."""
+
+    def __init__(self, rt, name, sd, arena=None, stride=1, ups=1, cin_pad=None, need_dx=True):
+        super().__init__(rt, name)
+        w = sd[name + ".weight"].float()               # [Cout, Cin, 3, 3]
+        self.Cout, self.Cin = w.shape[0], w.shape[1]
+        self.stride, self.ups = stride, ups
+        self.Cin_p = cin_pad or self.Cin
+        wf = torch.zeros(self.Cout, 3, 3, self.Cin_p, device=w.device)
+        wf[..., : self.Cin] = w.permute(0, 2, 3, 1)
+        self.Wf = wf.reshape(self.Cout, 9 * self.Cin_p).to(rt.device, rt.act).contiguous()
+        self.Wb = None
+        if need_dx:
+            self.Cout_p = _pad_to(self.Cout, 64)
+            wb = torch.zeros(self.Cin, 3, 3, self.Cout_p, device=w.device)
+            wb[..., : self.Cout] = w.permute(1, 2, 3, 0)
+            self.Wb = wb.reshape(self.Cin, 9 * self.Cout_p).to(rt.device, rt.act).contiguous()
+        self.bias = sd[name + ".bias"].to(rt.device, F32).contiguous()
+        self.lora = arena.add(name, self.Cout, 9 * self.Cin, conv_cin=self.Cin) if arena is not None else None
+        self.arena = arena
+
+    def geom(self, B, H, W):
+        """H, W = stored input spatial dims -> (fwd ConvGeom, Hout, Wout)."""
+        Hout = H * self.ups // self.stride
+        Wout = W * self.ups // self.stride
+        return _ops.ConvGeom(B, H, W, self.Cin_p, Hout, Wout, stride=self.stride, ups=self.ups), Hout, Wout
+
+    def forward(self, x, B, H, W, *, rowbias=None, residual=None, key="y", out=None, train=True):
+        g, Hout, Wout = self.geom(B, H, W)
+        M = B * Hout * Wout
+        y = out if out is not None else self.buf(key, M, self.Cout)
+        lora = None
+        if self.lora is not None:
+            T = self.buf("T", M, self.arena.Rp) if train else None
+            lora = (self.lora["A_s"], self.lora["B_s"], self.arena.scale, T)
+            self._x, self._g = x, g
+        self.rt.ops.gemm(x, self.Wf, y, conv=g, lora=lora, bias=self.bias, rowbias=rowbias, rows_per_batch=Hout * Wout,
+                         residual=residual)
+        self._dims = (B, H, W, Hout, Wout)
+        return y
+
+    def backward(self, dy, *, dres=None, key="dx", out=None):
+        """dy [B*Hout*Wout, Cout_p] (Cout_p = Cout rounded up to 64; only conv_out pads) -> dx [B*H*W, Cin] (+ dres)."""
+        B, H, W, Hout, Wout = self._dims
+        rt = self.rt
+        assert dy.shape[1] == self.Cout_p, "conv backward wants dy padded to a multiple of 64 channels"
+        if self.ups == 2:
+            # dX of conv(up2(x)): transposed conv at the upsampled resolution, then 2x2 block sums
+            gb = _ops.ConvGeom(B, Hout, Wout, self.Cout_p, Hout, Wout, flip=1)
+            dup = self.buf("dup", B * Hout * Wout, self.Cin)
+            rt.ops.gemm(dy, self.Wb, dup, conv=gb)
+            dx = out if out is not None else self.buf(key, B * H * W, self.Cin)
+            assert dres is None
+            return rt.ops.sum2x2(dup, dx, B=B, H=H, W=W)
+        gb = _ops.ConvGeom(B, Hout, Wout, self.Cout_p, H, W, flip=1, tr=int(self.stride == 2))
+        dx = out if out is not None else self.buf(key, B * H * W, self.Cin)
+        if self.lora is None:
+            return rt.ops.gemm(dy, self.Wb, dx, conv=gb, residual=dres)
+        # LoRA conv (stride 1): U = s * dy . Bup (per pixel);  dx = convT(dy, W) + convT(U, A) (+ dres)
+        M = B * Hout * Wout
+        U64 = self.buf("U64", M, 64, zero=True)
+        U = U64[:, : self.arena.Rp]
+        rt.ops.gemm(dy, self.lora["Bt_s"], U, alpha=self.arena.scale)
+        rt.ops.gemm(dy, self.Wb, dx, conv=gb, residual=dres)
+        rt.ops.gemm(U64, self.lora["Ab_s"], dx, conv=_ops.ConvGeom(B, Hout, Wout, 64, H, W, flip=1), residual=dx)
+        if not getattr(self, "_registered", False):
+            r = self.arena.rank
+            rt.lora_problems += [
+                dict(P=dy, Q=self._b["T"], out=self.lora["gB"], M=M, Cw=self.Cout, R=r, rank_major=False),
+                dict(P=self._x, Q=U, out=self.lora["gA"], M=M, Cw=9 * self.Cin, R=r, rank_major=True, conv=self._g)]
+            self._registered = True
+        return dx
+
+
+class GroupNorm(_Module):
+    def __init__(self, rt, name, sd, eps, silu):
+        super().__init__(rt, name)
+        self.gamma = sd[name + ".weight"].to(rt.device, F32).contiguous()
+        self.beta = sd[name + ".bias"].to(rt.device, F32).contiguous()
+        self.eps, self.silu, self.C = eps, silu, self.gamma.numel()
+
+    def forward(self, x1, x2, B, HW):
+        y = self.buf("y", B * HW, self.C)
+        stats = self.buf("stats", B * 64, dtype=F32)
+        self._in = (x1, x2, B, HW)
+        return self.rt.ops.groupnorm_fwd(x1, x2, y, stats, B=B, HW=HW, gamma=self.gamma, beta=self.beta, eps=self.eps, silu=self.silu)
+
+    def backward(self, dy, dres=None, out=None):
+        x1, x2, B, HW = self._in
+        dx = out if out is not None else self.buf("dx", B * HW, self.C)
+        return self.rt.ops.groupnorm_bwd(x1, x2, dy, dx, self._b["stats"], self.buf("bstats", B * 64, dtype=F32), B=B, HW=HW,
+                                         gamma=self.gamma, beta=self.beta, eps=self.eps, silu=self.silu, dres=dres)
+
+
+class LayerNorm(_Module):
+    def __init__(self, rt, name, sd, eps=1e-5):
+        super().__init__(rt, name)
+        self.gamma = sd[name + ".weight"].to(rt.device, F32).contiguous()
+        self.beta = sd[name + ".bias"].to(rt.device, F32).contiguous()
+        self.eps = eps
+
+    def forward(self, x):
+        y = self.buf("y", *x.shape)
+        self._x = x
+        return self.rt.ops.layernorm_fwd(x, y, self.buf("stats", x.shape[0] * 2, dtype=F32), gamma=self.gamma, beta=self.beta, eps=self.eps)
+
+    def backward(self, dy, dres=None, out=None):
+        dx = out if out is not None else self.buf("dx", *self._x.shape)
+        return self.rt.ops.layernorm_bwd(self._x, dy, dx, self._b["stats"], gamma=self.gamma, dres=dres)
+
+
+# ---------------------------------------------------------------------------------------- composite blocks
+
+CTX_PAD = 80   # the 77 text tokens are stored as 80 rows per batch (16-byte aligned transposed tiles)
+
+
+class Attention(_Module):
+    def __init__(self, rt, name, sd, arena, heads, cross, hooked):
+        super().__init__(rt, name)
+        self.to_q = Linear(rt, name + ".to_q", sd, arena)
+        self.to_k = Linear(rt, name + ".to_k", sd, arena)
+        self.to_v = Linear(rt, name + ".to_v", sd, arena)
+        self.to_out = Linear(rt, name + ".to_out.0", sd, arena)
+        self.heads, self.cross, self.hooked = heads, cross, hooked
+        self.C = self.to_q.N
+        self.d = self.C // heads
+        self.scale = 1.0 / math.sqrt(self.d)
+
+    def forward(self, x, ctx, B, N, residual):
+        """x [B*N, C]; ctx [B*CTX_PAD, D] for cross attention.  Returns residual + to_out(attn)."""
+        rt, C = self.rt, self.C
+        kv = ctx if self.cross else x
+        Nk, Nkp = (77, CTX_PAD) if self.cross else (N, N)
+        Mq, Mk = B * N, B * Nkp
+        Qt = self.buf("Qt", C, Mq)
+        Kt = self.buf("Kt", C, _pad_to(Mk, 8))
+        Vt = self.buf("Vt", C, _pad_to(Mk, 8))
+        q = self.to_q.forward(x, Ct=Qt)
+        k = self.to_k.forward(kv, Ct=Kt)
+        v = self.to_v.forward(kv, Ct=Vt)
+        O = self.buf("O", Mq, C)
+        L = self.buf("L", B * self.heads * N, dtype=F32)
+        self._dims = (B, N, Nk, Nkp)
+        rt.ops.attn_fwd(q, k, v, Vt, O, L, B=B, H=self.heads, Nq=N, Nk=Nk, Nqp=N, Nkp=Nkp, d=self.d, scale=self.scale)
+        if self.cross and self.hooked:
+            # DAAM side output (ti_cross_attn_loss.py:201-212): sum over heads of Q_h K_h^T / sqrt(d) = Q K^T / sqrt(d)
+            S = self.buf("S", B * N, CTX_PAD, dtype=F32)
+            for b in range(B):
+                rt.ops.gemm(q[b * N:(b + 1) * N], k[b * Nkp:(b + 1) * Nkp], S[b * N:(b + 1) * N], alpha=self.scale)
+            rt.daam.append((self.name, S.view(B, N, CTX_PAD)))
+        return self.to_out.forward(O, residual=residual)
+
+    def backward(self, dout, dctx=None):
+        """dout = grad of (residual + to_out(attn)); returns d(attention input) WITHOUT the residual path."""
+        rt, C = self.rt, self.C
+        B, N, Nk, Nkp = self._dims
+        Mq, Mk = B * N, B * Nkp
+        dOt = self.buf("dOt", C, Mq)
+        dO = self.to_out.backward(dout, Ct=dOt)
+        q, k, v = self.to_q._b["y"], self.to_k._b["y"], self.to_v._b["y"]
+        dq, dk, dv = self.buf("dq", Mq, C), self.buf("dk", Mk, C), self.buf("dv", Mk, C)
+        D = self.buf("D", B * self.heads * N, dtype=F32)
+        kw = {}
+        if self.cross:
+            ntiles = (Nk + 63) // 64
+            qs = max(1, min((N + 63) // 64, 320 // max(1, ntiles * self.heads * B)))
+            if qs > 1:
+                kw = dict(qsplit=qs, dK32=self.buf("dk32", Mk, C, dtype=F32), dV32=self.buf("dv32", Mk, C, dtype=F32))
+        rt.ops.attn_bwd(q, k, v, self._b["Kt"], self._b["Qt"], self._b["O"], self._b["L"], dO, dOt, D, dq, dk, dv,
+                        B=B, H=self.heads, Nq=N, Nk=Nk, Nqp=N, Nkp=Nkp, d=self.d, scale=self.scale, **kw)
+        dx = self.to_q.backward(dq)
+        if self.cross:
+            # gradient w.r.t. the text conditioning, accumulated over every cross-attention layer
+            self.to_k.backward(dk, dres=dctx, out=dctx)
+            self.to_v.backward(dv, dres=dctx, out=dctx)
+        else:
+            self.to_k.backward(dk, dres=dx, out=dx)
+            self.to_v.backward(dv, dres=dx, out=dx)
+        return dx
+
+
+class TransformerBlock(_Module):
+    def __init__(self, rt, name, sd, arena, heads, hooked):
+        super().__init__(rt, name)
+        self.norm1 = LayerNorm(rt, name + ".norm1", sd)
+        self.attn1 = Attention(rt, name + ".attn1", sd, arena, heads, cross=False, hooked=False)
+        self.norm2 = LayerNorm(rt, name + ".norm2", sd)
+        self.attn2 = Attention(rt, name + ".attn2", sd, arena, heads, cross=True, hooked=hooked)
+        self.norm3 = LayerNorm(rt, name + ".norm3", sd)
+        self.ff1 = Linear(rt, name + ".ff.net.0.proj", sd)
+        self.ff2 = Linear(rt, name + ".ff.net.2", sd)
+
+    def forward(self, x, ctx, B, N):
+        x1 = self.attn1.forward(self.norm1.forward(x), None, B, N, residual=x)
+        x2 = self.attn2.forward(self.norm2.forward(x1), ctx, B, N, residual=x1)
+        f1 = self.ff1.forward(self.norm3.forward(x2))
+        g = self.rt.ops.geglu_fwd(f1, self.buf("g", x.shape[0], f1.shape[1] // 2))
+        return self.ff2.forward(g, residual=x2)
+
+    def backward(self, dx3, dctx):
+        rt = self.rt
+        dg = self.ff2.backward(dx3)
+        df1 = rt.ops.geglu_bwd(self.ff1._b["y"], dg, self.buf("df1", *self.ff1._b["y"].shape))
+        dx2 = self.norm3.backward(self.ff1.backward(df1), dres=dx3)
+        dx1 = self.norm2.backward(self.attn2.backward(dx2, dctx), dres=dx2)
+        return self.norm1.backward(self.attn1.backward(dx1), dres=dx1)
+
+
+class Transformer2D(_Module):
+    def __init__(self, rt, name, sd, arena, C, heads, nlayers, hooked):
+        super().__init__(rt, name)
+        self.norm = GroupNorm(rt, name + ".norm", sd, 1e-6, silu=False)
+        self.proj_in = Linear(rt, name + ".proj_in", sd)
+        self.blocks = [TransformerBlock(rt, f"{name}.transformer_blocks.{k}", sd, arena, heads, hooked) for k in range(nlayers)]
+        self.proj_out = Linear(rt, name + ".proj_out", sd)
+
+    def forward(self, x, ctx, B, HW):
+        h = self.proj_in.forward(self.norm.forward(x, None, B, HW))
+        for blk in self.blocks:
+            h = blk.forward(h, ctx, B, HW)
+        return self.proj_out.forward(h, residual=x)
+
+    def backward(self, dout, dctx):
+        dh = self.proj_out.backward(dout)
+        for blk in reversed(self.blocks):
+            dh = blk.backward(dh, dctx)
+        return self.norm.backward(self.proj_in.backward(dh), dres=dout)
+
+
+class ResnetBlock(_Module):
+    def __init__(self, rt, name, sd, arena, cin1, cin2, cout):
+        super().__init__(rt, name)
+        self.cin1, self.cin2, self.cout = cin1, cin2, cout
+        self.norm1 = GroupNorm(rt, name + ".norm1", sd, 1e-5, silu=True)
+        self.conv1 = Conv3x3(rt, name + ".conv1", sd)
+        self.temb = Linear(rt, name + ".time_emb_proj", sd, need_dx=False)
+        self.norm2 = GroupNorm(rt, name + ".norm2", sd, 1e-5, silu=True)
+        self.conv2 = Conv3x3(rt, name + ".conv2", sd, arena)
+        self.shortcut = None
+        if (name + ".conv_shortcut.weight") in sd:
+            self.shortcut = Linear(rt, name + ".conv_shortcut", sd)
+            if cin2:
+                w = self.shortcut
+                w.W1, w.W2 = w.W[:, :cin1], w.W[:, cin1:]
+
+    def forward(self, x1, x2, semb, B, H, W):
+        """x1 (+x2: skip tensor, channel-concatenated) -> out [B*H*W, cout]; semb = silu(time embedding) [B, tdim]."""
+        rt = self.rt
+        HW = H * W
+        h = self.norm1.forward(x1, x2, B, HW)
+        tp = self.temb.forward(semb, train=False)
+        c1 = self.conv1.forward(h, B, H, W, rowbias=tp)
+        h2 = self.norm2.forward(c1, None, B, HW)
+        if self.shortcut is None:
+            sc = x1
+        else:
+            s = self.shortcut
+            sc = self.buf("sc", B * HW, self.cout)
+            if x2 is None:
+                rt.ops.gemm(x1, s.W, sc, bias=s.bias)
+            else:
+                rt.ops.gemm(x1, s.W1, sc, X2=x2, W2=s.W2, bias=s.bias)
+        self._in = (x1, x2, B, H, W)
+        return self.conv2.forward(h2, B, H, W, residual=sc)
+
+    def backward(self, dout):
+        """dout [M, cout] -> dx [M, cin1 + cin2] (caller splits the concat)."""
+        rt = self.rt
+        x1, x2, B, H, W = self._in
+        dh2 = self.conv2.backward(dout)
+        dc1 = self.norm2.backward(dh2)
+        dh1 = self.conv1.backward(dc1)
+        dres = dout if self.shortcut is None else self.shortcut.backward(dout, key="dsc")
+        return self.norm1.backward(dh1, dres=dres)
+
+
+class UNet(_Module):
+    """forward(noisy NHWC, timesteps, ctx[, pooled, time_ids]) -> eps_hat [B*h*w, 4] fp32;  backward(dpred)."""
+
+    def __init__(self, rt, version, sd, lora_rank=None, lora_alpha_multiplier=1.0):
+        super().__init__(rt, "unet")
+        cfg = CONFIGS[version] if isinstance(version, str) else version
+        self.cfg = cfg
+        boc = cfg["block_out_channels"]
+        for c in boc:
+            assert c % 64 == 0, "channel counts must be multiples of 64 (GEMM K-step / GroupNorm tiling)"
+        self.arena = LoraArena(rt, lora_rank, lora_alpha_multiplier) if lora_rank else None
+        ar, L = self.arena, cfg["layers_per_block"]
+        c0 = boc[0]
+        self.tdim = c0 * TIME_DIM_MULT
+        self.conv_in = Conv3x3(rt, "conv_in", sd, cin_pad=64, need_dx=False)
+        self.t1 = Linear(rt, "time_embedding.linear_1", sd, need_dx=False)
+        self.t2 = Linear(rt, "time_embedding.linear_2", sd, need_dx=False)
+        if cfg["addition"]:
+            self.a1 = Linear(rt, "add_embedding.linear_1", sd, need_dx=False)
+            self.a2 = Linear(rt, "add_embedding.linear_2", sd, need_dx=False)
+        self.down, self.up = [], []
+        out_c = c0
+        for i, c in enumerate(boc):
+            in_c, out_c = out_c, c
+            res, att = [], []
+            for j in range(L):
+                res.append(ResnetBlock(rt, f"down_blocks.{i}.resnets.{j}", sd, ar, in_c if j == 0 else out_c, 0, out_c))
+                if cfg["down_has_attn"][i]:
+                    att.append(Transformer2D(rt, f"down_blocks.{i}.attentions.{j}", sd, ar, out_c, cfg["heads"][i],
+                                             cfg["transformer_layers"][i], True))
+            ds = Conv3x3(rt, f"down_blocks.{i}.downsamplers.0.conv", sd, stride=2) if i != len(boc) - 1 else None
+            self.down.append((res, att, ds))
+        cm = boc[-1]
+        self.mid = (ResnetBlock(rt, "mid_block.resnets.0", sd, ar, cm, 0, cm),
+                    Transformer2D(rt, "mid_block.attentions.0", sd, ar, cm, cfg["heads"][-1], cfg["transformer_layers"][-1], False),
+                    ResnetBlock(rt, "mid_block.resnets.1", sd, ar, cm, 0, cm))
+        rev, rev_h, rev_l = list(reversed(boc)), list(reversed(cfg["heads"])), list(reversed(cfg["transformer_layers"]))
+        out_c = rev[0]
+        for i in range(len(boc)):
+            prev, out_c = out_c, rev[i]
+            in_c = rev[min(i + 1, len(boc) - 1)]
+            res, att = [], []
+            for j in range(L + 1):
+                skip = in_c if j == L else out_c
+                rin = prev if j == 0 else out_c
+                res.append(ResnetBlock(rt, f"up_blocks.{i}.resnets.{j}", sd, ar, rin, skip, out_c))
+                if cfg["up_has_attn"][i]:
+                    att.append(Transformer2D(rt, f"up_blocks.{i}.attentions.{j}", sd, ar, out_c, rev_h[i], rev_l[i], True))
+            us = Conv3x3(rt, f"up_blocks.{i}.upsamplers.0.conv", sd, ups=2) if i != len(boc) - 1 else None
+            self.up.append((res, att, us))
+        self.norm_out = GroupNorm(rt, "conv_norm_out", sd, 1e-5, silu=True)
+        self.conv_out = Conv3x3(rt, "conv_out", sd)
+        if ar is not None:
+            ar.finalize()
+        self._grad_plan = None
+
+    # ------------------------------------------------------------------------------------ forward
+    def forward(self, x, timesteps_f, ctx, pooled=None, time_ids=None, *, B, H, W):
+        """x: noisy latent NHWC padded to 64 channels [B*H*W, 64]; timesteps_f fp32 [B]; ctx [B*CTX_PAD, D];
+        pooled [B, P] (act dtype), time_ids fp32 [B*6] (SDXL).  Returns eps_hat fp32 [B*H*W, 4]."""
+        rt, cfg = self.rt, self.cfg
+        rt.daam = []
+        boc = cfg["block_out_channels"]
+        te = rt.ops.timestep_embedding(timesteps_f, self.buf("te", B, boc[0]))
+        e1 = self.t1.forward(te, train=False)
+        emb = self.t2.forward(rt.ops.map_bf16(_ops.MAP_SILU, e1, None, self.buf("e1s", *e1.shape)), train=False)
+        if cfg["addition"]:
+            tdim_add = cfg["addition_time_embed_dim"]
+            P = cfg["proj_class_in"] - 6 * tdim_add
+            add_in = self.buf("add_in", B, cfg["proj_class_in"])
+            add_in[:, :P].copy_(pooled)
+            for b in range(B):   # sinusoids of the 6 SDXL time ids land next to the pooled text embedding
+                rt.ops.timestep_embedding(time_ids[b * 6:(b + 1) * 6], add_in[b, P:].view(6, tdim_add))
+            a1 = self.a1.forward(add_in, train=False)
+            emb = self.a2.forward(rt.ops.map_bf16(_ops.MAP_SILU, a1, None, self.buf("a1s", *a1.shape)), residual=emb, train=False)
+        semb = rt.ops.map_bf16(_ops.MAP_SILU, emb, None, self.buf("semb", *emb.shape))
+
+        h = self.conv_in.forward(x, B, H, W, train=False)
+        skips = [(h, H, W)]
+        ch, cw = H, W
+        for (res, att, ds) in self.down:
+            for j, r in enumerate(res):
+                h = r.forward(h, None, semb, B, ch, cw)
+                if att:
+                    h = att[j].forward(h, ctx, B, ch * cw)
+                skips.append((h, ch, cw))
+            if ds is not None:
+                h = ds.forward(h, B, ch, cw, train=False)
+                ch, cw = ch // 2, cw // 2
+                skips.append((h, ch, cw))
+        h = self.mid[0].forward(h, None, semb, B, ch, cw)
+        h = self.mid[1].forward(h, ctx, B, ch * cw)
+        h = self.mid[2].forward(h, None, semb, B, ch, cw)
+        for (res, att, us) in self.up:
+            for j, r in enumerate(res):
+                s, sh, sw = skips.pop()
+                assert (sh, sw) == (ch, cw)
+                h = r.forward(h, s, semb, B, ch, cw)
+                if att:
+                    h = att[j].forward(h, ctx, B, ch * cw)
+            if us is not None:
+                h = us.forward(h, B, ch, cw, train=False)
+                ch, cw = ch * 2, cw * 2
+        hn = self.norm_out.forward(h, None, B, ch * cw)
+        self._dims = (B, H, W)
+        return self.conv_out.forward(hn, B, ch, cw, out=self.buf("pred", B * H * W, cfg["out_channels"], dtype=F32), train=False)
+
+    # ------------------------------------------------------------------------------------ backward
+    def backward(self, dpred64, dctx):
+        """dpred64: d loss / d eps_hat as NHWC [B*H*W, 64] (4 real channels); dctx [B*CTX_PAD, D] is ACCUMULATED into
+        (caller zeroes it).  LoRA gradients land in arena.grads."""
+        rt, cfg = self.rt, self.cfg
+        B, H, W = self._dims
+        boc = cfg["block_out_channels"]
+        dh = self.norm_out.backward(self.conv_out.backward(dpred64))
+        skip_grads = []
+        nlev = len(boc)
+        for idx in range(nlev - 1, -1, -1):
+            res, att, us = self.up[idx]
+            if us is not None:
+                dh = us.backward(dh)
+            for j in range(len(res) - 1, -1, -1):
+                if att:
+                    dh = att[j].backward(dh, dctx)
+                dcat = res[j].backward(dh)
+                c1 = res[j].cin1
+                dh = dcat[:, :c1]
+                skip_grads.append(dcat[:, c1:])
+        dh = self.mid[2].backward(dh)
+        dh = self.mid[1].backward(dh, dctx)
+        dh = self.mid[0].backward(dh)
+        # skip_grads[i] belongs to the i-th pushed skip tensor (the up path pops them last-in-first-out and this
+        # backward walks the up path in reverse), so the down path - also walked in reverse - pops from the end.
+        pop_skip = skip_grads.pop
+        for idx in range(nlev - 1, -1, -1):
+            res, att, ds = self.down[idx]
+            if ds is not None:
+                dh = self._add(dh, pop_skip(), ("ds", idx))
+                dh = ds.backward(dh)
+            for j in range(len(res) - 1, -1, -1):
+                dh = self._add(dh, pop_skip(), ("r", idx, j))
+                if att:
+                    dh = att[j].backward(dh, dctx)
+                dh = res[j].backward(dh)
+        # conv_in's own skip gradient and dX are not needed (its input is data, no adapter upstream)
+        if self.arena is not None:
+            if self._grad_plan is None:
+                self._grad_plan = rt.ops.LoraGradPlan(rt.lora_problems, self.arena.Rp, rt.device)
+            self._grad_plan.run()
+
+    def _add(self, a, b, key):
+        return self.rt.ops.add2d(a, b, self.buf(("add",) + key, *a.shape))

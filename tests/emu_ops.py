@@ -1,0 +1,292 @@
+"""TEST-ONLY emulation of the C-ABI ops (sd-lora-trainer_amd/ops.py) in plain torch on CPU.
+
+Two uses, both as a CHECKER and never as a product path:
+  * `-m "not gpu"` tests drive the host-side plan (sd-lora-trainer_amd/unet.py, step.py) through this table
+    to validate its explicit backward against the oracle's autograd;
+  * `-m gpu` tests use the same functions as the per-kernel reference for the HIP kernels.
+Each function documents the op's contract by restating it; math is done in fp32 and rounded to the
+dtype of the output buffer.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+F32 = torch.float32
+MAP_SILU, MAP_DSILU, MAP_ADD, MAP_GELU, MAP_DGELU, MAP_QGELU, MAP_DQGELU = range(7)
+
+
+class ConvGeom:
+    __slots__ = ("B", "Hin", "Win", "Cin", "Hout", "Wout", "stride", "ups", "flip", "tr")
+
+    def __init__(self, B, Hin, Win, Cin, Hout, Wout, stride=1, ups=1, flip=0, tr=0):
+        self.B, self.Hin, self.Win, self.Cin, self.Hout, self.Wout = B, Hin, Win, Cin, Hout, Wout
+        self.stride, self.ups, self.flip, self.tr = stride, ups, flip, tr
+
+
+def _conv_apply(X, Wm, g):
+    """X [B*Hin*Win, Cin] NHWC, Wm [N, 9*Cin] with k = tap*Cin + ci -> [B*Hout*Wout, N] (fp32)."""
+    N = Wm.shape[0]
+    x = X.float().reshape(g.B, g.Hin, g.Win, g.Cin).permute(0, 3, 1, 2)
+    wk = Wm.float().reshape(N, 3, 3, g.Cin).permute(0, 3, 1, 2)   # [N, Cin, dy, dx]
+    if g.tr:
+        assert g.flip
+        y = F.conv_transpose2d(x, wk.permute(1, 0, 2, 3), stride=2, padding=1, output_padding=1)
+    else:
+        if g.ups == 2:
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+        if g.flip:
+            wk = torch.flip(wk, dims=(2, 3))
+        y = F.conv2d(x, wk, stride=g.stride, padding=1)
+    assert y.shape[2] == g.Hout and y.shape[3] == g.Wout, (y.shape, g.Hout, g.Wout)
+    return y.permute(0, 2, 3, 1).reshape(g.B * g.Hout * g.Wout, N)
+
+
+def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
+         residual=None, alpha=1.0, Ct=None, tile=0):
+    acc = X.float() @ W.float().t() if conv is None else _conv_apply(X, W, conv)
+    if X2 is not None:
+        acc = acc + X2.float() @ W2.float().t()
+    if lora is not None:
+        Adown, Bup, scale, T_out = lora
+        T = X.float() @ Adown.float().t() if conv is None else _conv_apply(X, Adown, conv)
+        Tb = (T * scale).to(out.dtype if out.dtype != F32 else X.dtype)
+        if T_out is not None:
+            T_out.copy_(Tb)
+        acc = acc + Tb.float() @ Bup.float().t()
+    acc = acc * alpha
+    if bias is not None:
+        acc = acc + bias.float()
+    if rowbias is not None:
+        idx = torch.arange(acc.shape[0]) // rows_per_batch
+        acc = acc + rowbias.float()[idx]
+    if residual is not None:
+        acc = acc + residual.float()
+    out.copy_(acc.to(out.dtype))
+    if Ct is not None:
+        Ct[:, : acc.shape[0]].copy_(acc.t().to(Ct.dtype))
+    return out
+
+
+class LoraGradPlan:
+    def __init__(self, problems, Rp, device):
+        self.problems, self.accumulate = problems, False
+
+    def set_accumulate(self, flag):
+        self.accumulate = bool(flag)
+
+    def run(self):
+        for pr in self.problems:
+            P, Q, out, R = pr["P"], pr["Q"], pr["out"], pr["R"]
+            cv = pr.get("conv")
+            if cv is None:
+                Pm = P.float()
+            else:  # im2col with k = tap*Cin + ci
+                x = P.float().reshape(cv.B, cv.Hin, cv.Win, cv.Cin).permute(0, 3, 1, 2)
+                cols = F.unfold(x, 3, padding=1, stride=cv.stride)            # [B, Cin*9, L] with (ci, tap) order
+                cols = cols.reshape(cv.B, cv.Cin, 9, -1).permute(0, 3, 2, 1).reshape(-1, 9 * cv.Cin)
+                Pm = cols
+            g = Pm.t() @ Q.float()[:, :R]          # [Cw, R]
+            g = g.t().contiguous() if pr["rank_major"] else g
+            if self.accumulate:
+                out.add_(g.reshape(out.shape))
+            else:
+                out.copy_(g.reshape(out.shape))
+
+
+def _heads(t, B, Np, H, d):
+    return t.float().reshape(B, Np, H, d).permute(0, 2, 1, 3)   # [B,H,Np,d]
+
+
+def _attn_core(q, k, v, Nq, Nk, scale, causal):
+    s = (q @ k.transpose(-1, -2)) * scale
+    mask = torch.zeros(s.shape[-2], s.shape[-1], dtype=torch.bool)
+    mask[:, Nk:] = True
+    if causal:
+        mask |= torch.triu(torch.ones_like(mask), diagonal=1)
+    s = s.masked_fill(mask, float("-inf"))
+    return s
+
+
+def attn_fwd(Q, K, V, Vt, O, L, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=False):
+    C = H * d
+    q, k, v = _heads(Q[:, :C], B, Nqp, H, d), _heads(K[:, :C], B, Nkp, H, d), _heads(V[:, :C], B, Nkp, H, d)
+    assert torch.allclose(Vt[:, : B * Nkp].float(), V[:, :C].float().t()), "V^T operand is not the transpose of V"
+    s = _attn_core(q, k, v, Nq, Nk, scale, causal)
+    lse = torch.logsumexp(s, dim=-1)
+    o = torch.softmax(s, dim=-1) @ v
+    O[:, :C].copy_(o.permute(0, 2, 1, 3).reshape(B * Nqp, C).to(O.dtype))
+    L.copy_(lse[:, :, :Nq].reshape(-1))
+    return O
+
+
+def attn_bwd(Q, K, V, Kt, Qt, O, L, dO, dOt, D, dQ, dK, dV, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=False,
+             qsplit=1, dK32=None, dV32=None):
+    C = H * d
+    assert torch.allclose(Kt[:, : B * Nkp].float(), K[:, :C].float().t())
+    assert torch.allclose(Qt[:, : B * Nqp].float(), Q[:, :C].float().t())
+    assert torch.allclose(dOt[:, : B * Nqp].float(), dO[:, :C].float().t())
+    q = _heads(Q[:, :C], B, Nqp, H, d).requires_grad_(True)
+    k = _heads(K[:, :C], B, Nkp, H, d).requires_grad_(True)
+    v = _heads(V[:, :C], B, Nkp, H, d).requires_grad_(True)
+    s = _attn_core(q, k, v, Nq, Nk, scale, causal)
+    o = torch.softmax(s, dim=-1) @ v
+    go = _heads(dO[:, :C], B, Nqp, H, d).clone()
+    go[:, :, Nq:] = 0
+    gq, gk, gv = torch.autograd.grad(o, [q, k, v], go)
+    for dst, g, Np in ((dQ, gq, Nqp), (dK, gk, Nkp), (dV, gv, Nkp)):
+        dst[:, :C].copy_(g.permute(0, 2, 1, 3).reshape(B * Np, C).to(dst.dtype))
+
+
+def _gn_cat(x1, x2):
+    return x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], dim=1)
+
+
+def groupnorm_fwd(x1, x2, y, stats, *, B, HW, gamma, beta, eps, silu):
+    x = _gn_cat(x1, x2)
+    C = x.shape[1]
+    z = F.group_norm(x.reshape(B, HW, C).permute(0, 2, 1), 32, gamma.float(), beta.float(), eps)
+    if silu:
+        z = F.silu(z)
+    y.copy_(z.permute(0, 2, 1).reshape(B * HW, C).to(y.dtype))
+    return y
+
+
+def groupnorm_bwd(x1, x2, dy, dx, stats, bstats, *, B, HW, gamma, beta, eps, silu, dres=None):
+    x = _gn_cat(x1, x2).requires_grad_(True)
+    C = x.shape[1]
+    z = F.group_norm(x.reshape(B, HW, C).permute(0, 2, 1), 32, gamma.float(), beta.float(), eps)
+    if silu:
+        z = F.silu(z)
+    (g,) = torch.autograd.grad(z.permute(0, 2, 1).reshape(B * HW, C), x, dy.float())
+    if dres is not None:
+        g = g + dres.float()
+    dx.copy_(g.to(dx.dtype))
+    return dx
+
+
+def layernorm_fwd(x, y, stats, *, gamma, beta, eps=1e-5):
+    y.copy_(F.layer_norm(x.float(), (x.shape[1],), gamma.float(), beta.float(), eps).to(y.dtype))
+    return y
+
+
+def layernorm_bwd(x, dy, dx, stats, *, gamma, dres=None):
+    xx = x.float().requires_grad_(True)
+    z = F.layer_norm(xx, (x.shape[1],), gamma.float(), None, 1e-5)
+    (g,) = torch.autograd.grad(z, xx, dy.float())
+    if dres is not None:
+        g = g + dres.float()
+    dx.copy_(g.to(dx.dtype))
+    return dx
+
+
+def geglu_fwd(inp, out):
+    h, g = inp.float().chunk(2, dim=1)
+    out.copy_((h * F.gelu(g)).to(out.dtype))
+    return out
+
+
+def geglu_bwd(inp, dout, din):
+    x = inp.float().requires_grad_(True)
+    h, g = x.chunk(2, dim=1)
+    (gr,) = torch.autograd.grad(h * F.gelu(g), x, dout.float())
+    din.copy_(gr.to(din.dtype))
+    return din
+
+
+def map_bf16(op, x, dy, y):
+    xx = x.float()
+    if op == MAP_SILU:
+        r = F.silu(xx)
+    elif op == MAP_ADD:
+        r = xx + dy.float()
+    elif op == MAP_GELU:
+        r = F.gelu(xx)
+    elif op == MAP_QGELU:
+        r = xx * torch.sigmoid(1.702 * xx)
+    else:
+        xx = xx.requires_grad_(True)
+        f = {MAP_DSILU: F.silu, MAP_DGELU: F.gelu, MAP_DQGELU: lambda t: t * torch.sigmoid(1.702 * t)}[op](xx)
+        (r,) = torch.autograd.grad(f, xx, dy.float())
+    y.copy_(r.to(y.dtype))
+    return y
+
+
+def timestep_embedding(t, out):
+    half = out.shape[1] // 2
+    f = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=F32) / half)
+    a = t.float()[:, None] * f[None]
+    out.copy_(torch.cat([torch.cos(a), torch.sin(a)], dim=1).to(out.dtype))
+    return out
+
+
+def add_noise_nhwc(x0, noise, timesteps, alphas_cumprod, out, noisy_nchw=None):
+    B, C, H, W = x0.shape
+    a = alphas_cumprod[timesteps].view(B, 1, 1, 1)
+    noisy = a.sqrt() * x0 + (1 - a).sqrt() * noise
+    if noisy_nchw is not None:
+        noisy_nchw.copy_(noisy)
+    out.zero_()
+    out[:, :C].copy_(noisy.permute(0, 2, 3, 1).reshape(B * H * W, C).to(out.dtype))
+    return out
+
+
+def masked_mse_fwd_bwd(pred, noise, noisy, mask, timesteps, alphas_cumprod, sums, loss_out, dpred, *, snr_gamma,
+                       v_prediction=False, loss_scale=1.0):
+    B, C, H, W = noise.shape
+    p = pred[:, :C].float().reshape(B, H, W, C).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    a = alphas_cumprod[timesteps].view(B, 1, 1, 1)
+    target = a.sqrt() * noise - (1 - a).sqrt() * noisy if v_prediction else noise
+    e = (p - target).pow(2) * mask
+    per = e.flatten(1).mean(1)
+    if snr_gamma:
+        snr = (alphas_cumprod[timesteps].sqrt() / (1 - alphas_cumprod[timesteps]).sqrt()) ** 2
+        w = torch.minimum(snr, torch.full_like(snr, float(snr_gamma))) / snr + (1.0 if v_prediction else 0.0)
+        loss = (per * (w / w.mean())).mean()
+    else:
+        mm = mask.flatten(1).mean(1)
+        loss = (per / (mm / mm.mean())).mean()
+    (g,) = torch.autograd.grad(loss * loss_scale, p)
+    loss_out.fill_(float(loss))
+    dpred.zero_()
+    dpred[:, :C].copy_(g.permute(0, 2, 3, 1).reshape(B * H * W, C).to(dpred.dtype))
+
+
+def adamw_fused(p, g, m, v, hyper, l1_sum=None):
+    lr, b1, b2, eps, wd, bc1, bc2, l1c, gs = [float(x) for x in hyper[:9]]
+    if l1_sum is not None:
+        l1_sum.fill_(float(p.abs().sum()))
+    gi = g * gs + l1c * torch.sign(p)
+    m.mul_(b1).add_(gi, alpha=1 - b1)
+    v.mul_(b2).addcmul_(gi, gi, value=1 - b2)
+    p.mul_(1 - lr * wd).addcdiv_(m, v.sqrt() / math.sqrt(bc2) + eps, value=-lr / bc1)
+
+
+class ShadowPlan:
+    def __init__(self, entries, device):
+        self.entries = entries
+
+    def run(self, arena):
+        for (off, rows, cols, src_ld, dst, dstT) in self.entries:
+            src = torch.as_strided(arena, (rows, cols), (src_ld, 1), off)
+            if dst is not None:
+                dst[:rows, :cols].copy_(src.to(dst.dtype))
+            if dstT is not None:
+                dstT[:cols, :rows].copy_(src.t().to(dstT.dtype))
+
+
+def add2d(a, b, out):
+    out.copy_((a.float() + b.float()).to(out.dtype))
+    return out
+
+
+def sum2x2(inp, out, *, B, H, W):
+    C = inp.shape[1]
+    x = inp.float().reshape(B, H, 2, W, 2, C).sum(dim=(2, 4))
+    out.copy_(x.reshape(B * H * W, C).to(out.dtype))
+    return out
+
+
+def colsum(x, out, *, B, R):
+    out.copy_(x.float().reshape(B, R, -1).sum(1))
+    return out
