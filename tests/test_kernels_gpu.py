@@ -1,0 +1,345 @@
+"""Per-kernel parity (MI355X): every C-ABI entry point against the torch restatement of its contract
+(tests/emu_ops.py, fp32 math on the same bf16 inputs).  Tolerance for bf16 outputs: 1.5e-2 of the
+reference's max-abs (one bf16 ulp is 0.4-0.8 %; accumulation is fp32 on both sides) - written in `close`.
+"""
+import math
+
+import pytest
+import torch
+
+from tests import emu_ops as E
+
+pytestmark = pytest.mark.gpu
+BF, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from sd_lora_trainer_amd import ops as O
+    O._lib.load()
+    return O
+
+
+def close(got, ref, tol=1.5e-2, what=""):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    err = float((got - ref).abs().max())
+    scale = float(ref.abs().max())
+    assert err <= tol * scale + 1e-6, f"{what}: max err {err:.4g} vs scale {scale:.4g} (tol {tol})"
+
+
+def rnd(*shape, g, scale=1.0, dtype=BF):
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def dev(*ts):
+    return [t.cuda() if t is not None else None for t in ts]
+
+
+# --------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K,tile", [(256, 256, 128, 1), (200, 136, 64, 1), (77, 320, 192, 2), (1000, 77, 128, 3),
+                                        (1, 1280, 320, 0), (4096, 640, 640, 0), (300, 4, 576, 3)])
+def test_gemm_plain_epilogue(ops, M, N, K, tile):
+    g = torch.Generator().manual_seed(M + N + K)
+    X, W = rnd(M, K, g=g), rnd(N, K, g=g, scale=1 / math.sqrt(K))
+    bias = torch.randn(N, generator=g)
+    R = rnd(M, N, g=g)
+    rowb = rnd(4, N, g=g)
+    rpb = (M + 3) // 4
+    for out_dtype in (BF, F32):
+        ref = E.gemm(X, W, torch.empty(M, N, dtype=out_dtype), bias=bias, residual=R, rowbias=rowb, rows_per_batch=rpb, alpha=0.5)
+        Ct = torch.zeros(N, M + 8, dtype=BF).cuda()
+        Xd, Wd, bd, Rd, rbd = dev(X, W, bias, R, rowb)
+        out = ops.gemm(Xd, Wd, torch.empty(M, N, dtype=out_dtype, device="cuda"), bias=bd, residual=Rd, rowbias=rbd,
+                       rows_per_batch=rpb, alpha=0.5, Ct=Ct, tile=tile)
+        close(out, ref, what=f"gemm {M}x{N}x{K} {out_dtype}")
+        close(Ct[:, :M], ref.t(), what="gemm Ct")
+
+
+def test_gemm_strided_views_and_two_segments(ops):
+    g = torch.Generator().manual_seed(5)
+    M, N, K1, K2 = 520, 192, 128, 64
+    big = rnd(M, K1 + K2 + 64, g=g)
+    X1, X2 = big[:, :K1], big[:, K1:K1 + K2]
+    W = rnd(N, K1 + K2, g=g, scale=0.1)
+    ref = E.gemm(X1, W[:, :K1], torch.empty(M, N, dtype=BF), X2=X2, W2=W[:, K1:])
+    bigd, Wd = dev(big, W)
+    outbig = torch.zeros(M, N + 64, dtype=BF, device="cuda")
+    ops.gemm(bigd[:, :K1], Wd[:, :K1], outbig[:, :N], X2=bigd[:, K1:K1 + K2], W2=Wd[:, K1:])
+    close(outbig[:, :N], ref, what="2-segment strided")
+    assert float(outbig[:, N:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K,r,tile", [(256, 256, 128, 16, 1), (333, 200, 192, 4, 2), (77, 640, 2048, 16, 3),
+                                          (1024, 1280, 1280, 16, 0), (130, 64, 64, 24, 3), (200, 128, 64, 64, 1)])
+def test_gemm_fused_lora(ops, M, N, K, r, tile):
+    g = torch.Generator().manual_seed(M * 3 + r)
+    Rp = 16 if r <= 16 else (32 if r <= 32 else 64)
+    X, W = rnd(M, K, g=g), rnd(N, K, g=g, scale=1 / math.sqrt(K))
+    A = torch.zeros(Rp, K, dtype=BF)
+    A[:r] = rnd(r, K, g=g, scale=1 / math.sqrt(K))
+    Bu = torch.zeros(N, Rp, dtype=BF)
+    Bu[:, :r] = rnd(N, r, g=g, scale=0.3)
+    bias = torch.randn(N, generator=g)
+    Tref = torch.empty(M, Rp, dtype=BF)
+    ref = E.gemm(X, W, torch.empty(M, N, dtype=BF), lora=(A, Bu, 0.75, Tref), bias=bias)
+    Xd, Wd, Ad, Bd, bd = dev(X, W, A, Bu, bias)
+    T = torch.full((M, Rp), 7.0, dtype=BF, device="cuda")
+    out = ops.gemm(Xd, Wd, torch.empty(M, N, dtype=BF, device="cuda"), lora=(Ad, Bd, 0.75, T), bias=bd, tile=tile)
+    close(T, Tref, what="lora T_out")
+    close(out, ref, what=f"lora gemm {M}x{N}x{K} r{r}")
+    # the adapter must actually contribute
+    base = E.gemm(X, W, torch.empty(M, N, dtype=BF), bias=bias)
+    assert float((ref.float() - base.float()).abs().max()) > 0.05
+
+
+CONV_CASES = [
+    dict(B=2, H=16, W=16, Cin=64, Cout=128, stride=1, ups=1, flip=0, tr=0),
+    dict(B=1, H=16, W=24, Cin=128, Cout=64, stride=2, ups=1, flip=0, tr=0),
+    dict(B=2, H=8, W=8, Cin=64, Cout=64, stride=1, ups=2, flip=0, tr=0),
+    dict(B=2, H=12, W=16, Cin=64, Cout=192, stride=1, ups=1, flip=1, tr=0),
+    dict(B=1, H=8, W=12, Cin=128, Cout=64, stride=1, ups=1, flip=1, tr=1),
+    dict(B=1, H=64, W=64, Cin=320, Cout=320, stride=1, ups=1, flip=0, tr=0),
+]
+
+
+@pytest.mark.parametrize("c", CONV_CASES)
+def test_conv3x3_implicit_gemm(ops, c):
+    g = torch.Generator().manual_seed(c["H"] * 7 + c["Cin"])
+    B, H, W, Cin, Cout = c["B"], c["H"], c["W"], c["Cin"], c["Cout"]
+    if c["tr"]:
+        Hout, Wout = 2 * H, 2 * W
+    else:
+        Hout, Wout = H * c["ups"] // c["stride"], W * c["ups"] // c["stride"]
+    X = rnd(B * H * W, Cin, g=g)
+    Wm = rnd(Cout, 9 * Cin, g=g, scale=1 / math.sqrt(9 * Cin))
+    bias = torch.randn(Cout, generator=g)
+    R = rnd(B * Hout * Wout, Cout, g=g)
+    rowb = rnd(B, Cout, g=g)
+    for mod, mk in ((E, lambda t: t), (ops, lambda t: t.cuda())):
+        geom = mod.ConvGeom(B, H, W, Cin, Hout, Wout, stride=c["stride"], ups=c["ups"], flip=c["flip"], tr=c["tr"])
+        out = mod.gemm(mk(X), mk(Wm), mk(torch.empty(B * Hout * Wout, Cout, dtype=BF)), conv=geom, bias=mk(bias), residual=mk(R),
+                       rowbias=mk(rowb), rows_per_batch=Hout * Wout)
+        if mod is E:
+            ref = out
+    close(out, ref, what=f"conv {c}")
+
+
+def test_conv3x3_fused_lora_and_strided_input(ops):
+    g = torch.Generator().manual_seed(11)
+    B, H, W, Cin, Cout, r, Rp = 2, 16, 16, 64, 128, 8, 16
+    wide = rnd(B * H * W, Cin + 64, g=g)
+    X = wide[:, 64:]
+    Wm = rnd(Cout, 9 * Cin, g=g, scale=1 / math.sqrt(9 * Cin))
+    A = torch.zeros(Rp, 9 * Cin, dtype=BF)
+    A[:r] = rnd(r, 9 * Cin, g=g, scale=0.05)
+    Bu = torch.zeros(Cout, Rp, dtype=BF)
+    Bu[:, :r] = rnd(Cout, r, g=g, scale=0.3)
+    Tref = torch.empty(B * H * W, Rp, dtype=BF)
+    ref = E.gemm(X, Wm, torch.empty(B * H * W, Cout, dtype=BF), conv=E.ConvGeom(B, H, W, Cin, H, W), lora=(A, Bu, 1.0, Tref))
+    wd, Wd, Ad, Bd = dev(wide, Wm, A, Bu)
+    T = torch.empty(B * H * W, Rp, dtype=BF, device="cuda")
+    out = ops.gemm(wd[:, 64:], Wd, torch.empty(B * H * W, Cout, dtype=BF, device="cuda"), conv=ops.ConvGeom(B, H, W, Cin, H, W),
+                   lora=(Ad, Bd, 1.0, T))
+    close(T, Tref, what="conv lora T")
+    close(out, ref, what="conv lora out")
+
+
+# --------------------------------------------------------------------------------------------- LoRA grads
+def test_lora_grad_grouped(ops):
+    g = torch.Generator().manual_seed(21)
+    probs_cpu, probs_gpu = [], []
+    specs = [(300, 200, 16, 16, False, None), (1024, 640, 4, 16, True, None), (77, 2048, 16, 16, True, None),
+             (2 * 8 * 8, 9 * 64, 8, 16, True, (2, 8, 8, 64))]
+    for (M, Cw, R, Rp, rank_major, conv) in specs:
+        Q = rnd(M, Rp, g=g)
+        out = torch.zeros(Cw * R, dtype=F32)
+        if conv is None:
+            P = rnd(M, Cw, g=g)
+            cg_c = cg_g = None
+        else:
+            B, H, W, Cin = conv
+            P = rnd(B * H * W, Cin, g=g)
+            cg_c, cg_g = E.ConvGeom(B, H, W, Cin, H, W), ops.ConvGeom(B, H, W, Cin, H, W)
+        probs_cpu.append(dict(P=P, Q=Q, out=out, M=M, Cw=Cw, R=R, rank_major=rank_major, conv=cg_c))
+        probs_gpu.append(dict(P=P.cuda(), Q=Q.cuda(), out=torch.full((Cw * R,), 3.0, dtype=F32, device="cuda"), M=M, Cw=Cw, R=R,
+                              rank_major=rank_major, conv=cg_g))
+    E.LoraGradPlan(probs_cpu, 16, "cpu").run()
+    plan = ops.LoraGradPlan(probs_gpu, 16, torch.device("cuda"))
+    plan.run()
+    for pc, pg in zip(probs_cpu, probs_gpu):
+        close(pg["out"], pc["out"], tol=2e-3, what=f"lora grad M={pc['M']} Cw={pc['Cw']}")
+    plan.set_accumulate(True)
+    plan.run()
+    for pc, pg in zip(probs_cpu, probs_gpu):
+        close(pg["out"], 2 * pc["out"], tol=2e-3, what="lora grad accumulate")
+
+
+# --------------------------------------------------------------------------------------------- attention
+ATTN_CASES = [
+    dict(B=2, H=2, Nq=256, Nk=256, Nkp=256, d=64, causal=False, qsplit=1),
+    dict(B=1, H=10, Nq=1024, Nk=77, Nkp=80, d=64, causal=False, qsplit=4),
+    dict(B=2, H=3, Nq=192, Nk=77, Nkp=80, d=64, causal=False, qsplit=1),
+    dict(B=1, H=8, Nq=256, Nk=256, Nkp=256, d=40, causal=False, qsplit=1),
+    dict(B=1, H=2, Nq=128, Nk=128, Nkp=128, d=160, causal=False, qsplit=1),
+    dict(B=1, H=4, Nq=128, Nk=128, Nkp=128, d=80, causal=False, qsplit=1),
+    dict(B=2, H=2, Nq=77, Nk=77, Nkp=80, d=64, causal=True, qsplit=1),
+]
+
+
+@pytest.mark.parametrize("c", ATTN_CASES)
+def test_attention_fwd_bwd(ops, c):
+    g = torch.Generator().manual_seed(c["Nq"] + c["d"])
+    B, H, Nq, Nk, Nkp, d = c["B"], c["H"], c["Nq"], c["Nk"], c["Nkp"], c["d"]
+    Nqp = (Nq + 7) // 8 * 8
+    C = H * d
+    scale = 1 / math.sqrt(d)
+    Q, dO = rnd(B * Nqp, C, g=g), rnd(B * Nqp, C, g=g)
+    K, V = rnd(B * Nkp, C, g=g), rnd(B * Nkp, C, g=g)
+    if Nkp > Nk:
+        K.view(B, Nkp, C)[:, Nk:] = 0
+        V.view(B, Nkp, C)[:, Nk:] = 0
+    kw = dict(B=B, H=H, Nq=Nq, Nk=Nk, Nqp=Nqp, Nkp=Nkp, d=d, scale=scale, causal=c["causal"])
+    O_ref, L_ref = torch.zeros(B * Nqp, C, dtype=BF), torch.zeros(B * H * Nq)
+    E.attn_fwd(Q, K, V, V.t().contiguous(), O_ref, L_ref, **kw)
+    dQr, dKr, dVr = torch.zeros_like(Q), torch.zeros_like(K), torch.zeros_like(V)
+    E.attn_bwd(Q, K, V, K.t().contiguous(), Q.t().contiguous(), O_ref, L_ref, dO, dO.t().contiguous(), None, dQr, dKr, dVr, **kw)
+
+    Qd, Kd, Vd, dOd = dev(Q, K, V, dO)
+    Kt, Vt, Qt, dOt = Kd.t().contiguous(), Vd.t().contiguous(), Qd.t().contiguous(), dOd.t().contiguous()
+    O = torch.zeros(B * Nqp, C, dtype=BF, device="cuda")
+    L = torch.zeros(B * H * Nq, device="cuda")
+    ops.attn_fwd(Qd, Kd, Vd, Vt, O, L, **kw)
+    vq = torch.zeros(B, Nqp, 1, dtype=torch.bool)
+    vq[:, :Nq] = True
+    vq = vq.reshape(B * Nqp, 1)
+    close(O.cpu() * vq, O_ref * vq, what=f"attn fwd {c}")
+    close(L, L_ref, tol=2e-3, what="attn lse")
+    dQ, dK, dV = (torch.full_like(t, 5.0) for t in (Qd, Kd, Vd))
+    D = torch.zeros(B * H * Nq, device="cuda")
+    extra = {}
+    if c["qsplit"] > 1:
+        extra = dict(qsplit=c["qsplit"], dK32=torch.empty(B * Nkp, C, device="cuda"), dV32=torch.empty(B * Nkp, C, device="cuda"))
+    ops.attn_bwd(Qd, Kd, Vd, Kt, Qt, O, L, dOd, dOt, D, dQ, dK, dV, **kw, **extra)
+    close(dQ.cpu() * vq, dQr * vq, tol=2.5e-2, what=f"attn dQ {c}")
+    close(dK, dKr, tol=2.5e-2, what=f"attn dK {c}")
+    close(dV, dVr, tol=2.5e-2, what=f"attn dV {c}")
+
+
+# --------------------------------------------------------------------------------------------- norms / element-wise
+@pytest.mark.parametrize("B,HW,C1,C2,silu", [(2, 256, 320, 0, True), (1, 1024, 640, 320, True), (2, 64, 128, 64, False),
+                                             (1, 4096, 64, 0, True), (1, 100, 1920, 640, True)])
+def test_groupnorm_fwd_bwd(ops, B, HW, C1, C2, silu):
+    g = torch.Generator().manual_seed(C1 + HW)
+    C = C1 + C2
+    x1 = rnd(B * HW, C1, g=g) + 0.5
+    x2 = rnd(B * HW, C2, g=g, scale=2.0) if C2 else None
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    dy, dres = rnd(B * HW, C, g=g), rnd(B * HW, C, g=g)
+    kw = dict(B=B, HW=HW, eps=1e-5, silu=silu)
+    yr = E.groupnorm_fwd(x1, x2, torch.empty(B * HW, C, dtype=BF), None, gamma=gamma, beta=beta, **kw)
+    dxr = E.groupnorm_bwd(x1, x2, dy, torch.empty(B * HW, C, dtype=BF), None, None, gamma=gamma, beta=beta, dres=dres, **kw)
+    x1d, x2d, gd, bd, dyd, drd = dev(x1, x2, gamma, beta, dy, dres)
+    stats, bstats = torch.zeros(B * 64, device="cuda"), torch.zeros(B * 64, device="cuda")
+    y = ops.groupnorm_fwd(x1d, x2d, torch.empty(B * HW, C, dtype=BF, device="cuda"), stats, gamma=gd, beta=bd, **kw)
+    close(y, yr, what="groupnorm fwd")
+    dx = ops.groupnorm_bwd(x1d, x2d, dyd, torch.empty(B * HW, C, dtype=BF, device="cuda"), stats, bstats, gamma=gd, beta=bd, dres=drd, **kw)
+    close(dx, dxr, tol=2e-2, what="groupnorm bwd")
+
+
+@pytest.mark.parametrize("M,C", [(77, 768), (1000, 320), (256, 1280), (64, 2048)])
+def test_layernorm_fwd_bwd(ops, M, C):
+    g = torch.Generator().manual_seed(M + C)
+    x = rnd(M, C, g=g) + 0.3
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    dy, dres = rnd(M, C, g=g), rnd(M, C, g=g)
+    yr = E.layernorm_fwd(x, torch.empty(M, C, dtype=BF), None, gamma=gamma, beta=beta)
+    dxr = E.layernorm_bwd(x, dy, torch.empty(M, C, dtype=BF), None, gamma=gamma, dres=dres)
+    xd, gd, bd, dyd, drd = dev(x, gamma, beta, dy, dres)
+    stats = torch.zeros(M * 2, device="cuda")
+    close(ops.layernorm_fwd(xd, torch.empty(M, C, dtype=BF, device="cuda"), stats, gamma=gd, beta=bd), yr, what="ln fwd")
+    close(ops.layernorm_bwd(xd, dyd, torch.empty(M, C, dtype=BF, device="cuda"), stats, gamma=gd, dres=drd), dxr, tol=2e-2, what="ln bwd")
+
+
+def test_elementwise_family(ops):
+    g = torch.Generator().manual_seed(77)
+    M, Ch = 300, 640
+    inp, dout = rnd(M, 2 * Ch, g=g), rnd(M, Ch, g=g)
+    close(ops.geglu_fwd(inp.cuda(), torch.empty(M, Ch, dtype=BF, device="cuda")), E.geglu_fwd(inp, torch.empty(M, Ch, dtype=BF)), what="geglu fwd")
+    close(ops.geglu_bwd(inp.cuda(), dout.cuda(), torch.empty(M, 2 * Ch, dtype=BF, device="cuda")),
+          E.geglu_bwd(inp, dout, torch.empty(M, 2 * Ch, dtype=BF)), what="geglu bwd")
+    x, dy = rnd(64, 1280, g=g, scale=2.0), rnd(64, 1280, g=g)
+    for op in range(7):
+        need_dy = op in (E.MAP_DSILU, E.MAP_ADD, E.MAP_DGELU, E.MAP_DQGELU)
+        ref = E.map_bf16(op, x, dy if need_dy else None, torch.empty_like(x))
+        got = ops.map_bf16(op, x.cuda(), dy.cuda() if need_dy else None, torch.empty_like(x).cuda())
+        close(got, ref, what=f"map op {op}")
+    t = torch.tensor([0.0, 10.0, 999.0, 1024.0])
+    close(ops.timestep_embedding(t.cuda(), torch.empty(4, 320, dtype=BF, device="cuda")), E.timestep_embedding(t, torch.empty(4, 320, dtype=BF)),
+          tol=1e-2, what="timestep embedding")
+    a, b = rnd(200, 128, g=g), rnd(200, 192, g=g)
+    close(ops.add2d(a.cuda(), b.cuda()[:, 64:], torch.empty(200, 128, dtype=BF, device="cuda")), E.add2d(a, b[:, 64:], torch.empty(200, 128, dtype=BF)), what="add2d")
+    up = rnd(2 * 16 * 16, 64, g=g)
+    close(ops.sum2x2(up.cuda(), torch.empty(2 * 8 * 8, 64, dtype=BF, device="cuda"), B=2, H=8, W=8), E.sum2x2(up, torch.empty(128, 64, dtype=BF), B=2, H=8, W=8), what="sum2x2")
+    xs = rnd(3 * 100, 128, g=g)
+    close(ops.colsum(xs.cuda(), torch.empty(3, 128, device="cuda"), B=3, R=100), E.colsum(xs, torch.empty(3, 128), B=3, R=100), tol=2e-3, what="colsum")
+
+
+@pytest.mark.parametrize("B,gamma,vpred", [(1, 5.0, False), (4, 5.0, False), (3, 0.0, False), (2, 5.0, True)])
+def test_add_noise_and_masked_mse(ops, B, gamma, vpred):
+    g = torch.Generator().manual_seed(B)
+    h = 16
+    from oracle import loss_ref as L
+    acp = L.ddpm_alphas_cumprod()
+    x0, noise = torch.randn(B, 4, h, h, generator=g) * 0.13, torch.randn(B, 4, h, h, generator=g)
+    mask = (torch.rand(B, 1, h, h, generator=g) * 0.95 + 0.05).repeat(1, 4, 1, 1).contiguous()
+    t = torch.tensor([10, 900, 0, 999][:B])
+    noisy_ref = L.add_noise(acp, x0, noise, t)
+    out = torch.empty(B * h * h, 64, dtype=BF, device="cuda")
+    noisy = torch.empty(B, 4, h, h, device="cuda")
+    ops.add_noise_nhwc(x0.cuda(), noise.cuda(), t.cuda(), acp.cuda(), out, noisy)
+    close(noisy, noisy_ref, tol=1e-5, what="add_noise nchw")
+    close(out[:, :4], noisy_ref.permute(0, 2, 3, 1).reshape(-1, 4), tol=1e-2, what="add_noise nhwc")
+    assert float(out[:, 4:].abs().max()) == 0.0
+    pred = torch.randn(B * h * h, 4, generator=g)
+    loss_ref = L.diffusion_loss(pred.reshape(B, h, h, 4).permute(0, 3, 1, 2), noise, noisy_ref, mask, acp, t, snr_gamma=gamma,
+                                prediction_type="v_prediction" if vpred else "epsilon")
+    lo_e, dp_e = torch.zeros(1), torch.zeros(B * h * h, 64, dtype=BF)
+    E.masked_mse_fwd_bwd(pred, noise, noisy_ref, mask, t, acp, None, lo_e, dp_e, snr_gamma=gamma, v_prediction=vpred)
+    sums, lo, dp = torch.zeros(2 * B, device="cuda"), torch.zeros(1, device="cuda"), torch.empty(B * h * h, 64, dtype=BF, device="cuda")
+    ops.masked_mse_fwd_bwd(pred.cuda(), noise.cuda(), noisy, mask.cuda(), t.cuda(), acp.cuda(), sums, lo, dp, snr_gamma=gamma, v_prediction=vpred)
+    close(lo, loss_ref.reshape(1), tol=1e-5, what="masked mse loss vs oracle")
+    close(dp, dp_e, tol=1e-2, what="masked mse grad")
+
+
+def test_adamw_and_shadows(ops):
+    g = torch.Generator().manual_seed(9)
+    n = 100_003
+    p, gr = torch.randn(n, generator=g) * 0.1, torch.randn(n, generator=g) * 0.01
+    m, v = torch.zeros(n), torch.zeros(n)
+    pd, gd, md, vd = dev(p.clone(), gr, m.clone(), v.clone())
+    l1 = torch.zeros(1, device="cuda")
+    hyper = torch.zeros(16)
+    for step in (1, 2, 3):
+        hyper[:9] = torch.tensor([1e-3, 0.9, 0.999, 1e-8, 0.004, 1 - 0.9 ** step, 1 - 0.999 ** step, 0.03 / n, 1.0])
+        E.adamw_fused(p, gr, m, v, hyper)
+        ops.adamw_fused(pd, gd, md, vd, hyper.cuda(), l1)
+    close(pd, p, tol=1e-5, what="adamw params")
+    close(vd, v, tol=1e-5, what="adamw v")
+    close(l1, p.abs().sum().reshape(1), tol=2e-2, what="l1 sum (of pre-step params)")
+    arena = torch.randn(5000, generator=g)
+    ent_c, ent_g = [], []
+    specs = [(0, 4, 300, 300), (1200, 70, 4, 4), (1480 + 3 * 64, 8, 64, 9 * 64)]
+    ad = arena.cuda()
+    for (off, rows, cols, sld) in specs:
+        dc, dtc = torch.zeros(max(rows, 16), cols, dtype=BF), torch.zeros(cols, 128, dtype=BF)
+        ent_c.append((off, rows, cols, sld, dc, dtc[:, :96]))
+        dg, dtg = dc.cuda(), dtc.cuda()
+        ent_g.append((off, rows, cols, sld, dg, dtg[:, :96]))
+    E.ShadowPlan(ent_c, "cpu").run(arena)
+    ops.ShadowPlan(ent_g, torch.device("cuda")).run(ad)
+    for c_, g_ in zip(ent_c, ent_g):
+        assert torch.equal(g_[4].cpu(), c_[4]) and torch.equal(g_[5].cpu(), c_[5])
