@@ -1,0 +1,212 @@
+"""Headline benchmark: training images/sec, SDXL 1024x1024 (latent 128x128), rank-16 LoRA, batch 1 per GPU,
+job-parallel over N GPUs (BASELINE.json metric; reference loop /root/reference main.py:263-382).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: launched by torch.distributed.run, one rank per GPU; ranks are INDEPENDENT training jobs - the
+   hyper-parameter-sweep workload of scripts/create_hyperparam_sweep.py - so there is no data-path collective;
+   RCCL is only used for the timing barrier and the max-over-ranks reduction.)
+
+A "step" = one full optimisation step on one synthetic batch, inputs resident in HBM: DDPM add-noise, UNet+LoRA
+forward, masked/min-SNR MSE, backward to every LoRA A/B and to the text conditioning, fused AdamW(+L1), bf16 shadow
+refresh - one hipGraph replay.  Synthetic data / random-init weights of the exact architecture (no network here).
+
+Prints ONE JSON line.  roofline: the step is a dense contraction -> MFMA bound; achieved = algorithmic FLOPs of one
+step (2 x forward census, SURVEY.md 8d: 13.66 TFLOP for this config) / measured step time (HIP events on the stream
+the graph is replayed on); peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md).  cpu_baseline: the fp32 oracle
+(oracle/, a port of the reference path) timed on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_DENSE = 2.5e15
+
+
+def make_state(cfg, device, seed):
+    """Random-init weights of the exact architecture, generated directly in HBM."""
+    from sd_lora_trainer_amd import topology
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for n, shp in topology.param_shapes(cfg).items():
+        t = torch.randn(shp, generator=g, device=device, dtype=torch.float32)
+        if len(shp) >= 2:
+            t *= 1.0 / math.sqrt(math.prod(shp[1:]))
+        else:
+            t *= 0.02
+            if n.endswith(".weight"):   # norm gains
+                t += 1.0
+        sd[n] = t
+    return sd
+
+
+def lr_at(step, max_steps, unet_lr=1e-3, base=5e-5):
+    """LoRA learning-rate schedule of the reference (main.py:236-240, 268-291; warm-up = max_train_steps)."""
+    return base * (unet_lr / base) ** (step / max_steps)
+
+
+def cpu_baseline(version, rank, sample_hw):
+    """fp32 oracle (CPU port of the reference path) fwd+bwd on a bounded sample; returns dict for the JSON line."""
+    from oracle import loss_ref as L
+    from oracle import unet_ref as U
+    from sd_lora_trainer_amd import topology
+    cfg = U.CONFIGS[version]
+    torch.manual_seed(0)
+    sd = U.init_unet_state(cfg, seed=0)
+    lora = U.init_lora(cfg, rank, seed=1, b_std=0.01)
+    params = []
+    lg = {}
+    for k, (A, Bm) in lora.items():
+        A.requires_grad_(True), Bm.requires_grad_(True)
+        lg[k] = (A, Bm)
+        params += [A, Bm]
+    h = sample_hw
+    g = torch.Generator().manual_seed(1)
+    latent = torch.randn(1, 4, h, h, generator=g) * cfg["scaling_factor"]
+    noise = torch.randn(1, 4, h, h, generator=g)
+    mask = torch.rand(1, 1, h, h, generator=g).repeat(1, 4, 1, 1) * 0.95 + 0.05
+    t = torch.tensor([500])
+    ctx = torch.randn(1, 77, cfg["cross_dim"], generator=g).requires_grad_(True)
+    add = None
+    if cfg["addition"]:
+        add = {"text_embeds": torch.randn(1, 1280, generator=g), "time_ids": torch.tensor([[1024., 1024, 0, 0, 8. * h, 8. * h]])}
+    acp = L.ddpm_alphas_cumprod()
+    t0 = time.time()
+    noisy = L.add_noise(acp, latent, noise, t)
+    pred = U.unet_forward(cfg, sd, noisy, t, ctx, add, lora=lg)
+    loss = L.diffusion_loss(pred, noise, noisy, mask, acp, t, snr_gamma=5.0)
+    torch.autograd.grad(loss, params + [ctx])
+    dt = time.time() - t0
+    f_sample = 2 * topology.fwd_flops(topology.CONFIGS[version], 1, h, h, rank)["total"]
+    return dt, f_sample
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="sdxl", choices=["sdxl", "sd15", "tinyxl", "tiny15"])
+    ap.add_argument("--res", type=int, default=0, help="image resolution (default 1024 for sdxl, 512 for sd15)")
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--rank", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+
+    import sd_lora_trainer_amd.step as S
+    import sd_lora_trainer_amd.unet as M
+    from sd_lora_trainer_amd import topology
+
+    version = args.config
+    cfg = topology.CONFIGS[version]
+    res = args.res or (1024 if "xl" in version else 512)
+    B = args.batch or (1 if "xl" in version else 4)
+    h = res // 8
+    rt = M.Runtime(device, B)
+    sd = make_state(cfg, device, seed=rank)        # every rank = its own independent job
+    unet = M.UNet(rt, cfg, sd, lora_rank=args.rank)
+    del sd
+    torch.cuda.empty_cache()
+    g = torch.Generator(device=device).manual_seed(100 + rank)
+    arena = unet.arena
+    for e in arena.entries:   # peft "gaussian" init: A ~ N(0, 1/r), B = 0 at step 0 (optimizer.py:89)
+        e["A"].copy_(torch.randn(e["A"].shape, generator=g, device=device) / args.rank)
+        e["B"].zero_()
+    arena.refresh_shadows()
+    ts = S.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, l1_penalty=0.03, weight_decay=0.004)
+    rn = lambda *s: torch.randn(*s, generator=g, device=device)  # noqa: E731
+    latent = rn(B, 4, h, h) * cfg["scaling_factor"]
+    noise = rn(B, 4, h, h)
+    mask = (torch.rand(B, 1, h, h, generator=g, device=device) * 0.95 + 0.05).repeat(1, 4, 1, 1).contiguous()
+    timesteps = torch.randint(0, 1000, (B,), generator=g, device=device)
+    ctx = rn(B, 77, cfg["cross_dim"])
+    pooled = tid = None
+    if cfg["addition"]:
+        pooled = rn(B, cfg["proj_class_in"] - 6 * cfg["addition_time_embed_dim"])
+        tid = torch.tensor([[1024., 1024, 0, 0, float(res), float(res)]] * B, device=device)
+    ts.set_batch(latent, noise, timesteps, mask, ctx, pooled, tid)
+    if not args.no_graph:
+        ts.capture(warmup=2)
+    total = args.warmup + args.steps
+    for i in range(args.warmup):
+        ts.run(lr_at(i, total))
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        ts.run(lr_at(args.warmup + i, total))
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt)
+    loss = ts.total_loss()
+    assert math.isfinite(loss), "non-finite loss in the timed region"
+
+    if rank == 0:
+        f_step = 2.0 * topology.fwd_flops(cfg, B, h, h, args.rank)["total"]
+        t_step = elapsed / args.steps
+        achieved = f_step / (ev_ms * 1e-3 / args.steps)
+        out = {
+            "metric": "training images/sec, SDXL 1024px rank-16 LoRA, 1/2/4/8 GPU (job-parallel)",
+            "value": world * B * args.steps / elapsed,
+            "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": t_step * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{version} {res}x{res} LoRA rank {args.rank} batch {B}/GPU, UNet fwd+bwd+AdamW(+L1), "
+                                   "text conditioning injected (CLIP/TI path not in this round's step)",
+                       "global_batch": world * B, "parallelism": f"job-parallel x{world} (independent jobs, no collective)",
+                       "lora_params": arena.n, "graph": not args.no_graph, "final_loss": loss},
+            "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_DENSE, "traffic": None,
+                         "note": f"algorithmic {f_step / 1e12:.3f} TFLOP per step (2 x fwd census) / {ev_ms / args.steps:.3f} ms "
+                                 "per hipGraph replay (HIP events on the replay stream)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sample_hw = 64 if "xl" in version or version == "sd15" else h
+            dt, f_sample = cpu_baseline(version, args.rank, sample_hw)
+            scaled = dt * (f_step / B) / f_sample       # seconds per full-size image on this host
+            out["cpu_baseline"] = {"value": 1.0 / scaled, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": f"one fp32 oracle fwd+bwd step at {sample_hw * 8}x{sample_hw * 8} B=1 took {dt:.1f} s "
+                                             f"({f_sample / 1e12:.2f} TFLOP); scaled by the FLOP ratio to the {res}x{res} workload"}
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -330,7 +330,7 @@ def test_adamw_and_shadows(ops):
     close(pd, p, tol=1e-5, what="adamw params")
     close(vd, v, tol=1e-5, what="adamw v")
     close(l1, p.abs().sum().reshape(1), tol=2e-2, what="l1 sum (of pre-step params)")
-    arena = torch.randn(5000, generator=g)
+    arena = torch.randn(8000, generator=g)
     ent_c, ent_g = [], []
     specs = [(0, 4, 300, 300), (1200, 70, 4, 4), (1480 + 3 * 64, 8, 64, 9 * 64)]
     ad = arena.cuda()
