@@ -34,7 +34,11 @@ int sdlt_struct_size(int which); /* 0 gemm, 1 lora_grad_desc, 2 attn, 3 groupnor
  *         stride-2 form (dX of a stride-2 conv).  `zero` = >=128 B of zeros (out-of-image taps).
  * K, K2 multiples of 64; lora_R (padded rank) in {0,16,32,64}; Adown [lora_R,K], Bup [N,lora_R].
  * T_out (optional) receives s*X.Adown^T as bf16 [M,lora_R] (needed by the LoRA weight gradients).
- * tile: 0 = auto, 1 = 128x128, 2 = 64x128, 3 = 64x64 (rows x cols of C per workgroup).
+ * tile: 0 = auto, 1 = 128x128 (8 waves), 2 = 64x128 (8 waves), 3 = 64x64 (4 waves), 4 = 256x128 (8 waves),
+ *       5 = 128x128 (4 waves)   (rows x cols of C per workgroup).
+ * splitk: small-M problems leave most of the 256 CUs idle; the K loop is then split over several workgroups per
+ *         tile whose fp32 partials meet in ws_slab; the last arriver (ws_cnt ticket, agent-scope release/acquire)
+ *         reduces them and runs the epilogue - no extra launch.
  */
 typedef struct sdlt_gemm_params {
   const void* X; int64_t ldx;
@@ -59,6 +63,11 @@ typedef struct sdlt_gemm_params {
   int32_t out_fp32;
   int32_t tile;
   void* Ct; int64_t ldct;     /* optional transposed bf16 copy: Ct[n*ldct + m] */
+  int32_t splitk;             /* 0 = auto, 1 = off, n = split the K loop over n workgroups per tile */
+  int32_t ws_cnt_len;         /* ints in ws_cnt */
+  void* ws_slab; int64_t ws_slab_bytes;   /* split-K scratch: fp32 partial tiles (caller-owned, any contents) */
+  int32_t stages; int32_t pad_; /* LDS ring depth: 0 = auto (deepest that fits), 2 = double buffer (2 workgroups per CU) */
+  int32_t* ws_cnt;            /* split-K arrival counters, zero-initialised ONCE by the caller; kernels re-arm them */
 } sdlt_gemm_params;
 int sdlt_gemm_bf16(const sdlt_gemm_params* p, void* stream);
 

@@ -33,6 +33,7 @@ class GemmParams(C.Structure):
         ("C", vp), ("ldc", i64),
         ("out_fp32", i32), ("tile", i32),
         ("Ct", vp), ("ldct", i64),
+        ("splitk", i32), ("ws_cnt_len", i32), ("ws_slab", vp), ("ws_slab_bytes", i64), ("stages", i32), ("pad_", i32), ("ws_cnt", vp),
     ]
 
 

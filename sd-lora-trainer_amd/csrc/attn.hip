@@ -475,8 +475,8 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
 #define SMEM_DQ(D_) (2 * 64 * ((D_) * 2 + 16) + (D_) * TSTR)
   ATTN_DISPATCH(dp, attn_bwd_dq_kernel, gq, SMEM_DQ)
   if (p.qsplit > 1) {
-    hipMemsetAsync(p.dK32, 0, sizeof(float) * (size_t)p.B * p.Nkp * p.ld32, s);
-    hipMemsetAsync(p.dV32, 0, sizeof(float) * (size_t)p.B * p.Nkp * p.ld32, s);
+    sdlt_zero_async(p.dK32, sizeof(float) * (size_t)p.B * p.Nkp * p.ld32, s);
+    sdlt_zero_async(p.dV32, sizeof(float) * (size_t)p.B * p.Nkp * p.ld32, s);
   }
   dim3 gk(((p.Nk + 63) / 64) * p.qsplit, p.H, p.B);
 #define SMEM_DKV(D_) (2 * 64 * ((D_) * 2 + 16) + 2 * (D_) * TSTR + 512)

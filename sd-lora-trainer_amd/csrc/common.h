@@ -56,6 +56,20 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
                                    (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
 
+// Zero-fill as an ordinary kernel.  hipMemsetAsync captured into a hipGraph (ROCm 7.0 runtime inside the PyTorch wheel)
+// was observed to lose its ordering against the neighbouring kernel nodes on replay (GroupNorm statistics accumulated
+// onto stale sums from the 2nd replay on), so every in-step zeroing goes through a kernel node instead.
+static __global__ void sdlt_zero_kernel(uint32_t* p, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline void sdlt_zero_async(void* p, size_t bytes, hipStream_t s) {
+  size_t n = bytes / 4;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(sdlt_zero_kernel, dim3(blocks), dim3(256), 0, s, (uint32_t*)p, n);
+}
+
 void sdlt_set_error(const char* fmt, ...);
 #define SDLT_FAIL(code, ...)      \
   do {                            \

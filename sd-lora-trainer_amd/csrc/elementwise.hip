@@ -335,7 +335,7 @@ extern "C" int sdlt_adamw_fused(float* p, const float* g, float* m, float* v, in
                                 void* stream) {
   if (n <= 0) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_adamw_fused: n=%lld", (long long)n);
   hipStream_t s = (hipStream_t)stream;
-  if (l1_sum) hipMemsetAsync(l1_sum, 0, sizeof(float), s);
+  if (l1_sum) sdlt_zero_async(l1_sum, sizeof(float), s);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, g, m, v, n, hyper, l1_sum);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;

@@ -31,14 +31,19 @@ struct ConvGeom {
   int Hin, Win, Cin, Hout, Wout, stride, ups, flip, tr;
 };
 
-template <int MI, int NI, int MODE, int R16>
-__global__ __launch_bounds__(256) void gemm_kernel(const sdlt_gemm_params p) {
-  constexpr int BM = 2 * MI * 16, BN = 2 * NI * 16;
+// MI x NI 16x16 fragments per wave; waves are laid out 2 (m) x WN (n): WN = 2 -> 256 threads, WN = 4 -> 512 threads
+// (two waves per SIMD: the second half of the waves computes first and issues its DMA afterwards, so one wave's DMA
+// issue stalls overlap the other's MFMAs on every SIMD).
+template <int MI, int NI, int WN, int MODE, int R16, int NSTAGE>
+__global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p) {
+  constexpr int NW = 2 * WN, NTHR = NW * 64;
+  constexpr int BM = 2 * MI * 16, BN = WN * NI * 16;
   constexpr int XT = BM * ROW_BYTES, WT = BN * ROW_BYTES, AT = (R16 ? R16 * 16 : 0) * ROW_BYTES;
   constexpr int STAGE = XT + WT + AT;
+  constexpr int S = NSTAGE;                        // LDS ring depth: S-1 K-steps of DMA in flight under the MFMAs
   constexpr int TROW = R16 ? (R16 * 16 + 4) : 4;  // bf16 elements per Tsh row (+4 pad)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* tsh = smem + 2 * STAGE;
+  char* tsh = smem + S * STAGE;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
@@ -46,21 +51,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdlt_gemm_params p) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   int bid = blockIdx.x;
   {
-    const int nwg = nbm * nbn, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int nwg = nbm * nbn * (p.splitk > 1 ? p.splitk : 1), q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int bn = bid % nbn, bm = bid / nbn;
+  const int splitk = p.splitk > 1 ? p.splitk : 1;
+  const int tile_id = bid / splitk, split = bid - tile_id * splitk;   // splits of one tile are neighbours -> same XCD
+  const int bn = tile_id % nbn, bm = tile_id / nbn;
   const int m0 = bm * BM, n0 = bn * BN;
 
   // ---------------- per-lane staging geometry (fixed rows, fixed swizzled chunk) ----------------
   const int srow = lane >> 3;                       // row within an 8-row DMA piece
   const int schunk = (lane & 7) ^ (srow & 7);       // source chunk so that LDS holds chunk^(row&7)
-  constexpr int XI = BM / 32, WI = BN / 32;         // DMA pieces per wave
+  constexpr int XI = BM / 8 / NW, WI = BN / 8 / NW;  // DMA pieces (8 rows x 128 B) per wave
+  static_assert(XI >= 1 && WI >= 1 && XI * 8 * NW == BM && WI * 8 * NW == BN, "tile does not split evenly over the waves");
   const bf16_t* xptr[XI];
   int xb[XI], xh[XI], xw[XI];                       // conv: decoded output pixel (b<0 => row invalid)
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
-    int m = m0 + (wave + 4 * i) * 8 + srow;
+    int m = m0 + (wave + NW * i) * 8 + srow;
     if (MODE == 0) {
       int mc = m < p.M ? m : p.M - 1;
       xptr[i] = (const bf16_t*)p.X + (size_t)mc * p.ldx + schunk * 8;
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdlt_gemm_params p) {
   const bf16_t* wptr[WI];
 #pragma unroll
   for (int i = 0; i < WI; ++i) {
-    int n = n0 + (wave + 4 * i) * 8 + srow;
+    int n = n0 + (wave + NW * i) * 8 + srow;
     int nc = n < p.N ? n : p.N - 1;
     wptr[i] = (const bf16_t*)p.W + (size_t)nc * p.ldw + schunk * 8;
   }
@@ -90,13 +98,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdlt_gemm_params p) {
   if (p.K2 > 0) {
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      int m = m0 + (wave + 4 * i) * 8 + srow;
+      int m = m0 + (wave + NW * i) * 8 + srow;
       int mc = m < p.M ? m : p.M - 1;
       x2ptr[i] = (const bf16_t*)p.X2 + (size_t)mc * p.ldx2 + schunk * 8;
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-      int n = n0 + (wave + 4 * i) * 8 + srow;
+      int n = n0 + (wave + NW * i) * 8 + srow;
       int nc = n < p.N ? n : p.N - 1;
       w2ptr[i] = (const bf16_t*)p.W2 + (size_t)nc * p.ldw2 + schunk * 8;
     }
@@ -109,6 +117,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdlt_gemm_params p) {
   }
 
   const int nk1 = p.K / BK, nk2 = p.K2 / BK, nk = nk1 + nk2;
+  constexpr int AI = R16 ? ((2 * R16 + NW - 1) / NW) : 0;   // LoRA-down DMA instructions per wave and stage
+  constexpr int LPS = XI + WI + AI;                         // DMA instructions per wave and stage
 
   auto stage = [&](int kt, int buf) {
     char* base = smem + buf * STAGE;
@@ -116,7 +126,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdlt_gemm_params p) {
       const int k0 = kt * BK;
       if (MODE == 0) {
 #pragma unroll
-        for (int i = 0; i < XI; ++i) glds16(xptr[i] + k0, base + (wave + 4 * i) * 1024);
+        for (int i = 0; i < XI; ++i) glds16(xptr[i] + k0, base + (wave + NW * i) * 1024);
       } else {
         const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
         const int dy = tap / 3, dx = tap - dy * 3;
@@ -139,25 +149,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdlt_gemm_params p) {
             }
             if (ok) src = (const bf16_t*)p.X + ((size_t)(xb[i] * p.Hin + hi) * p.Win + wi) * p.ldx + ci0 + schunk * 8;
           }
-          glds16(src, base + (wave + 4 * i) * 1024);
+          glds16(src, base + (wave + NW * i) * 1024);
         }
       }
 #pragma unroll
-      for (int i = 0; i < WI; ++i) glds16(wptr[i] + k0, base + XT + (wave + 4 * i) * 1024);
+      for (int i = 0; i < WI; ++i) glds16(wptr[i] + k0, base + XT + (wave + NW * i) * 1024);
       if (R16) {
+        // every wave issues the SAME number of DMA instructions per stage (the counted vmcnt below relies on it);
+        // when there are fewer pieces than waves some waves re-load a piece - identical bytes to identical LDS addresses.
 #pragma unroll
-        for (int j = 0; j < (R16 * 2 + 3) / 4; ++j) {
-          int piece = wave + 4 * j;
-          if (piece < R16 * 2)
-            glds16(aptr + (size_t)(piece * 8 + srow) * p.ld_adown + k0, base + XT + WT + piece * 1024);
+        for (int j = 0; j < AI; ++j) {
+          int piece = (wave + NW * j) % (R16 * 2);
+          glds16(aptr + (size_t)(piece * 8 + srow) * p.ld_adown + k0, base + XT + WT + piece * 1024);
         }
       }
     } else {
       const int k0 = (kt - nk1) * BK;
 #pragma unroll
-      for (int i = 0; i < XI; ++i) glds16(x2ptr[i] + k0, base + (wave + 4 * i) * 1024);
+      for (int i = 0; i < XI; ++i) glds16(x2ptr[i] + k0, base + (wave + NW * i) * 1024);
 #pragma unroll
-      for (int i = 0; i < WI; ++i) glds16(w2ptr[i] + k0, base + XT + (wave + 4 * i) * 1024);
+      for (int i = 0; i < WI; ++i) glds16(w2ptr[i] + k0, base + XT + (wave + NW * i) * 1024);
     }
   };
 
@@ -167,7 +178,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdlt_gemm_params p) {
   for (int a = 0; a < NI; ++a)
 #pragma unroll
     for (int b = 0; b < MI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  constexpr int TMI = MI / 2;  // T fragments per wave (the two wn waves split the wave-row's mi)
+  constexpr int TMI = MI >= WN ? MI / WN : 1;  // T fragments per wave (the WN waves of a wave-row split its MI fragments)
+  const bool t_active = wn * TMI < MI;
   f32x4 tacc[R16 ? R16 : 1][TMI];
 #pragma unroll
   for (int a = 0; a < (R16 ? R16 : 1); ++a)
@@ -179,12 +191,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdlt_gemm_params p) {
   const int foff0 = frow * ROW_BYTES + (((0 * 4 + fk) ^ (frow & 7)) << 4);
   const int foff1 = frow * ROW_BYTES + (((1 * 4 + fk) ^ (frow & 7)) << 4);
 
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-    const char* base = smem + (kt & 1) * STAGE;
+  // this workgroup's share of the K steps (split-K: contiguous ranges of the combined segment-1 + segment-2 steps)
+  const int kbeg = (int)((long)nk * split / splitk), kend = (int)((long)nk * (split + 1) / splitk);
+  // prologue: S-1 stages in flight
+#pragma unroll
+  for (int t = 0; t < S - 1; ++t)
+    if (kbeg + t < kend) stage(kbeg + t, t);
+  for (int kt = kbeg; kt < kend; ++kt) {
+    // wait until stage kt has landed: this wave has issued stages up to min(kend-1, kt+S-2); each is LPS instructions
+    {
+      const int ahead = (kend - 1 < kt + S - 2 ? kend - 1 : kt + S - 2) - kt;
+      if (S >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+      else if (S >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();   // stage kt visible to all waves; everyone is done reading stage kt-1's buffer
+    asm volatile("" ::: "memory");
+    const bool early = WN == 2 || wave < NW / 2;
+    if (early && kt + S - 1 < kend) stage(kt + S - 1, (kt - kbeg + S - 1) % S);
+    const char* base = smem + ((kt - kbeg) % S) * STAGE;
     const char* xs = base + (wm * MI * 16) * ROW_BYTES;
     const char* ws = base + XT + (wn * NI * 16) * ROW_BYTES;
     const char* as = base + XT + WT;
@@ -203,7 +228,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdlt_gemm_params p) {
         for (int b = 0; b < MI; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
       if (R16) {
-        if (lora_step) {
+        if (lora_step && t_active) {
 #pragma unroll
           for (int j = 0; j < R16; ++j) {
             bf16x8 af = *(const bf16x8*)(as + j * 16 * ROW_BYTES + fo);
@@ -217,6 +242,65 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdlt_gemm_params p) {
         }
       }
     }
+    if (!early && kt + S - 1 < kend) stage(kt + S - 1, (kt - kbeg + S - 1) % S);
+  }
+
+  // ---------------- split-K: publish the partial tile, last arriver reduces (agent-scope release/acquire) ----------------
+  if (splitk > 1) {
+    constexpr int NACC = NI * MI, NT = R16 ? R16 * TMI : 0;
+    constexpr size_t SLAB = (size_t)(NACC + NT) * NTHR;    // float4 per (tile, split)
+    f32x4* slab = (f32x4*)p.ws_slab + ((size_t)tile_id * splitk + split) * SLAB;
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+      for (int b = 0; b < MI; ++b) slab[(a * MI + b) * NTHR + tid] = acc[a][b];
+    if (R16) {
+#pragma unroll
+      for (int j = 0; j < R16; ++j)
+#pragma unroll
+        for (int b = 0; b < TMI; ++b) slab[(NACC + j * TMI + b) * NTHR + tid] = tacc[j][b];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // also: every wave is done with the staging LDS, smem[0] can carry the ticket
+    int* cnt = p.ws_cnt + tile_id;
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      *(volatile int*)smem = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const int ticket = *(volatile int*)smem;
+    if (ticket != splitk - 1) return;      // not the last arriver of this tile
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch / graph replay
+    }
+    __syncthreads();
+    // fixed summation order 0..splitk-1 (own partial re-read from its slab) -> bitwise reproducible results
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+      for (int b = 0; b < MI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (R16) {
+#pragma unroll
+      for (int j = 0; j < R16; ++j)
+#pragma unroll
+        for (int b = 0; b < TMI; ++b) tacc[j][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int sp = 0; sp < splitk; ++sp) {
+      const f32x4* o = (const f32x4*)p.ws_slab + ((size_t)tile_id * splitk + sp) * SLAB;
+#pragma unroll
+      for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b) acc[a][b] += o[(a * MI + b) * NTHR + tid];
+      if (R16) {
+#pragma unroll
+        for (int j = 0; j < R16; ++j)
+#pragma unroll
+          for (int b = 0; b < TMI; ++b) tacc[j][b] += o[(NACC + j * TMI + b) * NTHR + tid];
+      }
+    }
+    __syncthreads();
   }
 
   // ---------------- fused LoRA-up ----------------
@@ -226,6 +310,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdlt_gemm_params p) {
     for (int j = 0; j < R16; ++j)
 #pragma unroll
       for (int b = 0; b < TMI; ++b) {
+        if (!t_active) continue;
         int ml = wm * MI * 16 + (wn * TMI + b) * 16 + frow;
         uint2 v;
         v.x = pack2bf(tacc[j][b][0] * p.lora_scale, tacc[j][b][1] * p.lora_scale);
@@ -236,7 +321,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdlt_gemm_params p) {
     if (p.T_out != nullptr && bn == 0) {
       // [BM rows][R] bf16 -> global, 8 B per lane
       constexpr int CH = R16 * 4;  // 8-byte chunks per row
-      for (int c = tid; c < BM * CH; c += 256) {
+      for (int c = tid; c < BM * CH; c += NTHR) {
         int ml = c / CH, cc = c - ml * CH;
         int m = m0 + ml;
         if (m < p.M) *(uint2*)((bf16_t*)p.T_out + (size_t)m * p.ld_t + cc * 4) = *(const uint2*)(tsh + ((size_t)ml * TROW + cc * 4) * 2);
@@ -319,37 +404,88 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdlt_gemm_params p) {
   }
 }
 
-template <int MI, int NI, int MODE, int R16>
+template <int MI, int NI, int WN, int MODE, int R16, int NSREQ>
 int launch(const sdlt_gemm_params& p, hipStream_t stream) {
-  constexpr int BM = 2 * MI * 16, BN = 2 * NI * 16;
+  constexpr int NTHR = 128 * WN;
+  constexpr int BM = 2 * MI * 16, BN = WN * NI * 16;
   constexpr int STAGE = (BM + BN + R16 * 16) * ROW_BYTES;
   constexpr int TSH = R16 ? BM * (R16 * 16 + 4) * 2 : 0;
-  const int smem = 2 * STAGE + TSH;
+  // LDS ring depth: NSREQ == 2 keeps the footprint small (several workgroups per CU overlap each other);
+  // otherwise as deep as 160 KB allows, up to 4.
+  constexpr int NS = NSREQ == 2 ? 2 : ((4 * STAGE + TSH <= 160 * 1024) ? 4 : ((3 * STAGE + TSH <= 160 * 1024) ? 3 : 2));
+  static_assert(NS * STAGE + TSH <= 160 * 1024, "LDS budget");
+  const int smem = NS * STAGE + TSH;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_kernel<MI, NI, MODE, R16>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute((const void*)gemm_kernel<MI, NI, WN, MODE, R16, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_kernel<MI, NI, MODE, R16>), dim3(nbm * nbn), dim3(256), smem, stream, p);
+  const int splitk = p.splitk > 1 ? p.splitk : 1;
+  if (splitk > 1) {
+    constexpr int TMI = MI >= WN ? MI / WN : 1;
+    const size_t slab_bytes = (size_t)(NI * MI + (R16 ? R16 * TMI : 0)) * NTHR * 16;
+    if (!p.ws_slab || !p.ws_cnt || (size_t)nbm * nbn * splitk * slab_bytes > (size_t)p.ws_slab_bytes || nbm * nbn > p.ws_cnt_len)
+      SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: split-K workspace too small (%d tiles x %d splits x %zu B)", nbm * nbn, splitk, slab_bytes);
+  }
+  hipLaunchKernelGGL((gemm_kernel<MI, NI, WN, MODE, R16, NS>), dim3(nbm * nbn * splitk), dim3(NTHR), smem, stream, p);
   return SDLT_OK;
 }
 
-template <int MODE, int R16>
-int dispatch_tile(const sdlt_gemm_params& p, hipStream_t s) {
-  int tile = p.tile;
-  if (tile == 0) {
-    // heuristic: largest tile that still gives >= ~1.5 waves of workgroups over the 256 CUs
-    auto nwg = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
-    if (nwg(128, 128) >= 384) tile = 1;
-    else if (nwg(64, 128) >= 320) tile = 2;
-    else tile = 3;
-  }
+// tile ids: 1 = 128x128 (8 waves), 2 = 64x128 (8 waves), 3 = 64x64 (4 waves), 4 = 256x128 (8 waves), 5 = 128x128 (4 waves)
+void tile_dims(int tile, int& bm, int& bn) {
   switch (tile) {
-    case 1: return launch<4, 4, MODE, R16>(p, s);
-    case 2: return launch<2, 4, MODE, R16>(p, s);
-    case 3: return launch<2, 2, MODE, R16>(p, s);
+    case 1: case 5: bm = 128; bn = 128; break;
+    case 2: bm = 64; bn = 128; break;
+    case 4: bm = 256; bn = 128; break;
+    default: bm = 64; bn = 64; break;
   }
+}
+
+template <int MODE, int R16>
+int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
+  sdlt_gemm_params p = pin;
+  const int ktot = p.K + p.K2;
+  if (p.tile == 0) {
+    // Shape heuristics from the tools/gemm_probe.py sweep on MI355X ("GEMM tile selection"):
+    //  * plenty of 128x128 tiles: 8-wave 128x128; with >= 2 tiles per CU use the shallow ring so 2 workgroups share a CU
+    //  * 160..511 tiles: short K -> 64x64 tiles, 2+ workgroups per CU; long K -> 128x128 with the deep ring
+    //  * fewer: 64x128 (8 waves) when K is short, otherwise 128x128 + split-K
+    const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (p.M <= 64) p.tile = p.N > 64 ? 2 : 3;
+    else if (p.N <= 64) p.tile = 3;
+    else if (t128 >= 512) { p.tile = 1; if (!p.stages) p.stages = 2; }
+    else if (t128 >= 160) {
+      if (ktot <= 2560) { p.tile = 3; if (!p.stages) p.stages = 2; }
+      else p.tile = 1;
+    } else if (ktot <= 2560) { p.tile = 2; if (!p.splitk) p.splitk = 1; }
+    else p.tile = 1;
+  }
+  int bm, bn;
+  tile_dims(p.tile, bm, bn);
+  if (p.splitk == 0) {
+    // Split K until ~one workgroup per CU exists, keeping >= 8 K-steps per split (the fenced hand-off costs a few us).
+    const long tiles = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+    const int nk = ktot / BK;
+    int sk = 1;
+    if (p.ws_slab && p.ws_cnt && tiles <= 96) {
+      sk = (int)((256 + tiles / 2) / tiles);
+      if (sk > nk / 8) sk = nk / 8;
+      if (sk > 16) sk = 16;
+      if (sk < 1) sk = 1;
+    }
+    p.splitk = sk;
+  }
+#define SDLT_TILE_CASES(NSV)                                         \
+  switch (p.tile) {                                                  \
+    case 1: return launch<4, 2, 4, MODE, R16, NSV>(p, s);            \
+    case 2: return launch<2, 2, 4, MODE, R16, NSV>(p, s);            \
+    case 3: return launch<2, 2, 2, MODE, R16, NSV>(p, s);            \
+    case 4: return launch<8, 2, 4, MODE, R16, NSV>(p, s);            \
+    case 5: return launch<4, 4, 2, MODE, R16, NSV>(p, s);            \
+  }
+  if (p.stages == 2) { SDLT_TILE_CASES(2) } else { SDLT_TILE_CASES(4) }
+#undef SDLT_TILE_CASES
   SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: tile id %d", p.tile);
 }
 

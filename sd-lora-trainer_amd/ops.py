@@ -43,6 +43,19 @@ def zero_page(device):
     return z
 
 
+_workspaces = {}
+
+
+def splitk_workspace(device):
+    """Per-device split-K scratch of sdlt_gemm_bf16: fp32 partial-tile slabs + zero-initialised arrival counters.
+    One workspace per device is enough while every GEMM of a process is enqueued on one stream."""
+    ws = _workspaces.get(device)
+    if ws is None:
+        ws = (torch.empty(96 << 20, dtype=torch.uint8, device=device), torch.zeros(4096, dtype=torch.int32, device=device))
+        _workspaces[device] = ws
+    return ws
+
+
 class ConvGeom:
     """Geometry of an implicit 3x3 convolution over an NHWC activation (sdlt_gemm_bf16 mode 1)."""
     __slots__ = ("B", "Hin", "Win", "Cin", "Hout", "Wout", "stride", "ups", "flip", "tr")
@@ -53,7 +66,7 @@ class ConvGeom:
 
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
-         residual=None, alpha=1.0, Ct=None, tile=0):
+         residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0):
     """out[M,N] = alpha*(X.W^T [+ X2.W2^T] [+ s*(X.Adown^T).Bup^T]) + bias + rowbias[m//rows_per_batch] + residual.
     lora = (Adown [Rp,K], Bup [N,Rp], scale, T_out [M,Rp] or None).  out dtype bf16 or fp32.  Ct: optional
     transposed bf16 copy [N, >=M].  conv: ConvGeom -> X is the NHWC activation [B*Hin*Win, Cin]."""
@@ -108,7 +121,9 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
         _chk2(Ct)
         assert Ct.shape[0] == N and Ct.shape[1] >= M
         p.Ct, p.ldct = _p(Ct), _ld(Ct)
-    p.tile = tile
+    p.tile, p.splitk, p.stages = tile, splitk, stages
+    slab, cnt = splitk_workspace(X.device)
+    p.ws_slab, p.ws_slab_bytes, p.ws_cnt, p.ws_cnt_len = _p(slab), slab.numel(), _p(cnt), cnt.numel()
     _lib.check(lib.sdlt_gemm_bf16(C.byref(p), _stream()), "sdlt_gemm_bf16")
     return out
 

@@ -43,7 +43,7 @@ def _conv_apply(X, Wm, g):
 
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
-         residual=None, alpha=1.0, Ct=None, tile=0):
+         residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0):
     acc = X.float() @ W.float().t() if conv is None else _conv_apply(X, W, conv)
     if X2 is not None:
         acc = acc + X2.float() @ W2.float().t()

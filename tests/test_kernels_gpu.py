@@ -41,7 +41,8 @@ def dev(*ts):
 
 # --------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K,tile", [(256, 256, 128, 1), (200, 136, 64, 1), (77, 320, 192, 2), (1000, 77, 128, 3),
-                                        (1, 1280, 320, 0), (4096, 640, 640, 0), (300, 4, 576, 3)])
+                                        (1, 1280, 320, 0), (4096, 640, 640, 0), (300, 4, 576, 3), (700, 300, 256, 4),
+                                        (333, 260, 320, 5)])
 def test_gemm_plain_epilogue(ops, M, N, K, tile):
     g = torch.Generator().manual_seed(M + N + K)
     X, W = rnd(M, K, g=g), rnd(N, K, g=g, scale=1 / math.sqrt(K))
@@ -74,7 +75,9 @@ def test_gemm_strided_views_and_two_segments(ops):
 
 
 @pytest.mark.parametrize("M,N,K,r,tile", [(256, 256, 128, 16, 1), (333, 200, 192, 4, 2), (77, 640, 2048, 16, 3),
-                                          (1024, 1280, 1280, 16, 0), (130, 64, 64, 24, 3), (200, 128, 64, 64, 1)])
+                                          (1024, 1280, 1280, 16, 0), (130, 64, 64, 24, 3), (200, 128, 64, 64, 1),
+                                          (600, 256, 384, 16, 4), (600, 256, 384, 32, 4), (300, 256, 384, 64, 5),
+                                          (300, 256, 384, 40, 4), (300, 256, 384, 16, 2), (300, 256, 384, 64, 2)])
 def test_gemm_fused_lora(ops, M, N, K, r, tile):
     g = torch.Generator().manual_seed(M * 3 + r)
     Rp = 16 if r <= 16 else (32 if r <= 32 else 64)
@@ -94,6 +97,33 @@ def test_gemm_fused_lora(ops, M, N, K, r, tile):
     # the adapter must actually contribute
     base = E.gemm(X, W, torch.empty(M, N, dtype=BF), bias=bias)
     assert float((ref.float() - base.float()).abs().max()) > 0.05
+
+
+@pytest.mark.parametrize("M,N,K,r,tile,splitk", [(256, 256, 1280, 0, 1, 3), (1024, 1280, 1280, 16, 0, 0), (1024, 1280, 5120, 0, 0, 0),
+                                                 (77, 640, 2048, 16, 0, 0), (300, 200, 640, 8, 3, 5), (130, 520, 1920, 64, 1, 4)])
+def test_gemm_split_k(ops, M, N, K, r, tile, splitk):
+    """split-K path: fp32 partial tiles meet in the workspace, last arriver reduces; run twice (counter re-arm)."""
+    g = torch.Generator().manual_seed(M + K + r)
+    X, W = rnd(M, K, g=g), rnd(N, K, g=g, scale=1 / math.sqrt(K))
+    bias, R = torch.randn(N, generator=g), rnd(M, N, g=g)
+    lora_c = lora_g = None
+    Tref = T = None
+    if r:
+        Rp = 16 if r <= 16 else (32 if r <= 32 else 64)
+        A = torch.zeros(Rp, K, dtype=BF)
+        A[:r] = rnd(r, K, g=g, scale=1 / math.sqrt(K))
+        Bu = torch.zeros(N, Rp, dtype=BF)
+        Bu[:, :r] = rnd(N, r, g=g, scale=0.3)
+        Tref, T = torch.empty(M, Rp, dtype=BF), torch.zeros(M, Rp, dtype=BF, device="cuda")
+        lora_c, lora_g = (A, Bu, 1.0, Tref), (A.cuda(), Bu.cuda(), 1.0, T)
+    ref = E.gemm(X, W, torch.empty(M, N, dtype=BF), lora=lora_c, bias=bias, residual=R)
+    Xd, Wd, bd, Rd = dev(X, W, bias, R)
+    for rep in range(3):
+        out = ops.gemm(Xd, Wd, torch.zeros(M, N, dtype=BF, device="cuda"), lora=lora_g, bias=bd, residual=Rd, tile=tile, splitk=splitk,
+                       stages=2 if rep == 2 else 0)
+        close(out, ref, what=f"split-K gemm rep {rep}")
+        if r:
+            close(T, Tref, what="split-K lora T_out")
 
 
 CONV_CASES = [

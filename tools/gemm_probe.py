@@ -1,0 +1,53 @@
+"""Scratch micro-benchmark: sdlt_gemm_bf16 kernel time vs (tile, splitk) for the SDXL shapes, measured inside a
+captured hipGraph (20 launches per replay) so host launch overhead does not pollute small kernels."""
+import sys, os, math, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sd_lora_trainer_amd import ops
+BF = torch.bfloat16
+
+def bench(M, N, K, tile, splitk, lora=False, conv=None, reps=20, stages=0):
+    X = torch.randn(M if conv is None else conv.B * conv.Hin * conv.Win, K if conv is None else conv.Cin, device="cuda").to(BF)
+    Ws = [torch.randn(N, K, device="cuda").to(BF) for _ in range(4)]   # rotate weights: frozen weights are never L2-hot in the real step
+    out = torch.empty(M, N, device="cuda", dtype=BF)
+    lo = None
+    if lora:
+        lo = (torch.randn(16, K, device="cuda").to(BF), torch.randn(N, 16, device="cuda").to(BF), 1.0, torch.empty(M, 16, device="cuda", dtype=BF))
+    def run():
+        for i in range(reps): ops.gemm(X, Ws[i % 4], out, lora=lo, conv=conv, tile=tile, splitk=splitk, stages=stages)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        run()
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        run()
+    gr.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): gr.replay()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (5 * reps)
+
+if __name__ == "__main__":
+    shapes = [("attn proj C1280", 1024, 1280, 1280, True, None), ("ff1 C1280", 1024, 10240, 1280, False, None), ("ff2 C1280", 1024, 1280, 5120, False, None),
+              ("ff1 bwd C1280", 1024, 1280, 10240, False, None), ("ff2 bwd", 1024, 5120, 1280, False, None),
+              ("attn proj C640", 4096, 640, 640, True, None), ("ff1 C640", 4096, 5120, 640, False, None), ("ff2 C640", 4096, 640, 2560, False, None),
+              ("cross kv C1280", 80, 1280, 2048, True, None), ("cross kv bwd", 80, 2048, 1280, True, None),
+              ("conv C1280 32x32", 1024, 1280, 9 * 1280, False, ops.ConvGeom(1, 32, 32, 1280, 32, 32)),
+              ("conv C640 64x64", 4096, 640, 9 * 640, False, ops.ConvGeom(1, 64, 64, 640, 64, 64)),
+              ("conv C320 128x128", 16384, 320, 9 * 320, False, ops.ConvGeom(1, 128, 128, 320, 128, 128)),
+              ("conv up 2560->1280", 1024, 1280, 9 * 2560, False, ops.ConvGeom(1, 32, 32, 2560, 32, 32)),
+              ("temb M=1", 1, 1280, 1280, False, None)]
+    for (name, M, N, K, lora, conv) in shapes:
+        res = []
+        for tile in (1, 2, 3, 4, 5):
+            for st in (0, 2):
+                try:
+                    us = bench(M, N, K, tile, 1, lora, conv, stages=st)
+                except Exception as e:
+                    continue
+                res.append((us, tile, st))
+        res.sort()
+        auto = bench(M, N, K, 0, 0, lora, conv)
+        fl = 2.0 * M * N * K
+        print(f"{name:22s} M{M} N{N} K{K} lora{int(lora)}: auto {auto:.1f}us ({fl/auto/1e6:.0f} TF) | best " + ", ".join(f"t{t}/st{k}:{u:.1f}" for u, t, k in res[:6]) + f" | worst {res[-1][0]:.1f}")
