@@ -38,25 +38,49 @@ __device__ __forceinline__ bf16x8 ld_frag_global(const bf16_t* p, bool ok) {
 }
 __device__ __forceinline__ int prow(int i, int half) { return ((i >> 2) << 3) + half * 4 + (i & 3); }
 
-// natural tile: dst[row][DP] (row stride NSTR bytes) <- src[(row0+row)*ld + col0 + c], rows >= nrows or c >= d zero-filled
+// Tiles are staged global -> registers -> LDS in two halves so the HBM/L2 latency of tile t+1 hides under the MFMAs
+// of tile t (registers are loaded before the compute phase and written to the other LDS buffer after it).
+// natural tile: [64 rows][DP] (row stride NSTR bytes) <- src[(row0+row)*ld + col0 + c]; rows >= nrows or c >= d read as 0
 template <int DP>
-__device__ __forceinline__ void load_tile_nat(char* dst, const bf16_t* src, int64_t ld, int64_t row0, int nrows, int col0, int d) {
-  constexpr int NSTR = DP * 2 + 16, CH = DP / 8;
-  for (int c = threadIdx.x; c < 64 * CH; c += 256) {
+struct TileRegs { uint4 r[DP / 32]; };
+
+template <int DP>
+__device__ __forceinline__ void gload_nat(TileRegs<DP>& t, const bf16_t* src, int64_t ld, int64_t row0, int nrows, int col0, int d) {
+  constexpr int CH = DP / 8;
+#pragma unroll
+  for (int i = 0; i < DP / 32; ++i) {
+    int c = threadIdx.x + 256 * i;
     int row = c / CH, ch = c - row * CH;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < nrows && ch * 8 < d) v = *(const uint4*)(src + (row0 + row) * ld + col0 + ch * 8);
-    *(uint4*)(dst + row * NSTR + ch * 16) = v;
+    t.r[i] = (row < nrows && ch * 8 < d) ? *(const uint4*)(src + (row0 + row) * ld + col0 + ch * 8) : make_uint4(0, 0, 0, 0);
   }
 }
-// transposed tile: dst[dd][64] (row stride TSTR) <- srcT[(col0+dd)*ldT + t0 + t], dd >= d or t >= ntok zero-filled
 template <int DP>
-__device__ __forceinline__ void load_tile_tr(char* dst, const bf16_t* srcT, int64_t ldT, int col0, int d, int64_t t0, int ntok) {
-  for (int c = threadIdx.x; c < DP * 8; c += 256) {
+__device__ __forceinline__ void sstore_nat(const TileRegs<DP>& t, char* dst) {
+  constexpr int NSTR = DP * 2 + 16, CH = DP / 8;
+#pragma unroll
+  for (int i = 0; i < DP / 32; ++i) {
+    int c = threadIdx.x + 256 * i;
+    int row = c / CH, ch = c - row * CH;
+    *(uint4*)(dst + row * NSTR + ch * 16) = t.r[i];
+  }
+}
+// transposed tile: [DP rows dd][64 tokens] (row stride TSTR) <- srcT[(col0+dd)*ldT + t0 + t]; dd >= d or t >= ntok read as 0
+template <int DP>
+__device__ __forceinline__ void gload_tr(TileRegs<DP>& t, const bf16_t* srcT, int64_t ldT, int col0, int d, int64_t t0, int ntok) {
+#pragma unroll
+  for (int i = 0; i < DP / 32; ++i) {
+    int c = threadIdx.x + 256 * i;
     int dd = c >> 3, ch = c & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (dd < d && ch * 8 < ntok) v = *(const uint4*)(srcT + (int64_t)(col0 + dd) * ldT + t0 + ch * 8);
-    *(uint4*)(dst + dd * TSTR + ch * 16) = v;
+    t.r[i] = (dd < d && ch * 8 < ntok) ? *(const uint4*)(srcT + (int64_t)(col0 + dd) * ldT + t0 + ch * 8) : make_uint4(0, 0, 0, 0);
+  }
+}
+template <int DP>
+__device__ __forceinline__ void sstore_tr(const TileRegs<DP>& t, char* dst) {
+#pragma unroll
+  for (int i = 0; i < DP / 32; ++i) {
+    int c = threadIdx.x + 256 * i;
+    int dd = c >> 3, ch = c & 7;
+    *(uint4*)(dst + dd * TSTR + ch * 16) = t.r[i];
   }
 }
 
@@ -65,8 +89,6 @@ template <int DP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const sdlt_attn_params p) {
   constexpr int NSTR = DP * 2 + 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem;
-  char* Vt = smem + 64 * NSTR;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
   const int d = p.d, hc = h * d;
@@ -84,12 +106,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const sdlt_attn_params p)
   const float sl2 = p.scale * LOG2E;
   const int kend = p.causal ? min(p.Nk, q0 + 64) : p.Nk;
 
-  for (int k0 = 0; k0 < kend; k0 += 64) {
-    __syncthreads();
-    const int nk = min(64, p.Nkp - k0);
-    load_tile_nat<DP>(Ks, (const bf16_t*)p.K, p.ldk, (int64_t)b * p.Nkp + k0, nk, hc, d);
-    load_tile_tr<DP>(Vt, (const bf16_t*)p.Vt, p.ldvt, hc, d, (int64_t)b * p.Nkp + k0, nk);
-    __syncthreads();
+  constexpr int FBUF = 64 * NSTR + DP * TSTR;   // one K tile + one V^T tile
+  TileRegs<DP> kr, vr;
+  gload_nat<DP>(kr, (const bf16_t*)p.K, p.ldk, (int64_t)b * p.Nkp, min(64, p.Nkp), hc, d);
+  gload_tr<DP>(vr, (const bf16_t*)p.Vt, p.ldvt, hc, d, (int64_t)b * p.Nkp, min(64, p.Nkp));
+  sstore_nat<DP>(kr, smem);
+  sstore_tr<DP>(vr, smem + 64 * NSTR);
+  __syncthreads();
+  int it = 0;
+  for (int k0 = 0; k0 < kend; k0 += 64, ++it) {
+    const char* Ks = smem + (it & 1) * FBUF;
+    const char* Vt = Ks + 64 * NSTR;
+    const bool more = k0 + 64 < kend;
+    if (more) {   // next tile's loads fly while this tile is computed
+      const int nk = min(64, p.Nkp - (k0 + 64));
+      gload_nat<DP>(kr, (const bf16_t*)p.K, p.ldk, (int64_t)b * p.Nkp + k0 + 64, nk, hc, d);
+      gload_tr<DP>(vr, (const bf16_t*)p.Vt, p.ldvt, hc, d, (int64_t)b * p.Nkp + k0 + 64, nk);
+    }
     f32x4 s[4];
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf) {
@@ -140,6 +173,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const sdlt_attn_params p)
         o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[df], 0, 0, 0);
       }
     }
+    if (more) {
+      char* nb = smem + ((it + 1) & 1) * FBUF;
+      sstore_nat<DP>(kr, nb);
+      sstore_tr<DP>(vr, nb + 64 * NSTR);
+    }
+    __syncthreads();
   }
   lsum += __shfl_xor(lsum, 16, 64);
   lsum += __shfl_xor(lsum, 32, 64);
@@ -190,9 +229,6 @@ template <int DP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const sdlt_attn_params p) {
   constexpr int NSTR = DP * 2 + 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem;
-  char* Vs = Ks + 64 * NSTR;
-  char* Kt = Vs + 64 * NSTR;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
   const int d = p.d, hc = h * d;
@@ -213,13 +249,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const sdlt_attn_params
   const float sl2 = p.scale * LOG2E;
   const int kend = p.causal ? min(p.Nk, q0 + 64) : p.Nk;
 
-  for (int k0 = 0; k0 < kend; k0 += 64) {
-    __syncthreads();
-    const int nk = min(64, p.Nkp - k0);
-    load_tile_nat<DP>(Ks, (const bf16_t*)p.K, p.ldk, (int64_t)b * p.Nkp + k0, nk, hc, d);
-    load_tile_nat<DP>(Vs, (const bf16_t*)p.V, p.ldv, (int64_t)b * p.Nkp + k0, nk, hc, d);
-    load_tile_tr<DP>(Kt, (const bf16_t*)p.Kt, p.ldkt, hc, d, (int64_t)b * p.Nkp + k0, nk);
-    __syncthreads();
+  constexpr int QBUF = 2 * 64 * NSTR + DP * TSTR;   // K, V natural + K^T
+  TileRegs<DP> kr, vr, tr;
+  {
+    const int nk = min(64, p.Nkp);
+    gload_nat<DP>(kr, (const bf16_t*)p.K, p.ldk, (int64_t)b * p.Nkp, nk, hc, d);
+    gload_nat<DP>(vr, (const bf16_t*)p.V, p.ldv, (int64_t)b * p.Nkp, nk, hc, d);
+    gload_tr<DP>(tr, (const bf16_t*)p.Kt, p.ldkt, hc, d, (int64_t)b * p.Nkp, nk);
+    sstore_nat<DP>(kr, smem);
+    sstore_nat<DP>(vr, smem + 64 * NSTR);
+    sstore_tr<DP>(tr, smem + 2 * 64 * NSTR);
+  }
+  __syncthreads();
+  int it = 0;
+  for (int k0 = 0; k0 < kend; k0 += 64, ++it) {
+    const char* Ks = smem + (it & 1) * QBUF;
+    const char* Vs = Ks + 64 * NSTR;
+    const char* Kt = Vs + 64 * NSTR;
+    const bool more = k0 + 64 < kend;
+    if (more) {
+      const int nk = min(64, p.Nkp - (k0 + 64));
+      gload_nat<DP>(kr, (const bf16_t*)p.K, p.ldk, (int64_t)b * p.Nkp + k0 + 64, nk, hc, d);
+      gload_nat<DP>(vr, (const bf16_t*)p.V, p.ldv, (int64_t)b * p.Nkp + k0 + 64, nk, hc, d);
+      gload_tr<DP>(tr, (const bf16_t*)p.Kt, p.ldkt, hc, d, (int64_t)b * p.Nkp + k0 + 64, nk);
+    }
     f32x4 s[4], dp[4];
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf) {
@@ -254,6 +307,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const sdlt_attn_params
         dq[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dq[df], 0, 0, 0);
       }
     }
+    if (more) {
+      char* nb = smem + ((it + 1) & 1) * QBUF;
+      sstore_nat<DP>(kr, nb);
+      sstore_nat<DP>(vr, nb + 64 * NSTR);
+      sstore_tr<DP>(tr, nb + 2 * 64 * NSTR);
+    }
+    __syncthreads();
   }
   if (q < p.Nqp) {   // pad rows: dq == 0
 #pragma unroll
@@ -274,12 +334,6 @@ template <int DP>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const sdlt_attn_params p) {
   constexpr int NSTR = DP * 2 + 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Qs = smem;
-  char* Gs = Qs + 64 * NSTR;            // dO natural
-  char* Qt = Gs + 64 * NSTR;            // [DP][64 q]
-  char* Gt = Qt + DP * TSTR;            // dO^T
-  float* Ls = (float*)(Gt + DP * TSTR); // [64]
-  float* Ds = Ls + 64;
   const int b = blockIdx.z, h = blockIdx.y;
   const int ktile = blockIdx.x / p.qsplit, split = blockIdx.x - ktile * p.qsplit;
   const int k0 = ktile * 64;
@@ -306,20 +360,49 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const sdlt_attn_para
   int qt_lo = split * per, qt_hi = min(nqt, qt_lo + per);
   if (p.causal) qt_lo = max(qt_lo, ktile);  // queries before this key tile never see it
 
-  for (int qt = qt_lo; qt < qt_hi; ++qt) {
+  constexpr int KBUF = 2 * 64 * NSTR + 2 * DP * TSTR + 512;   // Q, dO natural + Q^T, dO^T + L, D
+  constexpr bool DB = 2 * KBUF <= 160 * 1024;                 // double-buffered unless it would not fit the LDS
+  TileRegs<DP> qr, gr, qtr, gtr;
+  float lreg = 0.f, dreg = 0.f;
+  auto gload_all = [&](int qt) {
     const int q0 = qt * 64;
-    __syncthreads();
     const int nq = min(64, p.Nqp - q0);
-    load_tile_nat<DP>(Qs, (const bf16_t*)p.Q, p.ldq, (int64_t)b * p.Nqp + q0, nq, hc, d);
-    load_tile_nat<DP>(Gs, (const bf16_t*)p.dO, p.lddo, (int64_t)b * p.Nqp + q0, nq, hc, d);
-    load_tile_tr<DP>(Qt, (const bf16_t*)p.Qt, p.ldqt, hc, d, (int64_t)b * p.Nqp + q0, nq);
-    load_tile_tr<DP>(Gt, (const bf16_t*)p.dOt, p.lddot, hc, d, (int64_t)b * p.Nqp + q0, nq);
+    gload_nat<DP>(qr, (const bf16_t*)p.Q, p.ldq, (int64_t)b * p.Nqp + q0, nq, hc, d);
+    gload_nat<DP>(gr, (const bf16_t*)p.dO, p.lddo, (int64_t)b * p.Nqp + q0, nq, hc, d);
+    gload_tr<DP>(qtr, (const bf16_t*)p.Qt, p.ldqt, hc, d, (int64_t)b * p.Nqp + q0, nq);
+    gload_tr<DP>(gtr, (const bf16_t*)p.dOt, p.lddot, hc, d, (int64_t)b * p.Nqp + q0, nq);
     if (threadIdx.x < 64) {
       int qq = q0 + threadIdx.x;
-      Ls[threadIdx.x] = qq < p.Nq ? p.L[((int64_t)b * p.H + h) * p.Nq + qq] * LOG2E : 0.f;
-      Ds[threadIdx.x] = qq < p.Nq ? p.D[((int64_t)b * p.H + h) * p.Nq + qq] : 0.f;
+      lreg = qq < p.Nq ? p.L[((int64_t)b * p.H + h) * p.Nq + qq] * LOG2E : 0.f;
+      dreg = qq < p.Nq ? p.D[((int64_t)b * p.H + h) * p.Nq + qq] : 0.f;
     }
-    __syncthreads();
+  };
+  auto sstore_all = [&](char* base) {
+    sstore_nat<DP>(qr, base);
+    sstore_nat<DP>(gr, base + 64 * NSTR);
+    sstore_tr<DP>(qtr, base + 2 * 64 * NSTR);
+    sstore_tr<DP>(gtr, base + 2 * 64 * NSTR + DP * TSTR);
+    if (threadIdx.x < 64) {
+      float* ls = (float*)(base + 2 * 64 * NSTR + 2 * DP * TSTR);
+      ls[threadIdx.x] = lreg;
+      ls[64 + threadIdx.x] = dreg;
+    }
+  };
+  if (qt_lo < qt_hi) {
+    gload_all(qt_lo);
+    sstore_all(smem);
+  }
+  __syncthreads();
+  for (int qt = qt_lo; qt < qt_hi; ++qt) {
+    const int q0 = qt * 64;
+    const char* Qs = smem + (DB ? ((qt - qt_lo) & 1) * KBUF : 0);
+    const char* Gs = Qs + 64 * NSTR;
+    const char* Qt = Gs + 64 * NSTR;
+    const char* Gt = Qt + DP * TSTR;
+    const float* Ls = (const float*)(Gt + DP * TSTR);
+    const float* Ds = Ls + 64;
+    const bool more = qt + 1 < qt_hi;
+    if (more) gload_all(qt + 1);
     f32x4 s[4], dp[4];
 #pragma unroll
     for (int qf = 0; qf < 4; ++qf) {
@@ -362,6 +445,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const sdlt_attn_para
         dk[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf, dk[df], 0, 0, 0);
       }
     }
+    if (more) {
+      if (!DB) __syncthreads();   // single LDS buffer (DP = 160): everyone must be done reading it
+      sstore_all(smem + (DB ? ((qt - qt_lo + 1) & 1) * KBUF : 0));
+    }
+    __syncthreads();
   }
   if (key < p.Nkp) {   // pad rows [Nk, Nkp) receive zeros (their accumulators are zero: p == 0 there)
     const int64_t row = (int64_t)b * p.Nkp + key;
@@ -446,7 +534,7 @@ extern "C" int sdlt_attn_fwd(const sdlt_attn_params* pp, void* stream) {
   if (!p.Vt || (p.ldvt % 8) || (p.ldo % 4)) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_attn_fwd: needs V^T (ld %% 8) and ldo %% 4");
   const int dp = attn_dp(p.d);
   dim3 grid((p.Nq + 63) / 64, p.H, p.B);
-#define SMEM_FWD(D_) (64 * ((D_) * 2 + 16) + (D_) * TSTR)
+#define SMEM_FWD(D_) (2 * (64 * ((D_) * 2 + 16) + (D_) * TSTR))
   ATTN_DISPATCH(dp, attn_fwd_kernel, grid, SMEM_FWD)
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
@@ -472,14 +560,14 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
     hipLaunchKernelGGL(attn_prep_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)p.O, p.ldo, (const bf16_t*)p.dO, p.lddo, p.B, p.H, p.Nq, p.Nqp, p.d, p.D);
   }
   dim3 gq((p.Nq + 63) / 64, p.H, p.B);
-#define SMEM_DQ(D_) (2 * 64 * ((D_) * 2 + 16) + (D_) * TSTR)
+#define SMEM_DQ(D_) (2 * (2 * 64 * ((D_) * 2 + 16) + (D_) * TSTR))
   ATTN_DISPATCH(dp, attn_bwd_dq_kernel, gq, SMEM_DQ)
   if (p.qsplit > 1) {
     sdlt_zero_async(p.dK32, sizeof(float) * (size_t)p.B * p.Nkp * p.ld32, s);
     sdlt_zero_async(p.dV32, sizeof(float) * (size_t)p.B * p.Nkp * p.ld32, s);
   }
   dim3 gk(((p.Nk + 63) / 64) * p.qsplit, p.H, p.B);
-#define SMEM_DKV(D_) (2 * 64 * ((D_) * 2 + 16) + 2 * (D_) * TSTR + 512)
+#define SMEM_DKV(D_) ((2 * (2 * 64 * ((D_) * 2 + 16) + 2 * (D_) * TSTR + 512) <= 160 * 1024 ? 2 : 1) * (2 * 64 * ((D_) * 2 + 16) + 2 * (D_) * TSTR + 512))
   ATTN_DISPATCH(dp, attn_bwd_dkdv_kernel, gk, SMEM_DKV)
   if (p.qsplit > 1) {
     int C = p.H * p.d, rows = p.B * p.Nkp;

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   constexpr int S = NSTAGE;                        // LDS ring depth: S-1 K-steps of DMA in flight under the MFMAs
   constexpr int TROW = R16 ? (R16 * 16 + 4) : 4;  // bf16 elements per Tsh row (+4 pad)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* tsh = smem + S * STAGE;
+  char* tsh = smem + (S == 1 ? 2 : S) * STAGE;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
@@ -120,13 +120,13 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   constexpr int AI = R16 ? ((2 * R16 + NW - 1) / NW) : 0;   // LoRA-down DMA instructions per wave and stage
   constexpr int LPS = XI + WI + AI;                         // DMA instructions per wave and stage
 
-  auto stage = [&](int kt, int buf) {
-    char* base = smem + buf * STAGE;
+  // Enumerates the 8-row x 128-byte pieces this wave moves for K-step kt: f(j, src, lds_off) with j in [0, LPS).
+  auto for_each_piece = [&](int kt, auto&& f) {
     if (kt < nk1) {
       const int k0 = kt * BK;
       if (MODE == 0) {
 #pragma unroll
-        for (int i = 0; i < XI; ++i) glds16(xptr[i] + k0, base + (wave + NW * i) * 1024);
+        for (int i = 0; i < XI; ++i) f(i, xptr[i] + k0, (wave + NW * i) * 1024);
       } else {
         const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
         const int dy = tap / 3, dx = tap - dy * 3;
@@ -149,27 +149,32 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
             }
             if (ok) src = (const bf16_t*)p.X + ((size_t)(xb[i] * p.Hin + hi) * p.Win + wi) * p.ldx + ci0 + schunk * 8;
           }
-          glds16(src, base + (wave + NW * i) * 1024);
+          f(i, src, (wave + NW * i) * 1024);
         }
       }
 #pragma unroll
-      for (int i = 0; i < WI; ++i) glds16(wptr[i] + k0, base + XT + (wave + NW * i) * 1024);
+      for (int i = 0; i < WI; ++i) f(XI + i, wptr[i] + k0, XT + (wave + NW * i) * 1024);
       if (R16) {
-        // every wave issues the SAME number of DMA instructions per stage (the counted vmcnt below relies on it);
+        // every wave moves the SAME number of pieces per stage (the counted vmcnt of the DMA path relies on it);
         // when there are fewer pieces than waves some waves re-load a piece - identical bytes to identical LDS addresses.
 #pragma unroll
         for (int j = 0; j < AI; ++j) {
           int piece = (wave + NW * j) % (R16 * 2);
-          glds16(aptr + (size_t)(piece * 8 + srow) * p.ld_adown + k0, base + XT + WT + piece * 1024);
+          f(XI + WI + j, aptr + (size_t)(piece * 8 + srow) * p.ld_adown + k0, XT + WT + piece * 1024);
         }
       }
     } else {
       const int k0 = (kt - nk1) * BK;
 #pragma unroll
-      for (int i = 0; i < XI; ++i) glds16(x2ptr[i] + k0, base + (wave + NW * i) * 1024);
+      for (int i = 0; i < XI; ++i) f(i, x2ptr[i] + k0, (wave + NW * i) * 1024);
 #pragma unroll
-      for (int i = 0; i < WI; ++i) glds16(w2ptr[i] + k0, base + XT + (wave + NW * i) * 1024);
+      for (int i = 0; i < WI; ++i) f(XI + i, w2ptr[i] + k0, XT + (wave + NW * i) * 1024);
     }
+  };
+  // LDS-DMA path: global -> LDS directly (16 B per lane, destination = piece base + lane*16)
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * STAGE;
+    for_each_piece(kt, [&](int, const bf16_t* src, int off) { glds16(src, base + off); });
   };
 
   // ---------------- accumulators ----------------
@@ -193,23 +198,8 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
 
   // this workgroup's share of the K steps (split-K: contiguous ranges of the combined segment-1 + segment-2 steps)
   const int kbeg = (int)((long)nk * split / splitk), kend = (int)((long)nk * (split + 1) / splitk);
-  // prologue: S-1 stages in flight
-#pragma unroll
-  for (int t = 0; t < S - 1; ++t)
-    if (kbeg + t < kend) stage(kbeg + t, t);
-  for (int kt = kbeg; kt < kend; ++kt) {
-    // wait until stage kt has landed: this wave has issued stages up to min(kend-1, kt+S-2); each is LPS instructions
-    {
-      const int ahead = (kend - 1 < kt + S - 2 ? kend - 1 : kt + S - 2) - kt;
-      if (S >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-      else if (S >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();   // stage kt visible to all waves; everyone is done reading stage kt-1's buffer
-    asm volatile("" ::: "memory");
-    const bool early = WN == 2 || wave < NW / 2;
-    if (early && kt + S - 1 < kend) stage(kt + S - 1, (kt - kbeg + S - 1) % S);
-    const char* base = smem + ((kt - kbeg) % S) * STAGE;
+
+  auto compute = [&](const char* base, int kt) {
     const char* xs = base + (wm * MI * 16) * ROW_BYTES;
     const char* ws = base + XT + (wn * NI * 16) * ROW_BYTES;
     const char* as = base + XT + WT;
@@ -242,7 +232,55 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
         }
       }
     }
+  };
+
+  if (S == 1) {
+    // ---- register-staged pipeline: global -> VGPR two K-steps ahead, VGPR -> LDS one step ahead, 2 LDS buffers ----
+    uint4 ra[LPS], rb[LPS];
+    const int loff = lane * 16;
+    auto gload = [&](int kt, uint4 (&r)[LPS]) {
+      for_each_piece(kt, [&](int j, const bf16_t* src, int) { r[j] = *(const uint4*)src; });
+    };
+    auto sstore = [&](int kt, const uint4 (&r)[LPS], char* base) {
+      for_each_piece(kt, [&](int j, const bf16_t*, int off) { *(uint4*)(base + off + loff) = r[j]; });
+    };
+    char* buf0 = smem;
+    char* buf1 = smem + STAGE;
+    if (kbeg < kend) gload(kbeg, ra);
+    if (kbeg + 1 < kend) gload(kbeg + 1, rb);
+    if (kbeg < kend) sstore(kbeg, ra, buf0);
+    __syncthreads();
+    for (int kt = kbeg; kt < kend; kt += 2) {
+      if (kt + 2 < kend) gload(kt + 2, ra);
+      compute(buf0, kt);
+      if (kt + 1 < kend) sstore(kt + 1, rb, buf1);
+      __syncthreads();
+      if (kt + 1 >= kend) break;
+      if (kt + 3 < kend) gload(kt + 3, rb);
+      compute(buf1, kt + 1);
+      if (kt + 2 < kend) sstore(kt + 2, ra, buf0);
+      __syncthreads();
+    }
+  } else {
+  // prologue: S-1 stages in flight
+#pragma unroll
+  for (int t = 0; t < S - 1; ++t)
+    if (kbeg + t < kend) stage(kbeg + t, t);
+  for (int kt = kbeg; kt < kend; ++kt) {
+    // wait until stage kt has landed: this wave has issued stages up to min(kend-1, kt+S-2); each is LPS instructions
+    {
+      const int ahead = (kend - 1 < kt + S - 2 ? kend - 1 : kt + S - 2) - kt;
+      if (S >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+      else if (S >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();   // stage kt visible to all waves; everyone is done reading stage kt-1's buffer
+    asm volatile("" ::: "memory");
+    const bool early = WN == 2 || wave < NW / 2;
+    if (early && kt + S - 1 < kend) stage(kt + S - 1, (kt - kbeg + S - 1) % S);
+    compute(smem + ((kt - kbeg) % S) * STAGE, kt);
     if (!early && kt + S - 1 < kend) stage(kt + S - 1, (kt - kbeg + S - 1) % S);
+  }
   }
 
   // ---------------- split-K: publish the partial tile, last arriver reduces (agent-scope release/acquire) ----------------
@@ -412,9 +450,10 @@ int launch(const sdlt_gemm_params& p, hipStream_t stream) {
   constexpr int TSH = R16 ? BM * (R16 * 16 + 4) * 2 : 0;
   // LDS ring depth: NSREQ == 2 keeps the footprint small (several workgroups per CU overlap each other);
   // otherwise as deep as 160 KB allows, up to 4.
-  constexpr int NS = NSREQ == 2 ? 2 : ((4 * STAGE + TSH <= 160 * 1024) ? 4 : ((3 * STAGE + TSH <= 160 * 1024) ? 3 : 2));
-  static_assert(NS * STAGE + TSH <= 160 * 1024, "LDS budget");
-  const int smem = NS * STAGE + TSH;
+  constexpr int NS = NSREQ <= 2 ? NSREQ : ((4 * STAGE + TSH <= 160 * 1024) ? 4 : ((3 * STAGE + TSH <= 160 * 1024) ? 3 : 2));
+  constexpr int NBUF = NS == 1 ? 2 : NS;
+  static_assert(NBUF * STAGE + TSH <= 160 * 1024, "LDS budget");
+  const int smem = NBUF * STAGE + TSH;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)gemm_kernel<MI, NI, WN, MODE, R16, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -484,6 +523,8 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
     case 4: return launch<8, 2, 4, MODE, R16, NSV>(p, s);            \
     case 5: return launch<4, 4, 2, MODE, R16, NSV>(p, s);            \
   }
+  // (stages == 1, the register-staged loader, is kept in the kernel source but not instantiated: hipcc places its
+  //  staging registers in scratch - measured 3-6x slower than the LDS-DMA ring on every SDXL shape.)
   if (p.stages == 2) { SDLT_TILE_CASES(2) } else { SDLT_TILE_CASES(4) }
 #undef SDLT_TILE_CASES
   SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: tile id %d", p.tile);

@@ -120,7 +120,7 @@ def test_gemm_split_k(ops, M, N, K, r, tile, splitk):
     Xd, Wd, bd, Rd = dev(X, W, bias, R)
     for rep in range(3):
         out = ops.gemm(Xd, Wd, torch.zeros(M, N, dtype=BF, device="cuda"), lora=lora_g, bias=bd, residual=Rd, tile=tile, splitk=splitk,
-                       stages=2 if rep == 2 else 0)
+                       stages=(0, 2, 0)[rep])
         close(out, ref, what=f"split-K gemm rep {rep}")
         if r:
             close(T, Tref, what="split-K lora T_out")
@@ -149,13 +149,14 @@ def test_conv3x3_implicit_gemm(ops, c):
     bias = torch.randn(Cout, generator=g)
     R = rnd(B * Hout * Wout, Cout, g=g)
     rowb = rnd(B, Cout, g=g)
-    for mod, mk in ((E, lambda t: t), (ops, lambda t: t.cuda())):
+    for mod, mk, st in ((E, lambda t: t, 0), (ops, lambda t: t.cuda(), 0), (ops, lambda t: t.cuda(), 2)):
         geom = mod.ConvGeom(B, H, W, Cin, Hout, Wout, stride=c["stride"], ups=c["ups"], flip=c["flip"], tr=c["tr"])
         out = mod.gemm(mk(X), mk(Wm), mk(torch.empty(B * Hout * Wout, Cout, dtype=BF)), conv=geom, bias=mk(bias), residual=mk(R),
-                       rowbias=mk(rowb), rows_per_batch=Hout * Wout)
+                       rowbias=mk(rowb), rows_per_batch=Hout * Wout, stages=st)
         if mod is E:
             ref = out
-    close(out, ref, what=f"conv {c}")
+        else:
+            close(out, ref, what=f"conv {c} stages {st}")
 
 
 def test_conv3x3_fused_lora_and_strided_input(ops):
