@@ -102,17 +102,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
+    from sd_lora_trainer_amd import parallel
+    rank, world, local_rank = parallel.init_distributed("nccl")
+    torch.cuda.set_device(local_rank if world > 1 else 0)
     device = torch.device("cuda", local_rank if world > 1 else 0)
 
     import sd_lora_trainer_amd.step as S
@@ -153,11 +145,7 @@ def main():
     for i in range(args.warmup):
         ts.run(lr_at(i, total))
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
+    barrier = parallel.barrier_sync
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -166,12 +154,8 @@ def main():
         ts.run(lr_at(args.warmup + i, total))
     ev1.record()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device)
     ev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt)
     loss = ts.total_loss()
     assert math.isfinite(loss), "non-finite loss in the timed region"
 
