@@ -66,7 +66,8 @@ typedef struct sdlt_gemm_params {
   int32_t splitk;             /* 0 = auto, 1 = off, n = split the K loop over n workgroups per tile */
   int32_t ws_cnt_len;         /* ints in ws_cnt */
   void* ws_slab; int64_t ws_slab_bytes;   /* split-K scratch: fp32 partial tiles (caller-owned, any contents) */
-  int32_t stages; int32_t pad_; /* LDS ring depth: 0 = auto (deepest that fits), 2 = double buffer (2 workgroups per CU) */
+  int32_t stages;             /* LDS ring depth: 0 = auto (deepest that fits), 2 = double buffer (2 workgroups per CU) */
+  int32_t accumulate;         /* fp32 output only: C += result (DAAM score sums over layers) */
   int32_t* ws_cnt;            /* split-K arrival counters, zero-initialised ONCE by the caller; kernels re-arm them */
 } sdlt_gemm_params;
 int sdlt_gemm_bf16(const sdlt_gemm_params* p, void* stream);
@@ -210,10 +211,25 @@ int sdlt_lora_shadow_refresh(const sdlt_shadow_desc* descs_dev, const int32_t* b
 /* out[M,C] = a + b on strided 2-D bf16 views (gradient fan-in of the UNet skip connections). */
 int sdlt_add2d(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int32_t M, int32_t C, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ text-encoder / TI
+ * CLIP token + position embedding: out[b*Tp + t] = table[ids[b*T + t]] + pos[t] (t < T), rows T..Tp-1 zero.
+ * Replaces CLIPTextEmbeddings.forward inside pipe.encode_prompt (trainer/inference.py:132-139).  bf16 tables. */
+int sdlt_embed_gather(const void* table, int64_t ld_table, const int64_t* ids, const void* pos, int64_t ld_pos,
+                      int32_t B, int32_t T, int32_t Tp, int32_t D, void* out, int64_t ldo, void* stream);
+/* Gradient of the trainable token rows only: grad[j] (+)= sum over (b,t) with ids[b,t] == train_ids[j] of dx[b*Tp+t].
+ * Equivalent to the reference's full-table gradient followed by `grad[:-n_tokens] *= 0` (main.py:368-371). */
+int sdlt_embed_grad(const void* dx, int64_t lddx, const int64_t* ids, const int64_t* train_ids, int32_t n_train,
+                    int32_t B, int32_t T, int32_t Tp, int32_t D, float* grad, int32_t accumulate, void* stream);
+/* DistributionLoss.compute_std_loss (trainer/loss.py:291-297) on the trainable rows [n,D] (fp32) and its gradient:
+ * loss_out += w * mean_j (target_mean - std(row_j))^2 / target_var ; grad += d/d rows.  std is the unbiased std. */
+int sdlt_ti_std_reg(const float* rows, int32_t n, int32_t D, float target_mean, float target_var, float weight,
+                    float* grad, float* loss_out, void* stream);
+
 /* dX of nearest-2x upsampling: out[b,h,w,:] = sum of the 2x2 block of in [B,2H,2W,C]. */
 int sdlt_sum2x2(const void* in, int32_t B, int32_t H, int32_t W, int32_t C, void* out, void* stream);
-/* out[b,c] = sum_r x[b*R + r, c]  (fp32) - gradient of the per-batch time-embedding bias. */
-int sdlt_colsum(const void* x, int64_t ldx, int32_t B, int32_t R, int32_t C, float* out, void* stream);
+/* out[b,c] = sum_r x[b*R + r, c] (fp32 and/or bf16 [B,C], either may be NULL) - gradient of the per-batch
+ * time-embedding bias of a ResnetBlock2D (h + time_emb_proj(silu(temb))[:, :, None, None]). */
+int sdlt_colsum(const void* x, int64_t ldx, int32_t B, int32_t R, int32_t C, float* out, void* out_bf16, void* stream);
 
 #ifdef __cplusplus
 }

@@ -72,7 +72,7 @@ CONFIGS = {
         layers_per_block=1,
         transformer_layers=(1, 1, 2),
         heads=(1, 2, 2),                 # head_dim 64 like SDXL
-        cross_dim=64,
+        cross_dim=128,
         linear_proj=True,
         addition=True, addition_time_embed_dim=32, proj_class_in=64 + 6 * 32,
         in_channels=4, out_channels=4,

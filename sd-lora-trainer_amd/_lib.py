@@ -33,7 +33,7 @@ class GemmParams(C.Structure):
         ("C", vp), ("ldc", i64),
         ("out_fp32", i32), ("tile", i32),
         ("Ct", vp), ("ldct", i64),
-        ("splitk", i32), ("ws_cnt_len", i32), ("ws_slab", vp), ("ws_slab_bytes", i64), ("stages", i32), ("pad_", i32), ("ws_cnt", vp),
+        ("splitk", i32), ("ws_cnt_len", i32), ("ws_slab", vp), ("ws_slab_bytes", i64), ("stages", i32), ("accumulate", i32), ("ws_cnt", vp),
     ]
 
 
@@ -104,7 +104,10 @@ SYMBOLS = {
     "sdlt_adamw_fused": (i32, [vp, vp, vp, vp, i64, vp, vp, vp]),
     "sdlt_lora_shadow_refresh": (i32, [vp, vp, vp, i32, vp, vp]),
     "sdlt_sum2x2": (i32, [vp, i32, i32, i32, i32, vp, vp]),
-    "sdlt_colsum": (i32, [vp, i64, i32, i32, i32, vp, vp]),
+    "sdlt_colsum": (i32, [vp, i64, i32, i32, i32, vp, vp, vp]),
+    "sdlt_embed_gather": (i32, [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp]),
+    "sdlt_embed_grad": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "sdlt_ti_std_reg": (i32, [vp, i32, i32, f32, f32, f32, vp, vp, vp]),
 }
 
 _lib = None

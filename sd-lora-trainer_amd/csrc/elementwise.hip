@@ -256,7 +256,7 @@ __global__ void sum2x2_kernel(const bf16_t* in, int B, int H, int W, int C, bf16
 }
 
 // ------------------------------------------------------------------ column sums per batch: out[b, c] = sum_r x[b*R + r, c]  (fp32 out)
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* x, int64_t ldx, int R, int C, float* out) {
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* x, int64_t ldx, int R, int C, float* out, bf16_t* out_bf) {
   // grid (C/64, B); same 8 rows x 64 channels wave footprint as the norms
   __shared__ float sh[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -276,7 +276,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* x, int64_t ld
 #pragma unroll
     for (int j = 0; j < 8; ++j) sh[wave][(lane & 7) * 8 + j] = s[j];
   __syncthreads();
-  if (threadIdx.x < 64) out[(int64_t)b * C + blockIdx.x * 64 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+  if (threadIdx.x < 64) {
+    float v = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    if (out) out[(int64_t)b * C + blockIdx.x * 64 + threadIdx.x] = v;
+    if (out_bf) out_bf[(int64_t)b * C + blockIdx.x * 64 + threadIdx.x] = f2bf(v);
+  }
 }
 
 inline int grid_for(int64_t work_items, int block = 256) {
@@ -359,9 +363,9 @@ extern "C" int sdlt_sum2x2(const void* in, int32_t B, int32_t H, int32_t W, int3
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }
-extern "C" int sdlt_colsum(const void* x, int64_t ldx, int32_t B, int32_t R, int32_t C, float* out, void* stream) {
-  if (B <= 0 || R <= 0 || C <= 0 || (C % 64) || (ldx % 8)) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_colsum: B=%d R=%d C=%d", B, R, C);
-  hipLaunchKernelGGL(colsum_kernel, dim3(C / 64, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, R, C, out);
+extern "C" int sdlt_colsum(const void* x, int64_t ldx, int32_t B, int32_t R, int32_t C, float* out, void* out_bf16, void* stream) {
+  if (B <= 0 || R <= 0 || C <= 0 || (C % 64) || (ldx % 8) || (!out && !out_bf16)) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_colsum: B=%d R=%d C=%d", B, R, C);
+  hipLaunchKernelGGL(colsum_kernel, dim3(C / 64, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, R, C, out, (bf16_t*)out_bf16);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }

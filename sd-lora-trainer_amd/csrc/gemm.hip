@@ -419,6 +419,10 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
           for (int r = 0; r < 4; ++r) ((bf16_t*)p.Ct)[(size_t)(n + r) * p.ldct + m] = f2bf(v[r]);
         }
         if (p.out_fp32) {
+          if (p.accumulate) {
+            float4 old = *(const float4*)((const float*)p.C + (size_t)m * p.ldc + n);
+            v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+          }
           *(float4*)((float*)p.C + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
           uint2 o;
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
           if (p.rowbias) x += bf2f(((const bf16_t*)p.rowbias)[(size_t)brow * p.ld_rowbias + n + r]);
           if (p.R) x += bf2f(((const bf16_t*)p.R)[(size_t)m * p.ldr + n + r]);
           if (p.Ct) ((bf16_t*)p.Ct)[(size_t)(n + r) * p.ldct + m] = f2bf(x);
-          if (p.out_fp32) ((float*)p.C)[(size_t)m * p.ldc + n + r] = x;
+          if (p.out_fp32) ((float*)p.C)[(size_t)m * p.ldc + n + r] = p.accumulate ? ((float*)p.C)[(size_t)m * p.ldc + n + r] + x : x;
           else ((bf16_t*)p.C)[(size_t)m * p.ldc + n + r] = f2bf(x);
         }
       }
@@ -550,6 +554,7 @@ extern "C" int sdlt_gemm_bf16(const sdlt_gemm_params* pp, void* stream) {
   } else if (p.mode != 0) {
     SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: mode %d", p.mode);
   }
+  if (p.accumulate && !p.out_fp32) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: accumulate needs an fp32 output (use R for bf16)");
   int r16 = 0;
   if (p.lora_R) {
     if (p.lora_R != 16 && p.lora_R != 32 && p.lora_R != 64) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: padded LoRA rank %d (16/32/64)", p.lora_R);

@@ -66,7 +66,7 @@ class ConvGeom:
 
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
-         residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0):
+         residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False):
     """out[M,N] = alpha*(X.W^T [+ X2.W2^T] [+ s*(X.Adown^T).Bup^T]) + bias + rowbias[m//rows_per_batch] + residual.
     lora = (Adown [Rp,K], Bup [N,Rp], scale, T_out [M,Rp] or None).  out dtype bf16 or fp32.  Ct: optional
     transposed bf16 copy [N, >=M].  conv: ConvGeom -> X is the NHWC activation [B*Hin*Win, Cin]."""
@@ -121,7 +121,7 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
         _chk2(Ct)
         assert Ct.shape[0] == N and Ct.shape[1] >= M
         p.Ct, p.ldct = _p(Ct), _ld(Ct)
-    p.tile, p.splitk, p.stages = tile, splitk, stages
+    p.tile, p.splitk, p.stages, p.accumulate = tile, splitk, stages, int(accumulate)
     slab, cnt = splitk_workspace(X.device)
     p.ws_slab, p.ws_slab_bytes, p.ws_cnt, p.ws_cnt_len = _p(slab), slab.numel(), _p(cnt), cnt.numel()
     _lib.check(lib.sdlt_gemm_bf16(C.byref(p), _stream()), "sdlt_gemm_bf16")
@@ -380,7 +380,39 @@ def sum2x2(inp, out, *, B, H, W):
 
 
 def colsum(x, out, *, B, R):
+    """out[b, c] = sum over the R rows of batch b of x[:, c]; out is fp32 or bf16 [B, C]."""
     lib = _lib.load()
-    _chk2(x), _chk2(out, F32)
-    _lib.check(lib.sdlt_colsum(_p(x), _ld(x), B, R, x.shape[1], _p(out), _stream()), "sdlt_colsum")
+    _chk2(x)
+    assert out.is_cuda and out.dtype in (F32, BF16) and out.is_contiguous()
+    f, h = (_p(out), C.c_void_p(0)) if out.dtype == F32 else (C.c_void_p(0), _p(out))
+    _lib.check(lib.sdlt_colsum(_p(x), _ld(x), B, R, x.shape[1], f, h, _stream()), "sdlt_colsum")
     return out
+
+
+def embed_gather(table, ids, pos, out, *, B, T, Tp):
+    """out[b*Tp + t] = table[ids[b, t]] + pos[t]; rows T..Tp-1 of every batch are zero."""
+    lib = _lib.load()
+    _chk2(table), _chk2(pos), _chk2(out)
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and ids.numel() == B * T and out.shape[0] == B * Tp
+    _lib.check(lib.sdlt_embed_gather(_p(table), _ld(table), _p(ids), _p(pos), _ld(pos), B, T, Tp, table.shape[1], _p(out), _ld(out), _stream()),
+               "sdlt_embed_gather")
+    return out
+
+
+def embed_grad(dx, ids, train_ids, grad, *, B, T, Tp, accumulate=False):
+    """grad[j] (+)= sum of dx rows whose token id equals train_ids[j] (fp32 [n, D])."""
+    lib = _lib.load()
+    _chk2(dx), _chk2(grad, F32)
+    assert ids.dtype == torch.int64 and train_ids.dtype == torch.int64 and grad.is_contiguous()
+    _lib.check(lib.sdlt_embed_grad(_p(dx), _ld(dx), _p(ids), _p(train_ids), train_ids.numel(), B, T, Tp, dx.shape[1], _p(grad), int(accumulate),
+                                   _stream()), "sdlt_embed_grad")
+    return grad
+
+
+def ti_std_reg(rows, grad, loss_out, *, target_mean, target_var, weight):
+    """loss_out += weight * mean_j (target_mean - std(rows_j))^2 / target_var ; grad += its gradient (fp32 [n, D])."""
+    lib = _lib.load()
+    _chk2(rows, F32), _chk2(grad, F32), _chk2(loss_out, F32)
+    assert rows.is_contiguous() and grad.is_contiguous()
+    _lib.check(lib.sdlt_ti_std_reg(_p(rows), rows.shape[0], rows.shape[1], float(target_mean), float(target_var), float(weight), _p(grad),
+                                   _p(loss_out), _stream()), "sdlt_ti_std_reg")

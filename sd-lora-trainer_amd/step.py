@@ -9,7 +9,49 @@ import math
 import torch
 
 from . import ops as _ops
+from .clip import T_TOKENS, TP
+from .daam import TokenAttentionLoss
+from .ti import TiState
 from .unet import CTX_PAD, F32, Runtime, UNet
+
+assert TP == CTX_PAD
+
+
+class TextStack:
+    """The text encoders wired as diffusers' `encode_prompt` wires them (trainer/inference.py:131-177):
+    SD1.5: prompt_embeds = CLIP-L last_hidden_state (after final LN).
+    SDXL : prompt_embeds = concat(CLIP-L hidden_states[-2], bigG hidden_states[-2]); pooled = bigG text_embeds."""
+
+    def __init__(self, rt, encoders, pool_mode="argmax", eos_token_id=49407):
+        self.rt, self.encoders, self.pool_mode, self.eos = rt, encoders, pool_mode, eos_token_id
+        B = rt.B
+        self.ids = [torch.zeros(B, T_TOKENS, dtype=torch.int64, device=rt.device) for _ in encoders]
+        self.pool_rows = torch.zeros(B, dtype=torch.int64, device=rt.device)
+        self.widths = [e.D for e in encoders]
+
+    def set_ids(self, ids_per_encoder):
+        for dst, src in zip(self.ids, ids_per_encoder):
+            dst.copy_(src)
+        last = ids_per_encoder[-1].cpu()
+        # transformers CLIPTextModel pooling: legacy configs (eos_token_id == 2, SDXL's text_encoder_2) take argmax(input_ids),
+        # newer ones the first position equal to eos_token_id
+        pos = last.argmax(-1) if self.pool_mode == "argmax" else (last == self.eos).int().argmax(-1)
+        self.pool_rows.copy_(torch.arange(last.shape[0]) * TP + pos)
+
+    def forward(self, ctx):
+        off, pooled = 0, None
+        for e, ids, w in zip(self.encoders, self.ids, self.widths):
+            _, p = e.forward(ids, self.rt.B, hidden_out=ctx[:, off:off + w], pool_rows=self.pool_rows)
+            pooled = p if p is not None else pooled
+            off += w
+        return pooled
+
+    def backward(self, dctx, d_pooled, grad_rows):
+        off = 0
+        for e, w, g in zip(self.encoders, self.widths, grad_rows):
+            e.backward(dctx[:, off:off + w], d_pooled if e.with_projection else None, g)
+            off += w
+
 
 
 def ddpm_alphas_cumprod(n=1000, beta_start=0.00085, beta_end=0.012):
@@ -20,8 +62,13 @@ def ddpm_alphas_cumprod(n=1000, beta_start=0.00085, beta_end=0.012):
 
 class TrainStep:
     def __init__(self, rt: Runtime, unet: UNet, *, latent_hw, snr_gamma=5.0, v_prediction=False, l1_penalty=0.03,
-                 weight_decay=0.004, grad_accum=1, betas=(0.9, 0.999), eps=1e-8):
+                 weight_decay=0.004, grad_accum=1, betas=(0.9, 0.999), eps=1e-8, text: TextStack = None, n_tokens=3,
+                 token_attention_loss_w=3e-7, ti_weight_decay=0.0, ti_std_loss_w=0.01):
         self.rt, self.unet = rt, unet
+        self.text, self.ta_w, self.ti_wd = text, token_attention_loss_w, ti_weight_decay
+        self.ti = TiState(rt, text.encoders, n_tokens, ti_std_loss_w) if text is not None else None
+        self.ta = TokenAttentionLoss(rt, n_tokens) if text is not None else None
+        rt.want_dpooled = text is not None and unet.cfg["addition"]
         B, (h, w) = rt.B, latent_hw
         cfg = unet.cfg
         self.B, self.h, self.w = B, h, w
@@ -48,43 +95,72 @@ class TrainStep:
         self.graph = None
 
     # -------------------------------------------------------------------------------- inputs
-    def set_batch(self, latent, noise, timesteps, mask, ctx, pooled=None, time_ids=None):
-        """latent/noise/mask [B,4,h,w] fp32, timesteps int64 [B], ctx [B,77,D]; SDXL: pooled [B,P], time_ids [B,6]."""
+    def set_batch(self, latent, noise, timesteps, mask, ctx=None, pooled=None, time_ids=None, ids=None, caption_token_lists=None):
+        """latent/noise/mask [B,4,h,w] fp32, timesteps int64 [B]; SDXL: time_ids [B,6].
+        Without text encoders: ctx [B,77,D] (+ pooled [B,P]) are the injected conditioning.
+        With text encoders (textual inversion): ids = [input_ids [B,77] per tokenizer] and caption_token_lists[b] =
+        tokenizer.encode(caption_b) (unpadded, for the token-attention loss, loss.py:32)."""
         self.latent.copy_(latent)
         self.noise.copy_(noise)
         self.mask.copy_(mask)
         self.timesteps.copy_(timesteps)
         self.timesteps_f.copy_(timesteps.to(torch.float32))
-        self.ctx.view(self.B, CTX_PAD, -1)[:, :77].copy_(ctx)
-        if self.pooled is not None:
-            self.pooled.copy_(pooled)
+        if self.text is None:
+            self.ctx.view(self.B, CTX_PAD, -1)[:, :77].copy_(ctx)
+            if self.pooled is not None:
+                self.pooled.copy_(pooled)
+        else:
+            self.text.set_ids(ids)
+            train_ids = self.text.encoders[0].train_ids.tolist()
+            self.ta.set_captions(caption_token_lists, train_ids)
+        if self.time_ids is not None:
             self.time_ids.copy_(time_ids.reshape(-1).to(torch.float32))
 
-    def set_hyper(self, lr):
-        """Host scalars of this optimiser step -> device buffer (see sdlt_adamw_fused)."""
+    def set_hyper(self, lr, lr_ti=0.0):
+        """Host scalars of this optimiser step -> device buffers (see sdlt_adamw_fused)."""
         self.opt_step += 1
         b1, b2 = self.betas
         n = self.unet.arena.n
-        vals = [lr, b1, b2, self.eps, self.wd, 1.0 - b1 ** self.opt_step, 1.0 - b2 ** self.opt_step,
-                self.l1_penalty / n, 1.0]
+        bc = [1.0 - b1 ** self.opt_step, 1.0 - b2 ** self.opt_step]
+        vals = [lr, b1, b2, self.eps, self.wd, *bc, self.l1_penalty / n, 1.0]
         self.hyper[: len(vals)].copy_(torch.tensor(vals, dtype=torch.float32))
+        if self.ti is not None:
+            vals = [lr_ti, b1, b2, self.eps, self.ti_wd, *bc, 0.0, 1.0]
+            self.ti.hyper[: len(vals)].copy_(torch.tensor(vals, dtype=torch.float32))
 
     # -------------------------------------------------------------------------------- the step body
     def forward_backward(self):
         rt, u = self.rt, self.unet
         ops = rt.ops
+        pooled = self.pooled
+        if self.text is not None:                      # a4: text conditioning with the trainable token rows (main.py:306-308)
+            p = self.text.forward(self.ctx)
+            pooled = p if p is not None else pooled
         ops.add_noise_nhwc(self.latent, self.noise, self.timesteps, self.acp, self.x64, self.noisy)
-        pred = u.forward(self.x64, self.timesteps_f, self.ctx, self.pooled, self.time_ids, B=self.B, H=self.h, W=self.w)
+        pred = u.forward(self.x64, self.timesteps_f, self.ctx, pooled, self.time_ids, B=self.B, H=self.h, W=self.w)
+        scale = 1.0 / self.grad_accum
         ops.masked_mse_fwd_bwd(pred, self.noise, self.noisy, self.mask, self.timesteps, self.acp, self.sums, self.loss,
-                               self.dpred64, snr_gamma=self.snr_gamma, v_prediction=self.v_pred, loss_scale=1.0 / self.grad_accum)
+                               self.dpred64, snr_gamma=self.snr_gamma, v_prediction=self.v_pred, loss_scale=scale)
+        rt.daam_grads = None
+        if self.text is not None and self.ta_w > 0.0:  # a10/a11: token-attention loss on the hooked score maps (main.py:342-345)
+            self.ta.forward_backward(self.mask, self.w / self.h, self.ta_w * scale)
         self.dctx.zero_()
         u.backward(self.dpred64, self.dctx)
+        if self.text is not None:
+            P = self.pooled.shape[1] if self.pooled is not None else 0
+            d_pooled = u.dadd_in[:, :P] if rt.want_dpooled else None
+            self.text.backward(self.dctx, d_pooled, self.ti.grad_rows)
+            self.ti.add_regulariser()                  # a14 (only the std term is live by default, config.py:75-77)
         return pred
 
     def optimizer_step(self):
         a = self.unet.arena
         self.rt.ops.adamw_fused(a.params, a.grads, a.m, a.v, self.hyper, self.l1_sum)
         a.refresh_shadows()
+        if self.ti is not None:                        # a17: AdamW on the trainable token rows only
+            t = self.ti
+            self.rt.ops.adamw_fused(t.params, t.grads, t.m, t.v, t.hyper, None)
+            t.refresh_tables()
 
     def body(self):
         self.forward_backward()
@@ -95,7 +171,8 @@ class TrainStep:
         """Runs the body eagerly `warmup` times (allocates every persistent buffer, builds the grouped-gradient
         plan), then captures it.  AdamW state is restored afterwards so capture does not count as training."""
         a = self.unet.arena
-        snap = [t.clone() for t in (a.params, a.m, a.v)]
+        state = [a.params, a.m, a.v] + ([self.ti.params, self.ti.m, self.ti.v] if self.ti is not None else [])
+        snap = [t.clone() for t in state]
         step0 = self.opt_step
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -106,13 +183,15 @@ class TrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.body()
-        for t, c in zip((a.params, a.m, a.v), snap):
+        for t, c in zip(state, snap):
             t.copy_(c)
         a.refresh_shadows()
+        if self.ti is not None:
+            self.ti.refresh_tables()
         self.opt_step = step0
 
-    def run(self, lr):
-        self.set_hyper(lr)
+    def run(self, lr, lr_ti=0.0):
+        self.set_hyper(lr, lr_ti)
         if self.graph is not None:
             self.graph.replay()
         else:
@@ -120,4 +199,7 @@ class TrainStep:
 
     def total_loss(self):
         """img loss + L1 penalty as the reference logs it (main.py:339-361); forces a device sync."""
-        return float(self.loss) + self.l1_penalty * float(self.l1_sum) / self.unet.arena.n
+        tot = float(self.loss) + self.l1_penalty * float(self.l1_sum) / self.unet.arena.n
+        if self.text is not None:
+            tot += self.ta_w * float(self.ta.loss) + float(self.ti.reg_loss)
+        return tot

@@ -1,0 +1,55 @@
+"""Textual-inversion state: the trainable token-embedding rows of every text encoder, their AdamW moments and the
+token-std regulariser.
+
+reference: trainer/embedding_handler.py:13-62 (TokenEmbeddingsHandler: which rows are trainable),
+trainer/optimizer.py:107-155 (AdamW over the WHOLE embedding tables, weight decay ti_weight_decay = 0),
+main.py:368-371 (gradient rows [:-n_tokens] zeroed), trainer/loss.py:196-233, 254-297 (std regulariser).
+With zeroed gradients and zero weight decay every non-TI row is an exact no-op of AdamW, so only the n_tokens rows are
+stored and stepped here (pinned by tests/golden/adamw.pt: rows-only == masked full-table update).
+"""
+import torch
+
+from .unet import F32
+
+
+class TiState:
+    def __init__(self, rt, encoders, n_tok, std_loss_w=0.01):
+        self.rt, self.encoders, self.n_tok = rt, encoders, n_tok
+        sizes = [n_tok * e.D for e in encoders]
+        self.n = sum(sizes)
+        self.params, self.grads = rt.zeros(self.n, dtype=F32), rt.zeros(self.n, dtype=F32)
+        self.m, self.v = rt.zeros(self.n, dtype=F32), rt.zeros(self.n, dtype=F32)
+        self.rows, self.grad_rows, self.stats = [], [], []
+        sh, off = [], 0
+        for e, sz in zip(encoders, sizes):
+            r = self.params[off:off + sz].view(n_tok, e.D)
+            r.copy_(e.table[e.V - n_tok:].float())
+            self.rows.append(r)
+            self.grad_rows.append(self.grads[off:off + sz].view(n_tok, e.D))
+            sh.append((off, n_tok, e.D, e.D, e.table[e.V - n_tok:], None))
+            # DistributionLoss statistics of the PRETRAINED rows (loss.py:263-265)
+            pre = e.table[: e.V - n_tok].float()
+            stds = pre.std(-1)
+            self.stats.append((float(stds.mean()), float(stds.std() ** 2 / stds.mean())))
+            off += sz
+        self._plan = rt.ops.ShadowPlan(sh, rt.device)
+        self.std_loss_w = std_loss_w
+        self.reg_loss = rt.zeros(1, dtype=F32)
+        self.hyper = rt.zeros(16, dtype=F32)
+
+    def refresh_tables(self):
+        """fp32 master rows -> the bf16 embedding tables the encoders gather from."""
+        self._plan.run(self.params)
+
+    def load_rows(self, rows_per_encoder):
+        for r, src in zip(self.rows, rows_per_encoder):
+            r.copy_(src.to(self.rt.device, F32))
+        self.refresh_tables()
+
+    def add_regulariser(self):
+        """loss += std_loss_w * mean_enc( mean_tok( (sigma_bar - std(e_tok))^2 / v ) )   (loss.py:223-231); gradient
+        added to the row gradients, value accumulated in self.reg_loss."""
+        self.reg_loss.zero_()
+        w = self.std_loss_w / len(self.encoders)
+        for r, g, (tm, tv) in zip(self.rows, self.grad_rows, self.stats):
+            self.rt.ops.ti_std_reg(r, g, self.reg_loss, target_mean=tm, target_var=tv, weight=w)

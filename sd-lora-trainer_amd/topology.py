@@ -20,7 +20,7 @@ CONFIGS = {
                    layers_per_block=1, transformer_layers=(1, 1, 1), heads=(2, 2, 2), cross_dim=64, linear_proj=False,
                    addition=False, in_channels=4, out_channels=4, scaling_factor=0.18215),
     "tinyxl": dict(block_out_channels=(64, 128, 128), down_has_attn=(False, True, True), up_has_attn=(True, True, False),
-                   layers_per_block=1, transformer_layers=(1, 1, 2), heads=(1, 2, 2), cross_dim=64, linear_proj=True,
+                   layers_per_block=1, transformer_layers=(1, 1, 2), heads=(1, 2, 2), cross_dim=128, linear_proj=True,
                    addition=True, addition_time_embed_dim=32, proj_class_in=64 + 6 * 32, in_channels=4, out_channels=4,
                    scaling_factor=0.13025),
 }

@@ -39,7 +39,12 @@ class Runtime:
         self.device, self.B, self.act = torch.device(device), B, act_dtype
         self.ops = ops if ops is not None else _ops
         self.lora_problems = []      # filled by layers on their first backward
-        self.daam = []               # (name, scores fp32 [B, N, 80]) of hooked attn2 layers, reference order
+        self.daam = []               # (name, scores fp32 [B, N, CTX_PAD]) of hooked attn2 layers, reference order (keep_daam_maps)
+        self.keep_daam_maps = False  # per-layer maps are only needed for the reference's debug heat-map plots
+        self.daam_sums = {}          # tokens-per-image N -> (fp32 [B*N, CTX_PAD] sum of the hooked layers' raw scores, n_layers)
+        self.daam_grads = None       # N -> (dS bf16 [B*N, CTX_PAD], dS^T bf16 [B*CTX_PAD, N]) set by the token-attention loss
+        self.want_dpooled = False    # SDXL: back-propagate into the pooled text embedding (textual inversion)
+        self.dsemb = None
 
     def empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.act, device=self.device)
@@ -289,8 +294,8 @@ class LayerNorm(_Module):
         self.beta = sd[name + ".bias"].to(rt.device, F32).contiguous()
         self.eps = eps
 
-    def forward(self, x):
-        y = self.buf("y", *x.shape)
+    def forward(self, x, out=None):
+        y = out if out is not None else self.buf("y", *x.shape)
         self._x = x
         return self.rt.ops.layernorm_fwd(x, y, self.buf("stats", x.shape[0] * 2, dtype=F32), gamma=self.gamma, beta=self.beta, eps=self.eps)
 
@@ -301,7 +306,8 @@ class LayerNorm(_Module):
 
 # ---------------------------------------------------------------------------------------- composite blocks
 
-CTX_PAD = 80   # the 77 text tokens are stored as 80 rows per batch (16-byte aligned transposed tiles)
+CTX_PAD = 128  # the 77 text tokens are stored as 128 rows per batch: 16-byte aligned transposed tiles, a whole number of
+               # 64-wide K steps for the DAAM score-gradient GEMMs, and the row count the CLIP plan writes (clip.TP)
 
 
 class Attention(_Module):
@@ -333,11 +339,22 @@ class Attention(_Module):
         self._dims = (B, N, Nk, Nkp)
         rt.ops.attn_fwd(q, k, v, Vt, O, L, B=B, H=self.heads, Nq=N, Nk=Nk, Nqp=N, Nkp=Nkp, d=self.d, scale=self.scale)
         if self.cross and self.hooked:
-            # DAAM side output (ti_cross_attn_loss.py:201-212): sum over heads of Q_h K_h^T / sqrt(d) = Q K^T / sqrt(d)
-            S = self.buf("S", B * N, CTX_PAD, dtype=F32)
+            # DAAM side output (ti_cross_attn_loss.py:201-212): sum over heads of Q_h K_h^T / sqrt(d) = Q K^T / sqrt(d).
+            # The token-attention loss only ever uses the MEAN over layers of these maps (loss.py:23-52), so the layers
+            # of one resolution accumulate into one fp32 sum (GEMM epilogue, C += ...).
+            if N not in rt.daam_sums:
+                rt.daam_sums[N] = [rt.zeros(B * N, CTX_PAD, dtype=F32), 0, False]
+            ent = rt.daam_sums[N]
             for b in range(B):
-                rt.ops.gemm(q[b * N:(b + 1) * N], k[b * Nkp:(b + 1) * Nkp], S[b * N:(b + 1) * N], alpha=self.scale)
-            rt.daam.append((self.name, S.view(B, N, CTX_PAD)))
+                rt.ops.gemm(q[b * N:(b + 1) * N], k[b * Nkp:(b + 1) * Nkp], ent[0][b * N:(b + 1) * N], alpha=self.scale,
+                            accumulate=ent[2])
+            ent[2] = True
+            ent[1] += 1
+            if rt.keep_daam_maps:
+                S = self.buf("S", B * N, CTX_PAD, dtype=F32)
+                for b in range(B):
+                    rt.ops.gemm(q[b * N:(b + 1) * N], k[b * Nkp:(b + 1) * Nkp], S[b * N:(b + 1) * N], alpha=self.scale)
+                rt.daam.append((self.name, S.view(B, N, CTX_PAD)))
         return self.to_out.forward(O, residual=residual)
 
     def backward(self, dout, dctx=None):
@@ -358,6 +375,15 @@ class Attention(_Module):
                 kw = dict(qsplit=qs, dK32=self.buf("dk32", Mk, C, dtype=F32), dV32=self.buf("dv32", Mk, C, dtype=F32))
         rt.ops.attn_bwd(q, k, v, self._b["Kt"], self._b["Qt"], self._b["O"], self._b["L"], dO, dOt, D, dq, dk, dv,
                         B=B, H=self.heads, Nq=N, Nk=Nk, Nqp=N, Nkp=Nkp, d=self.d, scale=self.scale, **kw)
+        if self.cross and self.hooked and rt.daam_grads is not None:
+            # backward of the score side output: S = a Q K^T  ->  dQ += a dS K,  dK += a dS^T Q   (shared dS per resolution)
+            dS, dSt = rt.daam_grads[N]
+            Kt, Qt = self._b["Kt"], self._b["Qt"]
+            for b in range(B):
+                rt.ops.gemm(dS[b * N:(b + 1) * N], Kt[:, b * Nkp:(b + 1) * Nkp], dq[b * N:(b + 1) * N], residual=dq[b * N:(b + 1) * N],
+                            alpha=self.scale)
+                rt.ops.gemm(dSt[b * Nkp:(b + 1) * Nkp], Qt[:, b * N:(b + 1) * N], dk[b * Nkp:(b + 1) * Nkp], residual=dk[b * Nkp:(b + 1) * Nkp],
+                            alpha=self.scale)
         dx = self.to_q.backward(dq)
         if self.cross:
             # gradient w.r.t. the text conditioning, accumulated over every cross-attention layer
@@ -423,7 +449,7 @@ class ResnetBlock(_Module):
         self.cin1, self.cin2, self.cout = cin1, cin2, cout
         self.norm1 = GroupNorm(rt, name + ".norm1", sd, 1e-5, silu=True)
         self.conv1 = Conv3x3(rt, name + ".conv1", sd)
-        self.temb = Linear(rt, name + ".time_emb_proj", sd, need_dx=False)
+        self.temb = Linear(rt, name + ".time_emb_proj", sd)
         self.norm2 = GroupNorm(rt, name + ".norm2", sd, 1e-5, silu=True)
         self.conv2 = Conv3x3(rt, name + ".conv2", sd, arena)
         self.shortcut = None
@@ -459,6 +485,11 @@ class ResnetBlock(_Module):
         x1, x2, B, H, W = self._in
         dh2 = self.conv2.backward(dout)
         dc1 = self.norm2.backward(dh2)
+        if rt.want_dpooled:
+            # h = conv1(.) + time_emb_proj(silu(emb))[b]: d(proj output)[b] = column sums of dc1 over the pixels of image b;
+            # accumulated over all resnets into d silu(emb)
+            dtp = rt.ops.colsum(dc1, self.buf("dtp", B, self.cout), B=B, R=H * W)
+            self.temb.backward(dtp, dres=rt.dsemb, out=rt.dsemb)
         dh1 = self.conv1.backward(dc1)
         dres = dout if self.shortcut is None else self.shortcut.backward(dout, key="dsc")
         return self.norm1.backward(dh1, dres=dres)
@@ -482,8 +513,8 @@ class UNet(_Module):
         self.t1 = Linear(rt, "time_embedding.linear_1", sd, need_dx=False)
         self.t2 = Linear(rt, "time_embedding.linear_2", sd, need_dx=False)
         if cfg["addition"]:
-            self.a1 = Linear(rt, "add_embedding.linear_1", sd, need_dx=False)
-            self.a2 = Linear(rt, "add_embedding.linear_2", sd, need_dx=False)
+            self.a1 = Linear(rt, "add_embedding.linear_1", sd)
+            self.a2 = Linear(rt, "add_embedding.linear_2", sd)
         self.down, self.up = [], []
         out_c = c0
         for i, c in enumerate(boc):
@@ -526,6 +557,8 @@ class UNet(_Module):
         pooled [B, P] (act dtype), time_ids fp32 [B*6] (SDXL).  Returns eps_hat fp32 [B*H*W, 4]."""
         rt, cfg = self.rt, self.cfg
         rt.daam = []
+        for ent in rt.daam_sums.values():
+            ent[1], ent[2] = 0, False
         boc = cfg["block_out_channels"]
         te = rt.ops.timestep_embedding(timesteps_f, self.buf("te", B, boc[0]))
         e1 = self.t1.forward(te, train=False)
@@ -540,6 +573,7 @@ class UNet(_Module):
             a1 = self.a1.forward(add_in, train=False)
             emb = self.a2.forward(rt.ops.map_bf16(_ops.MAP_SILU, a1, None, self.buf("a1s", *a1.shape)), residual=emb, train=False)
         semb = rt.ops.map_bf16(_ops.MAP_SILU, emb, None, self.buf("semb", *emb.shape))
+        self._b["semb_in"] = emb
 
         h = self.conv_in.forward(x, B, H, W, train=False)
         skips = [(h, H, W)]
@@ -578,6 +612,9 @@ class UNet(_Module):
         rt, cfg = self.rt, self.cfg
         B, H, W = self._dims
         boc = cfg["block_out_channels"]
+        if rt.want_dpooled:
+            rt.dsemb = self.buf("dsemb", B, self.tdim, zero=True)
+            rt.dsemb.zero_()
         dh = self.norm_out.backward(self.conv_out.backward(dpred64))
         skip_grads = []
         nlev = len(boc)
@@ -609,6 +646,13 @@ class UNet(_Module):
                     dh = att[j].backward(dh, dctx)
                 dh = res[j].backward(dh)
         # conv_in's own skip gradient and dX are not needed (its input is data, no adapter upstream)
+        if rt.want_dpooled:
+            # emb = time_embedding(t) + add_embedding([pooled | sinusoid(time_ids)]); only the pooled text embedding is trainable
+            # upstream (textual inversion through text_encoder_2), so the timestep branch gets no backward.
+            demb = rt.ops.map_bf16(_ops.MAP_DSILU, self._b["semb_in"], rt.dsemb, self.buf("demb", B, self.tdim))
+            da1s = self.a2.backward(demb)
+            da1 = rt.ops.map_bf16(_ops.MAP_DSILU, self.a1._b["y"], da1s, self.buf("da1", *da1s.shape))
+            self.dadd_in = self.a1.backward(da1)
         if self.arena is not None:
             if self._grad_plan is None:
                 self._grad_plan = rt.ops.LoraGradPlan(rt.lora_problems, self.arena.Rp, rt.device)

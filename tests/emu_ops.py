@@ -43,7 +43,7 @@ def _conv_apply(X, Wm, g):
 
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
-         residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0):
+         residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False):
     acc = X.float() @ W.float().t() if conv is None else _conv_apply(X, W, conv)
     if X2 is not None:
         acc = acc + X2.float() @ W2.float().t()
@@ -62,6 +62,8 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
         acc = acc + rowbias.float()[idx]
     if residual is not None:
         acc = acc + residual.float()
+    if accumulate:
+        acc = acc + out.float()
     out.copy_(acc.to(out.dtype))
     if Ct is not None:
         Ct[:, : acc.shape[0]].copy_(acc.t().to(Ct.dtype))
@@ -288,5 +290,27 @@ def sum2x2(inp, out, *, B, H, W):
 
 
 def colsum(x, out, *, B, R):
-    out.copy_(x.float().reshape(B, R, -1).sum(1))
+    out.copy_(x.float().reshape(B, R, -1).sum(1).to(out.dtype))
     return out
+
+
+def embed_gather(table, ids, pos, out, *, B, T, Tp):
+    out.zero_()
+    emb = table.float()[ids.reshape(B, T)] + pos.float()[:T][None]
+    out.view(B, Tp, -1)[:, :T].copy_(emb.to(out.dtype))
+    return out
+
+
+def embed_grad(dx, ids, train_ids, grad, *, B, T, Tp, accumulate=False):
+    d = dx.float().reshape(B, Tp, -1)[:, :T]
+    g = torch.stack([(d * (ids.reshape(B, T) == int(t))[..., None]).sum(dim=(0, 1)) for t in train_ids])
+    grad.copy_(grad + g if accumulate else g)
+    return grad
+
+
+def ti_std_reg(rows, grad, loss_out, *, target_mean, target_var, weight):
+    r = rows.detach().clone().requires_grad_(True)
+    loss = weight * ((target_mean - r.std(-1)) ** 2 / target_var).mean()
+    (g,) = torch.autograd.grad(loss, r)
+    grad.add_(g)
+    loss_out.add_(float(loss))

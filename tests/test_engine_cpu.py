@@ -58,6 +58,7 @@ def test_engine_matches_oracle_autograd(version, B, gamma):
     pred_o, loss_o, grads_o, gctx_o = _oracle_step(cfg, sd, lora, rank, latent, noise, t, mask, ctx, add, gamma, 0.0)
 
     rt = unet_mod.Runtime("cpu", B, act_dtype=torch.float32, ops=emu_ops)
+    rt.keep_daam_maps = True
     unet = unet_mod.UNet(rt, topology.CONFIGS[version], sd, lora_rank=rank)
     unet.arena.load(lora)
     ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=gamma, l1_penalty=0.0, weight_decay=0.0)
@@ -81,6 +82,11 @@ def test_engine_matches_oracle_autograd(version, B, gamma):
     assert [n for n, _ in rt.daam] == [n for n, _ in daam_o]
     for (_, s), (_, so) in zip(rt.daam, daam_o):
         torch.testing.assert_close(s[:, :, :77], so, rtol=1e-3, atol=1e-3)
+    # per-resolution sums of the hooked maps (what the token-attention loss consumes)
+    for N, (ssum, nl, _) in rt.daam_sums.items():
+        ref = sum(so for _, so in daam_o if so.shape[1] == N)
+        assert nl == sum(1 for _, so in daam_o if so.shape[1] == N)
+        torch.testing.assert_close(ssum.view(B, N, -1)[:, :, :77], ref, rtol=1e-3, atol=1e-3)
 
     # one AdamW step with L1 (main.py:353-356) against the oracle restatement
     ts.l1_penalty, ts.wd = 0.03, 0.004

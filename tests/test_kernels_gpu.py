@@ -374,3 +374,36 @@ def test_adamw_and_shadows(ops):
     ops.ShadowPlan(ent_g, torch.device("cuda")).run(ad)
     for c_, g_ in zip(ent_c, ent_g):
         assert torch.equal(g_[4].cpu(), c_[4]) and torch.equal(g_[5].cpu(), c_[5])
+
+
+def test_ti_kernels_and_gemm_accumulate(ops):
+    g = torch.Generator().manual_seed(31)
+    B, T, Tp, D, V, n = 2, 77, 128, 768, 500, 3
+    table, pos = rnd(V, D, g=g), rnd(T, D, g=g, scale=0.1)
+    ids = torch.randint(0, V - n, (B, T), generator=g)
+    ids[0, 3:6] = torch.tensor([V - 3, V - 2, V - 1])
+    ids[1, 9] = V - 2
+    ref = E.embed_gather(table, ids, pos, torch.empty(B * Tp, D, dtype=BF), B=B, T=T, Tp=Tp)
+    got = ops.embed_gather(table.cuda(), ids.cuda(), pos.cuda(), torch.full((B * Tp, D), 9.0, dtype=BF, device="cuda"), B=B, T=T, Tp=Tp)
+    close(got, ref, what="embed_gather")
+    dx = rnd(B * Tp, D, g=g)
+    train = torch.arange(V - n, V)
+    gref = E.embed_grad(dx, ids, train, torch.zeros(n, D), B=B, T=T, Tp=Tp)
+    ggot = ops.embed_grad(dx.cuda(), ids.cuda(), train.cuda(), torch.full((n, D), 5.0, device="cuda"), B=B, T=T, Tp=Tp)
+    close(ggot, gref, tol=1e-5, what="embed_grad")
+    rows = torch.randn(n, D, generator=g) * 0.02
+    gr_c, lo_c = torch.zeros(n, D), torch.zeros(1)
+    E.ti_std_reg(rows, gr_c, lo_c, target_mean=0.015, target_var=3e-4, weight=0.005)
+    gr_g, lo_g = torch.zeros(n, D, device="cuda"), torch.zeros(1, device="cuda")
+    ops.ti_std_reg(rows.cuda(), gr_g, lo_g, target_mean=0.015, target_var=3e-4, weight=0.005)
+    close(gr_g, gr_c, tol=1e-4, what="ti_std_reg grad")
+    close(lo_g, lo_c, tol=1e-4, what="ti_std_reg loss")
+    # fp32 accumulate epilogue (DAAM score sums) and N = 128 padded text axis
+    X, W = rnd(300, 128, g=g), rnd(128, 128, g=g, scale=0.1)
+    acc_c, acc_g = torch.zeros(300, 128), torch.zeros(300, 128, device="cuda")
+    for i in range(3):
+        E.gemm(X, W, acc_c, alpha=0.125, accumulate=i > 0)
+        ops.gemm(X.cuda(), W.cuda(), acc_g, alpha=0.125, accumulate=i > 0)
+    close(acc_g, acc_c, tol=2e-3, what="gemm fp32 accumulate")
+    xs = rnd(2 * 100, 128, g=g)
+    close(ops.colsum(xs.cuda(), torch.empty(2, 128, dtype=BF, device="cuda"), B=2, R=100), E.colsum(xs, torch.empty(2, 128, dtype=BF), B=2, R=100), what="colsum bf16")

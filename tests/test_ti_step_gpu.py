@@ -1,0 +1,98 @@
+"""End-to-end textual-inversion step on the MI355X (bf16 HIP path) against the fp32 oracle (transformers CLIP +
+oracle/unet_ref.py + oracle/loss_ref.py): TI-row gradients, LoRA gradients, losses; then hipGraph replays train.
+Tolerances as tests/test_step_gpu.py (bf16 noise floor): cosine >= 0.99, relative L2 <= 8e-2, losses 2e-2."""
+import pytest
+import torch
+
+from tests.test_ti_step_cpu import EOS, NTOK, TRAIN_IDS, _captions, _hf
+
+pytestmark = pytest.mark.gpu
+
+
+def _cos_rel(a, b):
+    a, b = a.reshape(-1).double().cpu(), b.reshape(-1).double().cpu()
+    return float(a @ b / (a.norm() * b.norm() + 1e-30)), float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("version,B", [("tiny15", 2), ("tinyxl", 2)])
+def test_ti_step_gpu_matches_oracle(version, B):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import loss_ref as L
+    from oracle import unet_ref as U
+    import sd_lora_trainer_amd.clip as clip_mod
+    import sd_lora_trainer_amd.step as step_mod
+    import sd_lora_trainer_amd.unet as unet_mod
+    from sd_lora_trainer_amd import topology
+    cfg = U.CONFIGS[version]
+    xl = cfg["addition"]
+    rank, h, w_ta, w_std = 4, 16, 2e-2, 0.01
+    sd = U.init_unet_state(cfg, seed=0)
+    lora = U.init_lora(cfg, rank, seed=1, b_std=0.05)
+    hf = ([_hf("quick_gelu", False, 64, 1, 11), _hf("gelu", True, 64, 1, 12, proj=cfg["proj_class_in"] - 6 * cfg["addition_time_embed_dim"])]
+          if xl else [_hf("quick_gelu", False, 64, 2, 11)])
+    g = torch.Generator().manual_seed(3)
+    latent = torch.randn(B, 4, h, h, generator=g) * cfg["scaling_factor"]
+    noise = torch.randn(B, 4, h, h, generator=g)
+    mask = (torch.rand(B, 1, h, h, generator=g) * 0.95 + 0.05).repeat(1, 4, 1, 1).contiguous()
+    t = torch.tensor([10, 900][:B])
+    tid = torch.tensor([[1024., 1024, 0, 0, 128, 128]] * B) if xl else None
+    lists, ids = _captions(B)
+    # the HIP path stores tables/weights in bf16: round the oracle's CLIP weights the same way so both see the same model
+    for m in hf:
+        for p in m.parameters():
+            p.data = p.data.to(torch.bfloat16).float()
+    embs = [m.get_input_embeddings().weight for m in hf]
+    outs = [m(input_ids=ids, output_hidden_states=True) for m in hf]
+    if xl:
+        ctx = torch.cat([outs[0].hidden_states[-2], outs[1].hidden_states[-2]], dim=-1)
+        add = {"text_embeds": outs[1].text_embeds, "time_ids": tid}
+    else:
+        ctx, add = outs[0].last_hidden_state, None
+    lora_g, params = {}, []
+    for k, (A, Bm) in lora.items():
+        A, Bm = A.clone().requires_grad_(True), Bm.clone().requires_grad_(True)
+        lora_g[k] = (A, Bm)
+        params += [A, Bm]
+    acp = L.ddpm_alphas_cumprod()
+    noisy = L.add_noise(acp, latent, noise, t)
+    pred, daam = U.unet_forward(cfg, sd, noisy, t, ctx, add, lora=lora_g, return_daam=True)
+    img_loss = L.diffusion_loss(pred, noise, noisy, mask, acp, t, snr_gamma=5.0)
+    ta = L.token_attention_loss(L.daam_stack([s for _, s in daam], 1.0), mask, lists, TRAIN_IDS)
+    reg = torch.stack([L.DistributionStats(e.detach()[:-NTOK]).std_loss(e[-NTOK:]) for e in embs]).mean()
+    grads = torch.autograd.grad(img_loss + w_ta * ta + w_std * reg, params + embs)
+    g_lora = torch.cat([x.reshape(-1) for x in grads[:len(params)]])
+    g_rows = [ge[-NTOK:] for ge in grads[len(params):]]
+
+    rt = unet_mod.Runtime("cuda:0", B)
+    unet = unet_mod.UNet(rt, topology.CONFIGS[version], sd, lora_rank=rank)
+    unet.arena.load(lora)
+    sds = [{k: v.detach() for k, v in m.state_dict().items()} for m in hf]
+    if xl:
+        encs = [clip_mod.ClipTextEncoder(rt, "te1", sds[0], heads=1, act="quick_gelu", mode="penultimate", with_projection=False, n_train=NTOK),
+                clip_mod.ClipTextEncoder(rt, "te2", sds[1], heads=1, act="gelu", mode="penultimate", with_projection=True, n_train=NTOK)]
+    else:
+        encs = [clip_mod.ClipTextEncoder(rt, "te1", sds[0], heads=2, act="quick_gelu", mode="last", with_projection=False, n_train=NTOK)]
+    text = step_mod.TextStack(rt, encs, pool_mode="first_eos", eos_token_id=EOS)
+    ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, l1_penalty=0.0, weight_decay=0.0, text=text, n_tokens=NTOK,
+                            token_attention_loss_w=w_ta, ti_std_loss_w=w_std)
+    ts.set_batch(latent.cuda(), noise.cuda(), t.cuda(), mask.cuda(), time_ids=tid.cuda() if xl else None, ids=[ids] * len(encs),
+                 caption_token_lists=lists)
+    ts.forward_backward()
+    torch.cuda.synchronize()
+    assert abs(float(ts.loss) - float(img_loss)) <= 2e-2 * float(img_loss)
+    assert abs(float(ts.ta.loss) - float(ta)) <= 3e-2 * abs(float(ta))
+    assert abs(float(ts.ti.reg_loss) - w_std * float(reg)) <= 2e-2 * w_std * float(reg)
+    got_lora = torch.cat([x.reshape(-1) for k in unet.arena.export("grads").values() for x in k])
+    cos, rel = _cos_rel(got_lora, g_lora)
+    assert cos >= 0.99 and rel <= 8e-2, f"LoRA grads cos {cos} rel {rel}"
+    for got, ref in zip(ts.ti.grad_rows, g_rows):
+        cos, rel = _cos_rel(got, ref)
+        assert cos >= 0.985 and rel <= 0.12, f"TI row grads cos {cos} rel {rel}"
+    # graph replays: the loss of a fixed batch goes down when both LoRA and the token rows are trained
+    ts.capture(warmup=1)
+    losses = []
+    for i in range(6):
+        ts.run(1e-3, lr_ti=1e-3)
+        losses.append(ts.total_loss())
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
