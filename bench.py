@@ -48,6 +48,24 @@ def make_state(cfg, device, seed):
     return sd
 
 
+def make_clip_state(c, device, seed, n_new):
+    from sd_lora_trainer_amd import topology
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for n, shp in topology.clip_param_shapes(c, n_new).items():
+        t = torch.randn(shp, generator=g, device=device, dtype=torch.float32)
+        if "embedding" in n:
+            t *= 0.02
+        elif len(shp) == 2:
+            t *= 1.0 / math.sqrt(shp[1])
+        else:
+            t *= 0.02
+            if "layer_norm" in n and n.endswith(".weight"):
+                t += 1.0
+        sd[n] = t
+    return sd
+
+
 def lr_at(step, max_steps, unet_lr=1e-3, base=5e-5):
     """LoRA learning-rate schedule of the reference (main.py:236-240, 268-291; warm-up = max_train_steps)."""
     return base * (unet_lr / base) ** (step / max_steps)
@@ -100,6 +118,7 @@ def main():
     ap.add_argument("--rank", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-ti", action="store_true", help="inject the text conditioning instead of running the text encoders + TI")
     args = ap.parse_args()
 
     from sd_lora_trainer_amd import parallel
@@ -127,7 +146,23 @@ def main():
         e["A"].copy_(torch.randn(e["A"].shape, generator=g, device=device) / args.rank)
         e["B"].zero_()
     arena.refresh_shadows()
-    ts = S.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, l1_penalty=0.03, weight_decay=0.004)
+    text, n_tok = None, 3
+    clip_flops = 0.0
+    if not args.no_ti:
+        import sd_lora_trainer_amd.clip as CL
+        tiny = version.startswith("tiny")
+        kinds = (["tiny_l", "tiny_g"] if tiny else ["clip_l", "clip_g"]) if cfg["addition"] else (["tiny_l"] if tiny else ["clip_l"])
+        encs = []
+        for i, kd in enumerate(kinds):
+            c = topology.CLIP_CONFIGS[kd]
+            csd = make_clip_state(c, device, seed=1000 + 10 * rank + i, n_new=n_tok)
+            mode = "penultimate" if cfg["addition"] else "last"
+            enc = CL.ClipTextEncoder(rt, f"te{i + 1}", csd, heads=c["heads"], act=c["act"], mode=mode, with_projection=bool(c["proj"]), n_train=n_tok)
+            encs.append(enc)
+            clip_flops += topology.clip_fwd_flops(c, B, layers_run=enc.n_run)
+            del csd
+        text = S.TextStack(rt, encs, pool_mode="argmax")
+    ts = S.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, l1_penalty=0.03, weight_decay=0.004, text=text, n_tokens=n_tok)
     rn = lambda *s: torch.randn(*s, generator=g, device=device)  # noqa: E731
     latent = rn(B, 4, h, h) * cfg["scaling_factor"]
     noise = rn(B, 4, h, h)
@@ -138,12 +173,24 @@ def main():
     if cfg["addition"]:
         pooled = rn(B, cfg["proj_class_in"] - 6 * cfg["addition_time_embed_dim"])
         tid = torch.tensor([[1024., 1024, 0, 0, float(res), float(res)]] * B, device=device)
-    ts.set_batch(latent, noise, timesteps, mask, ctx, pooled, tid)
+    if text is None:
+        ts.set_batch(latent, noise, timesteps, mask, ctx, pooled, tid)
+    else:
+        vocab = text.encoders[0].V
+        tok = [vocab - 3, vocab - 2, vocab - 1]
+        lists, ids = [], torch.full((B, 77), 49407 if vocab > 49407 else vocab - 4, dtype=torch.int64)
+        for b in range(B):   # "a photo of <s0><s1><s2> ..." style caption: BOS, 8 words, the 3 TI tokens, EOS, padding
+            words = torch.randint(1000 if vocab > 2000 else 10, min(40000, vocab - 10), (8,)).tolist()
+            l = [49406 if vocab > 49407 else vocab - 5] + words[:4] + tok + words[4:] + [49407 if vocab > 49407 else vocab - 4]
+            ids[b, :len(l)] = torch.tensor(l)
+            lists.append(l)
+        ts.set_batch(latent, noise, timesteps, mask, time_ids=tid, ids=[ids] * len(text.encoders), caption_token_lists=lists)
     if not args.no_graph:
         ts.capture(warmup=2)
     total = args.warmup + args.steps
+    ti_lr = 1e-3 if text is not None else 0.0
     for i in range(args.warmup):
-        ts.run(lr_at(i, total))
+        ts.run(lr_at(i, total), ti_lr * (1 - i / total) ** 1.7)
 
     barrier = parallel.barrier_sync
     barrier()
@@ -151,7 +198,7 @@ def main():
     t0 = time.perf_counter()
     ev0.record()
     for i in range(args.steps):
-        ts.run(lr_at(args.warmup + i, total))
+        ts.run(lr_at(args.warmup + i, total), ti_lr * (1 - (args.warmup + i) / total) ** 1.7)     # main.py:271-274
     ev1.record()
     barrier()
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device)
@@ -171,8 +218,10 @@ def main():
             "ms_per_step": t_step * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{version} {res}x{res} LoRA rank {args.rank} batch {B}/GPU, UNet fwd+bwd+AdamW(+L1), "
-                                   "text conditioning injected (CLIP/TI path not in this round's step)",
+            "config": {"workload": f"{version} {res}x{res} LoRA rank {args.rank} batch {B}/GPU: UNet fwd+bwd, masked/min-SNR MSE, L1, AdamW"
+                                   + (", + textual inversion (text encoders fwd+bwd with 3 trainable tokens, token-attention loss, "
+                                      "std regulariser, rows-only AdamW)" if text is not None else ", text conditioning injected (--no-ti)"),
+                       "text_encoder_fwd_gflop_not_in_roofline": clip_flops / 1e9,
                        "global_batch": world * B, "parallelism": f"job-parallel x{world} (independent jobs, no collective)",
                        "lora_params": arena.n, "graph": not args.no_graph, "final_loss": loss},
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
@@ -181,7 +230,7 @@ def main():
                                  "per hipGraph replay (HIP events on the replay stream)"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            sample_hw = 64 if "xl" in version or version == "sd15" else h
+            sample_hw = 32 if "xl" in version or version == "sd15" else h
             dt, f_sample = cpu_baseline(version, args.rank, sample_hw)
             scaled = dt * (f_step / B) / f_sample       # seconds per full-size image on this host
             out["cpu_baseline"] = {"value": 1.0 / scaled, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",

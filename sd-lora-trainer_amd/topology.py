@@ -176,3 +176,46 @@ def fwd_flops(cfg, B, H, W, rank=16, n_ctx=77):
 
 def n_params(cfg):
     return sum(math.prod(s) for s in param_shapes(cfg).values())
+
+
+# ---------------------------------------------------------------------------------------------- text encoders
+# OpenAI CLIP ViT-L/14 text tower (SD1.5 + SDXL text_encoder) and OpenCLIP ViT-bigG/14 text tower (SDXL text_encoder_2)
+CLIP_CONFIGS = {
+    "clip_l": dict(vocab=49408, width=768, layers=12, heads=12, mlp=3072, act="quick_gelu", proj=None),
+    "clip_g": dict(vocab=49408, width=1280, layers=32, heads=20, mlp=5120, act="gelu", proj=1280),
+    "tiny_l": dict(vocab=1000, width=64, layers=2, heads=1, mlp=128, act="quick_gelu", proj=None),
+    "tiny_g": dict(vocab=1000, width=64, layers=3, heads=1, mlp=128, act="gelu", proj=64),
+}
+
+
+def clip_param_shapes(c, n_new_tokens=0, prefix="text_model."):
+    """Hugging Face CLIPTextModel(WithProjection) state-dict names -> shapes (vocab grown by the TI tokens,
+    embedding_handler.py:157-223)."""
+    P = OrderedDict()
+    D = c["width"]
+    P[prefix + "embeddings.token_embedding.weight"] = (c["vocab"] + n_new_tokens, D)
+    P[prefix + "embeddings.position_embedding.weight"] = (77, D)
+    for i in range(c["layers"]):
+        b = f"{prefix}encoder.layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            P[b + f"self_attn.{nm}.weight"] = (D, D)
+            P[b + f"self_attn.{nm}.bias"] = (D,)
+        for ln in ("layer_norm1", "layer_norm2"):
+            P[b + ln + ".weight"] = (D,)
+            P[b + ln + ".bias"] = (D,)
+        P[b + "mlp.fc1.weight"] = (c["mlp"], D)
+        P[b + "mlp.fc1.bias"] = (c["mlp"],)
+        P[b + "mlp.fc2.weight"] = (D, c["mlp"])
+        P[b + "mlp.fc2.bias"] = (D,)
+    P[prefix + "final_layer_norm.weight"] = (D,)
+    P[prefix + "final_layer_norm.bias"] = (D,)
+    if c["proj"]:
+        P["text_projection.weight"] = (c["proj"], D)
+    return P
+
+
+def clip_fwd_flops(c, B, layers_run=None, T=77):
+    """2*MAC of one text-encoder forward over T tokens (projections, MLP, causal attention counted dense)."""
+    D, L = c["width"], (layers_run if layers_run is not None else c["layers"])
+    per_layer = 2.0 * B * T * (4 * D * D + 2 * D * c["mlp"]) + 4.0 * B * T * T * D
+    return L * per_layer

@@ -26,7 +26,8 @@ def test_ti_step_gpu_matches_oracle(version, B):
     from sd_lora_trainer_amd import topology
     cfg = U.CONFIGS[version]
     xl = cfg["addition"]
-    rank, h, w_ta, w_std = 4, 16, 2e-2, 0.01
+    rank, w_ta, w_std = 4, 2e-2, 0.01
+    h = 32 if xl else 16      # every hooked map needs a multiple of 64 tokens (K of the score-gradient GEMMs)
     sd = U.init_unet_state(cfg, seed=0)
     lora = U.init_lora(cfg, rank, seed=1, b_std=0.05)
     hf = ([_hf("quick_gelu", False, 64, 1, 11), _hf("gelu", True, 64, 1, 12, proj=cfg["proj_class_in"] - 6 * cfg["addition_time_embed_dim"])]
@@ -36,7 +37,7 @@ def test_ti_step_gpu_matches_oracle(version, B):
     noise = torch.randn(B, 4, h, h, generator=g)
     mask = (torch.rand(B, 1, h, h, generator=g) * 0.95 + 0.05).repeat(1, 4, 1, 1).contiguous()
     t = torch.tensor([10, 900][:B])
-    tid = torch.tensor([[1024., 1024, 0, 0, 128, 128]] * B) if xl else None
+    tid = torch.tensor([[1024., 1024, 0, 0, 8. * h, 8. * h]] * B) if xl else None
     lists, ids = _captions(B)
     # the HIP path stores tables/weights in bf16: round the oracle's CLIP weights the same way so both see the same model
     for m in hf:
