@@ -35,7 +35,7 @@ int sdlt_struct_size(int which); /* 0 gemm, 1 lora_grad_desc, 2 attn, 3 groupnor
  * K, K2 multiples of 64; lora_R (padded rank) in {0,16,32,64}; Adown [lora_R,K], Bup [N,lora_R].
  * T_out (optional) receives s*X.Adown^T as bf16 [M,lora_R] (needed by the LoRA weight gradients).
  * tile: 0 = auto, 1 = 128x128 (8 waves), 2 = 64x128 (8 waves), 3 = 64x64 (4 waves), 4 = 256x128 (8 waves),
- *       5 = 128x128 (4 waves)   (rows x cols of C per workgroup).
+ *       5 = 128x128 (4 waves), 6 = 256x256 (8 waves)   (rows x cols of C per workgroup).
  * splitk: small-M problems leave most of the 256 CUs idle; the K loop is then split over several workgroups per
  *         tile whose fp32 partials meet in ws_slab; the last arriver (ws_cnt ticket, agent-scope release/acquire)
  *         reduces them and runs the epilogue - no extra launch.
@@ -227,7 +227,8 @@ int sdlt_ti_std_reg(const float* rows, int32_t n, int32_t D, float target_mean, 
 
 /* dX of nearest-2x upsampling: out[b,h,w,:] = sum of the 2x2 block of in [B,2H,2W,C]. */
 int sdlt_sum2x2(const void* in, int32_t B, int32_t H, int32_t W, int32_t C, void* out, void* stream);
-/* out[b,c] = sum_r x[b*R + r, c] (fp32 and/or bf16 [B,C], either may be NULL) - gradient of the per-batch
+/* out[b,c] = sum_r x[b*R + r, c]: fp32 [B,C] (always written; doubles as the reduction scratch) and optionally a bf16 copy -
+ * gradient of the per-batch
  * time-embedding bias of a ResnetBlock2D (h + time_emb_proj(silu(temb))[:, :, None, None]). */
 int sdlt_colsum(const void* x, int64_t ldx, int32_t B, int32_t R, int32_t C, float* out, void* out_bf16, void* stream);
 

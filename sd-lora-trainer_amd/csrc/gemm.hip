@@ -456,7 +456,9 @@ int launch(const sdlt_gemm_params& p, hipStream_t stream) {
   // otherwise as deep as 160 KB allows, up to 4.
   constexpr int NS = NSREQ <= 2 ? NSREQ : ((4 * STAGE + TSH <= 160 * 1024) ? 4 : ((3 * STAGE + TSH <= 160 * 1024) ? 3 : 2));
   constexpr int NBUF = NS == 1 ? 2 : NS;
-  static_assert(NBUF * STAGE + TSH <= 160 * 1024, "LDS budget");
+  if constexpr (NBUF * STAGE + TSH > 160 * 1024) {
+    SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: tile %dx%d with LoRA rank pad %d does not fit the 160 KB LDS", BM, BN, R16 * 16);
+  } else {
   const int smem = NBUF * STAGE + TSH;
   static bool attr_set = false;
   if (!attr_set) {
@@ -472,15 +474,18 @@ int launch(const sdlt_gemm_params& p, hipStream_t stream) {
       SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: split-K workspace too small (%d tiles x %d splits x %zu B)", nbm * nbn, splitk, slab_bytes);
   }
   hipLaunchKernelGGL((gemm_kernel<MI, NI, WN, MODE, R16, NS>), dim3(nbm * nbn * splitk), dim3(NTHR), smem, stream, p);
+  }
   return SDLT_OK;
 }
 
-// tile ids: 1 = 128x128 (8 waves), 2 = 64x128 (8 waves), 3 = 64x64 (4 waves), 4 = 256x128 (8 waves), 5 = 128x128 (4 waves)
+// tile ids: 1 = 128x128 (8 waves), 2 = 64x128 (8 waves), 3 = 64x64 (4 waves), 4 = 256x128 (8 waves), 5 = 128x128 (4 waves),
+//           6 = 256x256 (8 waves)
 void tile_dims(int tile, int& bm, int& bn) {
   switch (tile) {
     case 1: case 5: bm = 128; bn = 128; break;
     case 2: bm = 64; bn = 128; break;
     case 4: bm = 256; bn = 128; break;
+    case 6: bm = 256; bn = 256; break;
     default: bm = 64; bn = 64; break;
   }
 }
@@ -497,11 +502,12 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     if (p.M <= 64) p.tile = p.N > 64 ? 2 : 3;
     else if (p.N <= 64) p.tile = 3;
-    else if (t128 >= 512) { p.tile = 1; if (!p.stages) p.stages = 2; }
+    else if (t128 >= 320) { p.tile = 1; if (!p.stages) p.stages = 2; }
     else if (t128 >= 160) {
       if (ktot <= 2560) { p.tile = 3; if (!p.stages) p.stages = 2; }
       else p.tile = 1;
-    } else if (ktot <= 2560) { p.tile = 2; if (!p.splitk) p.splitk = 1; }
+    } else if (ktot <= 2560 && t128 > 32) { p.tile = 2; if (!p.splitk) p.splitk = 1; }
+    else if (ktot <= 2560) p.tile = 2;
     else p.tile = 1;
   }
   int bm, bn;
@@ -513,7 +519,8 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
     int sk = 1;
     if (p.ws_slab && p.ws_cnt && tiles <= 96) {
       sk = (int)((256 + tiles / 2) / tiles);
-      if (sk > nk / 8) sk = nk / 8;
+      const int min_steps = tiles <= 32 ? 3 : 8;    // a handful of tiles (text encoders, M = 128): latency-bound, split harder
+      if (sk > nk / min_steps) sk = nk / min_steps;
       if (sk > 16) sk = 16;
       if (sk < 1) sk = 1;
     }
@@ -526,6 +533,7 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
     case 3: return launch<2, 2, 2, MODE, R16, NSV>(p, s);            \
     case 4: return launch<8, 2, 4, MODE, R16, NSV>(p, s);            \
     case 5: return launch<4, 4, 2, MODE, R16, NSV>(p, s);            \
+    case 6: return launch<8, 4, 4, MODE, R16, NSV>(p, s);            \
   }
   // (stages == 1, the register-staged loader, is kept in the kernel source but not instantiated: hipcc places its
   //  staging registers in scratch - measured 3-6x slower than the LDS-DMA ring on every SDXL shape.)

@@ -379,12 +379,23 @@ def sum2x2(inp, out, *, B, H, W):
     return out
 
 
+_colsum_scratch = {}
+
+
 def colsum(x, out, *, B, R):
     """out[b, c] = sum over the R rows of batch b of x[:, c]; out is fp32 or bf16 [B, C]."""
     lib = _lib.load()
     _chk2(x)
     assert out.is_cuda and out.dtype in (F32, BF16) and out.is_contiguous()
-    f, h = (_p(out), C.c_void_p(0)) if out.dtype == F32 else (C.c_void_p(0), _p(out))
+    if out.dtype == F32:
+        f, h = _p(out), C.c_void_p(0)
+    else:
+        key = (x.device, out.data_ptr())
+        sc = _colsum_scratch.get(key)
+        if sc is None:
+            sc = torch.empty(out.shape, dtype=F32, device=x.device)
+            _colsum_scratch[key] = sc
+        f, h = _p(sc), _p(out)
     _lib.check(lib.sdlt_colsum(_p(x), _ld(x), B, R, x.shape[1], f, h, _stream()), "sdlt_colsum")
     return out
 

@@ -37,10 +37,11 @@ if __name__ == "__main__":
               ("conv C640 64x64", 4096, 640, 9 * 640, False, ops.ConvGeom(1, 64, 64, 640, 64, 64)),
               ("conv C320 128x128", 16384, 320, 9 * 320, False, ops.ConvGeom(1, 128, 128, 320, 128, 128)),
               ("conv up 2560->1280", 1024, 1280, 9 * 2560, False, ops.ConvGeom(1, 32, 32, 2560, 32, 32)),
-              ("temb M=1", 1, 1280, 1280, False, None)]
+              ("temb M=1", 1, 1280, 1280, False, None), ("clip M=128", 128, 1280, 1280, False, None), ("clip mlp M=128", 128, 5120, 1280, False, None),
+              ("big 8192^2 K5120", 8192, 8192, 5120, False, None)]
     for (name, M, N, K, lora, conv) in shapes:
         res = []
-        for tile in (1, 2, 3, 4, 5):
+        for tile in (1, 2, 3, 4, 6):
             for st in (0, 2):
                 try:
                     us = bench(M, N, K, tile, 1, lora, conv, stages=st)
