@@ -192,6 +192,27 @@ def main():
     torch.save(dict(traj=traj, table0=t0, table_grads=tgrads, table_final=table.detach().clone(), n_tokens=3),
                os.path.join(OUT, "adamw.pt"))
 
+    # ---- (ix) TrainingConfig derived-field snapshots for every shipped train_configs/*.json -----------
+    import glob
+    import json
+    import tempfile
+    import trainer.config as rconfig
+    snaps = {}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)                      # the reference mkdirs output_dir relative to the cwd
+        try:
+            for f in sorted(glob.glob(os.path.join(REF, "train_configs", "*.json"))):
+                c = rconfig.TrainingConfig.from_json(f)
+                d = c.dict()
+                for k in ("output_dir", "start_time", "seed", "device", "job_time"):     # time / host dependent
+                    d.pop(k, None)
+                snaps[os.path.basename(f)] = {"input": json.load(open(f)), "derived": d}
+        finally:
+            os.chdir(cwd)
+    with open(os.path.join(OUT, "config_snapshots.json"), "w") as fh:
+        json.dump(snaps, fh, indent=1, sort_keys=True)
+
     print("golden fixtures written to", os.path.normpath(OUT))
     for f in sorted(os.listdir(OUT)):
         print(" ", f, os.path.getsize(os.path.join(OUT, f)))

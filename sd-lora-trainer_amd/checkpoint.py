@@ -1,0 +1,81 @@
+"""Checkpoint writer in the reference's on-disk contract (trainer/checkpoint.py:104-221, 84-102;
+trainer/embedding_handler.py:401-422), consumed by stock ComfyUI `LoraLoader` + `embedding:NAME` and A1111:
+
+  {name}_{ver}_lora.safetensors        kohya keys  lora_unet_<module path, '.'->'_'>.lora_down.weight [r,Cin(,3,3)]
+                                                   ....lora_up.weight [Cout,r(,1,1)]   ....alpha (scalar = r)
+  {name}_{ver}_embeddings.safetensors  clip_l [n,768] (+ clip_g [n,1280] for SDXL)
+  special_params.json                  {"TOK": "<s0><s1><s2>"}
+  training_args.json                   the TrainingConfig
+
+The peft -> diffusers -> kohya key conversion the reference delegates to diffusers/peft (not installed here) is restated:
+peft `base_model.model.<path>.lora_A.weight` -> kohya `lora_unet_<path_>.lora_down.weight`, with the reference's own
+`base_model_model_` strip (checkpoint.py:93-100); alpha follows diffusers' `convert_state_dict_to_kohya`
+(= number of rows of lora_down, i.e. the rank) [3P-unverified, SURVEY.md 8f-1].
+"""
+import json
+import os
+
+import torch
+from safetensors.torch import load_file, save_file
+
+from .config import remove_delimiter_characters
+
+
+def kohya_key(module_path: str) -> str:
+    return "lora_unet_" + module_path.replace(".", "_")
+
+
+def lora_to_kohya(lora_dict, dtype=torch.float16):
+    """lora_dict: module -> (A, B) in peft layout (LoraArena.export()).  Returns the kohya state dict."""
+    sd = {}
+    for mod, (A, B) in lora_dict.items():
+        k = kohya_key(mod)
+        sd[k + ".lora_down.weight"] = A.detach().to(dtype).contiguous()
+        sd[k + ".lora_up.weight"] = B.detach().to(dtype).contiguous()
+        sd[k + ".alpha"] = torch.tensor(float(A.shape[0]))
+    return sd
+
+
+def kohya_to_lora(sd):
+    """Inverse of lora_to_kohya for a given set of module paths is ambiguous ('_' vs '.'); callers pass the targets."""
+    out = {}
+    for k in sd:
+        if k.endswith(".lora_down.weight"):
+            base = k[: -len(".lora_down.weight")]
+            out[base] = (sd[k].float(), sd[base + ".lora_up.weight"].float())
+    return out
+
+
+def save_checkpoint(output_dir, global_step, arena, ti_rows, token_dict, name, pretrained_model_version, config=None,
+                    txt_encoder_keys=("clip_l", "clip_g")):
+    """arena: unet.LoraArena (LoRA) ; ti_rows: list of [n_tokens, D] tensors per text encoder (or None)."""
+    os.makedirs(output_dir, exist_ok=True)
+    name = remove_delimiter_characters(name)
+    files = {}
+    if ti_rows:
+        emb = {txt_encoder_keys[i]: r.detach().float().cpu().contiguous() for i, r in enumerate(ti_rows)}
+        files["embeddings"] = os.path.join(output_dir, f"{name}_{pretrained_model_version}_embeddings.safetensors")
+        save_file(emb, files["embeddings"])
+    with open(os.path.join(output_dir, "special_params.json"), "w") as f:
+        json.dump(token_dict, f)
+    if arena is not None:
+        files["lora"] = os.path.join(output_dir, f"{name}_{pretrained_model_version}_lora.safetensors")
+        save_file(lora_to_kohya(arena.export()), files["lora"])
+        # adapter_config.json (peft `save_pretrained`, checkpoint.py:175) - the fields the reference's loader reads
+        with open(os.path.join(output_dir, "adapter_config.json"), "w") as f:
+            json.dump({"peft_type": "LORA", "r": arena.rank, "lora_alpha": arena.rank * arena.scale, "init_lora_weights": "gaussian",
+                       "target_modules": ["to_k", "to_q", "to_v", "to_out.0", "conv2"], "use_dora": False}, f, indent=2)
+    if config is not None:
+        config.save_as_json(os.path.join(output_dir, "training_args.json"))
+    return files
+
+
+def load_embeddings(path, txt_encoder_keys=("clip_l", "clip_g")):
+    sd = load_file(path)
+    return [sd[k] for k in txt_encoder_keys if k in sd]
+
+
+def load_lora(path, targets):
+    """-> module -> (A, B) for the given module paths (topology.lora_targets)."""
+    sd = load_file(path)
+    return {m: (sd[kohya_key(m) + ".lora_down.weight"].float(), sd[kohya_key(m) + ".lora_up.weight"].float()) for m in targets}

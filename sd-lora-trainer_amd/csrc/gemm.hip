@@ -56,7 +56,19 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   }
   const int splitk = p.splitk > 1 ? p.splitk : 1;
   const int tile_id = bid / splitk, split = bid - tile_id * splitk;   // splits of one tile are neighbours -> same XCD
-  const int bn = tile_id % nbn, bm = tile_id / nbn;
+  // Grouped rasterisation inside each XCD's contiguous chunk of tiles: walk GROUP_M row-tiles before moving to the next
+  // column-tile, so the ~32 workgroups an XCD runs concurrently form a compact super-tile (they share X panels AND W
+  // panels in that XCD's 4 MB L2 instead of streaming every W panel once per row of tiles).
+  int bm, bn;
+  {
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * nbn;
+    const int grp = tile_id / per_group, first_m = grp * GROUP_M;
+    const int gsz = nbm - first_m < GROUP_M ? nbm - first_m : GROUP_M;
+    const int in_grp = tile_id - grp * per_group;
+    bm = first_m + in_grp % gsz;
+    bn = in_grp / gsz;
+  }
   const int m0 = bm * BM, n0 = bn * BN;
 
   // ---------------- per-lane staging geometry (fixed rows, fixed swizzled chunk) ----------------

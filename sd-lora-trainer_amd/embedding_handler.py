@@ -1,0 +1,43 @@
+"""Textual-inversion token bookkeeping, mirroring trainer/embedding_handler.py (TokenEmbeddingsHandler:13-62, 157-223,
+401-456) on top of the engine's text encoders (clip.ClipTextEncoder) and TI state (ti.TiState).
+
+The reference grows each tokenizer/embedding table by `<s0>..<s{n-1}>` and initialises the new rows as
+randn * sigma_bar / std_cur (embedding_handler.py:209-213).  Here the tables are built with the n extra rows already in
+place (the last rows), so `initialize_new_tokens` only draws those rows."""
+import torch
+from safetensors.torch import save_file
+
+from .checkpoint import load_embeddings as _load_embeddings
+
+
+class TokenEmbeddingsHandler:
+    def __init__(self, ti_state, inserting_toks):
+        self.ti, self.inserting_toks = ti_state, list(inserting_toks)
+        self.encoders = ti_state.encoders
+        enc = self.encoders[0]
+        self.train_ids = list(range(enc.V - len(inserting_toks), enc.V))     # the new tokens are the last rows
+        self.embeddings_settings = {}
+
+    def initialize_new_tokens(self, seed=0):
+        """rows = randn * (mean per-row std of the pretrained table) / (mean per-row std of the draw)."""
+        g = torch.Generator().manual_seed(seed)            # seed_everything(seed) in the reference (:172)
+        rows = []
+        for idx, e in enumerate(self.encoders):
+            n = len(self.train_ids)
+            std_token_embedding = e.table[: e.V - n].float().std(dim=1).mean()
+            self.embeddings_settings[f"std_token_embedding_{idx}"] = std_token_embedding
+            init = torch.randn(n, e.D, generator=g)
+            init = init * float(std_token_embedding) / init.std(dim=1).mean()
+            rows.append(init)
+        self.ti.load_rows(rows)
+        return rows
+
+    def get_trainable_embeddings(self):
+        """{'txt_encoder_i': rows [n, D]} like embedding_handler.py:37-62 (fp32 master rows)."""
+        return {f"txt_encoder_{i}": r for i, r in enumerate(self.ti.rows)}
+
+    def save_embeddings(self, file_path, txt_encoder_keys=("clip_l", "clip_g")):
+        save_file({txt_encoder_keys[i]: r.detach().float().cpu().contiguous() for i, r in enumerate(self.ti.rows)}, file_path)
+
+    def load_embeddings(self, file_path, txt_encoder_keys=("clip_l", "clip_g")):
+        self.ti.load_rows(_load_embeddings(file_path, txt_encoder_keys))

@@ -1,0 +1,201 @@
+"""`train(config)`: the reference's orchestrator interface (main.py:34-551) for the part this engine owns - a *generator*
+that yields progress floats and returns `(config, output_save_dir)` through StopIteration.value, driven by the same
+train_configs/*.json files:   python -m sd_lora_trainer_amd.train cfg.json
+
+What is NOT here (out of scope): preprocessing/captioning/masking, VAE latent caching, validation rendering.
+The data source is therefore a *latent cache* - either a `.pt` file with the tensors the reference's dataset would produce
+(`latents [N,4,h,w]`, `masks [N,4,h,w]`, `input_ids [N,77]` per tokenizer, `token_lists`) or, when `lora_training_urls`
+starts with "synthetic:", a seeded synthetic cache.  Model weights come from diffusers/HF-named state dicts (`.safetensors` /
+`.pt`) or, for `pretrained_model = {"path": "synthetic:<version>"}`, seeded random weights of the exact architecture.
+"""
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from . import checkpoint as ckpt
+from . import schedule, topology
+from .config import TrainingConfig
+from .embedding_handler import TokenEmbeddingsHandler
+from .optimizer import OptimizerCollection
+
+
+def _random_state(shapes, device, seed, emb_scale=0.02):
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for n, shp in shapes.items():
+        t = torch.randn(shp, generator=g, device=device, dtype=torch.float32)
+        if "embedding" in n:
+            t *= emb_scale
+        elif len(shp) >= 2:
+            t *= 1.0 / math.sqrt(math.prod(shp[1:]))
+        else:
+            t *= 0.02
+            if ("norm" in n) and n.endswith(".weight"):
+                t += 1.0
+        sd[n] = t
+    return sd
+
+
+def build_models(config, rt):
+    """-> (unet, text_stack or None, version).  Mirrors load_models (trainer/models.py:7-54) for the parts on the step."""
+    from . import clip as CL
+    from . import step as S
+    from . import unet as M
+    path = (config.pretrained_model or {}).get("path", "")
+    if path.startswith("synthetic:"):
+        version = path.split(":", 1)[1]
+        cfg = topology.CONFIGS[version]
+        sd = _random_state(topology.param_shapes(cfg), rt.device, seed=config.seed)
+    else:
+        from safetensors.torch import load_file
+        sd = load_file(path)
+        version = config.sd_model_version or ("sdxl" if "add_embedding.linear_1.weight" in sd else "sd15")
+        cfg = topology.CONFIGS[version]
+    unet = M.UNet(rt, cfg, sd, lora_rank=config.lora_rank if config.is_lora else None, lora_alpha_multiplier=config.lora_alpha_multiplier)
+    text = None
+    if not config.disable_ti:
+        tiny = version.startswith("tiny")
+        kinds = (["tiny_l", "tiny_g"] if tiny else ["clip_l", "clip_g"]) if cfg["addition"] else (["tiny_l"] if tiny else ["clip_l"])
+        encs = []
+        for i, kd in enumerate(kinds):
+            c = topology.CLIP_CONFIGS[kd]
+            csd = _random_state(topology.clip_param_shapes(c, config.n_tokens), rt.device, seed=config.seed + 1 + i)
+            encs.append(CL.ClipTextEncoder(rt, f"te{i + 1}", csd, heads=c["heads"], act=c["act"], mode="penultimate" if cfg["addition"] else "last",
+                                           with_projection=bool(c["proj"]), n_train=config.n_tokens))
+        text = S.TextStack(rt, encs, pool_mode="argmax")
+    return unet, text, version
+
+
+def synthetic_cache(cfg, n_images, h, w, vocab, n_tokens, seed):
+    g = torch.Generator().manual_seed(seed)
+    tok = list(range(vocab - n_tokens, vocab))
+    bos, eos = (49406, 49407) if vocab > 49407 else (vocab - n_tokens - 2, vocab - n_tokens - 1)
+    ids = torch.full((n_images, 77), eos, dtype=torch.int64)
+    lists = []
+    for i in range(n_images):
+        words = torch.randint(1, bos - 1, (6,), generator=g).tolist()
+        l = [bos] + words[:3] + tok + words[3:] + [eos]
+        ids[i, :len(l)] = torch.tensor(l)
+        lists.append(l)
+    return dict(latents=torch.randn(n_images, 4, h, w, generator=g) * cfg["scaling_factor"],
+                masks=(torch.rand(n_images, 1, h, w, generator=g) * 0.95 + 0.05).repeat(1, 4, 1, 1), input_ids=ids, token_lists=lists,
+                tok_list=[bos] + tok + [eos])
+
+
+def train(config: TrainingConfig, runtime=None):
+    """Generator: yields progress in [0,1]; returns (config, output_save_dir)."""
+    from . import step as S
+    from . import unet as M
+    np.random.seed(config.seed)
+    torch.manual_seed(config.seed)
+    B = config.train_batch_size
+    rt = runtime or M.Runtime(config.device, B)
+    unet, text, version = build_models(config, rt)
+    cfg = unet.cfg
+    config.pretrained_model = dict(config.pretrained_model or {}, version=version)
+    if config.train_img_size is None:
+        config.train_img_size = [config.resolution, config.resolution]
+    w, h = config.train_img_size[0] // 8, config.train_img_size[1] // 8
+    if config.lora_training_urls.startswith("synthetic:"):
+        n_img = int(config.lora_training_urls.split(":")[1] or 8)
+        vocab = text.encoders[0].V if text is not None else 49411
+        cache = synthetic_cache(cfg, n_img, h, w, vocab, config.n_tokens, config.seed)
+    else:
+        cache = torch.load(config.lora_training_urls)
+    n_img = cache["latents"].shape[0]
+    steps_per_epoch = max(n_img // B, 1)
+    config.num_train_epochs = math.ceil(config.max_train_steps / steps_per_epoch)      # main.py:207
+
+    ts = S.TrainStep(rt, unet, latent_hw=(h, w), snr_gamma=config.snr_gamma, l1_penalty=config.l1_penalty, weight_decay=config.lora_weight_decay,
+                     grad_accum=config.gradient_accumulation_steps, text=text, n_tokens=config.n_tokens,
+                     token_attention_loss_w=config.token_attention_loss_w, ti_weight_decay=config.ti_weight_decay)
+    handler = None
+    if text is not None:
+        handler = TokenEmbeddingsHandler(ts.ti, config.inserting_list_tokens)
+        handler.initialize_new_tokens(seed=config.seed)
+    g = torch.Generator(device=rt.device).manual_seed(config.seed)
+    arena = unet.arena
+    for e in arena.entries:            # peft init_lora_weights="gaussian" (optimizer.py:89): A ~ N(0, 1/r), B = 0
+        e["A"].copy_(torch.randn(e["A"].shape, generator=g, device=rt.device) / config.lora_rank)
+        e["B"].zero_()
+    arena.refresh_shadows()
+    optimizers = OptimizerCollection(ts, config)
+    checkpoint_dir = os.path.join(config.output_dir, "checkpoints")
+    os.makedirs(checkpoint_dir, exist_ok=True)
+    time_ids = torch.tensor([[1024., 1024, 0, 0, float(config.resolution), float(config.resolution)]] * B) if cfg["addition"] else None
+    tok_string_ids = cache.get("tok_list")
+    losses = {"img_loss": [], "tot_loss": []}
+    global_step, images_done, start = 0, 0, time.time()
+    captured = False
+    perm_rng = np.random.RandomState(config.seed)
+    done = False
+    for epoch in range(config.num_train_epochs):
+        order = perm_rng.permutation(n_img)
+        for step_in_epoch in range(steps_per_epoch):
+            completion_f = schedule.completion_fraction(epoch, step_in_epoch, steps_per_epoch, config.num_train_epochs)
+            lrs = schedule.learning_rates(config, global_step, completion_f, ti_active=text is not None)
+            optimizers.optimizers["unet"].param_groups[0]["lr"] = lrs["unet"]
+            if text is not None:
+                optimizers.optimizers["textual_inversion"].param_groups[0]["lr"] = lrs["textual_inversion"]
+            idx = torch.as_tensor(order[step_in_epoch * B:(step_in_epoch + 1) * B])
+            latent, mask = cache["latents"][idx].to(rt.device), cache["masks"][idx].to(rt.device)
+            noise = torch.randn(latent.shape, generator=g, device=rt.device)
+            if config.noise_offset > 0.0:                                                # main.py:313-317
+                noise += config.noise_offset * torch.randn((B, 4, 1, 1), generator=g, device=rt.device)
+            timesteps = torch.randint(0, 1000, (B,), generator=g, device=rt.device)
+            if text is not None:
+                ids = cache["input_ids"][idx].clone()
+                lists = [cache["token_lists"][int(i)] for i in idx]
+                if config.caption_dropout > 0.0 and tok_string_ids is not None:           # main.py:300-304
+                    for b in range(B):
+                        if np.random.rand() < config.caption_dropout:
+                            lists[b] = list(tok_string_ids)
+                            ids[b] = ids[b, -1]
+                            ids[b, :len(tok_string_ids)] = torch.tensor(tok_string_ids)
+                ts.set_batch(latent, noise, timesteps, mask, time_ids=time_ids, ids=[ids] * len(text.encoders), caption_token_lists=lists)
+            else:
+                ctx = torch.randn(B, 77, cfg["cross_dim"], generator=g, device=rt.device)
+                pooled = torch.randn(B, 1280, generator=g, device=rt.device) if cfg["addition"] else None
+                ts.set_batch(latent, noise, timesteps, mask, ctx, pooled, time_ids)
+            if not captured and rt.device.type == "cuda":
+                ts.capture(warmup=1)
+                captured = True
+            optimizers.step()
+            optimizers.zero_grad()
+            if global_step % max(config.max_train_steps // 20, 1) == 0:
+                losses["img_loss"].append(float(ts.loss))
+                losses["tot_loss"].append(ts.total_loss())
+            images_done += B
+            global_step += 1
+            every = max(config.max_train_steps // 100, 1)         # main.py:457 divides by zero for max_train_steps < 100
+            if global_step % every == 0:
+                yield float(min(global_step / config.max_train_steps + 0.05, 1.0))
+            if global_step > config.max_train_steps:               # main.py:462 (runs max_train_steps + 1 steps)
+                done = True
+                break
+        if done:
+            break
+    output_save_dir = os.path.join(checkpoint_dir, f"checkpoint-{global_step}")
+    config.job_time = time.time() - config.start_time
+    config.training_attributes = dict(config.training_attributes, images_per_second=images_done / max(time.time() - start, 1e-9), losses=losses)
+    ckpt.save_checkpoint(output_save_dir, global_step, arena, ts.ti.rows if ts.ti is not None else None, config.token_dict, config.name,
+                         version, config=config)
+    return config, output_save_dir
+
+
+if __name__ == "__main__":
+    cfg = TrainingConfig.from_json(sys.argv[1])
+    gen = train(cfg)
+    try:
+        while True:
+            p = next(gen)
+            print(f"progress {p:.2f}", flush=True)
+    except StopIteration as e:
+        cfg, out = e.value
+        print(json.dumps({"output_save_dir": out, "job_time": cfg.job_time,
+                          "images_per_second": cfg.training_attributes["images_per_second"]}))

@@ -128,9 +128,9 @@ def attn_bwd(Q, K, V, Kt, Qt, O, L, dO, dOt, D, dQ, dK, dV, *, B, H, Nq, Nk, Nqp
     assert torch.allclose(Kt[:, : B * Nkp].float(), K[:, :C].float().t())
     assert torch.allclose(Qt[:, : B * Nqp].float(), Q[:, :C].float().t())
     assert torch.allclose(dOt[:, : B * Nqp].float(), dO[:, :C].float().t())
-    q = _heads(Q[:, :C], B, Nqp, H, d).requires_grad_(True)
-    k = _heads(K[:, :C], B, Nkp, H, d).requires_grad_(True)
-    v = _heads(V[:, :C], B, Nkp, H, d).requires_grad_(True)
+    q = _heads(Q[:, :C], B, Nqp, H, d).detach().clone().requires_grad_(True)
+    k = _heads(K[:, :C], B, Nkp, H, d).detach().clone().requires_grad_(True)
+    v = _heads(V[:, :C], B, Nkp, H, d).detach().clone().requires_grad_(True)
     s = _attn_core(q, k, v, Nq, Nk, scale, causal)
     o = torch.softmax(s, dim=-1) @ v
     go = _heads(dO[:, :C], B, Nqp, H, d).clone()
@@ -155,7 +155,7 @@ def groupnorm_fwd(x1, x2, y, stats, *, B, HW, gamma, beta, eps, silu):
 
 
 def groupnorm_bwd(x1, x2, dy, dx, stats, bstats, *, B, HW, gamma, beta, eps, silu, dres=None):
-    x = _gn_cat(x1, x2).requires_grad_(True)
+    x = _gn_cat(x1, x2).detach().clone().requires_grad_(True)
     C = x.shape[1]
     z = F.group_norm(x.reshape(B, HW, C).permute(0, 2, 1), 32, gamma.float(), beta.float(), eps)
     if silu:
@@ -173,7 +173,7 @@ def layernorm_fwd(x, y, stats, *, gamma, beta, eps=1e-5):
 
 
 def layernorm_bwd(x, dy, dx, stats, *, gamma, dres=None):
-    xx = x.float().requires_grad_(True)
+    xx = x.detach().float().clone().requires_grad_(True)
     z = F.layer_norm(xx, (x.shape[1],), gamma.float(), None, 1e-5)
     (g,) = torch.autograd.grad(z, xx, dy.float())
     if dres is not None:
@@ -189,7 +189,7 @@ def geglu_fwd(inp, out):
 
 
 def geglu_bwd(inp, dout, din):
-    x = inp.float().requires_grad_(True)
+    x = inp.detach().float().clone().requires_grad_(True)
     h, g = x.chunk(2, dim=1)
     (gr,) = torch.autograd.grad(h * F.gelu(g), x, dout.float())
     din.copy_(gr.to(din.dtype))
@@ -207,7 +207,7 @@ def map_bf16(op, x, dy, y):
     elif op == MAP_QGELU:
         r = xx * torch.sigmoid(1.702 * xx)
     else:
-        xx = xx.requires_grad_(True)
+        xx = xx.detach().clone().requires_grad_(True)
         f = {MAP_DSILU: F.silu, MAP_DGELU: F.gelu, MAP_DQGELU: lambda t: t * torch.sigmoid(1.702 * t)}[op](xx)
         (r,) = torch.autograd.grad(f, xx, dy.float())
     y.copy_(r.to(y.dtype))
@@ -236,7 +236,7 @@ def add_noise_nhwc(x0, noise, timesteps, alphas_cumprod, out, noisy_nchw=None):
 def masked_mse_fwd_bwd(pred, noise, noisy, mask, timesteps, alphas_cumprod, sums, loss_out, dpred, *, snr_gamma,
                        v_prediction=False, loss_scale=1.0):
     B, C, H, W = noise.shape
-    p = pred[:, :C].float().reshape(B, H, W, C).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    p = pred[:, :C].detach().float().reshape(B, H, W, C).permute(0, 3, 1, 2).clone().requires_grad_(True)
     a = alphas_cumprod[timesteps].view(B, 1, 1, 1)
     target = a.sqrt() * noise - (1 - a).sqrt() * noisy if v_prediction else noise
     e = (p - target).pow(2) * mask
@@ -249,7 +249,7 @@ def masked_mse_fwd_bwd(pred, noise, noisy, mask, timesteps, alphas_cumprod, sums
         mm = mask.flatten(1).mean(1)
         loss = (per / (mm / mm.mean())).mean()
     (g,) = torch.autograd.grad(loss * loss_scale, p)
-    loss_out.fill_(float(loss))
+    loss_out.fill_(float(loss.detach()))
     dpred.zero_()
     dpred[:, :C].copy_(g.permute(0, 2, 3, 1).reshape(B * H * W, C).to(dpred.dtype))
 

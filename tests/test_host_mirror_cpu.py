@@ -1,0 +1,112 @@
+"""Host-side mirrors of the reference's interfaces (CPU): TrainingConfig vs snapshots of the reference's own class on
+its shipped train_configs/*.json, LR schedules, caption dropout, checkpoint format, and the train() generator driven
+end-to-end through the op emulation on a tiny synthetic job."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_ref as L
+from tests import emu_ops
+
+import sd_lora_trainer_amd.unet as unet_mod
+from sd_lora_trainer_amd import checkpoint as ckpt
+from sd_lora_trainer_amd import schedule, topology
+from sd_lora_trainer_amd.config import TrainingConfig
+
+
+def test_training_config_matches_reference_snapshots(golden_dir, tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    snaps = json.load(open(os.path.join(golden_dir, "config_snapshots.json")))
+    assert len(snaps) == 11
+    for fname, s in snaps.items():
+        c = TrainingConfig(**s["input"])
+        d = c.model_dump()
+        for k, ref in s["derived"].items():
+            if k == "pretrained_model":
+                assert (d[k] or {}).get("version") == (ref or {}).get("version"), (fname, k)
+                continue
+            assert d[k] == ref, (fname, k, d[k], ref)
+        assert os.path.isdir(c.output_dir) and c.device == "cuda:0"
+        p = tmp_path / "roundtrip.json"
+        c.save_as_json(str(p))
+        assert json.load(open(p))["lora_rank"] == c.lora_rank
+
+
+def test_lr_schedules_and_caption_dropout(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    c = TrainingConfig(lora_training_urls="x", concept_mode="object", sd_model_version="sdxl", max_train_steps=400, unet_lr=1e-3, ti_lr=1e-3)
+    assert c.unet_lr_warmup_steps == 400
+    spe, epochs = 10, 40
+    for gs in (0, 1, 137, 279, 281, 399):
+        ep, st = divmod(gs, spe)
+        f = schedule.completion_fraction(ep, st, spe, epochs)
+        got = schedule.learning_rates(c, gs, f)
+        lr_u, lr_t, f_ref = L.lr_schedule(gs, st, ep, spe, epochs, unet_lr=1e-3, unet_lr_warmup_steps=400, ti_lr=1e-3)
+        assert abs(f - f_ref) < 1e-12 and abs(got["unet"] - lr_u) < 1e-15 and abs(got["textual_inversion"] - lr_t) < 1e-15
+    assert schedule.learning_rates(c, 0, 0.0)["unet"] == pytest.approx(5e-5)           # LoRA + TI cold start (main.py:236)
+    assert schedule.learning_rates(c, 400, 1.0)["unet"] == pytest.approx(1e-3)
+    assert schedule.learning_rates(c, 300, 0.75)["textual_inversion"] == 0.0            # frozen after 0.7
+    c2 = TrainingConfig(lora_training_urls="x", concept_mode="style", sd_model_version="sd15", disable_ti=True)
+    assert schedule.base_unet_lr(c2.is_lora, c2.disable_ti) == 2e-4 and schedule.base_unet_lr(False, True) == 1e-5
+    np.random.seed(0)
+    caps = schedule.apply_caption_dropout(["a"] * 1000, 0.1, "<s0><s1><s2>")
+    assert 60 < sum(x == "<s0><s1><s2>" for x in caps) < 140
+    assert schedule.apply_caption_dropout(["a", "b"], 0.0, "T") == ["a", "b"]
+
+
+def test_checkpoint_format_roundtrip(tmp_path):
+    cfg = topology.CONFIGS["tinyxl"]
+    rt = unet_mod.Runtime("cpu", 1, act_dtype=torch.float32, ops=emu_ops)
+    from oracle import unet_ref as U
+    unet = unet_mod.UNet(rt, cfg, U.init_unet_state(U.CONFIGS["tinyxl"], seed=0), lora_rank=4)
+    lora = U.init_lora(U.CONFIGS["tinyxl"], 4, seed=1, b_std=0.05)
+    unet.arena.load(lora)
+    rows = [torch.randn(3, 64), torch.randn(3, 64)]
+    files = ckpt.save_checkpoint(str(tmp_path), 10, unet.arena, rows, {"TOK": "<s0><s1><s2>"}, "my concept.v1", "sdxl")
+    assert os.path.basename(files["lora"]) == "my_concept_v1_sdxl_lora.safetensors"
+    assert os.path.basename(files["embeddings"]) == "my_concept_v1_sdxl_embeddings.safetensors"
+    from safetensors.torch import load_file
+    sd = load_file(files["lora"])
+    targets = topology.lora_targets(cfg)
+    assert len(sd) == 3 * len(targets)
+    k = "lora_unet_down_blocks_1_attentions_0_transformer_blocks_0_attn1_to_q"
+    assert sd[k + ".lora_down.weight"].shape == (4, 128) and sd[k + ".lora_up.weight"].shape == (128, 4) and float(sd[k + ".alpha"]) == 4.0
+    kc = "lora_unet_down_blocks_0_resnets_0_conv2"
+    assert sd[kc + ".lora_down.weight"].shape == (4, 64, 3, 3) and sd[kc + ".lora_up.weight"].shape == (64, 4, 1, 1)
+    assert not any("base_model" in key for key in sd)
+    back = ckpt.load_lora(files["lora"], targets)
+    for m in targets:
+        torch.testing.assert_close(back[m][0], lora[m][0], rtol=2e-3, atol=1e-4)      # fp16 on disk
+        torch.testing.assert_close(back[m][1], lora[m][1], rtol=2e-3, atol=1e-4)
+    emb = ckpt.load_embeddings(files["embeddings"])
+    assert torch.equal(emb[0], rows[0]) and torch.equal(emb[1], rows[1])
+    assert json.load(open(tmp_path / "special_params.json")) == {"TOK": "<s0><s1><s2>"}
+    assert json.load(open(tmp_path / "adapter_config.json"))["r"] == 4
+
+
+@pytest.mark.parametrize("version,disable_ti", [("tinyxl", False), ("tiny15", True)])
+def test_train_generator_end_to_end(tmp_path, monkeypatch, version, disable_ti):
+    monkeypatch.chdir(tmp_path)
+    from sd_lora_trainer_amd.train import train
+    cfg = TrainingConfig(lora_training_urls="synthetic:4", concept_mode="object", pretrained_model={"path": f"synthetic:{version}"}, seed=1,
+                         resolution=256 if version == "tinyxl" else 128, train_batch_size=2, max_train_steps=3, lora_rank=4, disable_ti=disable_ti,
+                         unet_lr=1e-3, ti_lr=1e-3, caption_dropout=0.5)
+    rt = unet_mod.Runtime("cpu", 2, act_dtype=torch.float32, ops=emu_ops)
+    gen = train(cfg, runtime=rt)
+    progress = []
+    try:
+        while True:
+            progress.append(next(gen))
+    except StopIteration as e:
+        config, out_dir = e.value
+    assert len(progress) == 4 and progress[-1] == 1.0          # max_train_steps + 1 steps (main.py:462), no ZeroDivisionError (:457)
+    assert os.path.isdir(out_dir) and out_dir.endswith("checkpoint-4")
+    names = sorted(os.listdir(out_dir))
+    assert any(n.endswith("_lora.safetensors") for n in names) and "training_args.json" in names and "special_params.json" in names
+    assert any(n.endswith("_embeddings.safetensors") for n in names) == (not disable_ti)
+    ta = json.load(open(os.path.join(out_dir, "training_args.json")))
+    assert ta["num_train_epochs"] == 2 and ta["pretrained_model"]["version"] == version
+    assert np.isfinite(ta["training_attributes"]["losses"]["tot_loss"]).all()
