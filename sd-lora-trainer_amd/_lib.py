@@ -10,7 +10,8 @@ import os
 import torch  # noqa: F401  (must be loaded before the HIP library, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdlt_kernels.so")
+# SDLT_KERNEL_LIB: load an alternative build of the SAME C-ABI (kernel A/B experiments); never a fallback
+LIB_PATH = os.environ.get("SDLT_KERNEL_LIB") or os.path.join(_HERE, "libsdlt_kernels.so")
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 

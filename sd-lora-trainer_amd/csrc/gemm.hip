@@ -132,6 +132,9 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   constexpr int AI = R16 ? ((2 * R16 + NW - 1) / NW) : 0;   // LoRA-down DMA instructions per wave and stage
   constexpr int LPS = XI + WI + AI;                         // DMA instructions per wave and stage
 
+  // this workgroup's share of the K steps (split-K: contiguous ranges of the combined segment-1 + segment-2 steps)
+  const int kbeg = (int)((long)nk * split / splitk), kend = (int)((long)nk * (split + 1) / splitk);
+
   // Enumerates the 8-row x 128-byte pieces this wave moves for K-step kt: f(j, src, lds_off) with j in [0, LPS).
   auto for_each_piece = [&](int kt, auto&& f) {
     if (kt < nk1) {
@@ -185,8 +188,10 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   };
   // LDS-DMA path: global -> LDS directly (16 B per lane, destination = piece base + lane*16)
   auto stage = [&](int kt, int buf) {
+#ifndef SDLT_LAB_NO_DMA
     char* base = smem + buf * STAGE;
     for_each_piece(kt, [&](int, const bf16_t* src, int off) { glds16(src, base + off); });
+#endif
   };
 
   // ---------------- accumulators ----------------
@@ -208,10 +213,10 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   const int foff0 = frow * ROW_BYTES + (((0 * 4 + fk) ^ (frow & 7)) << 4);
   const int foff1 = frow * ROW_BYTES + (((1 * 4 + fk) ^ (frow & 7)) << 4);
 
-  // this workgroup's share of the K steps (split-K: contiguous ranges of the combined segment-1 + segment-2 steps)
-  const int kbeg = (int)((long)nk * split / splitk), kend = (int)((long)nk * (split + 1) / splitk);
-
   auto compute = [&](const char* base, int kt) {
+#ifdef SDLT_LAB_NO_COMPUTE
+    return;
+#endif
     const char* xs = base + (wm * MI * 16) * ROW_BYTES;
     const char* ws = base + XT + (wn * NI * 16) * ROW_BYTES;
     const char* as = base + XT + WT;

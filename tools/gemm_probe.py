@@ -6,14 +6,16 @@ from sd_lora_trainer_amd import ops
 BF = torch.bfloat16
 
 def bench(M, N, K, tile, splitk, lora=False, conv=None, reps=20, stages=0):
-    X = torch.randn(M if conv is None else conv.B * conv.Hin * conv.Win, K if conv is None else conv.Cin, device="cuda").to(BF)
-    Ws = [torch.randn(N, K, device="cuda").to(BF) for _ in range(4)]   # rotate weights: frozen weights are never L2-hot in the real step
+    pad = int(os.environ.get('LDPAD', '0'))    # extra elements per row: probes L2/HBM channel camping of power-of-two-ish strides
+    Kx = K if conv is None else conv.Cin
+    X = torch.randn(M if conv is None else conv.B * conv.Hin * conv.Win, Kx + pad, device="cuda").to(BF)[:, :Kx]
+    Ws = [torch.randn(N, K + pad, device="cuda").to(BF)[:, :K] for _ in range(int(os.environ.get('NW', '4')))]   # rotate weights: frozen weights are never L2-hot in the real step
     out = torch.empty(M, N, device="cuda", dtype=BF)
     lo = None
     if lora:
         lo = (torch.randn(16, K, device="cuda").to(BF), torch.randn(N, 16, device="cuda").to(BF), 1.0, torch.empty(M, 16, device="cuda", dtype=BF))
     def run():
-        for i in range(reps): ops.gemm(X, Ws[i % 4], out, lora=lo, conv=conv, tile=tile, splitk=splitk, stages=stages)
+        for i in range(reps): ops.gemm(X, Ws[i % len(Ws)], out, lora=lo, conv=conv, tile=tile, splitk=splitk, stages=stages)
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
         run()

@@ -4,8 +4,8 @@ from gemm_probe import bench
 for (name, M, N, K, lora) in [("attn proj C1280", 1024, 1280, 1280, True), ("ff2", 1024, 1280, 5120, False), ("qkv fused-size", 1024, 3840, 1280, False), ("dn fused-size", 1024, 1280, 3840, False),
                               ("attn proj C640", 4096, 640, 640, True), ("qkv C640", 4096, 1920, 640, False), ("clip", 128, 1280, 1280, False), ("clip qkv", 128, 3840, 1280, False)]:
     res = []
-    for tile in (1, 2, 3, 4):
-        for sk in (1, 2, 3, 4, 6):
+    for tile in (1, 2, 3):
+        for sk in (1, 3):
             for st in (0, 2):
                 if sk > (K // 64) // 2: continue
                 try: us = bench(M, N, K, tile, sk, lora, None, stages=st)
