@@ -47,12 +47,14 @@ _workspaces = {}
 
 
 def splitk_workspace(device):
-    """Per-device split-K scratch of sdlt_gemm_bf16: fp32 partial-tile slabs + zero-initialised arrival counters.
-    One workspace per device is enough while every GEMM of a process is enqueued on one stream."""
-    ws = _workspaces.get(device)
+    """Split-K scratch of sdlt_gemm_bf16: fp32 partial-tile slabs + zero-initialised arrival counters.
+    One workspace per (device, stream): GEMMs enqueued on different streams may run concurrently (the two text encoders
+    do) and must not share slabs or counters; GEMMs on one stream are ordered, so they can."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
     if ws is None:
         ws = (torch.empty(96 << 20, dtype=torch.uint8, device=device), torch.zeros(4096, dtype=torch.int32, device=device))
-        _workspaces[device] = ws
+        _workspaces[key] = ws
     return ws
 
 

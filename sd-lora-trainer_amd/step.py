@@ -28,6 +28,7 @@ class TextStack:
         self.ids = [torch.zeros(B, T_TOKENS, dtype=torch.int64, device=rt.device) for _ in encoders]
         self.pool_rows = torch.zeros(B, dtype=torch.int64, device=rt.device)
         self.widths = [e.D for e in encoders]
+        self.side = [torch.cuda.Stream(device=rt.device) for _ in encoders] if torch.device(rt.device).type == "cuda" else []
 
     def set_ids(self, ids_per_encoder):
         for dst, src in zip(self.ids, ids_per_encoder):
@@ -38,20 +39,48 @@ class TextStack:
         pos = last.argmax(-1) if self.pool_mode == "argmax" else (last == self.eos).int().argmax(-1)
         self.pool_rows.copy_(torch.arange(last.shape[0]) * TP + pos)
 
+    def _fan_out(self, jobs):
+        """Run one job per encoder, each on its own side stream, joined before returning.  The encoders are
+        independent and each of their kernels fills a fraction of the chip (M = 128 rows), so CLIP-L rides along bigG
+        for free.  Works eagerly and inside hipGraph capture (fork/join become graph edges)."""
+        if not self.side:
+            for job in jobs:
+                job()
+            return
+        cur = torch.cuda.current_stream(self.rt.device)
+        for s in self.side:
+            s.wait_stream(cur)
+        # every branch gets its own stream and the calling stream only waits: ROCm's graph executor releases a forked
+        # branch when the forking queue reaches its *next* marker, so a branch left on the calling stream would hold the
+        # other one back until it is done (observed in the kernel trace)
+        for s, job in zip(self.side, jobs):
+            with torch.cuda.stream(s):
+                job()
+        for s in self.side:
+            cur.wait_stream(s)
+
     def forward(self, ctx):
-        off, pooled = 0, None
-        for e, ids, w in zip(self.encoders, self.ids, self.widths):
-            _, p = e.forward(ids, self.rt.B, hidden_out=ctx[:, off:off + w], pool_rows=self.pool_rows)
-            pooled = p if p is not None else pooled
+        out = [None] * len(self.encoders)
+        jobs, off = [], 0
+        for i, (e, ids, w) in enumerate(zip(self.encoders, self.ids, self.widths)):
+            def job(i=i, e=e, ids=ids, off=off, w=w):
+                _, out[i] = e.forward(ids, self.rt.B, hidden_out=ctx[:, off:off + w], pool_rows=self.pool_rows)
+            jobs.append(job)
             off += w
+        self._fan_out(jobs)
+        pooled = None
+        for p in out:
+            pooled = p if p is not None else pooled
         return pooled
 
     def backward(self, dctx, d_pooled, grad_rows):
-        off = 0
+        jobs, off = [], 0
         for e, w, g in zip(self.encoders, self.widths, grad_rows):
-            e.backward(dctx[:, off:off + w], d_pooled if e.with_projection else None, g)
+            def job(e=e, off=off, w=w, g=g):
+                e.backward(dctx[:, off:off + w], d_pooled if e.with_projection else None, g)
+            jobs.append(job)
             off += w
-
+        self._fan_out(jobs)
 
 
 def ddpm_alphas_cumprod(n=1000, beta_start=0.00085, beta_end=0.012):
@@ -92,7 +121,7 @@ class TrainStep:
         self.sums, self.loss, self.l1_sum = z(B * 2), z(1), z(1)
         self.hyper = z(16)
         self.opt_step = 0
-        self.graph = None
+        self.graph, self.graphs = None, []
 
     # -------------------------------------------------------------------------------- inputs
     def set_batch(self, latent, noise, timesteps, mask, ctx=None, pooled=None, time_ids=None, ids=None, caption_token_lists=None):
@@ -129,15 +158,20 @@ class TrainStep:
             self.ti.hyper[: len(vals)].copy_(torch.tensor(vals, dtype=torch.float32))
 
     # -------------------------------------------------------------------------------- the step body
-    def forward_backward(self):
-        rt, u = self.rt, self.unet
-        ops = rt.ops
-        pooled = self.pooled
+    # The step is cut into three phases so that each can be its own hipGraph: ROCm's graph executor only overlaps forked
+    # branches (the two text encoders) when the fork sits near the root of a small graph - inside the ~4600-node
+    # whole-step graph the branches were replayed strictly one after the other (kernel trace, tools/graph_branch_probe2.py).
+    def _phase_text_fwd(self):
+        self._pooled_live = self.pooled
         if self.text is not None:                      # a4: text conditioning with the trainable token rows (main.py:306-308)
             p = self.text.forward(self.ctx)
-            pooled = p if p is not None else pooled
+            self._pooled_live = p if p is not None else self.pooled
+
+    def _phase_unet(self):
+        rt, u = self.rt, self.unet
+        ops = rt.ops
         ops.add_noise_nhwc(self.latent, self.noise, self.timesteps, self.acp, self.x64, self.noisy)
-        pred = u.forward(self.x64, self.timesteps_f, self.ctx, pooled, self.time_ids, B=self.B, H=self.h, W=self.w)
+        pred = u.forward(self.x64, self.timesteps_f, self.ctx, self._pooled_live, self.time_ids, B=self.B, H=self.h, W=self.w)
         scale = 1.0 / self.grad_accum
         ops.masked_mse_fwd_bwd(pred, self.noise, self.noisy, self.mask, self.timesteps, self.acp, self.sums, self.loss,
                                self.dpred64, snr_gamma=self.snr_gamma, v_prediction=self.v_pred, loss_scale=scale)
@@ -146,12 +180,20 @@ class TrainStep:
             self.ta.forward_backward(self.mask, self.w / self.h, self.ta_w * scale)
         self.dctx.zero_()
         u.backward(self.dpred64, self.dctx)
+        self._pred = pred
+
+    def _phase_text_bwd(self):
         if self.text is not None:
             P = self.pooled.shape[1] if self.pooled is not None else 0
-            d_pooled = u.dadd_in[:, :P] if rt.want_dpooled else None
+            d_pooled = self.unet.dadd_in[:, :P] if self.rt.want_dpooled else None
             self.text.backward(self.dctx, d_pooled, self.ti.grad_rows)
             self.ti.add_regulariser()                  # a14 (only the std term is live by default, config.py:75-77)
-        return pred
+
+    def forward_backward(self):
+        self._phase_text_fwd()
+        self._phase_unet()
+        self._phase_text_bwd()
+        return self._pred
 
     def optimizer_step(self):
         a = self.unet.arena
@@ -166,10 +208,16 @@ class TrainStep:
         self.forward_backward()
         self.optimizer_step()
 
+    def _phases(self):
+        if self.text is None:
+            return [self.body]
+        return [self._phase_text_fwd, self._phase_unet, lambda: (self._phase_text_bwd(), self.optimizer_step())]
+
     # -------------------------------------------------------------------------------- graph capture / replay
     def capture(self, warmup=2):
         """Runs the body eagerly `warmup` times (allocates every persistent buffer, builds the grouped-gradient
-        plan), then captures it.  AdamW state is restored afterwards so capture does not count as training."""
+        plan), then captures it - one hipGraph per phase, sharing one memory pool, replayed back to back.  AdamW state
+        is restored afterwards so capture does not count as training."""
         a = self.unet.arena
         state = [a.params, a.m, a.v] + ([self.ti.params, self.ti.m, self.ti.v] if self.ti is not None else [])
         snap = [t.clone() for t in state]
@@ -180,9 +228,14 @@ class TrainStep:
             for _ in range(warmup):
                 self.body()
         torch.cuda.current_stream().wait_stream(s)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.body()
+        self.graphs, pool = [], None
+        for phase in self._phases():
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                phase()
+            pool = g.pool()
+            self.graphs.append(g)
+        self.graph = self.graphs[0]
         for t, c in zip(state, snap):
             t.copy_(c)
         a.refresh_shadows()
@@ -193,7 +246,8 @@ class TrainStep:
     def run(self, lr, lr_ti=0.0):
         self.set_hyper(lr, lr_ti)
         if self.graph is not None:
-            self.graph.replay()
+            for g in self.graphs:
+                g.replay()
         else:
             self.body()
 
