@@ -86,7 +86,10 @@ int sdlt_gemm_bf16(const sdlt_gemm_params* p, void* stream);
  *   dAdown= (s*U)^T . X      : P = X  [M,K],  Q = s*U [M,Rp]  (T_out of the dX GEMM),     out [R,K]
  * conv=1 gathers P rows like sdlt_gemm_bf16 mode 1 (forward geometry), for the 3x3 LoRA-down conv.
  * Replaces autograd's per-adapter dA/dB matmuls behind loss.backward() (main.py:363) for the
- * adapters created at trainer/optimizer.py:86-95.  One workgroup = one problem x 128 columns.
+ * adapters created at trainer/optimizer.py:86-95.  One workgroup = one problem x sdlt_lora_grad_block_cols()
+ * columns (64): block_desc[b] = problem of workgroup b, desc.first_block = its first workgroup.
+ * mfma=1 selects the MFMA kernel (needs: ldp, ldq, Cw multiples of 8; 16-byte aligned P, Q; conv: Cin % 64 == 0;
+ * desc.zero = a >= 512-byte zero page), mfma=0 the VALU kernel that takes any shape.
  */
 typedef struct sdlt_lora_grad_desc {
   const void* P; int64_t ldp;
@@ -101,7 +104,8 @@ typedef struct sdlt_lora_grad_desc {
   int32_t pad_;
 } sdlt_lora_grad_desc;
 int sdlt_lora_grad_grouped(const sdlt_lora_grad_desc* descs_dev, const int32_t* block_desc_dev,
-                           int32_t n_blocks, int32_t Rp, void* stream);
+                           int32_t n_blocks, int32_t Rp, int32_t mfma, void* stream);
+int32_t sdlt_lora_grad_block_cols(void);
 
 /* ------------------------------------------------------------------------------------------------
  * sdlt_attn_fwd / sdlt_attn_bwd : multi-head softmax attention, flash style (no score matrix in HBM).

@@ -89,7 +89,8 @@ SYMBOLS = {
     "sdlt_struct_size": (i32, [i32]),
     "sdlt_add2d": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, vp]),
     "sdlt_gemm_bf16": (i32, [C.POINTER(GemmParams), vp]),
-    "sdlt_lora_grad_grouped": (i32, [vp, vp, i32, i32, vp]),
+    "sdlt_lora_grad_grouped": (i32, [vp, vp, i32, i32, i32, vp]),
+    "sdlt_lora_grad_block_cols": (i32, []),
     "sdlt_attn_fwd": (i32, [C.POINTER(AttnParams), vp]),
     "sdlt_attn_bwd": (i32, [C.POINTER(AttnParams), vp]),
     "sdlt_groupnorm_fwd": (i32, [C.POINTER(GroupNormParams), vp]),

@@ -135,11 +135,19 @@ class LoraGradPlan:
 
     def __init__(self, problems, Rp, device):
         # problems: list of dict(P, Q, out, M, Cw, R, rank_major, conv=None|ConvGeom)
+        lib = _lib.load()
+        bc = lib.sdlt_lora_grad_block_cols()
+        # longest token streams first: a workgroup streams all M rows of its 64 columns, so the tail of the launch
+        # should be made of the short problems
+        order = sorted(range(len(problems)), key=lambda i: -problems[i]["M"])
         descs = (_lib.LoraGradDesc * len(problems))()
         block_desc = []
         self.keep = []
         nb = 0
-        for i, pr in enumerate(problems):
+        mfma = True
+        zp = zero_page(device)
+        for i, pi in enumerate(order):
+            pr = problems[pi]
             d = descs[i]
             P, Q, out = pr["P"], pr["Q"], pr["out"]
             _chk2(P), _chk2(Q), _chk2(out, F32)
@@ -147,19 +155,22 @@ class LoraGradPlan:
             d.M, d.Cw, d.R, d.Rp = pr["M"], pr["Cw"], pr["R"], Rp
             assert Q.shape[1] == Rp and Q.shape[0] == pr["M"] and out.numel() == pr["Cw"] * pr["R"] and out.is_contiguous()
             d.rank_major, d.accumulate = int(pr["rank_major"]), 0
+            d.zero = zp.data_ptr()
             cv = pr.get("conv")
+            ok = _ld(P) % 8 == 0 and _ld(Q) % 8 == 0 and pr["Cw"] % 8 == 0 and P.data_ptr() % 16 == 0 and Q.data_ptr() % 16 == 0
             if cv is not None:
                 d.conv, d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.stride = 1, cv.Hin, cv.Win, cv.Cin, cv.Hout, cv.Wout, cv.stride
                 assert pr["Cw"] == 9 * cv.Cin and pr["M"] == cv.B * cv.Hout * cv.Wout
-                d.zero = zero_page(device).data_ptr()
+                ok = ok and cv.Cin % bc == 0
             else:
                 assert P.shape[0] == pr["M"] and P.shape[1] == pr["Cw"]
+            mfma = mfma and ok
             d.first_block = nb
-            blocks = (pr["Cw"] + 127) // 128
+            blocks = (pr["Cw"] + bc - 1) // bc
             block_desc += [i] * blocks
             nb += blocks
             self.keep += [P, Q, out]
-        self.n_blocks, self.Rp = nb, Rp
+        self.n_blocks, self.Rp, self.mfma = nb, Rp, int(mfma)
         raw = bytes(descs)
         self.descs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
         self.block_desc_dev = torch.tensor(block_desc, dtype=torch.int32, device=device)
@@ -172,7 +183,7 @@ class LoraGradPlan:
 
     def run(self):
         lib = _lib.load()
-        _lib.check(lib.sdlt_lora_grad_grouped(_p(self.descs_dev), _p(self.block_desc_dev), self.n_blocks, self.Rp, _stream()),
+        _lib.check(lib.sdlt_lora_grad_grouped(_p(self.descs_dev), _p(self.block_desc_dev), self.n_blocks, self.Rp, self.mfma, _stream()),
                    "sdlt_lora_grad_grouped")
 
 

@@ -209,6 +209,33 @@ def test_lora_grad_grouped(ops):
         close(pg["out"], 2 * pc["out"], tol=2e-3, what="lora grad accumulate")
 
 
+@pytest.mark.parametrize("Rp,specs,expect_mfma", [
+    (64, [(520, 320, 64, True, None), (96, 64, 40, False, None), (2 * 8 * 8, 9 * 64, 64, True, (2, 8, 8, 64))], 1),
+    (32, [(333, 128, 24, True, None)], 1),
+    (16, [(100, 36, 16, True, None), (2 * 4 * 4, 9 * 32, 8, False, (2, 4, 4, 32))], 0),      # odd shapes -> VALU kernel
+])
+def test_lora_grad_grouped_ranks_and_fallback(ops, Rp, specs, expect_mfma):
+    g = torch.Generator().manual_seed(5 + Rp)
+    probs_cpu, probs_gpu = [], []
+    for (M, Cw, R, rank_major, conv) in specs:
+        Q = rnd(M, Rp, g=g)
+        if conv is None:
+            P, cg_c, cg_g = rnd(M, Cw, g=g), None, None
+        else:
+            B, H, W, Cin = conv
+            P = rnd(B * H * W, Cin, g=g)
+            cg_c, cg_g = E.ConvGeom(B, H, W, Cin, H, W), ops.ConvGeom(B, H, W, Cin, H, W)
+        probs_cpu.append(dict(P=P, Q=Q, out=torch.zeros(Cw * R, dtype=F32), M=M, Cw=Cw, R=R, rank_major=rank_major, conv=cg_c))
+        probs_gpu.append(dict(P=P.cuda(), Q=Q.cuda(), out=torch.full((Cw * R,), 3.0, dtype=F32, device="cuda"), M=M, Cw=Cw, R=R,
+                              rank_major=rank_major, conv=cg_g))
+    E.LoraGradPlan(probs_cpu, Rp, "cpu").run()
+    plan = ops.LoraGradPlan(probs_gpu, Rp, torch.device("cuda"))
+    assert plan.mfma == expect_mfma
+    plan.run()
+    for pc, pg in zip(probs_cpu, probs_gpu):
+        close(pg["out"], pc["out"], tol=2e-3, what=f"lora grad Rp={Rp} M={pc['M']} Cw={pc['Cw']}")
+
+
 # --------------------------------------------------------------------------------------------- attention
 ATTN_CASES = [
     dict(B=2, H=2, Nq=256, Nk=256, Nkp=256, d=64, causal=False, qsplit=1),
