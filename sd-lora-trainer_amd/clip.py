@@ -43,11 +43,11 @@ class ClipLayer(_Module):
     def forward(self, x, B, out=None):
         rt, M, D = self.rt, B * TP, self.D
         n1 = self.ln1.forward(x)
-        q = self.q.forward(n1, Ct=self.buf("Qt", D, M))
-        k = self.k.forward(n1, Ct=self.buf("Kt", D, M))
-        v = self.v.forward(n1, Ct=self.buf("Vt", D, M))
+        q = self.q.forward(n1)
+        k = self.k.forward(n1)
+        v = self.v.forward(n1)
         O, L = self.buf("O", M, D), self.buf("L", B * self.heads * T_TOKENS, dtype=F32)
-        rt.ops.attn_fwd(q, k, v, self._b["Vt"], O, L, **self._akw(B))
+        rt.ops.attn_fwd(q, k, v, None, O, L, **self._akw(B))
         x1 = self.o.forward(O, residual=x)
         f = self.fc1.forward(self.ln2.forward(x1))
         a = rt.ops.map_bf16(self.act, f, None, self.buf("a", *f.shape))
@@ -60,10 +60,10 @@ class ClipLayer(_Module):
         da = self.fc2.backward(dx2)
         df = rt.ops.map_bf16(self.dact, self.fc1._b["y"], da, self.buf("df", *da.shape))
         dx1 = self.ln2.backward(self.fc1.backward(df), dres=dx2)
-        dO = self.o.backward(dx1, Ct=self.buf("dOt", D, M))
+        dO = self.o.backward(dx1)
         dq, dk, dv = self.buf("dq", M, D), self.buf("dk", M, D), self.buf("dv", M, D)
-        rt.ops.attn_bwd(self.q._b["y"], self.k._b["y"], self.v._b["y"], self._b["Kt"], self._b["Qt"], self._b["O"], self._b["L"], dO,
-                        self._b["dOt"], self.buf("Dd", B * self.heads * T_TOKENS, dtype=F32), dq, dk, dv, **self._akw(B))
+        rt.ops.attn_bwd(self.q._b["y"], self.k._b["y"], self.v._b["y"], None, None, self._b["O"], self._b["L"], dO,
+                        None, self.buf("Dd", B * self.heads * T_TOKENS, dtype=F32), dq, dk, dv, **self._akw(B))
         dn1 = self.q.backward(dq)
         self.k.backward(dk, dres=dn1, out=dn1)
         self.v.backward(dv, dres=dn1, out=dn1)

@@ -8,9 +8,10 @@
 // sum_h Q_h K_h^T = Q K^T, and goes through sdlt_gemm_bf16.)
 //
 // Layout contract: Q/K/V/O/dO/dQ/dK/dV are token-major [B*N, C] with head h in columns [h*d,(h+1)*d).
-// Operands that an MFMA must contract over the TOKEN axis are also supplied transposed ([C, B*N],
-// written by the producing GEMM's epilogue, see sdlt_gemm_bf16 Ct) so every LDS tile is filled with
-// plain 16-byte copies and read with ds_read_b128 - no in-kernel transposes.
+// Every LDS tile is the natural [64 tokens][d] image filled with plain 16-byte copies.  Operands that an MFMA must
+// contract over the TOKEN axis (V in P.V, K in dS.K, Q and dO in the dK/dV products) are read from that same image
+// with the gfx950 transposing LDS read (ds_read_b64_tr_b16 x2 = one 16x16x32 fragment), so no transposed copy of any
+// tensor exists in HBM and each tile is fetched once.  (The Kt/Vt/Qt/dOt fields of sdlt_attn_params are ignored.)
 //
 // MFMA chaining without cross-lane traffic: all products are computed "swapped" (D[i][j] with j the
 // row that owns the softmax statistics), and the tile rows fed as the MFMA A operand are PERMUTED
@@ -23,7 +24,6 @@
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
-constexpr int TSTR = 64 * 2 + 16;  // bytes per row of a transposed [DP][64-token] tile
 
 __device__ __forceinline__ bf16x8 pack8(const float* a, const float* b) {
   union { uint4 u; bf16x8 v; } c;
@@ -37,6 +37,17 @@ __device__ __forceinline__ bf16x8 ld_frag_global(const bf16_t* p, bool ok) {
   return c.v;
 }
 __device__ __forceinline__ int prow(int i, int half) { return ((i >> 2) << 3) + half * 4 + (i & 3); }
+
+// MFMA fragment contracted over the ROW axis of a row-major bf16 LDS tile: lane (g = lane>>4, i = lane&15) receives rows
+// r0 + 8g + {0..7} of column c0 + i.  `p` = tile + (r0 + 8g + (i>>2)) * stride + (c0 + 4*(i&3)) * 2: each 16-lane group
+// hands the hardware a [4 rows][16 cols] block (lane i: row i>>2, columns 4*(i&3)..+3) and gets it back transposed.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 lds_tr_frag(const char* p, int stride) {
+  typedef __attribute__((address_space(3))) bf16x4* lds_ptr;
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)p);
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p + 4 * stride));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 
 // Tiles are staged global -> registers -> LDS in two halves so the HBM/L2 latency of tile t+1 hides under the MFMAs
 // of tile t (registers are loaded before the compute phase and written to the other LDS buffer after it).
@@ -64,26 +75,6 @@ __device__ __forceinline__ void sstore_nat(const TileRegs<DP>& t, char* dst) {
     *(uint4*)(dst + row * NSTR + ch * 16) = t.r[i];
   }
 }
-// transposed tile: [DP rows dd][64 tokens] (row stride TSTR) <- srcT[(col0+dd)*ldT + t0 + t]; dd >= d or t >= ntok read as 0
-template <int DP>
-__device__ __forceinline__ void gload_tr(TileRegs<DP>& t, const bf16_t* srcT, int64_t ldT, int col0, int d, int64_t t0, int ntok) {
-#pragma unroll
-  for (int i = 0; i < DP / 32; ++i) {
-    int c = threadIdx.x + 256 * i;
-    int dd = c >> 3, ch = c & 7;
-    t.r[i] = (dd < d && ch * 8 < ntok) ? *(const uint4*)(srcT + (int64_t)(col0 + dd) * ldT + t0 + ch * 8) : make_uint4(0, 0, 0, 0);
-  }
-}
-template <int DP>
-__device__ __forceinline__ void sstore_tr(const TileRegs<DP>& t, char* dst) {
-#pragma unroll
-  for (int i = 0; i < DP / 32; ++i) {
-    int c = threadIdx.x + 256 * i;
-    int dd = c >> 3, ch = c & 7;
-    *(uint4*)(dst + dd * TSTR + ch * 16) = t.r[i];
-  }
-}
-
 // =============================================================================== forward
 template <int DP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const sdlt_attn_params p) {
@@ -106,22 +97,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const sdlt_attn_params p)
   const float sl2 = p.scale * LOG2E;
   const int kend = p.causal ? min(p.Nk, q0 + 64) : p.Nk;
 
-  constexpr int FBUF = 64 * NSTR + DP * TSTR;   // one K tile + one V^T tile
+  constexpr int FBUF = 2 * 64 * NSTR;   // one K tile + one V tile
   TileRegs<DP> kr, vr;
   gload_nat<DP>(kr, (const bf16_t*)p.K, p.ldk, (int64_t)b * p.Nkp, min(64, p.Nkp), hc, d);
-  gload_tr<DP>(vr, (const bf16_t*)p.Vt, p.ldvt, hc, d, (int64_t)b * p.Nkp, min(64, p.Nkp));
+  gload_nat<DP>(vr, (const bf16_t*)p.V, p.ldv, (int64_t)b * p.Nkp, min(64, p.Nkp), hc, d);
   sstore_nat<DP>(kr, smem);
-  sstore_tr<DP>(vr, smem + 64 * NSTR);
+  sstore_nat<DP>(vr, smem + 64 * NSTR);
+  const int troff = (8 * g + (i >> 2)) * NSTR + (i & 3) * 8;   // transposing-read lane offset inside a natural tile
   __syncthreads();
   int it = 0;
   for (int k0 = 0; k0 < kend; k0 += 64, ++it) {
     const char* Ks = smem + (it & 1) * FBUF;
-    const char* Vt = Ks + 64 * NSTR;
+    const char* Vs = Ks + 64 * NSTR;
     const bool more = k0 + 64 < kend;
     if (more) {   // next tile's loads fly while this tile is computed
       const int nk = min(64, p.Nkp - (k0 + 64));
       gload_nat<DP>(kr, (const bf16_t*)p.K, p.ldk, (int64_t)b * p.Nkp + k0 + 64, nk, hc, d);
-      gload_tr<DP>(vr, (const bf16_t*)p.Vt, p.ldvt, hc, d, (int64_t)b * p.Nkp + k0 + 64, nk);
+      gload_nat<DP>(vr, (const bf16_t*)p.V, p.ldv, (int64_t)b * p.Nkp + k0 + 64, nk, hc, d);
     }
     f32x4 s[4];
 #pragma unroll
@@ -169,14 +161,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const sdlt_attn_params p)
       bf16x8 pf = pack8(a4, b4);
 #pragma unroll
       for (int df = 0; df < DP / 16; ++df) {
-        bf16x8 vf = *(const bf16x8*)(Vt + (df * 16 + i) * TSTR + (kb * 32 + g * 8) * 2);
+        bf16x8 vf = lds_tr_frag(Vs + troff + kb * 32 * NSTR + df * 32, NSTR);   // V[key block kb][columns df*16..]^T
         o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[df], 0, 0, 0);
       }
     }
     if (more) {
       char* nb = smem + ((it + 1) & 1) * FBUF;
       sstore_nat<DP>(kr, nb);
-      sstore_tr<DP>(vr, nb + 64 * NSTR);
+      sstore_nat<DP>(vr, nb + 64 * NSTR);
     }
     __syncthreads();
   }
@@ -249,29 +241,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const sdlt_attn_params
   const float sl2 = p.scale * LOG2E;
   const int kend = p.causal ? min(p.Nk, q0 + 64) : p.Nk;
 
-  constexpr int QBUF = 2 * 64 * NSTR + DP * TSTR;   // K, V natural + K^T
-  TileRegs<DP> kr, vr, tr;
+  constexpr int QBUF = 2 * 64 * NSTR;   // K, V natural
+  TileRegs<DP> kr, vr;
+  const int troff = (8 * g + (i >> 2)) * NSTR + (i & 3) * 8;
   {
     const int nk = min(64, p.Nkp);
     gload_nat<DP>(kr, (const bf16_t*)p.K, p.ldk, (int64_t)b * p.Nkp, nk, hc, d);
     gload_nat<DP>(vr, (const bf16_t*)p.V, p.ldv, (int64_t)b * p.Nkp, nk, hc, d);
-    gload_tr<DP>(tr, (const bf16_t*)p.Kt, p.ldkt, hc, d, (int64_t)b * p.Nkp, nk);
     sstore_nat<DP>(kr, smem);
     sstore_nat<DP>(vr, smem + 64 * NSTR);
-    sstore_tr<DP>(tr, smem + 2 * 64 * NSTR);
   }
   __syncthreads();
   int it = 0;
   for (int k0 = 0; k0 < kend; k0 += 64, ++it) {
     const char* Ks = smem + (it & 1) * QBUF;
     const char* Vs = Ks + 64 * NSTR;
-    const char* Kt = Vs + 64 * NSTR;
     const bool more = k0 + 64 < kend;
     if (more) {
       const int nk = min(64, p.Nkp - (k0 + 64));
       gload_nat<DP>(kr, (const bf16_t*)p.K, p.ldk, (int64_t)b * p.Nkp + k0 + 64, nk, hc, d);
       gload_nat<DP>(vr, (const bf16_t*)p.V, p.ldv, (int64_t)b * p.Nkp + k0 + 64, nk, hc, d);
-      gload_tr<DP>(tr, (const bf16_t*)p.Kt, p.ldkt, hc, d, (int64_t)b * p.Nkp + k0 + 64, nk);
     }
     f32x4 s[4], dp[4];
 #pragma unroll
@@ -303,7 +292,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const sdlt_attn_params
       bf16x8 dsf = pack8(a4, b4);
 #pragma unroll
       for (int df = 0; df < DP / 16; ++df) {
-        bf16x8 ktf = *(const bf16x8*)(Kt + (df * 16 + i) * TSTR + (kb * 32 + g * 8) * 2);
+        bf16x8 ktf = lds_tr_frag(Ks + troff + kb * 32 * NSTR + df * 32, NSTR);
         dq[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dq[df], 0, 0, 0);
       }
     }
@@ -311,7 +300,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const sdlt_attn_params
       char* nb = smem + ((it + 1) & 1) * QBUF;
       sstore_nat<DP>(kr, nb);
       sstore_nat<DP>(vr, nb + 64 * NSTR);
-      sstore_tr<DP>(tr, nb + 2 * 64 * NSTR);
     }
     __syncthreads();
   }
@@ -360,17 +348,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const sdlt_attn_para
   int qt_lo = split * per, qt_hi = min(nqt, qt_lo + per);
   if (p.causal) qt_lo = max(qt_lo, ktile);  // queries before this key tile never see it
 
-  constexpr int KBUF = 2 * 64 * NSTR + 2 * DP * TSTR + 512;   // Q, dO natural + Q^T, dO^T + L, D
+  constexpr int KBUF = 2 * 64 * NSTR + 512;   // Q, dO natural + L, D
   constexpr bool DB = 2 * KBUF <= 160 * 1024;                 // double-buffered unless it would not fit the LDS
-  TileRegs<DP> qr, gr, qtr, gtr;
+  TileRegs<DP> qr, gr;
+  const int troff = (8 * g + (i >> 2)) * NSTR + (i & 3) * 8;
   float lreg = 0.f, dreg = 0.f;
   auto gload_all = [&](int qt) {
     const int q0 = qt * 64;
     const int nq = min(64, p.Nqp - q0);
     gload_nat<DP>(qr, (const bf16_t*)p.Q, p.ldq, (int64_t)b * p.Nqp + q0, nq, hc, d);
     gload_nat<DP>(gr, (const bf16_t*)p.dO, p.lddo, (int64_t)b * p.Nqp + q0, nq, hc, d);
-    gload_tr<DP>(qtr, (const bf16_t*)p.Qt, p.ldqt, hc, d, (int64_t)b * p.Nqp + q0, nq);
-    gload_tr<DP>(gtr, (const bf16_t*)p.dOt, p.lddot, hc, d, (int64_t)b * p.Nqp + q0, nq);
     if (threadIdx.x < 64) {
       int qq = q0 + threadIdx.x;
       lreg = qq < p.Nq ? p.L[((int64_t)b * p.H + h) * p.Nq + qq] * LOG2E : 0.f;
@@ -380,10 +367,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const sdlt_attn_para
   auto sstore_all = [&](char* base) {
     sstore_nat<DP>(qr, base);
     sstore_nat<DP>(gr, base + 64 * NSTR);
-    sstore_tr<DP>(qtr, base + 2 * 64 * NSTR);
-    sstore_tr<DP>(gtr, base + 2 * 64 * NSTR + DP * TSTR);
     if (threadIdx.x < 64) {
-      float* ls = (float*)(base + 2 * 64 * NSTR + 2 * DP * TSTR);
+      float* ls = (float*)(base + 2 * 64 * NSTR);
       ls[threadIdx.x] = lreg;
       ls[64 + threadIdx.x] = dreg;
     }
@@ -397,9 +382,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const sdlt_attn_para
     const int q0 = qt * 64;
     const char* Qs = smem + (DB ? ((qt - qt_lo) & 1) * KBUF : 0);
     const char* Gs = Qs + 64 * NSTR;
-    const char* Qt = Gs + 64 * NSTR;
-    const char* Gt = Qt + DP * TSTR;
-    const float* Ls = (const float*)(Gt + DP * TSTR);
+    const float* Ls = (const float*)(Gs + 64 * NSTR);
     const float* Ds = Ls + 64;
     const bool more = qt + 1 < qt_hi;
     if (more) gload_all(qt + 1);
@@ -439,9 +422,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const sdlt_attn_para
       bf16x8 dsf = pack8(c4, e4);
 #pragma unroll
       for (int df = 0; df < DP / 16; ++df) {
-        bf16x8 gtf = *(const bf16x8*)(Gt + (df * 16 + i) * TSTR + (qb * 32 + g * 8) * 2);
+        bf16x8 gtf = lds_tr_frag(Gs + troff + qb * 32 * NSTR + df * 32, NSTR);
         dv[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gtf, pf, dv[df], 0, 0, 0);
-        bf16x8 qtf = *(const bf16x8*)(Qt + (df * 16 + i) * TSTR + (qb * 32 + g * 8) * 2);
+        bf16x8 qtf = lds_tr_frag(Qs + troff + qb * 32 * NSTR + df * 32, NSTR);
         dk[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf, dk[df], 0, 0, 0);
       }
     }
@@ -531,10 +514,10 @@ extern "C" int sdlt_attn_fwd(const sdlt_attn_params* pp, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   int rc = attn_check(p, "sdlt_attn_fwd");
   if (rc) return rc;
-  if (!p.Vt || (p.ldvt % 8) || (p.ldo % 4)) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_attn_fwd: needs V^T (ld %% 8) and ldo %% 4");
+  if (p.ldo % 4) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_attn_fwd: ldo %% 4");
   const int dp = attn_dp(p.d);
   dim3 grid((p.Nq + 63) / 64, p.H, p.B);
-#define SMEM_FWD(D_) (2 * (64 * ((D_) * 2 + 16) + (D_) * TSTR))
+#define SMEM_FWD(D_) (2 * (2 * 64 * ((D_) * 2 + 16)))
   ATTN_DISPATCH(dp, attn_fwd_kernel, grid, SMEM_FWD)
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
@@ -545,9 +528,9 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   int rc = attn_check(p, "sdlt_attn_bwd");
   if (rc) return rc;
-  if (!p.Kt || !p.Qt || !p.dOt || !p.L || !p.D || !p.O || !p.dO || !p.dQ)
-    SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_attn_bwd: missing operand (K^T, Q^T, dO^T, L, D, O, dO, dQ are required)");
-  if ((p.ldkt % 8) || (p.ldqt % 8) || (p.lddot % 8) || (p.lddo % 8) || (p.ldo % 8) || (p.lddq % 4))
+  if (!p.L || !p.D || !p.O || !p.dO || !p.dQ)
+    SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_attn_bwd: missing operand (L, D, O, dO, dQ are required)");
+  if ((p.lddo % 8) || (p.ldo % 8) || (p.lddq % 4))
     SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_attn_bwd: ld alignment");
   if (p.qsplit < 1) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_attn_bwd: qsplit=%d", p.qsplit);
   if (!p.dK || !p.dV || (p.lddk % 4) || (p.lddv % 4) || (p.qsplit > 1 && (!p.dK32 || !p.dV32 || (p.ld32 % 4))))
@@ -560,14 +543,14 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
     hipLaunchKernelGGL(attn_prep_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)p.O, p.ldo, (const bf16_t*)p.dO, p.lddo, p.B, p.H, p.Nq, p.Nqp, p.d, p.D);
   }
   dim3 gq((p.Nq + 63) / 64, p.H, p.B);
-#define SMEM_DQ(D_) (2 * (2 * 64 * ((D_) * 2 + 16) + (D_) * TSTR))
+#define SMEM_DQ(D_) (2 * (2 * 64 * ((D_) * 2 + 16)))
   ATTN_DISPATCH(dp, attn_bwd_dq_kernel, gq, SMEM_DQ)
   if (p.qsplit > 1) {
     sdlt_zero_async(p.dK32, sizeof(float) * (size_t)p.B * p.Nkp * p.ld32, s);
     sdlt_zero_async(p.dV32, sizeof(float) * (size_t)p.B * p.Nkp * p.ld32, s);
   }
   dim3 gk(((p.Nk + 63) / 64) * p.qsplit, p.H, p.B);
-#define SMEM_DKV(D_) ((2 * (2 * 64 * ((D_) * 2 + 16) + 2 * (D_) * TSTR + 512) <= 160 * 1024 ? 2 : 1) * (2 * 64 * ((D_) * 2 + 16) + 2 * (D_) * TSTR + 512))
+#define SMEM_DKV(D_) (2 * (2 * 64 * ((D_) * 2 + 16) + 512))
   ATTN_DISPATCH(dp, attn_bwd_dkdv_kernel, gk, SMEM_DKV)
   if (p.qsplit > 1) {
     int C = p.H * p.d, rows = p.B * p.Nkp;

@@ -200,8 +200,8 @@ def _attn_params(Q, K, V, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=False):
 def attn_fwd(Q, K, V, Vt, O, L, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=False):
     lib = _lib.load()
     p = _attn_params(Q, K, V, B=B, H=H, Nq=Nq, Nk=Nk, Nqp=Nqp, Nkp=Nkp, d=d, scale=scale, causal=causal)
-    _chk2(Vt), _chk2(O), _chk2(L, F32)
-    p.Vt, p.ldvt, p.O, p.ldo, p.L = _p(Vt), _ld(Vt), _p(O), _ld(O), _p(L)
+    _chk2(O), _chk2(L, F32)      # Vt is accepted for call compatibility and ignored: the kernel transposes V tiles in LDS
+    p.O, p.ldo, p.L = _p(O), _ld(O), _p(L)
     _lib.check(lib.sdlt_attn_fwd(C.byref(p), _stream()), "sdlt_attn_fwd")
     return O
 
@@ -210,10 +210,9 @@ def attn_bwd(Q, K, V, Kt, Qt, O, L, dO, dOt, D, dQ, dK, dV, *, B, H, Nq, Nk, Nqp
              qsplit=1, dK32=None, dV32=None):
     lib = _lib.load()
     p = _attn_params(Q, K, V, B=B, H=H, Nq=Nq, Nk=Nk, Nqp=Nqp, Nkp=Nkp, d=d, scale=scale, causal=causal)
-    for t in (Kt, Qt, O, dO, dOt, dQ, dK, dV):
+    for t in (O, dO, dQ, dK, dV):      # Kt / Qt / dOt: accepted and ignored (see attn_fwd)
         _chk2(t)
     _chk2(L, F32), _chk2(D, F32)
-    p.Kt, p.ldkt, p.Qt, p.ldqt, p.dOt, p.lddot = _p(Kt), _ld(Kt), _p(Qt), _ld(Qt), _p(dOt), _ld(dOt)
     p.O, p.ldo, p.L, p.dO, p.lddo, p.D = _p(O), _ld(O), _p(L), _p(dO), _ld(dO), _p(D)
     p.dQ, p.lddq, p.dK, p.lddk, p.dV, p.lddv = _p(dQ), _ld(dQ), _p(dK), _ld(dK), _p(dV), _ld(dV)
     p.qsplit = qsplit

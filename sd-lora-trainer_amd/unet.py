@@ -328,16 +328,16 @@ class Attention(_Module):
         kv = ctx if self.cross else x
         Nk, Nkp = (77, CTX_PAD) if self.cross else (N, N)
         Mq, Mk = B * N, B * Nkp
-        Qt = self.buf("Qt", C, Mq)
-        Kt = self.buf("Kt", C, _pad_to(Mk, 8))
-        Vt = self.buf("Vt", C, _pad_to(Mk, 8))
-        q = self.to_q.forward(x, Ct=Qt)
-        k = self.to_k.forward(kv, Ct=Kt)
-        v = self.to_v.forward(kv, Ct=Vt)
+        # transposed copies of Q and K are only needed as GEMM operands of the score side output's backward (hooked
+        # cross-attention); the attention kernels themselves read every tile in its natural layout
+        need_t = self.cross and self.hooked
+        q = self.to_q.forward(x, Ct=self.buf("Qt", C, Mq) if need_t else None)
+        k = self.to_k.forward(kv, Ct=self.buf("Kt", C, _pad_to(Mk, 8)) if need_t else None)
+        v = self.to_v.forward(kv)
         O = self.buf("O", Mq, C)
         L = self.buf("L", B * self.heads * N, dtype=F32)
         self._dims = (B, N, Nk, Nkp)
-        rt.ops.attn_fwd(q, k, v, Vt, O, L, B=B, H=self.heads, Nq=N, Nk=Nk, Nqp=N, Nkp=Nkp, d=self.d, scale=self.scale)
+        rt.ops.attn_fwd(q, k, v, None, O, L, B=B, H=self.heads, Nq=N, Nk=Nk, Nqp=N, Nkp=Nkp, d=self.d, scale=self.scale)
         if self.cross and self.hooked:
             # DAAM side output (ti_cross_attn_loss.py:201-212): sum over heads of Q_h K_h^T / sqrt(d) = Q K^T / sqrt(d).
             # The token-attention loss only ever uses the MEAN over layers of these maps (loss.py:23-52), so the layers
@@ -362,8 +362,7 @@ class Attention(_Module):
         rt, C = self.rt, self.C
         B, N, Nk, Nkp = self._dims
         Mq, Mk = B * N, B * Nkp
-        dOt = self.buf("dOt", C, Mq)
-        dO = self.to_out.backward(dout, Ct=dOt)
+        dO = self.to_out.backward(dout)
         q, k, v = self.to_q._b["y"], self.to_k._b["y"], self.to_v._b["y"]
         dq, dk, dv = self.buf("dq", Mq, C), self.buf("dk", Mk, C), self.buf("dv", Mk, C)
         D = self.buf("D", B * self.heads * N, dtype=F32)
@@ -373,7 +372,7 @@ class Attention(_Module):
             qs = max(1, min((N + 63) // 64, 320 // max(1, ntiles * self.heads * B)))
             if qs > 1:
                 kw = dict(qsplit=qs, dK32=self.buf("dk32", Mk, C, dtype=F32), dV32=self.buf("dv32", Mk, C, dtype=F32))
-        rt.ops.attn_bwd(q, k, v, self._b["Kt"], self._b["Qt"], self._b["O"], self._b["L"], dO, dOt, D, dq, dk, dv,
+        rt.ops.attn_bwd(q, k, v, None, None, self._b["O"], self._b["L"], dO, None, D, dq, dk, dv,
                         B=B, H=self.heads, Nq=N, Nk=Nk, Nqp=N, Nkp=Nkp, d=self.d, scale=self.scale, **kw)
         if self.cross and self.hooked and rt.daam_grads is not None:
             # backward of the score side output: S = a Q K^T  ->  dQ += a dS K,  dK += a dS^T Q   (shared dS per resolution)
