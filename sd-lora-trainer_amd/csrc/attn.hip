@@ -126,28 +126,33 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const sdlt_attn_params p)
         s[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[kk], s[kf], 0, 0, 0);
       }
     }
+    // scores stay raw; the softmax scale rides in the exponent's FMA.  Masking only runs on tiles that need it (wave-uniform).
+    const bool full = k0 + 64 <= p.Nk && !(p.causal && k0 + 63 > q0 + wave * 16);
+    if (!full) {
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int key = k0 + (kf >> 1) * 32 + g * 8 + (kf & 1) * 4 + r;
+          if (key >= p.Nk || (p.causal && key > q)) s[kf][r] = -1e30f;
+        }
+    }
     float tmax = -1e30f;
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int key = k0 + (kf >> 1) * 32 + g * 8 + (kf & 1) * 4 + r;
-        float v = s[kf][r] * sl2;
-        if (key >= p.Nk || (p.causal && key > q)) v = -1e30f;
-        s[kf][r] = v;
-        tmax = fmaxf(tmax, v);
-      }
+      for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[kf][r]);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float mn = fmaxf(m, tmax);
-    const float alpha = exp2f(m - mn);
+    const float mn = fmaxf(m, tmax * sl2);
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);
     m = mn;
     float rs = 0.f;
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float pv = exp2f(s[kf][r] - mn);
+        float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][r], sl2, -mn));
         s[kf][r] = pv;
         rs += pv;
       }
@@ -276,15 +281,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const sdlt_attn_params
         dp[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, gf[kk], dp[kf], 0, 0, 0);
       }
     }
+    // wave-uniform: every (query row of this wave, key of this tile) pair is live -> no per-element masking
+    const bool full = k0 + 64 <= p.Nk && q0 + wave * 16 + 16 <= p.Nq && !(p.causal && k0 + 63 > q0 + wave * 16);
+    if (full) {
 #pragma unroll
-    for (int kf = 0; kf < 4; ++kf)
+      for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int key = k0 + (kf >> 1) * 32 + g * 8 + (kf & 1) * 4 + r;
-        bool ok = qok && key < p.Nk && !(p.causal && key > q);
-        float pv = ok ? exp2f(s[kf][r] * sl2 - Lq) : 0.f;
-        s[kf][r] = pv * (dp[kf][r] - Dq) * p.scale;  // dS
-      }
+        for (int r = 0; r < 4; ++r) {
+          float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][r], sl2, -Lq));
+          s[kf][r] = pv * (dp[kf][r] - Dq) * p.scale;  // dS
+        }
+    } else {
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int key = k0 + (kf >> 1) * 32 + g * 8 + (kf & 1) * 4 + r;
+          bool ok = qok && key < p.Nk && !(p.causal && key > q);
+          float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][r], sl2, -Lq)) : 0.f;
+          s[kf][r] = pv * (dp[kf][r] - Dq) * p.scale;  // dS
+        }
+    }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       float a4[4] = {s[2 * kb][0], s[2 * kb][1], s[2 * kb][2], s[2 * kb][3]};
@@ -401,17 +418,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const sdlt_attn_para
       }
     }
     // s[qf][r] = S[q = q0 + (qf>>1)*32 + g*8 + (qf&1)*4 + r][key]
+    const bool full = q0 + 64 <= p.Nq && k0 + wave * 16 + 16 <= p.Nk && !(p.causal && k0 + wave * 16 + 15 > q0);
+    if (full) {
 #pragma unroll
-    for (int qf = 0; qf < 4; ++qf)
+      for (int qf = 0; qf < 4; ++qf) {
+        const f32x4 l4 = *(const f32x4*)(Ls + (qf >> 1) * 32 + g * 8 + (qf & 1) * 4);
+        const f32x4 d4 = *(const f32x4*)(Ds + (qf >> 1) * 32 + g * 8 + (qf & 1) * 4);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int ql = (qf >> 1) * 32 + g * 8 + (qf & 1) * 4 + r;
-        int qq = q0 + ql;
-        bool ok = kok && qq < p.Nq && !(p.causal && key > qq);
-        float pv = ok ? exp2f(s[qf][r] * sl2 - Ls[ql]) : 0.f;
-        s[qf][r] = pv;
-        dp[qf][r] = pv * (dp[qf][r] - Ds[ql]) * p.scale;
+        for (int r = 0; r < 4; ++r) {
+          float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qf][r], sl2, -l4[r]));
+          s[qf][r] = pv;
+          dp[qf][r] = pv * (dp[qf][r] - d4[r]) * p.scale;
+        }
       }
+    } else {
+#pragma unroll
+      for (int qf = 0; qf < 4; ++qf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int ql = (qf >> 1) * 32 + g * 8 + (qf & 1) * 4 + r;
+          int qq = q0 + ql;
+          bool ok = kok && qq < p.Nq && !(p.causal && key > qq);
+          float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[qf][r], sl2, -Ls[ql])) : 0.f;
+          s[qf][r] = pv;
+          dp[qf][r] = pv * (dp[qf][r] - Ds[ql]) * p.scale;
+        }
+    }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       float a4[4] = {s[2 * qb][0], s[2 * qb][1], s[2 * qb][2], s[2 * qb][3]};

@@ -18,16 +18,16 @@ typedef unsigned short bf16_t;  // raw storage type used in signatures
 #define SDLT_ERR_UNSUPPORTED (-4)
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even fp32 -> bf16 (NaN preserved as quiet NaN)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16, round-to-nearest-even, NaN stays a quiet NaN: the gfx950 hardware conversion (one v_cvt_pk_bf16_f32 per
+// pair).  The software version (add 0x7fff + lsb, NaN branch) cost ~6 VALU instructions and an exec-mask branch per
+// element and dominated the VALU time of the attention kernels' P / dS packing.
+typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+typedef float f32x2_hw __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  f32x2_hw f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_hw));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // d/dx silu(x) = s + x*s*(1-s), s = sigmoid(x)
 __device__ __forceinline__ float dsilu_f(float x) {
