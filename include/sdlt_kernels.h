@@ -69,6 +69,11 @@ typedef struct sdlt_gemm_params {
   int32_t stages;             /* LDS ring depth: 0 = auto (deepest that fits), 2 = double buffer (2 workgroups per CU) */
   int32_t accumulate;         /* fp32 output only: C += result (DAAM score sums over layers) */
   int32_t* ws_cnt;            /* split-K arrival counters, zero-initialised ONCE by the caller; kernels re-arm them */
+  int32_t lora_group_n;       /* > 0: N is a concatenation of projections, `lora_group_n` columns each, every one with its
+                                 own adapter: group g = n / lora_group_n uses Adown rows [g*lora_R, (g+1)*lora_R) and writes
+                                 T_out columns [g*lora_R, (g+1)*lora_R); Bup stays [N, lora_R].  Fused to_q|to_k|to_v and
+                                 the batched cross-attention to_k|to_v of all blocks.  Must be a multiple of the N tile. */
+  int32_t pad1_;
 } sdlt_gemm_params;
 int sdlt_gemm_bf16(const sdlt_gemm_params* p, void* stream);
 

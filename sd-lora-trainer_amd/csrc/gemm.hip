@@ -127,6 +127,10 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
     // piece index handled by this wave in round j: wave + 4*j  (< R16*2)
     aptr = (const bf16_t*)p.Adown + schunk * 8;
   }
+  // grouped adapters (fused projections): this tile's column group selects the Adown rows and the T_out columns
+  const int lgrp = (R16 && p.lora_group_n > 0) ? n0 / p.lora_group_n : 0;
+  const bool t_writer = R16 && (p.lora_group_n > 0 ? n0 == lgrp * p.lora_group_n : bn == 0);
+  if (R16) aptr += (size_t)lgrp * (R16 * 16) * p.ld_adown;
 
   const int nk1 = p.K / BK, nk2 = p.K2 / BK, nk = nk1 + nk2;
   constexpr int AI = R16 ? ((2 * R16 + NW - 1) / NW) : 0;   // LoRA-down DMA instructions per wave and stage
@@ -373,13 +377,13 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
         *(uint2*)(tsh + ((size_t)ml * TROW + j * 16 + fk * 4) * 2) = v;
       }
     __syncthreads();
-    if (p.T_out != nullptr && bn == 0) {
+    if (p.T_out != nullptr && t_writer) {
       // [BM rows][R] bf16 -> global, 8 B per lane
       constexpr int CH = R16 * 4;  // 8-byte chunks per row
       for (int c = tid; c < BM * CH; c += NTHR) {
         int ml = c / CH, cc = c - ml * CH;
         int m = m0 + ml;
-        if (m < p.M) *(uint2*)((bf16_t*)p.T_out + (size_t)m * p.ld_t + cc * 4) = *(const uint2*)(tsh + ((size_t)ml * TROW + cc * 4) * 2);
+        if (m < p.M) *(uint2*)((bf16_t*)p.T_out + (size_t)m * p.ld_t + lgrp * (R16 * 16) + cc * 4) = *(const uint2*)(tsh + ((size_t)ml * TROW + cc * 4) * 2);
       }
     }
 #pragma unroll
@@ -529,6 +533,8 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
   }
   int bm, bn;
   tile_dims(p.tile, bm, bn);
+  if (R16 && p.lora_group_n > 0 && (p.lora_group_n % bn))
+    SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: lora_group_n=%d is not a multiple of the %d-column tile", p.lora_group_n, bn);
   if (p.splitk == 0) {
     // Split K until ~one workgroup per CU exists, keeping >= 8 K-steps per split (the fenced hand-off costs a few us).
     const long tiles = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);

@@ -68,10 +68,12 @@ class ConvGeom:
 
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
-         residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False):
+         residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0):
     """out[M,N] = alpha*(X.W^T [+ X2.W2^T] [+ s*(X.Adown^T).Bup^T]) + bias + rowbias[m//rows_per_batch] + residual.
     lora = (Adown [Rp,K], Bup [N,Rp], scale, T_out [M,Rp] or None).  out dtype bf16 or fp32.  Ct: optional
-    transposed bf16 copy [N, >=M].  conv: ConvGeom -> X is the NHWC activation [B*Hin*Win, Cin]."""
+    transposed bf16 copy [N, >=M].  conv: ConvGeom -> X is the NHWC activation [B*Hin*Win, Cin].
+    lora_group_n > 0: W is a stack of G = N / lora_group_n projections with one adapter each:
+    Adown [G*Rp, K] (group-major), Bup [N, Rp], T_out [M, G*Rp]."""
     lib = _lib.load()
     p = _lib.GemmParams()
     _chk2(X), _chk2(W)
@@ -96,13 +98,18 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
     if lora is not None:
         Adown, Bup, scale, T_out = lora
         _chk2(Adown), _chk2(Bup)
-        Rp = Adown.shape[0]
-        assert Adown.shape[1] == K and tuple(Bup.shape) == (N, Rp), (Adown.shape, Bup.shape, N, K)
+        Rp = Bup.shape[1]
+        G = 1
+        if lora_group_n:
+            assert N % lora_group_n == 0
+            G = N // lora_group_n
+            p.lora_group_n = lora_group_n
+        assert tuple(Adown.shape) == (G * Rp, K) and Bup.shape[0] == N, (Adown.shape, Bup.shape, N, K, G)
         p.Adown, p.ld_adown, p.Bup, p.ld_bup = _p(Adown), _ld(Adown), _p(Bup), _ld(Bup)
         p.lora_R, p.lora_scale = Rp, float(scale)
         if T_out is not None:
             _chk2(T_out)
-            assert tuple(T_out.shape) == (M, Rp)
+            assert tuple(T_out.shape) == (M, G * Rp)
             p.T_out, p.ld_t = _p(T_out), _ld(T_out)
     p.alpha = float(alpha)
     if bias is not None:

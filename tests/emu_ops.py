@@ -43,7 +43,7 @@ def _conv_apply(X, Wm, g):
 
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
-         residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False):
+         residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0):
     acc = X.float() @ W.float().t() if conv is None else _conv_apply(X, W, conv)
     if X2 is not None:
         acc = acc + X2.float() @ W2.float().t()
@@ -53,7 +53,13 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
         Tb = (T * scale).to(out.dtype if out.dtype != F32 else X.dtype)
         if T_out is not None:
             T_out.copy_(Tb)
-        acc = acc + Tb.float() @ Bup.float().t()
+        if lora_group_n:   # stacked projections, one adapter per group of lora_group_n output columns
+            Rp = Bup.shape[1]
+            for gi in range(W.shape[0] // lora_group_n):
+                cols = slice(gi * lora_group_n, (gi + 1) * lora_group_n)
+                acc[:, cols] = acc[:, cols] + Tb[:, gi * Rp:(gi + 1) * Rp].float() @ Bup[cols].float().t()
+        else:
+            acc = acc + Tb.float() @ Bup.float().t()
     acc = acc * alpha
     if bias is not None:
         acc = acc + bias.float()

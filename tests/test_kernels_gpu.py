@@ -209,6 +209,22 @@ def test_lora_grad_grouped(ops):
         close(pg["out"], 2 * pc["out"], tol=2e-3, what="lora grad accumulate")
 
 
+@pytest.mark.parametrize("M,C,K,G,tile,splitk", [(200, 128, 192, 3, 0, 0), (128, 256, 256, 2, 1, 0), (128, 128, 512, 4, 2, 2), (520, 64, 128, 3, 3, 1)])
+def test_gemm_grouped_lora(ops, M, C, K, G, tile, splitk):
+    """Stacked projections (fused to_q|to_k|to_v): one adapter per group of C output columns."""
+    g = torch.Generator().manual_seed(M + C + G)
+    Rp = 16
+    X, W = rnd(M, K, g=g), rnd(G * C, K, g=g, scale=0.2)
+    Ad, Bu = rnd(G * Rp, K, g=g, scale=0.3), rnd(G * C, Rp, g=g, scale=0.3)
+    bias = rnd(G * C, g=g).float()
+    out_c, T_c = torch.zeros(M, G * C, dtype=BF), torch.zeros(M, G * Rp, dtype=BF)
+    E.gemm(X, W, out_c, lora=(Ad, Bu, 0.7, T_c), bias=bias, lora_group_n=C)
+    out_g, T_g = torch.zeros(M, G * C, dtype=BF, device="cuda"), torch.zeros(M, G * Rp, dtype=BF, device="cuda")
+    ops.gemm(X.cuda(), W.cuda(), out_g, lora=(Ad.cuda(), Bu.cuda(), 0.7, T_g), bias=bias.cuda(), lora_group_n=C, tile=tile, splitk=splitk)
+    close(T_g, T_c, tol=1.5e-2, what="grouped lora T_out")
+    close(out_g, out_c, tol=1.5e-2, what="grouped lora out")
+
+
 @pytest.mark.parametrize("Rp,specs,expect_mfma", [
     (64, [(520, 320, 64, True, None), (96, 64, 40, False, None), (2 * 8 * 8, 9 * 64, 64, True, (2, 8, 8, 64))], 1),
     (32, [(333, 128, 24, True, None)], 1),
