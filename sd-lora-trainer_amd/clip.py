@@ -15,7 +15,7 @@ import math
 import torch
 
 from . import ops as _ops
-from .unet import F32, LayerNorm, Linear, _Module
+from .unet import F32, LayerNorm, Linear, StackedLinear, _Module
 
 T_TOKENS = 77
 TP = 128
@@ -28,6 +28,7 @@ class ClipLayer(_Module):
         self.q = Linear(rt, name + ".self_attn.q_proj", sd)
         self.k = Linear(rt, name + ".self_attn.k_proj", sd)
         self.v = Linear(rt, name + ".self_attn.v_proj", sd)
+        self.qkv = StackedLinear(rt, name + ".self_attn.qkv", [self.q, self.k, self.v])
         self.o = Linear(rt, name + ".self_attn.out_proj", sd)
         self.ln2 = LayerNorm(rt, name + ".layer_norm2", sd)
         self.fc1 = Linear(rt, name + ".mlp.fc1", sd)
@@ -43,9 +44,7 @@ class ClipLayer(_Module):
     def forward(self, x, B, out=None):
         rt, M, D = self.rt, B * TP, self.D
         n1 = self.ln1.forward(x)
-        q = self.q.forward(n1)
-        k = self.k.forward(n1)
-        v = self.v.forward(n1)
+        q, k, v = self.qkv.forward(n1)
         O, L = self.buf("O", M, D), self.buf("L", B * self.heads * T_TOKENS, dtype=F32)
         rt.ops.attn_fwd(q, k, v, None, O, L, **self._akw(B))
         x1 = self.o.forward(O, residual=x)

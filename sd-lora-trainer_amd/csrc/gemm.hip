@@ -533,6 +533,10 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
   }
   int bm, bn;
   tile_dims(p.tile, bm, bn);
+  if (R16 && p.lora_group_n > 0 && (p.lora_group_n % bn) && pin.tile == 0 && p.lora_group_n % 64 == 0) {
+    p.tile = 3;   // narrow groups (head width 64): the 64x64 tile never straddles two adapters
+    tile_dims(p.tile, bm, bn);
+  }
   if (R16 && p.lora_group_n > 0 && (p.lora_group_n % bn))
     SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: lora_group_n=%d is not a multiple of the %d-column tile", p.lora_group_n, bn);
   if (p.splitk == 0) {

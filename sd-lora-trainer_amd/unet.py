@@ -192,6 +192,51 @@ class Linear(_Module):
         return dx
 
 
+class StackedLinear(_Module):
+    """Forward of several Linear layers that read the same input (to_q|to_k|to_v, to_k|to_v) as ONE GEMM over the
+    stacked weights, each projection keeping its own LoRA adapter (sdlt_gemm_bf16 lora_group_n).  The members keep their
+    own backward (dX needs per-projection dY anyway); this class only re-points their weights, LoRA shadows, outputs and
+    T buffers at slices of the stacked tensors.  Must be built before LoraArena.finalize()."""
+
+    def __init__(self, rt, name, members):
+        super().__init__(rt, name)
+        self.members = members
+        N, K = members[0].N, members[0].K
+        assert all(m.N == N and m.K == K for m in members), "stacked projections must share their shape"
+        self.N, self.K, self.G = N, K, len(members)
+        self.W = torch.cat([m.W for m in members], 0).contiguous()
+        for g, m in enumerate(members):
+            m.W = self.W[g * N:(g + 1) * N]
+        self.bias = torch.cat([m.bias for m in members]).contiguous() if members[0].bias is not None else None
+        self.arena = members[0].arena
+        self.has_lora = members[0].lora is not None
+        if self.has_lora:
+            Rp = self.arena.Rp
+            self.A_cat, self.B_cat = rt.zeros(self.G * Rp, K), rt.zeros(self.G * N, Rp)
+            for g, m in enumerate(members):   # the arena's shadow refresh now writes straight into the stacked operands
+                m.lora["A_s"] = self.A_cat[g * Rp:(g + 1) * Rp]
+                m.lora["B_s"] = self.B_cat[g * N:(g + 1) * N]
+
+    def forward(self, x, Ct=None):
+        """Returns the member outputs as column slices of one [M, G*N] buffer."""
+        M, N, G = x.shape[0], self.N, self.G
+        y = self.buf("y", M, G * N)
+        lora = None
+        if self.has_lora:
+            Rp = self.arena.Rp
+            T = self.buf("T", M, G * Rp)
+            lora = (self.A_cat, self.B_cat, self.arena.scale, T)
+        self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, Ct=Ct, lora_group_n=N if self.has_lora else 0)
+        outs = []
+        for g, m in enumerate(self.members):
+            m._x = x
+            m._b["y"] = y[:, g * N:(g + 1) * N]
+            if self.has_lora:
+                m._b["T"] = T[:, g * Rp:(g + 1) * Rp]
+            outs.append(m._b["y"])
+        return outs
+
+
 class Conv3x3(_Module):
     """3x3 conv (pad 1) on NHWC activations as an implicit GEMM; optional stride 2 / nearest-2x upsampled input."""
 
@@ -318,6 +363,8 @@ class Attention(_Module):
         self.to_v = Linear(rt, name + ".to_v", sd, arena)
         self.to_out = Linear(rt, name + ".to_out.0", sd, arena)
         self.heads, self.cross, self.hooked = heads, cross, hooked
+        # one GEMM for the projections that share an input: q|k|v of self-attention, k|v of cross-attention
+        self.stack = StackedLinear(rt, name + (".to_kv" if cross else ".to_qkv"), [self.to_k, self.to_v] if cross else [self.to_q, self.to_k, self.to_v])
         self.C = self.to_q.N
         self.d = self.C // heads
         self.scale = 1.0 / math.sqrt(self.d)
@@ -331,9 +378,14 @@ class Attention(_Module):
         # transposed copies of Q and K are only needed as GEMM operands of the score side output's backward (hooked
         # cross-attention); the attention kernels themselves read every tile in its natural layout
         need_t = self.cross and self.hooked
-        q = self.to_q.forward(x, Ct=self.buf("Qt", C, Mq) if need_t else None)
-        k = self.to_k.forward(kv, Ct=self.buf("Kt", C, _pad_to(Mk, 8)) if need_t else None)
-        v = self.to_v.forward(kv)
+        if self.cross:
+            q = self.to_q.forward(x, Ct=self.buf("Qt", C, Mq) if need_t else None)
+            KVt = self.buf("KVt", 2 * C, _pad_to(Mk, 8)) if need_t else None
+            k, v = self.stack.forward(kv, Ct=KVt)
+            if need_t:
+                self._b["Kt"] = KVt[:C]
+        else:
+            q, k, v = self.stack.forward(x)
         O = self.buf("O", Mq, C)
         L = self.buf("L", B * self.heads * N, dtype=F32)
         self._dims = (B, N, Nk, Nkp)
