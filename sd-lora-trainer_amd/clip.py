@@ -60,12 +60,10 @@ class ClipLayer(_Module):
         df = rt.ops.map_bf16(self.dact, self.fc1._b["y"], da, self.buf("df", *da.shape))
         dx1 = self.ln2.backward(self.fc1.backward(df), dres=dx2)
         dO = self.o.backward(dx1)
-        dq, dk, dv = self.buf("dq", M, D), self.buf("dk", M, D), self.buf("dv", M, D)
+        dqkv, (dq, dk, dv) = self.qkv.grad_slices(M)
         rt.ops.attn_bwd(self.q._b["y"], self.k._b["y"], self.v._b["y"], None, None, self._b["O"], self._b["L"], dO,
                         None, self.buf("Dd", B * self.heads * T_TOKENS, dtype=F32), dq, dk, dv, **self._akw(B))
-        dn1 = self.q.backward(dq)
-        self.k.backward(dk, dres=dn1, out=dn1)
-        self.v.backward(dv, dres=dn1, out=dn1)
+        dn1 = self.qkv.backward(dqkv)
         return self.ln1.backward(dn1, dres=dx1)
 
 

@@ -407,6 +407,10 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   }
 
   // ---------------- epilogue ----------------
+#ifdef SDLT_LAB_NO_EPILOGUE
+  if (acc[0][0][0] == 12345.f) ((float*)p.C)[0] = 1.f;
+  return;
+#endif
   // acc[a][b][r] = C[m = m0 + wm*MI*16 + b*16 + (lane&15)][n = n0 + wn*NI*16 + a*16 + (lane>>4)*4 + r]
   const bool vec_ok = ((p.ldc & 3) == 0) && (p.R == nullptr || (p.ldr & 3) == 0) &&
                       (p.rowbias == nullptr || (p.ld_rowbias & 3) == 0);

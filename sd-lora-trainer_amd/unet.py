@@ -236,6 +236,22 @@ class StackedLinear(_Module):
             outs.append(m._b["y"])
         return outs
 
+    def grad_slices(self, M):
+        """One [M, G*N] buffer whose column slices receive the members' output gradients (attention writes them there)."""
+        dy = self.buf("dy", M, self.G * self.N)
+        return dy, [dy[:, g * self.N:(g + 1) * self.N] for g in range(self.G)]
+
+    def backward(self, dy_cat, *, dres=None, out=None):
+        """dx = sum_g dy_g W_g = dy_cat . W_cat as ONE GEMM over K = G*N (projections without LoRA adapters only)."""
+        assert not self.has_lora
+        if getattr(self, "Wt", None) is None:
+            self.Wt = self.W.t().contiguous()
+            for m in self.members:
+                m.Wt = None          # the per-member transposes are dead once the stacked one exists
+        dx = out if out is not None else self.buf("dx", dy_cat.shape[0], self.K)
+        self.rt.ops.gemm(dy_cat, self.Wt, dx, residual=dres)
+        return dx
+
 
 class Conv3x3(_Module):
     """3x3 conv (pad 1) on NHWC activations as an implicit GEMM; optional stride 2 / nearest-2x upsampled input."""
