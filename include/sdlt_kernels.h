@@ -122,6 +122,8 @@ int32_t sdlt_lora_grad_block_cols(void);
  * (written by fwd, read by bwd), D = rowsum(dO*O) [B,H,Nq] fp32 scratch (written by bwd).
  * qsplit>1 splits the dK/dV reduction over query ranges (cross-attention: few keys, many queries),
  * accumulating in dK32/dV32 fp32 [B*Nkp, ld32] scratch before the bf16 store.  causal: CLIP.
+ * Cross-attention (qsplit > 1, !causal, Nkp <= 128, d <= 96) takes a single-pass kernel (D, dQ, dK, dV together):
+ * there qsplit = workgroups along the queries and dK32/dV32 must hold qsplit slabs, [qsplit][B*Nkp][ld32] each.
  */
 typedef struct sdlt_attn_params {
   const void* Q; int64_t ldq;

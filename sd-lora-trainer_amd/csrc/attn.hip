@@ -490,15 +490,276 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const sdlt_attn_para
   }
 }
 
-// fp32 [rows, C] (ld32) -> bf16 [rows, C] (ld) after the atomics of the query-split path
-__global__ void cvt_f32_bf16_kernel(const float* in, int64_t ldi, bf16_t* out, int64_t ldo, int rows, int C) {
+// =============================================================================== backward, cross-attention: dQ, dK, dV (and D) in ONE pass
+// Nk <= 128 keys (the 77 text tokens): one workgroup owns ALL keys of one (batch, head) and a range of 64-query tiles.
+// Per tile it runs both orientations of the score product: q-major (this wave's 16 query rows x 128 keys -> dQ rows,
+// written once, plus D = rowsum(dO * O), which replaces the separate prep kernel) and key-major (its 2 x 16 keys x
+// the 64 queries -> dK / dV accumulated in registers over the whole query range, then fp32 atomics).  Replaces the
+// prep + dQ + query-split dK/dV launches of the generic path for the UNet's cross-attention.
+template <int DP>
+__global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_params p) {
+  constexpr int NSTR = DP * 2 + 16;
+  constexpr int QBUF = 2 * 64 * NSTR;                   // Q, dO natural
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;                                      // [128][NSTR], resident
+  char* Vs = Ks + 128 * NSTR;
+  char* ring = Vs + 128 * NSTR;                         // 2 x QBUF
+  float* LD = (float*)(ring + 2 * QBUF);                // L*log2e [64], D [64] of the current tile
+  const int b = blockIdx.z, h = blockIdx.y, split = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
+  const int d = p.d, hc = h * d;
+  const float sl2 = p.scale * LOG2E;
+  const int troff = (8 * g + (i >> 2)) * NSTR + (i & 3) * 8;
+
+  TileRegs<DP> qr, gr;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {                         // resident K / V tiles (rows >= Nkp read as zero)
+    const int nk = min(64, max(0, p.Nkp - t * 64));
+    gload_nat<DP>(qr, (const bf16_t*)p.K, p.ldk, (int64_t)b * p.Nkp + t * 64, nk, hc, d);
+    gload_nat<DP>(gr, (const bf16_t*)p.V, p.ldv, (int64_t)b * p.Nkp + t * 64, nk, hc, d);
+    sstore_nat<DP>(qr, Ks + t * 64 * NSTR);
+    sstore_nat<DP>(gr, Vs + t * 64 * NSTR);
+  }
+  // key-major operands: this wave's keys w*64 + wave*16 + i
+  int key[2];
+  bool kok[2];
+  bf16x8 kf[2][DP / 32], vf[2][DP / 32];
+  f32x4 dk[2][DP / 16], dv[2][DP / 16];
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    key[w] = w * 64 + wave * 16 + i;
+    kok[w] = key[w] < p.Nk;
+#pragma unroll
+    for (int kk = 0; kk < DP / 32; ++kk) {
+      int col = kk * 32 + g * 8;
+      kf[w][kk] = ld_frag_global((const bf16_t*)p.K + ((int64_t)b * p.Nkp + key[w]) * p.ldk + hc + col, kok[w] && col < d);
+      vf[w][kk] = ld_frag_global((const bf16_t*)p.V + ((int64_t)b * p.Nkp + key[w]) * p.ldv + hc + col, kok[w] && col < d);
+    }
+#pragma unroll
+    for (int df = 0; df < DP / 16; ++df) {
+      dk[w][df] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dv[w][df] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const int nqt = (p.Nq + 63) / 64;
+  const int per = (nqt + p.qsplit - 1) / p.qsplit;
+  const int qt_lo = split * per, qt_hi = min(nqt, qt_lo + per);
+  auto gload_all = [&](int qt) {
+    const int q0 = qt * 64;
+    const int nq = min(64, p.Nqp - q0);
+    gload_nat<DP>(qr, (const bf16_t*)p.Q, p.ldq, (int64_t)b * p.Nqp + q0, nq, hc, d);
+    gload_nat<DP>(gr, (const bf16_t*)p.dO, p.lddo, (int64_t)b * p.Nqp + q0, nq, hc, d);
+  };
+  auto sstore_all = [&](char* base) {
+    sstore_nat<DP>(qr, base);
+    sstore_nat<DP>(gr, base + 64 * NSTR);
+  };
+  if (qt_lo < qt_hi) {
+    gload_all(qt_lo);
+    sstore_all(ring);
+  }
+  __syncthreads();
+  for (int qt = qt_lo; qt < qt_hi; ++qt) {
+    const int q0 = qt * 64;
+    const char* Qs = ring + ((qt - qt_lo) & 1) * QBUF;
+    const char* Gs = Qs + 64 * NSTR;
+    const bool more = qt + 1 < qt_hi;
+    if (more) gload_all(qt + 1);
+
+    // ---------------- q-major: this wave's rows q0 + wave*16 + i against all 128 keys -> D, dQ
+    {
+      const int ql = wave * 16 + i, q = q0 + ql;
+      const bool qok = q < p.Nq;
+      bf16x8 qf[DP / 32], gf[DP / 32];
+      float Dq = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < DP / 32; ++kk) {
+        const int col = kk * 32 + g * 8;
+        qf[kk] = *(const bf16x8*)(Qs + ql * NSTR + col * 2);
+        gf[kk] = *(const bf16x8*)(Gs + ql * NSTR + col * 2);
+        bf16x8 of = ld_frag_global((const bf16_t*)p.O + ((int64_t)b * p.Nqp + q) * p.ldo + hc + col, qok && col < d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Dq += (float)gf[kk][j] * (float)of[j];
+      }
+      Dq += __shfl_xor(Dq, 16, 64);
+      Dq += __shfl_xor(Dq, 32, 64);
+      const float Lq = qok ? p.L[((int64_t)b * p.H + h) * p.Nq + q] * LOG2E : 0.f;
+      if (g == 0) {
+        LD[ql] = Lq;
+        LD[64 + ql] = Dq;
+      }
+      f32x4 dq[DP / 16];
+#pragma unroll
+      for (int df = 0; df < DP / 16; ++df) dq[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if (half * 64 >= p.Nk) break;                   // uniform: no live key in the second half
+        f32x4 s2[4], dp2[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          s2[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          dp2[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          const int krow = half * 64 + (f >> 1) * 32 + prow(i, f & 1);
+#pragma unroll
+          for (int kk = 0; kk < DP / 32; ++kk) {
+            bf16x8 kfr = *(const bf16x8*)(Ks + krow * NSTR + (kk * 32 + g * 8) * 2);
+            s2[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[kk], s2[f], 0, 0, 0);
+            bf16x8 vfr = *(const bf16x8*)(Vs + krow * NSTR + (kk * 32 + g * 8) * 2);
+            dp2[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, gf[kk], dp2[f], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kx = half * 64 + (f >> 1) * 32 + g * 8 + (f & 1) * 4 + r;
+            const bool ok = qok && kx < p.Nk;
+            const float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s2[f][r], sl2, -Lq)) : 0.f;
+            s2[f][r] = pv * (dp2[f][r] - Dq) * p.scale;  // dS
+          }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          float a4[4] = {s2[2 * kb][0], s2[2 * kb][1], s2[2 * kb][2], s2[2 * kb][3]};
+          float b4[4] = {s2[2 * kb + 1][0], s2[2 * kb + 1][1], s2[2 * kb + 1][2], s2[2 * kb + 1][3]};
+          bf16x8 dsf = pack8(a4, b4);
+#pragma unroll
+          for (int df = 0; df < DP / 16; ++df) {
+            bf16x8 ktf = lds_tr_frag(Ks + troff + (half * 64 + kb * 32) * NSTR + df * 32, NSTR);
+            dq[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dq[df], 0, 0, 0);
+          }
+        }
+      }
+      if (q < p.Nqp) {   // pad rows: dq == 0
+#pragma unroll
+        for (int df = 0; df < DP / 16; ++df) {
+          int col = df * 16 + g * 4;
+          if (col < d) {
+            uint2 wv;
+            wv.x = pack2bf(dq[df][0], dq[df][1]);
+            wv.y = pack2bf(dq[df][2], dq[df][3]);
+            *(uint2*)((bf16_t*)p.dQ + ((int64_t)b * p.Nqp + q) * p.lddq + hc + col) = wv;
+          }
+        }
+      }
+    }
+    __syncthreads();   // L, D of all 64 rows visible
+
+    // ---------------- key-major: this wave's 2 x 16 keys against the tile's 64 queries -> dK, dV
+    {
+      const float* Ls = LD;
+      const float* Ds = LD + 64;
+      f32x4 s[2][4], dp[2][4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          s[w][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          dp[w][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const int qrow = (f >> 1) * 32 + prow(i, f & 1);
+#pragma unroll
+        for (int kk = 0; kk < DP / 32; ++kk) {
+          bf16x8 qfr = *(const bf16x8*)(Qs + qrow * NSTR + (kk * 32 + g * 8) * 2);
+          bf16x8 gfr = *(const bf16x8*)(Gs + qrow * NSTR + (kk * 32 + g * 8) * 2);
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            s[w][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[w][kk], s[w][f], 0, 0, 0);
+            dp[w][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gfr, vf[w][kk], dp[w][f], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ql2 = (f >> 1) * 32 + g * 8 + (f & 1) * 4 + r;
+            const bool ok = kok[w] && q0 + ql2 < p.Nq;
+            const float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[w][f][r], sl2, -Ls[ql2])) : 0.f;
+            s[w][f][r] = pv;
+            dp[w][f][r] = pv * (dp[w][f][r] - Ds[ql2]) * p.scale;
+          }
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        bf16x8 pf[2], dsf[2];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          float a4[4] = {s[w][2 * qb][0], s[w][2 * qb][1], s[w][2 * qb][2], s[w][2 * qb][3]};
+          float b4[4] = {s[w][2 * qb + 1][0], s[w][2 * qb + 1][1], s[w][2 * qb + 1][2], s[w][2 * qb + 1][3]};
+          pf[w] = pack8(a4, b4);
+          float c4[4] = {dp[w][2 * qb][0], dp[w][2 * qb][1], dp[w][2 * qb][2], dp[w][2 * qb][3]};
+          float e4[4] = {dp[w][2 * qb + 1][0], dp[w][2 * qb + 1][1], dp[w][2 * qb + 1][2], dp[w][2 * qb + 1][3]};
+          dsf[w] = pack8(c4, e4);
+        }
+#pragma unroll
+        for (int df = 0; df < DP / 16; ++df) {
+          bf16x8 gtf = lds_tr_frag(Gs + troff + qb * 32 * NSTR + df * 32, NSTR);
+          bf16x8 qtf = lds_tr_frag(Qs + troff + qb * 32 * NSTR + df * 32, NSTR);
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            dv[w][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gtf, pf[w], dv[w][df], 0, 0, 0);
+            dk[w][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf[w], dk[w][df], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (more) sstore_all(ring + ((qt - qt_lo + 1) & 1) * QBUF);
+    __syncthreads();
+  }
+  // partial dK / dV of this query range -> slab[split][b*Nkp + key][C] (plain 16-byte stores; attn_splitsum_kernel adds the
+  // slabs and converts).  Float atomics on the 77 x C block shared by every split were the whole cost of the old path.
+#pragma unroll
+  for (int w = 0; w < 2; ++w)
+    if (kok[w]) {
+      const int64_t row = ((int64_t)split * p.B + b) * p.Nkp + key[w];
+#pragma unroll
+      for (int df = 0; df < DP / 16; ++df) {
+        int col = df * 16 + g * 4;
+        if (col < d) {
+          *(f32x4*)(p.dK32 + row * p.ld32 + hc + col) = dk[w][df];
+          *(f32x4*)(p.dV32 + row * p.ld32 + hc + col) = dv[w][df];
+        }
+      }
+    }
+}
+
+// out[b*Nkp + key][c] = bf16(sum over splits of slab[split][b*Nkp + key][c]); pad keys [Nk, Nkp) get zeros
+__global__ void attn_splitsum_kernel(const float* s0, const float* s1, int nsplit, int64_t ld32, bf16_t* out0, int64_t ldo0, bf16_t* out1, int64_t ldo1,
+                                     int B, int Nk, int Nkp, int C) {
   const int nch = C >> 2;
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < (int64_t)rows * nch; t += (int64_t)gridDim.x * blockDim.x) {
-    int r = t / nch, c = (t - (int64_t)r * nch) * 4;
-    float4 v = *(const float4*)(in + r * ldi + c);
+  const int64_t per = (int64_t)B * Nkp * nch, sstride = (int64_t)B * Nkp * ld32;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < 2 * per; t += (int64_t)gridDim.x * blockDim.x) {
+    const bool second = t >= per;
+    const int64_t u = second ? t - per : t;
+    const int r = u / nch, c = (u - (int64_t)r * nch) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r % Nkp < Nk) {
+      const float* src = (second ? s1 : s0) + r * ld32 + c;
+      for (int sp = 0; sp < nsplit; ++sp) {
+        float4 v = *(const float4*)(src + sp * sstride);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    uint2 w;
+    w.x = pack2bf(acc.x, acc.y); w.y = pack2bf(acc.z, acc.w);
+    *(uint2*)((second ? out1 + r * ldo1 : out0 + r * ldo0) + c) = w;
+  }
+}
+
+// fp32 [rows, C] (ld32) -> bf16 [rows, C] (ld) after the atomics of the query-split path
+__global__ void cvt_f32_bf16_kernel(const float* in0, const float* in1, int64_t ldi, bf16_t* out0, int64_t ldo0, bf16_t* out1, int64_t ldo1,
+                                    int rows, int C) {
+  const int nch = C >> 2;
+  const int64_t per = (int64_t)rows * nch;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < 2 * per; t += (int64_t)gridDim.x * blockDim.x) {
+    const bool second = t >= per;
+    const int64_t u = second ? t - per : t;
+    int r = u / nch, c = (u - (int64_t)r * nch) * 4;
+    float4 v = *(const float4*)((second ? in1 : in0) + r * ldi + c);
     uint2 w;
     w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
-    *(uint2*)(out + r * ldo + c) = w;
+    *(uint2*)((second ? out1 + r * ldo1 : out0 + r * ldo0) + c) = w;
   }
 }
 
@@ -568,6 +829,33 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
   if (!p.dK || !p.dV || (p.lddk % 4) || (p.lddv % 4) || (p.qsplit > 1 && (!p.dK32 || !p.dV32 || (p.ld32 % 4))))
     SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_attn_bwd: dK/dV outputs for qsplit=%d", p.qsplit);
   const int dp = attn_dp(p.d);
+  const int C = p.H * p.d, krows = p.B * p.Nkp;
+  auto zero32 = [&]() {     // fp32 dK/dV scratch of the atomic paths; one launch when the two buffers are adjacent
+    const size_t n = (size_t)krows * p.ld32;
+    if (p.dV32 == p.dK32 + n) sdlt_zero_async(p.dK32, sizeof(float) * 2 * n, s);
+    else { sdlt_zero_async(p.dK32, sizeof(float) * n, s); sdlt_zero_async(p.dV32, sizeof(float) * n, s); }
+  };
+  auto cvt32 = [&]() {
+    int blocks = (int)(((int64_t)krows * C / 2 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cvt_f32_bf16_kernel, dim3(blocks), dim3(256), 0, s, p.dK32, p.dV32, p.ld32, (bf16_t*)p.dK, p.lddk, (bf16_t*)p.dV, p.lddv, krows, C);
+  };
+  if (p.qsplit > 1 && !p.causal && p.Nk <= 128 && p.Nkp <= 128 && dp <= 96) {
+    // cross-attention: prep + dQ + dK/dV in one kernel (see attn_bwd_cross_kernel); qsplit = workgroups along the queries,
+    // dK32 / dV32 = [qsplit][B*Nkp][ld32] partial slabs (any contents)
+    dim3 gx(p.qsplit, p.H, p.B);
+#define SMEM_X(D_) (2 * 128 * ((D_) * 2 + 16) + 2 * (2 * 64 * ((D_) * 2 + 16)) + 512)
+    if (dp == 64) { set_smem(attn_bwd_cross_kernel<64>, SMEM_X(64)); hipLaunchKernelGGL(attn_bwd_cross_kernel<64>, gx, dim3(256), SMEM_X(64), s, p); }
+    else { set_smem(attn_bwd_cross_kernel<96>, SMEM_X(96)); hipLaunchKernelGGL(attn_bwd_cross_kernel<96>, gx, dim3(256), SMEM_X(96), s, p); }
+    {
+      int blocks = (int)(((int64_t)krows * C / 2 + 255) / 256);
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(attn_splitsum_kernel, dim3(blocks), dim3(256), 0, s, p.dK32, p.dV32, p.qsplit, p.ld32, (bf16_t*)p.dK, p.lddk,
+                         (bf16_t*)p.dV, p.lddv, p.B, p.Nk, p.Nkp, C);
+    }
+    SDLT_CHECK_LAUNCH();
+    return SDLT_OK;
+  }
   {
     int64_t groups = (int64_t)p.B * p.Nqp * p.H;
     int blocks = (int)((groups * 8 + 255) / 256);
@@ -577,20 +865,11 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
   dim3 gq((p.Nq + 63) / 64, p.H, p.B);
 #define SMEM_DQ(D_) (2 * (2 * 64 * ((D_) * 2 + 16)))
   ATTN_DISPATCH(dp, attn_bwd_dq_kernel, gq, SMEM_DQ)
-  if (p.qsplit > 1) {
-    sdlt_zero_async(p.dK32, sizeof(float) * (size_t)p.B * p.Nkp * p.ld32, s);
-    sdlt_zero_async(p.dV32, sizeof(float) * (size_t)p.B * p.Nkp * p.ld32, s);
-  }
+  if (p.qsplit > 1) zero32();
   dim3 gk(((p.Nk + 63) / 64) * p.qsplit, p.H, p.B);
 #define SMEM_DKV(D_) (2 * (2 * 64 * ((D_) * 2 + 16) + 512))
   ATTN_DISPATCH(dp, attn_bwd_dkdv_kernel, gk, SMEM_DKV)
-  if (p.qsplit > 1) {
-    int C = p.H * p.d, rows = p.B * p.Nkp;
-    int blocks = (int)(((int64_t)rows * C / 4 + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(cvt_f32_bf16_kernel, dim3(blocks), dim3(256), 0, s, p.dK32, p.ld32, (bf16_t*)p.dK, p.lddk, rows, C);
-    hipLaunchKernelGGL(cvt_f32_bf16_kernel, dim3(blocks), dim3(256), 0, s, p.dV32, p.ld32, (bf16_t*)p.dV, p.lddv, rows, C);
-  }
+  if (p.qsplit > 1) cvt32();
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }

@@ -225,6 +225,8 @@ def attn_bwd(Q, K, V, Kt, Qt, O, L, dO, dOt, D, dQ, dK, dV, *, B, H, Nq, Nk, Nqp
     p.qsplit = qsplit
     if qsplit > 1:
         _chk2(dK32, F32), _chk2(dV32, F32)
+        if not causal and Nkp <= 128 and d <= 96:   # single-pass cross-attention kernel: one partial slab per query split
+            assert dK32.shape[0] >= qsplit * B * Nkp and dV32.shape[0] >= qsplit * B * Nkp, "dK32/dV32 must hold qsplit slabs"
         p.dK32, p.dV32, p.ld32 = _p(dK32), _p(dV32), _ld(dK32)
     _lib.check(lib.sdlt_attn_bwd(C.byref(p), _stream()), "sdlt_attn_bwd")
 

@@ -45,6 +45,15 @@ class Runtime:
         self.daam_grads = None       # N -> (dS bf16 [B*N, CTX_PAD], dS^T bf16 [B*CTX_PAD, N]) set by the token-attention loss
         self.want_dpooled = False    # SDXL: back-propagate into the pooled text embedding (textual inversion)
         self.dsemb = None
+        self._scratch = {}
+
+    def scratch(self, key, nfloats):
+        """fp32 scratch shared by every layer: valid only inside the op call that receives it (all ops run on one stream)."""
+        t = self._scratch.get(key)
+        if t is None or t.numel() < nfloats:
+            t = torch.empty(nfloats, dtype=F32, device=self.device)
+            self._scratch[key] = t
+        return t[:nfloats]
 
     def empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.act, device=self.device)
@@ -57,7 +66,7 @@ class _Module:
     def __init__(self, rt, name):
         self.rt, self.name, self._b = rt, name, {}
 
-    def buf(self, key, *shape, dtype=None, zero=False):
+    def buf(self, key, *shape, dtype=None, zero=False):  # persistent, owned by this module
         t = self._b.get(key)
         if t is None:
             t = (self.rt.zeros if zero else self.rt.empty)(*shape, dtype=dtype)
@@ -436,10 +445,11 @@ class Attention(_Module):
         D = self.buf("D", B * self.heads * N, dtype=F32)
         kw = {}
         if self.cross:
-            ntiles = (Nk + 63) // 64
-            qs = max(1, min((N + 63) // 64, 320 // max(1, ntiles * self.heads * B)))
-            if qs > 1:
-                kw = dict(qsplit=qs, dK32=self.buf("dk32", Mk, C, dtype=F32), dV32=self.buf("dv32", Mk, C, dtype=F32))
+            # cross-attention: ~160 workgroups, each owning all 77 keys of one head and a range of query tiles; the fp32
+            # dK/dV accumulators are adjacent so the kernel side zeroes / converts them with one launch each
+            qs = max(2, min((N + 63) // 64, 160 // max(1, self.heads * B)))
+            kv32 = rt.scratch("attn_dkv32", 2 * qs * Mk * C).view(2 * qs * Mk, C)    # partial slabs, consumed inside attn_bwd
+            kw = dict(qsplit=qs, dK32=kv32[:qs * Mk], dV32=kv32[qs * Mk:])
         rt.ops.attn_bwd(q, k, v, None, None, self._b["O"], self._b["L"], dO, None, D, dq, dk, dv,
                         B=B, H=self.heads, Nq=N, Nk=Nk, Nqp=N, Nkp=Nkp, d=self.d, scale=self.scale, **kw)
         if self.cross and self.hooked and rt.daam_grads is not None:

@@ -257,6 +257,8 @@ ATTN_CASES = [
     dict(B=2, H=2, Nq=256, Nk=256, Nkp=256, d=64, causal=False, qsplit=1),
     dict(B=1, H=10, Nq=1024, Nk=77, Nkp=80, d=64, causal=False, qsplit=4),
     dict(B=2, H=3, Nq=192, Nk=77, Nkp=80, d=64, causal=False, qsplit=1),
+    dict(B=2, H=3, Nq=200, Nk=77, Nkp=128, d=80, causal=False, qsplit=3),
+    dict(B=1, H=2, Nq=64, Nk=40, Nkp=40, d=40, causal=False, qsplit=2),
     dict(B=1, H=8, Nq=256, Nk=256, Nkp=256, d=40, causal=False, qsplit=1),
     dict(B=1, H=2, Nq=128, Nk=128, Nkp=128, d=160, causal=False, qsplit=1),
     dict(B=1, H=4, Nq=128, Nk=128, Nkp=128, d=80, causal=False, qsplit=1),
@@ -296,7 +298,8 @@ def test_attention_fwd_bwd(ops, c):
     D = torch.zeros(B * H * Nq, device="cuda")
     extra = {}
     if c["qsplit"] > 1:
-        extra = dict(qsplit=c["qsplit"], dK32=torch.empty(B * Nkp, C, device="cuda"), dV32=torch.empty(B * Nkp, C, device="cuda"))
+        ns = c["qsplit"]   # the single-pass cross-attention kernel wants one partial slab per query split
+        extra = dict(qsplit=ns, dK32=torch.full((ns * B * Nkp, C), float("nan"), device="cuda"), dV32=torch.full((ns * B * Nkp, C), float("nan"), device="cuda"))
     ops.attn_bwd(Qd, Kd, Vd, Kt, Qt, O, L, dOd, dOt, D, dQ, dK, dV, **kw, **extra)
     close(dQ.cpu() * vq, dQr * vq, tol=2.5e-2, what=f"attn dQ {c}")
     close(dK, dKr, tol=2.5e-2, what=f"attn dK {c}")

@@ -30,7 +30,7 @@ for (name, B, H, Nq, Nk, Nkp, d) in [("self N1024 H20", 1, 20, 1024, 1024, 1024,
     extra = {}
     if Nk < 128:
         qs = max(1, min((Nq + 63) // 64, 320 // (2 * H * B)))
-        extra = dict(qsplit=qs, dK32=torch.empty(B * Nkp, C, device="cuda"), dV32=torch.empty(B * Nkp, C, device="cuda"))
+        extra = dict(qsplit=qs, dK32=torch.empty(qs * B * Nkp, C, device="cuda"), dV32=torch.empty(qs * B * Nkp, C, device="cuda"))
     tb = timeit(lambda: ops.attn_bwd(Q, K, V, Kt, Qt, O, L, dO, dOt, D, dQ, dK, dV, **kw, **extra))
     fl = 4.0 * B * H * Nq * Nk * d
     print(f"{name:26s} fwd {tf:7.1f} us ({fl / tf / 1e6:6.0f} TF)   bwd {tb:7.1f} us ({2.5 * fl / tb / 1e6:6.0f} TF algorithmic 2.5x)")
