@@ -414,6 +414,65 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   // acc[a][b][r] = C[m = m0 + wm*MI*16 + b*16 + (lane&15)][n = n0 + wn*NI*16 + a*16 + (lane>>4)*4 + r]
   const bool vec_ok = ((p.ldc & 3) == 0) && (p.R == nullptr || (p.ldr & 3) == 0) &&
                       (p.rowbias == nullptr || (p.ld_rowbias & 3) == 0);
+#ifndef SDLT_LAB_DIRECT_EPILOGUE
+  // ---- staged store (the common bf16 case): the fragment layout gives every lane 4 consecutive columns of one row, i.e.
+  // a wave store would touch 16 rows x 32 B.  Instead the fp32 tile (alpha, bias, row bias applied) goes through the
+  // now idle staging LDS and leaves as full 256-byte row segments, 16 B per lane; the residual is read the same way and
+  // added before the single bf16 rounding.
+  // (not for the M = 128 text-encoder GEMMs: a handful of tiles, where the two extra barriers cost more than the wider stores save)
+  if ((long)p.M * p.N >= (1l << 20) && !p.out_fp32 && p.Ct == nullptr && vec_ok && (p.ldc & 7) == 0 && (p.N & 7) == 0 && (p.R == nullptr || (p.ldr & 7) == 0) &&
+      (((uintptr_t)p.C | (uintptr_t)p.R) & 15) == 0) {
+    constexpr int CST = BN + 4;                                    // fp32 elements per staged row (+4: bank spread)
+    constexpr int REGION = (S == 1 ? 2 : S) * STAGE;
+    constexpr int CROWS = BM * CST * 4 <= REGION ? BM : (BM / 2 * CST * 4 <= REGION ? BM / 2 : BM / 4);
+    static_assert(CROWS * CST * 4 <= REGION && CROWS % 16 == 0, "staged epilogue does not fit the staging LDS");
+    constexpr int NCH = BN / 8;                                    // 16-byte output chunks per row
+    float* csh = (float*)smem;
+    __syncthreads();                                               // every wave is past its last read of the staging LDS
+#pragma unroll
+    for (int pass = 0; pass < BM / CROWS; ++pass) {
+#pragma unroll
+      for (int b = 0; b < MI; ++b) {
+        const int ml = wm * MI * 16 + b * 16 + frow;
+        if ((wm * MI * 16 + b * 16) / CROWS != pass) continue;     // compile-time after unrolling except for wm
+        const int m = m0 + ml;
+        const int brow = (p.rowbias && m < p.M) ? m / p.rows_per_batch : 0;
+#pragma unroll
+        for (int a = 0; a < NI; ++a) {
+          const int nl = wn * NI * 16 + a * 16 + fk * 4;
+          const int n = n0 + nl;
+          f32x4 v = acc[a][b] * p.alpha;
+          if (n < p.N) {
+            if (p.bias) v += *(const f32x4*)(p.bias + n);
+            if (p.rowbias) {
+              uint2 rb = *(const uint2*)((const bf16_t*)p.rowbias + (size_t)brow * p.ld_rowbias + n);
+              v[0] += bf2f(rb.x & 0xffff); v[1] += bf2f(rb.x >> 16); v[2] += bf2f(rb.y & 0xffff); v[3] += bf2f(rb.y >> 16);
+            }
+          }
+          *(f32x4*)(csh + (ml - pass * CROWS) * CST + nl) = v;
+        }
+      }
+      __syncthreads();
+      for (int it = tid; it < CROWS * NCH; it += NTHR) {
+        const int row = it / NCH, ch = it - row * NCH;
+        const int m = m0 + pass * CROWS + row, n = n0 + ch * 8;
+        if (m >= p.M || n >= p.N) continue;
+        const float* src = csh + row * CST + ch * 8;
+        f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
+        if (p.R) {
+          uint4 rv = *(const uint4*)((const bf16_t*)p.R + (size_t)m * p.ldr + n);
+          lo[0] += bf2f(rv.x & 0xffff); lo[1] += bf2f(rv.x >> 16); lo[2] += bf2f(rv.y & 0xffff); lo[3] += bf2f(rv.y >> 16);
+          hi[0] += bf2f(rv.z & 0xffff); hi[1] += bf2f(rv.z >> 16); hi[2] += bf2f(rv.w & 0xffff); hi[3] += bf2f(rv.w >> 16);
+        }
+        uint4 o;
+        o.x = pack2bf(lo[0], lo[1]); o.y = pack2bf(lo[2], lo[3]); o.z = pack2bf(hi[0], hi[1]); o.w = pack2bf(hi[2], hi[3]);
+        *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+      }
+      if (pass + 1 < BM / CROWS) __syncthreads();
+    }
+    return;
+  }
+#endif
 #pragma unroll
   for (int b = 0; b < MI; ++b) {
     const int m = m0 + wm * MI * 16 + b * 16 + frow;
