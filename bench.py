@@ -210,6 +210,12 @@ def main():
         f_step = 2.0 * topology.fwd_flops(cfg, B, h, h, args.rank)["total"]
         t_step = elapsed / args.steps
         achieved = f_step / (ev_ms * 1e-3 / args.steps)
+        # HBM-side bytes per step: measured offline (PMC counters need rocprofv3 around the process), for the default workload only
+        traffic = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_sdxl1024_ti_hbm_traffic_pmc.json")
+        if version == "sdxl" and res == 1024 and B == 1 and args.rank == 16 and text is not None and os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = json.load(fh).get("traffic_bytes_per_step")
         out = {
             "metric": "training images/sec, SDXL 1024px rank-16 LoRA, 1/2/4/8 GPU (job-parallel)",
             "value": world * B * args.steps / elapsed,
@@ -225,9 +231,10 @@ def main():
                        "global_batch": world * B, "parallelism": f"job-parallel x{world} (independent jobs, no collective)",
                        "lora_params": arena.n, "graph": not args.no_graph, "final_loss": loss},
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_DENSE, "traffic": None,
+                         "frac": achieved / PEAK_BF16_DENSE, "traffic": traffic,
                          "note": f"algorithmic {f_step / 1e12:.3f} TFLOP per step (2 x fwd census) / {ev_ms / args.steps:.3f} ms "
-                                 "per hipGraph replay (HIP events on the replay stream)"},
+                                 "per step (HIP events on the replay stream); traffic = HBM-side bytes per step from the committed "
+                                 "rocprofv3 PMC passes of this command (profiles/r01_sdxl1024_ti_hbm_traffic_pmc.json), null for other configs"},
         }
         if world == 1 and not args.no_cpu_baseline:
             sample_hw = 32 if "xl" in version or version == "sd15" else h
