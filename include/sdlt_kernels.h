@@ -73,7 +73,9 @@ typedef struct sdlt_gemm_params {
                                  own adapter: group g = n / lora_group_n uses Adown rows [g*lora_R, (g+1)*lora_R) and writes
                                  T_out columns [g*lora_R, (g+1)*lora_R); Bup stays [N, lora_R].  Fused to_q|to_k|to_v and
                                  the batched cross-attention to_k|to_v of all blocks.  Must be a multiple of the N tile. */
-  int32_t pad1_;
+  int32_t lora_group_k;       /* > 0: K is a concatenation of G <= 4 groups of `lora_group_k` columns (the stacked dY of fused
+                                 projections), each with its own rank-16 adapter: Adown stays [16, K] (the groups' B^T side by
+                                 side), T_out is [M, G*16] and Bup [N, G*16].  lora_R must be 16, mode 0, no split-K. */
 } sdlt_gemm_params;
 int sdlt_gemm_bf16(const sdlt_gemm_params* p, void* stream);
 

@@ -35,7 +35,7 @@ class GemmParams(C.Structure):
         ("out_fp32", i32), ("tile", i32),
         ("Ct", vp), ("ldct", i64),
         ("splitk", i32), ("ws_cnt_len", i32), ("ws_slab", vp), ("ws_slab_bytes", i64), ("stages", i32), ("accumulate", i32), ("ws_cnt", vp),
-        ("lora_group_n", i32), ("pad1_", i32),
+        ("lora_group_n", i32), ("lora_group_k", i32),
     ]
 
 

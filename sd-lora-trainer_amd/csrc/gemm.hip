@@ -34,14 +34,18 @@ struct ConvGeom {
 // MI x NI 16x16 fragments per wave; waves are laid out 2 (m) x WN (n): WN = 2 -> 256 threads, WN = 4 -> 512 threads
 // (two waves per SIMD: the second half of the waves computes first and issues its DMA afterwards, so one wave's DMA
 // issue stalls overlap the other's MFMAs on every SIMD).
-template <int MI, int NI, int WN, int MODE, int R16, int NSTAGE>
+template <int MI, int NI, int WN, int MODE, int R16, int NSTAGE, int KG = 0>
 __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p) {
   constexpr int NW = 2 * WN, NTHR = NW * 64;
   constexpr int BM = 2 * MI * 16, BN = WN * NI * 16;
   constexpr int XT = BM * ROW_BYTES, WT = BN * ROW_BYTES, AT = (R16 ? R16 * 16 : 0) * ROW_BYTES;
   constexpr int STAGE = XT + WT + AT;
   constexpr int S = NSTAGE;                        // LDS ring depth: S-1 K-steps of DMA in flight under the MFMAs
-  constexpr int TROW = R16 ? (R16 * 16 + 4) : 4;  // bf16 elements per Tsh row (+4 pad)
+  // KG > 0 (K-grouped adapters, the dX of stacked projections): K is G <= KG groups of lora_group_k columns, each with its own
+  // rank-16 LoRA-down result; the accumulator is flushed to its 16 columns of Tsh at every group boundary.
+  constexpr int TW = (KG ? KG : R16) * 16;         // T columns held in Tsh
+  constexpr int TROW = R16 ? (TW + 4) : 4;         // bf16 elements per Tsh row (+4 pad)
+  static_assert(KG == 0 || R16 == 1, "K-grouped adapters: padded rank 16 only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* tsh = smem + (S == 1 ? 2 : S) * STAGE;
 
@@ -301,6 +305,23 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
     if (early && kt + S - 1 < kend) stage(kt + S - 1, (kt - kbeg + S - 1) % S);
     compute(smem + ((kt - kbeg) % S) * STAGE, kt);
     if (!early && kt + S - 1 < kend) stage(kt + S - 1, (kt - kbeg + S - 1) % S);
+    if constexpr (KG > 0) {
+      const int gsteps = p.lora_group_k / BK;
+      if ((kt + 1) % gsteps == 0) {          // last K-step of adapter group g: park s*T_g in its Tsh columns, restart the accumulator
+        const int grp = kt / gsteps;
+        if (t_active) {
+#pragma unroll
+          for (int b = 0; b < TMI; ++b) {
+            int ml = wm * MI * 16 + (wn * TMI + b) * 16 + frow;
+            uint2 v;
+            v.x = pack2bf(tacc[0][b][0] * p.lora_scale, tacc[0][b][1] * p.lora_scale);
+            v.y = pack2bf(tacc[0][b][2] * p.lora_scale, tacc[0][b][3] * p.lora_scale);
+            *(uint2*)(tsh + ((size_t)ml * TROW + grp * 16 + fk * 4) * 2) = v;
+            tacc[0][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      }
+    }
   }
   }
 
@@ -365,6 +386,7 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   // ---------------- fused LoRA-up ----------------
   if (R16) {
     // tacc[j][b][r] = T[m = wm*MI*16 + (wn*TMI+b)*16 + (lane&15)][rank = j*16 + (lane>>4)*4 + r]
+    if constexpr (KG == 0) {
 #pragma unroll
     for (int j = 0; j < R16; ++j)
 #pragma unroll
@@ -376,10 +398,12 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
         v.y = pack2bf(tacc[j][b][2] * p.lora_scale, tacc[j][b][3] * p.lora_scale);
         *(uint2*)(tsh + ((size_t)ml * TROW + j * 16 + fk * 4) * 2) = v;
       }
+    }
+    const int nup = KG ? p.K / p.lora_group_k : R16;   // 16-column blocks of T (K-grouped: one per adapter)
     __syncthreads();
     if (p.T_out != nullptr && t_writer) {
       // [BM rows][R] bf16 -> global, 8 B per lane
-      constexpr int CH = R16 * 4;  // 8-byte chunks per row
+      const int CH = nup * 4;  // 8-byte chunks per row
       for (int c = tid; c < BM * CH; c += NTHR) {
         int ml = c / CH, cc = c - ml * CH;
         int m = m0 + ml;
@@ -387,7 +411,8 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
       }
     }
 #pragma unroll
-    for (int j = 0; j < R16; ++j) {
+    for (int j = 0; j < (KG ? KG : R16); ++j) {
+      if (j >= nup) break;
       s16x4 tf[MI];
 #pragma unroll
       for (int b = 0; b < MI; ++b) {
@@ -530,12 +555,12 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   }
 }
 
-template <int MI, int NI, int WN, int MODE, int R16, int NSREQ>
+template <int MI, int NI, int WN, int MODE, int R16, int NSREQ, int KG = 0>
 int launch(const sdlt_gemm_params& p, hipStream_t stream) {
   constexpr int NTHR = 128 * WN;
   constexpr int BM = 2 * MI * 16, BN = WN * NI * 16;
   constexpr int STAGE = (BM + BN + R16 * 16) * ROW_BYTES;
-  constexpr int TSH = R16 ? BM * (R16 * 16 + 4) * 2 : 0;
+  constexpr int TSH = R16 ? BM * ((KG ? KG : R16) * 16 + 4) * 2 : 0;
   // LDS ring depth: NSREQ == 2 keeps the footprint small (several workgroups per CU overlap each other);
   // otherwise as deep as 160 KB allows, up to 4.
   constexpr int NS = NSREQ <= 2 ? NSREQ : ((4 * STAGE + TSH <= 160 * 1024) ? 4 : ((3 * STAGE + TSH <= 160 * 1024) ? 3 : 2));
@@ -546,7 +571,7 @@ int launch(const sdlt_gemm_params& p, hipStream_t stream) {
   const int smem = NBUF * STAGE + TSH;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_kernel<MI, NI, WN, MODE, R16, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute((const void*)gemm_kernel<MI, NI, WN, MODE, R16, NS, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
@@ -557,7 +582,7 @@ int launch(const sdlt_gemm_params& p, hipStream_t stream) {
     if (!p.ws_slab || !p.ws_cnt || (size_t)nbm * nbn * splitk * slab_bytes > (size_t)p.ws_slab_bytes || nbm * nbn > p.ws_cnt_len)
       SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: split-K workspace too small (%d tiles x %d splits x %zu B)", nbm * nbn, splitk, slab_bytes);
   }
-  hipLaunchKernelGGL((gemm_kernel<MI, NI, WN, MODE, R16, NS>), dim3(nbm * nbn * splitk), dim3(NTHR), smem, stream, p);
+  hipLaunchKernelGGL((gemm_kernel<MI, NI, WN, MODE, R16, NS, KG>), dim3(nbm * nbn * splitk), dim3(NTHR), smem, stream, p);
   }
   return SDLT_OK;
 }
@@ -577,6 +602,7 @@ void tile_dims(int tile, int& bm, int& bn) {
 template <int MODE, int R16>
 int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
   sdlt_gemm_params p = pin;
+  if (p.lora_group_k > 0) p.splitk = 1;   // the per-group T flush assumes one workgroup walks the whole K range
   const int ktot = p.K + p.K2;
   if (p.tile == 0) {
     // Shape heuristics from the tools/gemm_probe.py sweep on MI355X ("GEMM tile selection"):
@@ -627,6 +653,17 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
   }
   // (stages == 1, the register-staged loader, is kept in the kernel source but not instantiated: hipcc places its
   //  staging registers in scratch - measured 3-6x slower than the LDS-DMA ring on every SDXL shape.)
+  if (p.lora_group_k > 0 && pin.tile == 0 && (p.tile < 1 || p.tile > 3)) p.tile = 1;
+  if (p.lora_group_k > 0) {   // K-grouped adapters: plain GEMM mode, rank pad 16, tiles 1..3, deep ring
+    if constexpr (MODE == 0 && R16 == 1) {
+      switch (p.tile) {
+        case 1: return launch<4, 2, 4, 0, 1, 4, 4>(p, s);
+        case 2: return launch<2, 2, 4, 0, 1, 4, 4>(p, s);
+        case 3: return launch<2, 2, 2, 0, 1, 4, 4>(p, s);
+      }
+    }
+    SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: lora_group_k needs mode 0, padded rank 16 and tile 1..3 (tile %d)", p.tile);
+  }
   if (p.stages == 2) { SDLT_TILE_CASES(2) } else { SDLT_TILE_CASES(4) }
 #undef SDLT_TILE_CASES
   SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: tile id %d", p.tile);
@@ -659,6 +696,10 @@ extern "C" int sdlt_gemm_bf16(const sdlt_gemm_params* pp, void* stream) {
     if (p.K2) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: LoRA + second segment");
     if ((p.ld_adown % 8) || (p.ld_bup % 4) || (p.T_out && (p.ld_t % 4))) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_gemm_bf16: LoRA operand alignment");
     r16 = p.lora_R / 16;
+    if (p.lora_group_k > 0) {
+      if (p.lora_group_n > 0 || p.lora_R != 16 || p.mode != 0 || (p.lora_group_k % BK) || (p.K % p.lora_group_k) || p.K / p.lora_group_k > 4)
+        SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: lora_group_k=%d needs rank pad 16, mode 0, K = G*group_k with G <= 4, group_k %% 64 == 0", p.lora_group_k);
+    }
   }
   int rc;
 #define DISPATCH(MODE_)                                                 \

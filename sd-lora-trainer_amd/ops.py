@@ -68,12 +68,14 @@ class ConvGeom:
 
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
-         residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0):
+         residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0):
     """out[M,N] = alpha*(X.W^T [+ X2.W2^T] [+ s*(X.Adown^T).Bup^T]) + bias + rowbias[m//rows_per_batch] + residual.
     lora = (Adown [Rp,K], Bup [N,Rp], scale, T_out [M,Rp] or None).  out dtype bf16 or fp32.  Ct: optional
     transposed bf16 copy [N, >=M].  conv: ConvGeom -> X is the NHWC activation [B*Hin*Win, Cin].
     lora_group_n > 0: W is a stack of G = N / lora_group_n projections with one adapter each:
-    Adown [G*Rp, K] (group-major), Bup [N, Rp], T_out [M, G*Rp]."""
+    Adown [G*Rp, K] (group-major), Bup [N, Rp], T_out [M, G*Rp].
+    lora_group_k > 0: X is a stack of G = K / lora_group_k gradients (the dX of such a stack): Adown [16, K], Bup [N, G*16],
+    T_out [M, G*16]."""
     lib = _lib.load()
     p = _lib.GemmParams()
     _chk2(X), _chk2(W)
@@ -98,13 +100,18 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
     if lora is not None:
         Adown, Bup, scale, T_out = lora
         _chk2(Adown), _chk2(Bup)
-        Rp = Bup.shape[1]
-        G = 1
-        if lora_group_n:
-            assert N % lora_group_n == 0
-            G = N // lora_group_n
-            p.lora_group_n = lora_group_n
-        assert tuple(Adown.shape) == (G * Rp, K) and Bup.shape[0] == N, (Adown.shape, Bup.shape, N, K, G)
+        if lora_group_k:       # K-grouped: one rank-16 adapter per group of input columns
+            assert K % lora_group_k == 0 and not lora_group_n
+            G, Rp = K // lora_group_k, 16
+            assert tuple(Adown.shape) == (16, K) and tuple(Bup.shape) == (N, G * 16), (Adown.shape, Bup.shape)
+            p.lora_group_k = lora_group_k
+        else:
+            Rp, G = Bup.shape[1], 1
+            if lora_group_n:   # N-grouped: one adapter per group of output columns
+                assert N % lora_group_n == 0
+                G = N // lora_group_n
+                p.lora_group_n = lora_group_n
+            assert tuple(Adown.shape) == (G * Rp, K) and Bup.shape[0] == N, (Adown.shape, Bup.shape, N, K, G)
         p.Adown, p.ld_adown, p.Bup, p.ld_bup = _p(Adown), _ld(Adown), _p(Bup), _ld(Bup)
         p.lora_R, p.lora_scale = Rp, float(scale)
         if T_out is not None:

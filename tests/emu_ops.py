@@ -43,13 +43,18 @@ def _conv_apply(X, Wm, g):
 
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
-         residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0):
+         residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0):
     acc = X.float() @ W.float().t() if conv is None else _conv_apply(X, W, conv)
     if X2 is not None:
         acc = acc + X2.float() @ W2.float().t()
     if lora is not None:
         Adown, Bup, scale, T_out = lora
-        T = X.float() @ Adown.float().t() if conv is None else _conv_apply(X, Adown, conv)
+        if lora_group_k:   # stacked gradients: T_g = X_g . Adown[:, group g]^T, one 16-column block per group
+            Gk = X.shape[1] // lora_group_k
+            T = torch.cat([X[:, gi * lora_group_k:(gi + 1) * lora_group_k].float() @ Adown[:, gi * lora_group_k:(gi + 1) * lora_group_k].float().t()
+                           for gi in range(Gk)], 1)
+        else:
+            T = X.float() @ Adown.float().t() if conv is None else _conv_apply(X, Adown, conv)
         Tb = (T * scale).to(out.dtype if out.dtype != F32 else X.dtype)
         if T_out is not None:
             T_out.copy_(Tb)

@@ -225,6 +225,22 @@ def test_gemm_grouped_lora(ops, M, C, K, G, tile, splitk):
     close(out_g, out_c, tol=1.5e-2, what="grouped lora out")
 
 
+@pytest.mark.parametrize("M,N,C,G,tile", [(200, 128, 128, 3, 0), (1024, 256, 192, 2, 1), (130, 64, 64, 4, 3), (520, 320, 128, 3, 2)])
+def test_gemm_kgrouped_lora(ops, M, N, C, G, tile):
+    """dX of stacked projections: K = G*C stacked gradients, one rank-16 adapter per K group (+ residual)."""
+    g = torch.Generator().manual_seed(M + N + G)
+    K = G * C
+    X, W = rnd(M, K, g=g), rnd(N, K, g=g, scale=0.2)
+    Ad, Bu = rnd(16, K, g=g, scale=0.3), rnd(N, G * 16, g=g, scale=0.3)
+    res = rnd(M, N, g=g)
+    out_c, T_c = torch.zeros(M, N, dtype=BF), torch.zeros(M, G * 16, dtype=BF)
+    E.gemm(X, W, out_c, lora=(Ad, Bu, 0.7, T_c), residual=res, lora_group_k=C)
+    out_g, T_g = torch.zeros(M, N, dtype=BF, device="cuda"), torch.zeros(M, G * 16, dtype=BF, device="cuda")
+    ops.gemm(X.cuda(), W.cuda(), out_g, lora=(Ad.cuda(), Bu.cuda(), 0.7, T_g), residual=res.cuda(), lora_group_k=C, tile=tile)
+    close(T_g, T_c, tol=1.5e-2, what="k-grouped lora T_out")
+    close(out_g, out_c, tol=1.5e-2, what="k-grouped lora out")
+
+
 @pytest.mark.parametrize("Rp,specs,expect_mfma", [
     (64, [(520, 320, 64, True, None), (96, 64, 40, False, None), (2 * 8 * 8, 9 * 64, 64, True, (2, 8, 8, 64))], 1),
     (32, [(333, 128, 24, True, None)], 1),
