@@ -307,7 +307,7 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
     if (!early && kt + S - 1 < kend) stage(kt + S - 1, (kt - kbeg + S - 1) % S);
     if constexpr (KG > 0) {
       const int gsteps = p.lora_group_k / BK;
-      if ((kt + 1) % gsteps == 0) {          // last K-step of adapter group g: park s*T_g in its Tsh columns, restart the accumulator
+      if (splitk == 1 && (kt + 1) % gsteps == 0) {          // last K-step of adapter group g (split-K: one group per split, see the reduction): park s*T_g in its Tsh columns, restart the accumulator
         const int grp = kt / gsteps;
         if (t_active) {
 #pragma unroll
@@ -374,10 +374,25 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
 #pragma unroll
         for (int b = 0; b < MI; ++b) acc[a][b] += o[(a * MI + b) * NTHR + tid];
       if (R16) {
+        if constexpr (KG > 0) {
+          // K-grouped adapters under split-K: split sp covered exactly adapter group sp, its T goes to its own Tsh columns
+          if (t_active) {
+#pragma unroll
+            for (int b = 0; b < TMI; ++b) {
+              const f32x4 t = o[(NACC + b) * NTHR + tid];
+              int ml = wm * MI * 16 + (wn * TMI + b) * 16 + frow;
+              uint2 v;
+              v.x = pack2bf(t[0] * p.lora_scale, t[1] * p.lora_scale);
+              v.y = pack2bf(t[2] * p.lora_scale, t[3] * p.lora_scale);
+              *(uint2*)(tsh + ((size_t)ml * TROW + sp * 16 + fk * 4) * 2) = v;
+            }
+          }
+        } else {
 #pragma unroll
         for (int j = 0; j < R16; ++j)
 #pragma unroll
           for (int b = 0; b < TMI; ++b) tacc[j][b] += o[(NACC + j * TMI + b) * NTHR + tid];
+        }
       }
     }
     __syncthreads();
@@ -602,7 +617,12 @@ void tile_dims(int tile, int& bm, int& bn) {
 template <int MODE, int R16>
 int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
   sdlt_gemm_params p = pin;
-  if (p.lora_group_k > 0) p.splitk = 1;   // the per-group T flush assumes one workgroup walks the whole K range
+  if (p.lora_group_k > 0) {
+    // K-grouped adapters: either one workgroup walks the whole K range (T flushed per group) or exactly one split per group
+    const int G = p.K / p.lora_group_k;
+    const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    p.splitk = (pin.splitk == G || (pin.splitk == 0 && G > 1 && t128 * G <= 320 && p.ws_slab && p.ws_cnt)) ? G : 1;
+  }
   const int ktot = p.K + p.K2;
   if (p.tile == 0) {
     // Shape heuristics from the tools/gemm_probe.py sweep on MI355X ("GEMM tile selection"):

@@ -225,6 +225,13 @@ class StackedLinear(_Module):
             for g, m in enumerate(members):   # the arena's shadow refresh now writes straight into the stacked operands
                 m.lora["A_s"] = self.A_cat[g * Rp:(g + 1) * Rp]
                 m.lora["B_s"] = self.B_cat[g * N:(g + 1) * N]
+            # backward operands of the K-grouped dX GEMM (rank pad 16 only): the members' B^T side by side, their A^T side by side
+            self.kgrouped = Rp == 16 and self.G <= 4 and N % 64 == 0
+            if self.kgrouped:
+                self.Bt_cat, self.At_cat = rt.zeros(Rp, self.G * N), rt.zeros(K, self.G * Rp)
+                for g, m in enumerate(members):
+                    m.lora["Bt_s"] = self.Bt_cat[:, g * N:(g + 1) * N]
+                    m.lora["At_s"] = self.At_cat[:, g * Rp:(g + 1) * Rp]
 
     def forward(self, x, Ct=None):
         """Returns the member outputs as column slices of one [M, G*N] buffer."""
@@ -251,14 +258,26 @@ class StackedLinear(_Module):
         return dy, [dy[:, g * self.N:(g + 1) * self.N] for g in range(self.G)]
 
     def backward(self, dy_cat, *, dres=None, out=None):
-        """dx = sum_g dy_g W_g = dy_cat . W_cat as ONE GEMM over K = G*N (projections without LoRA adapters only)."""
-        assert not self.has_lora
+        """dx = sum_g dy_g (W_g + s B_g A_g) = dy_cat . W_cat (+ K-grouped LoRA) as ONE GEMM over K = G*N."""
+        M, N, G = dy_cat.shape[0], self.N, self.G
         if getattr(self, "Wt", None) is None:
             self.Wt = self.W.t().contiguous()
             for m in self.members:
                 m.Wt = None          # the per-member transposes are dead once the stacked one exists
-        dx = out if out is not None else self.buf("dx", dy_cat.shape[0], self.K)
-        self.rt.ops.gemm(dy_cat, self.Wt, dx, residual=dres)
+        dx = out if out is not None else self.buf("dx", M, self.K)
+        if not self.has_lora:
+            self.rt.ops.gemm(dy_cat, self.Wt, dx, residual=dres)
+            return dx
+        assert self.kgrouped
+        U = self.buf("U", M, G * 16)
+        if not getattr(self, "_registered", False):
+            r = self.arena.rank
+            for g, m in enumerate(self.members):
+                self.rt.lora_problems += [
+                    dict(P=dy_cat[:, g * N:(g + 1) * N], Q=m._b["T"], out=m.lora["gB"], M=M, Cw=N, R=r, rank_major=False),
+                    dict(P=m._x, Q=U[:, g * 16:(g + 1) * 16], out=m.lora["gA"], M=M, Cw=self.K, R=r, rank_major=True)]
+            self._registered = True
+        self.rt.ops.gemm(dy_cat, self.Wt, dx, lora=(self.Bt_cat, self.At_cat, self.arena.scale, U), residual=dres, lora_group_k=N)
         return dx
 
 
@@ -441,7 +460,14 @@ class Attention(_Module):
         Mq, Mk = B * N, B * Nkp
         dO = self.to_out.backward(dout)
         q, k, v = self.to_q._b["y"], self.to_k._b["y"], self.to_v._b["y"]
-        dq, dk, dv = self.buf("dq", Mq, C), self.buf("dk", Mk, C), self.buf("dv", Mk, C)
+        fused = self.stack.has_lora and self.stack.kgrouped or not self.stack.has_lora
+        if fused and self.cross:
+            dq = self.buf("dq", Mq, C)
+            dkv, (dk, dv) = self.stack.grad_slices(Mk)
+        elif fused:
+            dqkv, (dq, dk, dv) = self.stack.grad_slices(Mq)
+        else:
+            dq, dk, dv = self.buf("dq", Mq, C), self.buf("dk", Mk, C), self.buf("dv", Mk, C)
         D = self.buf("D", B * self.heads * N, dtype=F32)
         kw = {}
         if self.cross:
@@ -461,14 +487,19 @@ class Attention(_Module):
                             alpha=self.scale)
                 rt.ops.gemm(dSt[b * Nkp:(b + 1) * Nkp], Qt[:, b * N:(b + 1) * N], dk[b * Nkp:(b + 1) * Nkp], residual=dk[b * Nkp:(b + 1) * Nkp],
                             alpha=self.scale)
-        dx = self.to_q.backward(dq)
-        if self.cross:
-            # gradient w.r.t. the text conditioning, accumulated over every cross-attention layer
-            self.to_k.backward(dk, dres=dctx, out=dctx)
-            self.to_v.backward(dv, dres=dctx, out=dctx)
+        if fused and self.cross:
+            dx = self.to_q.backward(dq)
+            self.stack.backward(dkv, dres=dctx, out=dctx)      # gradient w.r.t. the text conditioning, accumulated over every cross-attention layer
+        elif fused:
+            dx = self.stack.backward(dqkv)
         else:
-            self.to_k.backward(dk, dres=dx, out=dx)
-            self.to_v.backward(dv, dres=dx, out=dx)
+            dx = self.to_q.backward(dq)
+            if self.cross:
+                self.to_k.backward(dk, dres=dctx, out=dctx)
+                self.to_v.backward(dv, dres=dctx, out=dctx)
+            else:
+                self.to_k.backward(dk, dres=dx, out=dx)
+                self.to_v.backward(dv, dres=dx, out=dx)
         return dx
 
 

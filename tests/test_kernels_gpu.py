@@ -225,8 +225,9 @@ def test_gemm_grouped_lora(ops, M, C, K, G, tile, splitk):
     close(out_g, out_c, tol=1.5e-2, what="grouped lora out")
 
 
+@pytest.mark.parametrize("splitk", [0, 1])
 @pytest.mark.parametrize("M,N,C,G,tile", [(200, 128, 128, 3, 0), (1024, 256, 192, 2, 1), (130, 64, 64, 4, 3), (520, 320, 128, 3, 2)])
-def test_gemm_kgrouped_lora(ops, M, N, C, G, tile):
+def test_gemm_kgrouped_lora(ops, M, N, C, G, tile, splitk):
     """dX of stacked projections: K = G*C stacked gradients, one rank-16 adapter per K group (+ residual)."""
     g = torch.Generator().manual_seed(M + N + G)
     K = G * C
@@ -236,7 +237,7 @@ def test_gemm_kgrouped_lora(ops, M, N, C, G, tile):
     out_c, T_c = torch.zeros(M, N, dtype=BF), torch.zeros(M, G * 16, dtype=BF)
     E.gemm(X, W, out_c, lora=(Ad, Bu, 0.7, T_c), residual=res, lora_group_k=C)
     out_g, T_g = torch.zeros(M, N, dtype=BF, device="cuda"), torch.zeros(M, G * 16, dtype=BF, device="cuda")
-    ops.gemm(X.cuda(), W.cuda(), out_g, lora=(Ad.cuda(), Bu.cuda(), 0.7, T_g), residual=res.cuda(), lora_group_k=C, tile=tile)
+    ops.gemm(X.cuda(), W.cuda(), out_g, lora=(Ad.cuda(), Bu.cuda(), 0.7, T_g), residual=res.cuda(), lora_group_k=C, tile=tile, splitk=splitk)
     close(T_g, T_c, tol=1.5e-2, what="k-grouped lora T_out")
     close(out_g, out_c, tol=1.5e-2, what="k-grouped lora out")
 
