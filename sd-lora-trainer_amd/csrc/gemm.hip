@@ -673,7 +673,12 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
   }
   // (stages == 1, the register-staged loader, is kept in the kernel source but not instantiated: hipcc places its
   //  staging registers in scratch - measured 3-6x slower than the LDS-DMA ring on every SDXL shape.)
-  if (p.lora_group_k > 0 && pin.tile == 0 && (p.tile < 1 || p.tile > 3)) p.tile = 1;
+  if (p.lora_group_k > 0 && pin.tile == 0) {
+    // only the deep-ring variants of tiles 1..3 exist for K-grouped adapters; with the long K = G*C loop the 128x128 tile
+    // wins as soon as it yields >= 64 workgroups (4096x640x1920: 31 us vs 61 us for 64x64)
+    const long t128k = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (t128k >= 64 || p.tile < 1 || p.tile > 3) p.tile = 1;
+  }
   if (p.lora_group_k > 0) {   // K-grouped adapters: plain GEMM mode, rank pad 16, tiles 1..3, deep ring
     if constexpr (MODE == 0 && R16 == 1) {
       switch (p.tile) {
