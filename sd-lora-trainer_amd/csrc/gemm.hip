@@ -630,12 +630,33 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
     //  * 160..511 tiles: short K -> 64x64 tiles, 2+ workgroups per CU; long K -> 128x128 with the deep ring
     //  * fewer: 64x128 (8 waves) when K is short, otherwise 128x128 + split-K
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    const int nk = ktot / BK;
+    const bool ws = p.ws_slab && p.ws_cnt;
     if (p.M <= 64) p.tile = p.N > 64 ? 2 : 3;
     else if (p.N <= 64) p.tile = 3;
+    else if (p.M <= 128) {
+      // text encoders / text-conditioning projections (M = 128): a few tiles, latency-bound.  ~250 workgroups, at most 4
+      // splits (more splits lose to the fenced hand-off), narrow tiles when N is small
+      p.tile = p.N <= 1536 ? 3 : 2;
+      if (!p.splitk) {
+        const long tiles = (long)((p.M + 63) / 64) * ((p.N + (p.tile == 3 ? 63 : 127)) / (p.tile == 3 ? 64 : 128));
+        int sk = ws ? (int)((256 + tiles / 2) / tiles) : 1;
+        if (sk > 4) sk = 4;
+        while (sk > 1 && nk / sk < 4) --sk;
+        p.splitk = sk < 1 ? 1 : sk;
+      }
+    }
+    else if (!R16 && MODE == 0 && p.M <= 1024 && p.N >= 8192 && ktot <= 2560) p.tile = 6;   // ff1 of the 32x32 blocks: 45 vs 53 us
+    else if (!R16 && MODE == 0 && t128 >= 320 && t128 <= 512 && p.N >= 1024) p.tile = 4;    // 1024x5120x1280: 27 vs 30 us
     else if (t128 >= 320) { p.tile = 1; if (!p.stages) p.stages = 2; }
     else if (t128 >= 160) {
       if (ktot <= 2560) { p.tile = 3; if (!p.stages) p.stages = 2; }
-      else p.tile = 1;
+      else {
+        // 4096 x 640 with a long K (3x3 convs of the 64x64 blocks, ff1 dX): 160 tiles x 3 splits, two workgroups per CU
+        p.tile = 1;
+        if (!p.stages) p.stages = 2;
+        if (!p.splitk && ws && nk / 3 >= 8) p.splitk = 3;
+      }
     } else if (ktot <= 2560 && t128 > 32) { p.tile = 2; if (!p.splitk) p.splitk = 1; }
     else if (ktot <= 2560) p.tile = 2;
     else p.tile = 1;
