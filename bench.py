@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-ti", action="store_true", help="inject the text conditioning instead of running the text encoders + TI")
+    ap.add_argument("--ti-frozen", action="store_true", help="time the step after freeze_ti_after_completion_f (ti lr = 0): no text-encoder backward")
     args = ap.parse_args()
 
     from sd_lora_trainer_amd import parallel
@@ -188,7 +189,7 @@ def main():
     if not args.no_graph:
         ts.capture(warmup=2)
     total = args.warmup + args.steps
-    ti_lr = 1e-3 if text is not None else 0.0
+    ti_lr = 1e-3 if (text is not None and not args.ti_frozen) else 0.0
     for i in range(args.warmup):
         ts.run(lr_at(i, total), ti_lr * (1 - i / total) ** 1.7)
 

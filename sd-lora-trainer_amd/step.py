@@ -121,7 +121,7 @@ class TrainStep:
         self.sums, self.loss, self.l1_sum = z(B * 2), z(1), z(1)
         self.hyper = z(16)
         self.opt_step = 0
-        self.graph, self.graphs = None, []
+        self.graph, self.graphs, self.graph_frozen = None, [], None
 
     # -------------------------------------------------------------------------------- inputs
     def set_batch(self, latent, noise, timesteps, mask, ctx=None, pooled=None, time_ids=None, ids=None, caption_token_lists=None):
@@ -213,6 +213,18 @@ class TrainStep:
             return [self.body]
         return [self._phase_text_fwd, self._phase_unet, lambda: (self._phase_text_bwd(), self.optimizer_step())]
 
+    def _phase_opt_frozen_ti(self):
+        """Last phase once the token embeddings are frozen (ti lr == 0, main.py:273-274): the reference still back-propagates
+        through both text encoders and runs AdamW with lr 0 on the tables; with lr == 0 that changes no parameter (decoupled
+        decay is lr * wd) and the regulariser is skipped (main.py:358), so only the LoRA optimiser remains."""
+        a = self.unet.arena
+        self.rt.ops.adamw_fused(a.params, a.grads, a.m, a.v, self.hyper, self.l1_sum)
+        a.refresh_shadows()
+
+    def grad_norm(self):
+        """Global L2 norm of the LoRA gradients, the reference's debug read-out (loss.py:108-125, main.py:373-379)."""
+        return float(self.unet.arena.grads.norm())
+
     # -------------------------------------------------------------------------------- graph capture / replay
     def capture(self, warmup=2):
         """Runs the body eagerly `warmup` times (allocates every persistent buffer, builds the grouped-gradient
@@ -236,6 +248,11 @@ class TrainStep:
             pool = g.pool()
             self.graphs.append(g)
         self.graph = self.graphs[0]
+        self.graph_frozen = None
+        if self.text is not None:
+            self.graph_frozen = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_frozen, pool=pool):
+                self._phase_opt_frozen_ti()
         for t, c in zip(state, snap):
             t.copy_(c)
         a.refresh_shadows()
@@ -245,9 +262,16 @@ class TrainStep:
 
     def run(self, lr, lr_ti=0.0):
         self.set_hyper(lr, lr_ti)
+        frozen = self.text is not None and lr_ti == 0.0
+        self._frozen_last = frozen
         if self.graph is not None:
-            for g in self.graphs:
+            graphs = self.graphs[:2] + [self.graph_frozen] if frozen else self.graphs
+            for g in graphs:
                 g.replay()
+        elif frozen:
+            self._phase_text_fwd()
+            self._phase_unet()
+            self._phase_opt_frozen_ti()
         else:
             self.body()
 
@@ -255,5 +279,5 @@ class TrainStep:
         """img loss + L1 penalty as the reference logs it (main.py:339-361); forces a device sync."""
         tot = float(self.loss) + self.l1_penalty * float(self.l1_sum) / self.unet.arena.n
         if self.text is not None:
-            tot += self.ta_w * float(self.ta.loss) + float(self.ti.reg_loss)
+            tot += self.ta_w * float(self.ta.loss) + (0.0 if getattr(self, "_frozen_last", False) else float(self.ti.reg_loss))
         return tot

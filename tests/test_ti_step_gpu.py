@@ -1,6 +1,8 @@
 """End-to-end textual-inversion step on the MI355X (bf16 HIP path) against the fp32 oracle (transformers CLIP +
 oracle/unet_ref.py + oracle/loss_ref.py): TI-row gradients, LoRA gradients, losses; then hipGraph replays train.
 Tolerances as tests/test_step_gpu.py (bf16 noise floor): cosine >= 0.99, relative L2 <= 8e-2, losses 2e-2."""
+import math
+
 import pytest
 import torch
 
@@ -97,3 +99,13 @@ def test_ti_step_gpu_matches_oracle(version, B):
         ts.run(1e-3, lr_ti=1e-3)
         losses.append(ts.total_loss())
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
+    # frozen token embeddings (ti lr == 0, main.py:273-274): the fast path skips the text-encoder backward and the rows-only
+    # AdamW - the token rows must stay bit-identical while the LoRA keeps training
+    rows0 = [p.clone() for p in [ts.ti.params]]
+    lora0 = unet.arena.params.clone()
+    for i in range(2):
+        ts.run(1e-3, lr_ti=0.0)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(rows0, [ts.ti.params]))
+    assert not torch.equal(lora0, unet.arena.params)
+    assert ts.grad_norm() > 0.0 and math.isfinite(ts.total_loss())
