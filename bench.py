@@ -214,7 +214,7 @@ def main():
         # HBM-side bytes per step: measured offline (PMC counters need rocprofv3 around the process), for the default workload only
         traffic = None
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_sdxl1024_ti_hbm_traffic_pmc.json")
-        if version == "sdxl" and res == 1024 and B == 1 and args.rank == 16 and text is not None and os.path.exists(tpath):
+        if version == "sdxl" and res == 1024 and B == 1 and args.rank == 16 and text is not None and not args.ti_frozen and os.path.exists(tpath):
             with open(tpath) as fh:
                 traffic = json.load(fh).get("traffic_bytes_per_step")
         out = {
@@ -227,7 +227,7 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{version} {res}x{res} LoRA rank {args.rank} batch {B}/GPU: UNet fwd+bwd, masked/min-SNR MSE, L1, AdamW"
                                    + (", + textual inversion (text encoders fwd+bwd with 3 trainable tokens, token-attention loss, "
-                                      "std regulariser, rows-only AdamW)" if text is not None else ", text conditioning injected (--no-ti)"),
+                                      "std regulariser, rows-only AdamW)" + (" [ti lr = 0: frozen-TI fast path, no text-encoder backward]" if args.ti_frozen else "") if text is not None else ", text conditioning injected (--no-ti)"),
                        "text_encoder_fwd_gflop_not_in_roofline": clip_flops / 1e9,
                        "global_batch": world * B, "parallelism": f"job-parallel x{world} (independent jobs, no collective)",
                        "lora_params": arena.n, "graph": not args.no_graph, "final_loss": loss},
