@@ -65,7 +65,15 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   // panels in that XCD's 4 MB L2 instead of streaming every W panel once per row of tiles).
   int bm, bn;
   {
-    constexpr int GROUP_M = 8;
+    // GROUP_M ~ sqrt(tiles one XCD holds at a time * BN / BM): the footprint of a g_m x g_n super-tile is g_m X panels +
+    // g_n W panels.  A fixed 8 made every XCD stream ALL of X when M is 8 row-tiles (1024 x 1280 x 5120 split 3: 97 MB of L2
+    // misses for 23.6 MB of operands).
+    const int per_xcd = (nbm * nbn + 7) >> 3;
+    int live = 32 / splitk;                          // tiles of the ~32 workgroups an XCD runs concurrently
+    live = live < 1 ? 1 : live;
+    live = per_xcd < live ? per_xcd : live;
+    int GROUP_M = (int)(sqrtf((float)live * BN / BM) + 0.5f);
+    GROUP_M = GROUP_M < 1 ? 1 : (GROUP_M > nbm ? nbm : GROUP_M);
     const int per_group = GROUP_M * nbn;
     const int grp = tile_id / per_group, first_m = grp * GROUP_M;
     const int gsz = nbm - first_m < GROUP_M ? nbm - first_m : GROUP_M;
