@@ -119,6 +119,10 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   }
   const bf16_t* x2ptr[XI];
   const bf16_t* w2ptr[WI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) x2ptr[i] = xptr[i];
+#pragma unroll
+  for (int i = 0; i < WI; ++i) w2ptr[i] = wptr[i];
   if (p.K2 > 0) {
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
@@ -152,13 +156,15 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   const int kbeg = (int)((long)nk * split / splitk), kend = (int)((long)nk * (split + 1) / splitk);
 
   // Enumerates the 8-row x 128-byte pieces this wave moves for K-step kt: f(j, src, lds_off) with j in [0, LPS).
+  // NOTE: the segment-1 / segment-2 operand pointers are picked per element with value selects.  Handing the two pointer
+  // ARRAYS to a common tail (if/else around the loops) made hipcc keep them in scratch and index them at run time: a
+  // scratch_load + s_waitcnt vmcnt(0) in front of the W pieces of EVERY stage, i.e. the whole DMA ring drained once per
+  // K-step in every kernel without LoRA.
   auto for_each_piece = [&](int kt, auto&& f) {
-    if (kt < nk1) {
-      const int k0 = kt * BK;
-      if (MODE == 0) {
-#pragma unroll
-        for (int i = 0; i < XI; ++i) f(i, xptr[i] + k0, (wave + NW * i) * 1024);
-      } else {
+    constexpr bool TWOSEG = MODE == 0 && R16 == 0;     // only plain GEMMs may carry a second K segment (host-checked)
+    const bool seg1 = !TWOSEG || kt < nk1;
+    const int k0 = (seg1 ? kt : kt - nk1) * BK;
+    if (MODE == 1) {
         const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
         const int dy = tap / 3, dx = tap - dy * 3;
         const int oy = p.flip ? 1 - dy : dy - 1, ox = p.flip ? 1 - dx : dx - 1;
@@ -182,24 +188,27 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
           }
           f(i, src, (wave + NW * i) * 1024);
         }
-      }
-#pragma unroll
-      for (int i = 0; i < WI; ++i) f(XI + i, wptr[i] + k0, XT + (wave + NW * i) * 1024);
-      if (R16) {
-        // every wave moves the SAME number of pieces per stage (the counted vmcnt of the DMA path relies on it);
-        // when there are fewer pieces than waves some waves re-load a piece - identical bytes to identical LDS addresses.
-#pragma unroll
-        for (int j = 0; j < AI; ++j) {
-          int piece = (wave + NW * j) % (R16 * 2);
-          f(XI + WI + j, aptr + (size_t)(piece * 8 + srow) * p.ld_adown + k0, XT + WT + piece * 1024);
-        }
-      }
     } else {
-      const int k0 = (kt - nk1) * BK;
 #pragma unroll
-      for (int i = 0; i < XI; ++i) f(i, x2ptr[i] + k0, (wave + NW * i) * 1024);
+      for (int i = 0; i < XI; ++i) {
+        const bf16_t* src = (!TWOSEG || seg1) ? xptr[i] : x2ptr[i];
+        f(i, src + k0, (wave + NW * i) * 1024);
+      }
+    }
 #pragma unroll
-      for (int i = 0; i < WI; ++i) f(XI + i, w2ptr[i] + k0, XT + (wave + NW * i) * 1024);
+    for (int i = 0; i < WI; ++i) {
+      const bf16_t* src = (!TWOSEG || seg1) ? wptr[i] : w2ptr[i];
+      f(XI + i, src + k0, XT + (wave + NW * i) * 1024);
+    }
+    if (R16) {
+      // (LoRA excludes a second segment.)  Every wave moves the SAME number of pieces per stage (the counted vmcnt of the
+      // DMA path relies on it); when there are fewer pieces than waves some waves re-load a piece - identical bytes to
+      // identical LDS addresses.
+#pragma unroll
+      for (int j = 0; j < AI; ++j) {
+        int piece = (wave + NW * j) % (R16 * 2);
+        f(XI + WI + j, aptr + (size_t)(piece * 8 + srow) * p.ld_adown + k0, XT + WT + piece * 1024);
+      }
     }
   };
   // LDS-DMA path: global -> LDS directly (16 B per lane, destination = piece base + lane*16)
@@ -237,6 +246,42 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
     const char* ws = base + XT + (wn * NI * 16) * ROW_BYTES;
     const char* as = base + XT + WT;
     const bool lora_step = R16 && kt < nk1;
+#ifdef SDLT_LAB_READS_UPFRONT
+    // every LDS read of the K-step first (one LDS round trip per step instead of four serial ones), then the MFMAs
+    bf16x8 xf2[2][MI], wf2[2][NI], af2[2][R16 ? R16 : 1], xt2[2][TMI];
+    const int tb = t_active ? wn * TMI : 0;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int fo = kk ? foff1 : foff0;
+#pragma unroll
+      for (int b = 0; b < MI; ++b) xf2[kk][b] = *(const bf16x8*)(xs + b * 16 * ROW_BYTES + fo);
+#pragma unroll
+      for (int a = 0; a < NI; ++a) wf2[kk][a] = *(const bf16x8*)(ws + a * 16 * ROW_BYTES + fo);
+      if (R16) {
+#pragma unroll
+        for (int j = 0; j < R16; ++j) af2[kk][j] = *(const bf16x8*)(as + j * 16 * ROW_BYTES + fo);
+#pragma unroll
+        for (int b = 0; b < TMI; ++b) xt2[kk][b] = *(const bf16x8*)(xs + (tb + b) * 16 * ROW_BYTES + fo);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[kk][a], xf2[kk][b], acc[a][b], 0, 0, 0);
+      if (R16) {
+        if (lora_step && t_active) {
+#pragma unroll
+          for (int j = 0; j < R16; ++j)
+#pragma unroll
+            for (int b = 0; b < TMI; ++b)
+              tacc[j][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af2[kk][j], xt2[kk][b], tacc[j][b], 0, 0, 0);
+        }
+      }
+    }
+#else
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int fo = kk ? foff1 : foff0;
@@ -265,6 +310,7 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
         }
       }
     }
+#endif
   };
 
   if (S == 1) {

@@ -11,6 +11,9 @@ def bench(M, N, K, tile, splitk, lora=False, conv=None, reps=20, stages=0):
     X = torch.randn(M if conv is None else conv.B * conv.Hin * conv.Win, Kx + pad, device="cuda").to(BF)[:, :Kx]
     Ws = [torch.randn(N, K + pad, device="cuda").to(BF)[:, :K] for _ in range(int(os.environ.get('NW', '4')))]   # rotate weights: frozen weights are never L2-hot in the real step
     out = torch.empty(M, N, device="cuda", dtype=BF)
+    if os.environ.get('HOT'):   # every row aliases row 0: all operand traffic hits in TCP/L2 (probe: is the K loop memory- or issue-bound?)
+        X = X[:1].expand(X.shape[0], X.shape[1])
+        Ws = [w[:1].expand(w.shape[0], w.shape[1]) for w in Ws]
     lo = None
     if lora:
         lo = (torch.randn(16, K, device="cuda").to(BF), torch.randn(N, 16, device="cuda").to(BF), 1.0, torch.empty(M, 16, device="cuda", dtype=BF))
