@@ -689,24 +689,22 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
     if (p.M <= 64) p.tile = p.N > 64 ? 2 : 3;
     else if (p.N <= 64) p.tile = 3;
     else if (p.M <= 128) {
-      // text encoders / text-conditioning projections (M = 128): a few tiles, latency-bound.  ~250 workgroups, at most 4
-      // splits (more splits lose to the fenced hand-off), narrow tiles when N is small
-      p.tile = p.N <= 1536 ? 3 : 2;
+      // text encoders / text-conditioning projections (M = 128): a few 64x64 tiles, latency-bound; split K only while the
+      // grid is far from one workgroup per CU (120+ tiles: none; 60+: 3; fewer: 4)
+      p.tile = 3;
       if (!p.splitk) {
-        const long tiles = (long)((p.M + 63) / 64) * ((p.N + (p.tile == 3 ? 63 : 127)) / (p.tile == 3 ? 64 : 128));
-        int sk = ws ? (int)((256 + tiles / 2) / tiles) : 1;
-        if (sk > 4) sk = 4;
+        const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+        int sk = !ws ? 1 : (tiles >= 100 ? 1 : (tiles >= 60 ? 3 : 4));
         while (sk > 1 && nk / sk < 4) --sk;
-        p.splitk = sk < 1 ? 1 : sk;
+        p.splitk = sk;
       }
     }
-    else if (!R16 && MODE == 0 && p.M <= 1024 && p.N >= 8192 && ktot <= 2560) p.tile = 6;   // ff1 of the 32x32 blocks: 45 vs 53 us
-    else if (!R16 && MODE == 0 && t128 >= 320 && t128 <= 512 && p.N >= 1024) p.tile = 4;    // 1024x5120x1280: 27 vs 30 us
-    else if (t128 >= 320) { p.tile = 1; if (!p.stages) p.stages = 2; }
+    else if (!R16 && MODE == 0 && t128 >= 320 && t128 <= 512 && p.N >= 1024) p.tile = 4;    // 4096x1920x640: 17.6 vs 19.7 us
+    else if (t128 >= 320) { p.tile = ktot <= 640 ? 1 : 2; if (!p.stages) p.stages = 2; }     // >= 2 workgroups per CU, shallow ring
     else if (t128 >= 160) {
-      if (ktot <= 2560) { p.tile = 3; if (!p.stages) p.stages = 2; }
+      if (ktot <= 2560 || (MODE == 0 && ktot <= 6144)) { p.tile = 3; if (!p.stages) p.stages = 2; }
       else {
-        // 4096 x 640 with a long K (3x3 convs of the 64x64 blocks, ff1 dX): 160 tiles x 3 splits, two workgroups per CU
+        // 4096 x 640 with a long K (3x3 convs of the 64x64 blocks): 160 tiles x 3 splits, two workgroups per CU
         p.tile = 1;
         if (!p.stages) p.stages = 2;
         if (!p.splitk && ws && nk / 3 >= 8) p.splitk = 3;
