@@ -345,24 +345,12 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
 #pragma unroll
   for (int t = 0; t < S - 1; ++t)
     if (kbeg + t < kend) stage(kbeg + t, t);
-  for (int kt = kbeg; kt < kend; ++kt) {
-    // wait until stage kt has landed: this wave has issued stages up to min(kend-1, kt+S-2); each is LPS instructions
-    {
-      const int ahead = (kend - 1 < kt + S - 2 ? kend - 1 : kt + S - 2) - kt;
-      if (S >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-      else if (S >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();   // stage kt visible to all waves; everyone is done reading stage kt-1's buffer
-    asm volatile("" ::: "memory");
-    const bool early = WN == 2 || wave < NW / 2;
-    if (early && kt + S - 1 < kend) stage(kt + S - 1, (kt - kbeg + S - 1) % S);
-    compute(smem + ((kt - kbeg) % S) * STAGE, kt);
-    if (!early && kt + S - 1 < kend) stage(kt + S - 1, (kt - kbeg + S - 1) % S);
+  const bool early = WN == 2 || wave < NW / 2;
+  auto kg_flush = [&](int kt) {
     if constexpr (KG > 0) {
       const int gsteps = p.lora_group_k / BK;
-      if (splitk == 1 && (kt + 1) % gsteps == 0) {          // last K-step of adapter group g (split-K: one group per split, see the reduction): park s*T_g in its Tsh columns, restart the accumulator
-        const int grp = kt / gsteps;
+      if (splitk == 1 && (kt + 1) % gsteps == 0) {   // last K-step of adapter group g (under split-K a split IS a group, see the
+        const int grp = kt / gsteps;                 // reduction): park s*T_g in its Tsh columns and restart the accumulator
         if (t_active) {
 #pragma unroll
           for (int b = 0; b < TMI; ++b) {
@@ -376,6 +364,35 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
         }
       }
     }
+  };
+  // Steady state (a stage is still to be issued): no data-dependent control flow in the loop - the wave has issued stages up
+  // to kt+S-2, so "stage kt landed" is always vmcnt((S-2)*LPS); ring slots advance by increment-and-wrap.  The scalar
+  // bookkeeping of the general form (min/sub/compare per wait, signed modulo per slot) was ~70 SALU instructions and six
+  // branches per K-step.
+  int kt = kbeg;
+  int rd = 0, wr = S - 1;                           // ring slot being consumed / being filled
+  for (; kt + S - 1 < kend; ++kt) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * LPS) : "memory");
+    __builtin_amdgcn_s_barrier();   // stage kt visible to all waves; everyone is done reading stage kt-1's buffer
+    asm volatile("" ::: "memory");
+    if (early) stage(kt + S - 1, wr);
+    compute(smem + rd * STAGE, kt);
+    if (!early) stage(kt + S - 1, wr);
+    kg_flush(kt);
+    rd = rd + 1 == S ? 0 : rd + 1;
+    wr = wr + 1 == S ? 0 : wr + 1;
+  }
+  // Drain: the last (up to) S-1 stages are in flight, nothing left to issue.
+  for (; kt < kend; ++kt) {
+    const int ahead = kend - 1 - kt;                // stages issued after stage kt
+    if (S >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+    else if (S >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    compute(smem + rd * STAGE, kt);
+    kg_flush(kt);
+    rd = rd + 1 == S ? 0 : rd + 1;
   }
   }
 
