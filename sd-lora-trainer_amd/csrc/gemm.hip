@@ -155,6 +155,12 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   // this workgroup's share of the K steps (split-K: contiguous ranges of the combined segment-1 + segment-2 steps)
   const int kbeg = (int)((long)nk * split / splitk), kend = (int)((long)nk * (split + 1) / splitk);
 
+  // implicit-GEMM conv: tap / channel offset of the NEXT stage to be issued (stages are issued strictly in K order from kbeg)
+  int cv_tap = 0, cv_ci0 = 0;
+  if (MODE == 1) {
+    cv_tap = (kbeg * BK) / p.Cin;
+    cv_ci0 = kbeg * BK - cv_tap * p.Cin;
+  }
   // Enumerates the 8-row x 128-byte pieces this wave moves for K-step kt: f(j, src, lds_off) with j in [0, LPS).
   // NOTE: the segment-1 / segment-2 operand pointers are picked per element with value selects.  Handing the two pointer
   // ARRAYS to a common tail (if/else around the loops) made hipcc keep them in scratch and index them at run time: a
@@ -165,7 +171,10 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
     const bool seg1 = !TWOSEG || kt < nk1;
     const int k0 = (seg1 ? kt : kt - nk1) * BK;
     if (MODE == 1) {
-        const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
+        // stages are issued in K order, so the (tap, channel offset) of the step is tracked incrementally (no division)
+        const int tap = cv_tap, ci0 = cv_ci0;
+        cv_ci0 += BK;
+        if (cv_ci0 >= p.Cin) { cv_ci0 = 0; ++cv_tap; }
         const int dy = tap / 3, dx = tap - dy * 3;
         const int oy = p.flip ? 1 - dy : dy - 1, ox = p.flip ? 1 - dx : dx - 1;
 #pragma unroll
@@ -246,7 +255,6 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
     const char* ws = base + XT + (wn * NI * 16) * ROW_BYTES;
     const char* as = base + XT + WT;
     const bool lora_step = R16 && kt < nk1;
-#ifdef SDLT_LAB_READS_UPFRONT
     // every LDS read of the K-step first (one LDS round trip per step instead of four serial ones), then the MFMAs
     bf16x8 xf2[2][MI], wf2[2][NI], af2[2][R16 ? R16 : 1], xt2[2][TMI];
     const int tb = t_active ? wn * TMI : 0;
@@ -281,36 +289,6 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
         }
       }
     }
-#else
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int fo = kk ? foff1 : foff0;
-      bf16x8 xf[MI], wf[NI];
-#pragma unroll
-      for (int b = 0; b < MI; ++b) xf[b] = *(const bf16x8*)(xs + b * 16 * ROW_BYTES + fo);
-#pragma unroll
-      for (int a = 0; a < NI; ++a) wf[a] = *(const bf16x8*)(ws + a * 16 * ROW_BYTES + fo);
-#pragma unroll
-      for (int a = 0; a < NI; ++a)
-#pragma unroll
-        for (int b = 0; b < MI; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
-      if (R16) {
-        if (lora_step && t_active) {
-#pragma unroll
-          for (int j = 0; j < R16; ++j) {
-            bf16x8 af = *(const bf16x8*)(as + j * 16 * ROW_BYTES + fo);
-#pragma unroll
-            for (int b = 0; b < TMI; ++b) {
-              // re-read the X fragment by address: indexing xf[] with the runtime wn would spill it
-              bf16x8 xt = *(const bf16x8*)(xs + (wn * TMI + b) * 16 * ROW_BYTES + fo);
-              tacc[j][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xt, tacc[j][b], 0, 0, 0);
-            }
-          }
-        }
-      }
-    }
-#endif
   };
 
   if (S == 1) {
