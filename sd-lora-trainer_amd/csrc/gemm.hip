@@ -59,7 +59,8 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int splitk = p.splitk > 1 ? p.splitk : 1;
-  const int tile_id = bid / splitk, split = bid - tile_id * splitk;   // splits of one tile are neighbours -> same XCD
+  // (integer divisions are ~40 scalar instructions each on this ISA: the common no-split case skips them)
+  const int tile_id = splitk == 1 ? bid : bid / splitk, split = splitk == 1 ? 0 : bid - tile_id * splitk;   // splits of one tile are neighbours -> same XCD
   // Grouped rasterisation inside each XCD's contiguous chunk of tiles: walk GROUP_M row-tiles before moving to the next
   // column-tile, so the ~32 workgroups an XCD runs concurrently form a compact super-tile (they share X panels AND W
   // panels in that XCD's 4 MB L2 instead of streaming every W panel once per row of tiles).
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   constexpr int LPS = XI + WI + AI;                         // DMA instructions per wave and stage
 
   // this workgroup's share of the K steps (split-K: contiguous ranges of the combined segment-1 + segment-2 steps)
-  const int kbeg = (int)((long)nk * split / splitk), kend = (int)((long)nk * (split + 1) / splitk);
+  const int kbeg = splitk == 1 ? 0 : nk * split / splitk, kend = splitk == 1 ? nk : nk * (split + 1) / splitk;   // 32-bit: nk < 2^15
 
   // implicit-GEMM conv: tap / channel offset of the NEXT stage to be issued (stages are issued strictly in K order from kbeg)
   int cv_tap = 0, cv_ci0 = 0;
