@@ -195,32 +195,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const sdlt_attn_params p)
   }
 }
 
-// =============================================================================== backward prep: D[b,h,q] = sum_d dO*O
-__global__ void attn_prep_kernel(const bf16_t* O, int64_t ldo, const bf16_t* dO, int64_t lddo, int B, int H, int Nq, int Nqp, int d, float* D) {
-  // one 8-lane group per (b,q,h); lane handles 8-element chunks
-  const int64_t total = (int64_t)B * Nqp * H;
-  const int sub = threadIdx.x & 7;
-  for (int64_t idx = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 3; idx < total; idx += ((int64_t)gridDim.x * blockDim.x) >> 3) {
-    int h = idx % H;
-    int64_t row = idx / H;  // b*Nqp + q
-    const int b = row / Nqp, q = row - (int64_t)b * Nqp;
-    if (q >= Nq) continue;   // uniform within the 8-lane group
-    float acc = 0.f;
-    for (int c = sub * 8; c < d; c += 64) {
-      uint4 a = *(const uint4*)(O + row * ldo + h * d + c);
-      uint4 g = *(const uint4*)(dO + row * lddo + h * d + c);
-      const uint32_t* ap = (const uint32_t*)&a;
-      const uint32_t* gp = (const uint32_t*)&g;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc += bf2f(ap[j] & 0xffff) * bf2f(gp[j] & 0xffff) + bf2f(ap[j] >> 16) * bf2f(gp[j] >> 16);
-    }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    acc += __shfl_xor(acc, 4, 64);
-    if (sub == 0) D[((int64_t)b * H + h) * Nq + q] = acc;
-  }
-}
-
 // =============================================================================== backward dQ (per 64-query tile)
 template <int DP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const sdlt_attn_params p) {
@@ -239,7 +213,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const sdlt_attn_params
     gf[kk] = ld_frag_global((const bf16_t*)p.dO + ((int64_t)b * p.Nqp + q) * p.lddo + hc + col, qok && col < d);
   }
   const float Lq = qok ? p.L[((int64_t)b * p.H + h) * p.Nq + q] * LOG2E : 0.f;
-  const float Dq = qok ? p.D[((int64_t)b * p.H + h) * p.Nq + q] : 0.f;
+  // D = rowsum(dO * O) of this wave's 16 query rows, from the dO fragments it holds anyway (no separate prep launch); stored
+  // for the dK/dV pass that follows on the same stream
+  float Dq = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < DP / 32; ++kk) {
+    int col = kk * 32 + g * 8;
+    bf16x8 of = ld_frag_global((const bf16_t*)p.O + ((int64_t)b * p.Nqp + q) * p.ldo + hc + col, qok && col < d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Dq += (float)gf[kk][j] * (float)of[j];
+  }
+  Dq += __shfl_xor(Dq, 16, 64);
+  Dq += __shfl_xor(Dq, 32, 64);
+  if (g == 0 && qok) p.D[((int64_t)b * p.H + h) * p.Nq + q] = Dq;
   f32x4 dq[DP / 16];
 #pragma unroll
   for (int df = 0; df < DP / 16; ++df) dq[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -855,12 +841,6 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
     }
     SDLT_CHECK_LAUNCH();
     return SDLT_OK;
-  }
-  {
-    int64_t groups = (int64_t)p.B * p.Nqp * p.H;
-    int blocks = (int)((groups * 8 + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(attn_prep_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)p.O, p.ldo, (const bf16_t*)p.dO, p.lddo, p.B, p.H, p.Nq, p.Nqp, p.d, p.D);
   }
   dim3 gq((p.Nq + 63) / 64, p.H, p.B);
 #define SMEM_DQ(D_) (2 * (2 * 64 * ((D_) * 2 + 16)))
