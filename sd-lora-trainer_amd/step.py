@@ -6,6 +6,8 @@ rates, bias corrections) live in a small device buffer that is updated before ea
 """
 import math
 
+import os
+
 import torch
 
 from . import ops as _ops
@@ -22,13 +24,18 @@ class TextStack:
     SD1.5: prompt_embeds = CLIP-L last_hidden_state (after final LN).
     SDXL : prompt_embeds = concat(CLIP-L hidden_states[-2], bigG hidden_states[-2]); pooled = bigG text_embeds."""
 
-    def __init__(self, rt, encoders, pool_mode="argmax", eos_token_id=49407):
+    def __init__(self, rt, encoders, pool_mode="argmax", eos_token_id=49407, concurrent=False):
         self.rt, self.encoders, self.pool_mode, self.eos = rt, encoders, pool_mode, eos_token_id
         B = rt.B
         self.ids = [torch.zeros(B, T_TOKENS, dtype=torch.int64, device=rt.device) for _ in encoders]
         self.pool_rows = torch.zeros(B, dtype=torch.int64, device=rt.device)
         self.widths = [e.D for e in encoders]
-        self.side = [torch.cuda.Stream(device=rt.device) for _ in encoders] if torch.device(rt.device).type == "cuda" else []
+        # concurrent=True runs the encoders on forked streams (and the step then replays three small hipGraphs, because
+        # ROCm's executor only overlaps branches forked near the root of a small graph).  Measured on the SDXL step it LOSES
+        # 1.7 ms: each fork/join costs ~0.7 ms of queue hand-off plus ~90 us at every cross-queue edge, more than CLIP-L
+        # (2.6 ms, mostly hidden) saves - so the default is one stream, one graph.
+        self.concurrent = bool(concurrent) and torch.device(rt.device).type == "cuda"
+        self.side = [torch.cuda.Stream(device=rt.device) for _ in encoders] if self.concurrent else []
 
     def set_ids(self, ids_per_encoder):
         for dst, src in zip(self.ids, ids_per_encoder):
@@ -121,7 +128,7 @@ class TrainStep:
         self.sums, self.loss, self.l1_sum = z(B * 2), z(1), z(1)
         self.hyper = z(16)
         self.opt_step = 0
-        self.graph, self.graphs, self.graph_frozen = None, [], None
+        self.graph, self.graphs, self.graphs_frozen = None, [], None
 
     # -------------------------------------------------------------------------------- inputs
     def set_batch(self, latent, noise, timesteps, mask, ctx=None, pooled=None, time_ids=None, ids=None, caption_token_lists=None):
@@ -158,9 +165,10 @@ class TrainStep:
             self.ti.hyper[: len(vals)].copy_(torch.tensor(vals, dtype=torch.float32))
 
     # -------------------------------------------------------------------------------- the step body
-    # The step is cut into three phases so that each can be its own hipGraph: ROCm's graph executor only overlaps forked
-    # branches (the two text encoders) when the fork sits near the root of a small graph - inside the ~4600-node
-    # whole-step graph the branches were replayed strictly one after the other (kernel trace, tools/graph_branch_probe2.py).
+    # The step is cut into three phases so that each CAN be its own hipGraph (TextStack(concurrent=True)): ROCm's graph
+    # executor only overlaps forked branches (the two text encoders) when the fork sits near the root of a small graph -
+    # inside the whole-step graph the branches were replayed strictly one after the other (kernel trace,
+    # tools/graph_branch_probe2.py).  By default the phases are captured back to back into ONE graph.
     def _phase_text_fwd(self):
         self._pooled_live = self.pooled
         if self.text is not None:                      # a4: text conditioning with the trainable token rows (main.py:306-308)
@@ -228,8 +236,8 @@ class TrainStep:
     # -------------------------------------------------------------------------------- graph capture / replay
     def capture(self, warmup=2):
         """Runs the body eagerly `warmup` times (allocates every persistent buffer, builds the grouped-gradient
-        plan), then captures it - one hipGraph per phase, sharing one memory pool, replayed back to back.  AdamW state
-        is restored afterwards so capture does not count as training."""
+        plan), then captures it: one hipGraph for the whole step (one per phase when the text encoders run on forked
+        streams), plus the frozen-TI variant.  AdamW state is restored afterwards so capture does not count as training."""
         a = self.unet.arena
         state = [a.params, a.m, a.v] + ([self.ti.params, self.ti.m, self.ti.v] if self.ti is not None else [])
         snap = [t.clone() for t in state]
@@ -240,19 +248,25 @@ class TrainStep:
             for _ in range(warmup):
                 self.body()
         torch.cuda.current_stream().wait_stream(s)
-        self.graphs, pool = [], None
-        for phase in self._phases():
+        def cap(fns, pool):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool):
-                phase()
-            pool = g.pool()
-            self.graphs.append(g)
+                for fn in fns:
+                    fn()
+            return g
+        phases = self._phases()
+        split = self.text is not None and self.text.concurrent      # one graph per phase only when the encoders fork
+        self.graphs, pool = [], None
+        for fns in ([[ph] for ph in phases] if split else [phases]):
+            self.graphs.append(cap(fns, pool))
+            pool = self.graphs[-1].pool()
         self.graph = self.graphs[0]
-        self.graph_frozen = None
-        if self.text is not None:
-            self.graph_frozen = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_frozen, pool=pool):
-                self._phase_opt_frozen_ti()
+        self.graphs_frozen = None
+        if self.text is not None:     # variant for ti lr == 0: same first phases, LoRA-only last phase
+            if split:
+                self.graphs_frozen = self.graphs[:2] + [cap([self._phase_opt_frozen_ti], pool)]
+            else:
+                self.graphs_frozen = [cap([self._phase_text_fwd, self._phase_unet, self._phase_opt_frozen_ti], pool)]
         for t, c in zip(state, snap):
             t.copy_(c)
         a.refresh_shadows()
@@ -265,8 +279,7 @@ class TrainStep:
         frozen = self.text is not None and lr_ti == 0.0
         self._frozen_last = frozen
         if self.graph is not None:
-            graphs = self.graphs[:2] + [self.graph_frozen] if frozen else self.graphs
-            for g in graphs:
+            for g in (self.graphs_frozen if frozen else self.graphs):
                 g.replay()
         elif frozen:
             self._phase_text_fwd()

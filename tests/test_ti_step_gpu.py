@@ -16,8 +16,8 @@ def _cos_rel(a, b):
     return float(a @ b / (a.norm() * b.norm() + 1e-30)), float((a - b).norm() / (b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("version,B", [("tiny15", 2), ("tinyxl", 2)])
-def test_ti_step_gpu_matches_oracle(version, B):
+@pytest.mark.parametrize("version,B,concurrent", [("tiny15", 2, False), ("tinyxl", 2, False), ("tinyxl", 2, True)])
+def test_ti_step_gpu_matches_oracle(version, B, concurrent):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from oracle import loss_ref as L
@@ -76,7 +76,7 @@ def test_ti_step_gpu_matches_oracle(version, B):
                 clip_mod.ClipTextEncoder(rt, "te2", sds[1], heads=1, act="gelu", mode="penultimate", with_projection=True, n_train=NTOK)]
     else:
         encs = [clip_mod.ClipTextEncoder(rt, "te1", sds[0], heads=2, act="quick_gelu", mode="last", with_projection=False, n_train=NTOK)]
-    text = step_mod.TextStack(rt, encs, pool_mode="first_eos", eos_token_id=EOS)
+    text = step_mod.TextStack(rt, encs, pool_mode="first_eos", eos_token_id=EOS, concurrent=concurrent)   # forked encoder streams + per-phase graphs
     ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, l1_penalty=0.0, weight_decay=0.0, text=text, n_tokens=NTOK,
                             token_attention_loss_w=w_ta, ti_std_loss_w=w_std)
     ts.set_batch(latent.cuda(), noise.cuda(), t.cuda(), mask.cuda(), time_ids=tid.cuda() if xl else None, ids=[ids] * len(encs),
