@@ -153,16 +153,36 @@ class TrainStep:
             self.time_ids.copy_(time_ids.reshape(-1).to(torch.float32))
 
     def set_hyper(self, lr, lr_ti=0.0):
-        """Host scalars of this optimiser step -> device buffers (see sdlt_adamw_fused)."""
+        """Host scalars of this optimiser step -> device buffers (see sdlt_adamw_fused).
+        The upload is an async copy from a ring of pinned staging rows: a pageable-memory copy would block the host until the
+        previous step has finished on the GPU, so the next graph launch could never be queued behind the running one (the
+        GPU then idled ~1 ms per step while the host caught up)."""
         self.opt_step += 1
         b1, b2 = self.betas
         n = self.unet.arena.n
         bc = [1.0 - b1 ** self.opt_step, 1.0 - b2 ** self.opt_step]
-        vals = [lr, b1, b2, self.eps, self.wd, *bc, self.l1_penalty / n, 1.0]
-        self.hyper[: len(vals)].copy_(torch.tensor(vals, dtype=torch.float32))
+        rows = [[lr, b1, b2, self.eps, self.wd, *bc, self.l1_penalty / n, 1.0]]
         if self.ti is not None:
-            vals = [lr_ti, b1, b2, self.eps, self.ti_wd, *bc, 0.0, 1.0]
-            self.ti.hyper[: len(vals)].copy_(torch.tensor(vals, dtype=torch.float32))
+            rows.append([lr_ti, b1, b2, self.eps, self.ti_wd, *bc, 0.0, 1.0])
+        cuda = self.hyper.is_cuda
+        if cuda and getattr(self, "_hyper_ring", None) is None:
+            self._hyper_ring = torch.zeros(64, 2, 16, dtype=torch.float32).pin_memory()
+            self._hyper_done = [None] * 64          # event after the copies of a slot: waited for before the slot is reused
+            self._hyper_slot = 0
+        if cuda and self._hyper_done[self._hyper_slot] is not None:
+            self._hyper_done[self._hyper_slot].synchronize()
+        for i, (vals, dst) in enumerate(zip(rows, [self.hyper] + ([self.ti.hyper] if self.ti is not None else []))):
+            if cuda:
+                stage = self._hyper_ring[self._hyper_slot, i]
+                stage[: len(vals)] = torch.tensor(vals, dtype=torch.float32)
+                dst[: len(vals)].copy_(stage[: len(vals)], non_blocking=True)
+            else:
+                dst[: len(vals)].copy_(torch.tensor(vals, dtype=torch.float32))
+        if cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._hyper_done[self._hyper_slot] = ev
+            self._hyper_slot = (self._hyper_slot + 1) % self._hyper_ring.shape[0]
 
     # -------------------------------------------------------------------------------- the step body
     # The step is cut into three phases so that each CAN be its own hipGraph (TextStack(concurrent=True)): ROCm's graph
@@ -256,17 +276,22 @@ class TrainStep:
             return g
         phases = self._phases()
         split = self.text is not None and self.text.concurrent      # one graph per phase only when the encoders fork
-        self.graphs, pool = [], None
-        for fns in ([[ph] for ph in phases] if split else [phases]):
-            self.graphs.append(cap(fns, pool))
-            pool = self.graphs[-1].pool()
+
+        def cap_set(pool):
+            graphs = []
+            for fns in ([[ph] for ph in phases] if split else [phases]):
+                graphs.append(cap(fns, pool))
+                pool = graphs[-1].pool()
+            frozen = None
+            if self.text is not None:     # variant for ti lr == 0: same first phases, LoRA-only last phase
+                if split:
+                    frozen = graphs[:2] + [cap([self._phase_opt_frozen_ti], pool)]
+                else:
+                    frozen = [cap([self._phase_text_fwd, self._phase_unet, self._phase_opt_frozen_ti], pool)]
+            return graphs, frozen, pool
+
+        self.graphs, self.graphs_frozen, _ = cap_set(None)
         self.graph = self.graphs[0]
-        self.graphs_frozen = None
-        if self.text is not None:     # variant for ti lr == 0: same first phases, LoRA-only last phase
-            if split:
-                self.graphs_frozen = self.graphs[:2] + [cap([self._phase_opt_frozen_ti], pool)]
-            else:
-                self.graphs_frozen = [cap([self._phase_text_fwd, self._phase_unet, self._phase_opt_frozen_ti], pool)]
         for t, c in zip(state, snap):
             t.copy_(c)
         a.refresh_shadows()
