@@ -54,7 +54,7 @@ def _cos_rel(a, b):
     return float(a @ b / (a.norm() * b.norm() + 1e-30)), float((a - b).norm() / (b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("version,B,gamma,rank", [("tiny15", 2, 5.0, 4), ("tinyxl", 1, 5.0, 16), ("tinyxl", 2, 0.0, 8)])
+@pytest.mark.parametrize("version,B,gamma,rank", [("tiny15", 2, 5.0, 4), ("tinyxl", 1, 5.0, 16), ("tinyxl", 2, 0.0, 8), ("tiny15", 1, 5.0, 32)])   # rank 32: padded rank 32, member-wise dX of the stacked projections
 def test_step_matches_fp32_oracle(version, B, gamma, rank):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
