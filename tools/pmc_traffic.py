@@ -21,7 +21,7 @@ out = {"kernels_per_step": n,
        "fetch_bytes_per_step": 2 * sum(fetch.values()), "write_bytes_per_step": sum(write.values()),
        "fetch_bytes_by_family": {k: 2 * v for k, v in sorted(fetch.items(), key=lambda kv: -kv[1])},
        "write_bytes_by_family": {k: v for k, v in sorted(write.items(), key=lambda kv: -kv[1])},
-       "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --no-cpu-baseline --steps 2 --warmup 1`; "
+       "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --no-graph --no-cpu-baseline --steps 2 --warmup 1` (eager launches of the same kernels; counter collection over the whole-step hipGraph does not finish); "
                "last full step; FETCH_SIZE doubled (gfx950: 128-B requests tallied at 64 B), WRITE_SIZE as reported (uncalibrated); "
                "Infinity-Cache hits are included in both"}
 out["traffic_bytes_per_step"] = out["fetch_bytes_per_step"] + out["write_bytes_per_step"]
