@@ -40,6 +40,15 @@ int sdlt_struct_size(int which); /* 0 gemm, 1 lora_grad_desc, 2 attn, 3 groupnor
  *         tile whose fp32 partials meet in ws_slab; the last arriver (ws_cnt ticket, agent-scope release/acquire)
  *         reduces them and runs the epilogue - no extra launch.
  */
+/* One problem of a batched launch (sdlt_gemm_params.batch): same M, N, K, leading dimensions, LoRA rank and epilogue
+ * options as the launch, its own operands.  NULL members fall back to the launch-wide pointer. */
+typedef struct sdlt_gemm_batch_item {
+  const void* X; const void* W;
+  const void* Adown; const void* Bup; void* T_out;
+  void* C; void* Ct;
+  const float* bias;
+} sdlt_gemm_batch_item;
+
 typedef struct sdlt_gemm_params {
   const void* X; int64_t ldx;
   const void* W; int64_t ldw;
@@ -76,6 +85,11 @@ typedef struct sdlt_gemm_params {
   int32_t lora_group_k;       /* > 0: K is a concatenation of G <= 4 groups of `lora_group_k` columns (the stacked dY of fused
                                  projections), each with its own rank-16 adapter: Adown stays [16, K] (the groups' B^T side by
                                  side), T_out is [M, G*16] and Bup [N, G*16].  lora_R must be 16, mode 0, no split-K. */
+  const sdlt_gemm_batch_item* batch;   /* device array of n_batch problems sharing this launch (the to_k|to_v projections of
+                                          every cross-attention layer read the same text conditioning: one launch for all of
+                                          them, and one for all their input gradients); no split-K */
+  int32_t n_batch;
+  int32_t pad2_;
 } sdlt_gemm_params;
 int sdlt_gemm_bf16(const sdlt_gemm_params* p, void* stream);
 

@@ -34,8 +34,19 @@ struct ConvGeom {
 // MI x NI 16x16 fragments per wave; waves are laid out 2 (m) x WN (n): WN = 2 -> 256 threads, WN = 4 -> 512 threads
 // (two waves per SIMD: the second half of the waves computes first and issues its DMA afterwards, so one wave's DMA
 // issue stalls overlap the other's MFMAs on every SIMD).
-template <int MI, int NI, int WN, int MODE, int R16, int NSTAGE, int KG = 0>
+template <int MI, int NI, int WN, int MODE, int R16, int NSTAGE, int KG = 0, int BT = 0>
 __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p) {
+  // batched launch: blockIdx.y picks the problem; its operand pointers replace the launch-wide ones (wave-uniform scalar loads)
+  // (BT is a template switch so that ordinary launches do not pay the extra kernarg loads and selects in their prologue)
+  const sdlt_gemm_batch_item* bi = BT ? p.batch + blockIdx.y : nullptr;
+  const void* pX = (bi && bi->X) ? bi->X : p.X;
+  const void* pW = (bi && bi->W) ? bi->W : p.W;
+  const void* pAdown = (bi && bi->Adown) ? bi->Adown : p.Adown;
+  const void* pBup = (bi && bi->Bup) ? bi->Bup : p.Bup;
+  void* pTout = (bi && bi->T_out) ? bi->T_out : p.T_out;
+  void* pC = (bi && bi->C) ? bi->C : p.C;
+  void* pCt = (bi && bi->Ct) ? bi->Ct : p.Ct;
+  const float* pBias = (bi && bi->bias) ? bi->bias : p.bias;
   constexpr int NW = 2 * WN, NTHR = NW * 64;
   constexpr int BM = 2 * MI * 16, BN = WN * NI * 16;
   constexpr int XT = BM * ROW_BYTES, WT = BN * ROW_BYTES, AT = (R16 ? R16 * 16 : 0) * ROW_BYTES;
@@ -96,7 +107,7 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
     int m = m0 + (wave + NW * i) * 8 + srow;
     if (MODE == 0) {
       int mc = m < p.M ? m : p.M - 1;
-      xptr[i] = (const bf16_t*)p.X + (size_t)mc * p.ldx + schunk * 8;
+      xptr[i] = (const bf16_t*)pX + (size_t)mc * p.ldx + schunk * 8;
       xb[i] = xh[i] = xw[i] = 0;
     } else {
       if (m < p.M) {
@@ -116,7 +127,7 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   for (int i = 0; i < WI; ++i) {
     int n = n0 + (wave + NW * i) * 8 + srow;
     int nc = n < p.N ? n : p.N - 1;
-    wptr[i] = (const bf16_t*)p.W + (size_t)nc * p.ldw + schunk * 8;
+    wptr[i] = (const bf16_t*)pW + (size_t)nc * p.ldw + schunk * 8;
   }
   const bf16_t* x2ptr[XI];
   const bf16_t* w2ptr[WI];
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   const bf16_t* aptr = nullptr;
   if (R16) {
     // piece index handled by this wave in round j: wave + 4*j  (< R16*2)
-    aptr = (const bf16_t*)p.Adown + schunk * 8;
+    aptr = (const bf16_t*)pAdown + schunk * 8;
   }
   // grouped adapters (fused projections): this tile's column group selects the Adown rows and the T_out columns
   const int lgrp = (R16 && p.lora_group_n > 0) ? n0 / p.lora_group_n : 0;
@@ -194,7 +205,7 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
               ok = hi >= 0 && wi >= 0 && hi < p.Hin * p.ups && wi < p.Win * p.ups;
               if (p.ups == 2) { hi >>= 1; wi >>= 1; }
             }
-            if (ok) src = (const bf16_t*)p.X + ((size_t)(xb[i] * p.Hin + hi) * p.Win + wi) * p.ldx + ci0 + schunk * 8;
+            if (ok) src = (const bf16_t*)pX + ((size_t)(xb[i] * p.Hin + hi) * p.Win + wi) * p.ldx + ci0 + schunk * 8;
           }
           f(i, src, (wave + NW * i) * 1024);
         }
@@ -466,13 +477,13 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
     }
     const int nup = KG ? p.K / p.lora_group_k : R16;   // 16-column blocks of T (K-grouped: one per adapter)
     __syncthreads();
-    if (p.T_out != nullptr && t_writer) {
+    if (pTout != nullptr && t_writer) {
       // [BM rows][R] bf16 -> global, 8 B per lane
       const int CH = nup * 4;  // 8-byte chunks per row
       for (int c = tid; c < BM * CH; c += NTHR) {
         int ml = c / CH, cc = c - ml * CH;
         int m = m0 + ml;
-        if (m < p.M) *(uint2*)((bf16_t*)p.T_out + (size_t)m * p.ld_t + lgrp * (R16 * 16) + cc * 4) = *(const uint2*)(tsh + ((size_t)ml * TROW + cc * 4) * 2);
+        if (m < p.M) *(uint2*)((bf16_t*)pTout + (size_t)m * p.ld_t + lgrp * (R16 * 16) + cc * 4) = *(const uint2*)(tsh + ((size_t)ml * TROW + cc * 4) * 2);
       }
     }
 #pragma unroll
@@ -488,7 +499,7 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
       for (int a = 0; a < NI; ++a) {
         int n = n0 + wn * NI * 16 + a * 16 + frow;
         int nc = n < p.N ? n : p.N - 1;
-        s16x4 bf = *(const s16x4*)((const bf16_t*)p.Bup + (size_t)nc * p.ld_bup + j * 16 + fk * 4);
+        s16x4 bf = *(const s16x4*)((const bf16_t*)pBup + (size_t)nc * p.ld_bup + j * 16 + fk * 4);
 #pragma unroll
         for (int b = 0; b < MI; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bf, tf[b], acc[a][b], 0, 0, 0);
@@ -498,7 +509,7 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
 
   // ---------------- epilogue ----------------
 #ifdef SDLT_LAB_NO_EPILOGUE
-  if (acc[0][0][0] == 12345.f) ((float*)p.C)[0] = 1.f;
+  if (acc[0][0][0] == 12345.f) ((float*)pC)[0] = 1.f;
   return;
 #endif
   // acc[a][b][r] = C[m = m0 + wm*MI*16 + b*16 + (lane&15)][n = n0 + wn*NI*16 + a*16 + (lane>>4)*4 + r]
@@ -510,8 +521,8 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   // now idle staging LDS and leaves as full 256-byte row segments, 16 B per lane; the residual is read the same way and
   // added before the single bf16 rounding.
   // (not for the M = 128 text-encoder GEMMs: a handful of tiles, where the two extra barriers cost more than the wider stores save)
-  if ((long)p.M * p.N >= (1l << 20) && !p.out_fp32 && p.Ct == nullptr && vec_ok && (p.ldc & 7) == 0 && (p.N & 7) == 0 && (p.R == nullptr || (p.ldr & 7) == 0) &&
-      (((uintptr_t)p.C | (uintptr_t)p.R) & 15) == 0) {
+  if ((long)p.M * p.N >= (1l << 20) && !p.out_fp32 && pCt == nullptr && vec_ok && (p.ldc & 7) == 0 && (p.N & 7) == 0 && (p.R == nullptr || (p.ldr & 7) == 0) &&
+      (((uintptr_t)pC | (uintptr_t)p.R) & 15) == 0) {
     constexpr int CST = BN + 4;                                    // fp32 elements per staged row (+4: bank spread)
     constexpr int REGION = (S == 1 ? 2 : S) * STAGE;
     constexpr int CROWS = BM * CST * 4 <= REGION ? BM : (BM / 2 * CST * 4 <= REGION ? BM / 2 : BM / 4);
@@ -533,7 +544,7 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
           const int n = n0 + nl;
           f32x4 v = acc[a][b] * p.alpha;
           if (n < p.N) {
-            if (p.bias) v += *(const f32x4*)(p.bias + n);
+            if (pBias) v += *(const f32x4*)(pBias + n);
             if (p.rowbias) {
               uint2 rb = *(const uint2*)((const bf16_t*)p.rowbias + (size_t)brow * p.ld_rowbias + n);
               v[0] += bf2f(rb.x & 0xffff); v[1] += bf2f(rb.x >> 16); v[2] += bf2f(rb.y & 0xffff); v[3] += bf2f(rb.y >> 16);
@@ -556,7 +567,7 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
         }
         uint4 o;
         o.x = pack2bf(lo[0], lo[1]); o.y = pack2bf(lo[2], lo[3]); o.z = pack2bf(hi[0], hi[1]); o.w = pack2bf(hi[2], hi[3]);
-        *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+        *(uint4*)((bf16_t*)pC + (size_t)m * p.ldc + n) = o;
       }
       if (pass + 1 < BM / CROWS) __syncthreads();
     }
@@ -576,8 +587,8 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] * p.alpha;
       if (vec_ok && n + 3 < p.N) {
-        if (p.bias) {
-          float4 bv = *(const float4*)(p.bias + n);
+        if (pBias) {
+          float4 bv = *(const float4*)(pBias + n);
           v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
         }
         if (p.rowbias) {
@@ -588,39 +599,39 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
           uint2 rv = *(const uint2*)((const bf16_t*)p.R + (size_t)m * p.ldr + n);
           v[0] += bf2f(rv.x & 0xffff); v[1] += bf2f(rv.x >> 16); v[2] += bf2f(rv.y & 0xffff); v[3] += bf2f(rv.y >> 16);
         }
-        if (p.Ct) {
+        if (pCt) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ((bf16_t*)p.Ct)[(size_t)(n + r) * p.ldct + m] = f2bf(v[r]);
+          for (int r = 0; r < 4; ++r) ((bf16_t*)pCt)[(size_t)(n + r) * p.ldct + m] = f2bf(v[r]);
         }
         if (p.out_fp32) {
           if (p.accumulate) {
-            float4 old = *(const float4*)((const float*)p.C + (size_t)m * p.ldc + n);
+            float4 old = *(const float4*)((const float*)pC + (size_t)m * p.ldc + n);
             v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
           }
-          *(float4*)((float*)p.C + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+          *(float4*)((float*)pC + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
           uint2 o;
           o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-          *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+          *(uint2*)((bf16_t*)pC + (size_t)m * p.ldc + n) = o;
         }
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (n + r >= p.N) break;
           float x = v[r];
-          if (p.bias) x += p.bias[n + r];
+          if (pBias) x += pBias[n + r];
           if (p.rowbias) x += bf2f(((const bf16_t*)p.rowbias)[(size_t)brow * p.ld_rowbias + n + r]);
           if (p.R) x += bf2f(((const bf16_t*)p.R)[(size_t)m * p.ldr + n + r]);
-          if (p.Ct) ((bf16_t*)p.Ct)[(size_t)(n + r) * p.ldct + m] = f2bf(x);
-          if (p.out_fp32) ((float*)p.C)[(size_t)m * p.ldc + n + r] = p.accumulate ? ((float*)p.C)[(size_t)m * p.ldc + n + r] + x : x;
-          else ((bf16_t*)p.C)[(size_t)m * p.ldc + n + r] = f2bf(x);
+          if (pCt) ((bf16_t*)pCt)[(size_t)(n + r) * p.ldct + m] = f2bf(x);
+          if (p.out_fp32) ((float*)pC)[(size_t)m * p.ldc + n + r] = p.accumulate ? ((float*)pC)[(size_t)m * p.ldc + n + r] + x : x;
+          else ((bf16_t*)pC)[(size_t)m * p.ldc + n + r] = f2bf(x);
         }
       }
     }
   }
 }
 
-template <int MI, int NI, int WN, int MODE, int R16, int NSREQ, int KG = 0>
+template <int MI, int NI, int WN, int MODE, int R16, int NSREQ, int KG = 0, int BT = 0>
 int launch(const sdlt_gemm_params& p, hipStream_t stream) {
   constexpr int NTHR = 128 * WN;
   constexpr int BM = 2 * MI * 16, BN = WN * NI * 16;
@@ -636,7 +647,7 @@ int launch(const sdlt_gemm_params& p, hipStream_t stream) {
   const int smem = NBUF * STAGE + TSH;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_kernel<MI, NI, WN, MODE, R16, NS, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute((const void*)gemm_kernel<MI, NI, WN, MODE, R16, NS, KG, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
@@ -647,7 +658,7 @@ int launch(const sdlt_gemm_params& p, hipStream_t stream) {
     if (!p.ws_slab || !p.ws_cnt || (size_t)nbm * nbn * splitk * slab_bytes > (size_t)p.ws_slab_bytes || nbm * nbn > p.ws_cnt_len)
       SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: split-K workspace too small (%d tiles x %d splits x %zu B)", nbm * nbn, splitk, slab_bytes);
   }
-  hipLaunchKernelGGL((gemm_kernel<MI, NI, WN, MODE, R16, NS, KG>), dim3(nbm * nbn * splitk), dim3(NTHR), smem, stream, p);
+  hipLaunchKernelGGL((gemm_kernel<MI, NI, WN, MODE, R16, NS, KG, BT>), dim3(nbm * nbn * splitk, BT ? p.n_batch : 1), dim3(NTHR), smem, stream, p);
   }
   return SDLT_OK;
 }
@@ -673,6 +684,7 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     p.splitk = (pin.splitk == G || (pin.splitk == 0 && G > 1 && t128 * G <= 320 && p.ws_slab && p.ws_cnt)) ? G : 1;
   }
+  if (p.batch) p.splitk = 1;            // batched launch: the problems fill the chip, the split-K scratch is per launch
   const int ktot = p.K + p.K2;
   if (p.tile == 0) {
     // Shape heuristics from the tools/gemm_probe.py sweep on MI355X ("GEMM tile selection"):
@@ -747,6 +759,25 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
     // wins as soon as it yields >= 64 workgroups (4096x640x1920: 31 us vs 61 us for 64x64)
     const long t128k = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     if (t128k >= 64 || p.tile < 1 || p.tile > 3) p.tile = 1;
+  }
+  if (p.batch) {   // batched launches exist for what uses them: plain GEMM mode, rank pad 16, tiles 1..3, deep ring
+    if constexpr (MODE == 0 && R16 == 1) {
+      if (p.n_batch < 1 || p.n_batch > 65535) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: n_batch=%d", p.n_batch);
+      if (p.lora_group_k > 0) {
+        switch (p.tile) {
+          case 1: return launch<4, 2, 4, 0, 1, 4, 4, 1>(p, s);
+          case 2: return launch<2, 2, 4, 0, 1, 4, 4, 1>(p, s);
+          case 3: return launch<2, 2, 2, 0, 1, 4, 4, 1>(p, s);
+        }
+      } else {
+        switch (p.tile) {
+          case 1: return launch<4, 2, 4, 0, 1, 4, 0, 1>(p, s);
+          case 2: return launch<2, 2, 4, 0, 1, 4, 0, 1>(p, s);
+          case 3: return launch<2, 2, 2, 0, 1, 4, 0, 1>(p, s);
+        }
+      }
+    }
+    SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: batched launch needs mode 0, padded LoRA rank 16 and tile 1..3 (tile %d)", p.tile);
   }
   if (p.lora_group_k > 0) {   // K-grouped adapters: plain GEMM mode, rank pad 16, tiles 1..3, deep ring
     if constexpr (MODE == 0 && R16 == 1) {

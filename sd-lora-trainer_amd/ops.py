@@ -68,14 +68,16 @@ class ConvGeom:
 
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
-         residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0):
+         residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0, batch=None):
     """out[M,N] = alpha*(X.W^T [+ X2.W2^T] [+ s*(X.Adown^T).Bup^T]) + bias + rowbias[m//rows_per_batch] + residual.
     lora = (Adown [Rp,K], Bup [N,Rp], scale, T_out [M,Rp] or None).  out dtype bf16 or fp32.  Ct: optional
     transposed bf16 copy [N, >=M].  conv: ConvGeom -> X is the NHWC activation [B*Hin*Win, Cin].
     lora_group_n > 0: W is a stack of G = N / lora_group_n projections with one adapter each:
     Adown [G*Rp, K] (group-major), Bup [N, Rp], T_out [M, G*Rp].
     lora_group_k > 0: X is a stack of G = K / lora_group_k gradients (the dX of such a stack): Adown [16, K], Bup [N, G*16],
-    T_out [M, G*16]."""
+    T_out [M, G*16].
+    batch: a GemmBatch - the launch runs len(batch) problems of identical shape / leading dimensions; the tensor arguments
+    describe problem 0 (shapes, strides, options), every problem's operand pointers come from the batch."""
     lib = _lib.load()
     p = _lib.GemmParams()
     _chk2(X), _chk2(W)
@@ -138,10 +140,34 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
         assert Ct.shape[0] == N and Ct.shape[1] >= M
         p.Ct, p.ldct = _p(Ct), _ld(Ct)
     p.tile, p.splitk, p.stages, p.accumulate = tile, splitk, stages, int(accumulate)
+    if batch is not None:
+        p.batch, p.n_batch = _p(batch.dev), batch.n
     slab, cnt = splitk_workspace(X.device)
     p.ws_slab, p.ws_slab_bytes, p.ws_cnt, p.ws_cnt_len = _p(slab), slab.numel(), _p(cnt), cnt.numel()
     _lib.check(lib.sdlt_gemm_bf16(C.byref(p), _stream()), "sdlt_gemm_bf16")
     return out
+
+
+class GemmBatch:
+    """Device-resident operand table of a batched sdlt_gemm_bf16 launch (sdlt_gemm_batch_item[]).
+    items: list of dict with tensors (or None) under X, W, Adown, Bup, T_out, C, Ct, bias - same shapes and strides per key."""
+    KEYS = ("X", "W", "Adown", "Bup", "T_out", "C", "Ct", "bias")
+
+    def __init__(self, items, device):
+        arr = (_lib.GemmBatchItem * len(items))()
+        self.keep = []
+        for i, it in enumerate(items):
+            for k in self.KEYS:
+                t = it.get(k)
+                if t is not None:
+                    assert t.is_cuda
+                    ref = items[0].get(k)
+                    assert ref is not None and t.shape == ref.shape and t.stride() == ref.stride() and t.dtype == ref.dtype, f"batch item {i}: {k} differs from item 0"
+                    setattr(arr[i], k, t.data_ptr())
+                    self.keep.append(t)
+        self.n = len(items)
+        self.items = items
+        self.dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
 
 
 class LoraGradPlan:

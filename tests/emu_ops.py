@@ -43,7 +43,14 @@ def _conv_apply(X, Wm, g):
 
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
-         residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0):
+         residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0, batch=None):
+    if batch is not None:     # batched launch: every problem with its own operands, same options
+        for it in batch.items:
+            lo = None if lora is None else (it.get("Adown", lora[0]) if it.get("Adown") is not None else lora[0], it.get("Bup") if it.get("Bup") is not None else lora[1], lora[2], it.get("T_out") if it.get("T_out") is not None else lora[3])
+            gemm(it["X"] if it.get("X") is not None else X, it["W"] if it.get("W") is not None else W, it["C"] if it.get("C") is not None else out, X2=X2, W2=W2, conv=conv, lora=lo,
+                 bias=it.get("bias") if it.get("bias") is not None else bias, rowbias=rowbias, rows_per_batch=rows_per_batch, residual=residual, alpha=alpha,
+                 Ct=it.get("Ct") if it.get("Ct") is not None else Ct, accumulate=accumulate, lora_group_n=lora_group_n, lora_group_k=lora_group_k)
+        return out
     acc = X.float() @ W.float().t() if conv is None else _conv_apply(X, W, conv)
     if X2 is not None:
         acc = acc + X2.float() @ W2.float().t()
@@ -79,6 +86,11 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
     if Ct is not None:
         Ct[:, : acc.shape[0]].copy_(acc.t().to(Ct.dtype))
     return out
+
+
+class GemmBatch:
+    def __init__(self, items, device):
+        self.items, self.n = items, len(items)
 
 
 class LoraGradPlan:

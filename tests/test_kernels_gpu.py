@@ -242,6 +242,37 @@ def test_gemm_kgrouped_lora(ops, M, N, C, G, tile, splitk):
     close(out_g, out_c, tol=1.5e-2, what="k-grouped lora out")
 
 
+@pytest.mark.parametrize("mode", ["ngroup", "kgroup"])
+def test_gemm_batched(ops, mode):
+    """One launch, several problems of identical shape (the to_k|to_v projections of all cross-attention layers)."""
+    g = torch.Generator().manual_seed(77)
+    nb, M, C, Kc = 5, 128, 128, 256
+    if mode == "ngroup":      # forward: shared X, per-problem stacked W [2C, K] with one adapter per C columns
+        N, K, kw = 2 * C, Kc, dict(lora_group_n=C)
+        mk = lambda: dict(W=rnd(N, K, g=g, scale=0.2), Adown=rnd(2 * 16, K, g=g, scale=0.3), Bup=rnd(N, 16, g=g, scale=0.3),
+                          T_out=torch.zeros(M, 32, dtype=BF), C=torch.zeros(M, N, dtype=BF), Ct=torch.zeros(N, M, dtype=BF))
+        X = rnd(M, K, g=g)
+    else:                     # backward: per-problem X = stacked gradients [M, 2C], W^T [N, 2C], one adapter per K group
+        N, K, kw = Kc, 2 * C, dict(lora_group_k=C)
+        mk = lambda: dict(X=rnd(M, K, g=g), W=rnd(N, K, g=g, scale=0.2), Adown=rnd(16, K, g=g, scale=0.3), Bup=rnd(N, 32, g=g, scale=0.3),
+                          T_out=torch.zeros(M, 32, dtype=BF), C=torch.zeros(M, N, dtype=BF))
+        X = None
+    items_c = [mk() for _ in range(nb)]
+    items_g = [{k: v.cuda() for k, v in it.items()} for it in items_c]
+    def run(mod, items, Xs):
+        it0 = items[0]
+        x0 = Xs if Xs is not None else it0["X"]
+        mod.gemm(x0, it0["W"], it0["C"], lora=(it0["Adown"], it0["Bup"], 0.5, it0["T_out"]), Ct=it0.get("Ct"),
+                 batch=mod.GemmBatch(items, x0.device), **kw)
+    run(E, items_c, X)
+    run(ops, items_g, X.cuda() if X is not None else None)
+    for ic, ig in zip(items_c, items_g):
+        close(ig["C"], ic["C"], tol=1.5e-2, what=f"batched {mode} C")
+        close(ig["T_out"], ic["T_out"], tol=1.5e-2, what=f"batched {mode} T")
+        if "Ct" in ic:
+            close(ig["Ct"], ic["Ct"], tol=1.5e-2, what="batched Ct")
+
+
 @pytest.mark.parametrize("Rp,specs,expect_mfma", [
     (64, [(520, 320, 64, True, None), (96, 64, 40, False, None), (2 * 8 * 8, 9 * 64, 64, True, (2, 8, 8, 64))], 1),
     (32, [(333, 128, 24, True, None)], 1),
