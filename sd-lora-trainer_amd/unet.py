@@ -233,16 +233,14 @@ class StackedLinear(_Module):
                     m.lora["Bt_s"] = self.Bt_cat[:, g * N:(g + 1) * N]
                     m.lora["At_s"] = self.At_cat[:, g * Rp:(g + 1) * Rp]
 
-    def forward(self, x, Ct=None):
-        """Returns the member outputs as column slices of one [M, G*N] buffer."""
+    def prepare(self, x):
+        """Allocates the stacked output / T buffers for input x and points the members at their slices (no launch)."""
         M, N, G = x.shape[0], self.N, self.G
         y = self.buf("y", M, G * N)
-        lora = None
+        T = None
         if self.has_lora:
             Rp = self.arena.Rp
             T = self.buf("T", M, G * Rp)
-            lora = (self.A_cat, self.B_cat, self.arena.scale, T)
-        self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, Ct=Ct, lora_group_n=N if self.has_lora else 0)
         outs = []
         for g, m in enumerate(self.members):
             m._x = x
@@ -250,6 +248,13 @@ class StackedLinear(_Module):
             if self.has_lora:
                 m._b["T"] = T[:, g * Rp:(g + 1) * Rp]
             outs.append(m._b["y"])
+        return y, T, outs
+
+    def forward(self, x, Ct=None):
+        """Returns the member outputs as column slices of one [M, G*N] buffer."""
+        y, T, outs = self.prepare(x)
+        lora = (self.A_cat, self.B_cat, self.arena.scale, T) if self.has_lora else None
+        self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, Ct=Ct, lora_group_n=self.N if self.has_lora else 0)
         return outs
 
     def grad_slices(self, M):
@@ -269,6 +274,17 @@ class StackedLinear(_Module):
             self.rt.ops.gemm(dy_cat, self.Wt, dx, residual=dres)
             return dx
         assert self.kgrouped
+        U = self.backward_operands(dy_cat)
+        self.rt.ops.gemm(dy_cat, self.Wt, dx, lora=(self.Bt_cat, self.At_cat, self.arena.scale, U), residual=dres, lora_group_k=N)
+        return dx
+
+    def backward_operands(self, dy_cat):
+        """Transposed stacked weight, U buffer and (once) the members' LoRA-gradient problems for the K-grouped dX GEMM."""
+        M, N, G = dy_cat.shape[0], self.N, self.G
+        if getattr(self, "Wt", None) is None:
+            self.Wt = self.W.t().contiguous()
+            for m in self.members:
+                m.Wt = None
         U = self.buf("U", M, G * 16)
         if not getattr(self, "_registered", False):
             r = self.arena.rank
@@ -277,8 +293,7 @@ class StackedLinear(_Module):
                     dict(P=dy_cat[:, g * N:(g + 1) * N], Q=m._b["T"], out=m.lora["gB"], M=M, Cw=N, R=r, rank_major=False),
                     dict(P=m._x, Q=U[:, g * 16:(g + 1) * 16], out=m.lora["gA"], M=M, Cw=self.K, R=r, rank_major=True)]
             self._registered = True
-        self.rt.ops.gemm(dy_cat, self.Wt, dx, lora=(self.Bt_cat, self.At_cat, self.arena.scale, U), residual=dres, lora_group_k=N)
-        return dx
+        return U
 
 
 class Conv3x3(_Module):
@@ -409,6 +424,7 @@ class Attention(_Module):
         self.heads, self.cross, self.hooked = heads, cross, hooked
         # one GEMM for the projections that share an input: q|k|v of self-attention, k|v of cross-attention
         self.stack = StackedLinear(rt, name + (".to_kv" if cross else ".to_qkv"), [self.to_k, self.to_v] if cross else [self.to_q, self.to_k, self.to_v])
+        self.kv_batched = False
         self.C = self.to_q.N
         self.d = self.C // heads
         self.scale = 1.0 / math.sqrt(self.d)
@@ -424,10 +440,13 @@ class Attention(_Module):
         need_t = self.cross and self.hooked
         if self.cross:
             q = self.to_q.forward(x, Ct=self.buf("Qt", C, Mq) if need_t else None)
-            KVt = self.buf("KVt", 2 * C, _pad_to(Mk, 8)) if need_t else None
-            k, v = self.stack.forward(kv, Ct=KVt)
-            if need_t:
-                self._b["Kt"] = KVt[:C]
+            if self.kv_batched:          # to_k|to_v of every cross-attention layer ran in one batched launch (UNet._cross_kv_forward)
+                k, v = self.to_k._b["y"], self.to_v._b["y"]
+            else:
+                KVt = self.buf("KVt", 2 * C, _pad_to(Mk, 8)) if need_t else None
+                k, v = self.stack.forward(kv, Ct=KVt)
+                if need_t:
+                    self._b["Kt"] = KVt[:C]
         else:
             q, k, v = self.stack.forward(x)
         O = self.buf("O", Mq, C)
@@ -489,7 +508,8 @@ class Attention(_Module):
                             alpha=self.scale)
         if fused and self.cross:
             dx = self.to_q.backward(dq)
-            self.stack.backward(dkv, dres=dctx, out=dctx)      # gradient w.r.t. the text conditioning, accumulated over every cross-attention layer
+            if not self.kv_batched:   # (batched: all layers' dkv go through one launch at the end of UNet.backward)
+                self.stack.backward(dkv, dres=dctx, out=dctx)      # gradient w.r.t. the text conditioning, accumulated over every cross-attention layer
         elif fused:
             dx = self.stack.backward(dqkv)
         else:
@@ -658,6 +678,14 @@ class UNet(_Module):
         if ar is not None:
             ar.finalize()
         self._grad_plan = None
+        # cross-attention to_k|to_v of every layer read the same text conditioning: one batched launch per (width, hooked)
+        # group in forward, and one for all their input gradients in backward (instead of 2 x 70 M = 128 GEMMs)
+        tfs = [t for (_, att, _) in self.down for t in att] + [self.mid[1]] + [t for (_, att, _) in self.up for t in att]
+        self.cross_attns = [blk.attn2 for t in tfs for blk in t.blocks]
+        ok = all(a.stack.has_lora and a.stack.kgrouped for a in self.cross_attns) and len(self.cross_attns) > 1
+        self._kv_groups = None
+        for a in self.cross_attns:
+            a.kv_batched = ok
 
     # ------------------------------------------------------------------------------------ forward
     def forward(self, x, timesteps_f, ctx, pooled=None, time_ids=None, *, B, H, W):
@@ -683,6 +711,7 @@ class UNet(_Module):
         semb = rt.ops.map_bf16(_ops.MAP_SILU, emb, None, self.buf("semb", *emb.shape))
         self._b["semb_in"] = emb
 
+        self._cross_kv_forward(ctx, B)
         h = self.conv_in.forward(x, B, H, W, train=False)
         skips = [(h, H, W)]
         ch, cw = H, W
@@ -761,10 +790,64 @@ class UNet(_Module):
             da1s = self.a2.backward(demb)
             da1 = rt.ops.map_bf16(_ops.MAP_DSILU, self.a1._b["y"], da1s, self.buf("da1", *da1s.shape))
             self.dadd_in = self.a1.backward(da1)
+        self._cross_kv_backward(dctx)
         if self.arena is not None:
             if self._grad_plan is None:
                 self._grad_plan = rt.ops.LoraGradPlan(rt.lora_problems, self.arena.Rp, rt.device)
             self._grad_plan.run()
+
+    # ------------------------------------------------------------------------------------ batched cross-attention K/V
+    def _cross_kv_forward(self, ctx, B):
+        if not self.cross_attns or not self.cross_attns[0].kv_batched:
+            return
+        rt = self.rt
+        if self._kv_groups is None:
+            groups = {}
+            for a in self.cross_attns:
+                groups.setdefault((a.C, a.hooked), []).append(a)
+            self._kv_groups = []
+            Mk = B * CTX_PAD
+            for (C, hooked), members in groups.items():
+                items = []
+                for a in members:
+                    st = a.stack
+                    y, T, _ = st.prepare(ctx)
+                    it = dict(W=st.W, Adown=st.A_cat, Bup=st.B_cat, T_out=T, C=y)
+                    if hooked:      # transposed K for the score side output's backward (see Attention.backward)
+                        KVt = a.buf("KVt", 2 * C, _pad_to(Mk, 8))
+                        a._b["Kt"] = KVt[:C]
+                        it["Ct"] = KVt
+                    items.append(it)
+                self._kv_groups.append((members, items, rt.ops.GemmBatch(items, rt.device)))
+        for members, items, batch in self._kv_groups:
+            st, it = members[0].stack, items[0]
+            rt.ops.gemm(ctx, st.W, it["C"], lora=(st.A_cat, st.B_cat, st.arena.scale, it["T_out"]), Ct=it.get("Ct"),
+                        lora_group_n=st.N, batch=batch)
+
+    def _cross_kv_backward(self, dctx):
+        """dctx += sum over all cross-attention layers of [dk | dv] . [Wk ; Wv] (+ their adapters): one batched K-grouped GEMM
+        per group into fp32 partials, summed once (instead of 70 read-modify-write passes over dctx in bf16)."""
+        if not self.cross_attns or not self.cross_attns[0].kv_batched:
+            return
+        rt = self.rt
+        if getattr(self, "_kv_bwd", None) is None:
+            n = len(self.cross_attns)
+            Mk, D = dctx.shape
+            part = self.buf("dctx_parts", n, Mk, D, dtype=F32)
+            self._kv_bwd, i = [], 0
+            for members, _, _ in self._kv_groups:
+                items = []
+                for a in members:
+                    st = a.stack
+                    dkv, _ = st.grad_slices(Mk)
+                    U = st.backward_operands(dkv)
+                    items.append(dict(X=dkv, W=st.Wt, Adown=st.Bt_cat, Bup=st.At_cat, T_out=U, C=part[i]))
+                    i += 1
+                self._kv_bwd.append((members, items, rt.ops.GemmBatch(items, rt.device)))
+        for members, items, batch in self._kv_bwd:
+            st, it = members[0].stack, items[0]
+            rt.ops.gemm(it["X"], it["W"], it["C"], lora=(it["Adown"], it["Bup"], st.arena.scale, it["T_out"]), lora_group_k=st.N, batch=batch)
+        dctx.add_(self._b["dctx_parts"].sum(0).to(dctx.dtype))
 
     def _add(self, a, b, key):
         return self.rt.ops.add2d(a, b, self.buf(("add",) + key, *a.shape))
