@@ -161,6 +161,8 @@ typedef struct sdlt_attn_params {
   float scale;
   int32_t qsplit;
   int32_t causal;
+  int32_t accumulate_dq;   /* single-pass cross-attention backward only: dQ += result, dK += result (the buffers already hold */
+  int32_t accumulate_dk;   /* the gradient of the score side output, written by one batched GEMM for all hooked layers)    */
 } sdlt_attn_params;
 int sdlt_attn_fwd(const sdlt_attn_params* p, void* stream);
 int sdlt_attn_bwd(const sdlt_attn_params* p, void* stream);

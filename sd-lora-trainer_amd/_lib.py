@@ -64,7 +64,7 @@ class AttnParams(C.Structure):
         ("dQ", vp), ("lddq", i64), ("dK", vp), ("lddk", i64), ("dV", vp), ("lddv", i64),
         ("dK32", vp), ("dV32", vp), ("ld32", i64),
         ("B", i32), ("H", i32), ("Nq", i32), ("Nk", i32), ("Nqp", i32), ("Nkp", i32), ("d", i32),
-        ("scale", f32), ("qsplit", i32), ("causal", i32),
+        ("scale", f32), ("qsplit", i32), ("causal", i32), ("accumulate_dq", i32), ("accumulate_dk", i32),
     ]
 
 

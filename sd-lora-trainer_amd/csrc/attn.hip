@@ -620,10 +620,16 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
         for (int df = 0; df < DP / 16; ++df) {
           int col = df * 16 + g * 4;
           if (col < d) {
+            uint2* dst = (uint2*)((bf16_t*)p.dQ + ((int64_t)b * p.Nqp + q) * p.lddq + hc + col);
+            if (p.accumulate_dq) {    // the buffer already holds the score side output's dQ (batched GEMM before the backward pass)
+              const uint2 old = *dst;
+              dq[df][0] += bf2f(old.x & 0xffff); dq[df][1] += bf2f(old.x >> 16);
+              dq[df][2] += bf2f(old.y & 0xffff); dq[df][3] += bf2f(old.y >> 16);
+            }
             uint2 wv;
             wv.x = pack2bf(dq[df][0], dq[df][1]);
             wv.y = pack2bf(dq[df][2], dq[df][3]);
-            *(uint2*)((bf16_t*)p.dQ + ((int64_t)b * p.Nqp + q) * p.lddq + hc + col) = wv;
+            *dst = wv;
           }
         }
       }
@@ -712,7 +718,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
 
 // out[b*Nkp + key][c] = bf16(sum over splits of slab[split][b*Nkp + key][c]); pad keys [Nk, Nkp) get zeros
 __global__ void attn_splitsum_kernel(const float* s0, const float* s1, int nsplit, int64_t ld32, bf16_t* out0, int64_t ldo0, bf16_t* out1, int64_t ldo1,
-                                     int B, int Nk, int Nkp, int C) {
+                                     int B, int Nk, int Nkp, int C, int acc0) {
   const int nch = C >> 2;
   const int64_t per = (int64_t)B * Nkp * nch, sstride = (int64_t)B * Nkp * ld32;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < 2 * per; t += (int64_t)gridDim.x * blockDim.x) {
@@ -727,9 +733,14 @@ __global__ void attn_splitsum_kernel(const float* s0, const float* s1, int nspli
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
     }
+    uint2* dst = (uint2*)((second ? out1 + r * ldo1 : out0 + r * ldo0) + c);
+    if (acc0 && !second) {   // dK += : the buffer holds the score side output's dK
+      const uint2 old = *dst;
+      acc.x += bf2f(old.x & 0xffff); acc.y += bf2f(old.x >> 16); acc.z += bf2f(old.y & 0xffff); acc.w += bf2f(old.y >> 16);
+    }
     uint2 w;
     w.x = pack2bf(acc.x, acc.y); w.y = pack2bf(acc.z, acc.w);
-    *(uint2*)((second ? out1 + r * ldo1 : out0 + r * ldo0) + c) = w;
+    *dst = w;
   }
 }
 
@@ -837,11 +848,12 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
       int blocks = (int)(((int64_t)krows * C / 2 + 255) / 256);
       if (blocks > 4096) blocks = 4096;
       hipLaunchKernelGGL(attn_splitsum_kernel, dim3(blocks), dim3(256), 0, s, p.dK32, p.dV32, p.qsplit, p.ld32, (bf16_t*)p.dK, p.lddk,
-                         (bf16_t*)p.dV, p.lddv, p.B, p.Nk, p.Nkp, C);
+                         (bf16_t*)p.dV, p.lddv, p.B, p.Nk, p.Nkp, C, p.accumulate_dk);
     }
     SDLT_CHECK_LAUNCH();
     return SDLT_OK;
   }
+  if (p.accumulate_dq || p.accumulate_dk) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_attn_bwd: accumulate_dq/dk exist for the single-pass cross-attention kernel only");
   dim3 gq((p.Nq + 63) / 64, p.H, p.B);
 #define SMEM_DQ(D_) (2 * (2 * 64 * ((D_) * 2 + 16)))
   ATTN_DISPATCH(dp, attn_bwd_dq_kernel, gq, SMEM_DQ)

@@ -760,7 +760,15 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
     const long t128k = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     if (t128k >= 64 || p.tile < 1 || p.tile > 3) p.tile = 1;
   }
-  if (p.batch) {   // batched launches exist for what uses them: plain GEMM mode, rank pad 16, tiles 1..3, deep ring
+  if (p.batch) {   // batched launches exist for what uses them: plain GEMM mode, no LoRA or rank pad 16, tiles 1..3, deep ring
+    if constexpr (MODE == 0 && R16 == 0) {
+      if (p.n_batch < 1 || p.n_batch > 65535) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: n_batch=%d", p.n_batch);
+      switch (p.tile) {
+        case 1: return launch<4, 2, 4, 0, 0, 4, 0, 1>(p, s);
+        case 2: return launch<2, 2, 4, 0, 0, 4, 0, 1>(p, s);
+        case 3: return launch<2, 2, 2, 0, 0, 4, 0, 1>(p, s);
+      }
+    }
     if constexpr (MODE == 0 && R16 == 1) {
       if (p.n_batch < 1 || p.n_batch > 65535) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: n_batch=%d", p.n_batch);
       if (p.lora_group_k > 0) {

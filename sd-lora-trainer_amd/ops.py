@@ -247,7 +247,7 @@ def attn_fwd(Q, K, V, Vt, O, L, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=Fals
 
 
 def attn_bwd(Q, K, V, Kt, Qt, O, L, dO, dOt, D, dQ, dK, dV, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=False,
-             qsplit=1, dK32=None, dV32=None):
+             qsplit=1, dK32=None, dV32=None, accumulate_dq=False, accumulate_dk=False):
     lib = _lib.load()
     p = _attn_params(Q, K, V, B=B, H=H, Nq=Nq, Nk=Nk, Nqp=Nqp, Nkp=Nkp, d=d, scale=scale, causal=causal)
     for t in (O, dO, dQ, dK, dV):      # Kt / Qt / dOt: accepted and ignored (see attn_fwd)
@@ -256,6 +256,7 @@ def attn_bwd(Q, K, V, Kt, Qt, O, L, dO, dOt, D, dQ, dK, dV, *, B, H, Nq, Nk, Nqp
     p.O, p.ldo, p.L, p.dO, p.lddo, p.D = _p(O), _ld(O), _p(L), _p(dO), _ld(dO), _p(D)
     p.dQ, p.lddq, p.dK, p.lddk, p.dV, p.lddv = _p(dQ), _ld(dQ), _p(dK), _ld(dK), _p(dV), _ld(dV)
     p.qsplit = qsplit
+    p.accumulate_dq, p.accumulate_dk = int(accumulate_dq), int(accumulate_dk)
     if qsplit > 1:
         _chk2(dK32, F32), _chk2(dV32, F32)
         if not causal and Nkp <= 128 and d <= 96:   # single-pass cross-attention kernel: one partial slab per query split

@@ -206,6 +206,8 @@ class TrainStep:
         rt.daam_grads = None
         if self.text is not None and self.ta_w > 0.0:  # a10/a11: token-attention loss on the hooked score maps (main.py:342-345)
             self.ta.forward_backward(self.mask, self.w / self.h, self.ta_w * scale)
+        rt.daam_applied = False
+        u.daam_backward()
         self.dctx.zero_()
         u.backward(self.dpred64, self.dctx)
         self._pred = pred

@@ -45,6 +45,7 @@ class Runtime:
         self.daam_grads = None       # N -> (dS bf16 [B*N, CTX_PAD], dS^T bf16 [B*CTX_PAD, N]) set by the token-attention loss
         self.want_dpooled = False    # SDXL: back-propagate into the pooled text embedding (textual inversion)
         self.dsemb = None
+        self.daam_applied = False    # this step's score-gradient GEMMs were issued up front (UNet.daam_backward)
         self._scratch = {}
 
     def scratch(self, key, nfloats):
@@ -425,6 +426,7 @@ class Attention(_Module):
         # one GEMM for the projections that share an input: q|k|v of self-attention, k|v of cross-attention
         self.stack = StackedLinear(rt, name + (".to_kv" if cross else ".to_qkv"), [self.to_k, self.to_v] if cross else [self.to_q, self.to_k, self.to_v])
         self.kv_batched = False
+        self.daam_batched = False
         self.C = self.to_q.N
         self.d = self.C // heads
         self.scale = 1.0 / math.sqrt(self.d)
@@ -495,9 +497,12 @@ class Attention(_Module):
             qs = max(2, min((N + 63) // 64, 160 // max(1, self.heads * B)))
             kv32 = rt.scratch("attn_dkv32", 2 * qs * Mk * C).view(2 * qs * Mk, C)    # partial slabs, consumed inside attn_bwd
             kw = dict(qsplit=qs, dK32=kv32[:qs * Mk], dV32=kv32[qs * Mk:])
+        pre = self.cross and self.hooked and rt.daam_grads is not None and rt.daam_applied and self.daam_batched
+        if pre:     # dq / dk already hold the score side output's gradient (UNet.daam_backward, one batched GEMM per group)
+            kw.update(accumulate_dq=True, accumulate_dk=True)
         rt.ops.attn_bwd(q, k, v, None, None, self._b["O"], self._b["L"], dO, None, D, dq, dk, dv,
                         B=B, H=self.heads, Nq=N, Nk=Nk, Nqp=N, Nkp=Nkp, d=self.d, scale=self.scale, **kw)
-        if self.cross and self.hooked and rt.daam_grads is not None:
+        if self.cross and self.hooked and rt.daam_grads is not None and not pre:
             # backward of the score side output: S = a Q K^T  ->  dQ += a dS K,  dK += a dS^T Q   (shared dS per resolution)
             dS, dSt = rt.daam_grads[N]
             Kt, Qt = self._b["Kt"], self._b["Qt"]
@@ -795,6 +800,42 @@ class UNet(_Module):
             if self._grad_plan is None:
                 self._grad_plan = rt.ops.LoraGradPlan(rt.lora_problems, self.arena.Rp, rt.device)
             self._grad_plan.run()
+
+    # ------------------------------------------------------------------------------------ batched score-gradient GEMMs
+    def daam_backward(self):
+        """Gradient of the token-attention loss w.r.t. Q and K of every hooked cross-attention layer, BEFORE the backward
+        pass: S_l = a Q_l K_l^T with one dS per resolution, so dQ_l = a dS K_l and dK_l = a dS^T Q_l are two batched GEMMs per
+        (resolution, width) group written straight into the layers' dq / dk buffers; the single-pass attention backward
+        then accumulates onto them (120 small launches -> 4 per batch element)."""
+        rt = self.rt
+        rt.daam_applied = False
+        if rt.daam_grads is None or not self.cross_attns:
+            return
+        if getattr(self, "_daam_plan", None) is None:
+            groups = {}
+            for a in self.cross_attns:
+                if a.hooked and a.kv_batched and a.d <= 96 and CTX_PAD <= 128 and "Qt" in a._b:
+                    groups.setdefault((a._dims[1], a.C), []).append(a)
+            plan = []
+            for (N, C), members in groups.items():
+                B, _, Nk, Nkp = members[0]._dims
+                Mq, Mk = B * N, B * Nkp
+                for b in range(B):
+                    iq, ik = [], []
+                    for a in members:
+                        dq = a.buf("dq", Mq, C)
+                        _, (dk, _) = a.stack.grad_slices(Mk)
+                        iq.append(dict(W=a._b["Kt"][:, b * Nkp:(b + 1) * Nkp], C=dq[b * N:(b + 1) * N]))
+                        ik.append(dict(W=a._b["Qt"][:, b * N:(b + 1) * N], C=dk[b * Nkp:(b + 1) * Nkp]))
+                    plan.append((N, b, Nkp, members[0].scale, iq, rt.ops.GemmBatch(iq, rt.device), ik, rt.ops.GemmBatch(ik, rt.device)))
+                for a in members:
+                    a.daam_batched = True
+            self._daam_plan = plan
+        for (N, b, Nkp, scale, iq, bq, ik, bk) in self._daam_plan:
+            dS, dSt = rt.daam_grads[N]
+            rt.ops.gemm(dS[b * N:(b + 1) * N], iq[0]["W"], iq[0]["C"], alpha=scale, batch=bq)
+            rt.ops.gemm(dSt[b * Nkp:(b + 1) * Nkp], ik[0]["W"], ik[0]["C"], alpha=scale, batch=bk)
+        rt.daam_applied = bool(self._daam_plan)
 
     # ------------------------------------------------------------------------------------ batched cross-attention K/V
     def _cross_kv_forward(self, ctx, B):

@@ -145,7 +145,7 @@ def attn_fwd(Q, K, V, Vt, O, L, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=Fals
 
 
 def attn_bwd(Q, K, V, Kt, Qt, O, L, dO, dOt, D, dQ, dK, dV, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=False,
-             qsplit=1, dK32=None, dV32=None):
+             qsplit=1, dK32=None, dV32=None, accumulate_dq=False, accumulate_dk=False):
     C = H * d
     q = _heads(Q[:, :C], B, Nqp, H, d).detach().clone().requires_grad_(True)
     k = _heads(K[:, :C], B, Nkp, H, d).detach().clone().requires_grad_(True)
@@ -155,8 +155,11 @@ def attn_bwd(Q, K, V, Kt, Qt, O, L, dO, dOt, D, dQ, dK, dV, *, B, H, Nq, Nk, Nqp
     go = _heads(dO[:, :C], B, Nqp, H, d).clone()
     go[:, :, Nq:] = 0
     gq, gk, gv = torch.autograd.grad(o, [q, k, v], go)
-    for dst, g, Np in ((dQ, gq, Nqp), (dK, gk, Nkp), (dV, gv, Nkp)):
-        dst[:, :C].copy_(g.permute(0, 2, 1, 3).reshape(B * Np, C).to(dst.dtype))
+    for dst, g, Np, acc in ((dQ, gq, Nqp, accumulate_dq), (dK, gk, Nkp, accumulate_dk), (dV, gv, Nkp, False)):
+        val = g.permute(0, 2, 1, 3).reshape(B * Np, C)
+        if acc:
+            val = val + dst[:, :C].float()
+        dst[:, :C].copy_(val.to(dst.dtype))
 
 
 def _gn_cat(x1, x2):

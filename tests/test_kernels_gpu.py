@@ -307,6 +307,7 @@ ATTN_CASES = [
     dict(B=2, H=3, Nq=192, Nk=77, Nkp=80, d=64, causal=False, qsplit=1),
     dict(B=2, H=3, Nq=200, Nk=77, Nkp=128, d=80, causal=False, qsplit=3),
     dict(B=1, H=2, Nq=64, Nk=40, Nkp=40, d=40, causal=False, qsplit=2),
+    dict(B=2, H=4, Nq=320, Nk=77, Nkp=128, d=64, causal=False, qsplit=3, accumulate=True),
     dict(B=1, H=8, Nq=256, Nk=256, Nkp=256, d=40, causal=False, qsplit=1),
     dict(B=1, H=2, Nq=128, Nk=128, Nkp=128, d=160, causal=False, qsplit=1),
     dict(B=1, H=4, Nq=128, Nk=128, Nkp=128, d=80, causal=False, qsplit=1),
@@ -330,7 +331,11 @@ def test_attention_fwd_bwd(ops, c):
     O_ref, L_ref = torch.zeros(B * Nqp, C, dtype=BF), torch.zeros(B * H * Nq)
     E.attn_fwd(Q, K, V, V.t().contiguous(), O_ref, L_ref, **kw)
     dQr, dKr, dVr = torch.zeros_like(Q), torch.zeros_like(K), torch.zeros_like(V)
-    E.attn_bwd(Q, K, V, K.t().contiguous(), Q.t().contiguous(), O_ref, L_ref, dO, dO.t().contiguous(), None, dQr, dKr, dVr, **kw)
+    acc = dict(accumulate_dq=True, accumulate_dk=True) if c.get("accumulate") else {}
+    if acc:   # the buffers already hold a gradient (the score side output's): the kernel adds to dQ and dK, overwrites dV
+        dQr, dKr = rnd(*Q.shape, g=g).clone(), rnd(*K.shape, g=g).clone()
+        dQ0, dK0 = dQr.clone(), dKr.clone()
+    E.attn_bwd(Q, K, V, K.t().contiguous(), Q.t().contiguous(), O_ref, L_ref, dO, dO.t().contiguous(), None, dQr, dKr, dVr, **kw, **acc)
 
     Qd, Kd, Vd, dOd = dev(Q, K, V, dO)
     Kt, Vt, Qt, dOt = Kd.t().contiguous(), Vd.t().contiguous(), Qd.t().contiguous(), dOd.t().contiguous()
@@ -343,12 +348,14 @@ def test_attention_fwd_bwd(ops, c):
     close(O.cpu() * vq, O_ref * vq, what=f"attn fwd {c}")
     close(L, L_ref, tol=2e-3, what="attn lse")
     dQ, dK, dV = (torch.full_like(t, 5.0) for t in (Qd, Kd, Vd))
+    if acc:
+        dQ, dK = dQ0.cuda(), dK0.cuda()
     D = torch.zeros(B * H * Nq, device="cuda")
     extra = {}
     if c["qsplit"] > 1:
         ns = c["qsplit"]   # the single-pass cross-attention kernel wants one partial slab per query split
         extra = dict(qsplit=ns, dK32=torch.full((ns * B * Nkp, C), float("nan"), device="cuda"), dV32=torch.full((ns * B * Nkp, C), float("nan"), device="cuda"))
-    ops.attn_bwd(Qd, Kd, Vd, Kt, Qt, O, L, dOd, dOt, D, dQ, dK, dV, **kw, **extra)
+    ops.attn_bwd(Qd, Kd, Vd, Kt, Qt, O, L, dOd, dOt, D, dQ, dK, dV, **kw, **extra, **acc)
     close(dQ.cpu() * vq, dQr * vq, tol=2.5e-2, what=f"attn dQ {c}")
     close(dK, dKr, tol=2.5e-2, what=f"attn dK {c}")
     close(dV, dVr, tol=2.5e-2, what=f"attn dV {c}")
