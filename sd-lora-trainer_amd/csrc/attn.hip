@@ -196,11 +196,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const sdlt_attn_params p)
 }
 
 // =============================================================================== backward dQ (per 64-query tile)
-template <int DP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const sdlt_attn_params p) {
+template <int DP, bool WRITE_D>
+__device__ __forceinline__ void attn_bwd_dq_body(const sdlt_attn_params& p, char* smem, const int bx) {
   constexpr int NSTR = DP * 2 + 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = bx * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
   const int d = p.d, hc = h * d;
   const int q = q0 + wave * 16 + i;
@@ -225,7 +224,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const sdlt_attn_params
   }
   Dq += __shfl_xor(Dq, 16, 64);
   Dq += __shfl_xor(Dq, 32, 64);
-  if (g == 0 && qok) p.D[((int64_t)b * p.H + h) * p.Nq + q] = Dq;
+  if (WRITE_D && g == 0 && qok) p.D[((int64_t)b * p.H + h) * p.Nq + q] = Dq;   // (merged launch: written by attn_prep_kernel instead)
   f32x4 dq[DP / 16];
 #pragma unroll
   for (int df = 0; df < DP / 16; ++df) dq[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -322,11 +321,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const sdlt_attn_params
 
 // =============================================================================== backward dK,dV (per 64-key tile, optional query split)
 template <int DP>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const sdlt_attn_params p) {
+__device__ __forceinline__ void attn_bwd_dkdv_body(const sdlt_attn_params& p, char* smem, const int bx) {
   constexpr int NSTR = DP * 2 + 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.z, h = blockIdx.y;
-  const int ktile = blockIdx.x / p.qsplit, split = blockIdx.x - ktile * p.qsplit;
+  const int ktile = bx / p.qsplit, split = bx - ktile * p.qsplit;
   const int k0 = ktile * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
   const int d = p.d, hc = h * d;
@@ -473,6 +471,52 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const sdlt_attn_para
         }
       }
     }
+  }
+}
+
+// =============================================================================== backward launch forms
+template <int DP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const sdlt_attn_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  attn_bwd_dq_body<DP, true>(p, smem, blockIdx.x);
+}
+template <int DP>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const sdlt_attn_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  attn_bwd_dkdv_body<DP>(p, smem, blockIdx.x);
+}
+// Self-attention: the dQ tiles and the dK/dV tiles of one layer in ONE launch (blockIdx.x < #query tiles: dQ role).  At
+// 1024 tokens x 20 heads either pass alone is 320 workgroups of 16 dependent steps - latency-bound, the chip half empty;
+// together they overlap.  The dK/dV role needs D of every query row, so D comes from attn_prep_kernel here.
+template <int DP>
+__global__ __launch_bounds__(256) void attn_bwd_both_kernel(const sdlt_attn_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ndq = (p.Nq + 63) / 64;
+  if ((int)blockIdx.x < ndq) attn_bwd_dq_body<DP, false>(p, smem, blockIdx.x);
+  else attn_bwd_dkdv_body<DP>(p, smem, blockIdx.x - ndq);
+}
+// D[b,h,q] = sum_d dO*O (8 lanes per (row, head))
+__global__ void attn_prep_kernel(const bf16_t* O, int64_t ldo, const bf16_t* dO, int64_t lddo, int B, int H, int Nq, int Nqp, int d, float* D) {
+  const int64_t total = (int64_t)B * Nqp * H;
+  const int sub = threadIdx.x & 7;
+  for (int64_t idx = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 3; idx < total; idx += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+    int h = idx % H;
+    int64_t row = idx / H;  // b*Nqp + q
+    const int b = row / Nqp, q = row - (int64_t)b * Nqp;
+    if (q >= Nq) continue;   // uniform within the 8-lane group
+    float acc = 0.f;
+    for (int c = sub * 8; c < d; c += 64) {
+      uint4 a = *(const uint4*)(O + row * ldo + h * d + c);
+      uint4 g = *(const uint4*)(dO + row * lddo + h * d + c);
+      const uint32_t* ap = (const uint32_t*)&a;
+      const uint32_t* gp = (const uint32_t*)&g;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc += bf2f(ap[j] & 0xffff) * bf2f(gp[j] & 0xffff) + bf2f(ap[j] >> 16) * bf2f(gp[j] >> 16);
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (sub == 0) D[((int64_t)b * H + h) * Nq + q] = acc;
   }
 }
 
@@ -850,6 +894,19 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
       hipLaunchKernelGGL(attn_splitsum_kernel, dim3(blocks), dim3(256), 0, s, p.dK32, p.dV32, p.qsplit, p.ld32, (bf16_t*)p.dK, p.lddk,
                          (bf16_t*)p.dV, p.lddv, p.B, p.Nk, p.Nkp, C, p.accumulate_dk);
     }
+    SDLT_CHECK_LAUNCH();
+    return SDLT_OK;
+  }
+  if (p.qsplit == 1 && !p.accumulate_dq && !p.accumulate_dk &&
+      (int64_t)((p.Nq + 63) / 64 + (p.Nk + 63) / 64) * p.H * p.B <= 2048) {   // (bigger grids are throughput-bound: two launches are 5 % faster there)
+    // self-attention (UNet, text encoders): D, then dQ and dK/dV tiles in one launch (see attn_bwd_both_kernel)
+    int64_t groups = (int64_t)p.B * p.Nqp * p.H;
+    int blocks = (int)((groups * 8 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(attn_prep_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)p.O, p.ldo, (const bf16_t*)p.dO, p.lddo, p.B, p.H, p.Nq, p.Nqp, p.d, p.D);
+    dim3 gb((p.Nq + 63) / 64 + (p.Nk + 63) / 64, p.H, p.B);
+#define SMEM_BOTH(D_) (2 * (2 * 64 * ((D_) * 2 + 16) + 512))
+    ATTN_DISPATCH(dp, attn_bwd_both_kernel, gb, SMEM_BOTH)
     SDLT_CHECK_LAUNCH();
     return SDLT_OK;
   }
