@@ -226,6 +226,18 @@ int sdlt_masked_mse_fwd_bwd(const float* pred, int64_t ldp, const float* noise, 
  * lr, beta1, beta2, eps, weight_decay, 1-beta1^t, 1-beta2^t, l1 coefficient, grad scale.  l1_sum (optional) <- sum|p|. */
 int sdlt_adamw_fused(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float* l1_sum, void* stream);
 
+/* One Prodigy step over a flat fp32 arena (third-party prodigyopt==1.0, selected by `unet_optimizer_type` / `ti_optimizer`
+ * = "prodigy": trainer/optimizer.py:24-34 and :135-145; effective-lr read-out trainer/optimizer.py:206-234), with the L1
+ * penalty of main.py:353-356 folded in as a subgradient like sdlt_adamw_fused.  All state stays on the device:
+ *   p0 = parameters at the first step, m/v = exp_avg / exp_avg_sq, s = the Prodigy direction estimate   (fp32 [n] each)
+ *   hyper (fp32[13]): lr, beta1, beta2, beta3, eps, weight_decay, d_coef, growth_rate, l1 coefficient, grad scale,
+ *                     use_bias_correction, safeguard_warmup, decouple (flags as 0/1)
+ *   state (fp32[9]):  d, d0, d_max, d_numerator, d_denom, d_hat, k, dlr of this step, 1 if the step was applied
+ *   acc   (fp64[2]):  scratch for the two global sums (<g, p0 - p> and sum|s|)
+ * A step with lr == 0 or all-zero gradients changes nothing (the reference returns before updating any state). */
+int sdlt_prodigy_step(float* p, const float* g, const float* p0, float* m, float* v, float* s, int64_t n,
+                      const float* hyper, float* state, double* acc, float* l1_sum, void* stream);
+
 /* bf16 compute copies of the fp32 LoRA arena, in both orientations (dst [rows, ld], dstT [cols, ldT]). */
 typedef struct sdlt_shadow_desc {
   int64_t offset;      /* element offset of the tensor in the fp32 arena */

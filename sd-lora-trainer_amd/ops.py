@@ -383,6 +383,23 @@ def adamw_fused(p, g, m, v, hyper, l1_sum=None):
     _lib.check(lib.sdlt_adamw_fused(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _p(l1_sum), _stream()), "sdlt_adamw_fused")
 
 
+PRODIGY_HYPER = ("lr", "beta1", "beta2", "beta3", "eps", "weight_decay", "d_coef", "growth_rate", "l1_coef", "grad_scale",
+                 "use_bias_correction", "safeguard_warmup", "decouple")
+PRODIGY_STATE = ("d", "d0", "d_max", "d_numerator", "d_denom", "d_hat", "k", "dlr", "active")
+
+
+def prodigy_step(p, g, p0, m, v, s, hyper, state, acc, l1_sum=None):
+    """One prodigyopt-1.0 step on a flat fp32 arena; hyper / state are device fp32 rows laid out as PRODIGY_HYPER /
+    PRODIGY_STATE, acc is a device fp64[2] scratch (include/sdlt_kernels.h: sdlt_prodigy_step)."""
+    lib = _lib.load()
+    for t in (p, g, p0, m, v, s, hyper, state):
+        _chk2(t, F32)
+        assert t.is_contiguous()
+    assert acc.dtype == torch.float64 and acc.numel() >= 2 and hyper.numel() >= len(PRODIGY_HYPER) and state.numel() >= len(PRODIGY_STATE)
+    _lib.check(lib.sdlt_prodigy_step(_p(p), _p(g), _p(p0), _p(m), _p(v), _p(s), p.numel(), _p(hyper), _p(state), _p(acc),
+                                     _p(l1_sum), _stream()), "sdlt_prodigy_step")
+
+
 class ShadowPlan:
     """Descriptor table for sdlt_lora_shadow_refresh: fp32 arena tensors -> bf16 compute copies."""
 

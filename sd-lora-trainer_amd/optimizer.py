@@ -3,7 +3,8 @@ objects with a mutable `.param_groups[0]['lr']`, `.step()` and `.zero_grad()`.
 
 In the reference each is a torch.optim.AdamW; here both are views onto the fused device-side AdamW of `step.TrainStep`
 (sdlt_adamw_fused): main.py-style code writes the learning rates into `param_groups`, `OptimizerCollection.step()`
-hands them to the captured step.  Gradients are overwritten every step, so `zero_grad` is a no-op kept for the interface."""
+hands them to the captured step.  Gradients are overwritten every step, so `zero_grad` is a no-op kept for the interface.
+`unet_optimizer_type` / `ti_optimizer` = "prodigy" select the device-side Prodigy step (sdlt_prodigy_step) instead."""
 
 
 class _FusedAdamWHandle:
@@ -15,16 +16,50 @@ class _FusedAdamWHandle:
         pass
 
 
+class _FusedProdigyHandle:
+    """Prodigy group (prodigyopt 1.0 as built at trainer/optimizer.py:24-34 / 135-145) backed by step.ProdigyState.
+    `param_groups[0]` carries the keys `get_current_lr` reads (d, k, betas, use_bias_correction, optimizer.py:214-223);
+    d and k live on the device and are pulled by `sync()`."""
+
+    def __init__(self, name, state, lr, weight_decay):
+        self.name, self.state = name, state
+        self.param_groups = [dict(state.group(lr), weight_decay=weight_decay)]
+
+    def sync(self):
+        self.param_groups[0].update(self.state.group(self.param_groups[0]["lr"]))
+
+    def zero_grad(self):
+        pass
+
+
+def get_current_lr(optimizer):
+    """trainer/optimizer.py:206-234: the effective step size d * lr * bias_correction of a Prodigy group, the plain lr of
+    anything else."""
+    g = optimizer.param_groups[0]
+    if "d" not in g:
+        return g["lr"]
+    optimizer.sync()
+    bc = 1.0
+    if g["use_bias_correction"]:
+        b1, b2 = g["betas"]
+        bc = ((1 - b2 ** (g["k"] + 1)) ** 0.5) / (1 - b1 ** (g["k"] + 1))
+    return g["d"] * g["lr"] * bc
+
+
 class OptimizerCollection:
     """order of the reference: textual inversion, text-encoder LoRA (not supported: off by default, config.py:115), unet."""
 
     def __init__(self, train_step, config):
         self.ts = train_step
         self.optimizers = {
-            "textual_inversion": _FusedAdamWHandle("ti", config.ti_lr, config.ti_weight_decay) if train_step.ti is not None else None,
+            "textual_inversion": None,
             "text_encoders": None,
-            "unet": _FusedAdamWHandle("unet", 1e-4, config.lora_weight_decay),
+            "unet": _FusedAdamWHandle("unet", 1e-4, config.lora_weight_decay) if train_step.prodigy is None
+            else _FusedProdigyHandle("unet", train_step.prodigy, 1.0, config.lora_weight_decay),
         }
+        if train_step.ti is not None:
+            self.optimizers["textual_inversion"] = _FusedAdamWHandle("ti", config.ti_lr, config.ti_weight_decay) \
+                if train_step.prodigy_ti is None else _FusedProdigyHandle("ti", train_step.prodigy_ti, 1.0, config.ti_weight_decay)
         self.learning_rate_tracker = {k: [] for k, v in self.optimizers.items() if v is not None}
 
     def step(self):

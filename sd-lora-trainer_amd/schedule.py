@@ -17,12 +17,16 @@ def completion_fraction(epoch, step_in_epoch, steps_per_epoch, num_train_epochs)
 
 def learning_rates(config, global_step, completion_f, ti_active=True, text_lora_active=False):
     """-> dict(unet=..., textual_inversion=..., text_encoders=...) exactly as main.py:268-291 writes them into
-    param_groups[0]['lr'] (ti_optimizer == 'prodigy' leaves the TI lr untouched there; not supported here)."""
+    param_groups[0]['lr'].  With ti_optimizer == 'prodigy' the loop leaves the TI lr untouched (main.py:269), i.e. at the
+    1.0 the optimizer was built with (optimizer.py:130,137) - no decay and no freeze."""
     out = {}
     if ti_active:
-        lr_ti = config.ti_lr * (1 - completion_f) ** 1.7
-        if completion_f > config.freeze_ti_after_completion_f:
-            lr_ti = 0.0
+        if config.ti_optimizer == "prodigy":
+            lr_ti = 1.0
+        else:
+            lr_ti = config.ti_lr * (1 - completion_f) ** 1.7
+            if completion_f > config.freeze_ti_after_completion_f:
+                lr_ti = 0.0
         out["textual_inversion"] = lr_ti
     if text_lora_active:
         lr = config.text_encoder_lora_lr * (1 - completion_f) ** 2.0

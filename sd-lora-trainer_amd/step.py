@@ -96,10 +96,54 @@ def ddpm_alphas_cumprod(n=1000, beta_start=0.00085, beta_end=0.012):
     return torch.cumprod(1.0 - betas, dim=0)
 
 
+class ProdigyState:
+    """Device-resident state of ONE Prodigy parameter group over a flat fp32 arena (sdlt_prodigy_step): p0, s and the
+    scalars d, d_max, d_numerator, k.  Constructor values are the ones the reference passes (trainer/optimizer.py:24-34,
+    135-145): betas (0.9, 0.99), decoupled decay, bias correction and safeguard warm-up on, d0 = 1e-6, eps = 1e-8."""
+
+    def __init__(self, rt, params, *, d_coef=1.0, growth_rate=float("inf"), weight_decay=0.0, betas=(0.9, 0.99), eps=1e-8, d0=1e-6):
+        self.rt, self.params = rt, params
+        self.p0, self.s = torch.zeros_like(params), torch.zeros_like(params)
+        self.state = rt.zeros(16, dtype=F32)
+        self.acc = torch.zeros(2, dtype=torch.float64, device=params.device)
+        self.d0, self.betas = d0, betas
+        self.const = [betas[0], betas[1], math.sqrt(betas[1]), eps, weight_decay, d_coef, growth_rate]
+        self.reset()
+
+    def reset(self):
+        """Back to step 0; p0 is taken from the parameters when the first step is queued."""
+        self.s.zero_()
+        self.state.zero_()
+        self.state[:3] = self.d0
+        self.started = False
+
+    def before_run(self):
+        if not self.started:
+            self.p0.copy_(self.params)
+            self.started = True
+
+    def hyper_row(self, lr, l1_coef):
+        return [lr, *self.const, l1_coef, 1.0, 1.0, 1.0, 1.0]
+
+    def step(self, grads, m, v, hyper, l1_sum):
+        self.rt.ops.prodigy_step(self.params, grads, self.p0, m, v, self.s, hyper, self.state, self.acc, l1_sum)
+
+    def group(self, lr):
+        """The keys `get_current_lr` reads from a Prodigy param group (trainer/optimizer.py:206-234); one device sync."""
+        st = self.state.tolist()
+        return dict(d=st[0], d0=st[1], d_max=st[2], d_numerator=st[3], d_denom=st[4], d_hat=st[5], k=int(st[6]), lr=lr,
+                    betas=self.betas, use_bias_correction=True)
+
+
 class TrainStep:
     def __init__(self, rt: Runtime, unet: UNet, *, latent_hw, snr_gamma=5.0, v_prediction=False, l1_penalty=0.03,
                  weight_decay=0.004, grad_accum=1, betas=(0.9, 0.999), eps=1e-8, text: TextStack = None, n_tokens=3,
-                 token_attention_loss_w=3e-7, ti_weight_decay=0.0, ti_std_loss_w=0.01):
+                 token_attention_loss_w=3e-7, ti_weight_decay=0.0, ti_std_loss_w=0.01, optimizer="adamw", ti_optimizer="adamw",
+                 prodigy_d_coef=1.0, prodigy_growth_rate=1.05):
+        if optimizer not in ("adamw", "prodigy"):      # AdamW8bit (bitsandbytes) belongs to the full fine-tune, not built
+            raise NotImplementedError(f"Invalid optimizer_name for unet: {optimizer}")
+        if ti_optimizer not in ("adamw", "prodigy"):
+            raise NotImplementedError(f"Invalid optimizer_name: '{ti_optimizer}'")
         self.rt, self.unet = rt, unet
         self.text, self.ta_w, self.ti_wd = text, token_attention_loss_w, ti_weight_decay
         self.ti = TiState(rt, text.encoders, n_tokens, ti_std_loss_w) if text is not None else None
@@ -129,6 +173,12 @@ class TrainStep:
         self.hyper = z(16)
         self.opt_step = 0
         self.graph, self.graphs, self.graphs_frozen = None, [], None
+        # optional Prodigy groups (trainer/optimizer.py:24-34: growth_rate = unet_prodigy_growth_factor, d_coef = prodigy_d_coef;
+        # :135-145 for the token rows: d_coef 1, unbounded growth)
+        self.prodigy = ProdigyState(rt, unet.arena.params, d_coef=prodigy_d_coef, growth_rate=prodigy_growth_rate,
+                                    weight_decay=weight_decay) if optimizer == "prodigy" else None
+        self.prodigy_ti = ProdigyState(rt, self.ti.params, weight_decay=ti_weight_decay) \
+            if (self.ti is not None and ti_optimizer == "prodigy") else None
 
     # -------------------------------------------------------------------------------- inputs
     def set_batch(self, latent, noise, timesteps, mask, ctx=None, pooled=None, time_ids=None, ids=None, caption_token_lists=None):
@@ -161,9 +211,14 @@ class TrainStep:
         b1, b2 = self.betas
         n = self.unet.arena.n
         bc = [1.0 - b1 ** self.opt_step, 1.0 - b2 ** self.opt_step]
-        rows = [[lr, b1, b2, self.eps, self.wd, *bc, self.l1_penalty / n, 1.0]]
+        rows = [[lr, b1, b2, self.eps, self.wd, *bc, self.l1_penalty / n, 1.0] if self.prodigy is None
+                else self.prodigy.hyper_row(lr, self.l1_penalty / n)]
         if self.ti is not None:
-            rows.append([lr_ti, b1, b2, self.eps, self.ti_wd, *bc, 0.0, 1.0])
+            rows.append([lr_ti, b1, b2, self.eps, self.ti_wd, *bc, 0.0, 1.0] if self.prodigy_ti is None
+                        else self.prodigy_ti.hyper_row(lr_ti, 0.0))
+        for pr in (self.prodigy, self.prodigy_ti):
+            if pr is not None:
+                pr.before_run()
         cuda = self.hyper.is_cuda
         if cuda and getattr(self, "_hyper_ring", None) is None:
             self._hyper_ring = torch.zeros(64, 2, 16, dtype=torch.float32).pin_memory()
@@ -225,13 +280,22 @@ class TrainStep:
         self._phase_text_bwd()
         return self._pred
 
-    def optimizer_step(self):
+    def _unet_optimizer(self):
         a = self.unet.arena
-        self.rt.ops.adamw_fused(a.params, a.grads, a.m, a.v, self.hyper, self.l1_sum)
+        if self.prodigy is not None:
+            self.prodigy.step(a.grads, a.m, a.v, self.hyper, self.l1_sum)
+        else:
+            self.rt.ops.adamw_fused(a.params, a.grads, a.m, a.v, self.hyper, self.l1_sum)
         a.refresh_shadows()
-        if self.ti is not None:                        # a17: AdamW on the trainable token rows only
+
+    def optimizer_step(self):
+        self._unet_optimizer()
+        if self.ti is not None:                        # a17: the trainable token rows only
             t = self.ti
-            self.rt.ops.adamw_fused(t.params, t.grads, t.m, t.v, t.hyper, None)
+            if self.prodigy_ti is not None:
+                self.prodigy_ti.step(t.grads, t.m, t.v, t.hyper, None)
+            else:
+                self.rt.ops.adamw_fused(t.params, t.grads, t.m, t.v, t.hyper, None)
             t.refresh_tables()
 
     def body(self):
@@ -247,9 +311,7 @@ class TrainStep:
         """Last phase once the token embeddings are frozen (ti lr == 0, main.py:273-274): the reference still back-propagates
         through both text encoders and runs AdamW with lr 0 on the tables; with lr == 0 that changes no parameter (decoupled
         decay is lr * wd) and the regulariser is skipped (main.py:358), so only the LoRA optimiser remains."""
-        a = self.unet.arena
-        self.rt.ops.adamw_fused(a.params, a.grads, a.m, a.v, self.hyper, self.l1_sum)
-        a.refresh_shadows()
+        self._unet_optimizer()
 
     def grad_norm(self):
         """Global L2 norm of the LoRA gradients, the reference's debug read-out (loss.py:108-125, main.py:373-379)."""
@@ -299,11 +361,14 @@ class TrainStep:
         a.refresh_shadows()
         if self.ti is not None:
             self.ti.refresh_tables()
+        for pr in (self.prodigy, self.prodigy_ti):
+            if pr is not None:
+                pr.reset()
         self.opt_step = step0
 
     def run(self, lr, lr_ti=0.0):
         self.set_hyper(lr, lr_ti)
-        frozen = self.text is not None and lr_ti == 0.0
+        frozen = self.text is not None and lr_ti == 0.0     # (Prodigy with lr 0 is a no-op as well: sdlt_prodigy_step)
         self._frozen_last = frozen
         if self.graph is not None:
             for g in (self.graphs_frozen if frozen else self.graphs):

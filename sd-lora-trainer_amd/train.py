@@ -113,7 +113,9 @@ def train(config: TrainingConfig, runtime=None):
 
     ts = S.TrainStep(rt, unet, latent_hw=(h, w), snr_gamma=config.snr_gamma, l1_penalty=config.l1_penalty, weight_decay=config.lora_weight_decay,
                      grad_accum=config.gradient_accumulation_steps, text=text, n_tokens=config.n_tokens,
-                     token_attention_loss_w=config.token_attention_loss_w, ti_weight_decay=config.ti_weight_decay)
+                     token_attention_loss_w=config.token_attention_loss_w, ti_weight_decay=config.ti_weight_decay,
+                     optimizer=config.unet_optimizer_type, ti_optimizer=config.ti_optimizer,
+                     prodigy_d_coef=config.prodigy_d_coef, prodigy_growth_rate=config.unet_prodigy_growth_factor)
     handler = None
     if text is not None:
         handler = TokenEmbeddingsHandler(ts.ti, config.inserting_list_tokens)

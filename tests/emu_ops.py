@@ -286,6 +286,50 @@ def adamw_fused(p, g, m, v, hyper, l1_sum=None):
     p.mul_(1 - lr * wd).addcdiv_(m, v.sqrt() / math.sqrt(bc2) + eps, value=-lr / bc1)
 
 
+PRODIGY_HYPER = ("lr", "beta1", "beta2", "beta3", "eps", "weight_decay", "d_coef", "growth_rate", "l1_coef", "grad_scale",
+                 "use_bias_correction", "safeguard_warmup", "decouple")
+PRODIGY_STATE = ("d", "d0", "d_max", "d_numerator", "d_denom", "d_hat", "k", "dlr", "active")
+
+
+def prodigy_step(p, g, p0, m, v, s, hyper, state, acc, l1_sum=None):
+    """sdlt_prodigy_step in torch (fp32 tensors, fp64 sums): the same four stages as csrc/optim.hip."""
+    h = dict(zip(PRODIGY_HYPER, [float(x) for x in hyper[:len(PRODIGY_HYPER)]]))
+    st = dict(zip(PRODIGY_STATE, [float(x) for x in state[:len(PRODIGY_STATE)]]))
+    f32 = lambda x: float(torch.tensor(x, dtype=torch.float32))  # noqa: E731
+    bc = 1.0
+    if h["use_bias_correction"]:
+        bc = f32(math.sqrt(f32(1 - f32(h["beta2"] ** (st["k"] + 1)))) / f32(1 - f32(h["beta1"] ** (st["k"] + 1))))
+    d, d0, dlr = st["d"], st["d0"], f32(f32(st["d"] * h["lr"]) * bc)
+    if l1_sum is not None:
+        l1_sum.fill_(float(p.abs().sum()))
+    dot = den = 0.0
+    if h["lr"] > 0:
+        gi = g * h["grad_scale"] + h["l1_coef"] * torch.sign(p)
+        if not h["decouple"] and h["weight_decay"] != 0:
+            gi = gi + h["weight_decay"] * p
+        dot = float((gi.double() * (p0 - p).double()).sum())
+        m.mul_(h["beta1"]).add_(gi, alpha=f32(d * f32(1 - h["beta1"])))
+        v.mul_(h["beta2"]).addcmul_(gi, gi, value=f32(f32(d * d) * f32(1 - h["beta2"])))
+        s.mul_(h["beta3"]).add_(gi, alpha=f32(f32(d / d0) * (d if h["safeguard_warmup"] else dlr)))
+        den = float(s.abs().double().sum())
+    state[PRODIGY_STATE.index("dlr")] = dlr
+    if den == 0.0:
+        state[PRODIGY_STATE.index("active")] = 0.0
+        return
+    num = st["d_numerator"] * h["beta3"] + f32(d / d0) * dlr * dot
+    d_hat, d_max = d, st["d_max"]
+    if h["lr"] > 0:
+        d_hat = f32(h["d_coef"] * num / den)
+        if d == d0:
+            d = max(d, d_hat)
+        d_max = max(d_max, d_hat)
+        d = min(d_max, f32(d * h["growth_rate"]))
+    for k_, val in (("d_numerator", num), ("d_denom", den), ("d", d), ("d_max", d_max), ("d_hat", d_hat), ("k", st["k"] + 1), ("active", 1.0)):
+        state[PRODIGY_STATE.index(k_)] = val
+    decay = 1.0 - h["weight_decay"] * dlr if h["decouple"] else 1.0
+    p.mul_(decay).addcdiv_(m, v.sqrt() + f32(d * h["eps"]), value=-dlr)
+
+
 class ShadowPlan:
     def __init__(self, entries, device):
         self.entries = entries

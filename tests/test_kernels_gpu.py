@@ -447,6 +447,44 @@ def test_add_noise_and_masked_mse(ops, B, gamma, vpred):
     close(dp, dp_e, tol=1e-2, what="masked mse grad")
 
 
+@pytest.mark.parametrize("n,wd,growth,l1", [(100_003, 0.004, 1.05, 0.03), (3 * 2048, 0.0, float("inf"), 0.0), (3_000_001, 0.004, 1.02, 0.0)])
+def test_prodigy_step_vs_oracle(ops, n, wd, growth, l1):
+    """sdlt_prodigy_step (four launches, scalars on the device) against oracle/prodigy_ref.py as the reference builds it
+    (optimizer.py:24-34: betas (0.9, 0.99), bias correction, safeguard warm-up, decoupled decay), 10 steps with a
+    consistent gradient field so that d really adapts, one lr == 0 step in the middle (must be a no-op)."""
+    import math
+    from oracle import prodigy_ref as P
+    g = torch.Generator().manual_seed(11)
+    p_init = torch.randn(n, generator=g) * 0.1
+    target = torch.randn(n, generator=g) * 0.1
+    opt = P.Prodigy([p_init.clone()], lr=1.0, betas=(0.9, 0.99), decouple=True, use_bias_correction=True, safeguard_warmup=True,
+                    weight_decay=wd, growth_rate=growth, d_coef=1.0)
+    pd, p0d, md, vd, sd = dev(p_init.clone(), p_init.clone(), torch.zeros(n), torch.zeros(n), torch.zeros(n))
+    state = torch.zeros(16)
+    state[:3] = 1e-6
+    state, acc, l1s = state.cuda(), torch.zeros(2, dtype=torch.float64, device="cuda"), torch.zeros(1, device="cuda")
+    for i in range(10):
+        lr = 0.0 if i == 5 else 1.0
+        gr = (opt.params[0] - target) + 0.05 * torch.randn(n, generator=g)
+        opt.param_groups[0]["lr"] = lr
+        before = pd.clone()
+        opt.step([gr + l1 / n * torch.sign(opt.params[0])])
+        hyper = torch.tensor([lr, 0.9, 0.99, math.sqrt(0.99), 1e-8, wd, 1.0, growth, l1 / n, 1.0, 1.0, 1.0, 1.0, 0, 0, 0])
+        ops.prodigy_step(pd, gr.cuda(), p0d, md, vd, sd, hyper.cuda(), state, acc, l1s)
+        if i == 5:
+            assert torch.equal(pd, before) and float(state[8]) == 0.0
+    st = state.tolist()
+    grp = opt.param_groups[0]
+    assert grp["d"] > 1.1e-6, "the test field must make d grow"
+    assert abs(st[0] - grp["d"]) <= 1e-3 * grp["d"], (st[0], grp["d"])
+    assert int(st[6]) == grp["k"] == 9
+    assert abs(st[3] - grp["d_numerator"]) <= 1e-3 * abs(grp["d_numerator"])
+    d = (pd.cpu() - opt.params[0]).abs().max()
+    moved = (opt.params[0] - p_init).abs().max()
+    assert float(d) <= 2e-3 * float(moved), (float(d), float(moved))
+    close(l1s, opt.params[0].abs().sum().reshape(1), tol=2e-2, what="l1 sum")
+
+
 def test_adamw_and_shadows(ops):
     g = torch.Generator().manual_seed(9)
     n = 100_003

@@ -106,6 +106,38 @@ def test_step_matches_fp32_oracle(version, B, gamma, rank):
     assert losses[-1] < losses[0], f"loss did not go down over 5 replayed steps on a fixed batch: {losses}"
 
 
+def test_prodigy_step_in_graph():
+    """unet_optimizer_type = "prodigy": the captured step (d, k, numerator live on the device) trains a fixed batch, and d
+    leaves d0; the group read-out of `get_current_lr` (optimizer.py:206-234) follows."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import sd_lora_trainer_amd.step as S
+    import sd_lora_trainer_amd.unet as M
+    from sd_lora_trainer_amd import topology
+    version, B, rank, h = "tinyxl", 2, 8, 16
+    cfg = U.CONFIGS[version]
+    sd = U.init_unet_state(cfg, seed=0)
+    lora = U.init_lora(cfg, rank, seed=1, b_std=0.05)
+    latent, noise, mask, t, ctx, pooled, tid, add = _inputs(cfg, B, h)
+    rt = M.Runtime("cuda:0", B)
+    unet = M.UNet(rt, topology.CONFIGS[version], sd, lora_rank=rank)
+    unet.arena.load(lora)
+    ts = S.TrainStep(rt, unet, latent_hw=(h, h), optimizer="prodigy", prodigy_growth_rate=1.5)
+    dv = lambda x: x.cuda() if x is not None else None  # noqa: E731
+    ts.set_batch(dv(latent), dv(noise), dv(t), dv(mask), dv(ctx), dv(pooled), dv(tid))
+    p_start = unet.arena.params.clone()
+    ts.capture(warmup=1)
+    assert torch.equal(unet.arena.params, p_start) and ts.prodigy.group(1.0)["k"] == 0        # capture is not training
+    losses = []
+    for i in range(40):
+        ts.run(1.0)
+        losses.append(float(ts.loss))
+    grp = ts.prodigy.group(1.0)
+    assert grp["k"] == 40 and grp["d"] > 10 * grp["d0"], grp
+    assert torch.equal(ts.prodigy.p0, p_start)
+    assert all(x == x for x in losses) and max(losses[-5:]) < 1.05 * losses[0], losses      # adapts d without blowing up
+
+
 def test_train_generator_on_gpu(tmp_path, monkeypatch):
     """main.py-style driver: config -> train() generator -> kohya checkpoint, on the HIP path with hipGraph replay."""
     if not torch.cuda.is_available():
