@@ -481,7 +481,8 @@ def test_prodigy_step_vs_oracle(ops, n, wd, growth, l1):
     assert abs(st[3] - grp["d_numerator"]) <= 1e-3 * abs(grp["d_numerator"])
     d = (pd.cpu() - opt.params[0]).abs().max()
     moved = (opt.params[0] - p_init).abs().max()
-    assert float(d) <= 2e-3 * float(moved), (float(d), float(moved))
+    ulp = float(opt.params[0].abs().max()) * 2.0 ** -23        # the parameters only move ~1e-5 in 10 steps from d0 = 1e-6
+    assert float(d) <= 2e-3 * float(moved) + 2 * ulp, (float(d), float(moved))
     close(l1s, opt.params[0].abs().sum().reshape(1), tol=2e-2, what="l1 sum")
 
 
