@@ -25,11 +25,21 @@ def kohya_key(module_path: str) -> str:
     return "lora_unet_" + module_path.replace(".", "_")
 
 
-def lora_to_kohya(lora_dict, dtype=torch.float16):
+def kohya_text_key(module_path: str) -> str:
+    """Text-encoder adapters (checkpoint.py:177-181, 188-199 hand them to diffusers' save_lora_weights as
+    text_encoder / text_encoder_2 layers): diffusers' convert_state_dict_to_kohya maps those prefixes to lora_te1_ /
+    lora_te2_ [3P-unverified, diffusers 0.29.2]."""
+    for pre, k in (("text_encoder_2.", "lora_te2_"), ("text_encoder.", "lora_te1_")):
+        if module_path.startswith(pre):
+            return k + module_path[len(pre):].replace(".", "_")
+    raise ValueError(f"not a text-encoder module: {module_path}")
+
+
+def lora_to_kohya(lora_dict, dtype=torch.float16, key=kohya_key):
     """lora_dict: module -> (A, B) in peft layout (LoraArena.export()).  Returns the kohya state dict."""
     sd = {}
     for mod, (A, B) in lora_dict.items():
-        k = kohya_key(mod)
+        k = key(mod)
         sd[k + ".lora_down.weight"] = A.detach().to(dtype).contiguous()
         sd[k + ".lora_up.weight"] = B.detach().to(dtype).contiguous()
         sd[k + ".alpha"] = torch.tensor(float(A.shape[0]))
@@ -47,8 +57,9 @@ def kohya_to_lora(sd):
 
 
 def save_checkpoint(output_dir, global_step, arena, ti_rows, token_dict, name, pretrained_model_version, config=None,
-                    txt_encoder_keys=("clip_l", "clip_g")):
-    """arena: unet.LoraArena (LoRA) ; ti_rows: list of [n_tokens, D] tensors per text encoder (or None)."""
+                    txt_encoder_keys=("clip_l", "clip_g"), text_arena=None):
+    """arena: unet.LoraArena (LoRA) ; ti_rows: list of [n_tokens, D] tensors per text encoder (or None);
+    text_arena: the text encoders' LoraArena when they are LoRA-trained (same file, lora_te1_/lora_te2_ keys)."""
     os.makedirs(output_dir, exist_ok=True)
     name = remove_delimiter_characters(name)
     files = {}
@@ -60,7 +71,10 @@ def save_checkpoint(output_dir, global_step, arena, ti_rows, token_dict, name, p
         json.dump(token_dict, f)
     if arena is not None:
         files["lora"] = os.path.join(output_dir, f"{name}_{pretrained_model_version}_lora.safetensors")
-        save_file(lora_to_kohya(arena.export()), files["lora"])
+        sd = lora_to_kohya(arena.export())
+        if text_arena is not None:
+            sd.update(lora_to_kohya(text_arena.export(), key=kohya_text_key))
+        save_file(sd, files["lora"])
         # adapter_config.json (peft `save_pretrained`, checkpoint.py:175) - the fields the reference's loader reads
         with open(os.path.join(output_dir, "adapter_config.json"), "w") as f:
             json.dump({"peft_type": "LORA", "r": arena.rank, "lora_alpha": arena.rank * arena.scale, "init_lora_weights": "gaussian",

@@ -21,15 +21,32 @@ T_TOKENS = 77
 TP = 128
 
 
+class _Renamed(dict):
+    """state-dict view that resolves `<lora name>.weight` to the checkpoint key: the LoRA entry of a text-encoder
+    projection is named with the encoder's prefix (`text_encoder.` / `text_encoder_2.`) so that both encoders can share
+    one arena, while the weights are looked up under their Hugging Face names."""
+
+    def __init__(self, sd, prefix):
+        self.sd, self.prefix = sd, prefix
+
+    def __getitem__(self, k):
+        return self.sd[k[len(self.prefix):]]
+
+    def get(self, k, default=None):
+        return self.sd.get(k[len(self.prefix):], default)
+
+
 class ClipLayer(_Module):
-    def __init__(self, rt, name, sd, heads, act):
+    def __init__(self, rt, name, sd, heads, act, arena=None, lora_prefix=""):
         super().__init__(rt, name)
         self.ln1 = LayerNorm(rt, name + ".layer_norm1", sd)
-        self.q = Linear(rt, name + ".self_attn.q_proj", sd)
-        self.k = Linear(rt, name + ".self_attn.k_proj", sd)
-        self.v = Linear(rt, name + ".self_attn.v_proj", sd)
+        # optional text-encoder LoRA on q/k/v/out_proj (trainer/optimizer.py:157-167)
+        psd = _Renamed(sd, lora_prefix)
+        self.q = Linear(rt, lora_prefix + name + ".self_attn.q_proj", psd, arena)
+        self.k = Linear(rt, lora_prefix + name + ".self_attn.k_proj", psd, arena)
+        self.v = Linear(rt, lora_prefix + name + ".self_attn.v_proj", psd, arena)
         self.qkv = StackedLinear(rt, name + ".self_attn.qkv", [self.q, self.k, self.v])
-        self.o = Linear(rt, name + ".self_attn.out_proj", sd)
+        self.o = Linear(rt, lora_prefix + name + ".self_attn.out_proj", psd, arena)
         self.ln2 = LayerNorm(rt, name + ".layer_norm2", sd)
         self.fc1 = Linear(rt, name + ".mlp.fc1", sd)
         self.fc2 = Linear(rt, name + ".mlp.fc2", sd)
@@ -63,7 +80,12 @@ class ClipLayer(_Module):
         dqkv, (dq, dk, dv) = self.qkv.grad_slices(M)
         rt.ops.attn_bwd(self.q._b["y"], self.k._b["y"], self.v._b["y"], None, None, self._b["O"], self._b["L"], dO,
                         None, self.buf("Dd", B * self.heads * T_TOKENS, dtype=F32), dq, dk, dv, **self._akw(B))
-        dn1 = self.qkv.backward(dqkv)
+        if self.qkv.has_lora and not self.qkv.kgrouped:     # adapter rank > 16: member-wise dX, summed through the residual input
+            dn1 = self.q.backward(dq)
+            dn1 = self.k.backward(dk, dres=dn1, key="dx2")
+            dn1 = self.v.backward(dv, dres=dn1, key="dx3")
+        else:
+            dn1 = self.qkv.backward(dqkv)
         return self.ln1.backward(dn1, dres=dx1)
 
 
@@ -72,7 +94,9 @@ class ClipTextEncoder(_Module):
        mode "penultimate": hidden = output of layer L-1 (HF hidden_states[-2], no final LN)   (SDXL prompt embeds)
        with_projection: pooled = text_projection(final_layer_norm(layer_L)[pool position])     (SDXL text_encoder_2)"""
 
-    def __init__(self, rt, name, sd, *, heads, act, mode, with_projection, n_train):
+    def __init__(self, rt, name, sd, *, heads, act, mode, with_projection, n_train, arena=None, lora_prefix=""):
+        """arena: optional unet.LoraArena shared by the text encoders (text-encoder LoRA, trainer/optimizer.py:157-202);
+        its entries are named lora_prefix + the Hugging Face module path."""
         super().__init__(rt, name)
         # transformers 4.x (the reference's pin) prefixes every key with "text_model."; 5.x drops it for CLIPTextModel
         pre = "text_model." if "text_model.embeddings.token_embedding.weight" in sd else ""
@@ -88,7 +112,7 @@ class ClipTextEncoder(_Module):
         # layers whose output is never consumed are not built (SDXL CLIP-L: the last layer only feeds an unused pooled output)
         self.n_run = nl if (mode == "last" or with_projection) else nl - 1
         self.n_hidden = nl if mode == "last" else nl - 1              # hidden state = output of this many layers
-        self.layers = [ClipLayer(rt, f"{pre}encoder.layers.{i}", sd, heads, act) for i in range(self.n_run)]
+        self.layers = [ClipLayer(rt, f"{pre}encoder.layers.{i}", sd, heads, act, arena, lora_prefix) for i in range(self.n_run)]
         self.final_ln = LayerNorm(rt, pre + "final_layer_norm", sd) if (mode == "last" or with_projection) else None
         self.proj = Linear(rt, "text_projection", sd) if with_projection else None
         self.train_ids = torch.arange(self.V - n_train, self.V, dtype=torch.int64, device=rt.device)

@@ -47,7 +47,7 @@ def get_current_lr(optimizer):
 
 
 class OptimizerCollection:
-    """order of the reference: textual inversion, text-encoder LoRA (not supported: off by default, config.py:115), unet."""
+    """order of the reference: textual inversion, text-encoder LoRA (off by default, config.py:115), unet."""
 
     def __init__(self, train_step, config):
         self.ts = train_step
@@ -60,6 +60,8 @@ class OptimizerCollection:
         if train_step.ti is not None:
             self.optimizers["textual_inversion"] = _FusedAdamWHandle("ti", config.ti_lr, config.ti_weight_decay) \
                 if train_step.prodigy_ti is None else _FusedProdigyHandle("ti", train_step.prodigy_ti, 1.0, config.ti_weight_decay)
+        if getattr(train_step, "te_arena", None) is not None:      # optimizer.py:190-199: AdamW only
+            self.optimizers["text_encoders"] = _FusedAdamWHandle("text_encoders", config.text_encoder_lora_lr, config.text_encoder_lora_weight_decay)
         self.learning_rate_tracker = {k: [] for k, v in self.optimizers.items() if v is not None}
 
     def step(self):
@@ -67,7 +69,8 @@ class OptimizerCollection:
         lr_unet = self.optimizers["unet"].param_groups[0]["lr"]
         ti = self.optimizers["textual_inversion"]
         lr_ti = ti.param_groups[0]["lr"] if ti is not None else 0.0
-        self.ts.run(lr_unet, lr_ti)
+        te = self.optimizers["text_encoders"]
+        self.ts.run(lr_unet, lr_ti, te.param_groups[0]["lr"] if te is not None else 0.0)
         for k in self.learning_rate_tracker:
             self.learning_rate_tracker[k].append(self.optimizers[k].param_groups[0]["lr"])
 

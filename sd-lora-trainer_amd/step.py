@@ -24,8 +24,11 @@ class TextStack:
     SD1.5: prompt_embeds = CLIP-L last_hidden_state (after final LN).
     SDXL : prompt_embeds = concat(CLIP-L hidden_states[-2], bigG hidden_states[-2]); pooled = bigG text_embeds."""
 
-    def __init__(self, rt, encoders, pool_mode="argmax", eos_token_id=49407, concurrent=False):
+    def __init__(self, rt, encoders, pool_mode="argmax", eos_token_id=49407, concurrent=False, arena=None):
+        """arena: the (finalized) LoraArena the encoders' q/k/v/out_proj adapters live in, when the text encoders are
+        LoRA-trained too (`text_encoder_lora_optimizer`, trainer/optimizer.py:157-202); None otherwise."""
         self.rt, self.encoders, self.pool_mode, self.eos = rt, encoders, pool_mode, eos_token_id
+        self.arena, self._grad_plan = arena, None
         B = rt.B
         self.ids = [torch.zeros(B, T_TOKENS, dtype=torch.int64, device=rt.device) for _ in encoders]
         self.pool_rows = torch.zeros(B, dtype=torch.int64, device=rt.device)
@@ -88,6 +91,10 @@ class TextStack:
             jobs.append(job)
             off += w
         self._fan_out(jobs)
+        if self.arena is not None:                     # dA / dB of every text-encoder adapter in one grouped launch
+            if self._grad_plan is None:
+                self._grad_plan = self.rt.ops.LoraGradPlan(self.arena.problems, self.arena.Rp, self.rt.device)
+            self._grad_plan.run()
 
 
 def ddpm_alphas_cumprod(n=1000, beta_start=0.00085, beta_end=0.012):
@@ -139,7 +146,7 @@ class TrainStep:
     def __init__(self, rt: Runtime, unet: UNet, *, latent_hw, snr_gamma=5.0, v_prediction=False, l1_penalty=0.03,
                  weight_decay=0.004, grad_accum=1, betas=(0.9, 0.999), eps=1e-8, text: TextStack = None, n_tokens=3,
                  token_attention_loss_w=3e-7, ti_weight_decay=0.0, ti_std_loss_w=0.01, optimizer="adamw", ti_optimizer="adamw",
-                 prodigy_d_coef=1.0, prodigy_growth_rate=1.05):
+                 prodigy_d_coef=1.0, prodigy_growth_rate=1.05, text_lora_weight_decay=1e-5):
         if optimizer not in ("adamw", "prodigy"):      # AdamW8bit (bitsandbytes) belongs to the full fine-tune, not built
             raise NotImplementedError(f"Invalid optimizer_name for unet: {optimizer}")
         if ti_optimizer not in ("adamw", "prodigy"):
@@ -179,6 +186,10 @@ class TrainStep:
                                     weight_decay=weight_decay) if optimizer == "prodigy" else None
         self.prodigy_ti = ProdigyState(rt, self.ti.params, weight_decay=ti_weight_decay) \
             if (self.ti is not None and ti_optimizer == "prodigy") else None
+        # a21: text-encoder LoRA (AdamW only, optimizer.py:190-199): its own arena, learning rate and weight decay
+        self.te_arena = text.arena if text is not None else None
+        self.te_wd = text_lora_weight_decay
+        self.te_hyper = z(16) if self.te_arena is not None else None
 
     # -------------------------------------------------------------------------------- inputs
     def set_batch(self, latent, noise, timesteps, mask, ctx=None, pooled=None, time_ids=None, ids=None, caption_token_lists=None):
@@ -202,7 +213,7 @@ class TrainStep:
         if self.time_ids is not None:
             self.time_ids.copy_(time_ids.reshape(-1).to(torch.float32))
 
-    def set_hyper(self, lr, lr_ti=0.0):
+    def set_hyper(self, lr, lr_ti=0.0, lr_te=0.0):
         """Host scalars of this optimiser step -> device buffers (see sdlt_adamw_fused).
         The upload is an async copy from a ring of pinned staging rows: a pageable-memory copy would block the host until the
         previous step has finished on the GPU, so the next graph launch could never be queued behind the running one (the
@@ -216,17 +227,21 @@ class TrainStep:
         if self.ti is not None:
             rows.append([lr_ti, b1, b2, self.eps, self.ti_wd, *bc, 0.0, 1.0] if self.prodigy_ti is None
                         else self.prodigy_ti.hyper_row(lr_ti, 0.0))
+        dsts = [self.hyper] + ([self.ti.hyper] if self.ti is not None else [])
+        if self.te_arena is not None:
+            rows.append([lr_te, b1, b2, self.eps, self.te_wd, *bc, 0.0, 1.0])
+            dsts.append(self.te_hyper)
         for pr in (self.prodigy, self.prodigy_ti):
             if pr is not None:
                 pr.before_run()
         cuda = self.hyper.is_cuda
         if cuda and getattr(self, "_hyper_ring", None) is None:
-            self._hyper_ring = torch.zeros(64, 2, 16, dtype=torch.float32).pin_memory()
+            self._hyper_ring = torch.zeros(64, 3, 16, dtype=torch.float32).pin_memory()
             self._hyper_done = [None] * 64          # event after the copies of a slot: waited for before the slot is reused
             self._hyper_slot = 0
         if cuda and self._hyper_done[self._hyper_slot] is not None:
             self._hyper_done[self._hyper_slot].synchronize()
-        for i, (vals, dst) in enumerate(zip(rows, [self.hyper] + ([self.ti.hyper] if self.ti is not None else []))):
+        for i, (vals, dst) in enumerate(zip(rows, dsts)):
             if cuda:
                 stage = self._hyper_ring[self._hyper_slot, i]
                 stage[: len(vals)] = torch.tensor(vals, dtype=torch.float32)
@@ -297,6 +312,10 @@ class TrainStep:
             else:
                 self.rt.ops.adamw_fused(t.params, t.grads, t.m, t.v, t.hyper, None)
             t.refresh_tables()
+        if self.te_arena is not None:                  # a21, between TI and UNet in the reference's order (optimizer.py:265-275)
+            e = self.te_arena
+            self.rt.ops.adamw_fused(e.params, e.grads, e.m, e.v, self.te_hyper, None)
+            e.refresh_shadows()
 
     def body(self):
         self.forward_backward()
@@ -324,6 +343,8 @@ class TrainStep:
         streams), plus the frozen-TI variant.  AdamW state is restored afterwards so capture does not count as training."""
         a = self.unet.arena
         state = [a.params, a.m, a.v] + ([self.ti.params, self.ti.m, self.ti.v] if self.ti is not None else [])
+        if self.te_arena is not None:
+            state += [self.te_arena.params, self.te_arena.m, self.te_arena.v]
         snap = [t.clone() for t in state]
         step0 = self.opt_step
         s = torch.cuda.Stream()
@@ -347,7 +368,7 @@ class TrainStep:
                 graphs.append(cap(fns, pool))
                 pool = graphs[-1].pool()
             frozen = None
-            if self.text is not None:     # variant for ti lr == 0: same first phases, LoRA-only last phase
+            if self.text is not None and self.te_arena is None:     # variant for ti lr == 0: same first phases, LoRA-only last phase
                 if split:
                     frozen = graphs[:2] + [cap([self._phase_opt_frozen_ti], pool)]
                 else:
@@ -361,14 +382,18 @@ class TrainStep:
         a.refresh_shadows()
         if self.ti is not None:
             self.ti.refresh_tables()
+        if self.te_arena is not None:
+            self.te_arena.refresh_shadows()
         for pr in (self.prodigy, self.prodigy_ti):
             if pr is not None:
                 pr.reset()
         self.opt_step = step0
 
-    def run(self, lr, lr_ti=0.0):
-        self.set_hyper(lr, lr_ti)
-        frozen = self.text is not None and lr_ti == 0.0     # (Prodigy with lr 0 is a no-op as well: sdlt_prodigy_step)
+    def run(self, lr, lr_ti=0.0, lr_te=0.0):
+        self.set_hyper(lr, lr_ti, lr_te)
+        # frozen-TI fast path (Prodigy with lr 0 is a no-op as well: sdlt_prodigy_step); never with text-encoder LoRA, whose
+        # gradients need the text backward for the whole run
+        frozen = self.text is not None and lr_ti == 0.0 and self.te_arena is None
         self._frozen_last = frozen
         if self.graph is not None:
             for g in (self.graphs_frozen if frozen else self.graphs):

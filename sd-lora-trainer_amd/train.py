@@ -58,16 +58,24 @@ def build_models(config, rt):
         cfg = topology.CONFIGS[version]
     unet = M.UNet(rt, cfg, sd, lora_rank=config.lora_rank if config.is_lora else None, lora_alpha_multiplier=config.lora_alpha_multiplier)
     text = None
+    if config.text_encoder_lora_optimizer is not None and config.disable_ti:
+        raise NotImplementedError("text-encoder LoRA without textual inversion: the text stack is only built for TI runs")
     if not config.disable_ti:
         tiny = version.startswith("tiny")
         kinds = (["tiny_l", "tiny_g"] if tiny else ["clip_l", "clip_g"]) if cfg["addition"] else (["tiny_l"] if tiny else ["clip_l"])
         encs = []
+        te_arena = None
+        if config.text_encoder_lora_optimizer is not None:         # a21 (main.py:116-126, optimizer.py:157-202)
+            te_arena = M.LoraArena(rt, config.text_encoder_lora_rank, config.lora_alpha_multiplier, problems=[])
         for i, kd in enumerate(kinds):
             c = topology.CLIP_CONFIGS[kd]
             csd = _random_state(topology.clip_param_shapes(c, config.n_tokens), rt.device, seed=config.seed + 1 + i)
             encs.append(CL.ClipTextEncoder(rt, f"te{i + 1}", csd, heads=c["heads"], act=c["act"], mode="penultimate" if cfg["addition"] else "last",
-                                           with_projection=bool(c["proj"]), n_train=config.n_tokens))
-        text = S.TextStack(rt, encs, pool_mode="argmax")
+                                           with_projection=bool(c["proj"]), n_train=config.n_tokens, arena=te_arena,
+                                           lora_prefix="text_encoder." if i == 0 else "text_encoder_2."))
+        if te_arena is not None:
+            te_arena.finalize()
+        text = S.TextStack(rt, encs, pool_mode="argmax", arena=te_arena)
     return unet, text, version
 
 
@@ -115,7 +123,8 @@ def train(config: TrainingConfig, runtime=None):
                      grad_accum=config.gradient_accumulation_steps, text=text, n_tokens=config.n_tokens,
                      token_attention_loss_w=config.token_attention_loss_w, ti_weight_decay=config.ti_weight_decay,
                      optimizer=config.unet_optimizer_type, ti_optimizer=config.ti_optimizer,
-                     prodigy_d_coef=config.prodigy_d_coef, prodigy_growth_rate=config.unet_prodigy_growth_factor)
+                     prodigy_d_coef=config.prodigy_d_coef, prodigy_growth_rate=config.unet_prodigy_growth_factor,
+                     text_lora_weight_decay=config.text_encoder_lora_weight_decay)
     handler = None
     if text is not None:
         handler = TokenEmbeddingsHandler(ts.ti, config.inserting_list_tokens)
@@ -126,6 +135,11 @@ def train(config: TrainingConfig, runtime=None):
         e["A"].copy_(torch.randn(e["A"].shape, generator=g, device=rt.device) / config.lora_rank)
         e["B"].zero_()
     arena.refresh_shadows()
+    if ts.te_arena is not None:
+        for e in ts.te_arena.entries:
+            e["A"].copy_(torch.randn(e["A"].shape, generator=g, device=rt.device) / config.text_encoder_lora_rank)
+            e["B"].zero_()
+        ts.te_arena.refresh_shadows()
     optimizers = OptimizerCollection(ts, config)
     checkpoint_dir = os.path.join(config.output_dir, "checkpoints")
     os.makedirs(checkpoint_dir, exist_ok=True)
@@ -140,7 +154,10 @@ def train(config: TrainingConfig, runtime=None):
         order = perm_rng.permutation(n_img)
         for step_in_epoch in range(steps_per_epoch):
             completion_f = schedule.completion_fraction(epoch, step_in_epoch, steps_per_epoch, config.num_train_epochs)
-            lrs = schedule.learning_rates(config, global_step, completion_f, ti_active=text is not None)
+            lrs = schedule.learning_rates(config, global_step, completion_f, ti_active=text is not None,
+                                          text_lora_active=ts.te_arena is not None)
+            if ts.te_arena is not None:
+                optimizers.optimizers["text_encoders"].param_groups[0]["lr"] = lrs["text_encoders"]
             optimizers.optimizers["unet"].param_groups[0]["lr"] = lrs["unet"]
             if text is not None:
                 optimizers.optimizers["textual_inversion"].param_groups[0]["lr"] = lrs["textual_inversion"]
@@ -186,7 +203,7 @@ def train(config: TrainingConfig, runtime=None):
     config.job_time = time.time() - config.start_time
     config.training_attributes = dict(config.training_attributes, images_per_second=images_done / max(time.time() - start, 1e-9), losses=losses)
     ckpt.save_checkpoint(output_save_dir, global_step, arena, ts.ti.rows if ts.ti is not None else None, config.token_dict, config.name,
-                         version, config=config)
+                         version, config=config, text_arena=ts.te_arena)
     return config, output_save_dir
 
 

@@ -80,8 +80,11 @@ class _Module:
 class LoraArena:
     """Flat fp32 master copy of every LoRA A/B (plus grads and AdamW moments) and the bf16 compute copies."""
 
-    def __init__(self, rt, rank, alpha_multiplier=1.0):
+    def __init__(self, rt, rank, alpha_multiplier=1.0, problems=None):
         self.rt, self.rank = rt, rank
+        # LoRA-gradient problems of the adapters in this arena, appended by the layers on their first backward.  The UNet
+        # arena shares the runtime's list; the text-encoder arena (step.TextStack) keeps its own, run after the text backward.
+        self.problems = rt.lora_problems if problems is None else problems
         self.Rp = 16 if rank <= 16 else (32 if rank <= 32 else 64)
         assert rank <= 64, "LoRA rank > 64 not supported by the fused kernels"
         self.scale = (rank * alpha_multiplier) / rank  # peft: lora_alpha / r, lora_alpha = r * multiplier (optimizer.py:88)
@@ -194,7 +197,7 @@ class Linear(_Module):
             lora = (self.lora["Bt_s"], self.lora["At_s"], self.arena.scale, U)
             if not getattr(self, "_registered", False):
                 r = self.arena.rank
-                self.rt.lora_problems += [
+                self.arena.problems += [
                     dict(P=dy, Q=self._b["T"], out=self.lora["gB"], M=M, Cw=self.N, R=r, rank_major=False),
                     dict(P=self._x, Q=U, out=self.lora["gA"], M=M, Cw=self.K, R=r, rank_major=True)]
                 self._registered = True
@@ -290,7 +293,7 @@ class StackedLinear(_Module):
         if not getattr(self, "_registered", False):
             r = self.arena.rank
             for g, m in enumerate(self.members):
-                self.rt.lora_problems += [
+                self.arena.problems += [
                     dict(P=dy_cat[:, g * N:(g + 1) * N], Q=m._b["T"], out=m.lora["gB"], M=M, Cw=N, R=r, rank_major=False),
                     dict(P=m._x, Q=U[:, g * 16:(g + 1) * 16], out=m.lora["gA"], M=M, Cw=self.K, R=r, rank_major=True)]
             self._registered = True
@@ -365,7 +368,7 @@ class Conv3x3(_Module):
         rt.ops.gemm(U64, self.lora["Ab_s"], dx, conv=_ops.ConvGeom(B, Hout, Wout, 64, H, W, flip=1), residual=dx)
         if not getattr(self, "_registered", False):
             r = self.arena.rank
-            rt.lora_problems += [
+            self.arena.problems += [
                 dict(P=dy, Q=self._b["T"], out=self.lora["gB"], M=M, Cw=self.Cout, R=r, rank_major=False),
                 dict(P=self._x, Q=U, out=self.lora["gA"], M=M, Cw=9 * self.Cin, R=r, rank_major=True, conv=self._g)]
             self._registered = True
@@ -798,7 +801,7 @@ class UNet(_Module):
         self._cross_kv_backward(dctx)
         if self.arena is not None:
             if self._grad_plan is None:
-                self._grad_plan = rt.ops.LoraGradPlan(rt.lora_problems, self.arena.Rp, rt.device)
+                self._grad_plan = rt.ops.LoraGradPlan(self.arena.problems, self.arena.Rp, rt.device)
             self._grad_plan.run()
 
     # ------------------------------------------------------------------------------------ batched score-gradient GEMMs

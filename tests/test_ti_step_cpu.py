@@ -119,3 +119,103 @@ def test_ti_step_matches_oracle(version, B):
         L.adamw_step(p, gr, m, v, 1, 1e-3, weight_decay=0.0)
         torch.testing.assert_close(r1, p, rtol=1e-5, atol=1e-7)
         torch.testing.assert_close(enc.table[-NTOK:].float(), p, rtol=1e-5, atol=1e-7)    # gathered table was refreshed
+
+
+@pytest.mark.parametrize("version,B,rank", [("tiny15", 2, 4), ("tinyxl", 1, 16), ("tiny15", 1, 24)])     # rank 24: member-wise dX of q|k|v
+def test_text_encoder_lora_matches_oracle(version, B, rank):
+    """a21 (`text_encoder_lora_optimizer`, trainer/optimizer.py:157-202): peft LoRA on q/k/v/out_proj of every text-encoder
+    layer, trained by its own AdamW next to TI and the UNet LoRA.  Oracle: Hugging Face CLIP called functionally with
+    W + (alpha/r) B A in place of the four projection weights, autograd for dA / dB."""
+    from torch.func import functional_call
+    import sd_lora_trainer_amd.checkpoint as ckpt
+    cfg = U.CONFIGS[version]
+    xl = cfg["addition"]
+    h, w_ta, w_std = 16, 2e-2, 0.01
+    sd = U.init_unet_state(cfg, seed=0)
+    lora = U.init_lora(cfg, 4, seed=1, b_std=0.05)
+    if xl:
+        hf = [_hf("quick_gelu", False, 64, 1, 11), _hf("gelu", True, 64, 1, 12, proj=cfg["proj_class_in"] - 6 * cfg["addition_time_embed_dim"])]
+    else:
+        hf = [_hf("quick_gelu", False, 64, 2, 11)]
+    g = torch.Generator().manual_seed(3)
+    latent = torch.randn(B, 4, h, h, generator=g) * cfg["scaling_factor"]
+    noise = torch.randn(B, 4, h, h, generator=g)
+    mask = (torch.rand(B, 1, h, h, generator=g) * 0.95 + 0.05).repeat(1, 4, 1, 1).contiguous()
+    t = torch.tensor([10, 900][:B])
+    tid = torch.tensor([[1024., 1024, 0, 0, 128, 128]] * B) if xl else None
+    lists, ids = _captions(B)
+
+    # ------------------------------------------------------------------ the plan (built first: it names the adapters)
+    rt = unet_mod.Runtime("cpu", B, act_dtype=torch.float32, ops=emu_ops)
+    unet = unet_mod.UNet(rt, topology.CONFIGS[version], sd, lora_rank=4)
+    unet.arena.load(lora)
+    te_arena = unet_mod.LoraArena(rt, rank, 1.0, problems=[])
+    sds = [{k: v.detach() for k, v in m.state_dict().items()} for m in hf]
+    prefixes = ["text_encoder.", "text_encoder_2."]
+    kw = [dict(heads=1, act="quick_gelu", mode="penultimate", with_projection=False), dict(heads=1, act="gelu", mode="penultimate", with_projection=True)] \
+        if xl else [dict(heads=2, act="quick_gelu", mode="last", with_projection=False)]
+    encs = [clip_mod.ClipTextEncoder(rt, f"te{i + 1}", sds[i], n_train=NTOK, arena=te_arena, lora_prefix=prefixes[i], **k) for i, k in enumerate(kw)]
+    te_arena.finalize()
+    gl = torch.Generator().manual_seed(21)
+    te_lora = {e["name"]: (torch.randn(rank, e["K"], generator=gl) / rank, torch.randn(e["N"], rank, generator=gl) * 0.05) for e in te_arena.entries}
+    te_arena.load(te_lora)
+    n_layers_run = [3 if (not xl or i == 1) else 2 for i in range(len(hf))]            # SDXL CLIP-L: the last layer feeds nothing
+    assert len(te_arena.entries) == 4 * sum(n_layers_run)
+    text = step_mod.TextStack(rt, encs, pool_mode="first_eos", eos_token_id=EOS, arena=te_arena)
+    ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, l1_penalty=0.0, weight_decay=0.0, text=text, n_tokens=NTOK,
+                            token_attention_loss_w=w_ta, ti_std_loss_w=w_std, text_lora_weight_decay=1e-5)
+    ts.set_batch(latent, noise, t, mask, time_ids=tid, ids=[ids] * len(encs), caption_token_lists=lists)
+    ts.forward_backward()
+
+    # ------------------------------------------------------------------ oracle (autograd through merged projections)
+    te_g, te_params, outs = {}, [], []
+    for i, m in enumerate(hf):
+        over = {}
+        for name, (A, Bm) in te_lora.items():
+            if not name.startswith(prefixes[i]) or (i == 0 and name.startswith(prefixes[1])):
+                continue
+            A, Bm = A.clone().requires_grad_(True), Bm.clone().requires_grad_(True)
+            te_g[name] = (A, Bm)
+            te_params += [A, Bm]
+            key = name[len(prefixes[i]):] + ".weight"
+            over[key] = sds[i][key] + te_arena.scale * Bm @ A
+        outs.append(functional_call(m, over, kwargs=dict(input_ids=ids, output_hidden_states=True)))
+    embs = [m.get_input_embeddings().weight for m in hf]
+    if xl:
+        ctx = torch.cat([outs[0].hidden_states[-2], outs[1].hidden_states[-2]], dim=-1)
+        add = {"text_embeds": outs[1].text_embeds, "time_ids": tid}
+    else:
+        ctx, add = outs[0].last_hidden_state, None
+    acp = L.ddpm_alphas_cumprod()
+    noisy = L.add_noise(acp, latent, noise, t)
+    pred, daam = U.unet_forward(cfg, sd, noisy, t, ctx, add, lora={k: v for k, v in lora.items()}, return_daam=True)
+    img_loss = L.diffusion_loss(pred, noise, noisy, mask, acp, t, snr_gamma=5.0)
+    ta = L.token_attention_loss(L.daam_stack([s for _, s in daam], 1.0), mask, lists, TRAIN_IDS)
+    reg = torch.stack([L.DistributionStats(e.detach()[:-NTOK]).std_loss(e[-NTOK:]) for e in embs]).mean()
+    grads = torch.autograd.grad(img_loss + w_ta * ta + w_std * reg, te_params + embs)
+    torch.testing.assert_close(ts.loss[0], img_loss.detach(), rtol=1e-4, atol=1e-6)
+    got = te_arena.export("grads")
+    assert set(got) == set(te_g)
+    gmax = max(float(x.abs().max()) for x in grads[:len(te_params)])
+    assert gmax > 0
+    for i, name in enumerate(te_g):
+        for a, b_ in zip(got[name], (grads[2 * i], grads[2 * i + 1])):
+            assert float((a - b_).abs().max()) <= 3e-3 * float(b_.abs().max()) + 1e-6 * gmax, (name, float((a - b_).abs().max()), float(b_.abs().max()))
+    for got_r, ref in zip(ts.ti.grad_rows, [ge[-NTOK:] for ge in grads[len(te_params):]]):
+        assert float((got_r - ref).abs().max()) <= 3e-3 * float(ref.abs().max())
+
+    # one optimiser step: the text-encoder arena follows AdamW with its own lr / weight decay, the other groups theirs
+    p0, g0 = te_arena.params.clone(), te_arena.grads.clone()
+    ts.set_hyper(1e-3, lr_ti=1e-3, lr_te=2e-4)
+    ts.optimizer_step()
+    pref, m_, v_ = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    L.adamw_step(pref, g0, m_, v_, 1, 2e-4, weight_decay=1e-5)
+    torch.testing.assert_close(te_arena.params, pref, rtol=1e-5, atol=1e-8)
+    e0 = te_arena.entries[0]
+    torch.testing.assert_close(e0["A_s"][:rank].float(), e0["A"], rtol=1e-6, atol=0)          # compute copies refreshed
+    # kohya keys of the text-encoder adapters in the checkpoint file
+    ksd = ckpt.lora_to_kohya(te_arena.export(), key=ckpt.kohya_text_key)
+    k0 = ckpt.kohya_text_key(e0["name"])
+    assert k0.startswith("lora_te1_") and k0.endswith("encoder_layers_0_self_attn_q_proj") and k0 + ".lora_down.weight" in ksd
+    if xl:
+        assert any(k.startswith("lora_te2_") for k in ksd)

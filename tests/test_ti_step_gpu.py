@@ -109,3 +109,105 @@ def test_ti_step_gpu_matches_oracle(version, B, concurrent):
     assert all(torch.equal(a, b) for a, b in zip(rows0, [ts.ti.params]))
     assert not torch.equal(lora0, unet.arena.params)
     assert ts.grad_norm() > 0.0 and math.isfinite(ts.total_loss())
+
+
+@pytest.mark.parametrize("version,B,rank", [("tiny15", 2, 16), ("tinyxl", 2, 8)])
+def test_text_encoder_lora_gpu_matches_oracle(version, B, rank):
+    """a21: LoRA on q/k/v/out_proj of the text encoders (trainer/optimizer.py:157-202) on the HIP path - fused into the
+    stacked q|k|v GEMM (N-grouped forward, K-grouped dX) and the out_proj GEMM - against autograd through Hugging Face
+    CLIP with merged projections; then graph replays with all three optimizers live."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from torch.func import functional_call
+    from oracle import loss_ref as L
+    from oracle import unet_ref as U
+    import sd_lora_trainer_amd.clip as clip_mod
+    import sd_lora_trainer_amd.step as step_mod
+    import sd_lora_trainer_amd.unet as unet_mod
+    from sd_lora_trainer_amd import topology
+    cfg = U.CONFIGS[version]
+    xl = cfg["addition"]
+    w_ta, w_std = 2e-2, 0.01
+    h = 32 if xl else 16
+    sd = U.init_unet_state(cfg, seed=0)
+    lora = U.init_lora(cfg, 4, seed=1, b_std=0.05)
+    hf = ([_hf("quick_gelu", False, 64, 1, 11), _hf("gelu", True, 64, 1, 12, proj=cfg["proj_class_in"] - 6 * cfg["addition_time_embed_dim"])]
+          if xl else [_hf("quick_gelu", False, 64, 2, 11)])
+    for m in hf:
+        for p in m.parameters():
+            p.data = p.data.to(torch.bfloat16).float()
+    g = torch.Generator().manual_seed(3)
+    latent = torch.randn(B, 4, h, h, generator=g) * cfg["scaling_factor"]
+    noise = torch.randn(B, 4, h, h, generator=g)
+    mask = (torch.rand(B, 1, h, h, generator=g) * 0.95 + 0.05).repeat(1, 4, 1, 1).contiguous()
+    t = torch.tensor([10, 900][:B])
+    tid = torch.tensor([[1024., 1024, 0, 0, 8. * h, 8. * h]] * B) if xl else None
+    lists, ids = _captions(B)
+
+    rt = unet_mod.Runtime("cuda:0", B)
+    unet = unet_mod.UNet(rt, topology.CONFIGS[version], sd, lora_rank=4)
+    unet.arena.load(lora)
+    te_arena = unet_mod.LoraArena(rt, rank, 1.0, problems=[])
+    sds = [{k: v.detach() for k, v in m.state_dict().items()} for m in hf]
+    prefixes = ["text_encoder.", "text_encoder_2."]
+    kw = [dict(heads=1, act="quick_gelu", mode="penultimate", with_projection=False), dict(heads=1, act="gelu", mode="penultimate", with_projection=True)] \
+        if xl else [dict(heads=2, act="quick_gelu", mode="last", with_projection=False)]
+    encs = [clip_mod.ClipTextEncoder(rt, f"te{i + 1}", sds[i], n_train=NTOK, arena=te_arena, lora_prefix=prefixes[i], **k) for i, k in enumerate(kw)]
+    te_arena.finalize()
+    gl = torch.Generator().manual_seed(21)
+    bf = lambda x: x.to(torch.bfloat16).float()  # noqa: E731  (the compute copies are bf16)
+    te_lora = {e["name"]: (bf(torch.randn(rank, e["K"], generator=gl) / rank), bf(torch.randn(e["N"], rank, generator=gl) * 0.05)) for e in te_arena.entries}
+    te_arena.load(te_lora)
+    text = step_mod.TextStack(rt, encs, pool_mode="first_eos", eos_token_id=EOS, arena=te_arena)
+    ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, l1_penalty=0.0, weight_decay=0.0, text=text, n_tokens=NTOK,
+                            token_attention_loss_w=w_ta, ti_std_loss_w=w_std)
+    ts.set_batch(latent.cuda(), noise.cuda(), t.cuda(), mask.cuda(), time_ids=tid.cuda() if xl else None, ids=[ids] * len(encs),
+                 caption_token_lists=lists)
+    ts.forward_backward()
+    torch.cuda.synchronize()
+
+    te_params, names, outs = [], [], []
+    for i, m in enumerate(hf):
+        over = {}
+        for name, (A, Bm) in te_lora.items():
+            if not name.startswith(prefixes[i]):
+                continue
+            A, Bm = A.clone().requires_grad_(True), Bm.clone().requires_grad_(True)
+            te_params += [A, Bm]
+            names.append(name)
+            key = name[len(prefixes[i]):] + ".weight"
+            over[key] = sds[i][key] + te_arena.scale * Bm @ A
+        outs.append(functional_call(m, over, kwargs=dict(input_ids=ids, output_hidden_states=True)))
+    embs = [m.get_input_embeddings().weight for m in hf]
+    if xl:
+        ctx = torch.cat([outs[0].hidden_states[-2], outs[1].hidden_states[-2]], dim=-1)
+        add = {"text_embeds": outs[1].text_embeds, "time_ids": tid}
+    else:
+        ctx, add = outs[0].last_hidden_state, None
+    acp = L.ddpm_alphas_cumprod()
+    noisy = L.add_noise(acp, latent, noise, t)
+    pred, daam = U.unet_forward(cfg, sd, noisy, t, ctx, add, lora={k: v for k, v in lora.items()}, return_daam=True)
+    img_loss = L.diffusion_loss(pred, noise, noisy, mask, acp, t, snr_gamma=5.0)
+    ta = L.token_attention_loss(L.daam_stack([s for _, s in daam], 1.0), mask, lists, TRAIN_IDS)
+    reg = torch.stack([L.DistributionStats(e.detach()[:-NTOK]).std_loss(e[-NTOK:]) for e in embs]).mean()
+    grads = torch.autograd.grad(img_loss + w_ta * ta + w_std * reg, te_params + embs)
+    assert abs(float(ts.loss) - float(img_loss)) <= 2e-2 * float(img_loss)
+    got = te_arena.export("grads")
+    got_flat = torch.cat([x.reshape(-1) for n in names for x in got[n]])
+    ref_flat = torch.cat([x.reshape(-1) for x in grads[:len(te_params)]])
+    cos, rel = _cos_rel(got_flat, ref_flat)
+    assert cos >= 0.985 and rel <= 0.12, f"text-encoder LoRA grads cos {cos} rel {rel}"
+    for got_r, ref in zip(ts.ti.grad_rows, [ge[-NTOK:] for ge in grads[len(te_params):]]):
+        cos, rel = _cos_rel(got_r, ref)
+        assert cos >= 0.985 and rel <= 0.12, f"TI row grads cos {cos} rel {rel}"
+    ts.capture(warmup=1)
+    te0 = te_arena.params.clone()
+    losses = []
+    for i in range(6):
+        ts.run(1e-3, lr_ti=1e-3, lr_te=1e-3)
+        losses.append(ts.total_loss())
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
+    assert not torch.equal(te0, te_arena.params)
+    ts.run(1e-3, lr_ti=0.0, lr_te=1e-3)          # no frozen fast path while the text encoders are LoRA-trained
+    torch.cuda.synchronize()
+    assert math.isfinite(ts.total_loss())
