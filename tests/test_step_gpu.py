@@ -138,8 +138,10 @@ def test_prodigy_step_in_graph():
     assert all(x == x for x in losses) and max(losses[-5:]) < 1.05 * losses[0], losses      # adapts d without blowing up
 
 
-def test_train_generator_on_gpu(tmp_path, monkeypatch):
-    """main.py-style driver: config -> train() generator -> kohya checkpoint, on the HIP path with hipGraph replay."""
+@pytest.mark.parametrize("extra", [{}, dict(text_encoder_lora_optimizer="adamw", text_encoder_lora_lr=1e-4, text_encoder_lora_rank=8, ti_optimizer="prodigy")])
+def test_train_generator_on_gpu(tmp_path, monkeypatch, extra):
+    """main.py-style driver: config -> train() generator -> kohya checkpoint, on the HIP path with hipGraph replay.
+    Second case: text-encoder LoRA (a21) next to the UNet LoRA, Prodigy on the token rows (a17)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import json
@@ -148,7 +150,7 @@ def test_train_generator_on_gpu(tmp_path, monkeypatch):
     from sd_lora_trainer_amd.config import TrainingConfig
     from sd_lora_trainer_amd.train import train
     cfg = TrainingConfig(lora_training_urls="synthetic:8", concept_mode="object", pretrained_model={"path": "synthetic:tinyxl"}, seed=3, resolution=256,
-                         train_batch_size=2, max_train_steps=40, lora_rank=8, unet_lr=2e-3, ti_lr=2e-3, caption_dropout=0.1)
+                         train_batch_size=2, max_train_steps=40, lora_rank=8, unet_lr=2e-3, ti_lr=2e-3, caption_dropout=0.1, **extra)
     gen = train(cfg)
     try:
         while True:
@@ -159,4 +161,9 @@ def test_train_generator_on_gpu(tmp_path, monkeypatch):
     tot = ta["training_attributes"]["losses"]["tot_loss"]
     assert all(map(lambda x: x == x and abs(x) < 1e4, tot)) and len(tot) >= 10
     assert sum(tot[-5:]) / 5 < sum(tot[:5]) / 5, tot          # trains on the synthetic concept
-    assert any(n.endswith("_sdxl_lora.safetensors") or n.endswith("_tinyxl_lora.safetensors") for n in os.listdir(out))
+    lora_files = [n for n in os.listdir(out) if n.endswith("_sdxl_lora.safetensors") or n.endswith("_tinyxl_lora.safetensors")]
+    assert lora_files
+    if extra:
+        from safetensors.torch import load_file
+        keys = list(load_file(os.path.join(out, lora_files[0])))
+        assert any(k.startswith("lora_te1_") for k in keys) and any(k.startswith("lora_te2_") for k in keys) and any(k.startswith("lora_unet_") for k in keys)
