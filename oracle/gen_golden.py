@@ -212,6 +212,29 @@ def main():
             os.chdir(cwd)
     with open(os.path.join(OUT, "config_snapshots.json"), "w") as fh:
         json.dump(snaps, fh, indent=1, sort_keys=True)
+    gen_target_prompt_loss()
+
+
+def gen_target_prompt_loss():
+    """(xi) TokenEmbeddingsHandler.compute_target_prompt_loss (embedding_handler.py:288-318), the objective of the
+    token warm-up (pre_optimize_token_embeddings, :321-399): called unbound on a stand-in `self` that already holds the
+    encoded target, so no pipeline is needed.  Values and autograd gradients w.r.t. the prompt embeddings."""
+    _install_stubs()
+    import types as _t
+    import trainer.embedding_handler as reh
+    g = torch.Generator().manual_seed(77)
+    cases = []
+    for B, D, P in [(1, 32, None), (2, 48, 24), (3, 256, 128)]:
+        pe = torch.randn(B, 77, D, generator=g).requires_grad_(True)
+        tpe = torch.randn(1, 77, D, generator=g)
+        ppe = torch.randn(B, P, generator=g).requires_grad_(True) if P else None
+        tppe = torch.randn(1, P, generator=g) if P else None
+        me = _t.SimpleNamespace(target_prompt="x", target_prompt_embeds=tpe, target_pooled_prompt_embeds=tppe)
+        loss = reh.TokenEmbeddingsHandler.compute_target_prompt_loss(me, "x", pe, ppe, None, None)
+        grads = torch.autograd.grad(loss, [pe] + ([ppe] if P else []))
+        cases.append(dict(prompt_embeds=pe.detach(), target=tpe, pooled=ppe.detach() if P else None, target_pooled=tppe,
+                          loss=loss.detach(), d_prompt=grads[0], d_pooled=grads[1] if P else None))
+    torch.save(cases, os.path.join(OUT, "target_prompt_loss.pt"))
 
     print("golden fixtures written to", os.path.normpath(OUT))
     for f in sorted(os.listdir(OUT)):

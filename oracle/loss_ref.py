@@ -7,6 +7,7 @@ CPU fp32 restatement of the reference's OWN numerics on the training-step path:
                                                      trainer/loss.py:10-80)
   * DistributionLoss std / covariance regularisers  (trainer/loss.py:254-297)
   * L1 penalty                                      (main.py:353-356)
+  * token warm-up objective                         (trainer/embedding_handler.py:288-318)
   * AdamW step (torch.optim.AdamW defaults)         (trainer/optimizer.py:18)
   * LR schedules                                    (main.py:236-240, 268-291)
 
@@ -150,6 +151,19 @@ class DistributionStats:
         adj = r - r.mean(0)
         cov = adj.T @ adj / (r.shape[0] - 1)
         return torch.norm(self.target_cov - cov, p="fro") / (r.shape[1] ** 2)
+
+
+def target_prompt_loss(prompt_embeds, target_embeds, pooled=None, target_pooled=None):
+    """TokenEmbeddingsHandler.compute_target_prompt_loss (trainer/embedding_handler.py:288-318), the objective of the
+    token warm-up loop (:321-399, weighted 0.2 there): MSE + (1 - mean cosine) to the encoded target prompt, plus a
+    quarter of the same on the pooled embedding.  Pinned by tests/golden/target_prompt_loss.pt."""
+    B = prompt_embeds.size(0)
+    target = target_embeds.expand(B, -1, -1)
+    loss = F.mse_loss(prompt_embeds, target) + 1.0 - F.cosine_similarity(prompt_embeds, target, dim=-1).mean()
+    if pooled is not None:
+        tp = target_pooled.expand(B, -1)
+        loss = loss + 0.25 * (F.mse_loss(pooled, tp) + 1.0 - F.cosine_similarity(pooled, tp, dim=-1).mean())
+    return loss
 
 
 def l1_penalty(params, weight):

@@ -332,6 +332,58 @@ class TrainStep:
         decay is lr * wd) and the regulariser is skipped (main.py:358), so only the LoRA optimiser remains."""
         self._unet_optimizer()
 
+    # -------------------------------------------------------------------------------- a20: token warm-up
+    def token_warmup(self, prompt_ids, target_ids, steps, lr, weight_decay=None):
+        """`pre_optimize_token_embeddings` (trainer/embedding_handler.py:321-399; off unless token_warmup_steps > 0 and a
+        gpt_description exists): optimise the token rows WITHOUT the denoiser so that the encoding of the bare trigger
+        prompt moves towards the encoding of a description.  Per step: encode the trigger prompt, loss = 0.2 * (MSE +
+        1 - cos [+ 0.25 * the same on the pooled embedding]) against the detached target (:288-318) + 0.5 * the token-std
+        regulariser (:384), back through the text encoders to the token rows, AdamW (a FRESH optimizer: its moments are
+        discarded afterwards, :345-354).  prompt_ids / target_ids: one int64 [77] row per tokenizer.  Runs eagerly (a
+        one-off loop before training); the objective's few hundred KB of arithmetic are torch ops, everything else is
+        the text-encoder plan of the step.  Returns the per-step loss values."""
+        text, ti, rt, B = self.text, self.ti, self.rt, self.B
+        dev = rt.device
+        ctxv = self.ctx.view(B, CTX_PAD, -1)
+
+        def encode(ids_per_tok):
+            text.set_ids([i.to(dev).view(1, T_TOKENS).expand(B, T_TOKENS) for i in ids_per_tok])
+            return text.forward(self.ctx)
+
+        pooled = encode(target_ids)                     # the target is encoded with the CURRENT rows and then detached
+        tgt = ctxv[:, :T_TOKENS].float().clone()
+        tgt_pooled = pooled.float().clone() if pooled is not None else None
+        tgt_n = tgt.norm(dim=-1, keepdim=True)
+        m, v = torch.zeros_like(ti.params), torch.zeros_like(ti.params)
+        wd = self.ti_wd if weight_decay is None else weight_decay
+        b1, b2 = self.betas
+        n_rows, D = B * T_TOKENS, tgt.shape[-1]
+        d_pooled = rt.zeros(*pooled.shape) if pooled is not None else None
+        losses = []
+        for k in range(1, steps + 1):
+            pooled = encode(prompt_ids)
+            p = ctxv[:, :T_TOKENS].float()
+            pn = p.norm(dim=-1, keepdim=True)
+            cos = (p * tgt).sum(-1, keepdim=True) / (pn * tgt_n)
+            loss = ((p - tgt) ** 2).mean() + 1.0 - cos.mean()
+            dp = 2.0 * (p - tgt) / (n_rows * D) - (tgt / (pn * tgt_n) - cos * p / (pn * pn)) / n_rows
+            if pooled is not None:
+                q = pooled.float()
+                qn, tn = q.norm(dim=-1, keepdim=True), tgt_pooled.norm(dim=-1, keepdim=True)
+                cq = (q * tgt_pooled).sum(-1, keepdim=True) / (qn * tn)
+                loss = loss + 0.25 * (((q - tgt_pooled) ** 2).mean() + 1.0 - cq.mean())
+                dq = 2.0 * (q - tgt_pooled) / q.numel() - (tgt_pooled / (qn * tn) - cq * q / (qn * qn)) / B
+                d_pooled.copy_(0.2 * 0.25 * dq)
+            self.dctx.zero_()
+            self.dctx.view(B, CTX_PAD, -1)[:, :T_TOKENS] = (0.2 * dp).to(self.dctx.dtype)
+            text.backward(self.dctx, d_pooled, ti.grad_rows)
+            ti.add_regulariser(std_loss_w=0.5)
+            ti.hyper[:9] = torch.tensor([lr, b1, b2, self.eps, wd, 1.0 - b1 ** k, 1.0 - b2 ** k, 0.0, 1.0], dtype=F32)
+            rt.ops.adamw_fused(ti.params, ti.grads, m, v, ti.hyper, None)
+            ti.refresh_tables()
+            losses.append(0.2 * float(loss) + float(ti.reg_loss))
+        return losses
+
     def grad_norm(self):
         """Global L2 norm of the LoRA gradients, the reference's debug read-out (loss.py:108-125, main.py:373-379)."""
         return float(self.unet.arena.grads.norm())

@@ -46,10 +46,11 @@ class TiState:
             r.copy_(src.to(self.rt.device, F32))
         self.refresh_tables()
 
-    def add_regulariser(self):
+    def add_regulariser(self, std_loss_w=None):
         """loss += std_loss_w * mean_enc( mean_tok( (sigma_bar - std(e_tok))^2 / v ) )   (loss.py:223-231); gradient
-        added to the row gradients, value accumulated in self.reg_loss."""
+        added to the row gradients, value accumulated in self.reg_loss.  std_loss_w defaults to the step's 0.01; the
+        token warm-up passes 0.5 (embedding_handler.py:384)."""
         self.reg_loss.zero_()
-        w = self.std_loss_w / len(self.encoders)
+        w = (self.std_loss_w if std_loss_w is None else std_loss_w) / len(self.encoders)
         for r, g, (tm, tv) in zip(self.rows, self.grad_rows, self.stats):
             self.rt.ops.ti_std_reg(r, g, self.reg_loss, target_mean=tm, target_var=tv, weight=w)

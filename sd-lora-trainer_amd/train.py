@@ -92,7 +92,7 @@ def synthetic_cache(cfg, n_images, h, w, vocab, n_tokens, seed):
         lists.append(l)
     return dict(latents=torch.randn(n_images, 4, h, w, generator=g) * cfg["scaling_factor"],
                 masks=(torch.rand(n_images, 1, h, w, generator=g) * 0.95 + 0.05).repeat(1, 4, 1, 1), input_ids=ids, token_lists=lists,
-                tok_list=[bos] + tok + [eos])
+                tok_list=[bos] + tok + [eos], description_ids=[bos] + torch.randint(1, bos - 1, (8,), generator=g).tolist() + [eos])
 
 
 def train(config: TrainingConfig, runtime=None):
@@ -129,6 +129,17 @@ def train(config: TrainingConfig, runtime=None):
     if text is not None:
         handler = TokenEmbeddingsHandler(ts.ti, config.inserting_list_tokens)
         handler.initialize_new_tokens(seed=config.seed)
+    # a20 token warm-up (main.py -> embedding_handler.pre_optimize_token_embeddings, :321-399): only with token_warmup_steps > 0
+    # and a description of the concept (training_attributes["gpt_description"], tokenised by the data stage: `description_ids`)
+    if text is not None and config.token_warmup_steps > 0 and (config.training_attributes or {}).get("gpt_description") \
+            and cache.get("description_ids") is not None and cache.get("tok_list") is not None:
+        def row(l):
+            r = torch.full((77,), int(cache["input_ids"][0, -1]), dtype=torch.int64)
+            r[:len(l)] = torch.tensor(l)
+            return r
+        n_enc = len(text.encoders)
+        warm = ts.token_warmup([row(cache["tok_list"])] * n_enc, [row(cache["description_ids"])] * n_enc, config.token_warmup_steps, config.ti_lr)
+        config.training_attributes = dict(config.training_attributes, token_warmup_losses=[warm[0], warm[-1]])
     g = torch.Generator(device=rt.device).manual_seed(config.seed)
     arena = unet.arena
     for e in arena.entries:            # peft init_lora_weights="gaussian" (optimizer.py:89): A ~ N(0, 1/r), B = 0

@@ -85,3 +85,16 @@ def test_daam_processor_attention_math(golden_dir):
         grads = torch.autograd.grad([o, scores], [x, ctx] + ws, [c["go"], c["gs"]])
         for got, key in zip(grads, ("gx", "gctx", "gwq", "gwk", "gwv", "gwo")):
             torch.testing.assert_close(got, c[key], rtol=1e-4, atol=1e-5)
+
+
+def test_target_prompt_loss(golden_dir):
+    """embedding_handler.py:288-318 (token warm-up objective): values and gradients from the reference's own method."""
+    for c in _load(golden_dir, "target_prompt_loss.pt"):
+        pe = c["prompt_embeds"].clone().requires_grad_(True)
+        pp = c["pooled"].clone().requires_grad_(True) if c["pooled"] is not None else None
+        loss = L.target_prompt_loss(pe, c["target"], pp, c["target_pooled"])
+        torch.testing.assert_close(loss, c["loss"], rtol=1e-6, atol=1e-7)
+        grads = torch.autograd.grad(loss, [pe] + ([pp] if pp is not None else []))
+        torch.testing.assert_close(grads[0], c["d_prompt"], rtol=1e-5, atol=1e-9)
+        if pp is not None:
+            torch.testing.assert_close(grads[1], c["d_pooled"], rtol=1e-5, atol=1e-9)

@@ -138,7 +138,7 @@ def test_prodigy_step_in_graph():
     assert all(x == x for x in losses) and max(losses[-5:]) < 1.05 * losses[0], losses      # adapts d without blowing up
 
 
-@pytest.mark.parametrize("extra", [{}, dict(text_encoder_lora_optimizer="adamw", text_encoder_lora_lr=1e-4, text_encoder_lora_rank=8, ti_optimizer="prodigy")])
+@pytest.mark.parametrize("extra", [{}, dict(text_encoder_lora_optimizer="adamw", text_encoder_lora_lr=1e-4, text_encoder_lora_rank=8, ti_optimizer="prodigy", token_warmup_steps=5, training_attributes={"gpt_description": "a synthetic concept"})])
 def test_train_generator_on_gpu(tmp_path, monkeypatch, extra):
     """main.py-style driver: config -> train() generator -> kohya checkpoint, on the HIP path with hipGraph replay.
     Second case: text-encoder LoRA (a21) next to the UNet LoRA, Prodigy on the token rows (a17)."""
@@ -164,6 +164,8 @@ def test_train_generator_on_gpu(tmp_path, monkeypatch, extra):
     lora_files = [n for n in os.listdir(out) if n.endswith("_sdxl_lora.safetensors") or n.endswith("_tinyxl_lora.safetensors")]
     assert lora_files
     if extra:
+        w0, w1 = ta["training_attributes"]["token_warmup_losses"]        # a20 ran and its objective went down
+        assert w1 < w0, (w0, w1)
         from safetensors.torch import load_file
         keys = list(load_file(os.path.join(out, lora_files[0])))
         assert any(k.startswith("lora_te1_") for k in keys) and any(k.startswith("lora_te2_") for k in keys) and any(k.startswith("lora_unet_") for k in keys)

@@ -219,3 +219,59 @@ def test_text_encoder_lora_matches_oracle(version, B, rank):
     assert k0.startswith("lora_te1_") and k0.endswith("encoder_layers_0_self_attn_q_proj") and k0 + ".lora_down.weight" in ksd
     if xl:
         assert any(k.startswith("lora_te2_") for k in ksd)
+
+
+@pytest.mark.parametrize("version", ["tiny15", "tinyxl"])
+def test_token_warmup_matches_oracle(version):
+    """a20 `pre_optimize_token_embeddings` (trainer/embedding_handler.py:321-399): k AdamW steps on the token rows against
+    the same loop written with Hugging Face CLIP + autograd + torch.optim.AdamW on the full (gradient-masked) tables."""
+    cfg = U.CONFIGS[version]
+    xl = cfg["addition"]
+    B, h, steps, lr = 2, 16, 4, 2e-3
+    if xl:
+        hf = [_hf("quick_gelu", False, 64, 1, 11), _hf("gelu", True, 64, 1, 12, proj=cfg["proj_class_in"] - 6 * cfg["addition_time_embed_dim"])]
+    else:
+        hf = [_hf("quick_gelu", False, 64, 2, 11)]
+    prompt = torch.full((77,), EOS, dtype=torch.int64)
+    prompt[:5] = torch.tensor([BOS] + TRAIN_IDS + [EOS])
+    target = torch.full((77,), EOS, dtype=torch.int64)
+    target[:6] = torch.tensor([BOS, 5, 17, 33, 41, EOS])
+
+    rt = unet_mod.Runtime("cpu", B, act_dtype=torch.float32, ops=emu_ops)
+    unet = unet_mod.UNet(rt, topology.CONFIGS[version], U.init_unet_state(cfg, seed=0), lora_rank=4)
+    sds = [{k: v.detach().clone() for k, v in m.state_dict().items()} for m in hf]
+    kw = [dict(heads=1, act="quick_gelu", mode="penultimate", with_projection=False), dict(heads=1, act="gelu", mode="penultimate", with_projection=True)] \
+        if xl else [dict(heads=2, act="quick_gelu", mode="last", with_projection=False)]
+    encs = [clip_mod.ClipTextEncoder(rt, f"te{i + 1}", sds[i], n_train=NTOK, **k) for i, k in enumerate(kw)]
+    text = step_mod.TextStack(rt, encs, pool_mode="first_eos", eos_token_id=EOS)
+    ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), text=text, n_tokens=NTOK)
+    got_losses = ts.token_warmup([prompt] * len(encs), [target] * len(encs), steps, lr)
+
+    embs = [m.get_input_embeddings().weight for m in hf]
+    stats = [L.DistributionStats(e.detach()[:-NTOK].clone()) for e in embs]
+    opt = torch.optim.AdamW(embs, lr=lr, weight_decay=0.0)
+
+    def encode(ids):
+        outs = [m(input_ids=ids.view(1, 77), output_hidden_states=True) for m in hf]
+        if xl:
+            return torch.cat([outs[0].hidden_states[-2], outs[1].hidden_states[-2]], dim=-1), outs[1].text_embeds
+        return outs[0].last_hidden_state, None
+    with torch.no_grad():
+        tgt, tgt_pooled = encode(target)
+    ref_losses = []
+    for _ in range(steps):
+        pe, pooled = encode(prompt)
+        loss = 0.2 * L.target_prompt_loss(pe, tgt, pooled, tgt_pooled)
+        loss = loss + 0.5 * torch.stack([st.std_loss(e[-NTOK:]) for st, e in zip(stats, embs)]).mean()
+        opt.zero_grad()
+        loss.backward()
+        for e in embs:
+            e.grad.data[:-NTOK] *= 0.0
+        opt.step()
+        ref_losses.append(float(loss))
+    torch.testing.assert_close(torch.tensor(got_losses), torch.tensor(ref_losses), rtol=2e-4, atol=1e-6)
+    for r, e, enc in zip(ts.ti.rows, embs, encs):
+        moved = float((e[-NTOK:] - enc.table[-NTOK:]).abs().max())
+        torch.testing.assert_close(r, e.detach()[-NTOK:], rtol=0, atol=2e-2 * steps * lr)
+        assert float((r - e.detach()[-NTOK:]).abs().max()) <= 2e-2 * steps * lr, moved
+    assert float(ts.ti.m.abs().max()) == 0.0                 # the warm-up optimizer's moments are not carried into training

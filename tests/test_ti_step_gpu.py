@@ -211,3 +211,60 @@ def test_text_encoder_lora_gpu_matches_oracle(version, B, rank):
     ts.run(1e-3, lr_ti=0.0, lr_te=1e-3)          # no frozen fast path while the text encoders are LoRA-trained
     torch.cuda.synchronize()
     assert math.isfinite(ts.total_loss())
+
+
+def test_token_warmup_gpu_matches_oracle():
+    """a20 on the HIP path (bf16 text encoders) against the Hugging Face + autograd + torch.optim.AdamW loop."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import loss_ref as L
+    from oracle import unet_ref as U
+    import sd_lora_trainer_amd.clip as clip_mod
+    import sd_lora_trainer_amd.step as step_mod
+    import sd_lora_trainer_amd.unet as unet_mod
+    from sd_lora_trainer_amd import topology
+    from tests.test_ti_step_cpu import BOS
+    version, B, h, steps, lr = "tinyxl", 2, 32, 4, 2e-3
+    cfg = U.CONFIGS[version]
+    hf = [_hf("quick_gelu", False, 64, 1, 11), _hf("gelu", True, 64, 1, 12, proj=cfg["proj_class_in"] - 6 * cfg["addition_time_embed_dim"])]
+    for m in hf:
+        for p in m.parameters():
+            p.data = p.data.to(torch.bfloat16).float()
+    prompt = torch.full((77,), EOS, dtype=torch.int64)
+    prompt[:5] = torch.tensor([BOS] + TRAIN_IDS + [EOS])
+    target = torch.full((77,), EOS, dtype=torch.int64)
+    target[:6] = torch.tensor([BOS, 5, 17, 33, 41, EOS])
+    rt = unet_mod.Runtime("cuda:0", B)
+    unet = unet_mod.UNet(rt, topology.CONFIGS[version], U.init_unet_state(cfg, seed=0), lora_rank=4)
+    sds = [{k: v.detach().clone() for k, v in m.state_dict().items()} for m in hf]
+    encs = [clip_mod.ClipTextEncoder(rt, "te1", sds[0], heads=1, act="quick_gelu", mode="penultimate", with_projection=False, n_train=NTOK),
+            clip_mod.ClipTextEncoder(rt, "te2", sds[1], heads=1, act="gelu", mode="penultimate", with_projection=True, n_train=NTOK)]
+    text = step_mod.TextStack(rt, encs, pool_mode="first_eos", eos_token_id=EOS)
+    ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), text=text, n_tokens=NTOK)
+    rows0 = [r.clone() for r in ts.ti.rows]
+    got = ts.token_warmup([prompt] * 2, [target] * 2, steps, lr)
+
+    embs = [m.get_input_embeddings().weight for m in hf]
+    stats = [L.DistributionStats(e.detach()[:-NTOK].clone()) for e in embs]
+    opt = torch.optim.AdamW(embs, lr=lr, weight_decay=0.0)
+
+    def encode(ids):
+        outs = [m(input_ids=ids.view(1, 77), output_hidden_states=True) for m in hf]
+        return torch.cat([outs[0].hidden_states[-2], outs[1].hidden_states[-2]], dim=-1), outs[1].text_embeds
+    with torch.no_grad():
+        tgt, tgt_pooled = encode(target)
+    ref = []
+    for _ in range(steps):
+        pe, pooled = encode(prompt)
+        loss = 0.2 * L.target_prompt_loss(pe, tgt, pooled, tgt_pooled) + 0.5 * torch.stack([st.std_loss(e[-NTOK:]) for st, e in zip(stats, embs)]).mean()
+        opt.zero_grad()
+        loss.backward()
+        for e in embs:
+            e.grad.data[:-NTOK] *= 0.0
+        opt.step()
+        ref.append(float(loss))
+    assert all(abs(a - b) <= 2e-2 * abs(b) for a, b in zip(got, ref)), (got, ref)
+    assert got[-1] < got[0]
+    for r, r0, e in zip(ts.ti.rows, rows0, embs):
+        cos, rel = _cos_rel(r - r0, e.detach()[-NTOK:] - r0.cpu())
+        assert cos >= 0.9, f"row update direction cos {cos}"        # Adam's first steps are ~lr*sign(g): sign flips of tiny g
