@@ -189,6 +189,43 @@ def groupnorm_bwd(x1, x2, dy, dx, stats, bstats, *, B, HW, gamma, beta, eps, sil
     return dx
 
 
+def groupnorm_affine_grad(x1, x2, dy, stats, dgamma, dbeta, *, B, HW, gamma, beta, eps, silu):
+    x = _gn_cat(x1, x2).detach()
+    C = x.shape[1]
+    ga, be = gamma.detach().float().clone().requires_grad_(True), beta.detach().float().clone().requires_grad_(True)
+    z = F.group_norm(x.reshape(B, HW, C).permute(0, 2, 1), 32, ga, be, eps)
+    if silu:
+        z = F.silu(z)
+    g1, g2 = torch.autograd.grad(z.permute(0, 2, 1).reshape(B * HW, C), [ga, be], dy.float())
+    dgamma.copy_(g1)
+    dbeta.copy_(g2)
+
+
+def layernorm_affine_grad(x, dy, stats, dgamma, dbeta):
+    xh = F.layer_norm(x.detach().float(), (x.shape[1],), None, None, 1e-5)
+    dgamma.copy_((dy.float() * xh).sum(0))
+    dbeta.copy_(dy.float().sum(0))
+
+
+def wgrad_transpose(x, out):
+    out.zero_()
+    out[:, :x.shape[0]] = x.t()
+    return out
+
+
+def wgrad_im2col_t(x, out, *, B, H, W, stride=1, ups=1):
+    C = x.shape[1]
+    img = x.float().reshape(B, H, W, C).permute(0, 3, 1, 2)
+    if ups == 2:
+        img = F.interpolate(img, scale_factor=2, mode="nearest")
+    cols = F.unfold(img, 3, padding=1, stride=stride)                  # [B, C*9, L], row c*9 + tap
+    L = cols.shape[-1]
+    cols = cols.reshape(B, C, 9, L).permute(2, 1, 0, 3).reshape(9 * C, B * L)     # row tap*C + c, column (b, oy, ox)
+    out.zero_()
+    out[:, :B * L] = cols.to(out.dtype)
+    return out
+
+
 def layernorm_fwd(x, y, stats, *, gamma, beta, eps=1e-5):
     y.copy_(F.layer_norm(x.float(), (x.shape[1],), gamma.float(), beta.float(), eps).to(y.dtype))
     return y

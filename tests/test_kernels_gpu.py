@@ -547,3 +547,83 @@ def test_ti_kernels_and_gemm_accumulate(ops):
     close(acc_g, acc_c, tol=2e-3, what="gemm fp32 accumulate")
     xs = rnd(2 * 100, 128, g=g)
     close(ops.colsum(xs.cuda(), torch.empty(2, 128, dtype=BF, device="cuda"), B=2, R=100), E.colsum(xs, torch.empty(2, 128, dtype=BF), B=2, R=100), what="colsum bf16")
+
+
+# ------------------------------------------------------------------------------------------------ full fine-tune support
+@pytest.mark.parametrize("M,C", [(4096, 320), (77, 64), (130, 8), (2, 1280)])
+def test_wgrad_transpose(ops, M, C):
+    g = torch.Generator().manual_seed(0)
+    Mp = (M + 63) // 64 * 64
+    big = torch.randn(M, C + 8, generator=g).to(BF)
+    x = big[:, :C]                                                   # strided source rows
+    ref = E.wgrad_transpose(x, torch.zeros(C, Mp, dtype=BF))
+    out = torch.full((C, Mp), 7.0, dtype=BF, device="cuda")
+    ops.wgrad_transpose(big.cuda()[:, :C], out)
+    assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("B,H,W,C,stride,ups", [(2, 16, 16, 64, 1, 1), (1, 8, 12, 320, 1, 1), (2, 16, 16, 128, 2, 1), (1, 8, 8, 64, 1, 2), (3, 5, 7, 8, 1, 1)])
+def test_wgrad_im2col_t(ops, B, H, W, C, stride, ups):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B * H * W, C, generator=g).to(BF)
+    M = B * (H * ups // stride) * (W * ups // stride)
+    Mp = (M + 63) // 64 * 64
+    ref = E.wgrad_im2col_t(x, torch.zeros(9 * C, Mp, dtype=BF), B=B, H=H, W=W, stride=stride, ups=ups)
+    out = torch.full((9 * C, Mp), 7.0, dtype=BF, device="cuda")
+    ops.wgrad_im2col_t(x.cuda(), out, B=B, H=H, W=W, stride=stride, ups=ups)
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_weight_gradient_gemm(ops):
+    """dW = dY^T X through the transposed panels + sdlt_gemm_bf16 (fp32 output), linear and 3x3 conv (vs autograd)."""
+    g = torch.Generator().manual_seed(2)
+    M, N, K = 1000, 192, 320
+    x, dy = torch.randn(M, K, generator=g).to(BF), torch.randn(M, N, generator=g).to(BF)
+    Mp = 1024
+    xT, dyT = torch.empty(K, Mp, dtype=BF, device="cuda"), torch.empty(N, Mp, dtype=BF, device="cuda")
+    ops.wgrad_transpose(x.cuda(), xT)
+    ops.wgrad_transpose(dy.cuda(), dyT)
+    dW = torch.zeros(N, K, device="cuda")
+    ops.gemm(dyT, xT, dW)
+    close(dW, dy.float().t() @ x.float(), tol=2e-3, what="linear dW")
+    B, H, W, Cin, Cout = 2, 16, 16, 64, 128
+    xi = torch.randn(B * H * W, Cin, generator=g).to(BF)
+    dyo = torch.randn(B * H * W, Cout, generator=g).to(BF)
+    w = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    y = torch.nn.functional.conv2d(xi.float().reshape(B, H, W, Cin).permute(0, 3, 1, 2), w, padding=1)
+    (gw,) = torch.autograd.grad(y, w, dyo.float().reshape(B, H, W, Cout).permute(0, 3, 1, 2))
+    cols, dyT = torch.empty(9 * Cin, B * H * W, dtype=BF, device="cuda"), torch.empty(Cout, B * H * W, dtype=BF, device="cuda")
+    ops.wgrad_im2col_t(xi.cuda(), cols, B=B, H=H, W=W)
+    ops.wgrad_transpose(dyo.cuda(), dyT)
+    dWc = torch.zeros(Cout, 9 * Cin, device="cuda")
+    ops.gemm(dyT, cols, dWc)
+    close(dWc, gw.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin), tol=2e-3, what="conv dW (tap-major)")
+
+
+@pytest.mark.parametrize("two,silu", [(False, True), (True, True), (False, False)])
+def test_norm_affine_grads(ops, two, silu):
+    g = torch.Generator().manual_seed(3)
+    B, HW, C = 2, 96, 128
+    x = (torch.randn(B * HW, C, generator=g) * 1.5 + 0.3).to(BF)
+    dy = torch.randn(B * HW, C, generator=g).to(BF)
+    gamma, beta = torch.randn(C, generator=g) * 0.2 + 1.0, torch.randn(C, generator=g) * 0.1
+    x1, x2 = (x[:, :48].contiguous(), x[:, 48:].contiguous()) if two else (x, None)
+    dgr, dbr = torch.zeros(C), torch.zeros(C)
+    E.groupnorm_affine_grad(x1, x2, dy, None, dgr, dbr, B=B, HW=HW, gamma=gamma, beta=beta, eps=1e-5, silu=silu)
+    y, stats = torch.empty(B * HW, C, dtype=BF, device="cuda"), torch.zeros(B * 64, device="cuda")
+    kw = dict(B=B, HW=HW, gamma=gamma.cuda(), beta=beta.cuda(), eps=1e-5, silu=silu)
+    d1, d2 = x1.cuda(), (x2.cuda() if two else None)
+    ops.groupnorm_fwd(d1, d2, y, stats, **kw)
+    dg, db = torch.full((C,), 9.0, device="cuda"), torch.full((C,), 9.0, device="cuda")
+    ops.groupnorm_affine_grad(d1, d2, dy.cuda(), stats, dg, db, **kw)
+    close(dg, dgr, tol=5e-3, what="GN dgamma")
+    close(db, dbr, tol=5e-3, what="GN dbeta")
+    # LayerNorm
+    M = 300
+    xl, dyl = torch.randn(M, C, generator=g).to(BF), torch.randn(M, C, generator=g).to(BF)
+    E.layernorm_affine_grad(xl, dyl, None, dgr, dbr)
+    yl, st = torch.empty(M, C, dtype=BF, device="cuda"), torch.zeros(M * 2, device="cuda")
+    ops.layernorm_fwd(xl.cuda(), yl, st, gamma=gamma.cuda(), beta=beta.cuda())
+    ops.layernorm_affine_grad(xl.cuda(), dyl.cuda(), st, dg, db)
+    close(dg, dgr, tol=5e-3, what="LN dgamma")
+    close(db, dbr, tol=5e-3, what="LN dbeta")
