@@ -1,0 +1,142 @@
+"""Full-UNet fine-tune: `is_lora = False` in the reference means `unet.requires_grad_(True)` and an
+optimizer over `unet.parameters()` (/root/reference main.py:144-149, trainer/optimizer.py:6-39); the example config is
+train_configs/full_finetuning_example.json (SDXL, 512 px, batch 4, no textual inversion).
+
+`WeightTrainer` is the flat fp32 master copy of EVERY UNet parameter (weights, biases, norm affine) with its gradient and
+AdamW moments, the weight-gradient plan the leaf layers call from their backward, and the refresh of the bf16 compute
+copies (both orientations) after each optimizer step.
+
+  * dW[N,K] = dY^T X contracts over tokens: both operands are transposed once into token-contiguous panels
+    (sdlt_wgrad_transpose / sdlt_wgrad_im2col_t) and multiplied by the MFMA GEMM with an fp32 output that IS the
+    parameter's slice of the gradient arena (no per-parameter gradient tensors, one all-reduce buffer for data parallel).
+  * biases: column sums of dY; norm affine: sdlt_*_affine_grad.  Biases and gamma/beta are used by the kernels in fp32,
+    so the layers read them straight from the master arena - only matrix weights have bf16 copies to refresh.
+  * 3x3 conv weights are stored tap-major [Cout, (ky, kx, ci)] like the forward GEMM operand; `export()` / `load()`
+    convert to / from the PyTorch [Cout, Cin, 3, 3] layout of the checkpoint.
+"""
+import torch
+
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+class WeightTrainer:
+    def __init__(self, rt):
+        self.rt = rt
+        self.entries = []          # dict(name, off, shape (arena layout), kind)
+        self.by_name = {}
+        self.n = 0
+        self._binds = []           # callables run at finalize (point layer attributes at arena views)
+        self._shadow = []          # ShadowPlan descriptors (offset, rows, cols, src_ld, dst, dstT)
+        self.params = self.grads = self.m = self.v = None
+        self.registering = False   # True only while the UNet builds its layers (the text encoders share the leaf classes)
+
+    # ------------------------------------------------------------------ registration (layer constructors)
+    def add(self, name, init, kind="matrix"):
+        """init: fp32 tensor in ARENA layout.  Offsets are kept 16-byte aligned so every slice can be a GEMM output."""
+        self.n = (self.n + 3) // 4 * 4
+        e = dict(name=name, off=self.n, shape=tuple(init.shape), kind=kind, init=init.detach().to("cpu", F32).contiguous())
+        self.n += init.numel()
+        self.entries.append(e)
+        self.by_name[name] = e
+        return e
+
+    def on_finalize(self, fn):
+        self._binds.append(fn)
+
+    def shadow(self, entry, rows, cols, src_ld, dst, dstT, offset=0):
+        self._shadow.append((entry, offset, rows, cols, src_ld, dst, dstT))
+
+    def finalize(self):
+        rt = self.rt
+        z = lambda: torch.zeros(self.n, dtype=F32, device=rt.device)  # noqa: E731
+        self.params, self.grads, self.m, self.v = z(), z(), z(), z()
+        for e in self.entries:
+            self.view(e).copy_(e.pop("init").to(rt.device))
+        for fn in self._binds:
+            fn()
+        sh = [(e["off"] + o, r, c, ld, d, dt) for (e, o, r, c, ld, d, dt) in self._shadow]
+        self._plan = rt.ops.ShadowPlan(sh, rt.device) if sh else None
+
+    def view(self, e, which="params"):
+        t = getattr(self, which)
+        n = 1
+        for s in e["shape"]:
+            n *= s
+        return t[e["off"]: e["off"] + n].view(e["shape"])
+
+    def refresh(self):
+        """fp32 master -> bf16 compute copies (W and W^T of every matrix / conv weight)."""
+        if self._plan is not None:
+            self._plan.run(self.params)
+
+    # ------------------------------------------------------------------ weight-gradient plan (leaf backward)
+    def _panel(self, key, rows, Mp):
+        n = rows * Mp
+        return self.rt.scratch(key, (n + 1) // 2).view(BF16)[:n].view(rows, Mp)
+
+    def linear(self, went, bent, xs, dy, n_rows=None):
+        """went: [N, K] weight entry; xs: list of inputs whose channel concatenation is the layer input ([M, K_i] each);
+        dy [M, >=N] (only the first N columns are the layer's output gradient)."""
+        ops = self.rt.ops
+        N, K = went["shape"]
+        M = dy.shape[0]
+        Mp = _pad64(M)
+        dyT = ops.wgrad_transpose(dy[:, :N] if dy.shape[1] != N else dy, self._panel("wg_dy", N, Mp))
+        gW = self.view(went, "grads")
+        k0 = 0
+        for x in xs:
+            Ki = x.shape[1]
+            xT = ops.wgrad_transpose(x, self._panel("wg_x", Ki, Mp))
+            ops.gemm(dyT, xT, gW[:, k0:k0 + Ki] if len(xs) > 1 else gW)
+            k0 += Ki
+        assert k0 == K, (went["name"], k0, K)
+        if bent is not None:
+            self.bias(bent, dy, N)
+
+    def bias(self, bent, dy, N):
+        ops = self.rt.ops
+        M, Nd = dy.shape
+        if Nd == N and N % 64 == 0:
+            ops.colsum(dy, self.view(bent, "grads").view(1, N), B=1, R=M)
+        else:                      # conv_out: 4 real channels inside a 64-wide gradient
+            tmp = self.rt.scratch("wg_bias", _pad64(Nd)).view(1, -1)[:, :Nd]
+            ops.colsum(dy, tmp, B=1, R=M)
+            self.view(bent, "grads").copy_(tmp[0, :N])
+
+    def conv3x3(self, went, bent, x, dy, *, B, H, W, Cin, stride, ups):
+        """went: [Cout, 9*Cin] (tap-major); x NHWC [B*H*W, >=Cin]; dy [M, Cout_p]."""
+        ops = self.rt.ops
+        Cout = went["shape"][0]
+        M = dy.shape[0]
+        Mp = _pad64(M)
+        dyT = ops.wgrad_transpose(dy[:, :Cout] if dy.shape[1] != Cout else dy, self._panel("wg_dy", Cout, Mp))
+        cols = ops.wgrad_im2col_t(x[:, :Cin] if x.shape[1] != Cin else x, self._panel("wg_x", 9 * Cin, Mp), B=B, H=H, W=W,
+                                  stride=stride, ups=ups)
+        ops.gemm(dyT, cols, self.view(went, "grads"))
+        self.bias(bent, dy, Cout)
+
+    # ------------------------------------------------------------------ host side: checkpoint layouts
+    def export(self, which="params"):
+        """-> {diffusers parameter name: fp32 tensor in the PyTorch layout}."""
+        out = {}
+        for e in self.entries:
+            t = self.view(e, which).detach().float().cpu()
+            if e["kind"] == "conv3x3":
+                co, k9 = t.shape
+                t = t.reshape(co, 3, 3, k9 // 9).permute(0, 3, 1, 2).contiguous()
+            elif e["kind"] == "conv1x1":
+                t = t.reshape(*t.shape, 1, 1)
+            out[e["name"]] = t
+        return out
+
+    def load(self, sd):
+        for e in self.entries:
+            t = sd[e["name"]].to(self.rt.device, F32)
+            if e["kind"] == "conv3x3":
+                t = t.permute(0, 2, 3, 1).reshape(e["shape"])
+            self.view(e).copy_(t.reshape(e["shape"]))
+        self.refresh()

@@ -46,6 +46,7 @@ class Runtime:
         self.want_dpooled = False    # SDXL: back-propagate into the pooled text embedding (textual inversion)
         self.dsemb = None
         self.daam_applied = False    # this step's score-gradient GEMMs were issued up front (UNet.daam_backward)
+        self.trainer = None          # fullft.WeightTrainer when the whole UNet is trained (is_lora = False)
         self._scratch = {}
 
     def scratch(self, key, nfloats):
@@ -176,6 +177,22 @@ class Linear(_Module):
         self.bias = b.to(rt.device, F32).contiguous() if b is not None else None
         self.lora = arena.add(name, self.N, self.K) if arena is not None else None
         self.arena = arena
+        # full fine-tune: the fp32 master of weight / bias lives in the trainer's arena (fullft.WeightTrainer)
+        tr = rt.trainer if (rt.trainer is not None and rt.trainer.registering) else None
+        self.trainer = tr
+        if tr is not None:
+            self.went = tr.add(name + ".weight", w.float(), "conv1x1" if sd[name + ".weight"].dim() == 4 else "matrix")
+            self.bent = tr.add(name + ".bias", b.float(), "vector") if b is not None else None
+            tr.on_finalize(self._bind_trainer)
+
+    def _bind_trainer(self):
+        tr = self.trainer
+        tr.shadow(self.went, self.N, self.K, self.K, self.W, self.Wt)     # bf16 W (and W^T) follow the master after each step
+        if self.bent is not None:
+            self.bias = tr.view(self.bent)
+
+    def weight_grad(self, dy, xs=None):
+        self.trainer.linear(self.went, self.bent, xs if xs is not None else [self._x], dy)
 
     def forward(self, x, *, residual=None, Ct=None, key="y", out=None, train=True):
         M = x.shape[0]
@@ -184,6 +201,8 @@ class Linear(_Module):
         if self.lora is not None:
             T = self.buf("T", M, self.arena.Rp) if train else None
             lora = (self.lora["A_s"], self.lora["B_s"], self.arena.scale, T)
+            self._x = x
+        if self.trainer is not None:
             self._x = x
         self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, residual=residual, Ct=Ct)
         return y
@@ -201,6 +220,8 @@ class Linear(_Module):
                     dict(P=dy, Q=self._b["T"], out=self.lora["gB"], M=M, Cw=self.N, R=r, rank_major=False),
                     dict(P=self._x, Q=U, out=self.lora["gA"], M=M, Cw=self.K, R=r, rank_major=True)]
                 self._registered = True
+        if self.trainer is not None:
+            self.weight_grad(dy)
         self.rt.ops.gemm(dy, self.Wt, dx, lora=lora, residual=dres, Ct=Ct)
         return dx
 
@@ -223,6 +244,17 @@ class StackedLinear(_Module):
         self.bias = torch.cat([m.bias for m in members]).contiguous() if members[0].bias is not None else None
         self.arena = members[0].arena
         self.has_lora = members[0].lora is not None
+        self.trainer = members[0].trainer
+        if self.trainer is not None:
+            # the members' master weights are consecutive in the trainer's arena: one [G*N, K] gradient, one dW GEMM
+            assert self.bias is None, "stacked projections with biases are not part of the UNet"
+            e0 = members[0].went
+            for g, m in enumerate(members):
+                assert m.went["off"] == e0["off"] + g * N * K, "stacked members must be registered back to back"
+            self.went = dict(name=name + ".weight", off=e0["off"], shape=(self.G * N, K), kind="matrix")
+            self.Wt = self.W.t().contiguous()
+            for g, m in enumerate(members):
+                m.Wt = self.Wt[:, g * N:(g + 1) * N]
         if self.has_lora:
             Rp = self.arena.Rp
             self.A_cat, self.B_cat = rt.zeros(self.G * Rp, K), rt.zeros(self.G * N, Rp)
@@ -274,6 +306,8 @@ class StackedLinear(_Module):
             for m in self.members:
                 m.Wt = None          # the per-member transposes are dead once the stacked one exists
         dx = out if out is not None else self.buf("dx", M, self.K)
+        if self.trainer is not None:
+            self.trainer.linear(self.went, None, [self.members[0]._x], dy_cat)
         if not self.has_lora:
             self.rt.ops.gemm(dy_cat, self.Wt, dx, residual=dres)
             return dx
@@ -321,6 +355,24 @@ class Conv3x3(_Module):
         self.bias = sd[name + ".bias"].to(rt.device, F32).contiguous()
         self.lora = arena.add(name, self.Cout, 9 * self.Cin, conv_cin=self.Cin) if arena is not None else None
         self.arena = arena
+        tr = rt.trainer if (rt.trainer is not None and rt.trainer.registering) else None
+        self.trainer = tr
+        if tr is not None:         # master weight tap-major [Cout, (ky, kx, ci)], like the forward GEMM operand
+            self.went = tr.add(name + ".weight", w.permute(0, 2, 3, 1).reshape(self.Cout, 9 * self.Cin), "conv3x3")
+            self.bent = tr.add(name + ".bias", sd[name + ".bias"].float(), "vector")
+            tr.on_finalize(self._bind_trainer)
+
+    def _bind_trainer(self):
+        tr, Cin, Cout = self.trainer, self.Cin, self.Cout
+        self.bias = tr.view(self.bent)
+        for tap in range(9):       # per tap: [Cout, Cin] block of the master -> forward operand slice and (transposed) dX operand slice
+            dst = self.Wf[:, tap * self.Cin_p: tap * self.Cin_p + Cin]
+            dstT = self.Wb[:, tap * self.Cout_p: tap * self.Cout_p + Cout] if self.Wb is not None else None
+            tr.shadow(self.went, Cout, Cin, 9 * Cin, dst, dstT, offset=tap * Cin)
+
+    def weight_grad(self, dy):
+        B, H, W, Hout, Wout = self._dims
+        self.trainer.conv3x3(self.went, self.bent, self._x, dy, B=B, H=H, W=W, Cin=self.Cin, stride=self.stride, ups=self.ups)
 
     def geom(self, B, H, W):
         """H, W = stored input spatial dims -> (fwd ConvGeom, Hout, Wout)."""
@@ -337,6 +389,8 @@ class Conv3x3(_Module):
             T = self.buf("T", M, self.arena.Rp) if train else None
             lora = (self.lora["A_s"], self.lora["B_s"], self.arena.scale, T)
             self._x, self._g = x, g
+        if self.trainer is not None:
+            self._x = x
         self.rt.ops.gemm(x, self.Wf, y, conv=g, lora=lora, bias=self.bias, rowbias=rowbias, rows_per_batch=Hout * Wout,
                          residual=residual)
         self._dims = (B, H, W, Hout, Wout)
@@ -347,6 +401,8 @@ class Conv3x3(_Module):
         B, H, W, Hout, Wout = self._dims
         rt = self.rt
         assert dy.shape[1] == self.Cout_p, "conv backward wants dy padded to a multiple of 64 channels"
+        if self.trainer is not None:
+            self.weight_grad(dy)
         if self.ups == 2:
             # dX of conv(up2(x)): transposed conv at the upsampled resolution, then 2x2 block sums
             gb = _ops.ConvGeom(B, Hout, Wout, self.Cout_p, Hout, Wout, flip=1)
@@ -375,12 +431,27 @@ class Conv3x3(_Module):
         return dx
 
 
+def _register_affine(layer, rt, name, sd):
+    """full fine-tune: gamma / beta are read by the norm kernels in fp32 straight from the trainer's master arena."""
+    tr = rt.trainer if (rt.trainer is not None and rt.trainer.registering) else None
+    layer.trainer = tr
+    if tr is None:
+        return
+    layer.gent = tr.add(name + ".weight", sd[name + ".weight"].float(), "vector")
+    layer.bent = tr.add(name + ".bias", sd[name + ".bias"].float(), "vector")
+
+    def bind():
+        layer.gamma, layer.beta = tr.view(layer.gent), tr.view(layer.bent)
+    tr.on_finalize(bind)
+
+
 class GroupNorm(_Module):
     def __init__(self, rt, name, sd, eps, silu):
         super().__init__(rt, name)
         self.gamma = sd[name + ".weight"].to(rt.device, F32).contiguous()
         self.beta = sd[name + ".bias"].to(rt.device, F32).contiguous()
         self.eps, self.silu, self.C = eps, silu, self.gamma.numel()
+        _register_affine(self, rt, name, sd)
 
     def forward(self, x1, x2, B, HW):
         y = self.buf("y", B * HW, self.C)
@@ -391,6 +462,10 @@ class GroupNorm(_Module):
     def backward(self, dy, dres=None, out=None):
         x1, x2, B, HW = self._in
         dx = out if out is not None else self.buf("dx", B * HW, self.C)
+        if self.trainer is not None:
+            tr = self.trainer
+            self.rt.ops.groupnorm_affine_grad(x1, x2, dy, self._b["stats"], tr.view(self.gent, "grads"), tr.view(self.bent, "grads"), B=B, HW=HW,
+                                              gamma=self.gamma, beta=self.beta, eps=self.eps, silu=self.silu)
         return self.rt.ops.groupnorm_bwd(x1, x2, dy, dx, self._b["stats"], self.buf("bstats", B * 64, dtype=F32), B=B, HW=HW,
                                          gamma=self.gamma, beta=self.beta, eps=self.eps, silu=self.silu, dres=dres)
 
@@ -401,6 +476,7 @@ class LayerNorm(_Module):
         self.gamma = sd[name + ".weight"].to(rt.device, F32).contiguous()
         self.beta = sd[name + ".bias"].to(rt.device, F32).contiguous()
         self.eps = eps
+        _register_affine(self, rt, name, sd)
 
     def forward(self, x, out=None):
         y = out if out is not None else self.buf("y", *x.shape)
@@ -409,6 +485,9 @@ class LayerNorm(_Module):
 
     def backward(self, dy, dres=None, out=None):
         dx = out if out is not None else self.buf("dx", *self._x.shape)
+        if self.trainer is not None:
+            tr = self.trainer
+            self.rt.ops.layernorm_affine_grad(self._x, dy, self._b["stats"], tr.view(self.gent, "grads"), tr.view(self.bent, "grads"))
         return self.rt.ops.layernorm_bwd(self._x, dy, dx, self._b["stats"], gamma=self.gamma, dres=dres)
 
 
@@ -621,23 +700,39 @@ class ResnetBlock(_Module):
         x1, x2, B, H, W = self._in
         dh2 = self.conv2.backward(dout)
         dc1 = self.norm2.backward(dh2)
-        if rt.want_dpooled:
+        if rt.want_dpooled or self.temb.trainer is not None:
             # h = conv1(.) + time_emb_proj(silu(emb))[b]: d(proj output)[b] = column sums of dc1 over the pixels of image b;
             # accumulated over all resnets into d silu(emb)
             dtp = rt.ops.colsum(dc1, self.buf("dtp", B, self.cout), B=B, R=H * W)
             self.temb.backward(dtp, dres=rt.dsemb, out=rt.dsemb)
         dh1 = self.conv1.backward(dc1)
-        dres = dout if self.shortcut is None else self.shortcut.backward(dout, key="dsc")
+        if self.shortcut is not None and self.shortcut.trainer is not None:      # its forward is issued here, not through Linear.forward
+            self.shortcut._x = x1
+            self.shortcut.trainer = None                                       # (the hook inside backward would not know about x2)
+            try:
+                dres = self.shortcut.backward(dout, key="dsc")
+            finally:
+                self.shortcut.trainer = rt.trainer
+            self.shortcut.weight_grad(dout, xs=[x1] if x2 is None else [x1, x2])
+        else:
+            dres = dout if self.shortcut is None else self.shortcut.backward(dout, key="dsc")
         return self.norm1.backward(dh1, dres=dres)
 
 
 class UNet(_Module):
     """forward(noisy NHWC, timesteps, ctx[, pooled, time_ids]) -> eps_hat [B*h*w, 4] fp32;  backward(dpred)."""
 
-    def __init__(self, rt, version, sd, lora_rank=None, lora_alpha_multiplier=1.0):
+    def __init__(self, rt, version, sd, lora_rank=None, lora_alpha_multiplier=1.0, trainer=None):
+        """trainer: a fullft.WeightTrainer -> every parameter of the UNet is registered with it and trained (the
+        reference's `is_lora = False` branch, main.py:144-149); lora_rank must then be None."""
         super().__init__(rt, "unet")
         cfg = CONFIGS[version] if isinstance(version, str) else version
         self.cfg = cfg
+        self.trainer = trainer
+        if trainer is not None:
+            assert lora_rank is None, "full fine-tune and LoRA are exclusive (config.is_lora)"
+            rt.trainer = trainer
+            trainer.registering = True
         boc = cfg["block_out_channels"]
         for c in boc:
             assert c % 64 == 0, "channel counts must be multiples of 64 (GEMM K-step / GroupNorm tiling)"
@@ -647,7 +742,7 @@ class UNet(_Module):
         self.tdim = c0 * TIME_DIM_MULT
         self.conv_in = Conv3x3(rt, "conv_in", sd, cin_pad=64, need_dx=False)
         self.t1 = Linear(rt, "time_embedding.linear_1", sd, need_dx=False)
-        self.t2 = Linear(rt, "time_embedding.linear_2", sd, need_dx=False)
+        self.t2 = Linear(rt, "time_embedding.linear_2", sd, need_dx=trainer is not None)
         if cfg["addition"]:
             self.a1 = Linear(rt, "add_embedding.linear_1", sd)
             self.a2 = Linear(rt, "add_embedding.linear_2", sd)
@@ -685,6 +780,9 @@ class UNet(_Module):
         self.conv_out = Conv3x3(rt, "conv_out", sd)
         if ar is not None:
             ar.finalize()
+        if trainer is not None:
+            trainer.registering = False
+            trainer.finalize()
         self._grad_plan = None
         # cross-attention to_k|to_v of every layer read the same text conditioning: one batched launch per (width, hooked)
         # group in forward, and one for all their input gradients in backward (instead of 2 x 70 M = 128 GEMMs)
@@ -757,7 +855,8 @@ class UNet(_Module):
         rt, cfg = self.rt, self.cfg
         B, H, W = self._dims
         boc = cfg["block_out_channels"]
-        if rt.want_dpooled:
+        tr = self.trainer
+        if rt.want_dpooled or tr is not None:
             rt.dsemb = self.buf("dsemb", B, self.tdim, zero=True)
             rt.dsemb.zero_()
         dh = self.norm_out.backward(self.conv_out.backward(dpred64))
@@ -790,14 +889,21 @@ class UNet(_Module):
                 if att:
                     dh = att[j].backward(dh, dctx)
                 dh = res[j].backward(dh)
-        # conv_in's own skip gradient and dX are not needed (its input is data, no adapter upstream)
-        if rt.want_dpooled:
-            # emb = time_embedding(t) + add_embedding([pooled | sinusoid(time_ids)]); only the pooled text embedding is trainable
-            # upstream (textual inversion through text_encoder_2), so the timestep branch gets no backward.
+        # conv_in's own skip gradient and dX are not needed (its input is data, no adapter upstream) - unless conv_in itself trains
+        if tr is not None:
+            self.conv_in.weight_grad(self._add(dh, pop_skip(), ("cin",)))
+        if rt.want_dpooled or tr is not None:
+            # emb = time_embedding(t) + add_embedding([pooled | sinusoid(time_ids)]); with LoRA only the pooled text embedding is
+            # trainable upstream (textual inversion through text_encoder_2), so the timestep branch gets no backward; the
+            # full fine-tune trains both MLPs.
             demb = rt.ops.map_bf16(_ops.MAP_DSILU, self._b["semb_in"], rt.dsemb, self.buf("demb", B, self.tdim))
-            da1s = self.a2.backward(demb)
-            da1 = rt.ops.map_bf16(_ops.MAP_DSILU, self.a1._b["y"], da1s, self.buf("da1", *da1s.shape))
-            self.dadd_in = self.a1.backward(da1)
+            if cfg["addition"]:
+                da1s = self.a2.backward(demb)
+                da1 = rt.ops.map_bf16(_ops.MAP_DSILU, self.a1._b["y"], da1s, self.buf("da1", *da1s.shape))
+                self.dadd_in = self.a1.backward(da1)
+            if tr is not None:
+                de1s = self.t2.backward(demb)
+                self.t1.weight_grad(rt.ops.map_bf16(_ops.MAP_DSILU, self.t1._b["y"], de1s, self.buf("de1", *de1s.shape)))
         self._cross_kv_backward(dctx)
         if self.arena is not None:
             if self._grad_plan is None:
