@@ -73,6 +73,8 @@ class WeightTrainer:
         if self._plan is not None:
             self._plan.run(self.params)
 
+    refresh_shadows = refresh      # same optimizer-facing surface as unet.LoraArena (params / grads / m / v / n / refresh_shadows)
+
     # ------------------------------------------------------------------ weight-gradient plan (leaf backward)
     def _panel(self, key, rows, Mp):
         n = rows * Mp

@@ -146,12 +146,25 @@ class TrainStep:
     def __init__(self, rt: Runtime, unet: UNet, *, latent_hw, snr_gamma=5.0, v_prediction=False, l1_penalty=0.03,
                  weight_decay=0.004, grad_accum=1, betas=(0.9, 0.999), eps=1e-8, text: TextStack = None, n_tokens=3,
                  token_attention_loss_w=3e-7, ti_weight_decay=0.0, ti_std_loss_w=0.01, optimizer="adamw", ti_optimizer="adamw",
-                 prodigy_d_coef=1.0, prodigy_growth_rate=1.05, text_lora_weight_decay=1e-5):
+                 prodigy_d_coef=1.0, prodigy_growth_rate=1.05, text_lora_weight_decay=1e-5, process_group=None):
+        """process_group: data-parallel full fine-tune only (`unet.trainer` set) - a torch.distributed group (or True for the
+        default one) over which the gradient arena is all-reduced once per optimiser step (RCCL on the GPU)."""
         if optimizer not in ("adamw", "prodigy"):      # AdamW8bit (bitsandbytes) belongs to the full fine-tune, not built
             raise NotImplementedError(f"Invalid optimizer_name for unet: {optimizer}")
         if ti_optimizer not in ("adamw", "prodigy"):
             raise NotImplementedError(f"Invalid optimizer_name: '{ti_optimizer}'")
         self.rt, self.unet = rt, unet
+        # the trained parameter group of the UNet: the LoRA arena, or every weight (full fine-tune, main.py:144-149)
+        self.full_ft = getattr(unet, "trainer", None) is not None
+        self.group = unet.trainer if self.full_ft else unet.arena
+        if self.full_ft:
+            l1_penalty = 0.0       # main.py:353: the L1 term only exists over unet_lora_parameters
+        self.pg, self.world = None, 1
+        if process_group is not None:
+            import torch.distributed as dist
+            assert self.full_ft, "LoRA / TI jobs are independent per GPU (no collective); only the full fine-tune is data parallel"
+            self.pg = None if process_group is True else process_group
+            self.world = dist.get_world_size(self.pg)
         self.text, self.ta_w, self.ti_wd = text, token_attention_loss_w, ti_weight_decay
         self.ti = TiState(rt, text.encoders, n_tokens, ti_std_loss_w) if text is not None else None
         self.ta = TokenAttentionLoss(rt, n_tokens) if text is not None else None
@@ -182,7 +195,7 @@ class TrainStep:
         self.graph, self.graphs, self.graphs_frozen = None, [], None
         # optional Prodigy groups (trainer/optimizer.py:24-34: growth_rate = unet_prodigy_growth_factor, d_coef = prodigy_d_coef;
         # :135-145 for the token rows: d_coef 1, unbounded growth)
-        self.prodigy = ProdigyState(rt, unet.arena.params, d_coef=prodigy_d_coef, growth_rate=prodigy_growth_rate,
+        self.prodigy = ProdigyState(rt, self.group.params, d_coef=prodigy_d_coef, growth_rate=prodigy_growth_rate,
                                     weight_decay=weight_decay) if optimizer == "prodigy" else None
         self.prodigy_ti = ProdigyState(rt, self.ti.params, weight_decay=ti_weight_decay) \
             if (self.ti is not None and ti_optimizer == "prodigy") else None
@@ -220,9 +233,10 @@ class TrainStep:
         GPU then idled ~1 ms per step while the host caught up)."""
         self.opt_step += 1
         b1, b2 = self.betas
-        n = self.unet.arena.n
+        n = self.group.n
         bc = [1.0 - b1 ** self.opt_step, 1.0 - b2 ** self.opt_step]
-        rows = [[lr, b1, b2, self.eps, self.wd, *bc, self.l1_penalty / n, 1.0] if self.prodigy is None
+        # data parallel: the all-reduce SUMS the ranks' gradients, the mean is the optimizer's gradient scale
+        rows = [[lr, b1, b2, self.eps, self.wd, *bc, self.l1_penalty / n, 1.0 / self.world] if self.prodigy is None
                 else self.prodigy.hyper_row(lr, self.l1_penalty / n)]
         if self.ti is not None:
             rows.append([lr_ti, b1, b2, self.eps, self.ti_wd, *bc, 0.0, 1.0] if self.prodigy_ti is None
@@ -296,12 +310,20 @@ class TrainStep:
         return self._pred
 
     def _unet_optimizer(self):
-        a = self.unet.arena
+        a = self.group
+        l1 = None if self.full_ft else self.l1_sum
         if self.prodigy is not None:
-            self.prodigy.step(a.grads, a.m, a.v, self.hyper, self.l1_sum)
+            self.prodigy.step(a.grads, a.m, a.v, self.hyper, l1)
         else:
-            self.rt.ops.adamw_fused(a.params, a.grads, a.m, a.v, self.hyper, self.l1_sum)
+            self.rt.ops.adamw_fused(a.params, a.grads, a.m, a.v, self.hyper, l1)
         a.refresh_shadows()
+
+    def sync_gradients(self):
+        """Data-parallel full fine-tune: ONE all-reduce (sum) of the flat fp32 gradient arena per optimiser step - the only
+        exchange step of the whole path.  RCCL over xGMI on the GPU (backend "nccl"), gloo in the CPU tests."""
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.group.grads, group=self.pg)
 
     def optimizer_step(self):
         self._unet_optimizer()
@@ -319,9 +341,12 @@ class TrainStep:
 
     def body(self):
         self.forward_backward()
+        self.sync_gradients()
         self.optimizer_step()
 
     def _phases(self):
+        if self.world > 1:         # the collective stays outside the graphs: forward+backward | all-reduce | optimizer
+            return [self.forward_backward, self.optimizer_step]
         if self.text is None:
             return [self.body]
         return [self._phase_text_fwd, self._phase_unet, lambda: (self._phase_text_bwd(), self.optimizer_step())]
@@ -386,14 +411,14 @@ class TrainStep:
 
     def grad_norm(self):
         """Global L2 norm of the LoRA gradients, the reference's debug read-out (loss.py:108-125, main.py:373-379)."""
-        return float(self.unet.arena.grads.norm())
+        return float(self.group.grads.norm())
 
     # -------------------------------------------------------------------------------- graph capture / replay
     def capture(self, warmup=2):
         """Runs the body eagerly `warmup` times (allocates every persistent buffer, builds the grouped-gradient
         plan), then captures it: one hipGraph for the whole step (one per phase when the text encoders run on forked
         streams), plus the frozen-TI variant.  AdamW state is restored afterwards so capture does not count as training."""
-        a = self.unet.arena
+        a = self.group
         state = [a.params, a.m, a.v] + ([self.ti.params, self.ti.m, self.ti.v] if self.ti is not None else [])
         if self.te_arena is not None:
             state += [self.te_arena.params, self.te_arena.m, self.te_arena.v]
@@ -412,7 +437,7 @@ class TrainStep:
                     fn()
             return g
         phases = self._phases()
-        split = self.text is not None and self.text.concurrent      # one graph per phase only when the encoders fork
+        split = (self.text is not None and self.text.concurrent) or self.world > 1      # one graph per phase when the encoders fork / DDP
 
         def cap_set(pool):
             graphs = []
@@ -447,7 +472,11 @@ class TrainStep:
         # gradients need the text backward for the whole run
         frozen = self.text is not None and lr_ti == 0.0 and self.te_arena is None
         self._frozen_last = frozen
-        if self.graph is not None:
+        if self.graph is not None and self.world > 1:
+            self.graphs[0].replay()
+            self.sync_gradients()
+            self.graphs[1].replay()
+        elif self.graph is not None:
             for g in (self.graphs_frozen if frozen else self.graphs):
                 g.replay()
         elif frozen:
@@ -459,7 +488,7 @@ class TrainStep:
 
     def total_loss(self):
         """img loss + L1 penalty as the reference logs it (main.py:339-361); forces a device sync."""
-        tot = float(self.loss) + self.l1_penalty * float(self.l1_sum) / self.unet.arena.n
+        tot = float(self.loss) + self.l1_penalty * float(self.l1_sum) / self.group.n
         if self.text is not None:
             tot += self.ta_w * float(self.ta.loss) + (0.0 if getattr(self, "_frozen_last", False) else float(self.ti.reg_loss))
         return tot
