@@ -62,3 +62,73 @@ def test_timing_protocol_two_ranks_gloo():
         assert abs(mx - 0.10) < 1e-9                 # MAX over ranks
         assert abs(thr - 2 * 10 / 0.10) < 1e-6       # whole-job throughput = sum of units / slowest replica
         assert wall >= 0.10 - 1e-3                   # the barrier made the fast rank wait for the slow one
+
+
+# ------------------------------------------------------------------------------------------------ data-parallel full fine-tune
+def _ddp_worker(rank, world, port, out):
+    """Each rank holds ONE sample of a 2-sample batch; after the gradient all-reduce (sum, mean folded into the optimizer's
+    gradient scale) both ranks must hold the parameters a single process gets from the full batch."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from oracle import unet_ref as U
+    from sd_lora_trainer_amd import fullft, topology
+    from sd_lora_trainer_amd import step as step_mod
+    from sd_lora_trainer_amd import unet as unet_mod
+    from tests import emu_ops
+    from tests.test_fullft_cpu import _inputs
+    parallel.init_distributed("gloo")
+    cfg, h = U.CONFIGS["tiny15"], 16
+    sd = U.init_unet_state(cfg, seed=0)
+    latent, noise, mask, t, ctx, _, _, _ = _inputs(cfg, 2, h)
+    mask = torch.ones_like(mask)        # per-sample losses independent of the rest of the batch (gamma = 0 branch normalises by the batch mask mean)
+    rt = unet_mod.Runtime("cpu", 1, act_dtype=torch.float32, ops=emu_ops)
+    tr = fullft.WeightTrainer(rt)
+    unet = unet_mod.UNet(rt, topology.CONFIGS["tiny15"], sd, trainer=tr)
+    ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=0.0, process_group=True)
+    s = slice(rank, rank + 1)
+    for _ in range(2):
+        ts.set_batch(latent[s], noise[s], t[s], mask[s], ctx[s])
+        ts.run(1e-3)
+    out.put((rank, tr.params.numpy().copy(), float(ts.loss), tr.grads.numpy().copy()))      # numpy: pickled through the pipe (a shared-memory tensor dies with the worker)
+    torch.distributed.destroy_process_group()
+
+
+def test_fullft_data_parallel_two_ranks_gloo():
+    from oracle import unet_ref as U
+    from sd_lora_trainer_amd import fullft, topology
+    from sd_lora_trainer_amd import step as step_mod
+    from sd_lora_trainer_amd import unet as unet_mod
+    from tests import emu_ops
+    from tests.test_fullft_cpu import _inputs
+    ctx_mp = mp.get_context("spawn")
+    q = ctx_mp.Queue()
+    port = _free_port()
+    procs = [ctx_mp.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process, both samples in one batch
+    cfg, h = U.CONFIGS["tiny15"], 16
+    sd = U.init_unet_state(cfg, seed=0)
+    latent, noise, mask, t, ctx, _, _, _ = _inputs(cfg, 2, h)
+    mask = torch.ones_like(mask)
+    rt = unet_mod.Runtime("cpu", 2, act_dtype=torch.float32, ops=emu_ops)
+    tr = fullft.WeightTrainer(rt)
+    unet = unet_mod.UNet(rt, topology.CONFIGS["tiny15"], sd, trainer=tr)
+    ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=0.0)
+    for _ in range(2):
+        ts.set_batch(latent, noise, t, mask, ctx)
+        ts.run(1e-3)
+    p0, p1 = torch.from_numpy(res[0][1]), torch.from_numpy(res[1][1])
+    assert torch.equal(p0, p1), "ranks diverged"
+    # the all-reduced arena holds the SUM of the ranks' gradients = 2 x the gradient of the batch-mean loss
+    g_ddp, g_one = torch.from_numpy(res[0][3]) / 2, tr.grads
+    assert float((g_ddp - g_one).abs().max()) <= 2e-3 * float(g_one.abs().max())     # 2nd step: the replicas already differ by the sign-noise above
+    # parameters: identical up to Adam's sign(g) steps where the gradient is analytically zero (e.g. a conv bias in front of
+    # a GroupNorm: +-1e-9 of rounding noise becomes +-lr), so only a small fraction of the elements may differ
+    frac = float(((p0 - tr.params).abs() > 5e-2 * 2e-3).float().mean())
+    assert frac < 0.02, frac
+    assert abs(0.5 * (res[0][2] + res[1][2]) - float(ts.loss)) <= 1e-4 * abs(float(ts.loss))
