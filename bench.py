@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-ti", action="store_true", help="inject the text conditioning instead of running the text encoders + TI")
     ap.add_argument("--ti-frozen", action="store_true", help="time the step after freeze_ti_after_completion_f (ti lr = 0): no text-encoder backward")
+    ap.add_argument("--full-ft", action="store_true", help="full-UNet fine-tune (BASELINE configs[4], train_configs/full_finetuning_example.json: "
+                    "SDXL 512 px, batch 4 per GPU, AdamW over every UNet parameter); data parallel with one gradient all-reduce per step when --gpus > 1")
     args = ap.parse_args()
 
     from sd_lora_trainer_amd import parallel
@@ -133,23 +135,31 @@ def main():
 
     version = args.config
     cfg = topology.CONFIGS[version]
-    res = args.res or (1024 if "xl" in version else 512)
-    B = args.batch or (1 if "xl" in version else 4)
+    full_ft = args.full_ft
+    res = args.res or (512 if full_ft else (1024 if "xl" in version else 512))
+    B = args.batch or (4 if full_ft else (1 if "xl" in version else 4))
     h = res // 8
     rt = M.Runtime(device, B)
-    sd = make_state(cfg, device, seed=rank)        # every rank = its own independent job
-    unet = M.UNet(rt, cfg, sd, lora_rank=args.rank)
+    g = torch.Generator(device=device).manual_seed(100 + rank)
+    if full_ft:
+        from sd_lora_trainer_amd import fullft
+        sd = make_state(cfg, device, seed=0)       # data-parallel replicas start from the same weights
+        trainer = fullft.WeightTrainer(rt)
+        unet = M.UNet(rt, cfg, sd, trainer=trainer)
+        arena = trainer
+    else:
+        sd = make_state(cfg, device, seed=rank)    # every rank = its own independent job
+        unet = M.UNet(rt, cfg, sd, lora_rank=args.rank)
+        arena = unet.arena
+        for e in arena.entries:   # peft "gaussian" init: A ~ N(0, 1/r), B = 0 at step 0 (optimizer.py:89)
+            e["A"].copy_(torch.randn(e["A"].shape, generator=g, device=device) / args.rank)
+            e["B"].zero_()
+        arena.refresh_shadows()
     del sd
     torch.cuda.empty_cache()
-    g = torch.Generator(device=device).manual_seed(100 + rank)
-    arena = unet.arena
-    for e in arena.entries:   # peft "gaussian" init: A ~ N(0, 1/r), B = 0 at step 0 (optimizer.py:89)
-        e["A"].copy_(torch.randn(e["A"].shape, generator=g, device=device) / args.rank)
-        e["B"].zero_()
-    arena.refresh_shadows()
     text, n_tok = None, 3
     clip_flops = 0.0
-    if not args.no_ti:
+    if not args.no_ti and not full_ft:             # the full fine-tune example disables textual inversion
         import sd_lora_trainer_amd.clip as CL
         tiny = version.startswith("tiny")
         kinds = (["tiny_l", "tiny_g"] if tiny else ["clip_l", "clip_g"]) if cfg["addition"] else (["tiny_l"] if tiny else ["clip_l"])
@@ -163,7 +173,8 @@ def main():
             clip_flops += topology.clip_fwd_flops(c, B, layers_run=enc.n_run)
             del csd
         text = S.TextStack(rt, encs, pool_mode="argmax")
-    ts = S.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, l1_penalty=0.03, weight_decay=0.004, text=text, n_tokens=n_tok)
+    ts = S.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, l1_penalty=0.03, weight_decay=0.004, text=text, n_tokens=n_tok,
+                     process_group=True if (full_ft and world > 1) else None)
     rn = lambda *s: torch.randn(*s, generator=g, device=device)  # noqa: E731
     latent = rn(B, 4, h, h) * cfg["scaling_factor"]
     noise = rn(B, 4, h, h)
@@ -208,7 +219,8 @@ def main():
     assert math.isfinite(loss), "non-finite loss in the timed region"
 
     if rank == 0:
-        f_step = 2.0 * topology.fwd_flops(cfg, B, h, h, args.rank)["total"]
+        # LoRA: dX only (+ small adapter terms) = 2 x forward; full fine-tune: dX and dW = 3 x forward
+        f_step = (3.0 * topology.fwd_flops(cfg, B, h, h, 0)["total"]) if full_ft else 2.0 * topology.fwd_flops(cfg, B, h, h, args.rank)["total"]
         t_step = elapsed / args.steps
         achieved = f_step / (ev_ms * 1e-3 / args.steps)
         # HBM-side bytes per step: measured offline (PMC counters need rocprofv3 around the process), for the default workload only
@@ -225,19 +237,23 @@ def main():
             "ms_per_step": t_step * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{version} {res}x{res} LoRA rank {args.rank} batch {B}/GPU: UNet fwd+bwd, masked/min-SNR MSE, L1, AdamW"
+            "config": {"workload": (f"{version} {res}x{res} FULL-UNet fine-tune batch {B}/GPU: UNet fwd + bwd (dX and every dW), masked/min-SNR MSE, "
+                                    f"AdamW over {arena.n / 1e6:.0f} M parameters, bf16 operand refresh" if full_ft else
+                                    f"{version} {res}x{res} LoRA rank {args.rank} batch {B}/GPU: UNet fwd+bwd, masked/min-SNR MSE, L1, AdamW")
                                    + (", + textual inversion (text encoders fwd+bwd with 3 trainable tokens, token-attention loss, "
                                       "std regulariser, rows-only AdamW)" + (" [ti lr = 0: frozen-TI fast path, no text-encoder backward]" if args.ti_frozen else "") if text is not None else ", text conditioning injected (--no-ti)"),
                        "text_encoder_fwd_gflop_not_in_roofline": clip_flops / 1e9,
-                       "global_batch": world * B, "parallelism": f"job-parallel x{world} (independent jobs, no collective)",
-                       "lora_params": arena.n, "graph": not args.no_graph, "final_loss": loss},
+                       "global_batch": world * B,
+                       "parallelism": (f"dp{world}: one fp32 gradient all-reduce of {arena.n * 4 / 1e9:.1f} GB per step (RCCL)" if (full_ft and world > 1)
+                                       else f"job-parallel x{world} (independent jobs, no collective)"),
+                       "trained_params": arena.n, "graph": not args.no_graph, "final_loss": loss},
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_DENSE, "traffic": traffic,
                          "note": f"algorithmic {f_step / 1e12:.3f} TFLOP per step (2 x fwd census) / {ev_ms / args.steps:.3f} ms "
                                  "per step (HIP events on the replay stream); traffic = HBM-side bytes per step from the committed "
                                  "rocprofv3 PMC passes of this command (profiles/r01_sdxl1024_ti_hbm_traffic_pmc.json), null for other configs"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not full_ft:
             sample_hw = 32 if "xl" in version or version == "sd15" else h
             dt, f_sample = cpu_baseline(version, args.rank, sample_hw)
             scaled = dt * (f_step / B) / f_sample       # seconds per full-size image on this host

@@ -38,7 +38,7 @@ class WeightTrainer:
     def add(self, name, init, kind="matrix"):
         """init: fp32 tensor in ARENA layout.  Offsets are kept 16-byte aligned so every slice can be a GEMM output."""
         self.n = (self.n + 3) // 4 * 4
-        e = dict(name=name, off=self.n, shape=tuple(init.shape), kind=kind, init=init.detach().to("cpu", F32).contiguous())
+        e = dict(name=name, off=self.n, shape=tuple(init.shape), kind=kind, init=init.detach().to(F32))
         self.n += init.numel()
         self.entries.append(e)
         self.by_name[name] = e
