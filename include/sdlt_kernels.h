@@ -258,7 +258,9 @@ int sdlt_adamw_fused(float* p, const float* g, float* m, float* v, int64_t n, co
 int sdlt_prodigy_step(float* p, const float* g, const float* p0, float* m, float* v, float* s, int64_t n,
                       const float* hyper, float* state, double* acc, float* l1_sum, void* stream);
 
-/* bf16 compute copies of the fp32 LoRA arena, in both orientations (dst [rows, ld], dstT [cols, ldT]). */
+/* bf16 compute copies of an fp32 master arena (LoRA adapters; every UNet weight in the full fine-tune), in both
+ * orientations (dst [rows, ld], dstT [cols, ldT]).  One workgroup per 64x64 tile of a tensor: block_desc[b] = descriptor of
+ * block b, block_first[d] = first block of descriptor d, a tensor owns ceil(rows/64)*ceil(cols/64) consecutive blocks. */
 typedef struct sdlt_shadow_desc {
   int64_t offset;      /* element offset of the tensor in the fp32 arena */
   int64_t src_ld;      /* row stride of the tensor inside the arena (elements) */

@@ -203,19 +203,57 @@ __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, int64
   }
 }
 
-// ------------------------------------------------------------------ LoRA bf16 shadows (both orientations) from the fp32 arena
-// one descriptor per parameter tensor [rows, cols] (row-major in the arena):
-//   dst  [rows_pad?, ld ]  <- same orientation        dstT [cols, ldT] <- transposed
-__global__ void shadow_kernel(const sdlt_shadow_desc* descs, const int32_t* block_desc, const int32_t* block_first,
-                              const float* arena) {
+// ------------------------------------------------------------------ bf16 compute copies (both orientations) of an fp32 master arena
+// one descriptor per parameter tensor [rows, cols] (row stride src_ld in the arena):
+//   dst  [rows, ld ]  <- same orientation        dstT [cols, ldT] <- transposed
+// One workgroup per 64x64 tile: the fp32 rows are read as 256-B lines, converted once, and both copies leave as
+// contiguous runs along their own fast axis (the transposed one through LDS).  Used for the LoRA adapters (a few MB) and
+// for every UNet weight of the full fine-tune (2.57 G parameters: 10 GB read, 2 x 5 GB written per step).
+__global__ __launch_bounds__(256) void shadow_kernel(const sdlt_shadow_desc* descs, const int32_t* block_desc, const int32_t* block_first,
+                                                     const float* arena) {
+  __shared__ bf16_t tile[64][72];
   const sdlt_shadow_desc d = descs[block_desc[blockIdx.x]];
-  const int64_t n = (int64_t)d.rows * d.cols;
-  const int64_t start = (int64_t)(blockIdx.x - block_first[block_desc[blockIdx.x]]) * 4096;
-  for (int64_t i = start + threadIdx.x; i < start + 4096 && i < n; i += blockDim.x) {
-    int r = i / d.cols, c = i - (int64_t)r * d.cols;
-    bf16_t v = f2bf(arena[d.offset + (int64_t)r * d.src_ld + c]);
-    if (d.dst) ((bf16_t*)d.dst)[(int64_t)r * d.ld + c] = v;
-    if (d.dstT) ((bf16_t*)d.dstT)[(int64_t)c * d.ldT + r] = v;
+  const int t = blockIdx.x - block_first[block_desc[blockIdx.x]];
+  const int tiles_c = (d.cols + 63) >> 6;
+  const int r0 = (t / tiles_c) << 6, c0 = (t % tiles_c) << 6;
+  const int thr = threadIdx.x;
+  {
+    const int c = c0 + (thr & 63);
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+      const int r = r0 + k * 4 + (thr >> 6);
+      float v = (r < d.rows && c < d.cols) ? arena[d.offset + (int64_t)r * d.src_ld + c] : 0.f;
+      tile[k * 4 + (thr >> 6)][thr & 63] = f2bf(v);
+    }
+  }
+  __syncthreads();
+  const int q = thr >> 2, ch = (thr & 3) * 16;
+  if (d.dst) {
+    const int r = r0 + q;
+    if (r < d.rows) {
+      bf16_t* p = (bf16_t*)d.dst + (int64_t)r * d.ld + c0 + ch;
+      if (c0 + ch + 16 <= d.cols && (((uintptr_t)p) & 15) == 0) {
+        *(uint4*)p = *(const uint4*)&tile[q][ch];
+        *(uint4*)(p + 8) = *(const uint4*)&tile[q][ch + 8];
+      } else {
+        for (int j = 0; j < 16 && c0 + ch + j < d.cols; ++j) p[j] = tile[q][ch + j];
+      }
+    }
+  }
+  if (d.dstT) {
+    const int c = c0 + q;
+    if (c < d.cols) {
+      bf16_t v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = tile[ch + j][q];
+      bf16_t* p = (bf16_t*)d.dstT + (int64_t)c * d.ldT + r0 + ch;
+      if (r0 + ch + 16 <= d.rows && (((uintptr_t)p) & 15) == 0) {
+        *(uint4*)p = *(const uint4*)&v[0];
+        *(uint4*)(p + 8) = *(const uint4*)&v[8];
+      } else {
+        for (int j = 0; j < 16 && r0 + ch + j < d.rows; ++j) p[j] = v[j];
+      }
+    }
   }
 }
 

@@ -18,50 +18,53 @@ struct GatherGeom {
 };
 
 // grid (Mp/64, ceil(C/64), taps); block 256.  out[(tap*C + c) * ldo + m] = x[src(m, tap) * ldx + c]
+// A thread owns the row PAIR (2i, 2i+1) of the tile and 8 channels: two 16-B loads, and each channel's two values leave
+// as one 32-bit word (m, m+1 adjacent in the transposed tile), so the LDS sees 8 word writes and 4 b64 reads per thread.
+__device__ __forceinline__ int64_t gather_src(int m, int M, int tap, const GatherGeom& g) {
+  if (m >= M) return -1;
+  if (!g.conv) return m;
+  const int hw = g.Hout * g.Wout;
+  const int b = m / hw, rem = m - b * hw, oy = rem / g.Wout, ox = rem - oy * g.Wout;
+  const int iy = oy * g.stride + tap / 3 - 1, ix = ox * g.stride + tap % 3 - 1;
+  if (iy < 0 || iy >= g.H * g.ups || ix < 0 || ix >= g.W * g.ups) return -1;
+  return ((int64_t)b * g.H + iy / g.ups) * g.W + ix / g.ups;
+}
+
+__device__ __forceinline__ uint4 load_row8(const bf16_t* x, int64_t ldx, int64_t src, int c, int C) {
+  uint4 u = make_uint4(0, 0, 0, 0);
+  if (src < 0 || c >= C) return u;
+  if (c + 8 <= C) return *(const uint4*)(x + src * ldx + c);
+  bf16_t tmp[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ragged channel tail (conv_in: 4 channels)
+  for (int j = 0; j < 8 && c + j < C; ++j) tmp[j] = x[src * ldx + c + j];
+  return *(const uint4*)tmp;
+}
+
 __global__ __launch_bounds__(256) void transpose_gather_kernel(const bf16_t* x, int64_t ldx, int M, int C, bf16_t* out,
                                                                 int64_t ldo, GatherGeom g) {
-  __shared__ bf16_t tile[64][64 + 2];
+  __shared__ uint32_t tileT[64][34];          // [channel][row pair], 8-B aligned rows
   const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tap = blockIdx.z;
   const int t = threadIdx.x;
   {
-    const int r = t >> 2, cc = (t & 3) * 16;
-    const int m = m0 + r;
-    int64_t src = -1;
-    if (m < M) {
-      if (!g.conv) src = m;
-      else {
-        const int hw = g.Hout * g.Wout;
-        const int b = m / hw, rem = m - b * hw, oy = rem / g.Wout, ox = rem - oy * g.Wout;
-        const int iy = oy * g.stride + tap / 3 - 1, ix = ox * g.stride + tap % 3 - 1;
-        if (iy >= 0 && iy < g.H * g.ups && ix >= 0 && ix < g.W * g.ups)
-          src = ((int64_t)b * g.H + iy / g.ups) * g.W + ix / g.ups;
-      }
-    }
+    const int i = t >> 3, cc = (t & 7) * 8;
+    const int m = m0 + 2 * i;
+    const uint4 a = load_row8(x, ldx, gather_src(m, M, tap, g), c0 + cc, C);
+    const uint4 b = load_row8(x, ldx, gather_src(m + 1, M, tap, g), c0 + cc, C);
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int c = c0 + cc + h * 8;
-      uint4 u = make_uint4(0, 0, 0, 0);
-      if (src >= 0 && c + 8 <= C) u = *(const uint4*)(x + src * ldx + c);
-      else if (src >= 0 && c < C) {           // ragged channel tail (C % 8 != 0 never happens for 16-B rows; C % 64 may)
-        bf16_t tmp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int j = 0; j < 8 && c + j < C; ++j) tmp[j] = x[src * ldx + c + j];
-        u = *(const uint4*)tmp;
-      }
-      const bf16_t* e = (const bf16_t*)&u;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) tile[r][cc + h * 8 + j] = e[j];
+    for (int j = 0; j < 4; ++j) {
+      tileT[cc + 2 * j][i] = (aw[j] & 0xffffu) | (bw[j] << 16);
+      tileT[cc + 2 * j + 1][i] = (aw[j] >> 16) | (bw[j] & 0xffff0000u);
     }
   }
   __syncthreads();
   {
-    const int c = t >> 2, mm = (t & 3) * 16;
+    const int c = t >> 2, w0 = (t & 3) * 8;     // 8 words = 16 tokens
     if (c0 + c < C) {
-      bf16_t v[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = tile[mm + j][c];
-      bf16_t* dst = out + ((int64_t)tap * C + c0 + c) * ldo + m0 + mm;
-      *(uint4*)dst = *(const uint4*)&v[0];
-      *(uint4*)(dst + 8) = *(const uint4*)&v[8];
+      const uint2* src = (const uint2*)&tileT[c][w0];
+      const uint2 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
+      bf16_t* dst = out + ((int64_t)tap * C + c0 + c) * ldo + m0 + w0 * 2;
+      *(uint4*)dst = make_uint4(p0.x, p0.y, p1.x, p1.y);
+      *(uint4*)(dst + 8) = make_uint4(p2.x, p2.y, p3.x, p3.y);
     }
   }
 }

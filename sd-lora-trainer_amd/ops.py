@@ -459,7 +459,7 @@ class ShadowPlan:
                 _chk2(dstT)
                 d.dstT, d.ldT = dstT.data_ptr(), _ld(dstT)
             block_first.append(nb)
-            blocks = (rows * cols + 4095) // 4096
+            blocks = ((rows + 63) // 64) * ((cols + 63) // 64)         # one workgroup per 64x64 tile
             block_desc += [i] * blocks
             nb += blocks
             self.keep += [dst, dstT]
