@@ -57,7 +57,7 @@ def kohya_to_lora(sd):
 
 
 def save_checkpoint(output_dir, global_step, arena, ti_rows, token_dict, name, pretrained_model_version, config=None,
-                    txt_encoder_keys=("clip_l", "clip_g"), text_arena=None):
+                    txt_encoder_keys=("clip_l", "clip_g"), text_arena=None, unet_weights=None):
     """arena: unet.LoraArena (LoRA) ; ti_rows: list of [n_tokens, D] tensors per text encoder (or None);
     text_arena: the text encoders' LoraArena when they are LoRA-trained (same file, lora_te1_/lora_te2_ keys)."""
     os.makedirs(output_dir, exist_ok=True)
@@ -79,6 +79,11 @@ def save_checkpoint(output_dir, global_step, arena, ti_rows, token_dict, name, p
         with open(os.path.join(output_dir, "adapter_config.json"), "w") as f:
             json.dump({"peft_type": "LORA", "r": arena.rank, "lora_alpha": arena.rank * arena.scale, "init_lora_weights": "gaussian",
                        "target_modules": ["to_k", "to_q", "to_v", "to_out.0", "conv2"], "use_dora": False}, f, indent=2)
+    if unet_weights is not None:
+        # is_lora == False (checkpoint.py:210-212): `unet.save_pretrained(output_dir)` = the whole fine-tuned UNet under its
+        # diffusers parameter names in diffusion_pytorch_model.safetensors
+        files["unet"] = os.path.join(output_dir, "diffusion_pytorch_model.safetensors")
+        save_file({k: v.to(torch.float16).contiguous() for k, v in unet_weights.export().items()}, files["unet"])
     if config is not None:
         config.save_as_json(os.path.join(output_dir, "training_args.json"))
     return files

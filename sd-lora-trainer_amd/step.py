@@ -149,7 +149,11 @@ class TrainStep:
                  prodigy_d_coef=1.0, prodigy_growth_rate=1.05, text_lora_weight_decay=1e-5, process_group=None):
         """process_group: data-parallel full fine-tune only (`unet.trainer` set) - a torch.distributed group (or True for the
         default one) over which the gradient arena is all-reduced once per optimiser step (RCCL on the GPU)."""
-        if optimizer not in ("adamw", "prodigy"):      # AdamW8bit (bitsandbytes) belongs to the full fine-tune, not built
+        if optimizer == "AdamW8bit":
+            # bitsandbytes' AdamW8bit (optimizer.py:19-21, the full fine-tune example) is AdamW with block-quantised moments, a
+            # memory saving for 24 GB cards; with 288 GB the fp32 moments of all 2.57 G parameters fit (31 GB), so it runs as AdamW
+            optimizer = "adamw"
+        if optimizer not in ("adamw", "prodigy"):
             raise NotImplementedError(f"Invalid optimizer_name for unet: {optimizer}")
         if ti_optimizer not in ("adamw", "prodigy"):
             raise NotImplementedError(f"Invalid optimizer_name: '{ti_optimizer}'")

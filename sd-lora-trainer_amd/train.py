@@ -56,7 +56,11 @@ def build_models(config, rt):
         sd = load_file(path)
         version = config.sd_model_version or ("sdxl" if "add_embedding.linear_1.weight" in sd else "sd15")
         cfg = topology.CONFIGS[version]
-    unet = M.UNet(rt, cfg, sd, lora_rank=config.lora_rank if config.is_lora else None, lora_alpha_multiplier=config.lora_alpha_multiplier)
+    if config.is_lora:
+        unet = M.UNet(rt, cfg, sd, lora_rank=config.lora_rank, lora_alpha_multiplier=config.lora_alpha_multiplier)
+    else:                          # main.py:144-149: full fine-tune, every UNet parameter trained
+        from . import fullft
+        unet = M.UNet(rt, cfg, sd, trainer=fullft.WeightTrainer(rt))
     text = None
     if config.text_encoder_lora_optimizer is not None and config.disable_ti:
         raise NotImplementedError("text-encoder LoRA without textual inversion: the text stack is only built for TI runs")
@@ -119,7 +123,9 @@ def train(config: TrainingConfig, runtime=None):
     steps_per_epoch = max(n_img // B, 1)
     config.num_train_epochs = math.ceil(config.max_train_steps / steps_per_epoch)      # main.py:207
 
-    ts = S.TrainStep(rt, unet, latent_hw=(h, w), snr_gamma=config.snr_gamma, l1_penalty=config.l1_penalty, weight_decay=config.lora_weight_decay,
+    import torch.distributed as dist
+    ddp = (not config.is_lora) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    ts = S.TrainStep(rt, unet, latent_hw=(h, w), process_group=True if ddp else None, snr_gamma=config.snr_gamma, l1_penalty=config.l1_penalty, weight_decay=config.lora_weight_decay,
                      grad_accum=config.gradient_accumulation_steps, text=text, n_tokens=config.n_tokens,
                      token_attention_loss_w=config.token_attention_loss_w, ti_weight_decay=config.ti_weight_decay,
                      optimizer=config.unet_optimizer_type, ti_optimizer=config.ti_optimizer,
@@ -142,10 +148,11 @@ def train(config: TrainingConfig, runtime=None):
         config.training_attributes = dict(config.training_attributes, token_warmup_losses=[warm[0], warm[-1]])
     g = torch.Generator(device=rt.device).manual_seed(config.seed)
     arena = unet.arena
-    for e in arena.entries:            # peft init_lora_weights="gaussian" (optimizer.py:89): A ~ N(0, 1/r), B = 0
-        e["A"].copy_(torch.randn(e["A"].shape, generator=g, device=rt.device) / config.lora_rank)
-        e["B"].zero_()
-    arena.refresh_shadows()
+    if arena is not None:
+        for e in arena.entries:        # peft init_lora_weights="gaussian" (optimizer.py:89): A ~ N(0, 1/r), B = 0
+            e["A"].copy_(torch.randn(e["A"].shape, generator=g, device=rt.device) / config.lora_rank)
+            e["B"].zero_()
+        arena.refresh_shadows()
     if ts.te_arena is not None:
         for e in ts.te_arena.entries:
             e["A"].copy_(torch.randn(e["A"].shape, generator=g, device=rt.device) / config.text_encoder_lora_rank)
@@ -190,7 +197,7 @@ def train(config: TrainingConfig, runtime=None):
                 ts.set_batch(latent, noise, timesteps, mask, time_ids=time_ids, ids=[ids] * len(text.encoders), caption_token_lists=lists)
             else:
                 ctx = torch.randn(B, 77, cfg["cross_dim"], generator=g, device=rt.device)
-                pooled = torch.randn(B, 1280, generator=g, device=rt.device) if cfg["addition"] else None
+                pooled = torch.randn(B, cfg["proj_class_in"] - 6 * cfg["addition_time_embed_dim"], generator=g, device=rt.device) if cfg["addition"] else None
                 ts.set_batch(latent, noise, timesteps, mask, ctx, pooled, time_ids)
             if not captured and rt.device.type == "cuda":
                 ts.capture(warmup=1)
@@ -214,7 +221,7 @@ def train(config: TrainingConfig, runtime=None):
     config.job_time = time.time() - config.start_time
     config.training_attributes = dict(config.training_attributes, images_per_second=images_done / max(time.time() - start, 1e-9), losses=losses)
     ckpt.save_checkpoint(output_save_dir, global_step, arena, ts.ti.rows if ts.ti is not None else None, config.token_dict, config.name,
-                         version, config=config, text_arena=ts.te_arena)
+                         version, config=config, text_arena=ts.te_arena, unet_weights=unet.trainer)
     return config, output_save_dir
 
 

@@ -147,4 +147,4 @@ def test_trainstep_prodigy_plumbing():
     assert get_current_lr(hnd) == pytest.approx(P.effective_lr(opt.param_groups[0]), rel=1e-4)
     assert hnd.param_groups[0]["k"] == 3 and hnd.param_groups[0]["use_bias_correction"]
     with pytest.raises(NotImplementedError):
-        step_mod.TrainStep(rt, unet, latent_hw=(h, h), optimizer="AdamW8bit")
+        step_mod.TrainStep(rt, unet, latent_hw=(h, h), optimizer="sgd")

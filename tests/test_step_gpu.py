@@ -138,7 +138,7 @@ def test_prodigy_step_in_graph():
     assert all(x == x for x in losses) and max(losses[-5:]) < 1.05 * losses[0], losses      # adapts d without blowing up
 
 
-@pytest.mark.parametrize("extra", [{}, dict(text_encoder_lora_optimizer="adamw", text_encoder_lora_lr=1e-4, text_encoder_lora_rank=8, ti_optimizer="prodigy", token_warmup_steps=5, training_attributes={"gpt_description": "a synthetic concept"})])
+@pytest.mark.parametrize("extra", [{}, dict(is_lora=False, disable_ti=True, unet_optimizer_type="AdamW8bit", unet_lr=2e-4), dict(text_encoder_lora_optimizer="adamw", text_encoder_lora_lr=1e-4, text_encoder_lora_rank=8, ti_optimizer="prodigy", token_warmup_steps=5, training_attributes={"gpt_description": "a synthetic concept"})])
 def test_train_generator_on_gpu(tmp_path, monkeypatch, extra):
     """main.py-style driver: config -> train() generator -> kohya checkpoint, on the HIP path with hipGraph replay.
     Second case: text-encoder LoRA (a21) next to the UNet LoRA, Prodigy on the token rows (a17)."""
@@ -149,8 +149,10 @@ def test_train_generator_on_gpu(tmp_path, monkeypatch, extra):
     monkeypatch.chdir(tmp_path)
     from sd_lora_trainer_amd.config import TrainingConfig
     from sd_lora_trainer_amd.train import train
-    cfg = TrainingConfig(lora_training_urls="synthetic:8", concept_mode="object", pretrained_model={"path": "synthetic:tinyxl"}, seed=3, resolution=256,
-                         train_batch_size=2, max_train_steps=40, lora_rank=8, unet_lr=2e-3, ti_lr=2e-3, caption_dropout=0.1, **extra)
+    kw = dict(lora_training_urls="synthetic:8", concept_mode="object", pretrained_model={"path": "synthetic:tinyxl"}, seed=3, resolution=256,
+              train_batch_size=2, max_train_steps=40, lora_rank=8, unet_lr=2e-3, ti_lr=2e-3, caption_dropout=0.1)
+    kw.update(extra)
+    cfg = TrainingConfig(**kw)
     gen = train(cfg)
     try:
         while True:
@@ -161,6 +163,12 @@ def test_train_generator_on_gpu(tmp_path, monkeypatch, extra):
     tot = ta["training_attributes"]["losses"]["tot_loss"]
     assert all(map(lambda x: x == x and abs(x) < 1e4, tot)) and len(tot) >= 10
     assert sum(tot[-5:]) / 5 < sum(tot[:5]) / 5, tot          # trains on the synthetic concept
+    if extra.get("is_lora") is False:      # full fine-tune (full_finetuning_example.json): the whole UNet under its diffusers names
+        from safetensors.torch import load_file
+        sd = load_file(os.path.join(out, "diffusion_pytorch_model.safetensors"))
+        assert sd["conv_in.weight"].shape == (64, 4, 3, 3) or sd["conv_in.weight"].dim() == 4
+        assert "mid_block.attentions.0.transformer_blocks.0.attn1.to_q.weight" in sd and "conv_norm_out.bias" in sd
+        return
     lora_files = [n for n in os.listdir(out) if n.endswith("_sdxl_lora.safetensors") or n.endswith("_tinyxl_lora.safetensors")]
     assert lora_files
     if extra:
