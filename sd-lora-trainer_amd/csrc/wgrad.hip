@@ -125,6 +125,15 @@ __global__ __launch_bounds__(256) void norm_affine_grad_kernel(CatIn2 in, const 
   }
 }
 
+// gamma and beta gradients are adjacent in the trainer's arena: one zero launch covers both
+void zero_pair(float* dgamma, float* dbeta, int C, hipStream_t s) {
+  if (dbeta == dgamma + C) sdlt_zero_async(dgamma, sizeof(float) * 2 * C, s);
+  else {
+    sdlt_zero_async(dgamma, sizeof(float) * C, s);
+    sdlt_zero_async(dbeta, sizeof(float) * C, s);
+  }
+}
+
 int row_chunks(int64_t M, int cblocks) {
   int64_t want = 1024 / cblocks;                // ~4 workgroups per CU in total
   int64_t maxc = (M + 63) / 64;
@@ -164,8 +173,7 @@ extern "C" int sdlt_layernorm_affine_grad(const void* x, int64_t ldx, const void
                                           const float* stats, float* dgamma, float* dbeta, void* stream) {
   if (M <= 0 || C <= 0 || !stats || !dgamma || !dbeta) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_layernorm_affine_grad: M=%d C=%d", M, C);
   hipStream_t s = (hipStream_t)stream;
-  sdlt_zero_async(dgamma, sizeof(float) * C, s);
-  sdlt_zero_async(dbeta, sizeof(float) * C, s);
+  zero_pair(dgamma, dbeta, C, s);
   CatIn2 in{(const bf16_t*)x, ldx, C, nullptr, 0};
   const int cb = (C + 63) / 64;
   hipLaunchKernelGGL(norm_affine_grad_kernel<0>, dim3(cb, row_chunks(M, cb)), dim3(256), 0, s, in, (const bf16_t*)dy, lddy,
@@ -179,8 +187,7 @@ extern "C" int sdlt_groupnorm_affine_grad(const sdlt_groupnorm_params* pp, float
   if (p.B <= 0 || p.HW <= 0 || p.C <= 0 || (p.C % 32) || !p.stats || !p.dy || !dgamma || !dbeta)
     SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_groupnorm_affine_grad: B=%d HW=%d C=%d", p.B, p.HW, p.C);
   hipStream_t s = (hipStream_t)stream;
-  sdlt_zero_async(dgamma, sizeof(float) * p.C, s);
-  sdlt_zero_async(dbeta, sizeof(float) * p.C, s);
+  zero_pair(dgamma, dbeta, p.C, s);
   CatIn2 in{(const bf16_t*)p.x1, p.ldx1, p.x2 ? p.C1 : p.C, (const bf16_t*)p.x2, p.ldx2};
   const int cb = (p.C + 63) / 64;
   const int64_t M = (int64_t)p.B * p.HW;
