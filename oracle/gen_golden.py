@@ -213,6 +213,66 @@ def main():
     with open(os.path.join(OUT, "config_snapshots.json"), "w") as fh:
         json.dump(snaps, fh, indent=1, sort_keys=True)
     gen_target_prompt_loss()
+    gen_dataset()
+
+
+def gen_dataset():
+    """(xii) PreprocessedDataset (trainer/dataset.py:31-193) run on a small on-disk dataset with a duck-typed VAE encoder
+    (returns a given posterior) and image processor: processed captions, latent-resolution masks and the fetched latents
+    for a seeded RNG.  Inputs (mask images as uint8 arrays, captions, posterior moments) travel with the outputs."""
+    _install_stubs()
+    import tempfile
+    import types as _t
+    import numpy as np
+    import pandas as pd
+    from PIL import Image
+    import trainer.dataset as rds
+    rng = np.random.RandomState(5)
+    g = torch.Generator().manual_seed(9)
+    n, size, lat = 3, [64, 48], (6, 8)                 # size = [w, h]; latent = [h/8, w/8]
+    posts = [torch.randn(1, 8, *lat, generator=g) for _ in range(n)]
+    posts[1][:, 4:] = 25.0                             # exercises the logvar clamp at 20
+    masks_u8 = [rng.randint(0, 256, (40, 52)).astype(np.uint8) for _ in range(n)]
+    captions = ["A photo of TOK, on a Beach", float("nan"), "tok and Tok with a dog"]
+    sub = {"TOK": "<s0><s1><s2>"}
+
+    class Dist:                                        # diffusers DiagonalGaussianDistribution (3P), restated for the fake encoder
+        def __init__(self, p):
+            self.mean, lv = torch.chunk(p, 2, dim=1)
+            self.std = torch.exp(0.5 * torch.clamp(lv, -30.0, 20.0))
+
+        def sample(self):
+            return self.mean + self.std * torch.randn(self.mean.shape)
+
+    class Enc:
+        dtype, device = torch.float32, torch.device("cpu")
+        config = _t.SimpleNamespace(scaling_factor=0.13025)
+
+        def __init__(self):
+            self.i = 0
+
+        def encode(self, image):
+            d = Dist(posts[self.i])
+            self.i += 1
+            return _t.SimpleNamespace(latent_dist=d)
+
+    pipe = _t.SimpleNamespace(image_processor=_t.SimpleNamespace(
+        preprocess=lambda pil: torch.from_numpy(np.array(pil).astype(np.float32) / 127.5 - 1.0).permute(2, 0, 1).unsqueeze(0)))
+    with tempfile.TemporaryDirectory() as tmp:
+        rows = []
+        for i in range(n):
+            Image.fromarray(rng.randint(0, 256, (40, 52, 3)).astype(np.uint8)).save(os.path.join(tmp, f"{i}.png"))
+            Image.fromarray(masks_u8[i]).save(os.path.join(tmp, f"{i}_mask.png"))
+            rows.append(dict(image_path=f"{i}.png", mask_path=f"{i}_mask.png", caption=captions[i]))
+        pd.DataFrame(rows).to_csv(os.path.join(tmp, "captions.csv"), index=False)
+        torch.manual_seed(123)
+        ds = rds.PreprocessedDataset(tmp, pipe, Enc(), size=size, substitute_caption_map=sub)
+        torch.manual_seed(321)
+        items = [ds[i] for i in range(n)]
+    torch.save(dict(posteriors=posts, masks_u8=masks_u8, captions_in=["" if c != c else c for c in captions], nan_index=1,
+                    substitute=sub, size=size, scaling_factor=0.13025, fetch_seed=321,
+                    captions=[it[0] for it in items], latents=[it[1] for it in items], masks=[it[2] for it in items]),
+               os.path.join(OUT, "dataset.pt"))
 
 
 def gen_target_prompt_loss():

@@ -21,6 +21,7 @@ from . import checkpoint as ckpt
 from . import schedule, topology
 from .config import TrainingConfig
 from .embedding_handler import TokenEmbeddingsHandler
+from .dataset import DiagonalGaussian
 from .optimizer import OptimizerCollection
 
 
@@ -94,7 +95,9 @@ def synthetic_cache(cfg, n_images, h, w, vocab, n_tokens, seed):
         l = [bos] + words[:3] + tok + words[3:] + [eos]
         ids[i, :len(l)] = torch.tensor(l)
         lists.append(l)
-    return dict(latents=torch.randn(n_images, 4, h, w, generator=g) * cfg["scaling_factor"],
+    # like the reference's dataset the cache holds the VAE POSTERIOR of each image (mean | logvar), sampled anew on every fetch
+    post = torch.cat([torch.randn(n_images, 4, h, w, generator=g), torch.full((n_images, 4, h, w), -4.0)], dim=1)
+    return dict(posterior=post,
                 masks=(torch.rand(n_images, 1, h, w, generator=g) * 0.95 + 0.05).repeat(1, 4, 1, 1), input_ids=ids, token_lists=lists,
                 tok_list=[bos] + tok + [eos], description_ids=[bos] + torch.randint(1, bos - 1, (8,), generator=g).tolist() + [eos])
 
@@ -119,7 +122,7 @@ def train(config: TrainingConfig, runtime=None):
         cache = synthetic_cache(cfg, n_img, h, w, vocab, config.n_tokens, config.seed)
     else:
         cache = torch.load(config.lora_training_urls)
-    n_img = cache["latents"].shape[0]
+    n_img = (cache["posterior"] if "posterior" in cache else cache["latents"]).shape[0]
     steps_per_epoch = max(n_img // B, 1)
     config.num_train_epochs = math.ceil(config.max_train_steps / steps_per_epoch)      # main.py:207
 
@@ -180,7 +183,12 @@ def train(config: TrainingConfig, runtime=None):
             if text is not None:
                 optimizers.optimizers["textual_inversion"].param_groups[0]["lr"] = lrs["textual_inversion"]
             idx = torch.as_tensor(order[step_in_epoch * B:(step_in_epoch + 1) * B])
-            latent, mask = cache["latents"][idx].to(rt.device), cache["masks"][idx].to(rt.device)
+            mask = cache["masks"][idx].to(rt.device)
+            if "posterior" in cache:       # dataset.py:184-187: latent_dist.sample() * scaling_factor on EVERY fetch
+                dist = DiagonalGaussian(cache["posterior"][idx].to(rt.device))
+                latent = dist.sample(g) * cfg["scaling_factor"]
+            else:
+                latent = cache["latents"][idx].to(rt.device)
             noise = torch.randn(latent.shape, generator=g, device=rt.device)
             if config.noise_offset > 0.0:                                                # main.py:313-317
                 noise += config.noise_offset * torch.randn((B, 4, 1, 1), generator=g, device=rt.device)

@@ -110,3 +110,31 @@ def test_train_generator_end_to_end(tmp_path, monkeypatch, version, disable_ti):
     ta = json.load(open(os.path.join(out_dir, "training_args.json")))
     assert ta["num_train_epochs"] == 2 and ta["pretrained_model"]["version"] == version
     assert np.isfinite(ta["training_attributes"]["losses"]["tot_loss"]).all()
+
+
+def test_latent_cache_matches_reference_dataset(golden_dir):
+    """dataset.py:31-193 (PreprocessedDataset) run in this container on a 3-image dataset with a duck-typed VAE encoder
+    (tests/golden/dataset.pt, oracle/gen_golden.py::gen_dataset): processed captions, latent-resolution masks and the
+    per-fetch posterior samples of `sd_lora_trainer_amd.dataset.LatentCache`."""
+    import os
+    import torch
+    from PIL import Image
+    from sd_lora_trainer_amd.dataset import LatentCache
+    g = torch.load(os.path.join(golden_dir, "dataset.pt"), weights_only=False)
+    caps = list(g["captions_in"])
+    caps[g["nan_index"]] = float("nan")
+    cache = LatentCache(g["posteriors"], [Image.fromarray(m) for m in g["masks_u8"]], caps, scaling_factor=g["scaling_factor"],
+                        size=g["size"], substitute_caption_map=g["substitute"])
+    assert cache.captions == list(g["captions"])
+    assert "<s0><s1><s2>" in cache.captions[0] and cache.captions[1] == "" and cache.captions[2].count("<s0><s1><s2>") == 2
+    torch.manual_seed(g["fetch_seed"])          # the reference samples from the global RNG
+    for i in range(len(cache)):
+        c, lat, m = cache[i]
+        torch.testing.assert_close(lat, g["latents"][i], rtol=1e-6, atol=1e-7)
+        assert torch.equal(m, g["masks"][i]) and m.shape == lat.shape
+    a, b = cache[0][1], cache[0][1]
+    assert not torch.equal(a, b)                # a fresh posterior sample on every fetch (dataset.py:186)
+    caps_b, lats, masks = cache.batch([2, 0])
+    assert lats.shape == (2, 4, 6, 8) and masks.shape == lats.shape and caps_b[0] == cache.captions[2]
+    ones = LatentCache(g["posteriors"][:1], None, ["x"], scaling_factor=1.0, size=g["size"])
+    assert torch.equal(ones.masks[0], torch.ones(4, 6, 8))
