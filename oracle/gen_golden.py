@@ -214,6 +214,26 @@ def main():
         json.dump(snaps, fh, indent=1, sort_keys=True)
     gen_target_prompt_loss()
     gen_dataset()
+    gen_blend_conditions()
+
+
+def gen_blend_conditions():
+    """(xiii) blend_conditions (trainer/inference.py:180-228): SDXL 4-tuples and SD1.5 2-tuples, default and explicit token scale."""
+    _install_stubs()
+    import contextlib
+    import io
+    import trainer.inference as rinf
+    g = torch.Generator().manual_seed(41)
+    cases = []
+    for sdxl in (True, False):
+        for lora_scale, token_scale in [(0.75, None), (0.85, None), (0.3, 0.0), (1.0, None)]:
+            mk = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+            e1 = (mk(1, 77, 32), mk(1, 77, 32)) + ((mk(1, 16), mk(1, 16)) if sdxl else ())
+            e2 = (mk(1, 77, 32), mk(1, 77, 32)) + ((mk(1, 16), mk(1, 16)) if sdxl else ())
+            with contextlib.redirect_stdout(io.StringIO()):
+                out, ts = rinf.blend_conditions(e1, e2, lora_scale, token_scale=token_scale)
+            cases.append(dict(e1=e1, e2=e2, lora_scale=lora_scale, token_scale_in=token_scale, out=out, token_scale=float(ts)))
+    torch.save(cases, os.path.join(OUT, "blend_conditions.pt"))
 
 
 def gen_dataset():
