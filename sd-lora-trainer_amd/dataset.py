@@ -2,8 +2,8 @@
 (/root/reference trainer/dataset.py:31-193) keeps, per image, the VAE POSTERIOR (not a latent) and the latent-
 resolution mask, and draws a fresh `latent_dist.sample() * scaling_factor` on every fetch (dataset.py:184-193) - the noise
 of the encoder is part of the training signal.  Captions are lower-cased and the trigger words substituted once
-(dataset.py:46-52).  The VAE encode itself (fp32, once per job) is outside this round's scope: `LatentCache` starts from
-the encoder's moments tensor `[1, 8, h, w]` (mean | logvar), which is what `vae.encode(x).latent_dist.parameters` holds.
+(dataset.py:46-52).  `LatentCache` holds the encoder's moments tensor `[1, 8, h, w]` (mean | logvar) per image - what
+`vae.encode(x).latent_dist.parameters` holds; `LatentCache.from_folder` produces them with vae.VaeEncoder (once per job).
 
 `DiagonalGaussian` restates diffusers' DiagonalGaussianDistribution (0.29.2, third party): logvar clamped to [-30, 20],
 std = exp(0.5 logvar), sample = mean + std * N(0, 1).
@@ -25,6 +25,15 @@ class DiagonalGaussian:
 
     def mode(self):
         return self.mean
+
+
+def prepare_image(pil_image, w=512, h=512):
+    """dataset.py:11-17: bicubic resize to the training size, then diffusers' VaeImageProcessor.preprocess for a PIL input
+    whose size is already a multiple of 8: RGB / 255 -> [1, 3, h, w] -> 2x - 1 (third party, restated)."""
+    from PIL import Image
+    pil_image = pil_image.resize((w, h), resample=Image.BICUBIC, reducing_gap=1)
+    arr = np.array(pil_image.convert("RGB")).astype(np.float32) / 255.0
+    return torch.from_numpy(arr).permute(2, 0, 1).unsqueeze(0) * 2.0 - 1.0
 
 
 def prepare_mask(pil_image, w=512, h=512):
@@ -70,6 +79,24 @@ class LatentCache:
                       for i, d in enumerate(self.dists)]
         self.captions = process_captions(captions, substitute_caption_map)
         self.scaling_factor, self.latent_hw = scaling_factor, hw
+
+    @classmethod
+    def from_folder(cls, data_dir, encoder, *, size, scaling_factor, substitute_caption_map=None):
+        """PreprocessedDataset.__init__ (dataset.py:31-90): `captions.csv` (image_path, caption[, mask_path]) in data_dir,
+        every image encoded ONCE by the VAE encoder (vae.VaeEncoder.encode_moments -> the posterior's moments)."""
+        import csv
+        import os
+        from PIL import Image
+        with open(os.path.join(data_dir, "captions.csv"), newline="") as fh:
+            rows = list(csv.DictReader(fh))
+        posts, masks = [], []
+        for r in rows:
+            img = prepare_image(Image.open(os.path.join(data_dir, r["image_path"])).convert("RGB"), size[0], size[1])
+            posts.append(encoder.encode_moments(img).float().cpu())
+            if "mask_path" in r:
+                masks.append(Image.open(os.path.join(data_dir, r["mask_path"])))
+        caps = [r.get("caption") if r.get("caption") not in (None, "") else float("nan") for r in rows]
+        return cls(posts, masks if masks else None, caps, scaling_factor=scaling_factor, size=size, substitute_caption_map=substitute_caption_map)
 
     def __len__(self):
         return len(self.dists)

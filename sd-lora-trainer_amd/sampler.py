@@ -104,3 +104,29 @@ class LatentSampler:
             e = eps[0:1] + guidance_scale * (eps[1:2] - eps[0:1])
             x = s.step(e, i, x)
         return x
+
+
+def render_images(sampler, decoder, embeds_list, render_size, out_dir, train_step, seed, *, scaling_factor, lora_scale,
+                  n_steps=25, guidance_scale=8.0):
+    """The loop of `render_images` (inference.py:363-385) after prompt encoding: one image per conditioning 4-tuple, ONE
+    generator seeded once for all of them, latents -> vae.decode(latents / scaling_factor) -> [0, 1] -> JPEG quality 95 as
+    `img_{train_step:04d}_{i}.jpg`; the adapters are set back to scale 1 afterwards.  render_size = (width, height)."""
+    import os
+    from PIL import Image
+    from . import vae as _vae
+    os.makedirs(out_dir, exist_ok=True)
+    dev = sampler.rt.device
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    w, h = render_size[0] // 8, render_size[1] // 8
+    sampler.set_lora_scale(lora_scale)
+    paths = []
+    try:
+        for i, embeds in enumerate(embeds_list):
+            lat = sampler.sample(embeds, h, w, steps=n_steps, guidance_scale=guidance_scale, generator=gen, size=(render_size[1], render_size[0]))
+            img = _vae.postprocess(decoder.decode(lat / scaling_factor))[0].permute(1, 2, 0)
+            arr = (img.float().cpu().numpy() * 255).round().astype("uint8")
+            paths.append(os.path.join(out_dir, f"img_{train_step:04d}_{i}.jpg"))
+            Image.fromarray(arr).save(paths[-1], format="JPEG", quality=95)
+    finally:
+        sampler.set_lora_scale(1.0)
+    return paths
