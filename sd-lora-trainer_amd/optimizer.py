@@ -64,13 +64,14 @@ class OptimizerCollection:
             self.optimizers["text_encoders"] = _FusedAdamWHandle("text_encoders", config.text_encoder_lora_lr, config.text_encoder_lora_weight_decay)
         self.learning_rate_tracker = {k: [] for k, v in self.optimizers.items() if v is not None}
 
-    def step(self):
-        """Runs forward, backward and both fused AdamW updates of ONE training step with the current learning rates."""
+    def step(self, last_batch=False):
+        """Runs forward, backward and the fused optimizer updates of ONE training step with the current learning rates (under
+        gradient accumulation the optimizers only step on every k-th call or on the last batch of an epoch, main.py:366)."""
         lr_unet = self.optimizers["unet"].param_groups[0]["lr"]
         ti = self.optimizers["textual_inversion"]
         lr_ti = ti.param_groups[0]["lr"] if ti is not None else 0.0
         te = self.optimizers["text_encoders"]
-        self.ts.run(lr_unet, lr_ti, te.param_groups[0]["lr"] if te is not None else 0.0)
+        self.ts.run(lr_unet, lr_ti, te.param_groups[0]["lr"] if te is not None else 0.0, last_batch=last_batch)
         for k in self.learning_rate_tracker:
             self.learning_rate_tracker[k].append(self.optimizers[k].param_groups[0]["lr"])
 

@@ -207,6 +207,13 @@ class TrainStep:
         self.te_arena = text.arena if text is not None else None
         self.te_wd = text_lora_weight_decay
         self.te_hyper = z(16) if self.te_arena is not None else None
+        # gradient accumulation (main.py:362-366): every micro-step back-propagates loss / k; the optimizers step on the k-th
+        # (or on the last batch of an epoch).  The kernels overwrite their gradient buffers, so micro-steps add them into
+        # accumulators that are handed back at the boundary.
+        self._micro, self._acc, self.graphs_micro = 0, None, None
+        if grad_accum > 1:
+            gs = [self.group.grads] + ([self.ti.grads] if self.ti is not None else []) + ([self.te_arena.grads] if self.te_arena is not None else [])
+            self._acc = [(g_, torch.zeros_like(g_)) for g_ in gs]
 
     # -------------------------------------------------------------------------------- inputs
     def set_batch(self, latent, noise, timesteps, mask, ctx=None, pooled=None, time_ids=None, ids=None, caption_token_lists=None):
@@ -305,7 +312,8 @@ class TrainStep:
             P = self.pooled.shape[1] if self.pooled is not None else 0
             d_pooled = self.unet.dadd_in[:, :P] if self.rt.want_dpooled else None
             self.text.backward(self.dctx, d_pooled, self.ti.grad_rows)
-            self.ti.add_regulariser()                  # a14 (only the std term is live by default, config.py:75-77)
+            # a14 (only the std term is live by default, config.py:75-77); part of the loss, hence / k under accumulation
+            self.ti.add_regulariser(std_loss_w=self.ti.std_loss_w / self.grad_accum)
 
     def forward_backward(self):
         self._phase_text_fwd()
@@ -343,14 +351,30 @@ class TrainStep:
             self.rt.ops.adamw_fused(e.params, e.grads, e.m, e.v, self.te_hyper, None)
             e.refresh_shadows()
 
+    def _accumulate(self, release):
+        if self._acc is not None:
+            for g_, a in self._acc:
+                a.add_(g_)
+                if release:
+                    g_.copy_(a)
+                    a.zero_()
+
+    def body_micro(self):
+        """A micro-step that is not an accumulation boundary: gradients only."""
+        self.forward_backward()
+        self._accumulate(False)
+
     def body(self):
         self.forward_backward()
+        self._accumulate(True)
         self.sync_gradients()
         self.optimizer_step()
 
     def _phases(self):
         if self.world > 1:         # the collective stays outside the graphs: forward+backward | all-reduce | optimizer
-            return [self.forward_backward, self.optimizer_step]
+            return [lambda: (self.forward_backward(), self._accumulate(True)), self.optimizer_step]
+        if self._acc is not None:
+            return [self.body]
         if self.text is None:
             return [self.body]
         return [self._phase_text_fwd, self._phase_unet, lambda: (self._phase_text_bwd(), self.optimizer_step())]
@@ -456,8 +480,13 @@ class TrainStep:
                     frozen = [cap([self._phase_text_fwd, self._phase_unet, self._phase_opt_frozen_ti], pool)]
             return graphs, frozen, pool
 
-        self.graphs, self.graphs_frozen, _ = cap_set(None)
+        self.graphs, self.graphs_frozen, pool = cap_set(None)
         self.graph = self.graphs[0]
+        if self._acc is not None:
+            self.graphs_frozen = None
+            self.graphs_micro = [cap([self.body_micro], pool)]
+            for _, acc_buf in self._acc:
+                acc_buf.zero_()
         for t, c in zip(state, snap):
             t.copy_(c)
         a.refresh_shadows()
@@ -470,11 +499,20 @@ class TrainStep:
                 pr.reset()
         self.opt_step = step0
 
-    def run(self, lr, lr_ti=0.0, lr_te=0.0):
+    def run(self, lr, lr_ti=0.0, lr_te=0.0, last_batch=False):
+        if self._acc is not None:
+            self._micro += 1
+            if self._micro % self.grad_accum != 0 and not last_batch:        # main.py:366
+                if self.graphs_micro is not None:
+                    self.graphs_micro[0].replay()
+                else:
+                    self.body_micro()
+                return
+            self._micro = 0
         self.set_hyper(lr, lr_ti, lr_te)
         # frozen-TI fast path (Prodigy with lr 0 is a no-op as well: sdlt_prodigy_step); never with text-encoder LoRA, whose
         # gradients need the text backward for the whole run
-        frozen = self.text is not None and lr_ti == 0.0 and self.te_arena is None
+        frozen = self.text is not None and lr_ti == 0.0 and self.te_arena is None and self._acc is None
         self._frozen_last = frozen
         if self.graph is not None and self.world > 1:
             self.graphs[0].replay()

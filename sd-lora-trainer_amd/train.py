@@ -210,7 +210,7 @@ def train(config: TrainingConfig, runtime=None):
             if not captured and rt.device.type == "cuda":
                 ts.capture(warmup=1)
                 captured = True
-            optimizers.step()
+            optimizers.step(last_batch=step_in_epoch + 1 == steps_per_epoch)
             optimizers.zero_grad()
             if global_step % max(config.max_train_steps // 20, 1) == 0:
                 losses["img_loss"].append(float(ts.loss))

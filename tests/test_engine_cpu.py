@@ -99,3 +99,43 @@ def test_engine_matches_oracle_autograd(version, B, gamma):
     pref, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
     L.adamw_step(pref, gref, m, v, 1, 1e-3, weight_decay=0.004)
     torch.testing.assert_close(unet.arena.params, pref, rtol=1e-5, atol=1e-7)
+
+
+def test_gradient_accumulation():
+    """main.py:362-366: loss / k per micro-step, optimizers step on every k-th micro-step (or on the last batch of an epoch).
+    Accumulated gradient == mean of the micro-batch gradients; parameters only move at the boundary."""
+    cfg, B, rank, h = U.CONFIGS["tiny15"], 1, 4, 16
+    sd = U.init_unet_state(cfg, seed=0)
+    lora = U.init_lora(cfg, rank, seed=1, b_std=0.05)
+    g = torch.Generator().manual_seed(4)
+    batches = [(torch.randn(B, 4, h, h, generator=g) * cfg["scaling_factor"], torch.randn(B, 4, h, h, generator=g), torch.tensor([100 + 400 * i]),
+                torch.ones(B, 4, h, h), torch.randn(B, 77, cfg["cross_dim"], generator=g)) for i in range(3)]
+
+    def make(ga):
+        rt = unet_mod.Runtime("cpu", B, act_dtype=torch.float32, ops=emu_ops)
+        unet = unet_mod.UNet(rt, topology.CONFIGS["tiny15"], sd, lora_rank=rank)
+        unet.arena.load(lora)
+        return unet, step_mod.TrainStep(rt, unet, latent_hw=(h, h), l1_penalty=0.0, weight_decay=0.0, grad_accum=ga)
+    u1, t1 = make(1)
+    gs = []
+    for b in batches[:2]:
+        t1.set_batch(*b)
+        t1.forward_backward()
+        gs.append(u1.arena.grads.clone())
+    u2, t2 = make(2)
+    p0 = u2.arena.params.clone()
+    t2.set_batch(*batches[0])
+    t2.run(1e-3)
+    assert torch.equal(u2.arena.params, p0) and t2.opt_step == 0          # micro-step: no optimizer step
+    t2.set_batch(*batches[1])
+    t2.run(1e-3)
+    assert t2.opt_step == 1 and not torch.equal(u2.arena.params, p0)
+    torch.testing.assert_close(u2.arena.grads, 0.5 * (gs[0] + gs[1]), rtol=1e-5, atol=1e-9)
+    pref, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    L.adamw_step(pref, 0.5 * (gs[0] + gs[1]), m, v, 1, 1e-3, weight_decay=0.0)
+    torch.testing.assert_close(u2.arena.params, pref, rtol=1e-5, atol=1e-8)
+    # last batch of an epoch forces the step even though the accumulation window is not full
+    p1 = u2.arena.params.clone()
+    t2.set_batch(*batches[2])
+    t2.run(1e-3, last_batch=True)
+    assert t2.opt_step == 2 and not torch.equal(u2.arena.params, p1) and t2._micro == 0

@@ -177,3 +177,41 @@ def test_train_generator_on_gpu(tmp_path, monkeypatch, extra):
         from safetensors.torch import load_file
         keys = list(load_file(os.path.join(out, lora_files[0])))
         assert any(k.startswith("lora_te1_") for k in keys) and any(k.startswith("lora_te2_") for k in keys) and any(k.startswith("lora_unet_") for k in keys)
+
+
+def test_gradient_accumulation_graphs():
+    """gradient_accumulation_steps = 2 on the HIP path with hipGraph replays: a micro graph (gradients only) and the boundary
+    graph (accumulate, hand back, optimizer); parameters move on every second call only."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import sd_lora_trainer_amd.step as S
+    import sd_lora_trainer_amd.unet as M
+    from sd_lora_trainer_amd import topology
+    version, B, rank, h = "tinyxl", 1, 8, 16
+    cfg = U.CONFIGS[version]
+    sd = U.init_unet_state(cfg, seed=0)
+    latent, noise, mask, t, ctx, pooled, tid, add = _inputs(cfg, B, h)
+    rt = M.Runtime("cuda:0", B)
+    unet = M.UNet(rt, topology.CONFIGS[version], sd, lora_rank=rank)
+    unet.arena.load(U.init_lora(cfg, rank, seed=1, b_std=0.05))
+    ts = S.TrainStep(rt, unet, latent_hw=(h, h), grad_accum=2)
+    dv = lambda x: x.cuda() if x is not None else None  # noqa: E731
+    ts.set_batch(dv(latent), dv(noise), dv(t), dv(mask), dv(ctx), dv(pooled), dv(tid))
+    ts.capture(warmup=1)
+    moved = []
+    for i in range(4):
+        p = unet.arena.params.clone()
+        ts.run(1e-3)
+        torch.cuda.synchronize()
+        moved.append(not torch.equal(p, unet.arena.params))
+    assert moved == [False, True, False, True] and ts.opt_step == 2
+    # same batch twice: the accumulated gradient equals the single-step gradient (two halves)
+    g_acc = unet.arena.grads.clone()
+    ts2 = S.TrainStep(rt, unet, latent_hw=(h, h), grad_accum=1)
+    ts2.set_batch(dv(latent), dv(noise), dv(t), dv(mask), dv(ctx), dv(pooled), dv(tid))
+    unet.arena.params.copy_(p)
+    unet.arena.refresh_shadows()
+    ts2.forward_backward()
+    torch.cuda.synchronize()
+    cos, rel = _cos_rel(g_acc, unet.arena.grads)
+    assert cos >= 0.995 and rel <= 5e-2, (cos, rel)
