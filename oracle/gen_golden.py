@@ -215,6 +215,23 @@ def main():
     gen_target_prompt_loss()
     gen_dataset()
     gen_blend_conditions()
+    gen_prompt_norm()
+
+
+def gen_prompt_norm():
+    """(xiv) ConditioningRegularizer._compute_regularization_loss (trainer/loss.py:235-239) with autograd gradients."""
+    _install_stubs()
+    import types as _t
+    import trainer.loss as rloss
+    g = torch.Generator().manual_seed(17)
+    cases = []
+    for B, D, target in [(1, 64, 34.5), (3, 48, 27.8)]:
+        pe = (torch.randn(B, 77, D, generator=g) * 3).requires_grad_(True)
+        me = _t.SimpleNamespace(target_norm=target)
+        loss, val = rloss.ConditioningRegularizer._compute_regularization_loss(me, pe)
+        (gr,) = torch.autograd.grad(loss, pe)
+        cases.append(dict(prompt_embeds=pe.detach(), target=target, loss=loss.detach(), value=val.detach(), grad=gr))
+    torch.save(cases, os.path.join(OUT, "prompt_norm.pt"))
 
 
 def gen_blend_conditions():

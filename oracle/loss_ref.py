@@ -153,6 +153,14 @@ class DistributionStats:
         return torch.norm(self.target_cov - cov, p="fro") / (r.shape[1] ** 2)
 
 
+def prompt_norm_loss(prompt_embeds, target_norm):
+    """ConditioningRegularizer._compute_regularization_loss (trainer/loss.py:235-239), weighted by cond_reg_w (0 by default):
+    the mean over tokens 2.. of the batch-mean embedding norm is pulled to 34.5 (SDXL) / 27.8 (SD1.5) (loss.py:182).
+    Returns (loss, norm value)."""
+    value = prompt_embeds.norm(dim=-1).mean(dim=0)[2:].mean()
+    return (value - target_norm) ** 2, value
+
+
 def target_prompt_loss(prompt_embeds, target_embeds, pooled=None, target_pooled=None):
     """TokenEmbeddingsHandler.compute_target_prompt_loss (trainer/embedding_handler.py:288-318), the objective of the
     token warm-up loop (:321-399, weighted 0.2 there): MSE + (1 - mean cosine) to the encoded target prompt, plus a

@@ -146,7 +146,8 @@ class TrainStep:
     def __init__(self, rt: Runtime, unet: UNet, *, latent_hw, snr_gamma=5.0, v_prediction=False, l1_penalty=0.03,
                  weight_decay=0.004, grad_accum=1, betas=(0.9, 0.999), eps=1e-8, text: TextStack = None, n_tokens=3,
                  token_attention_loss_w=3e-7, ti_weight_decay=0.0, ti_std_loss_w=0.01, optimizer="adamw", ti_optimizer="adamw",
-                 prodigy_d_coef=1.0, prodigy_growth_rate=1.05, text_lora_weight_decay=1e-5, process_group=None):
+                 prodigy_d_coef=1.0, prodigy_growth_rate=1.05, text_lora_weight_decay=1e-5, process_group=None,
+                 cond_reg_w=0.0, tok_cov_reg_w=0.0, cond_target_norm=None):
         """process_group: data-parallel full fine-tune only (`unet.trainer` set) - a torch.distributed group (or True for the
         default one) over which the gradient arena is all-reduced once per optimiser step (RCCL on the GPU)."""
         if optimizer == "AdamW8bit":
@@ -207,6 +208,10 @@ class TrainStep:
         self.te_arena = text.arena if text is not None else None
         self.te_wd = text_lora_weight_decay
         self.te_hyper = z(16) if self.te_arena is not None else None
+        # optional regularisers of ConditioningRegularizer (loss.py:196-251), both weighted 0 by default (config.py:75-77)
+        self.cond_reg_w, self.tok_cov_reg_w = cond_reg_w, tok_cov_reg_w
+        self.cond_target_norm = cond_target_norm if cond_target_norm is not None else (34.5 if unet.cfg["addition"] else 27.8)   # loss.py:182
+        self.cond_reg_loss, self.cond_norm = z(1), z(1)
         # gradient accumulation (main.py:362-366): every micro-step back-propagates loss / k; the optimizers step on the k-th
         # (or on the last batch of an epoch).  The kernels overwrite their gradient buffers, so micro-steps add them into
         # accumulators that are handed back at the boundary.
@@ -311,7 +316,20 @@ class TrainStep:
         if self.text is not None:
             P = self.pooled.shape[1] if self.pooled is not None else 0
             d_pooled = self.unet.dadd_in[:, :P] if self.rt.want_dpooled else None
+            if self.cond_reg_w > 0.0:
+                # cond_reg_w * (mean_{t >= 2} mean_b |prompt_embeds[b, t]| - target)^2  (loss.py:201-205, 235-239): its gradient
+                # joins the UNet's gradient w.r.t. the conditioning before the text-encoder backward
+                pe = self.ctx.view(self.B, CTX_PAD, -1)[:, 2:T_TOKENS].float()
+                nrm = pe.norm(dim=-1, keepdim=True)
+                val = nrm.mean()
+                self.cond_norm.copy_(val.reshape(1))
+                self.cond_reg_loss.copy_((self.cond_reg_w * (val - self.cond_target_norm) ** 2).reshape(1))
+                coef = self.cond_reg_w / self.grad_accum * 2.0 * (val - self.cond_target_norm) / (self.B * (T_TOKENS - 2))
+                dv = self.dctx.view(self.B, CTX_PAD, -1)
+                dv[:, 2:T_TOKENS] += (coef * pe / nrm).to(dv.dtype)
             self.text.backward(self.dctx, d_pooled, self.ti.grad_rows)
+            if self.tok_cov_reg_w > 0.0:
+                self.ti.add_covariance(self.tok_cov_reg_w / self.grad_accum)
             # a14 (only the std term is live by default, config.py:75-77); part of the loss, hence / k under accumulation
             self.ti.add_regulariser(std_loss_w=self.ti.std_loss_w / self.grad_accum)
 

@@ -31,6 +31,7 @@ class TiState:
             pre = e.table[: e.V - n_tok].float()
             stds = pre.std(-1)
             self.stats.append((float(stds.mean()), float(stds.std() ** 2 / stds.mean())))
+            self._pretrained = getattr(self, "_pretrained", []) + [(e, e.V - n_tok)]
             off += sz
         self._plan = rt.ops.ShadowPlan(sh, rt.device)
         self.std_loss_w = std_loss_w
@@ -54,3 +55,25 @@ class TiState:
         w = (self.std_loss_w if std_loss_w is None else std_loss_w) / len(self.encoders)
         for r, g, (tm, tv) in zip(self.rows, self.grad_rows, self.stats):
             self.rt.ops.ti_std_reg(r, g, self.reg_loss, target_mean=tm, target_var=tv, weight=w)
+
+    def add_covariance(self, weight):
+        """tok_cov_reg_w term (trainer/loss.py:213-221, 275-289; weight 0 by default): loss += weight * mean_enc( || Cov(pretrained
+        table) - Cov(rows) ||_F / D^2 ), gradient added to the row gradients.  [n, D] x [D, D] arithmetic on the trainable rows:
+        torch ops (the target covariance of each table is built once, lazily)."""
+        if getattr(self, "_target_cov", None) is None:
+            self._target_cov = []
+            for e, nv in self._pretrained:
+                t = e.table[:nv].float()
+                adj = t - t.mean(0)
+                self._target_cov.append(adj.T @ adj / (nv - 1))
+        self.cov_loss = torch.zeros(1, dtype=F32, device=self.rt.device)
+        w = weight / len(self.encoders)
+        for r, g, T in zip(self.rows, self.grad_rows, self._target_cov):
+            n, D = r.shape
+            A = r - r.mean(0)
+            diff = T - A.T @ A / (n - 1)
+            nrm = torch.linalg.norm(diff)
+            self.cov_loss += w * nrm / (D * D)
+            G = -diff / (nrm * D * D)                    # d loss / d Cov(rows)
+            dA = A @ (G + G.T) / (n - 1)
+            g.add_(w * (dA - dA.mean(0)))

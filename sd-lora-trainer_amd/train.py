@@ -133,7 +133,8 @@ def train(config: TrainingConfig, runtime=None):
                      token_attention_loss_w=config.token_attention_loss_w, ti_weight_decay=config.ti_weight_decay,
                      optimizer=config.unet_optimizer_type, ti_optimizer=config.ti_optimizer,
                      prodigy_d_coef=config.prodigy_d_coef, prodigy_growth_rate=config.unet_prodigy_growth_factor,
-                     text_lora_weight_decay=config.text_encoder_lora_weight_decay)
+                     text_lora_weight_decay=config.text_encoder_lora_weight_decay,
+                     cond_reg_w=config.cond_reg_w, tok_cov_reg_w=config.tok_cov_reg_w)
     handler = None
     if text is not None:
         handler = TokenEmbeddingsHandler(ts.ti, config.inserting_list_tokens)

@@ -98,3 +98,14 @@ def test_target_prompt_loss(golden_dir):
         torch.testing.assert_close(grads[0], c["d_prompt"], rtol=1e-5, atol=1e-9)
         if pp is not None:
             torch.testing.assert_close(grads[1], c["d_pooled"], rtol=1e-5, atol=1e-9)
+
+
+def test_prompt_norm_regulariser(golden_dir):
+    """loss.py:235-239 (cond_reg_w term): value, norm read-out and gradient from the reference's own method."""
+    for c in _load(golden_dir, "prompt_norm.pt"):
+        pe = c["prompt_embeds"].clone().requires_grad_(True)
+        loss, val = L.prompt_norm_loss(pe, c["target"])
+        torch.testing.assert_close(loss, c["loss"], rtol=1e-6, atol=1e-8)
+        torch.testing.assert_close(val, c["value"], rtol=1e-6, atol=0)
+        (gr,) = torch.autograd.grad(loss, pe)
+        torch.testing.assert_close(gr, c["grad"], rtol=1e-5, atol=1e-10)

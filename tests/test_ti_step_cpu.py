@@ -275,3 +275,58 @@ def test_token_warmup_matches_oracle(version):
         torch.testing.assert_close(r, e.detach()[-NTOK:], rtol=0, atol=2e-2 * steps * lr)
         assert float((r - e.detach()[-NTOK:]).abs().max()) <= 2e-2 * steps * lr, moved
     assert float(ts.ti.m.abs().max()) == 0.0                 # the warm-up optimizer's moments are not carried into training
+
+
+@pytest.mark.parametrize("version", ["tiny15", "tinyxl"])
+def test_optional_regularisers_match_oracle(version):
+    """cond_reg_w (prompt-embedding norm, loss.py:201-205, 235-239) and tok_cov_reg_w (covariance of the token rows,
+    loss.py:213-221, 275-289), both 0 by default: token-row gradients of the whole step with the two terms switched on."""
+    cfg = U.CONFIGS[version]
+    xl = cfg["addition"]
+    B, rank, h, w_cond, w_cov = 2, 4, 16, 3e-3, 50.0
+    sd = U.init_unet_state(cfg, seed=0)
+    lora = U.init_lora(cfg, rank, seed=1, b_std=0.05)
+    hf = [_hf("quick_gelu", False, 64, 1, 11), _hf("gelu", True, 64, 1, 12, proj=cfg["proj_class_in"] - 6 * cfg["addition_time_embed_dim"])] if xl \
+        else [_hf("quick_gelu", False, 64, 2, 11)]
+    g = torch.Generator().manual_seed(3)
+    latent = torch.randn(B, 4, h, h, generator=g) * cfg["scaling_factor"]
+    noise = torch.randn(B, 4, h, h, generator=g)
+    mask = torch.ones(B, 4, h, h)
+    t = torch.tensor([10, 900])
+    tid = torch.tensor([[1024., 1024, 0, 0, 128, 128]] * B) if xl else None
+    lists, ids = _captions(B)
+    target = 34.5 if xl else 27.8
+
+    embs = [m.get_input_embeddings().weight for m in hf]
+    outs = [m(input_ids=ids, output_hidden_states=True) for m in hf]
+    if xl:
+        ctx = torch.cat([outs[0].hidden_states[-2], outs[1].hidden_states[-2]], dim=-1)
+        add = {"text_embeds": outs[1].text_embeds, "time_ids": tid}
+    else:
+        ctx, add = outs[0].last_hidden_state, None
+    acp = L.ddpm_alphas_cumprod()
+    noisy = L.add_noise(acp, latent, noise, t)
+    pred = U.unet_forward(cfg, sd, noisy, t, ctx, add, lora={k: v for k, v in lora.items()})
+    img_loss = L.diffusion_loss(pred, noise, noisy, mask, acp, t, snr_gamma=5.0)
+    cond, norm_val = L.prompt_norm_loss(ctx, target)
+    cov = torch.stack([L.DistributionStats(e.detach()[:-NTOK]).cov_loss(e[-NTOK:]) for e in embs]).mean()
+    grads = torch.autograd.grad(img_loss + w_cond * cond + w_cov * cov, embs)
+
+    rt = unet_mod.Runtime("cpu", B, act_dtype=torch.float32, ops=emu_ops)
+    unet = unet_mod.UNet(rt, topology.CONFIGS[version], sd, lora_rank=rank)
+    unet.arena.load(lora)
+    sds = [{k: v.detach() for k, v in m.state_dict().items()} for m in hf]
+    kw = [dict(heads=1, act="quick_gelu", mode="penultimate", with_projection=False), dict(heads=1, act="gelu", mode="penultimate", with_projection=True)] \
+        if xl else [dict(heads=2, act="quick_gelu", mode="last", with_projection=False)]
+    encs = [clip_mod.ClipTextEncoder(rt, f"te{i + 1}", sds[i], n_train=NTOK, **k) for i, k in enumerate(kw)]
+    text = step_mod.TextStack(rt, encs, pool_mode="first_eos", eos_token_id=EOS)
+    ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, l1_penalty=0.0, weight_decay=0.0, text=text, n_tokens=NTOK,
+                            token_attention_loss_w=0.0, ti_std_loss_w=0.0, cond_reg_w=w_cond, tok_cov_reg_w=w_cov)
+    ts.set_batch(latent, noise, t, mask, time_ids=tid, ids=[ids] * len(encs), caption_token_lists=lists)
+    ts.forward_backward()
+    torch.testing.assert_close(ts.cond_norm[0], norm_val.detach(), rtol=1e-4, atol=0)
+    torch.testing.assert_close(ts.cond_reg_loss[0], (w_cond * cond).detach(), rtol=1e-3, atol=1e-8)
+    torch.testing.assert_close(ts.ti.cov_loss[0], (w_cov * cov).detach(), rtol=1e-4, atol=1e-9)
+    for got, ref in zip(ts.ti.grad_rows, [ge[-NTOK:] for ge in grads]):
+        scale = float(ref.abs().max())
+        assert scale > 0 and float((got - ref).abs().max()) <= 3e-3 * scale, (float((got - ref).abs().max()), scale)
