@@ -204,20 +204,23 @@ int sdlt_layernorm_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy,
  * nn.Linear / nn.Conv2d weight, bias and norm affine parameter of the UNet receives a gradient.
  * dW[N,K] = dY^T X contracts over tokens; both operands are first transposed into token-contiguous bf16 panels and the
  * product is an ordinary sdlt_gemm_bf16 call (X := dY^T [N,Mp], W := X^T [K,Mp], fp32 output [N,K]):
- *   sdlt_wgrad_transpose : out[c*ldo + m] = x[m*ldx + c]           (m < M; columns M..Mp-1 zero; Mp % 64 == 0)
+ *   sdlt_wgrad_transpose : out[c*ldo + m] = x[m*ldx + c]           (m < M; columns M..Mp-1 zero; Mp % 64 == 0);
+ *                          colsum_acc (optional, fp32 [C]) += column sums of x - the bias gradient when x = dY, for free
  *   sdlt_wgrad_im2col_t  : transposed im2col of an NHWC activation for a 3x3 / pad-1 conv:
  *                          out[(tap*C + c)*ldo + m] = x[b, (oy*stride+ky-1)/ups, (ox*stride+kx-1)/ups, c] or 0 outside,
  *                          m = (b, oy, ox) over the conv OUTPUT grid (H*ups/stride x W*ups/stride), tap = ky*3 + kx.
- * Bias gradients are sdlt_colsum of dY.  d gamma / d beta of the norms (zeroed, then accumulated with fp32 atomics):
+ * d gamma / d beta of the norms (fp32 atomics; zeroed first unless `accumulate`, in which case the caller has zeroed them -
+ * the trainer keeps all vector gradients in one region and clears it with a single launch per step):
  *   sdlt_layernorm_affine_grad : dgamma[c] = sum_m dy*xhat, dbeta[c] = sum_m dy     (stats of sdlt_layernorm_fwd)
  *   sdlt_groupnorm_affine_grad : same for GroupNorm(32) (+SiLU: dy is the gradient w.r.t. the activated output); reads
  *                                x1/x2, dy, stats, gamma, beta, eps, silu, B, HW, C of the params struct. */
-int sdlt_wgrad_transpose(const void* x, int64_t ldx, int32_t M, int32_t C, void* out, int64_t ldo, int32_t Mp, void* stream);
+int sdlt_wgrad_transpose(const void* x, int64_t ldx, int32_t M, int32_t C, void* out, int64_t ldo, int32_t Mp, float* colsum_acc,
+                         void* stream);
 int sdlt_wgrad_im2col_t(const void* x, int64_t ldx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t stride, int32_t ups,
                         void* out, int64_t ldo, int32_t Mp, void* stream);
 int sdlt_layernorm_affine_grad(const void* x, int64_t ldx, const void* dy, int64_t lddy, int32_t M, int32_t C,
-                               const float* stats, float* dgamma, float* dbeta, void* stream);
-int sdlt_groupnorm_affine_grad(const sdlt_groupnorm_params* p, float* dgamma, float* dbeta, void* stream);
+                               const float* stats, float* dgamma, float* dbeta, int32_t accumulate, void* stream);
+int sdlt_groupnorm_affine_grad(const sdlt_groupnorm_params* p, float* dgamma, float* dbeta, int32_t accumulate, void* stream);
 
 /* GEGLU (diffusers FeedForward, activation_fn="geglu"): in [M, 2*Ch] = (h | g), out = h * gelu(g). */
 int sdlt_geglu_fwd(const void* in, int64_t ldin, int32_t M, int32_t Ch, void* out, int64_t ldout, void* stream);

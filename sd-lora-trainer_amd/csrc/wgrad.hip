@@ -40,7 +40,7 @@ __device__ __forceinline__ uint4 load_row8(const bf16_t* x, int64_t ldx, int64_t
 }
 
 __global__ __launch_bounds__(256) void transpose_gather_kernel(const bf16_t* x, int64_t ldx, int M, int C, bf16_t* out,
-                                                                int64_t ldo, GatherGeom g) {
+                                                                int64_t ldo, GatherGeom g, float* colsum) {
   __shared__ uint32_t tileT[64][34];          // [channel][row pair], 8-B aligned rows
   const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tap = blockIdx.z;
   const int t = threadIdx.x;
@@ -65,6 +65,16 @@ __global__ __launch_bounds__(256) void transpose_gather_kernel(const bf16_t* x, 
       bf16_t* dst = out + ((int64_t)tap * C + c0 + c) * ldo + m0 + w0 * 2;
       *(uint4*)dst = make_uint4(p0.x, p0.y, p1.x, p1.y);
       *(uint4*)(dst + 8) = make_uint4(p2.x, p2.y, p3.x, p3.y);
+      if (colsum) {
+        // bias gradient for free: the 16 tokens this thread just read, summed; the 4 threads of a channel combine, one atomic each tile
+        const uint32_t w[8] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, p3.x, p3.y};
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += bf2f(w[j] & 0xffffu) + bf2f(w[j] >> 16);
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        if ((t & 3) == 0) atomicAdd(&colsum[c0 + c], sum);
+      }
     }
   }
 }
@@ -145,12 +155,12 @@ int row_chunks(int64_t M, int cblocks) {
 }  // namespace
 
 extern "C" int sdlt_wgrad_transpose(const void* x, int64_t ldx, int32_t M, int32_t C, void* out, int64_t ldo, int32_t Mp,
-                                    void* stream) {
+                                    float* colsum_acc, void* stream) {
   if (M <= 0 || C <= 0 || Mp < M || (Mp % 64) || (ldx % 8) || (ldo % 8) || ldo < Mp)
     SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wgrad_transpose: M=%d C=%d Mp=%d ldx=%lld ldo=%lld", M, C, Mp, (long long)ldx, (long long)ldo);
   GatherGeom g{};
   hipLaunchKernelGGL(transpose_gather_kernel, dim3(Mp / 64, (C + 63) / 64, 1), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, ldx, M, C, (bf16_t*)out, ldo, g);
+                     (const bf16_t*)x, ldx, M, C, (bf16_t*)out, ldo, g, colsum_acc);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }
@@ -164,16 +174,16 @@ extern "C" int sdlt_wgrad_im2col_t(const void* x, int64_t ldx, int32_t B, int32_
   if (Mp < M || (Mp % 64) || (ldx % 8) || (ldo % 8) || ldo < Mp)
     SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wgrad_im2col_t: M=%lld Mp=%d ldx=%lld ldo=%lld", (long long)M, Mp, (long long)ldx, (long long)ldo);
   hipLaunchKernelGGL(transpose_gather_kernel, dim3(Mp / 64, (C + 63) / 64, 9), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, ldx, (int)M, C, (bf16_t*)out, ldo, g);
+                     (const bf16_t*)x, ldx, (int)M, C, (bf16_t*)out, ldo, g, (float*)nullptr);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }
 
 extern "C" int sdlt_layernorm_affine_grad(const void* x, int64_t ldx, const void* dy, int64_t lddy, int32_t M, int32_t C,
-                                          const float* stats, float* dgamma, float* dbeta, void* stream) {
+                                          const float* stats, float* dgamma, float* dbeta, int32_t accumulate, void* stream) {
   if (M <= 0 || C <= 0 || !stats || !dgamma || !dbeta) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_layernorm_affine_grad: M=%d C=%d", M, C);
   hipStream_t s = (hipStream_t)stream;
-  zero_pair(dgamma, dbeta, C, s);
+  if (!accumulate) zero_pair(dgamma, dbeta, C, s);
   CatIn2 in{(const bf16_t*)x, ldx, C, nullptr, 0};
   const int cb = (C + 63) / 64;
   hipLaunchKernelGGL(norm_affine_grad_kernel<0>, dim3(cb, row_chunks(M, cb)), dim3(256), 0, s, in, (const bf16_t*)dy, lddy,
@@ -182,12 +192,12 @@ extern "C" int sdlt_layernorm_affine_grad(const void* x, int64_t ldx, const void
   return SDLT_OK;
 }
 
-extern "C" int sdlt_groupnorm_affine_grad(const sdlt_groupnorm_params* pp, float* dgamma, float* dbeta, void* stream) {
+extern "C" int sdlt_groupnorm_affine_grad(const sdlt_groupnorm_params* pp, float* dgamma, float* dbeta, int32_t accumulate, void* stream) {
   const sdlt_groupnorm_params& p = *pp;
   if (p.B <= 0 || p.HW <= 0 || p.C <= 0 || (p.C % 32) || !p.stats || !p.dy || !dgamma || !dbeta)
     SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_groupnorm_affine_grad: B=%d HW=%d C=%d", p.B, p.HW, p.C);
   hipStream_t s = (hipStream_t)stream;
-  zero_pair(dgamma, dbeta, p.C, s);
+  if (!accumulate) zero_pair(dgamma, dbeta, p.C, s);
   CatIn2 in{(const bf16_t*)p.x1, p.ldx1, p.x2 ? p.C1 : p.C, (const bf16_t*)p.x2, p.ldx2};
   const int cb = (p.C + 63) / 64;
   const int64_t M = (int64_t)p.B * p.HW;

@@ -9,7 +9,8 @@ copies (both orientations) after each optimizer step.
   * dW[N,K] = dY^T X contracts over tokens: both operands are transposed once into token-contiguous panels
     (sdlt_wgrad_transpose / sdlt_wgrad_im2col_t) and multiplied by the MFMA GEMM with an fp32 output that IS the
     parameter's slice of the gradient arena (no per-parameter gradient tensors, one all-reduce buffer for data parallel).
-  * biases: column sums of dY; norm affine: sdlt_*_affine_grad.  Biases and gamma/beta are used by the kernels in fp32,
+  * biases: column sums of dY, a by-product of the pass that transposes dY; norm affine: sdlt_*_affine_grad.  All vector
+    gradients live in one tail region of the arena, cleared by one launch per step.  Biases and gamma/beta are used by the kernels in fp32,
     so the layers read them straight from the master arena - only matrix weights have bf16 copies to refresh.
   * 3x3 conv weights are stored tap-major [Cout, (ky, kx, ci)] like the forward GEMM operand; `export()` / `load()`
     convert to / from the PyTorch [Cout, Cin, 3, 3] layout of the checkpoint.
@@ -28,7 +29,8 @@ class WeightTrainer:
         self.rt = rt
         self.entries = []          # dict(name, off, shape (arena layout), kind)
         self.by_name = {}
-        self.n = 0
+        self.n = 0                 # matrix region [0, n_mat), then the vector region (biases, norm affine) [n_mat, n)
+        self.nv = 0
         self._binds = []           # callables run at finalize (point layer attributes at arena views)
         self._shadow = []          # ShadowPlan descriptors (offset, rows, cols, src_ld, dst, dstT)
         self.params = self.grads = self.m = self.v = None
@@ -37,9 +39,17 @@ class WeightTrainer:
     # ------------------------------------------------------------------ registration (layer constructors)
     def add(self, name, init, kind="matrix"):
         """init: fp32 tensor in ARENA layout.  Offsets are kept 16-byte aligned so every slice can be a GEMM output."""
-        self.n = (self.n + 3) // 4 * 4
-        e = dict(name=name, off=self.n, shape=tuple(init.shape), kind=kind, init=init.detach().to(F32))
-        self.n += init.numel()
+        assert self.params is None, "register before finalize()"
+        if kind == "vector":
+            # vectors live behind all matrices: their gradients are accumulated with atomics (column sums, norm affine), so the
+            # whole region is cleared with ONE launch per step instead of one per tensor
+            self.nv = (self.nv + 3) // 4 * 4
+            e = dict(name=name, voff=self.nv, off=None, shape=tuple(init.shape), kind=kind, init=init.detach().to(F32))
+            self.nv += init.numel()
+        else:
+            self.n = (self.n + 3) // 4 * 4
+            e = dict(name=name, off=self.n, shape=tuple(init.shape), kind=kind, init=init.detach().to(F32))
+            self.n += init.numel()
         self.entries.append(e)
         self.by_name[name] = e
         return e
@@ -52,6 +62,11 @@ class WeightTrainer:
 
     def finalize(self):
         rt = self.rt
+        self.n_mat = (self.n + 3) // 4 * 4
+        for e in self.entries:
+            if e["kind"] == "vector":
+                e["off"] = self.n_mat + e.pop("voff")
+        self.n = self.n_mat + self.nv
         z = lambda: torch.zeros(self.n, dtype=F32, device=rt.device)  # noqa: E731
         self.params, self.grads, self.m, self.v = z(), z(), z(), z()
         for e in self.entries:
@@ -73,6 +88,10 @@ class WeightTrainer:
         if self._plan is not None:
             self._plan.run(self.params)
 
+    def zero_vector_grads(self):
+        """Once per backward: bias and norm-affine gradients are accumulated (fp32 atomics) by the kernels that produce them."""
+        self.grads[self.n_mat:].zero_()
+
     refresh_shadows = refresh      # same optimizer-facing surface as unet.LoraArena (params / grads / m / v / n / refresh_shadows)
 
     # ------------------------------------------------------------------ weight-gradient plan (leaf backward)
@@ -87,7 +106,9 @@ class WeightTrainer:
         N, K = went["shape"]
         M = dy.shape[0]
         Mp = _pad64(M)
-        dyT = ops.wgrad_transpose(dy[:, :N] if dy.shape[1] != N else dy, self._panel("wg_dy", N, Mp))
+        # the bias gradient (column sums of dY) falls out of the transposing pass over dY
+        dyT = ops.wgrad_transpose(dy[:, :N] if dy.shape[1] != N else dy, self._panel("wg_dy", N, Mp),
+                                  colsum_acc=self.view(bent, "grads") if bent is not None else None)
         gW = self.view(went, "grads")
         k0 = 0
         for x in xs:
@@ -96,18 +117,6 @@ class WeightTrainer:
             ops.gemm(dyT, xT, gW[:, k0:k0 + Ki] if len(xs) > 1 else gW)
             k0 += Ki
         assert k0 == K, (went["name"], k0, K)
-        if bent is not None:
-            self.bias(bent, dy, N)
-
-    def bias(self, bent, dy, N):
-        ops = self.rt.ops
-        M, Nd = dy.shape
-        if Nd == N and N % 64 == 0:
-            ops.colsum(dy, self.view(bent, "grads").view(1, N), B=1, R=M)
-        else:                      # conv_out: 4 real channels inside a 64-wide gradient
-            tmp = self.rt.scratch("wg_bias", _pad64(Nd)).view(1, -1)[:, :Nd]
-            ops.colsum(dy, tmp, B=1, R=M)
-            self.view(bent, "grads").copy_(tmp[0, :N])
 
     def conv3x3(self, went, bent, x, dy, *, B, H, W, Cin, stride, ups):
         """went: [Cout, 9*Cin] (tap-major); x NHWC [B*H*W, >=Cin]; dy [M, Cout_p]."""
@@ -115,11 +124,11 @@ class WeightTrainer:
         Cout = went["shape"][0]
         M = dy.shape[0]
         Mp = _pad64(M)
-        dyT = ops.wgrad_transpose(dy[:, :Cout] if dy.shape[1] != Cout else dy, self._panel("wg_dy", Cout, Mp))
+        dyT = ops.wgrad_transpose(dy[:, :Cout] if dy.shape[1] != Cout else dy, self._panel("wg_dy", Cout, Mp),
+                                  colsum_acc=self.view(bent, "grads"))
         cols = ops.wgrad_im2col_t(x[:, :Cin] if x.shape[1] != Cin else x, self._panel("wg_x", 9 * Cin, Mp), B=B, H=H, W=W,
                                   stride=stride, ups=ups)
         ops.gemm(dyT, cols, self.view(went, "grads"))
-        self.bias(bent, dy, Cout)
 
     # ------------------------------------------------------------------ host side: checkpoint layouts
     def export(self, which="params"):

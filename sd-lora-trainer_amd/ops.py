@@ -301,32 +301,36 @@ def groupnorm_bwd(x1, x2, dy, dx, stats, bstats, *, B, HW, gamma, beta, eps, sil
     return dx
 
 
-def groupnorm_affine_grad(x1, x2, dy, stats, dgamma, dbeta, *, B, HW, gamma, beta, eps, silu):
+def groupnorm_affine_grad(x1, x2, dy, stats, dgamma, dbeta, *, B, HW, gamma, beta, eps, silu, accumulate=False):
     """d gamma / d beta of GroupNorm(32)(+SiLU) for the full fine-tune (sdlt_groupnorm_affine_grad); fp32 [C] outputs."""
     lib = _lib.load()
     p = _gn_params(x1, x2, B, HW, gamma, beta, eps, silu, stats)
     _chk2(dy), _chk2(dgamma, F32), _chk2(dbeta, F32)
     assert dgamma.numel() == p.C and dbeta.numel() == p.C and dgamma.is_contiguous() and dbeta.is_contiguous()
     p.dy, p.lddy = _p(dy), _ld(dy)
-    _lib.check(lib.sdlt_groupnorm_affine_grad(C.byref(p), _p(dgamma), _p(dbeta), _stream()), "sdlt_groupnorm_affine_grad")
+    _lib.check(lib.sdlt_groupnorm_affine_grad(C.byref(p), _p(dgamma), _p(dbeta), int(accumulate), _stream()), "sdlt_groupnorm_affine_grad")
 
 
-def layernorm_affine_grad(x, dy, stats, dgamma, dbeta):
+def layernorm_affine_grad(x, dy, stats, dgamma, dbeta, accumulate=False):
     lib = _lib.load()
     _chk2(x), _chk2(dy), _chk2(stats, F32), _chk2(dgamma, F32), _chk2(dbeta, F32)
     M, Cc = x.shape
     assert dgamma.numel() == Cc and dbeta.numel() == Cc and dgamma.is_contiguous() and dbeta.is_contiguous()
-    _lib.check(lib.sdlt_layernorm_affine_grad(_p(x), _ld(x), _p(dy), _ld(dy), M, Cc, _p(stats), _p(dgamma), _p(dbeta), _stream()),
+    _lib.check(lib.sdlt_layernorm_affine_grad(_p(x), _ld(x), _p(dy), _ld(dy), M, Cc, _p(stats), _p(dgamma), _p(dbeta), int(accumulate), _stream()),
                "sdlt_layernorm_affine_grad")
 
 
-def wgrad_transpose(x, out):
-    """out [C, Mp] <- x[M, C]^T, columns M..Mp-1 zero (Mp = out.shape[1], multiple of 64): token-contiguous GEMM panel."""
+def wgrad_transpose(x, out, colsum_acc=None):
+    """out [C, Mp] <- x[M, C]^T, columns M..Mp-1 zero (Mp = out.shape[1], multiple of 64): token-contiguous GEMM panel.
+    colsum_acc (fp32 [C], optional) += column sums of x (accumulated: the caller zeroes it)."""
     lib = _lib.load()
     _chk2(x), _chk2(out)
     M, Cc = x.shape
     assert out.shape[0] == Cc
-    _lib.check(lib.sdlt_wgrad_transpose(_p(x), _ld(x), M, Cc, _p(out), _ld(out), out.shape[1], _stream()), "sdlt_wgrad_transpose")
+    if colsum_acc is not None:
+        _chk2(colsum_acc, F32)
+        assert colsum_acc.numel() == Cc and colsum_acc.is_contiguous()
+    _lib.check(lib.sdlt_wgrad_transpose(_p(x), _ld(x), M, Cc, _p(out), _ld(out), out.shape[1], _p(colsum_acc), _stream()), "sdlt_wgrad_transpose")
     return out
 
 

@@ -465,7 +465,7 @@ class GroupNorm(_Module):
         if self.trainer is not None:
             tr = self.trainer
             self.rt.ops.groupnorm_affine_grad(x1, x2, dy, self._b["stats"], tr.view(self.gent, "grads"), tr.view(self.bent, "grads"), B=B, HW=HW,
-                                              gamma=self.gamma, beta=self.beta, eps=self.eps, silu=self.silu)
+                                              gamma=self.gamma, beta=self.beta, eps=self.eps, silu=self.silu, accumulate=True)
         return self.rt.ops.groupnorm_bwd(x1, x2, dy, dx, self._b["stats"], self.buf("bstats", B * 64, dtype=F32), B=B, HW=HW,
                                          gamma=self.gamma, beta=self.beta, eps=self.eps, silu=self.silu, dres=dres)
 
@@ -487,7 +487,7 @@ class LayerNorm(_Module):
         dx = out if out is not None else self.buf("dx", *self._x.shape)
         if self.trainer is not None:
             tr = self.trainer
-            self.rt.ops.layernorm_affine_grad(self._x, dy, self._b["stats"], tr.view(self.gent, "grads"), tr.view(self.bent, "grads"))
+            self.rt.ops.layernorm_affine_grad(self._x, dy, self._b["stats"], tr.view(self.gent, "grads"), tr.view(self.bent, "grads"), accumulate=True)
         return self.rt.ops.layernorm_bwd(self._x, dy, dx, self._b["stats"], gamma=self.gamma, dres=dres)
 
 
@@ -856,6 +856,8 @@ class UNet(_Module):
         B, H, W = self._dims
         boc = cfg["block_out_channels"]
         tr = self.trainer
+        if tr is not None:
+            tr.zero_vector_grads()
         if rt.want_dpooled or tr is not None:
             rt.dsemb = self.buf("dsemb", B, self.tdim, zero=True)
             rt.dsemb.zero_()

@@ -189,7 +189,7 @@ def groupnorm_bwd(x1, x2, dy, dx, stats, bstats, *, B, HW, gamma, beta, eps, sil
     return dx
 
 
-def groupnorm_affine_grad(x1, x2, dy, stats, dgamma, dbeta, *, B, HW, gamma, beta, eps, silu):
+def groupnorm_affine_grad(x1, x2, dy, stats, dgamma, dbeta, *, B, HW, gamma, beta, eps, silu, accumulate=False):
     x = _gn_cat(x1, x2).detach()
     C = x.shape[1]
     ga, be = gamma.detach().float().clone().requires_grad_(True), beta.detach().float().clone().requires_grad_(True)
@@ -197,19 +197,30 @@ def groupnorm_affine_grad(x1, x2, dy, stats, dgamma, dbeta, *, B, HW, gamma, bet
     if silu:
         z = F.silu(z)
     g1, g2 = torch.autograd.grad(z.permute(0, 2, 1).reshape(B * HW, C), [ga, be], dy.float())
-    dgamma.copy_(g1)
-    dbeta.copy_(g2)
+    if accumulate:
+        dgamma.add_(g1)
+        dbeta.add_(g2)
+    else:
+        dgamma.copy_(g1)
+        dbeta.copy_(g2)
 
 
-def layernorm_affine_grad(x, dy, stats, dgamma, dbeta):
+def layernorm_affine_grad(x, dy, stats, dgamma, dbeta, accumulate=False):
     xh = F.layer_norm(x.detach().float(), (x.shape[1],), None, None, 1e-5)
-    dgamma.copy_((dy.float() * xh).sum(0))
-    dbeta.copy_(dy.float().sum(0))
+    g1, g2 = (dy.float() * xh).sum(0), dy.float().sum(0)
+    if accumulate:
+        dgamma.add_(g1)
+        dbeta.add_(g2)
+    else:
+        dgamma.copy_(g1)
+        dbeta.copy_(g2)
 
 
-def wgrad_transpose(x, out):
+def wgrad_transpose(x, out, colsum_acc=None):
     out.zero_()
     out[:, :x.shape[0]] = x.t()
+    if colsum_acc is not None:
+        colsum_acc.add_(x.float().sum(0))
     return out
 
 

@@ -558,8 +558,10 @@ def test_wgrad_transpose(ops, M, C):
     x = big[:, :C]                                                   # strided source rows
     ref = E.wgrad_transpose(x, torch.zeros(C, Mp, dtype=BF))
     out = torch.full((C, Mp), 7.0, dtype=BF, device="cuda")
-    ops.wgrad_transpose(big.cuda()[:, :C], out)
+    acc = torch.full((C,), 0.5, device="cuda")                          # accumulated into (the trainer zeroes the region once per step)
+    ops.wgrad_transpose(big.cuda()[:, :C], out, colsum_acc=acc)
     assert torch.equal(out.cpu(), ref)
+    close(acc, 0.5 + x.float().sum(0), tol=2e-3, what="column sums (bias gradient) from the transposing pass")
 
 
 @pytest.mark.parametrize("B,H,W,C,stride,ups", [(2, 16, 16, 64, 1, 1), (1, 8, 12, 320, 1, 1), (2, 16, 16, 128, 2, 1), (1, 8, 8, 64, 1, 2), (3, 5, 7, 8, 1, 1)])
