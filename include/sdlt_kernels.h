@@ -273,6 +273,12 @@ typedef struct sdlt_shadow_desc {
 } sdlt_shadow_desc;
 int sdlt_lora_shadow_refresh(const sdlt_shadow_desc* descs_dev, const int32_t* block_desc_dev, const int32_t* block_first_dev,
                              int32_t n_blocks, const float* arena, void* stream);
+/* The same tiles with the AdamW step fused in (full fine-tune: one pass over all matrix parameters): p, m, v are updated in
+ * place from g with the hyper row of sdlt_adamw_fused (its L1 coefficient is ignored), then converted as above.  The
+ * descriptors must tile every element exactly once (tensors not covered keep their old value: step them with
+ * sdlt_adamw_fused). */
+int sdlt_adamw_shadow_refresh(const sdlt_shadow_desc* descs_dev, const int32_t* block_desc_dev, const int32_t* block_first_dev,
+                              int32_t n_blocks, float* p, const float* g, float* m, float* v, const float* hyper, void* stream);
 
 /* out[M,C] = a + b on strided 2-D bf16 views (gradient fan-in of the UNet skip connections). */
 int sdlt_add2d(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int32_t M, int32_t C, void* stream);

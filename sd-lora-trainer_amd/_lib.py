@@ -116,6 +116,7 @@ SYMBOLS = {
     "sdlt_layernorm_affine_grad": (i32, [vp, i64, vp, i64, i32, i32, vp, vp, vp, i32, vp]),
     "sdlt_groupnorm_affine_grad": (i32, [vp, vp, vp, i32, vp]),
     "sdlt_lora_shadow_refresh": (i32, [vp, vp, vp, i32, vp, vp]),
+    "sdlt_adamw_shadow_refresh": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
     "sdlt_sum2x2": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "sdlt_colsum": (i32, [vp, i64, i32, i32, i32, vp, vp, vp]),
     "sdlt_embed_gather": (i32, [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp]),

@@ -209,8 +209,11 @@ __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, int64
 // One workgroup per 64x64 tile: the fp32 rows are read as 256-B lines, converted once, and both copies leave as
 // contiguous runs along their own fast axis (the transposed one through LDS).  Used for the LoRA adapters (a few MB) and
 // for every UNet weight of the full fine-tune (2.57 G parameters: 10 GB read, 2 x 5 GB written per step).
+// ADAMW: the same tiles also carry the optimizer step (p, g, m, v read, p, m, v written) before the conversion - one pass over
+// the 2.57 G parameters of the full fine-tune instead of AdamW's 7 words + the refresh's re-read of p.
+template <bool ADAMW>
 __global__ __launch_bounds__(256) void shadow_kernel(const sdlt_shadow_desc* descs, const int32_t* block_desc, const int32_t* block_first,
-                                                     const float* arena) {
+                                                     float* arena, const float* g, float* m, float* v, const float* hyper) {
   __shared__ bf16_t tile[64][72];
   const sdlt_shadow_desc d = descs[block_desc[blockIdx.x]];
   const int t = blockIdx.x - block_first[block_desc[blockIdx.x]];
@@ -222,8 +225,20 @@ __global__ __launch_bounds__(256) void shadow_kernel(const sdlt_shadow_desc* des
 #pragma unroll 4
     for (int k = 0; k < 16; ++k) {
       const int r = r0 + k * 4 + (thr >> 6);
-      float v = (r < d.rows && c < d.cols) ? arena[d.offset + (int64_t)r * d.src_ld + c] : 0.f;
-      tile[k * 4 + (thr >> 6)][thr & 63] = f2bf(v);
+      float val = 0.f;
+      if (r < d.rows && c < d.cols) {
+        const int64_t i = d.offset + (int64_t)r * d.src_ld + c;
+        val = arena[i];
+        if (ADAMW) {          // torch.optim.AdamW, exactly as adamw_kernel (no L1 term: main.py:353 applies it to LoRA tensors only)
+          const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2 = hyper[6], gs = hyper[8];
+          const float gi = g[i] * gs;
+          const float mi = b1 * m[i] + (1.f - b1) * gi;
+          const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+          val = val * (1.f - lr * wd) - (lr / bc1) * mi / (sqrtf(vi) * rsqrtf(bc2) + eps);
+          arena[i] = val; m[i] = mi; v[i] = vi;
+        }
+      }
+      tile[k * 4 + (thr >> 6)][thr & 63] = f2bf(val);
     }
   }
   __syncthreads();
@@ -386,7 +401,15 @@ extern "C" int sdlt_adamw_fused(float* p, const float* g, float* m, float* v, in
 extern "C" int sdlt_lora_shadow_refresh(const sdlt_shadow_desc* descs_dev, const int32_t* block_desc_dev, const int32_t* block_first_dev,
                                         int32_t n_blocks, const float* arena, void* stream) {
   if (n_blocks <= 0) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_lora_shadow_refresh: n_blocks=%d", n_blocks);
-  hipLaunchKernelGGL(shadow_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, block_desc_dev, block_first_dev, arena);
+  hipLaunchKernelGGL(shadow_kernel<false>, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, block_desc_dev, block_first_dev,
+                     const_cast<float*>(arena), (const float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+extern "C" int sdlt_adamw_shadow_refresh(const sdlt_shadow_desc* descs_dev, const int32_t* block_desc_dev, const int32_t* block_first_dev,
+                                         int32_t n_blocks, float* p, const float* g, float* m, float* v, const float* hyper, void* stream) {
+  if (n_blocks <= 0 || !p || !g || !m || !v || !hyper) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_adamw_shadow_refresh: n_blocks=%d or a null buffer", n_blocks);
+  hipLaunchKernelGGL(shadow_kernel<true>, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, block_desc_dev, block_first_dev, p, g, m, v, hyper);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }

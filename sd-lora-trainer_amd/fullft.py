@@ -88,6 +88,15 @@ class WeightTrainer:
         if self._plan is not None:
             self._plan.run(self.params)
 
+    def adamw_step(self, hyper):
+        """torch.optim.AdamW over the whole arena and the refresh of the bf16 operands: the matrix region in ONE tiled pass
+        (sdlt_adamw_shadow_refresh: p, g, m, v -> p, m, v, W, W^T), the vector region (biases, norm affine: used in fp32) with
+        sdlt_adamw_fused."""
+        ops, nm = self.rt.ops, self.n_mat
+        self._plan.adamw(self.params, self.grads, self.m, self.v, hyper)
+        if self.nv:
+            ops.adamw_fused(self.params[nm:], self.grads[nm:], self.m[nm:], self.v[nm:], hyper, None)
+
     def zero_vector_grads(self):
         """Once per backward: bias and norm-affine gradients are accumulated (fp32 atomics) by the kernels that produce them."""
         self.grads[self.n_mat:].zero_()

@@ -479,6 +479,18 @@ class ShadowPlan:
                                                 _p(arena), _stream()), "sdlt_lora_shadow_refresh")
 
 
+def _shadow_adamw(self, p, g, m, v, hyper):
+    """AdamW step fused into the refresh tiles (sdlt_adamw_shadow_refresh); covers exactly the elements the plan's descriptors tile."""
+    lib = _lib.load()
+    for t in (p, g, m, v, hyper):
+        _chk2(t, F32)
+    _lib.check(lib.sdlt_adamw_shadow_refresh(_p(self.descs_dev), _p(self.block_desc_dev), _p(self.block_first_dev), self.n_blocks,
+                                             _p(p), _p(g), _p(m), _p(v), _p(hyper), _stream()), "sdlt_adamw_shadow_refresh")
+
+
+ShadowPlan.adamw = _shadow_adamw
+
+
 def add2d(a, b, out):
     lib = _lib.load()
     _chk2(a), _chk2(b), _chk2(out)

@@ -342,6 +342,9 @@ class TrainStep:
     def _unet_optimizer(self):
         a = self.group
         l1 = None if self.full_ft else self.l1_sum
+        if self.full_ft and self.prodigy is None:
+            a.adamw_step(self.hyper)           # optimizer step and operand refresh in one tiled pass over the matrices
+            return
         if self.prodigy is not None:
             self.prodigy.step(a.grads, a.m, a.v, self.hyper, l1)
         else:

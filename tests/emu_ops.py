@@ -391,6 +391,22 @@ class ShadowPlan:
                 dstT[:cols, :rows].copy_(src.t().to(dstT.dtype))
 
 
+def _shadow_adamw(self, p, g, m, v, hyper):
+    """sdlt_adamw_shadow_refresh: AdamW on exactly the elements the descriptors tile, then the refresh."""
+    lr, b1, b2, eps, wd, bc1, bc2, _, gs = [float(x) for x in hyper[:9]]
+    for (off, rows, cols, src_ld, dst, dstT) in self.entries:
+        views = [torch.as_strided(t, (rows, cols), (src_ld, 1), off) for t in (p, g, m, v)]
+        pv, gv, mv, vv = views
+        gi = gv * gs
+        mv.mul_(b1).add_(gi, alpha=1 - b1)
+        vv.mul_(b2).addcmul_(gi, gi, value=1 - b2)
+        pv.mul_(1 - lr * wd).addcdiv_(mv, vv.sqrt() / math.sqrt(bc2) + eps, value=-lr / bc1)
+    self.run(p)
+
+
+ShadowPlan.adamw = _shadow_adamw
+
+
 def add2d(a, b, out):
     out.copy_((a.float() + b.float()).to(out.dtype))
     return out

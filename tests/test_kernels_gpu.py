@@ -629,3 +629,35 @@ def test_norm_affine_grads(ops, two, silu):
     ops.layernorm_affine_grad(xl.cuda(), dyl.cuda(), st, dg, db)
     close(dg, dgr, tol=5e-3, what="LN dgamma")
     close(db, dbr, tol=5e-3, what="LN dbeta")
+
+
+def test_adamw_fused_into_refresh_tiles(ops):
+    """sdlt_adamw_shadow_refresh: AdamW step + both bf16 copies per 64x64 tile (the full fine-tune's optimizer pass), incl. a
+    conv-style tensor whose taps are separate descriptors over a strided master ([Cout, 9*Cin], per-tap [Cout, Cin] blocks)."""
+    g = torch.Generator().manual_seed(12)
+    specs = [(0, 200, 130, 130), (26000, 70, 192, 192)]                       # (offset, rows, cols, src_ld)
+    cout, cin, base = 96, 40, 40000
+    specs += [(base + tap * cin, cout, cin, 9 * cin) for tap in range(9)]
+    n = base + cout * 9 * cin
+    p = torch.randn(n, generator=g) * 0.1
+    gr, m, v = torch.randn(n, generator=g) * 0.01, torch.rand(n, generator=g) * 0.01, torch.rand(n, generator=g) * 1e-4
+    hyper = torch.zeros(16)
+    hyper[:9] = torch.tensor([1e-3, 0.9, 0.999, 1e-8, 0.004, 1 - 0.9 ** 3, 1 - 0.999 ** 3, 0.0, 0.5])
+    ent_c, ent_g, outs = [], [], []
+    for (off, rows, cols, sld) in specs:
+        dc, dtc = torch.zeros(rows, cols + 8, dtype=BF), torch.zeros(cols, rows + 8, dtype=BF)
+        dg, dtg = dc.cuda(), dtc.cuda()
+        ent_c.append((off, rows, cols, sld, dc[:, :cols], dtc[:, :rows]))
+        ent_g.append((off, rows, cols, sld, dg[:, :cols], dtg[:, :rows]))
+        outs.append((dc, dtc, dg, dtg))
+    pc, mc, vc = p.clone(), m.clone(), v.clone()
+    E.ShadowPlan(ent_c, "cpu").adamw(pc, gr, mc, vc, hyper)
+    pd, gd, md, vd = dev(p.clone(), gr, m.clone(), v.clone())
+    ops.ShadowPlan(ent_g, "cuda").adamw(pd, gd, md, vd, hyper.cuda())
+    close(pd, pc, tol=1e-5, what="fused adamw params")
+    close(md, mc, tol=1e-5, what="fused adamw m")
+    close(vd, vc, tol=1e-5, what="fused adamw v")
+    assert torch.equal(pd.cpu()[200 * 130:26000], p[200 * 130:26000])         # elements no descriptor covers are untouched
+    for dc, dtc, dg, dtg in outs:
+        close(dg, dc, tol=4e-3, what="refreshed operand")
+        close(dtg, dtc, tol=4e-3, what="refreshed transposed operand")
