@@ -218,6 +218,14 @@ int sdlt_wgrad_transpose(const void* x, int64_t ldx, int32_t M, int32_t C, void*
                          void* stream);
 int sdlt_wgrad_im2col_t(const void* x, int64_t ldx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t stride, int32_t ups,
                         void* out, int64_t ldo, int32_t Mp, void* stream);
+/* Batched forms: n problems of identical geometry, each with its own pointers (device array of items).  The trainer defers
+ * the weight gradients of a backward pass to its end and issues all layers of one shape together: one panel launch per
+ * operand and one batched sdlt_gemm_bf16 (sdlt_gemm_params.batch) instead of three launches per layer. */
+typedef struct sdlt_wgrad_tr_item { const void* x; void* out; float* colsum; } sdlt_wgrad_tr_item;
+int sdlt_wgrad_transpose_batch(const sdlt_wgrad_tr_item* items_dev, int32_t n, int64_t ldx, int32_t M, int32_t C, int64_t ldo, int32_t Mp,
+                               void* stream);
+int sdlt_wgrad_im2col_t_batch(const sdlt_wgrad_tr_item* items_dev, int32_t n, int64_t ldx, int32_t B, int32_t H, int32_t W, int32_t C,
+                              int32_t stride, int32_t ups, int64_t ldo, int32_t Mp, void* stream);
 int sdlt_layernorm_affine_grad(const void* x, int64_t ldx, const void* dy, int64_t lddy, int32_t M, int32_t C,
                                const float* stats, float* dgamma, float* dbeta, int32_t accumulate, void* stream);
 int sdlt_groupnorm_affine_grad(const sdlt_groupnorm_params* p, float* dgamma, float* dbeta, int32_t accumulate, void* stream);

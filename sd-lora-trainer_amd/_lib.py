@@ -113,6 +113,8 @@ SYMBOLS = {
     "sdlt_prodigy_step": (i32, [vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp]),
     "sdlt_wgrad_transpose": (i32, [vp, i64, i32, i32, vp, i64, i32, vp, vp]),
     "sdlt_wgrad_im2col_t": (i32, [vp, i64, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp]),
+    "sdlt_wgrad_transpose_batch": (i32, [vp, i32, i64, i32, i32, i64, i32, vp]),
+    "sdlt_wgrad_im2col_t_batch": (i32, [vp, i32, i64, i32, i32, i32, i32, i32, i32, i64, i32, vp]),
     "sdlt_layernorm_affine_grad": (i32, [vp, i64, vp, i64, i32, i32, vp, vp, vp, i32, vp]),
     "sdlt_groupnorm_affine_grad": (i32, [vp, vp, vp, i32, vp]),
     "sdlt_lora_shadow_refresh": (i32, [vp, vp, vp, i32, vp, vp]),

@@ -39,10 +39,19 @@ __device__ __forceinline__ uint4 load_row8(const bf16_t* x, int64_t ldx, int64_t
   return *(const uint4*)tmp;
 }
 
+// items != nullptr: batched launch - blockIdx.z = problem * taps + tap, every problem with its own x / out / colsum pointers
+// and the shared geometry (the weight gradients of all layers of one shape are issued together at the end of the backward)
 __global__ __launch_bounds__(256) void transpose_gather_kernel(const bf16_t* x, int64_t ldx, int M, int C, bf16_t* out,
-                                                                int64_t ldo, GatherGeom g, float* colsum) {
+                                                                int64_t ldo, GatherGeom g, float* colsum,
+                                                                const sdlt_wgrad_tr_item* items, int taps) {
   __shared__ uint32_t tileT[64][34];          // [channel][row pair], 8-B aligned rows
-  const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tap = blockIdx.z;
+  int tap = blockIdx.z;
+  if (items) {
+    const sdlt_wgrad_tr_item it = items[blockIdx.z / taps];
+    tap = blockIdx.z % taps;
+    x = (const bf16_t*)it.x; out = (bf16_t*)it.out; colsum = it.colsum;
+  }
+  const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int t = threadIdx.x;
   {
     const int i = t >> 3, cc = (t & 7) * 8;
@@ -160,7 +169,7 @@ extern "C" int sdlt_wgrad_transpose(const void* x, int64_t ldx, int32_t M, int32
     SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wgrad_transpose: M=%d C=%d Mp=%d ldx=%lld ldo=%lld", M, C, Mp, (long long)ldx, (long long)ldo);
   GatherGeom g{};
   hipLaunchKernelGGL(transpose_gather_kernel, dim3(Mp / 64, (C + 63) / 64, 1), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, ldx, M, C, (bf16_t*)out, ldo, g, colsum_acc);
+                     (const bf16_t*)x, ldx, M, C, (bf16_t*)out, ldo, g, colsum_acc, (const sdlt_wgrad_tr_item*)nullptr, 1);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }
@@ -174,7 +183,33 @@ extern "C" int sdlt_wgrad_im2col_t(const void* x, int64_t ldx, int32_t B, int32_
   if (Mp < M || (Mp % 64) || (ldx % 8) || (ldo % 8) || ldo < Mp)
     SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wgrad_im2col_t: M=%lld Mp=%d ldx=%lld ldo=%lld", (long long)M, Mp, (long long)ldx, (long long)ldo);
   hipLaunchKernelGGL(transpose_gather_kernel, dim3(Mp / 64, (C + 63) / 64, 9), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, ldx, (int)M, C, (bf16_t*)out, ldo, g, (float*)nullptr);
+                     (const bf16_t*)x, ldx, (int)M, C, (bf16_t*)out, ldo, g, (float*)nullptr, (const sdlt_wgrad_tr_item*)nullptr, 9);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+
+extern "C" int sdlt_wgrad_transpose_batch(const sdlt_wgrad_tr_item* items_dev, int32_t n, int64_t ldx, int32_t M, int32_t C, int64_t ldo,
+                                          int32_t Mp, void* stream) {
+  if (!items_dev || n <= 0 || n > 65535 || M <= 0 || C <= 0 || Mp < M || (Mp % 64) || (ldx % 8) || (ldo % 8) || ldo < Mp)
+    SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wgrad_transpose_batch: n=%d M=%d C=%d Mp=%d ldx=%lld ldo=%lld", n, M, C, Mp, (long long)ldx, (long long)ldo);
+  GatherGeom g{};
+  hipLaunchKernelGGL(transpose_gather_kernel, dim3(Mp / 64, (C + 63) / 64, n), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)nullptr, ldx, M, C, (bf16_t*)nullptr, ldo, g, (float*)nullptr, items_dev, 1);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+
+extern "C" int sdlt_wgrad_im2col_t_batch(const sdlt_wgrad_tr_item* items_dev, int32_t n, int64_t ldx, int32_t B, int32_t H, int32_t W,
+                                         int32_t C, int32_t stride, int32_t ups, int64_t ldo, int32_t Mp, void* stream) {
+  if (!items_dev || n <= 0 || 9 * n > 65535 || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (stride != 1 && stride != 2) || (ups != 1 && ups != 2) ||
+      (stride == 2 && ups == 2))
+    SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wgrad_im2col_t_batch: n=%d B=%d H=%d W=%d C=%d stride=%d ups=%d", n, B, H, W, C, stride, ups);
+  GatherGeom g{1, B, H, W, H * ups / stride, W * ups / stride, stride, ups};
+  const int64_t M = (int64_t)B * g.Hout * g.Wout;
+  if (Mp < M || (Mp % 64) || (ldx % 8) || (ldo % 8) || ldo < Mp)
+    SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wgrad_im2col_t_batch: M=%lld Mp=%d ldx=%lld ldo=%lld", (long long)M, Mp, (long long)ldx, (long long)ldo);
+  hipLaunchKernelGGL(transpose_gather_kernel, dim3(Mp / 64, (C + 63) / 64, 9 * n), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)nullptr, ldx, (int)M, C, (bf16_t*)nullptr, ldo, g, (float*)nullptr, items_dev, 9);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }

@@ -35,6 +35,12 @@ class WeightTrainer:
         self._shadow = []          # ShadowPlan descriptors (offset, rows, cols, src_ld, dst, dstT)
         self.params = self.grads = self.m = self.v = None
         self.registering = False   # True only while the UNet builds its layers (the text encoders share the leaf classes)
+        # Deferred, batched weight gradients: the leaf layers only RECORD (weight, inputs, dY) during the first backward; flush()
+        # at the end of every backward issues all layers of one shape together - one panel launch per operand and one batched
+        # GEMM for e.g. the 60 FF projections of the 1280-wide transformer blocks.  Legal because every activation and every
+        # layer gradient lives in a persistent, layer-owned buffer until the next forward.
+        self.defer = True
+        self._jobs, self._wplan = [], None
 
     # ------------------------------------------------------------------ registration (layer constructors)
     def add(self, name, init, kind="matrix"):
@@ -111,6 +117,10 @@ class WeightTrainer:
     def linear(self, went, bent, xs, dy, n_rows=None):
         """went: [N, K] weight entry; xs: list of inputs whose channel concatenation is the layer input ([M, K_i] each);
         dy [M, >=N] (only the first N columns are the layer's output gradient)."""
+        if self.defer:
+            if self._wplan is None:
+                self._jobs.append(("lin", went, bent, list(xs), dy, None))
+            return
         ops = self.rt.ops
         N, K = went["shape"]
         M = dy.shape[0]
@@ -129,6 +139,10 @@ class WeightTrainer:
 
     def conv3x3(self, went, bent, x, dy, *, B, H, W, Cin, stride, ups):
         """went: [Cout, 9*Cin] (tap-major); x NHWC [B*H*W, >=Cin]; dy [M, Cout_p]."""
+        if self.defer:
+            if self._wplan is None:
+                self._jobs.append(("conv", went, bent, [x], dy, dict(B=B, H=H, W=W, stride=stride, ups=ups, Cin=Cin)))
+            return
         ops = self.rt.ops
         Cout = went["shape"][0]
         M = dy.shape[0]
@@ -138,6 +152,62 @@ class WeightTrainer:
         cols = ops.wgrad_im2col_t(x[:, :Cin] if x.shape[1] != Cin else x, self._panel("wg_x", 9 * Cin, Mp), B=B, H=H, W=W,
                                   stride=stride, ups=ups)
         ops.gemm(dyT, cols, self.view(went, "grads"))
+
+    def flush(self):
+        """End of a backward pass: run the weight-gradient plan recorded during the first one."""
+        if not self.defer:
+            return
+        if self._wplan is None:
+            self._wplan = self._build_wplan(self._jobs)
+            self._jobs = None
+        ops = self.rt.ops
+        for panels, gemms in self._wplan:
+            for pb in panels:
+                pb.run()
+            for (X, W, C_, batch, tile) in gemms:
+                ops.gemm(X, W, C_, batch=batch, tile=tile)
+
+    def _build_wplan(self, jobs):
+        from collections import OrderedDict
+        rt, ops, dev = self.rt, self.rt.ops, self.rt.device
+        groups = OrderedDict()
+        for kind, went, bent, xs, dy, geom in jobs:
+            N = went["shape"][0]
+            dyv = dy[:, :N] if dy.shape[1] != N else dy
+            if kind == "conv":
+                xs = [xs[0][:, :geom["Cin"]] if xs[0].shape[1] != geom["Cin"] else xs[0]]
+            key = (kind, tuple(dyv.shape), dyv.stride(), tuple((tuple(x.shape), x.stride()) for x in xs), bent is not None,
+                   tuple(sorted(geom.items())) if geom else None, went["shape"])
+            groups.setdefault(key, []).append((went, bent, xs, dyv, geom))
+        plan = []
+        for key, members in groups.items():
+            kind, n = key[0], len(members)
+            went0, _, xs0, dy0, geom = members[0]
+            N, K = went0["shape"]
+            M = dy0.shape[0]
+            Mp = _pad64(M)
+            dyT = torch.empty(n, N, Mp, dtype=BF16, device=dev)
+            panels = [ops.WgradPanelBatch([(m[3], dyT[i], self.view(m[1], "grads") if m[1] is not None else None) for i, m in enumerate(members)], dev)]
+            gemms, k0 = [], 0
+            for j, x0 in enumerate(xs0):
+                rows = (9 if kind == "conv" else 1) * x0.shape[1]
+                xT = torch.empty(n, rows, Mp, dtype=BF16, device=dev)
+                conv = dict(B=geom["B"], H=geom["H"], W=geom["W"], stride=geom["stride"], ups=geom["ups"]) if kind == "conv" else None
+                panels.append(ops.WgradPanelBatch([(m[2][j], xT[i], None) for i, m in enumerate(members)], dev, conv=conv))
+                outs = []
+                for m in members:
+                    gW = self.view(m[0], "grads")
+                    outs.append(gW[:, k0:k0 + rows] if len(xs0) > 1 else gW)
+                k0 += rows
+                t128 = ((N + 127) // 128) * ((rows + 127) // 128)
+                if n >= 4:          # enough problems to fill the chip without split-K: one batched launch
+                    items = [dict(X=dyT[i], W=xT[i], C=outs[i]) for i in range(n)]
+                    gemms.append((dyT[0], xT[0], outs[0], ops.GemmBatch(items, dev), 1 if t128 >= 8 else 3))
+                else:               # a few long-K problems (the 128x128-resolution convs): individual launches keep their split-K
+                    gemms += [(dyT[i], xT[i], outs[i], None, 0) for i in range(n)]
+            assert k0 == K, (went0["name"], k0, K)
+            plan.append((panels, gemms))
+        return plan
 
     # ------------------------------------------------------------------ host side: checkpoint layouts
     def export(self, which="params"):

@@ -334,6 +334,35 @@ def wgrad_transpose(x, out, colsum_acc=None):
     return out
 
 
+class WgradPanelBatch:
+    """Device table of sdlt_wgrad_tr_item for the batched panel launches: items = [(x, out, colsum or None)], identical
+    shapes / strides; conv = None (plain transpose) or dict(B, H, W, stride, ups) (transposed im2col)."""
+
+    def __init__(self, items, device, conv=None):
+        import struct
+        x0, o0, _ = items[0]
+        for x, o, cs in items:
+            _chk2(x), _chk2(o)
+            assert x.shape == x0.shape and x.stride() == x0.stride() and o.shape == o0.shape and o.stride() == o0.stride()
+            if cs is not None:
+                _chk2(cs, F32)
+                assert cs.is_contiguous() and cs.numel() == x.shape[1]
+        raw = b"".join(struct.pack("QQQ", x.data_ptr(), o.data_ptr(), cs.data_ptr() if cs is not None else 0) for x, o, cs in items)
+        self.dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self.items, self.n, self.conv = items, len(items), conv
+
+    def run(self):
+        lib = _lib.load()
+        x0, o0, _ = self.items[0]
+        if self.conv is None:
+            _lib.check(lib.sdlt_wgrad_transpose_batch(_p(self.dev), self.n, _ld(x0), x0.shape[0], x0.shape[1], _ld(o0), o0.shape[1], _stream()),
+                       "sdlt_wgrad_transpose_batch")
+        else:
+            c = self.conv
+            _lib.check(lib.sdlt_wgrad_im2col_t_batch(_p(self.dev), self.n, _ld(x0), c["B"], c["H"], c["W"], x0.shape[1], c["stride"], c["ups"],
+                                                     _ld(o0), o0.shape[1], _stream()), "sdlt_wgrad_im2col_t_batch")
+
+
 def wgrad_im2col_t(x, out, *, B, H, W, stride=1, ups=1):
     """out [9*C, Mp] <- transposed im2col of the NHWC activation x [B*H*W, C] for a 3x3 pad-1 conv (rows tap*C + c)."""
     lib = _lib.load()

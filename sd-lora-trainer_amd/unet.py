@@ -906,6 +906,8 @@ class UNet(_Module):
             if tr is not None:
                 de1s = self.t2.backward(demb)
                 self.t1.weight_grad(rt.ops.map_bf16(_ops.MAP_DSILU, self.t1._b["y"], de1s, self.buf("de1", *de1s.shape)))
+        if tr is not None:
+            tr.flush()             # every weight gradient of this pass, batched by layer shape
         self._cross_kv_backward(dctx)
         if self.arena is not None:
             if self._grad_plan is None:

@@ -224,6 +224,18 @@ def wgrad_transpose(x, out, colsum_acc=None):
     return out
 
 
+class WgradPanelBatch:
+    def __init__(self, items, device, conv=None):
+        self.items, self.n, self.conv = items, len(items), conv
+
+    def run(self):
+        for x, o, cs in self.items:
+            if self.conv is None:
+                wgrad_transpose(x, o, colsum_acc=cs)
+            else:
+                wgrad_im2col_t(x, o, **self.conv)
+
+
 def wgrad_im2col_t(x, out, *, B, H, W, stride=1, ups=1):
     C = x.shape[1]
     img = x.float().reshape(B, H, W, C).permute(0, 3, 1, 2)
