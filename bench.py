@@ -226,8 +226,12 @@ def main():
         # HBM-side bytes per step: measured offline (PMC counters need rocprofv3 around the process), for the default workload only
         traffic = None
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_sdxl1024_ti_hbm_traffic_pmc.json")
-        if version == "sdxl" and res == 1024 and B == 1 and args.rank == 16 and text is not None and not args.ti_frozen and os.path.exists(tpath):
+        if version == "sdxl" and res == 1024 and B == 1 and args.rank == 16 and text is not None and not args.ti_frozen and not full_ft and os.path.exists(tpath):
             with open(tpath) as fh:
+                traffic = json.load(fh).get("traffic_bytes_per_step")
+        fpath = os.path.join(os.path.dirname(tpath), "r01_fullft_hbm_traffic_pmc.json")
+        if full_ft and version == "sdxl" and res == 512 and B == 4 and os.path.exists(fpath):
+            with open(fpath) as fh:
                 traffic = json.load(fh).get("traffic_bytes_per_step")
         out = {
             "metric": "training images/sec, SDXL 1024px rank-16 LoRA, 1/2/4/8 GPU (job-parallel)",
