@@ -187,6 +187,9 @@ typedef struct sdlt_groupnorm_params {
   const void* dres; int64_t lddres;
   void* dx; int64_t lddx;
   float* bstats;
+  int32_t stats_zeroed;   /* 1: the caller already cleared stats (fwd) / bstats (bwd) - e.g. one fill over an arena of all
+                             GroupNorm statistics per pass instead of one zero launch per layer */
+  int32_t pad_;
 } sdlt_groupnorm_params;
 int sdlt_groupnorm_fwd(const sdlt_groupnorm_params* p, void* stream);
 int sdlt_groupnorm_bwd(const sdlt_groupnorm_params* p, void* stream);

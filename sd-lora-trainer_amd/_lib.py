@@ -81,6 +81,7 @@ class GroupNormParams(C.Structure):
         ("dres", vp), ("lddres", i64),
         ("dx", vp), ("lddx", i64),
         ("bstats", vp),
+        ("stats_zeroed", i32), ("pad_", i32),
     ]
 
 

@@ -326,7 +326,7 @@ extern "C" int sdlt_groupnorm_fwd(const sdlt_groupnorm_params* pp, void* stream)
   if (rc) return rc;
   if (p.ldy % 8) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_groupnorm_fwd: ldy %% 8");
   CatIn in{(const bf16_t*)p.x1, p.ldx1, p.C1, (const bf16_t*)p.x2, p.ldx2};
-  sdlt_zero_async(p.stats, sizeof(float) * p.B * G * 2, s);
+  if (!p.stats_zeroed) sdlt_zero_async(p.stats, sizeof(float) * p.B * G * 2, s);
   dim3 grid = gn_grid(p);
   hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, s, in, p.HW, p.C, p.stats);
   if (p.silu)
@@ -344,7 +344,7 @@ extern "C" int sdlt_groupnorm_bwd(const sdlt_groupnorm_params* pp, void* stream)
   if (rc) return rc;
   if ((p.lddy % 8) || (p.lddx % 8) || (p.dres && (p.lddres % 8))) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_groupnorm_bwd: ld %% 8");
   CatIn in{(const bf16_t*)p.x1, p.ldx1, p.C1, (const bf16_t*)p.x2, p.ldx2};
-  sdlt_zero_async(p.bstats, sizeof(float) * p.B * G * 2, s);
+  if (!p.stats_zeroed) sdlt_zero_async(p.bstats, sizeof(float) * p.B * G * 2, s);
   dim3 grid = gn_grid(p);
   if (p.silu) {
     hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.gamma, p.beta, p.eps, p.bstats);

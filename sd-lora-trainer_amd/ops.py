@@ -280,18 +280,20 @@ def _gn_params(x1, x2, B, HW, gamma, beta, eps, silu, stats):
     return p
 
 
-def groupnorm_fwd(x1, x2, y, stats, *, B, HW, gamma, beta, eps, silu):
+def groupnorm_fwd(x1, x2, y, stats, *, B, HW, gamma, beta, eps, silu, stats_zeroed=False):
     lib = _lib.load()
     p = _gn_params(x1, x2, B, HW, gamma, beta, eps, silu, stats)
+    p.stats_zeroed = int(stats_zeroed)
     _chk2(y)
     p.y, p.ldy = _p(y), _ld(y)
     _lib.check(lib.sdlt_groupnorm_fwd(C.byref(p), _stream()), "sdlt_groupnorm_fwd")
     return y
 
 
-def groupnorm_bwd(x1, x2, dy, dx, stats, bstats, *, B, HW, gamma, beta, eps, silu, dres=None):
+def groupnorm_bwd(x1, x2, dy, dx, stats, bstats, *, B, HW, gamma, beta, eps, silu, dres=None, stats_zeroed=False):
     lib = _lib.load()
     p = _gn_params(x1, x2, B, HW, gamma, beta, eps, silu, stats)
+    p.stats_zeroed = int(stats_zeroed)
     _chk2(dy), _chk2(dx), _chk2(bstats, F32)
     p.dy, p.lddy, p.dx, p.lddx, p.bstats = _p(dy), _ld(dy), _p(dx), _ld(dx), _p(bstats)
     if dres is not None:

@@ -48,6 +48,24 @@ class Runtime:
         self.daam_applied = False    # this step's score-gradient GEMMs were issued up front (UNet.daam_backward)
         self.trainer = None          # fullft.WeightTrainer when the whole UNet is trained (is_lora = False)
         self._scratch = {}
+        # GroupNorm statistics (forward sums, backward sums) of all layers live in two small arenas: the UNet clears each with one
+        # fill per pass (gn_prezero) instead of one zero launch per layer (92 per SDXL step)
+        self._gn_arena = {"fwd": [None, 0], "bwd": [None, 0]}
+        self.gn_prezero = False
+
+    def gn_stats(self, which, n):
+        ar = self._gn_arena[which]
+        if ar[0] is None:
+            ar[0] = torch.zeros(1 << 18, dtype=F32, device=self.device)      # 256 K floats: 2048 GroupNorm calls at batch 2
+        assert ar[1] + n <= ar[0].numel(), "GroupNorm statistics arena exhausted"
+        v = ar[0][ar[1]: ar[1] + n]
+        ar[1] += n
+        return v
+
+    def gn_clear(self, which):
+        ar = self._gn_arena[which]
+        if ar[0] is not None and ar[1]:
+            ar[0][: ar[1]].zero_()
 
     def scratch(self, key, nfloats):
         """fp32 scratch shared by every layer: valid only inside the op call that receives it (all ops run on one stream)."""
@@ -455,9 +473,12 @@ class GroupNorm(_Module):
 
     def forward(self, x1, x2, B, HW):
         y = self.buf("y", B * HW, self.C)
-        stats = self.buf("stats", B * 64, dtype=F32)
+        if "stats" not in self._b:
+            self._b["stats"] = self.rt.gn_stats("fwd", B * 64)
+        stats = self._b["stats"]
         self._in = (x1, x2, B, HW)
-        return self.rt.ops.groupnorm_fwd(x1, x2, y, stats, B=B, HW=HW, gamma=self.gamma, beta=self.beta, eps=self.eps, silu=self.silu)
+        return self.rt.ops.groupnorm_fwd(x1, x2, y, stats, B=B, HW=HW, gamma=self.gamma, beta=self.beta, eps=self.eps, silu=self.silu,
+                                         stats_zeroed=self.rt.gn_prezero)
 
     def backward(self, dy, dres=None, out=None):
         x1, x2, B, HW = self._in
@@ -466,8 +487,10 @@ class GroupNorm(_Module):
             tr = self.trainer
             self.rt.ops.groupnorm_affine_grad(x1, x2, dy, self._b["stats"], tr.view(self.gent, "grads"), tr.view(self.bent, "grads"), B=B, HW=HW,
                                               gamma=self.gamma, beta=self.beta, eps=self.eps, silu=self.silu, accumulate=True)
-        return self.rt.ops.groupnorm_bwd(x1, x2, dy, dx, self._b["stats"], self.buf("bstats", B * 64, dtype=F32), B=B, HW=HW,
-                                         gamma=self.gamma, beta=self.beta, eps=self.eps, silu=self.silu, dres=dres)
+        if "bstats" not in self._b:
+            self._b["bstats"] = self.rt.gn_stats("bwd", B * 64)
+        return self.rt.ops.groupnorm_bwd(x1, x2, dy, dx, self._b["stats"], self._b["bstats"], B=B, HW=HW,
+                                         gamma=self.gamma, beta=self.beta, eps=self.eps, silu=self.silu, dres=dres, stats_zeroed=self.rt.gn_prezero)
 
 
 class LayerNorm(_Module):
@@ -798,6 +821,15 @@ class UNet(_Module):
         """x: noisy latent NHWC padded to 64 channels [B*H*W, 64]; timesteps_f fp32 [B]; ctx [B*CTX_PAD, D];
         pooled [B, P] (act dtype), time_ids fp32 [B*6] (SDXL).  Returns eps_hat fp32 [B*H*W, 4]."""
         rt, cfg = self.rt, self.cfg
+        rt.gn_clear("fwd")          # one fill for the statistics of every GroupNorm of this pass
+        rt.gn_prezero = True
+        try:
+            return self._forward(x, timesteps_f, ctx, pooled, time_ids, B=B, H=H, W=W)
+        finally:
+            rt.gn_prezero = False
+
+    def _forward(self, x, timesteps_f, ctx, pooled=None, time_ids=None, *, B, H, W):
+        rt, cfg = self.rt, self.cfg
         rt.daam = []
         for ent in rt.daam_sums.values():
             ent[1], ent[2] = 0, False
@@ -852,6 +884,15 @@ class UNet(_Module):
     def backward(self, dpred64, dctx):
         """dpred64: d loss / d eps_hat as NHWC [B*H*W, 64] (4 real channels); dctx [B*CTX_PAD, D] is ACCUMULATED into
         (caller zeroes it).  LoRA gradients land in arena.grads."""
+        rt = self.rt
+        rt.gn_clear("bwd")
+        rt.gn_prezero = True
+        try:
+            return self._backward(dpred64, dctx)
+        finally:
+            rt.gn_prezero = False
+
+    def _backward(self, dpred64, dctx):
         rt, cfg = self.rt, self.cfg
         B, H, W = self._dims
         boc = cfg["block_out_channels"]

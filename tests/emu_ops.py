@@ -166,7 +166,7 @@ def _gn_cat(x1, x2):
     return x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], dim=1)
 
 
-def groupnorm_fwd(x1, x2, y, stats, *, B, HW, gamma, beta, eps, silu):
+def groupnorm_fwd(x1, x2, y, stats, *, B, HW, gamma, beta, eps, silu, stats_zeroed=False):
     x = _gn_cat(x1, x2)
     C = x.shape[1]
     z = F.group_norm(x.reshape(B, HW, C).permute(0, 2, 1), 32, gamma.float(), beta.float(), eps)
@@ -176,7 +176,7 @@ def groupnorm_fwd(x1, x2, y, stats, *, B, HW, gamma, beta, eps, silu):
     return y
 
 
-def groupnorm_bwd(x1, x2, dy, dx, stats, bstats, *, B, HW, gamma, beta, eps, silu, dres=None):
+def groupnorm_bwd(x1, x2, dy, dx, stats, bstats, *, B, HW, gamma, beta, eps, silu, dres=None, stats_zeroed=False):
     x = _gn_cat(x1, x2).detach().clone().requires_grad_(True)
     C = x.shape[1]
     z = F.group_norm(x.reshape(B, HW, C).permute(0, 2, 1), 32, gamma.float(), beta.float(), eps)
