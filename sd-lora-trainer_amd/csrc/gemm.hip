@@ -710,7 +710,11 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
     else if (!R16 && MODE == 0 && t128 >= 320 && t128 <= 512 && p.N >= 1024) p.tile = 4;    // 4096x1920x640: 17.6 vs 19.7 us
     else if (t128 >= 320) { p.tile = ktot <= 640 ? 1 : 2; if (!p.stages) p.stages = 2; }     // >= 2 workgroups per CU, shallow ring
     else if (t128 >= 160) {
-      if (ktot <= 2560 || (MODE == 0 && ktot <= 6144)) { p.tile = 3; if (!p.stages) p.stages = 2; }
+      // measured in the whole step (not in the hot-loop probe, where the 64x64 tile wins): 160..319 tiles of a plain / LoRA GEMM
+      // run best as 128x128 tiles with the deep ring (55.2 -> 54.5 ms per SDXL step); the short-K convs keep 64x64
+      // (the other classes were re-checked the same way, whole-step A/B per class: every alternative tile / ring / split was slower)
+      if (MODE == 0 && ktot <= 6144) { p.tile = 1; if (!p.stages) p.stages = 4; }
+      else if (ktot <= 2560 || (MODE == 0 && ktot <= 6144)) { p.tile = 3; if (!p.stages) p.stages = 2; }
       else {
         // 4096 x 640 with a long K (3x3 convs of the 64x64 blocks): 160 tiles x 3 splits, two workgroups per CU
         p.tile = 1;
