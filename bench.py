@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-ti", action="store_true", help="inject the text conditioning instead of running the text encoders + TI")
     ap.add_argument("--ti-frozen", action="store_true", help="time the step after freeze_ti_after_completion_f (ti lr = 0): no text-encoder backward")
+    ap.add_argument("--jobs-per-gpu", type=int, default=1, help="independent LoRA jobs stepped concurrently on each GPU (own weights, adapters, "
+                    "text encoders and hipGraph each, one stream per job); a 'step' then advances every job once")
     ap.add_argument("--full-ft", action="store_true", help="full-UNet fine-tune (BASELINE configs[4], train_configs/full_finetuning_example.json: "
                     "SDXL 512 px, batch 4 per GPU, AdamW over every UNet parameter); data parallel with one gradient all-reduce per step when --gpus > 1")
     args = ap.parse_args()
@@ -139,94 +141,126 @@ def main():
     res = args.res or (512 if full_ft else (1024 if "xl" in version else 512))
     B = args.batch or (4 if full_ft else (1 if "xl" in version else 4))
     h = res // 8
-    rt = M.Runtime(device, B)
-    g = torch.Generator(device=device).manual_seed(100 + rank)
-    if full_ft:
-        from sd_lora_trainer_amd import fullft
-        sd = make_state(cfg, device, seed=0)       # data-parallel replicas start from the same weights
-        trainer = fullft.WeightTrainer(rt)
-        unet = M.UNet(rt, cfg, sd, trainer=trainer)
-        arena = trainer
-    else:
-        sd = make_state(cfg, device, seed=rank)    # every rank = its own independent job
-        unet = M.UNet(rt, cfg, sd, lora_rank=args.rank)
-        arena = unet.arena
-        for e in arena.entries:   # peft "gaussian" init: A ~ N(0, 1/r), B = 0 at step 0 (optimizer.py:89)
-            e["A"].copy_(torch.randn(e["A"].shape, generator=g, device=device) / args.rank)
-            e["B"].zero_()
-        arena.refresh_shadows()
-    del sd
-    torch.cuda.empty_cache()
-    text, n_tok = None, 3
-    clip_flops = 0.0
-    if not args.no_ti and not full_ft:             # the full fine-tune example disables textual inversion
-        import sd_lora_trainer_amd.clip as CL
-        tiny = version.startswith("tiny")
-        kinds = (["tiny_l", "tiny_g"] if tiny else ["clip_l", "clip_g"]) if cfg["addition"] else (["tiny_l"] if tiny else ["clip_l"])
-        encs = []
-        for i, kd in enumerate(kinds):
-            c = topology.CLIP_CONFIGS[kd]
-            csd = make_clip_state(c, device, seed=1000 + 10 * rank + i, n_new=n_tok)
-            mode = "penultimate" if cfg["addition"] else "last"
-            enc = CL.ClipTextEncoder(rt, f"te{i + 1}", csd, heads=c["heads"], act=c["act"], mode=mode, with_projection=bool(c["proj"]), n_train=n_tok)
-            encs.append(enc)
-            clip_flops += topology.clip_fwd_flops(c, B, layers_run=enc.n_run)
-            del csd
-        text = S.TextStack(rt, encs, pool_mode="argmax")
-    ts = S.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, l1_penalty=0.03, weight_decay=0.004, text=text, n_tokens=n_tok,
-                     process_group=True if (full_ft and world > 1) else None)
-    rn = lambda *s: torch.randn(*s, generator=g, device=device)  # noqa: E731
-    latent = rn(B, 4, h, h) * cfg["scaling_factor"]
-    noise = rn(B, 4, h, h)
-    mask = (torch.rand(B, 1, h, h, generator=g, device=device) * 0.95 + 0.05).repeat(1, 4, 1, 1).contiguous()
-    timesteps = torch.randint(0, 1000, (B,), generator=g, device=device)
-    ctx = rn(B, 77, cfg["cross_dim"])
-    pooled = tid = None
-    if cfg["addition"]:
-        pooled = rn(B, cfg["proj_class_in"] - 6 * cfg["addition_time_embed_dim"])
-        tid = torch.tensor([[1024., 1024, 0, 0, float(res), float(res)]] * B, device=device)
-    if text is None:
-        ts.set_batch(latent, noise, timesteps, mask, ctx, pooled, tid)
-    else:
-        vocab = text.encoders[0].V
-        tok = [vocab - 3, vocab - 2, vocab - 1]
-        lists, ids = [], torch.full((B, 77), 49407 if vocab > 49407 else vocab - 4, dtype=torch.int64)
-        for b in range(B):   # "a photo of <s0><s1><s2> ..." style caption: BOS, 8 words, the 3 TI tokens, EOS, padding
-            words = torch.randint(1000 if vocab > 2000 else 10, min(40000, vocab - 10), (8,)).tolist()
-            l = [49406 if vocab > 49407 else vocab - 5] + words[:4] + tok + words[4:] + [49407 if vocab > 49407 else vocab - 4]
-            ids[b, :len(l)] = torch.tensor(l)
-            lists.append(l)
-        ts.set_batch(latent, noise, timesteps, mask, time_ids=tid, ids=[ids] * len(text.encoders), caption_token_lists=lists)
-    if not args.no_graph:
-        ts.capture(warmup=2)
+    J = max(1, args.jobs_per_gpu)
+    assert not (full_ft and J > 1), "the full fine-tune is one data-parallel job"
+
+    def build_job(jidx):
+        """One independent training job (own weights copy, own adapters, own text encoders, own hipGraph)."""
+        seed = rank * 16 + jidx
+        rt = M.Runtime(device, B)
+        g = torch.Generator(device=device).manual_seed(100 + seed)
+        if full_ft:
+            from sd_lora_trainer_amd import fullft
+            sd = make_state(cfg, device, seed=0)       # data-parallel replicas start from the same weights
+            trainer = fullft.WeightTrainer(rt)
+            unet = M.UNet(rt, cfg, sd, trainer=trainer)
+            arena = trainer
+        else:
+            sd = make_state(cfg, device, seed=seed)    # every rank = its own independent job
+            unet = M.UNet(rt, cfg, sd, lora_rank=args.rank)
+            arena = unet.arena
+            for e in arena.entries:   # peft "gaussian" init: A ~ N(0, 1/r), B = 0 at step 0 (optimizer.py:89)
+                e["A"].copy_(torch.randn(e["A"].shape, generator=g, device=device) / args.rank)
+                e["B"].zero_()
+            arena.refresh_shadows()
+        del sd
+        torch.cuda.empty_cache()
+        text, n_tok = None, 3
+        clip_flops = 0.0
+        if not args.no_ti and not full_ft:             # the full fine-tune example disables textual inversion
+            import sd_lora_trainer_amd.clip as CL
+            tiny = version.startswith("tiny")
+            kinds = (["tiny_l", "tiny_g"] if tiny else ["clip_l", "clip_g"]) if cfg["addition"] else (["tiny_l"] if tiny else ["clip_l"])
+            encs = []
+            for i, kd in enumerate(kinds):
+                c = topology.CLIP_CONFIGS[kd]
+                csd = make_clip_state(c, device, seed=1000 + 10 * seed + i, n_new=n_tok)
+                mode = "penultimate" if cfg["addition"] else "last"
+                enc = CL.ClipTextEncoder(rt, f"te{i + 1}", csd, heads=c["heads"], act=c["act"], mode=mode, with_projection=bool(c["proj"]), n_train=n_tok)
+                encs.append(enc)
+                clip_flops += topology.clip_fwd_flops(c, B, layers_run=enc.n_run)
+                del csd
+            text = S.TextStack(rt, encs, pool_mode="argmax")
+        ts = S.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, l1_penalty=0.03, weight_decay=0.004, text=text, n_tokens=n_tok,
+                         process_group=True if (full_ft and world > 1) else None)
+        rn = lambda *s: torch.randn(*s, generator=g, device=device)  # noqa: E731
+        latent = rn(B, 4, h, h) * cfg["scaling_factor"]
+        noise = rn(B, 4, h, h)
+        mask = (torch.rand(B, 1, h, h, generator=g, device=device) * 0.95 + 0.05).repeat(1, 4, 1, 1).contiguous()
+        timesteps = torch.randint(0, 1000, (B,), generator=g, device=device)
+        ctx = rn(B, 77, cfg["cross_dim"])
+        pooled = tid = None
+        if cfg["addition"]:
+            pooled = rn(B, cfg["proj_class_in"] - 6 * cfg["addition_time_embed_dim"])
+            tid = torch.tensor([[1024., 1024, 0, 0, float(res), float(res)]] * B, device=device)
+        if text is None:
+            ts.set_batch(latent, noise, timesteps, mask, ctx, pooled, tid)
+        else:
+            vocab = text.encoders[0].V
+            tok = [vocab - 3, vocab - 2, vocab - 1]
+            lists, ids = [], torch.full((B, 77), 49407 if vocab > 49407 else vocab - 4, dtype=torch.int64)
+            for b in range(B):   # "a photo of <s0><s1><s2> ..." style caption: BOS, 8 words, the 3 TI tokens, EOS, padding
+                words = torch.randint(1000 if vocab > 2000 else 10, min(40000, vocab - 10), (8,)).tolist()
+                l = [49406 if vocab > 49407 else vocab - 5] + words[:4] + tok + words[4:] + [49407 if vocab > 49407 else vocab - 4]
+                ids[b, :len(l)] = torch.tensor(l)
+                lists.append(l)
+            ts.set_batch(latent, noise, timesteps, mask, time_ids=tid, ids=[ids] * len(text.encoders), caption_token_lists=lists)
+        if not args.no_graph:
+            ts.capture(warmup=2)
+        return ts, arena, text, clip_flops
+
+    # J independent jobs per GPU, each on its own stream with its own graph: at batch 1 the step is bound by per-kernel latency and
+    # partial waves of workgroups, so the replays of two jobs overlap on the GPU (two PROCESSES time-slice instead)
+    cur = torch.cuda.current_stream(device)
+    streams = [cur] if J == 1 else [torch.cuda.Stream(device=device) for _ in range(J)]
+    jobs = []
+    for j in range(J):
+        streams[j].wait_stream(cur)
+        with torch.cuda.stream(streams[j]):
+            jobs.append(build_job(j))
+        streams[j].synchronize()
+    ts, arena, text, clip_flops = jobs[0]
     total = args.warmup + args.steps
     ti_lr = 1e-3 if (text is not None and not args.ti_frozen) else 0.0
+
+    def step_all(i):
+        for (tsj, _, _, _), st in zip(jobs, streams):
+            with torch.cuda.stream(st):
+                tsj.run(lr_at(i, total), ti_lr * (1 - i / total) ** 1.7)                            # main.py:271-274
+
     for i in range(args.warmup):
-        ts.run(lr_at(i, total), ti_lr * (1 - i / total) ** 1.7)
+        step_all(i)
+    for st in streams:
+        cur.wait_stream(st)
 
     barrier = parallel.barrier_sync
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
+    for st in streams:
+        st.wait_stream(cur)
     for i in range(args.steps):
-        ts.run(lr_at(args.warmup + i, total), ti_lr * (1 - (args.warmup + i) / total) ** 1.7)     # main.py:271-274
+        step_all(args.warmup + i)
+    for st in streams:
+        cur.wait_stream(st)
     ev1.record()
     barrier()
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device)
     ev_ms = ev0.elapsed_time(ev1)
-    loss = ts.total_loss()
-    assert math.isfinite(loss), "non-finite loss in the timed region"
+    losses = [tsj.total_loss() for tsj, _, _, _ in jobs]
+    loss = losses[0]
+    assert all(math.isfinite(x) for x in losses), "non-finite loss in the timed region"
 
     if rank == 0:
         # LoRA: dX only (+ small adapter terms) = 2 x forward; full fine-tune: dX and dW = 3 x forward (SURVEY 8d)
         f_step = (3.0 * topology.fwd_flops(cfg, B, h, h, 0)["total"]) if full_ft else 2.0 * topology.fwd_flops(cfg, B, h, h, args.rank)["total"]
         t_step = elapsed / args.steps
-        achieved = f_step / (ev_ms * 1e-3 / args.steps)
+        achieved = J * f_step / (ev_ms * 1e-3 / args.steps)
         # HBM-side bytes per step: measured offline (PMC counters need rocprofv3 around the process), for the default workload only
         traffic = None
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_sdxl1024_ti_hbm_traffic_pmc.json")
-        if version == "sdxl" and res == 1024 and B == 1 and args.rank == 16 and text is not None and not args.ti_frozen and not full_ft and os.path.exists(tpath):
+        if version == "sdxl" and res == 1024 and B == 1 and args.rank == 16 and text is not None and not args.ti_frozen and not full_ft and J == 1 and os.path.exists(tpath):
             with open(tpath) as fh:
                 traffic = json.load(fh).get("traffic_bytes_per_step")
         fpath = os.path.join(os.path.dirname(tpath), "r01_fullft_hbm_traffic_pmc.json")
@@ -235,7 +269,7 @@ def main():
                 traffic = json.load(fh).get("traffic_bytes_per_step")
         out = {
             "metric": "training images/sec, SDXL 1024px rank-16 LoRA, 1/2/4/8 GPU (job-parallel)",
-            "value": world * B * args.steps / elapsed,
+            "value": world * J * B * args.steps / elapsed,
             "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": t_step * 1e3,
@@ -247,13 +281,14 @@ def main():
                                    + (", + textual inversion (text encoders fwd+bwd with 3 trainable tokens, token-attention loss, "
                                       "std regulariser, rows-only AdamW)" + (" [ti lr = 0: frozen-TI fast path, no text-encoder backward]" if args.ti_frozen else "") if text is not None else ", text conditioning injected (--no-ti)"),
                        "text_encoder_fwd_gflop_not_in_roofline": clip_flops / 1e9,
-                       "global_batch": world * B,
+                       "jobs_per_gpu": J, "global_batch": world * J * B,
                        "parallelism": (f"dp{world}: one fp32 gradient all-reduce of {arena.n * 4 / 1e9:.1f} GB per step (RCCL)" if (full_ft and world > 1)
-                                       else f"job-parallel x{world} (independent jobs, no collective)"),
+                                       else f"job-parallel x{world * J} ({world} GPU(s) x {J} independent job(s) per GPU, no collective)"
+                                            + (f"; a step advances every job once ({J} images per GPU and step), ms_per_step is per such step" if J > 1 else "")),
                        "trained_params": arena.n, "graph": not args.no_graph, "final_loss": loss},
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_DENSE, "traffic": traffic,
-                         "note": f"algorithmic {f_step / 1e12:.3f} TFLOP per step (2 x fwd census) / {ev_ms / args.steps:.3f} ms "
+                         "note": f"algorithmic {J} x {f_step / 1e12:.3f} TFLOP per step (2 x fwd census) / {ev_ms / args.steps:.3f} ms "
                                  "per step (HIP events on the replay stream); traffic = HBM-side bytes per step from the committed "
                                  "rocprofv3 PMC passes of this command (profiles/r01_sdxl1024_ti_hbm_traffic_pmc.json), null for other configs"},
         }

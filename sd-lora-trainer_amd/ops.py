@@ -44,13 +44,31 @@ def zero_page(device):
 
 
 _workspaces = {}
+_ws_owner = None
+
+
+class workspace_owner:
+    """`with workspace_owner(key):` - every GEMM enqueued inside uses the split-K workspace of `key` instead of the current
+    stream's.  A training job captures its step under its own key: two jobs whose graphs replay concurrently on one GPU must
+    not share slabs / counters, and torch may capture both graphs on the same internal stream."""
+
+    def __init__(self, key):
+        self.key = key
+
+    def __enter__(self):
+        global _ws_owner
+        self.prev, _ws_owner = _ws_owner, self.key
+
+    def __exit__(self, *a):
+        global _ws_owner
+        _ws_owner = self.prev
 
 
 def splitk_workspace(device):
     """Split-K scratch of sdlt_gemm_bf16: fp32 partial-tile slabs + zero-initialised arrival counters.
-    One workspace per (device, stream): GEMMs enqueued on different streams may run concurrently (the two text encoders
-    do) and must not share slabs or counters; GEMMs on one stream are ordered, so they can."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    One workspace per (device, stream) - or per owner, see workspace_owner: GEMMs enqueued on different streams may run
+    concurrently (the two text encoders do) and must not share slabs or counters; GEMMs on one stream are ordered, so they can."""
+    key = (device, ("owner", _ws_owner) if _ws_owner is not None else torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None:
         ws = (torch.empty(96 << 20, dtype=torch.uint8, device=device), torch.zeros(4096, dtype=torch.int32, device=device))

@@ -463,7 +463,19 @@ class TrainStep:
         return float(self.group.grads.norm())
 
     # -------------------------------------------------------------------------------- graph capture / replay
+    def _ws(self):
+        """Scope in which this job's GEMMs use their own split-K workspace (ops.workspace_owner); a no-op for the CPU emulation."""
+        own = getattr(self.rt.ops, "workspace_owner", None)
+        if own is None or (self.text is not None and self.text.concurrent):      # forked encoders keep one workspace per stream
+            import contextlib
+            return contextlib.nullcontext()
+        return own(id(self))
+
     def capture(self, warmup=2):
+        with self._ws():
+            return self._capture(warmup)
+
+    def _capture(self, warmup=2):
         """Runs the body eagerly `warmup` times (allocates every persistent buffer, builds the grouped-gradient
         plan), then captures it: one hipGraph for the whole step (one per phase when the text encoders run on forked
         streams), plus the frozen-TI variant.  AdamW state is restored afterwards so capture does not count as training."""
@@ -521,6 +533,10 @@ class TrainStep:
         self.opt_step = step0
 
     def run(self, lr, lr_ti=0.0, lr_te=0.0, last_batch=False):
+        with self._ws():
+            return self._run(lr, lr_ti, lr_te, last_batch)
+
+    def _run(self, lr, lr_ti=0.0, lr_te=0.0, last_batch=False):
         if self._acc is not None:
             self._micro += 1
             if self._micro % self.grad_accum != 0 and not last_batch:        # main.py:366
