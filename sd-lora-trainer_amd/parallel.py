@@ -24,18 +24,21 @@ def job_env(job_index, n_gpus, base_env=None):
     return env
 
 
-def sweep_plan(config_paths, n_gpus):
-    """[(config, gpu, wave)]: jobs run in waves of n_gpus, job i on GPU i mod n_gpus."""
-    return [(c, i % n_gpus, i // n_gpus) for i, c in enumerate(config_paths)]
+def sweep_plan(config_paths, n_gpus, jobs_per_gpu=1):
+    """[(config, gpu, wave)]: jobs run in waves of n_gpus * jobs_per_gpu; with jobs_per_gpu = 1 job i runs on GPU i mod n_gpus,
+    otherwise consecutive groups of jobs_per_gpu configs share a GPU (and ONE process: train.train_concurrent)."""
+    return [(c, (i // jobs_per_gpu) % n_gpus, i // (jobs_per_gpu * n_gpus)) for i, c in enumerate(config_paths)]
 
 
-def run_sweep(config_paths, n_gpus, entry=("-m", "sd_lora_trainer_amd.train"), dry_run=False):
-    """Launch a hyper-parameter sweep job-parallel; returns the list of (cmd, env) (and runs them unless dry_run)."""
+def run_sweep(config_paths, n_gpus, entry=("-m", "sd_lora_trainer_amd.train"), dry_run=False, jobs_per_gpu=1):
+    """Launch a hyper-parameter sweep job-parallel; returns the list of (cmd, env) (and runs them unless dry_run).
+    jobs_per_gpu > 1: each process gets that many configs and steps them concurrently on its GPU (one stream per job)."""
+    groups = [config_paths[i:i + jobs_per_gpu] for i in range(0, len(config_paths), jobs_per_gpu)]
     launched = []
-    for wave_start in range(0, len(config_paths), n_gpus):
+    for wave_start in range(0, len(groups), n_gpus):
         procs = []
-        for i, cfg in enumerate(config_paths[wave_start:wave_start + n_gpus], start=wave_start):
-            cmd = [sys.executable, *entry, cfg]
+        for i, grp in enumerate(groups[wave_start:wave_start + n_gpus], start=wave_start):
+            cmd = [sys.executable, *entry, *grp]
             env = job_env(i, n_gpus)
             launched.append((cmd, {k: env[k] for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")}))
             if not dry_run:

@@ -102,8 +102,9 @@ def synthetic_cache(cfg, n_images, h, w, vocab, n_tokens, seed):
                 tok_list=[bos] + tok + [eos], description_ids=[bos] + torch.randint(1, bos - 1, (8,), generator=g).tolist() + [eos])
 
 
-def train(config: TrainingConfig, runtime=None):
-    """Generator: yields progress in [0,1]; returns (config, output_save_dir)."""
+def train(config: TrainingConfig, runtime=None, every_step=False):
+    """Generator: yields progress in [0,1]; returns (config, output_save_dir).  every_step: also yield (None) after every
+    optimizer call, so that several jobs can be advanced in lock-step by train_concurrent."""
     from . import step as S
     from . import unet as M
     np.random.seed(config.seed)
@@ -221,6 +222,8 @@ def train(config: TrainingConfig, runtime=None):
             every = max(config.max_train_steps // 100, 1)         # main.py:457 divides by zero for max_train_steps < 100
             if global_step % every == 0:
                 yield float(min(global_step / config.max_train_steps + 0.05, 1.0))
+            elif every_step:
+                yield None
             if global_step > config.max_train_steps:               # main.py:462 (runs max_train_steps + 1 steps)
                 done = True
                 break
@@ -234,14 +237,43 @@ def train(config: TrainingConfig, runtime=None):
     return config, output_save_dir
 
 
+def train_concurrent(configs, on_progress=None, runtimes=None):
+    """Several independent jobs on ONE GPU, in one process: every job gets its own stream, weights, adapters and hipGraph, and the
+    jobs are advanced round-robin one optimizer call at a time.  At batch 1 the step is bound by per-kernel latency and partial
+    waves of workgroups, so the replays of two jobs overlap on the device (+30 % aggregate images/s for two SDXL jobs; two
+    PROCESSES on one GPU time-slice instead).  The jobs share numpy's / torch's global RNG (caption dropout), like jobs started
+    from one shell script share nothing but the device.  Returns [(config, output_save_dir)] in the order of `configs`."""
+    use_cuda = torch.cuda.is_available() and all(str(c.device).startswith("cuda") for c in configs)
+    streams = [torch.cuda.Stream() if use_cuda else None for _ in configs]
+    gens = [train(c, runtime=runtimes[i] if runtimes else None, every_step=True) for i, c in enumerate(configs)]
+    results, live = [None] * len(configs), set(range(len(configs)))
+    while live:
+        for i in sorted(live):
+            try:
+                if streams[i] is not None:
+                    with torch.cuda.stream(streams[i]):
+                        p = next(gens[i])
+                else:
+                    p = next(gens[i])
+                if p is not None and on_progress is not None:
+                    on_progress(i, p)
+            except StopIteration as e:
+                results[i] = e.value
+                live.discard(i)
+    return results
+
+
 if __name__ == "__main__":
-    cfg = TrainingConfig.from_json(sys.argv[1])
-    gen = train(cfg)
-    try:
-        while True:
-            p = next(gen)
-            print(f"progress {p:.2f}", flush=True)
-    except StopIteration as e:
-        cfg, out = e.value
+    cfgs = [TrainingConfig.from_json(a) for a in sys.argv[1:]]
+    if len(cfgs) > 1:            # python -m sd_lora_trainer_amd.train a.json b.json : the jobs share this process's GPU
+        res = train_concurrent(cfgs, on_progress=lambda i, p: print(f"job {i} progress {p:.2f}", flush=True))
+    else:
+        gen = train(cfgs[0])
+        try:
+            while True:
+                print(f"progress {next(gen):.2f}", flush=True)
+        except StopIteration as e:
+            res = [e.value]
+    for cfg, out in res:
         print(json.dumps({"output_save_dir": out, "job_time": cfg.job_time,
                           "images_per_second": cfg.training_attributes["images_per_second"]}))

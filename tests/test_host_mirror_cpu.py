@@ -138,3 +138,26 @@ def test_latent_cache_matches_reference_dataset(golden_dir):
     assert lats.shape == (2, 4, 6, 8) and masks.shape == lats.shape and caps_b[0] == cache.captions[2]
     ones = LatentCache(g["posteriors"][:1], None, ["x"], scaling_factor=1.0, size=g["size"])
     assert torch.equal(ones.masks[0], torch.ones(4, 6, 8))
+
+
+def test_train_concurrent_and_sweep_groups(tmp_path, monkeypatch):
+    """Two jobs advanced in lock-step in one process (train.train_concurrent; on the GPU each on its own stream / graph), and
+    the sweep launcher's grouping of configs per GPU process."""
+    monkeypatch.chdir(tmp_path)
+    from sd_lora_trainer_amd import parallel
+    from sd_lora_trainer_amd.train import train_concurrent
+    cfgs = [TrainingConfig(lora_training_urls="synthetic:4", concept_mode="object", pretrained_model={"path": "synthetic:tiny15"}, seed=1 + i, name=f"job{i}",
+                           output_dir=str(tmp_path / f"out{i}"), resolution=128, train_batch_size=1, max_train_steps=3 + i, lora_rank=4, disable_ti=True,
+                           unet_lr=1e-3) for i in range(2)]
+    rts = [unet_mod.Runtime("cpu", 1, act_dtype=torch.float32, ops=emu_ops) for _ in cfgs]
+    seen = []
+    res = train_concurrent(cfgs, on_progress=lambda i, p: seen.append(i), runtimes=rts)
+    assert [os.path.basename(out) for _, out in res] == ["checkpoint-4", "checkpoint-4"]      # 4 images / epoch bound both runs (main.py:207, 462)
+    assert all(any(n.endswith("_lora.safetensors") for n in os.listdir(out)) for _, out in res)
+    assert str(tmp_path / "out0") in res[0][1] and str(tmp_path / "out1") in res[1][1]
+    assert set(seen) == {0, 1} and seen[:2] == [0, 1]                       # interleaved, not one after the other
+    plan = parallel.sweep_plan([f"c{i}" for i in range(10)], 2, jobs_per_gpu=2)
+    assert [(g, w) for _, g, w in plan] == [(0, 0), (0, 0), (1, 0), (1, 0), (0, 1), (0, 1), (1, 1), (1, 1), (0, 2), (0, 2)]
+    launched = parallel.run_sweep([f"c{i}.json" for i in range(5)], 2, dry_run=True, jobs_per_gpu=2)
+    assert [cmd[-2:] if len(cmd) > 4 else cmd[-1:] for cmd, _ in launched] == [["c0.json", "c1.json"], ["c2.json", "c3.json"], ["c4.json"]]
+    assert [env["HIP_VISIBLE_DEVICES"] for _, env in launched] == ["0", "1", "0"]

@@ -216,3 +216,23 @@ def test_gradient_accumulation_graphs():
     torch.cuda.synchronize()
     cos, rel = _cos_rel(g_acc, unet.arena.grads)
     assert cos >= 0.995 and rel <= 5e-2, (cos, rel)
+
+
+def test_train_concurrent_on_gpu(tmp_path, monkeypatch):
+    """Two independent jobs in one process, each on its own stream with its own hipGraph (train.train_concurrent): both train
+    and write their own checkpoints; the graphs replay concurrently, so they must not share any scratch (split-K workspace)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import json
+    import os
+    monkeypatch.chdir(tmp_path)
+    from sd_lora_trainer_amd.config import TrainingConfig
+    from sd_lora_trainer_amd.train import train_concurrent
+    cfgs = [TrainingConfig(lora_training_urls="synthetic:8", concept_mode="object", pretrained_model={"path": "synthetic:tinyxl"}, seed=3 + i, name=f"job{i}",
+                           output_dir=str(tmp_path / f"out{i}"), resolution=256, train_batch_size=1, max_train_steps=40, lora_rank=8 * (i + 1),
+                           unet_lr=2e-3, ti_lr=2e-3) for i in range(2)]
+    res = train_concurrent(cfgs)
+    for i, (cfg, out) in enumerate(res):
+        tot = json.load(open(os.path.join(out, "training_args.json")))["training_attributes"]["losses"]["tot_loss"]
+        assert all(x == x and abs(x) < 1e4 for x in tot) and sum(tot[-5:]) / 5 < sum(tot[:5]) / 5, (i, tot)
+        assert str(tmp_path / f"out{i}") in out
