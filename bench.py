@@ -277,7 +277,8 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": (f"{version} {res}x{res} FULL-UNet fine-tune batch {B}/GPU: UNet fwd + bwd (dX and every dW), masked/min-SNR MSE, "
                                     f"AdamW over {arena.n / 1e6:.0f} M parameters, bf16 operand refresh" if full_ft else
-                                    f"{version} {res}x{res} LoRA rank {args.rank} batch {B}/GPU: UNet fwd+bwd, masked/min-SNR MSE, L1, AdamW")
+                                    f"{version} {res}x{res} LoRA rank {args.rank} batch {B}" + ("/GPU" if J == 1 else f" per job, {J} concurrent jobs/GPU")
+                                    + ": UNet fwd+bwd, masked/min-SNR MSE, L1, AdamW")
                                    + (", + textual inversion (text encoders fwd+bwd with 3 trainable tokens, token-attention loss, "
                                       "std regulariser, rows-only AdamW)" + (" [ti lr = 0: frozen-TI fast path, no text-encoder backward]" if args.ti_frozen else "") if text is not None else ", text conditioning injected (--no-ti)"),
                        "text_encoder_fwd_gflop_not_in_roofline": clip_flops / 1e9,
