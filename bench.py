@@ -211,6 +211,9 @@ def main():
 
     # J independent jobs per GPU, each on its own stream with its own graph: at batch 1 the step is bound by per-kernel latency and
     # partial waves of workgroups, so the replays of two jobs overlap on the GPU (two PROCESSES time-slice instead)
+    if J > 1:
+        from sd_lora_trainer_amd import ops as _ops
+        _ops.set_throughput_hint(True)
     cur = torch.cuda.current_stream(device)
     streams = [cur] if J == 1 else [torch.cuda.Stream(device=device) for _ in range(J)]
     jobs = []

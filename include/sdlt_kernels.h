@@ -89,7 +89,9 @@ typedef struct sdlt_gemm_params {
                                           every cross-attention layer read the same text conditioning: one launch for all of
                                           them, and one for all their input gradients); no split-K */
   int32_t n_batch;
-  int32_t pad2_;
+  int32_t throughput_hint;            /* 1: several independent jobs share the device (train_concurrent): the other jobs fill idle CUs,
+                                         so the tile heuristics trade workgroup count for per-tile efficiency (256x128 tiles
+                                         for the >= 320-tile classes and the mid-size convs).  0: one job - fill the chip. */
 } sdlt_gemm_params;
 int sdlt_gemm_bf16(const sdlt_gemm_params* p, void* stream);
 

@@ -36,7 +36,7 @@ class GemmParams(C.Structure):
         ("Ct", vp), ("ldct", i64),
         ("splitk", i32), ("ws_cnt_len", i32), ("ws_slab", vp), ("ws_slab_bytes", i64), ("stages", i32), ("accumulate", i32), ("ws_cnt", vp),
         ("lora_group_n", i32), ("lora_group_k", i32),
-        ("batch", vp), ("n_batch", i32), ("pad2_", i32),
+        ("batch", vp), ("n_batch", i32), ("throughput_hint", i32),
     ]
 
 

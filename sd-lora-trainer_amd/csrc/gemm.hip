@@ -707,6 +707,12 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
         p.splitk = sk;
       }
     }
+    else if (p.throughput_hint && !p.batch && !p.lora_group_k && (t128 >= 320 || (MODE == 1 && t128 >= 160))) {
+      // several jobs share the device (whole-step A/B with two concurrent SDXL jobs: 85.0 -> 82.8 ms per pair): the other job
+      // fills the CUs a launch leaves idle, so the 256x128 tile (0.75 operand-path cycles per MFMA cycle instead of 1.0) wins
+      // although it halves the workgroup count.  With ONE job the same rule loses 0.3 ms.
+      p.tile = 4;
+    }
     else if (!R16 && MODE == 0 && t128 >= 320 && t128 <= 512 && p.N >= 1024) p.tile = 4;    // 4096x1920x640: 17.6 vs 19.7 us
     else if (t128 >= 320) { p.tile = ktot <= 640 ? 1 : 2; if (!p.stages) p.stages = 2; }     // >= 2 workgroups per CU, shallow ring
     else if (t128 >= 160) {

@@ -85,6 +85,16 @@ class ConvGeom:
         self.stride, self.ups, self.flip, self.tr = stride, ups, flip, tr
 
 
+THROUGHPUT_HINT = False
+
+
+def set_throughput_hint(flag):
+    """Several independent jobs are stepped concurrently on this device (train.train_concurrent, bench.py --jobs-per-gpu): every
+    GEMM enqueued (i.e. captured) from now on carries sdlt_gemm_params.throughput_hint."""
+    global THROUGHPUT_HINT
+    THROUGHPUT_HINT = bool(flag)
+
+
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
          residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0, batch=None):
     """out[M,N] = alpha*(X.W^T [+ X2.W2^T] [+ s*(X.Adown^T).Bup^T]) + bias + rowbias[m//rows_per_batch] + residual.
@@ -113,6 +123,7 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
         p.stride, p.ups, p.flip, p.tr = conv.stride, conv.ups, conv.flip, conv.tr
         p.zero = _p(zero_page(X.device))
     p.M, p.N, p.K = M, N, K
+    p.throughput_hint = int(THROUGHPUT_HINT)
     if X2 is not None:
         _chk2(X2), _chk2(W2)
         assert X2.shape[0] == M and W2.shape[0] == N and X2.shape[1] == W2.shape[1]

@@ -42,6 +42,10 @@ def _conv_apply(X, Wm, g):
     return y.permute(0, 2, 3, 1).reshape(g.B * g.Hout * g.Wout, N)
 
 
+def set_throughput_hint(flag):
+    pass
+
+
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
          residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0, batch=None):
     if batch is not None:     # batched launch: every problem with its own operands, same options

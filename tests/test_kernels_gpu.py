@@ -661,3 +661,30 @@ def test_adamw_fused_into_refresh_tiles(ops):
     for dc, dtc, dg, dtg in outs:
         close(dg, dc, tol=4e-3, what="refreshed operand")
         close(dtg, dtc, tol=4e-3, what="refreshed transposed operand")
+
+
+def test_gemm_throughput_hint(ops):
+    """sdlt_gemm_params.throughput_hint (several jobs share the device): the heuristics pick 256x128 tiles for the >= 320-tile
+    classes and the mid-size convs - same results."""
+    g = torch.Generator().manual_seed(21)
+    ops.set_throughput_hint(True)
+    try:
+        for (M, N, K, lora) in [(4096, 1920, 640, False), (4096, 1280, 640, True), (1024, 10240, 1280, False)]:
+            X = torch.randn(M, K, generator=g).to(BF)
+            W = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
+            lo_c = lo_g = None
+            if lora:
+                A, Bm = (torch.randn(16, K, generator=g) / K ** 0.5).to(BF), (torch.randn(N, 16, generator=g) * 0.1).to(BF)
+                lo_c, lo_g = (A, Bm, 0.5, torch.zeros(M, 16, dtype=BF)), (A.cuda(), Bm.cuda(), 0.5, torch.zeros(M, 16, dtype=BF, device="cuda"))
+            ref = E.gemm(X, W, torch.zeros(M, N, dtype=BF), lora=lo_c)
+            out = ops.gemm(X.cuda(), W.cuda(), torch.zeros(M, N, dtype=BF, device="cuda"), lora=lo_g)
+            close(out, ref, what=f"hinted gemm {M}x{N}x{K} lora={lora}")
+        Bc, H, Wd, Cin, Cout = 1, 64, 64, 128, 640                      # 4096 x 640 conv: the 160..319-tile conv class
+        x = torch.randn(Bc * H * Wd, Cin, generator=g).to(BF)
+        w = (torch.randn(Cout, 9 * Cin, generator=g) / (9 * Cin) ** 0.5).to(BF)
+        geom = ops.ConvGeom(Bc, H, Wd, Cin, H, Wd)
+        ref = E.gemm(x, w, torch.zeros(Bc * H * Wd, Cout, dtype=BF), conv=E.ConvGeom(Bc, H, Wd, Cin, H, Wd) if hasattr(E, "ConvGeom") else geom)
+        out = ops.gemm(x.cuda(), w.cuda(), torch.zeros(Bc * H * Wd, Cout, dtype=BF, device="cuda"), conv=geom)
+        close(out, ref, what="hinted conv")
+    finally:
+        ops.set_throughput_hint(False)
