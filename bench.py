@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--ti-frozen", action="store_true", help="time the step after freeze_ti_after_completion_f (ti lr = 0): no text-encoder backward")
     ap.add_argument("--jobs-per-gpu", type=int, default=1, help="independent LoRA jobs stepped concurrently on each GPU (own weights, adapters, "
                     "text encoders and hipGraph each, one stream per job); a 'step' then advances every job once")
+    ap.add_argument("--no-concurrent", action="store_true", help="skip the extra two-jobs-per-GPU measurement of the default run")
     ap.add_argument("--full-ft", action="store_true", help="full-UNet fine-tune (BASELINE configs[4], train_configs/full_finetuning_example.json: "
                     "SDXL 512 px, batch 4 per GPU, AdamW over every UNet parameter); data parallel with one gradient all-reduce per step when --gpus > 1")
     args = ap.parse_args()
@@ -303,6 +304,38 @@ def main():
             out["cpu_baseline"] = {"value": 1.0 / scaled, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
                                    "sample": f"one fp32 oracle fwd+bwd step at {sample_hw * 8}x{sample_hw * 8} B=1 took {dt:.1f} s "
                                              f"({f_sample / 1e12:.2f} TFLOP); scaled by the FLOP ratio to the {res}x{res} workload"}
+        if world == 1 and J == 1 and not full_ft and not args.no_graph and not args.no_concurrent:
+            # Extra measurement (never `value`): the same workload with TWO independent jobs stepped concurrently on this GPU,
+            # each on its own stream with its own hipGraph (train.train_concurrent).
+            from sd_lora_trainer_amd import ops as _ops
+            _ops.set_throughput_hint(True)
+            try:
+                st2 = [torch.cuda.Stream(device=device) for _ in range(2)]
+                pair = []
+                for j, st in enumerate(st2):
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        pair.append(build_job(8 + j)[0])
+                    st.synchronize()
+
+                def pair_step(i):
+                    for tsj, st in zip(pair, st2):
+                        with torch.cuda.stream(st):
+                            tsj.run(lr_at(i, total), ti_lr * (1 - i / total) ** 1.7)
+                for i in range(args.warmup):
+                    pair_step(i)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(args.steps):
+                    pair_step(args.warmup + i)
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t1
+                assert all(math.isfinite(tsj.total_loss()) for tsj in pair)
+                out["two_jobs_per_gpu"] = {"value": 2 * B * args.steps / dt2, "unit": "images/s", "ms_per_pair_of_steps": dt2 / args.steps * 1e3,
+                                           "note": "extra measurement, not `value`: two independent jobs of the same workload in this process, one stream + "
+                                                   "hipGraph each (python bench.py --jobs-per-gpu 2 reports it as the main figure)"}
+            finally:
+                _ops.set_throughput_hint(False)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
