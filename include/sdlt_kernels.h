@@ -223,6 +223,14 @@ int sdlt_wgrad_transpose(const void* x, int64_t ldx, int32_t M, int32_t C, void*
                          void* stream);
 int sdlt_wgrad_im2col_t(const void* x, int64_t ldx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t stride, int32_t ups,
                         void* out, int64_t ldo, int32_t Mp, void* stream);
+/* All norm layers of one shape in one launch (accumulating: the caller has zeroed dgamma / dbeta).  groupnorm = 0: LayerNorm
+ * over [B*HW, C] rows (x2 unused); 1: GroupNorm(32)(+SiLU), x = concat(x1 [.., C1], x2 [.., C - C1]) or x1 alone (C1 = 0). */
+typedef struct sdlt_affine_grad_item {
+  const void* x1; const void* x2; const void* dy; const float* stats; const float* gamma; const float* beta; float* dgamma; float* dbeta;
+} sdlt_affine_grad_item;
+int sdlt_affine_grad_batch(const sdlt_affine_grad_item* items_dev, int32_t n, int32_t groupnorm, int64_t ldx1, int32_t C1, int64_t ldx2,
+                           int64_t lddy, int32_t B, int32_t HW, int32_t C, float eps, int32_t silu, void* stream);
+
 /* Batched forms: n problems of identical geometry, each with its own pointers (device array of items).  The trainer defers
  * the weight gradients of a backward pass to its end and issues all layers of one shape together: one panel launch per
  * operand and one batched sdlt_gemm_bf16 (sdlt_gemm_params.batch) instead of three launches per layer. */

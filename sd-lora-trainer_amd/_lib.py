@@ -115,6 +115,7 @@ SYMBOLS = {
     "sdlt_wgrad_transpose": (i32, [vp, i64, i32, i32, vp, i64, i32, vp, vp]),
     "sdlt_wgrad_im2col_t": (i32, [vp, i64, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp]),
     "sdlt_wgrad_transpose_batch": (i32, [vp, i32, i64, i32, i32, i64, i32, vp]),
+    "sdlt_affine_grad_batch": (i32, [vp, i32, i32, i64, i32, i64, i64, i32, i32, i32, f32, i32, vp]),
     "sdlt_wgrad_im2col_t_batch": (i32, [vp, i32, i64, i32, i32, i32, i32, i32, i32, i64, i32, vp]),
     "sdlt_layernorm_affine_grad": (i32, [vp, i64, vp, i64, i32, i32, vp, vp, vp, i32, vp]),
     "sdlt_groupnorm_affine_grad": (i32, [vp, vp, vp, i32, vp]),

@@ -99,11 +99,18 @@ struct CatIn2 {
   }
 };
 
+// items != nullptr: batched launch, blockIdx.z = problem (all norm layers of one shape at the end of the backward)
 template <int MODE>
 __global__ __launch_bounds__(256) void norm_affine_grad_kernel(CatIn2 in, const bf16_t* dy, int64_t lddy, int64_t M, int HW, int C,
                                                                 const float* stats, const float* gamma, const float* beta,
-                                                                float eps, int silu, float* dgamma, float* dbeta) {
+                                                                float eps, int silu, float* dgamma, float* dbeta,
+                                                                const sdlt_affine_grad_item* items) {
   __shared__ float red[2][4][64];
+  if (items) {
+    const sdlt_affine_grad_item it = items[blockIdx.z];
+    in.x1 = (const bf16_t*)it.x1; in.x2 = (const bf16_t*)it.x2; dy = (const bf16_t*)it.dy; stats = it.stats;
+    gamma = it.gamma; beta = it.beta; dgamma = it.dgamma; dbeta = it.dbeta;
+  }
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   const int64_t per = (M + gridDim.y - 1) / gridDim.y;
@@ -222,7 +229,7 @@ extern "C" int sdlt_layernorm_affine_grad(const void* x, int64_t ldx, const void
   CatIn2 in{(const bf16_t*)x, ldx, C, nullptr, 0};
   const int cb = (C + 63) / 64;
   hipLaunchKernelGGL(norm_affine_grad_kernel<0>, dim3(cb, row_chunks(M, cb)), dim3(256), 0, s, in, (const bf16_t*)dy, lddy,
-                     (int64_t)M, 1, C, stats, nullptr, nullptr, 0.f, 0, dgamma, dbeta);
+                     (int64_t)M, 1, C, stats, nullptr, nullptr, 0.f, 0, dgamma, dbeta, (const sdlt_affine_grad_item*)nullptr);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }
@@ -237,7 +244,26 @@ extern "C" int sdlt_groupnorm_affine_grad(const sdlt_groupnorm_params* pp, float
   const int cb = (p.C + 63) / 64;
   const int64_t M = (int64_t)p.B * p.HW;
   hipLaunchKernelGGL(norm_affine_grad_kernel<1>, dim3(cb, row_chunks(M, cb)), dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy,
-                     M, p.HW, p.C, p.stats, p.gamma, p.beta, p.eps, p.silu, dgamma, dbeta);
+                     M, p.HW, p.C, p.stats, p.gamma, p.beta, p.eps, p.silu, dgamma, dbeta, (const sdlt_affine_grad_item*)nullptr);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+
+extern "C" int sdlt_affine_grad_batch(const sdlt_affine_grad_item* items_dev, int32_t n, int32_t groupnorm, int64_t ldx1, int32_t C1,
+                                      int64_t ldx2, int64_t lddy, int32_t B, int32_t HW, int32_t C, float eps, int32_t silu, void* stream) {
+  if (!items_dev || n <= 0 || n > 65535 || B <= 0 || HW <= 0 || C <= 0 || (groupnorm && (C % 32)))
+    SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_affine_grad_batch: n=%d B=%d HW=%d C=%d", n, B, HW, C);
+  CatIn2 in{nullptr, ldx1, C1 > 0 ? C1 : C, nullptr, ldx2};
+  const int cb = (C + 63) / 64;
+  const int64_t M = (int64_t)B * HW;
+  int rc = row_chunks(M, cb * n);
+  if (rc < 1) rc = 1;
+  if (groupnorm)
+    hipLaunchKernelGGL(norm_affine_grad_kernel<1>, dim3(cb, rc, n), dim3(256), 0, (hipStream_t)stream, in, (const bf16_t*)nullptr, lddy, M, HW, C,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, eps, silu, (float*)nullptr, (float*)nullptr, items_dev);
+  else
+    hipLaunchKernelGGL(norm_affine_grad_kernel<0>, dim3(cb, rc, n), dim3(256), 0, (hipStream_t)stream, in, (const bf16_t*)nullptr, lddy, M, 1, C,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f, 0, (float*)nullptr, (float*)nullptr, items_dev);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }

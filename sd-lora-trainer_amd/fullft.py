@@ -41,6 +41,7 @@ class WeightTrainer:
         # layer gradient lives in a persistent, layer-owned buffer until the next forward.
         self.defer = True
         self._jobs, self._wplan = [], None
+        self._affine_jobs, self._aplan = [], None
 
     # ------------------------------------------------------------------ registration (layer constructors)
     def add(self, name, init, kind="matrix"):
@@ -153,10 +154,40 @@ class WeightTrainer:
                                   stride=stride, ups=ups)
         ops.gemm(dyT, cols, self.view(went, "grads"))
 
+    def affine(self, *, groupnorm, x1, x2, dy, stats, gamma, beta, gent, bent, B, HW, eps=0.0, silu=False):
+        """d gamma / d beta of one norm layer (accumulated into the pre-zeroed vector region): deferred and batched like the
+        weight gradients - all LayerNorms of the 1280-wide blocks are ONE launch."""
+        dg, db = self.view(gent, "grads"), self.view(bent, "grads")
+        if self.defer:
+            if self._aplan is None:
+                self._affine_jobs.append(dict(gn=bool(groupnorm), x1=x1, x2=x2, dy=dy, stats=stats, gamma=gamma, beta=beta, dgamma=dg, dbeta=db,
+                                              B=B, HW=HW, eps=eps, silu=bool(silu)))
+            return
+        ops = self.rt.ops
+        if groupnorm:
+            ops.groupnorm_affine_grad(x1, x2, dy, stats, dg, db, B=B, HW=HW, gamma=gamma, beta=beta, eps=eps, silu=silu, accumulate=True)
+        else:
+            ops.layernorm_affine_grad(x1, dy, stats, dg, db, accumulate=True)
+
+    def _build_aplan(self, jobs):
+        from collections import OrderedDict
+        groups = OrderedDict()
+        for j in jobs:
+            key = (j["gn"], tuple(j["x1"].shape), j["x1"].stride(), None if j["x2"] is None else (tuple(j["x2"].shape), j["x2"].stride()),
+                   tuple(j["dy"].shape), j["dy"].stride(), j["B"], j["HW"], j["eps"], j["silu"])
+            groups.setdefault(key, []).append(j)
+        return [self.rt.ops.AffineGradBatch(m, self.rt.device, groupnorm=m[0]["gn"], B=m[0]["B"], HW=m[0]["HW"], eps=m[0]["eps"], silu=m[0]["silu"])
+                for m in groups.values()]
+
     def flush(self):
         """End of a backward pass: run the weight-gradient plan recorded during the first one."""
         if not self.defer:
             return
+        if self._aplan is None:
+            self._aplan = self._build_aplan(self._affine_jobs)
+            self._affine_jobs = None
+        for ab in self._aplan:
+            ab.run()
         if self._wplan is None:
             self._wplan = self._build_wplan(self._jobs)
             self._jobs = None

@@ -365,6 +365,35 @@ def wgrad_transpose(x, out, colsum_acc=None):
     return out
 
 
+class AffineGradBatch:
+    """Device table of sdlt_affine_grad_item: the d gamma / d beta of all norm layers of one shape in one launch.
+    items: dict(x1, x2|None, dy, stats, gamma, beta, dgamma, dbeta); shared: groupnorm, B, HW, eps, silu."""
+
+    def __init__(self, items, device, *, groupnorm, B, HW, eps=0.0, silu=False):
+        import struct
+        i0 = items[0]
+        for it in items:
+            for k in ("x1", "dy"):
+                _chk2(it[k])
+                assert it[k].shape == i0[k].shape and it[k].stride() == i0[k].stride()
+            assert (it["x2"] is None) == (i0["x2"] is None)
+            for k in ("stats", "dgamma", "dbeta"):
+                _chk2(it[k], F32)
+        ptr = lambda t: t.data_ptr() if t is not None else 0  # noqa: E731
+        raw = b"".join(struct.pack("8Q", ptr(it["x1"]), ptr(it["x2"]), ptr(it["dy"]), ptr(it["stats"]), ptr(it.get("gamma")), ptr(it.get("beta")),
+                                   ptr(it["dgamma"]), ptr(it["dbeta"])) for it in items)
+        self.dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self.items, self.n = items, len(items)
+        C1 = i0["x1"].shape[1]
+        self.C = C1 + (i0["x2"].shape[1] if i0["x2"] is not None else 0)
+        self.args = (int(groupnorm), _ld(i0["x1"]), C1 if i0["x2"] is not None else 0, _ld(i0["x2"]) if i0["x2"] is not None else 0, _ld(i0["dy"]),
+                     B, HW, self.C, float(eps), int(silu))
+
+    def run(self):
+        lib = _lib.load()
+        _lib.check(lib.sdlt_affine_grad_batch(_p(self.dev), self.n, *self.args, _stream()), "sdlt_affine_grad_batch")
+
+
 class WgradPanelBatch:
     """Device table of sdlt_wgrad_tr_item for the batched panel launches: items = [(x, out, colsum or None)], identical
     shapes / strides; conv = None (plain transpose) or dict(B, H, W, stride, ups) (transposed im2col)."""

@@ -484,9 +484,8 @@ class GroupNorm(_Module):
         x1, x2, B, HW = self._in
         dx = out if out is not None else self.buf("dx", B * HW, self.C)
         if self.trainer is not None:
-            tr = self.trainer
-            self.rt.ops.groupnorm_affine_grad(x1, x2, dy, self._b["stats"], tr.view(self.gent, "grads"), tr.view(self.bent, "grads"), B=B, HW=HW,
-                                              gamma=self.gamma, beta=self.beta, eps=self.eps, silu=self.silu, accumulate=True)
+            self.trainer.affine(groupnorm=True, x1=x1, x2=x2, dy=dy, stats=self._b["stats"], gamma=self.gamma, beta=self.beta, gent=self.gent,
+                                bent=self.bent, B=B, HW=HW, eps=self.eps, silu=self.silu)
         if "bstats" not in self._b:
             self._b["bstats"] = self.rt.gn_stats("bwd", B * 64)
         return self.rt.ops.groupnorm_bwd(x1, x2, dy, dx, self._b["stats"], self._b["bstats"], B=B, HW=HW,
@@ -509,8 +508,8 @@ class LayerNorm(_Module):
     def backward(self, dy, dres=None, out=None):
         dx = out if out is not None else self.buf("dx", *self._x.shape)
         if self.trainer is not None:
-            tr = self.trainer
-            self.rt.ops.layernorm_affine_grad(self._x, dy, self._b["stats"], tr.view(self.gent, "grads"), tr.view(self.bent, "grads"), accumulate=True)
+            self.trainer.affine(groupnorm=False, x1=self._x, x2=None, dy=dy, stats=self._b["stats"], gamma=self.gamma, beta=self.beta,
+                                gent=self.gent, bent=self.bent, B=1, HW=self._x.shape[0])
         return self.rt.ops.layernorm_bwd(self._x, dy, dx, self._b["stats"], gamma=self.gamma, dres=dres)
 
 

@@ -228,6 +228,19 @@ def wgrad_transpose(x, out, colsum_acc=None):
     return out
 
 
+class AffineGradBatch:
+    def __init__(self, items, device, *, groupnorm, B, HW, eps=0.0, silu=False):
+        self.items, self.kw, self.gn = items, dict(B=B, HW=HW, eps=eps, silu=silu), groupnorm
+
+    def run(self):
+        for it in self.items:
+            if self.gn:
+                groupnorm_affine_grad(it["x1"], it["x2"], it["dy"], it["stats"], it["dgamma"], it["dbeta"], gamma=it["gamma"], beta=it["beta"],
+                                      accumulate=True, **self.kw)
+            else:
+                layernorm_affine_grad(it["x1"], it["dy"], it["stats"], it["dgamma"], it["dbeta"], accumulate=True)
+
+
 class WgradPanelBatch:
     def __init__(self, items, device, conv=None):
         self.items, self.n, self.conv = items, len(items), conv
