@@ -244,25 +244,30 @@ def train_concurrent(configs, on_progress=None, runtimes=None):
     PROCESSES on one GPU time-slice instead).  The jobs share numpy's / torch's global RNG (caption dropout), like jobs started
     from one shell script share nothing but the device.  Returns [(config, output_save_dir)] in the order of `configs`."""
     use_cuda = torch.cuda.is_available() and all(str(c.device).startswith("cuda") for c in configs)
-    if use_cuda and len(configs) > 1:
+    hinted = use_cuda and len(configs) > 1
+    if hinted:
         from . import ops as _ops
         _ops.set_throughput_hint(True)       # the GEMM tile heuristics know that other jobs fill the CUs a launch leaves idle
     streams = [torch.cuda.Stream() if use_cuda else None for _ in configs]
     gens = [train(c, runtime=runtimes[i] if runtimes else None, every_step=True) for i, c in enumerate(configs)]
     results, live = [None] * len(configs), set(range(len(configs)))
-    while live:
-        for i in sorted(live):
-            try:
-                if streams[i] is not None:
-                    with torch.cuda.stream(streams[i]):
+    try:
+        while live:
+            for i in sorted(live):
+                try:
+                    if streams[i] is not None:
+                        with torch.cuda.stream(streams[i]):
+                            p = next(gens[i])
+                    else:
                         p = next(gens[i])
-                else:
-                    p = next(gens[i])
-                if p is not None and on_progress is not None:
-                    on_progress(i, p)
-            except StopIteration as e:
-                results[i] = e.value
-                live.discard(i)
+                    if p is not None and on_progress is not None:
+                        on_progress(i, p)
+                except StopIteration as e:
+                    results[i] = e.value
+                    live.discard(i)
+    finally:
+        if hinted:
+            _ops.set_throughput_hint(False)
     return results
 
 
