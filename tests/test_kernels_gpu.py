@@ -688,3 +688,20 @@ def test_gemm_throughput_hint(ops):
         close(out, ref, what="hinted conv")
     finally:
         ops.set_throughput_hint(False)
+
+
+def test_splitk_workspace_per_owner(ops):
+    """Concurrent jobs must not share split-K slabs / counters: inside `workspace_owner(key)` the workspace belongs to the key, not
+    to the stream (torch captures different jobs' graphs on the same internal stream); a split-K GEMM is correct under either."""
+    base = ops.splitk_workspace(torch.device("cuda:0"))
+    with ops.workspace_owner("job-a"):
+        wa = ops.splitk_workspace(torch.device("cuda:0"))
+        with ops.workspace_owner("job-b"):
+            wb = ops.splitk_workspace(torch.device("cuda:0"))
+        assert ops.splitk_workspace(torch.device("cuda:0"))[0].data_ptr() == wa[0].data_ptr()
+        g = torch.Generator().manual_seed(4)
+        X, W = torch.randn(128, 2048, generator=g).to(BF), (torch.randn(256, 2048, generator=g) / 45).to(BF)
+        out = ops.gemm(X.cuda(), W.cuda(), torch.zeros(128, 256, dtype=BF, device="cuda"), splitk=4)
+        close(out, E.gemm(X, W, torch.zeros(128, 256, dtype=BF)), what="split-K GEMM under an owner workspace")
+    assert len({base[0].data_ptr(), wa[0].data_ptr(), wb[0].data_ptr()}) == 3 and len({base[1].data_ptr(), wa[1].data_ptr(), wb[1].data_ptr()}) == 3
+    assert ops.splitk_workspace(torch.device("cuda:0"))[0].data_ptr() == base[0].data_ptr()
