@@ -95,7 +95,8 @@ def cpu_baseline(version, rank, sample_hw):
     ctx = torch.randn(1, 77, cfg["cross_dim"], generator=g).requires_grad_(True)
     add = None
     if cfg["addition"]:
-        add = {"text_embeds": torch.randn(1, 1280, generator=g), "time_ids": torch.tensor([[1024., 1024, 0, 0, 8. * h, 8. * h]])}
+        add = {"text_embeds": torch.randn(1, cfg["proj_class_in"] - 6 * cfg["addition_time_embed_dim"], generator=g),
+               "time_ids": torch.tensor([[1024., 1024, 0, 0, 8. * h, 8. * h]])}
     acp = L.ddpm_alphas_cumprod()
     t0 = time.time()
     noisy = L.add_noise(acp, latent, noise, t)
