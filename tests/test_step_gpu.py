@@ -236,3 +236,32 @@ def test_train_concurrent_on_gpu(tmp_path, monkeypatch):
         tot = json.load(open(os.path.join(out, "training_args.json")))["training_attributes"]["losses"]["tot_loss"]
         assert all(x == x and abs(x) < 1e4 for x in tot) and sum(tot[-5:]) / 5 < sum(tot[:5]) / 5, (i, tot)
         assert str(tmp_path / f"out{i}") in out
+
+
+def test_bench_json_contract():
+    """bench.py prints ONE JSON line with the driver's fields plus `roofline`, `cpu_baseline` and the extra `two_jobs_per_gpu`
+    object (toy topology so that the whole script takes seconds)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "tinyxl", "--res", "256", "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["unit"] == "images/s" and d["data"] == "synthetic" and d["dtype"] == "bf16" and "workload" in d["config"] and d["config"]["jobs_per_gpu"] == 1
+    assert abs(d["value"] - d["config"]["global_batch"] * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert d["two_jobs_per_gpu"]["value"] > 0 and d["two_jobs_per_gpu"]["unit"] == "images/s"
