@@ -10,7 +10,8 @@ StableDiffusion(XL)Pipeline.__call__ with an EulerDiscreteScheduler(timestep_spa
 
 PARITY UNPINNED at the diffusers boundary (0.29.2 is neither vendored nor installed).  Known answers that ARE pinned in
 tests/test_sampler_cpu.py: sigma_max of the SD scaled-linear schedule = 14.6146, trailing timesteps of 25 steps start at 999
-and end at 39, init_noise_sigma = sqrt(sigma_max^2 + 1).
+and end at 39, init_noise_sigma = sigma_max (diffusers returns max(sigmas) for "linspace"/"trailing" spacing and
+sqrt(sigma_max^2 + 1) only for "leading"; the reference sets timestep_spacing="trailing", inference.py:358-360).
 """
 import numpy as np
 import torch
@@ -31,7 +32,7 @@ def sample_latents(cfg, sd, lora, lora_scale, embeds, noise, steps, guidance_sca
     """lora: module -> (A, B) (peft layout) or None; the adapters enter with weight lora_scale (set_adapters)."""
     c, uc, pc, puc = (tuple(embeds) + (None, None))[:4]
     timesteps, sigmas = euler_trailing(steps)
-    x = noise.float() * float((sigmas.max() ** 2 + 1) ** 0.5)
+    x = noise.float() * float(sigmas.max())                 # init_noise_sigma for trailing spacing
     h, w = x.shape[-2:]
     ctx = torch.cat([uc, c], 0)
     add = None

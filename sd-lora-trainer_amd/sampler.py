@@ -8,7 +8,7 @@ VAE's job (vae.py).
 `EulerDiscrete` restates diffusers' EulerDiscreteScheduler (0.29.2, third party, parity unpinned) for the configuration the
 reference builds (`from_config(training scheduler config, timestep_spacing="trailing")`: scaled-linear betas, epsilon or
 v prediction, no Karras sigmas): sigma_t = sqrt((1 - abar_t) / abar_t), timesteps = round(arange(T, 0, -T/n)) - 1, sigmas
-interpolated at those timesteps plus a final 0, initial noise scaled by sqrt(sigma_max^2 + 1), model input x / sqrt(sigma^2 + 1),
+interpolated at those timesteps plus a final 0, initial noise scaled by sigma_max (trailing spacing), model input x / sqrt(sigma^2 + 1),
 x_next = x + d * (sigma_next - sigma) with d = eps (epsilon prediction).
 """
 import numpy as np
@@ -39,7 +39,9 @@ class EulerDiscrete:
         sig = np.interp(ts, np.arange(self.T), self.sigmas_all)
         self.timesteps = ts.astype(np.float32)
         self.sigmas = np.concatenate([sig, [0.0]]).astype(np.float32)
-        self.init_noise_sigma = float(np.sqrt(self.sigmas.max() ** 2 + 1))
+        # diffusers 0.29.2 EulerDiscreteScheduler.init_noise_sigma: max(sigmas) for timestep_spacing in ("linspace", "trailing") -
+        # the reference's configuration (inference.py:358-360); sqrt(sigma_max^2 + 1) only for "leading"
+        self.init_noise_sigma = float(self.sigmas.max())
         return self
 
     def scale_model_input(self, x, i):

@@ -1,0 +1,315 @@
+"""Parity on the REAL SDXL / SD1.5 topologies (BASELINE.json configs 2, 3, 5), not on toy models: the exact
+UNet2DConditionModel wiring and widths (SDXL: 2,567,463,684 parameters, 10-deep 1280-wide transformer stacks, 20 heads;
+SD1.5: 859,520,964), the exact CLIP-L / OpenCLIP-bigG text towers (12 x 768, 32 x 1280 + projection), rank-16 adapters on all
+560+17 / 128+22 target layers, random-init weights (no checkpoints offline), bf16-exact so both sides see the same model.
+
+  (a) ONE LoRA + textual-inversion step at a reduced latent (32 x 32; the CPU fp32 oracle takes seconds) against
+      oracle/step_ref.py (main.py:263-382): prediction, image loss, token-attention loss, LoRA gradient, token-row gradients;
+  (b) a 6-step LOSS TRAJECTORY under AdamW (both optimizers live, L1 penalty, regulariser) with injected latents / noise /
+      timesteps / captions: every step's losses against the oracle's, and the final LoRA / token-row state;
+  (c) at the FULL BASELINE size (SDXL 128 x 128 batch 1; SD1.5 64 x 64 batch 4) the size-independent properties: finite,
+      hipGraph replay == eager gradients, optimizer state advances, loss goes down on a fixed batch;
+  (d) the full fine-tune (cfg5) on the SDXL topology: EVERY parameter's gradient against oracle autograd.
+
+Stated tolerances (bf16 storage of every activation, fp32 accumulation, ~200 GEMMs deep on SDXL):
+  prediction max-abs <= 4e-2 of max|pred|; losses <= 2e-2 relative (token-attention loss 3e-2); LoRA-gradient cosine >= 0.99 and
+  relative L2 <= 8e-2; token-row gradients cosine >= 0.985; trajectory: per-step image loss <= 3e-2 relative.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NTOK = 3
+
+
+class Vocab:
+    """Token ids of a CLIP vocabulary of `size` entries with the NTOK trigger tokens appended (embedding_handler.py:157-223)."""
+
+    def __init__(self, size):
+        self.size = size
+        self.bos, self.eos = (49406, 49407) if size >= 49408 else (size - 2, size - 1)
+        self.train_ids = [size + i for i in range(NTOK)]
+
+
+REAL = Vocab(49408)
+
+
+def _cos_rel(a, b):
+    a, b = a.reshape(-1).double().cpu(), b.reshape(-1).double().cpu()
+    return float(a @ b / (a.norm() * b.norm() + 1e-30)), float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _bf16_exact(sd):
+    return {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+
+
+_CACHE = {}
+
+
+def _unet_state(version):
+    """bf16-exact random UNet weights of the real topology, built once per session (2.57 G normal draws take ~40 s)."""
+    from oracle import unet_ref as U
+    if version not in _CACHE:
+        _CACHE.clear()            # one 10 GB state at a time
+        _CACHE[version] = _bf16_exact(U.init_unet_state(U.CONFIGS[version], seed=0))
+    return _CACHE[version]
+
+
+def _hf_clip(kind, seed, legacy_eos=None):
+    """Hugging Face CLIP text tower of the real size with the 3 new token rows appended (embedding_handler.py:157-223)."""
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
+    from sd_lora_trainer_amd import topology
+    c = topology.CLIP_CONFIGS[kind]
+    vc = Vocab(c["vocab"])
+    legacy_eos = bool(c["proj"]) if legacy_eos is None else legacy_eos
+    torch.manual_seed(seed)
+    # SDXL's text_encoder_2 ships the legacy eos_token_id = 2 -> pooled output at argmax(input_ids) (transformers CLIPTextTransformer)
+    cfg = CLIPTextConfig(vocab_size=c["vocab"] + NTOK, hidden_size=c["width"], intermediate_size=c["mlp"], num_hidden_layers=c["layers"],
+                         num_attention_heads=c["heads"], max_position_embeddings=77, hidden_act=c["act"], projection_dim=c["proj"] or 768,
+                         eos_token_id=2 if legacy_eos else vc.eos, bos_token_id=vc.bos, pad_token_id=1)
+    m = (CLIPTextModelWithProjection if c["proj"] else CLIPTextModel)(cfg).eval()
+    for p in m.parameters():
+        if p.dim() == 1:
+            p.data.add_(0.05 * torch.randn_like(p))
+        p.data = p.data.to(torch.bfloat16).float()
+    return m
+
+
+def _captions(B, seed, vc=REAL):
+    g = torch.Generator().manual_seed(seed)
+    lists = []
+    for b in range(B):
+        words = torch.randint(3, vc.bos - 1, (7,), generator=g).tolist()
+        if b % 4 == 3:
+            lists.append([vc.bos] + words + [vc.eos])                 # a caption without the trigger tokens (loss.py:40-43)
+        else:
+            lists.append([vc.bos] + words[:3] + vc.train_ids + words[3:] + [vc.eos])
+    ids = torch.full((B, 77), vc.eos, dtype=torch.int64)
+    for b, l in enumerate(lists):
+        ids[b, :len(l)] = torch.tensor(l)
+    return lists, ids
+
+
+def _batch(cfg, B, h, seed, tvals, vc=REAL):
+    g = torch.Generator().manual_seed(seed)
+    latent = torch.randn(B, 4, h, h, generator=g) * cfg["scaling_factor"]
+    noise = torch.randn(B, 4, h, h, generator=g)
+    mask = (torch.rand(B, 1, h, h, generator=g) * 0.95 + 0.05).repeat(1, 4, 1, 1).contiguous()
+    t = torch.tensor(tvals[:B])
+    lists, ids = _captions(B, seed, vc)
+    return dict(latent=latent, noise=noise, mask=mask, t=t, lists=lists, ids=ids)
+
+
+def _build_product(version, B, h, sd, lora, hf, rank, kinds=None, device="cuda:0", ops=None, act_dtype=torch.bfloat16, **step_kw):
+    import sd_lora_trainer_amd.clip as clip_mod
+    import sd_lora_trainer_amd.step as step_mod
+    import sd_lora_trainer_amd.unet as unet_mod
+    from sd_lora_trainer_amd import topology
+    xl = topology.CONFIGS[version]["addition"]
+    rt = unet_mod.Runtime(device, B, act_dtype=act_dtype, ops=ops)
+    unet = unet_mod.UNet(rt, topology.CONFIGS[version], sd, lora_rank=rank)
+    unet.arena.load(lora)
+    text = None
+    if hf is not None:
+        kinds = kinds or (["clip_l", "clip_g"] if xl else ["clip_l"])
+        encs = []
+        for i, (m, kd) in enumerate(zip(hf, kinds)):
+            c = topology.CLIP_CONFIGS[kd]
+            csd = {k: v.detach().clone() for k, v in m.state_dict().items()}      # (a CPU runtime would alias the oracle's tables)
+            encs.append(clip_mod.ClipTextEncoder(rt, f"te{i + 1}", csd, heads=c["heads"], act=c["act"], mode="penultimate" if xl else "last",
+                                                 with_projection=bool(c["proj"]), n_train=NTOK))
+        text = step_mod.TextStack(rt, encs, pool_mode="argmax" if xl else "first_eos", eos_token_id=Vocab(topology.CLIP_CONFIGS[kinds[0]]["vocab"]).eos)
+    ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), text=text, n_tokens=NTOK, **step_kw)
+    return rt, unet, ts
+
+
+def _set(ts, b, xl, h, n_enc):
+    dev = ts.rt.device
+    tid = torch.tensor([[1024., 1024, 0, 0, 8. * h, 8. * h]] * b["latent"].shape[0]) if xl else None
+    ts.set_batch(b["latent"].to(dev), b["noise"].to(dev), b["t"].to(dev), b["mask"].to(dev), time_ids=tid.to(dev) if xl else None,
+                 ids=[b["ids"]] * n_enc, caption_token_lists=b["lists"])
+    return tid
+
+
+TOL_BF16 = dict(pred=4e-2, loss=3e-2, ta=5e-2, reg=5e-2, cos=0.99, rel=8e-2, rows_cos=0.985, disp_cos=0.9, rows_final=2e-2)
+TOL_FP32 = dict(pred=2e-3, loss=1e-3, ta=2e-3, reg=2e-3, cos=0.9999, rel=5e-3, rows_cos=0.9999, disp_cos=0.99, rows_final=1e-3)
+
+
+def run_step_and_trajectory(version, B, h, sd, kinds, *, device, ops=None, act_dtype=torch.bfloat16, tol=TOL_BF16, rank=16, n_steps=6):
+    """(a) + (b) for one topology; shared with the CPU test of the same flow on the toy topologies (op emulation, fp32)."""
+    from oracle import step_ref as R
+    from oracle import unet_ref as U
+    from sd_lora_trainer_amd import topology
+    cfg = U.CONFIGS[version]
+    xl = cfg["addition"]
+    w_ta = 2e-2            # token-attention weight raised from 3e-7 so that its gradient is visible in the comparison
+    lr, lr_ti = 4e-4, 1e-3
+    vc = Vocab(topology.CLIP_CONFIGS[kinds[0]]["vocab"])
+    lora = U.init_lora(cfg, rank, seed=1, b_std=0.02)
+    hf = [_hf_clip(k, 11 + i) for i, k in enumerate(kinds)]
+    batches = [_batch(cfg, B, h, 3, [10, 900, 500, 999], vc), _batch(cfg, B, h, 4, [700, 50, 300, 850], vc)]
+    cuda = torch.device(device).type == "cuda"
+    sync = torch.cuda.synchronize if cuda else (lambda: None)
+
+    rt, unet, ts = _build_product(version, B, h, sd, lora, hf, rank, kinds=kinds, device=device, ops=ops, act_dtype=act_dtype, snr_gamma=5.0,
+                                  l1_penalty=0.03, weight_decay=0.004, token_attention_loss_w=w_ta, ti_std_loss_w=0.01)
+    ref = R.RefTrainer(cfg, sd, lora, text_models=hf, n_tokens=NTOK, train_ids=vc.train_ids, snr_gamma=5.0, l1_penalty=0.03,
+                       weight_decay=0.004, token_attention_loss_w=w_ta, ti_std_loss_w=0.01)
+    names = list(lora)
+    n_enc = len(hf)
+    traj = []
+    for step in range(n_steps):
+        b = batches[step % 2]
+        tid = _set(ts, b, xl, h, n_enc)
+        o = ref.step(b["latent"], b["noise"], b["t"], b["mask"], lr=lr, lr_ti=lr_ti, ids=b["ids"], caption_token_lists=b["lists"], time_ids=tid)
+        if step == 0:
+            # eager first step: everything the oracle exposes
+            pred = ts.forward_backward().float().cpu().reshape(B, h, h, 4).permute(0, 3, 1, 2)
+            sync()
+            assert torch.isfinite(pred).all()
+            err = float((pred - o["pred"]).abs().max()) / float(o["pred"].abs().max())
+            assert err <= tol["pred"], f"prediction error {err}"
+            got = unet.arena.export("grads")
+            cos, rel = _cos_rel(torch.cat([t.reshape(-1) for k in names for t in got[k]]), o["lora_grads"])
+            assert cos >= tol["cos"] and rel <= tol["rel"], f"LoRA grads cos {cos} rel {rel}"
+            for got_r, ref_r in zip(ts.ti.grad_rows, o["row_grads"]):
+                cos, rel = _cos_rel(got_r, ref_r)
+                assert cos >= tol["rows_cos"], f"token-row grads cos {cos} rel {rel}"
+            ts.sync_gradients()
+            ts.set_hyper(lr, lr_ti)
+            ts.optimizer_step()
+        else:
+            if step == 1 and cuda:
+                ts.capture(warmup=1)            # from here on: hipGraph replays, as train() runs them
+            ts.run(lr, lr_ti=lr_ti)
+        sync()
+        traj.append((float(ts.loss), o["img_loss"], float(ts.ta.loss), o["token_attention_loss"], float(ts.ti.reg_loss), o["reg"],
+                     float(ts.l1_sum) / unet.arena.n, o["l1"]))
+    for i, (l, lo, ta, tao, rg, rgo, l1, l1o) in enumerate(traj):
+        assert abs(l - lo) <= tol["loss"] * abs(lo), f"step {i}: image loss {l} vs oracle {lo}; trajectory {traj}"
+        assert abs(ta - tao) <= tol["ta"] * abs(tao), f"step {i}: token-attention loss {ta} vs {tao}; {traj}"
+        assert abs(rg - rgo) <= tol["reg"] * abs(rgo) + 1e-7, f"step {i}: token regulariser {rg} vs {rgo}; {traj}"
+        assert abs(l1 - l1o) <= 1e-3 * abs(l1o), f"step {i}: L1 norm {l1} vs {l1o}"
+    # training moved the loss of the revisited batches (so the comparison above is not a comparison of constants)
+    assert traj[n_steps - 2][1] < traj[0][1] and traj[n_steps - 1][1] < traj[1][1], traj
+    # final state: the LoRA displacement and the token rows agree with the oracle's
+    start = torch.cat([t.reshape(-1) for k in names for t in lora[k]])
+    got = unet.arena.export("params")
+    cos, rel = _cos_rel(torch.cat([t.reshape(-1) for k in names for t in got[k]]) - start, ref.lora_flat() - start)
+    assert cos >= tol["disp_cos"], f"LoRA displacement after {n_steps} AdamW steps: cos {cos} rel {rel}"
+    for rows, table in zip(ts.ti.rows, ref.tables):
+        cos, rel = _cos_rel(rows, table.detach()[-NTOK:])
+        assert cos >= 0.999 and rel <= tol["rows_final"], f"token rows after {n_steps} steps: cos {cos} rel {rel}"
+    return traj
+
+
+@pytest.mark.parametrize("version,B", [("sdxl", 1), ("sd15", 4)])
+def test_real_topology_step_and_trajectory(version, B):
+    """(a) + (b): first step in detail, then 5 more optimizer steps; batches alternate between two injected ones so that the
+    effect of training on a revisited batch is part of what is compared."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import unet_ref as U
+    kinds = ["clip_l", "clip_g"] if U.CONFIGS[version]["addition"] else ["clip_l"]
+    run_step_and_trajectory(version, B, 32, _unet_state(version), kinds, device="cuda:0")
+
+
+@pytest.mark.parametrize("version,B,h", [("sdxl", 1, 128), ("sd15", 4, 64)])
+def test_full_size_properties(version, B, h):
+    """(c): the BASELINE configs at their full size - no oracle (a CPU step would take minutes), size-independent properties."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import unet_ref as U
+    cfg = U.CONFIGS[version]
+    xl = cfg["addition"]
+    rank = 16
+    sd = _unet_state(version)
+    lora = U.init_lora(cfg, rank, seed=1, b_std=0.02)
+    hf = [_hf_clip("clip_l", 11), _hf_clip("clip_g", 12)] if xl else [_hf_clip("clip_l", 11)]
+    rt, unet, ts = _build_product(version, B, h, sd, lora, hf, rank, token_attention_loss_w=3e-7)
+    b = _batch(cfg, B, h, 3, [10, 900, 500, 999])
+    _set(ts, b, xl, h, len(hf))
+    pred = ts.forward_backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(pred).all() and torch.isfinite(unet.arena.grads).all() and float(unet.arena.grads.abs().max()) > 0
+    assert all(torch.isfinite(r).all() and float(r.abs().max()) > 0 for r in ts.ti.grad_rows)
+    g_eager, rows_eager, loss_eager = unet.arena.grads.clone(), [r.clone() for r in ts.ti.grad_rows], float(ts.loss)
+    ts.capture(warmup=1)
+    p0, rows0 = unet.arena.params.clone(), ts.ti.params.clone()
+    assert float(unet.arena.m.abs().max()) == 0.0 and ts.opt_step == 0           # capture is not training
+    ts.run(1e-3, lr_ti=1e-3)
+    torch.cuda.synchronize()
+    assert abs(float(ts.loss) - loss_eager) <= 2e-3 * abs(loss_eager), (float(ts.loss), loss_eager)
+    cos, rel = _cos_rel(unet.arena.grads, g_eager)
+    assert cos >= 0.995 and rel <= 5e-2, f"graph replay vs eager LoRA gradients: cos {cos} rel {rel}"
+    for a, e in zip(ts.ti.grad_rows, rows_eager):
+        cos, rel = _cos_rel(a, e)
+        assert cos >= 0.99, f"graph replay vs eager token-row gradients: cos {cos} rel {rel}"
+    # optimizer state advanced: moments non-zero, parameters moved by ~lr, L1 norm read-out equals mean|p| of the arena
+    assert ts.opt_step == 1 and float(unet.arena.m.abs().max()) > 0 and float(unet.arena.v.abs().max()) > 0
+    d = (unet.arena.params - p0).abs()
+    assert 0 < float(d.max()) <= 1.2e-3 and float(d.mean()) > 1e-4
+    assert float((ts.ti.params - rows0).abs().max()) > 0
+    assert abs(float(ts.l1_sum) - float(p0.abs().sum())) <= 1e-3 * float(p0.abs().sum())
+    losses = [ts.total_loss()]
+    for i in range(7):
+        ts.run(1e-3, lr_ti=1e-3)
+        losses.append(ts.total_loss())
+    assert all(math.isfinite(x) for x in losses) and losses[-1] < losses[0], losses
+    # frozen token rows (ti lr == 0): bit-identical rows, LoRA still trains
+    rows1 = ts.ti.params.clone()
+    ts.run(1e-3, lr_ti=0.0)
+    torch.cuda.synchronize()
+    assert torch.equal(rows1, ts.ti.params)
+
+
+def test_fullft_real_sdxl_topology():
+    """(d) cfg5's model: full fine-tune of the real SDXL UNet, batch 2 at a 32 x 32 latent - the gradient of every one of the
+    2,567,463,684 parameters against autograd through the fp32 oracle; then graph replays train."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import unet_ref as U
+    from sd_lora_trainer_amd import fullft, topology
+    import sd_lora_trainer_amd.step as S
+    import sd_lora_trainer_amd.unet as M
+    from tests.test_fullft_cpu import _inputs, oracle_grads
+    version, B, h = "sdxl", 2, 32
+    cfg = U.CONFIGS[version]
+    sd = _unet_state(version)
+    latent, noise, mask, t, ctx, pooled, tid, add = _inputs(cfg, B, h)
+    pred_o, loss_o, grads_o = oracle_grads(cfg, sd, latent, noise, t, mask, ctx, add)
+    rt = M.Runtime("cuda:0", B)
+    tr = fullft.WeightTrainer(rt)
+    unet = M.UNet(rt, topology.CONFIGS[version], sd, trainer=tr)
+    assert tr.n >= 2567463684
+    ts = S.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0)
+    dv = lambda x: x.cuda() if x is not None else None  # noqa: E731
+    ts.set_batch(dv(latent), dv(noise), dv(t), dv(mask), dv(ctx), dv(pooled), dv(tid))
+    pred = ts.forward_backward().float().cpu().reshape(B, h, h, 4).permute(0, 3, 1, 2)
+    torch.cuda.synchronize()
+    assert float((pred - pred_o).abs().max()) <= 4e-2 * float(pred_o.abs().max())
+    assert abs(float(ts.loss) - loss_o) <= 2e-2 * abs(loss_o)
+    got = tr.export("grads")
+    names = list(grads_o)
+    num = den_a = den_b = dif = 0.0
+    worst = (1.0, None)
+    for k in names:            # streamed: the flat concatenation would be another 2 x 10 GB
+        a, b_ = got[k].reshape(-1).double(), grads_o[k].reshape(-1).double()
+        ab, aa, bb = float(a @ b_), float(a @ a), float(b_ @ b_)
+        num, den_a, den_b, dif = num + ab, den_a + aa, den_b + bb, dif + float((a - b_) @ (a - b_))
+        if b_.numel() >= 64 and bb > 0:
+            c = ab / math.sqrt(aa * bb + 1e-300)
+            worst = min(worst, (c, k))
+    cos, rel = num / math.sqrt(den_a * den_b), math.sqrt(dif / den_b)
+    assert cos >= 0.99 and rel <= 8e-2, f"all-parameter gradient: cos {cos} rel {rel}"
+    assert worst[0] >= 0.95, worst
+    del got, grads_o
+    ts.capture(warmup=1)
+    losses = []
+    for i in range(6):
+        ts.run(2e-5)
+        losses.append(float(ts.loss))
+    assert all(x == x for x in losses) and losses[-1] < losses[0], losses

@@ -32,7 +32,7 @@ def test_euler_trailing_known_answers():
     assert s.timesteps[0] == 999 and s.timesteps[-1] == 39 and len(s.timesteps) == 25 and len(s.sigmas) == 26
     assert float(s.sigmas[0]) == pytest.approx(14.6146, abs=2e-4)    # sigma_max of the SD scaled-linear schedule
     assert s.sigmas[-1] == 0.0 and all(a > b for a, b in zip(s.sigmas, s.sigmas[1:]))
-    assert s.init_noise_sigma == pytest.approx(math.sqrt(14.6146 ** 2 + 1), abs=2e-4)
+    assert s.init_noise_sigma == pytest.approx(14.6146, abs=2e-4)     # trailing spacing: max(sigmas), NOT sqrt(sigma_max^2 + 1)
     ts, sig = SR.euler_trailing(25)
     assert list(ts) == [int(t) for t in s.timesteps]
     torch.testing.assert_close(torch.tensor(sig, dtype=torch.float32), torch.tensor(s.sigmas), rtol=1e-6, atol=0)
