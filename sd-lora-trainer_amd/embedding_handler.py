@@ -19,17 +19,27 @@ class TokenEmbeddingsHandler:
         self.embeddings_settings = {}
 
     def initialize_new_tokens(self, seed=0):
-        """rows = randn * (mean per-row std of the pretrained table) / (mean per-row std of the draw)."""
+        """rows = randn * sigma_bar / (mean per-row std of the draw), sigma_bar = mean per-row std of the RESIZED table - the
+        reference takes it after `resize_token_embeddings`, i.e. over all rows incl. the not yet initialised new ones
+        (embedding_handler.py:183, 195-197; 3 rows of 49,411).  The draw itself is `torch.randn` after `seed_everything(seed)`
+        (:172, 210); the reference's global generator has by then also been advanced by transformers' resize initialisation, which
+        depends on the transformers version, so the statistics are what is pinned (tests/golden/token_init.pt), not the bits.
+        Afterwards the regulariser's target statistics are taken over the whole table, as `ConditioningRegularizer` is built after
+        the initialisation (main.py:92-105, loss.py:190-193)."""
         g = torch.Generator().manual_seed(seed)            # seed_everything(seed) in the reference (:172)
         rows = []
+        n = len(self.train_ids)
         for idx, e in enumerate(self.encoders):
-            n = len(self.train_ids)
-            std_token_embedding = e.table[: e.V - n].float().std(dim=1).mean()
+            std_token_embedding = e.table.float().std(dim=1).mean()
             self.embeddings_settings[f"std_token_embedding_{idx}"] = std_token_embedding
             init = torch.randn(n, e.D, generator=g)
             init = init * float(std_token_embedding) / init.std(dim=1).mean()
             rows.append(init)
+            inu = torch.ones(e.V, dtype=torch.bool)
+            inu[self.train_ids] = False
+            self.embeddings_settings[f"index_no_updates_{idx}"] = inu
         self.ti.load_rows(rows)
+        self.ti.set_reference_stats(whole_table=True)
         return rows
 
     def get_trainable_embeddings(self):

@@ -27,16 +27,25 @@ class TiState:
             self.rows.append(r)
             self.grad_rows.append(self.grads[off:off + sz].view(n_tok, e.D))
             sh.append((off, n_tok, e.D, e.D, e.table[e.V - n_tok:], None))
-            # DistributionLoss statistics of the PRETRAINED rows (loss.py:263-265)
-            pre = e.table[: e.V - n_tok].float()
-            stds = pre.std(-1)
-            self.stats.append((float(stds.mean()), float(stds.std() ** 2 / stds.mean())))
             self._pretrained = getattr(self, "_pretrained", []) + [(e, e.V - n_tok)]
             off += sz
+        self.set_reference_stats(whole_table=False)
         self._plan = rt.ops.ShadowPlan(sh, rt.device)
         self.std_loss_w = std_loss_w
         self.reg_loss = rt.zeros(1, dtype=F32)
         self.hyper = rt.zeros(16, dtype=F32)
+
+    def set_reference_stats(self, whole_table):
+        """DistributionLoss statistics (loss.py:263-265): mean of the per-row std and its normalised variance, over the pretrained
+        rows - or over the WHOLE table incl. the freshly initialised new rows, which is what the reference's regulariser sees
+        (it is constructed after `initialize_new_tokens`, main.py:92-105; TokenEmbeddingsHandler.initialize_new_tokens calls this)."""
+        self.stats, self._target_cov = [], None
+        pre = []
+        for e, nv in self._pretrained:
+            stds = (e.table if whole_table else e.table[:nv]).float().std(-1)
+            self.stats.append((float(stds.mean()), float(stds.std() ** 2 / stds.mean())))
+            pre.append((e, e.V if whole_table else nv))
+        self._cov_rows = pre
 
     def refresh_tables(self):
         """fp32 master rows -> the bf16 embedding tables the encoders gather from."""
@@ -62,7 +71,7 @@ class TiState:
         torch ops (the target covariance of each table is built once, lazily)."""
         if getattr(self, "_target_cov", None) is None:
             self._target_cov = []
-            for e, nv in self._pretrained:
+            for e, nv in self._cov_rows:
                 t = e.table[:nv].float()
                 adj = t - t.mean(0)
                 self._target_cov.append(adj.T @ adj / (nv - 1))

@@ -50,11 +50,24 @@ _CACHE = {}
 
 
 def _unet_state(version):
-    """bf16-exact random UNet weights of the real topology, built once per session (2.57 G normal draws take ~40 s)."""
+    """bf16-exact random UNet weights of the real topology (fan-in scaled like oracle.unet_ref.init_unet_state), built once per
+    version: drawn on the GPU when there is one (2.57 G normal draws take ~40 s on one host core) and handed to both sides."""
     from oracle import unet_ref as U
     if version not in _CACHE:
         _CACHE.clear()            # one 10 GB state at a time
-        _CACHE[version] = _bf16_exact(U.init_unet_state(U.CONFIGS[version], seed=0))
+        if torch.cuda.is_available():
+            g = torch.Generator(device="cuda").manual_seed(0)
+            sd = {}
+            for n, shp in U.param_shapes(U.CONFIGS[version]).items():
+                t = torch.randn(shp, generator=g, device="cuda", dtype=torch.float32)
+                is_norm = (".norm" in n or n.startswith("conv_norm_out")) and len(shp) == 1
+                t = t * (1.0 / math.sqrt(math.prod(shp[1:])) if len(shp) >= 2 else 0.02)
+                if is_norm and n.endswith(".weight"):
+                    t = 1.0 + t
+                sd[n] = t.to(torch.bfloat16).float().cpu()
+            _CACHE[version] = sd
+        else:
+            _CACHE[version] = _bf16_exact(U.init_unet_state(U.CONFIGS[version], seed=0))
     return _CACHE[version]
 
 
@@ -206,8 +219,7 @@ def run_step_and_trajectory(version, B, h, sd, kinds, *, device, ops=None, act_d
     return traj
 
 
-@pytest.mark.parametrize("version,B", [("sdxl", 1), ("sd15", 4)])
-def test_real_topology_step_and_trajectory(version, B):
+def _case_step_and_trajectory(version, B):
     """(a) + (b): first step in detail, then 5 more optimizer steps; batches alternate between two injected ones so that the
     effect of training on a revisited batch is part of what is compared."""
     if not torch.cuda.is_available():
@@ -217,8 +229,7 @@ def test_real_topology_step_and_trajectory(version, B):
     run_step_and_trajectory(version, B, 32, _unet_state(version), kinds, device="cuda:0")
 
 
-@pytest.mark.parametrize("version,B,h", [("sdxl", 1, 128), ("sd15", 4, 64)])
-def test_full_size_properties(version, B, h):
+def _case_full_size_properties(version, B, h):
     """(c): the BASELINE configs at their full size - no oracle (a CPU step would take minutes), size-independent properties."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
@@ -266,7 +277,7 @@ def test_full_size_properties(version, B, h):
     assert torch.equal(rows1, ts.ti.params)
 
 
-def test_fullft_real_sdxl_topology():
+def _case_fullft_real_sdxl_topology():
     """(d) cfg5's model: full fine-tune of the real SDXL UNet, batch 2 at a 32 x 32 latent - the gradient of every one of the
     2,567,463,684 parameters against autograd through the fp32 oracle; then graph replays train."""
     if not torch.cuda.is_available():
@@ -313,3 +324,18 @@ def test_fullft_real_sdxl_topology():
         ts.run(2e-5)
         losses.append(float(ts.loss))
     assert all(x == x for x in losses) and losses[-1] < losses[0], losses
+
+
+# Ordered so that each 10 GB weight state is built once: all SDXL cases, then all SD1.5 cases.
+@pytest.mark.parametrize("case", ["sdxl-step-trajectory", "sdxl-full-size", "sdxl-fullft-gradients", "sd15-step-trajectory", "sd15-full-size"])
+def test_real_topology(case):
+    if case == "sdxl-step-trajectory":
+        _case_step_and_trajectory("sdxl", 1)
+    elif case == "sdxl-full-size":
+        _case_full_size_properties("sdxl", 1, 128)
+    elif case == "sdxl-fullft-gradients":
+        _case_fullft_real_sdxl_topology()
+    elif case == "sd15-step-trajectory":
+        _case_step_and_trajectory("sd15", 4)
+    else:
+        _case_full_size_properties("sd15", 4, 64)
