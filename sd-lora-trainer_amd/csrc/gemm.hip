@@ -60,8 +60,9 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* tsh = smem + (S == 1 ? 2 : S) * STAGE;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it in an SGPR
   const int wm = wave & 1, wn = wave >> 1;
+  const int frow = lane & 15, fk = lane >> 4;
   // XCD-aware remap: consecutive tile ids (sharing an X panel) land on the same XCD/L2.
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   int bid = blockIdx.x;
@@ -161,8 +162,15 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   if (R16) aptr += (size_t)lgrp * (R16 * 16) * p.ld_adown;
 
   const int nk1 = p.K / BK, nk2 = p.K2 / BK, nk = nk1 + nk2;
-  constexpr int AI = R16 ? ((2 * R16 + NW - 1) / NW) : 0;   // LoRA-down DMA instructions per wave and stage
-  constexpr int LPS = XI + WI + AI;                         // DMA instructions per wave and stage
+  // LoRA-down tile: 2*R16 pieces per stage.  Fewer pieces than waves (rank pad 16 in an 8-wave tile: 2 pieces): only the first
+  // 2*R16 waves move one each and run with their own DMA count - the counted vmcnt below is an immediate, so the two kinds
+  // of waves take different (wave-uniform) branches.  (Every wave re-loading a piece, as before, added 8 KB to the 24 KB of
+  // a 64x128 stage on the texture-address path that bounds the K loop.)
+  constexpr bool A_FEW = R16 && 2 * R16 < NW;
+  constexpr int AI = R16 ? (A_FEW ? 1 : (2 * R16 + NW - 1) / NW) : 0;   // LoRA-down DMA instructions per (loading) wave and stage
+  constexpr int LPS = XI + WI + AI;                         // DMA instructions per wave and stage (a_loader waves)
+  constexpr int LPS0 = XI + WI;                             // ... of the waves that move no LoRA-down piece
+  const bool a_loader = !A_FEW || wave < 2 * R16;
 
   // this workgroup's share of the K steps (split-K: contiguous ranges of the combined segment-1 + segment-2 steps)
   const int kbeg = splitk == 1 ? 0 : nk * split / splitk, kend = splitk == 1 ? nk : nk * (split + 1) / splitk;   // 32-bit: nk < 2^15
@@ -225,10 +233,14 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
       // (LoRA excludes a second segment.)  Every wave moves the SAME number of pieces per stage (the counted vmcnt of the
       // DMA path relies on it); when there are fewer pieces than waves some waves re-load a piece - identical bytes to
       // identical LDS addresses.
+      if constexpr (A_FEW) {
+        if (a_loader) f(XI + WI, aptr + (size_t)(wave * 8 + srow) * p.ld_adown + k0, XT + WT + wave * 1024);
+      } else {
 #pragma unroll
-      for (int j = 0; j < AI; ++j) {
-        int piece = (wave + NW * j) % (R16 * 2);
-        f(XI + WI + j, aptr + (size_t)(piece * 8 + srow) * p.ld_adown + k0, XT + WT + piece * 1024);
+        for (int j = 0; j < AI; ++j) {
+          int piece = (wave + NW * j) % (R16 * 2);
+          f(XI + WI + j, aptr + (size_t)(piece * 8 + srow) * p.ld_adown + k0, XT + WT + piece * 1024);
+        }
       }
     }
   };
@@ -239,6 +251,64 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
     for_each_piece(kt, [&](int, const bf16_t* src, int off) { glds16(src, base + off); });
 #endif
   };
+
+  // ---------------- epilogue operands, fetched BEFORE the K loop ----------------
+  // LoRA-up fragments, bias and (staged epilogue) the residual tile used to be loaded where they are consumed: three dependent
+  // global-load latencies after the last MFMA of every launch (~1 us each; the K loop of a 1024 x 1280 x 1280 projection is
+  // ~7 us).  They are issued here instead - older than every DMA stage, so the counted vmcnt waits of the ring still hold
+  // (loads retire in order) - and are long complete when the loop ends.
+  constexpr int NUPMAX = KG ? KG : (R16 ? R16 : 1);
+  s16x4 bupf[NUPMAX][NI];
+  if (R16) {
+    const int nup_ = KG ? p.K / p.lora_group_k : R16;
+#pragma unroll
+    for (int j = 0; j < NUPMAX; ++j)
+#pragma unroll
+      for (int a = 0; a < NI; ++a) {
+        const int n = n0 + wn * NI * 16 + a * 16 + frow;
+        const int nc = n < p.N ? n : p.N - 1;
+        bupf[j][a] = (s16x4){0, 0, 0, 0};
+        if (j < nup_) bupf[j][a] = *(const s16x4*)((const bf16_t*)pBup + (size_t)nc * p.ld_bup + j * 16 + fk * 4);
+      }
+  }
+  f32x4 biasf[NI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a) {
+    const int n = n0 + wn * NI * 16 + a * 16 + fk * 4;
+    biasf[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (pBias) {
+      if (n + 3 < p.N) biasf[a] = *(const f32x4*)(pBias + n);
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.N) biasf[a][r] = pBias[n + r];
+      }
+    }
+  }
+  // staged (bf16, full-row-segment) epilogue: geometry and the residual tile in the store loop's own layout
+  constexpr int CST = BN + 4;                                    // fp32 elements per staged row (+4: bank spread)
+  constexpr int REGION = (S == 1 ? 2 : S) * STAGE;
+  constexpr int CROWS = BM * CST * 4 <= REGION ? BM : (BM / 2 * CST * 4 <= REGION ? BM / 2 : BM / 4);
+  static_assert(CROWS * CST * 4 <= REGION && CROWS % 16 == 0, "staged epilogue does not fit the staging LDS");
+  constexpr int NCH = BN / 8;                                    // 16-byte output chunks per row
+  constexpr int QPP = CROWS * NCH / NTHR;                        // store-loop iterations per thread and pass
+  constexpr int RIT = (BM / CROWS) * QPP;
+  constexpr bool RPRE = RIT <= 4 && QPP * NTHR == CROWS * NCH;   // residual prefetch: at most 4 x 16 B per lane
+  const bool vec_ok = ((p.ldc & 3) == 0) && (p.R == nullptr || (p.ldr & 3) == 0) &&
+                      (p.rowbias == nullptr || (p.ld_rowbias & 3) == 0);
+  const bool staged = (long)p.M * p.N >= (1l << 20) && !p.out_fp32 && pCt == nullptr && vec_ok && (p.ldc & 7) == 0 && (p.N & 7) == 0 &&
+                      (p.R == nullptr || (p.ldr & 7) == 0) && (((uintptr_t)pC | (uintptr_t)p.R) & 15) == 0;
+  uint4 rpre[RPRE ? RIT : 1];
+  const bool rpre_on = RPRE && staged && p.R != nullptr && splitk == 1;   // (split-K: only the last arriver of a tile would use it)
+  if (rpre_on) {
+#pragma unroll
+    for (int t = 0; t < RIT; ++t) {
+      const int it = tid + (t % QPP) * NTHR, row = it / NCH, ch = it - row * NCH;
+      const int m = m0 + (t / QPP) * CROWS + row, n = n0 + ch * 8;
+      rpre[t] = (uint4){0u, 0u, 0u, 0u};
+      if (m < p.M && n < p.N) rpre[t] = *(const uint4*)((const bf16_t*)p.R + (size_t)m * p.ldr + n);
+    }
+  }
 
   // ---------------- accumulators ----------------
   f32x4 acc[NI][MI];
@@ -254,7 +324,6 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
 #pragma unroll
     for (int b = 0; b < TMI; ++b) tacc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int frow = lane & 15, fk = lane >> 4;
   // byte offset of this lane's fragment chunk inside a 16-row block, for kk = 0/1
   const int foff0 = frow * ROW_BYTES + (((0 * 4 + fk) ^ (frow & 7)) << 4);
   const int foff1 = frow * ROW_BYTES + (((1 * 4 + fk) ^ (frow & 7)) << 4);
@@ -362,7 +431,8 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   int kt = kbeg;
   int rd = 0, wr = S - 1;                           // ring slot being consumed / being filled
   for (; kt + S - 1 < kend; ++kt) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * LPS) : "memory");
+    if (a_loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * LPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * LPS0) : "memory");
     __builtin_amdgcn_s_barrier();   // stage kt visible to all waves; everyone is done reading stage kt-1's buffer
     asm volatile("" ::: "memory");
     if (early) stage(kt + S - 1, wr);
@@ -375,9 +445,13 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   // Drain: the last (up to) S-1 stages are in flight, nothing left to issue.
   for (; kt < kend; ++kt) {
     const int ahead = kend - 1 - kt;                // stages issued after stage kt
-    if (S >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-    else if (S >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (S >= 4 && ahead >= 2) {
+      if (a_loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS0) : "memory");
+    } else if (S >= 3 && ahead >= 1) {
+      if (a_loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS0) : "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     compute(smem + rd * STAGE, kt);
@@ -497,12 +571,9 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
       }
 #pragma unroll
       for (int a = 0; a < NI; ++a) {
-        int n = n0 + wn * NI * 16 + a * 16 + frow;
-        int nc = n < p.N ? n : p.N - 1;
-        s16x4 bf = *(const s16x4*)((const bf16_t*)pBup + (size_t)nc * p.ld_bup + j * 16 + fk * 4);
 #pragma unroll
         for (int b = 0; b < MI; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bf, tf[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bupf[j][a], tf[b], acc[a][b], 0, 0, 0);
       }
     }
   }
@@ -513,21 +584,13 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   return;
 #endif
   // acc[a][b][r] = C[m = m0 + wm*MI*16 + b*16 + (lane&15)][n = n0 + wn*NI*16 + a*16 + (lane>>4)*4 + r]
-  const bool vec_ok = ((p.ldc & 3) == 0) && (p.R == nullptr || (p.ldr & 3) == 0) &&
-                      (p.rowbias == nullptr || (p.ld_rowbias & 3) == 0);
 #ifndef SDLT_LAB_DIRECT_EPILOGUE
   // ---- staged store (the common bf16 case): the fragment layout gives every lane 4 consecutive columns of one row, i.e.
   // a wave store would touch 16 rows x 32 B.  Instead the fp32 tile (alpha, bias, row bias applied) goes through the
   // now idle staging LDS and leaves as full 256-byte row segments, 16 B per lane; the residual is read the same way and
   // added before the single bf16 rounding.
   // (not for the M = 128 text-encoder GEMMs: a handful of tiles, where the two extra barriers cost more than the wider stores save)
-  if ((long)p.M * p.N >= (1l << 20) && !p.out_fp32 && pCt == nullptr && vec_ok && (p.ldc & 7) == 0 && (p.N & 7) == 0 && (p.R == nullptr || (p.ldr & 7) == 0) &&
-      (((uintptr_t)pC | (uintptr_t)p.R) & 15) == 0) {
-    constexpr int CST = BN + 4;                                    // fp32 elements per staged row (+4: bank spread)
-    constexpr int REGION = (S == 1 ? 2 : S) * STAGE;
-    constexpr int CROWS = BM * CST * 4 <= REGION ? BM : (BM / 2 * CST * 4 <= REGION ? BM / 2 : BM / 4);
-    static_assert(CROWS * CST * 4 <= REGION && CROWS % 16 == 0, "staged epilogue does not fit the staging LDS");
-    constexpr int NCH = BN / 8;                                    // 16-byte output chunks per row
+  if (staged) {
     float* csh = (float*)smem;
     __syncthreads();                                               // every wave is past its last read of the staging LDS
 #pragma unroll
@@ -542,9 +605,8 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
         for (int a = 0; a < NI; ++a) {
           const int nl = wn * NI * 16 + a * 16 + fk * 4;
           const int n = n0 + nl;
-          f32x4 v = acc[a][b] * p.alpha;
+          f32x4 v = acc[a][b] * p.alpha + biasf[a];
           if (n < p.N) {
-            if (pBias) v += *(const f32x4*)(pBias + n);
             if (p.rowbias) {
               uint2 rb = *(const uint2*)((const bf16_t*)p.rowbias + (size_t)brow * p.ld_rowbias + n);
               v[0] += bf2f(rb.x & 0xffff); v[1] += bf2f(rb.x >> 16); v[2] += bf2f(rb.y & 0xffff); v[3] += bf2f(rb.y >> 16);
@@ -554,14 +616,22 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
         }
       }
       __syncthreads();
-      for (int it = tid; it < CROWS * NCH; it += NTHR) {
+#pragma unroll
+      for (int q = 0; q < (RPRE ? QPP : (CROWS * NCH + NTHR - 1) / NTHR); ++q) {
+        const int it = tid + q * NTHR;
+        if (!RPRE && it >= CROWS * NCH) break;
         const int row = it / NCH, ch = it - row * NCH;
         const int m = m0 + pass * CROWS + row, n = n0 + ch * 8;
         if (m >= p.M || n >= p.N) continue;
         const float* src = csh + row * CST + ch * 8;
         f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
         if (p.R) {
-          uint4 rv = *(const uint4*)((const bf16_t*)p.R + (size_t)m * p.ldr + n);
+          uint4 rv;
+          bool have = false;
+          if constexpr (RPRE) {
+            if (rpre_on) { rv = rpre[pass * QPP + q]; have = true; }
+          }
+          if (!have) rv = *(const uint4*)((const bf16_t*)p.R + (size_t)m * p.ldr + n);
           lo[0] += bf2f(rv.x & 0xffff); lo[1] += bf2f(rv.x >> 16); lo[2] += bf2f(rv.y & 0xffff); lo[3] += bf2f(rv.y >> 16);
           hi[0] += bf2f(rv.z & 0xffff); hi[1] += bf2f(rv.z >> 16); hi[2] += bf2f(rv.w & 0xffff); hi[3] += bf2f(rv.w >> 16);
         }
@@ -587,10 +657,8 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] * p.alpha;
       if (vec_ok && n + 3 < p.N) {
-        if (pBias) {
-          float4 bv = *(const float4*)(pBias + n);
-          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += biasf[a][r];
         if (p.rowbias) {
           uint2 rb = *(const uint2*)((const bf16_t*)p.rowbias + (size_t)brow * p.ld_rowbias + n);
           v[0] += bf2f(rb.x & 0xffff); v[1] += bf2f(rb.x >> 16); v[2] += bf2f(rb.y & 0xffff); v[3] += bf2f(rb.y >> 16);
@@ -618,8 +686,7 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (n + r >= p.N) break;
-          float x = v[r];
-          if (pBias) x += pBias[n + r];
+          float x = v[r] + biasf[a][r];
           if (p.rowbias) x += bf2f(((const bf16_t*)p.rowbias)[(size_t)brow * p.ld_rowbias + n + r]);
           if (p.R) x += bf2f(((const bf16_t*)p.R)[(size_t)m * p.ldr + n + r]);
           if (pCt) ((bf16_t*)pCt)[(size_t)(n + r) * p.ldct + m] = f2bf(x);

@@ -219,3 +219,60 @@ def clip_fwd_flops(c, B, layers_run=None, T=77):
     D, L = c["width"], (layers_run if layers_run is not None else c["layers"])
     per_layer = 2.0 * B * T * (4 * D * D + 2 * D * c["mlp"]) + 4.0 * B * T * T * D
     return L * per_layer
+
+
+# ---------------------------------------------------------------------------------------------- VAE (AutoencoderKL)
+# diffusers AutoencoderKL as SD1.5 / SDXL ship it (trainer/models.py:17-32 loads it inside the pipeline); "tiny" keeps the wiring
+# at toy widths.  Used for synthetic (random-init) VAEs of the latent cache / validation render when no checkpoint is configured.
+VAE_CONFIGS = {
+    "sd": dict(block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4, in_channels=3),
+    "tiny": dict(block_out_channels=(64, 64, 128), layers_per_block=1, latent_channels=4, in_channels=3),
+}
+
+
+def vae_param_shapes(c):
+    """diffusers-name -> shape of every AutoencoderKL parameter (encoder, quant convs, decoder)."""
+    P = OrderedDict()
+    boc, L, zc, ic = c["block_out_channels"], c["layers_per_block"], c["latent_channels"], c["in_channels"]
+
+    def conv(n, i, o, k=3):
+        P[n + ".weight"], P[n + ".bias"] = (o, i, k, k), (o,)
+
+    def vec(n, ch):
+        P[n + ".weight"], P[n + ".bias"] = (ch,), (ch,)
+
+    def resnet(n, i, o):
+        vec(n + ".norm1", i), conv(n + ".conv1", i, o), vec(n + ".norm2", o), conv(n + ".conv2", o, o)
+        if i != o:
+            conv(n + ".conv_shortcut", i, o, 1)
+
+    def mid(n, ch):
+        resnet(n + ".resnets.0", ch, ch)
+        vec(n + ".attentions.0.group_norm", ch)
+        for k in ("to_q", "to_k", "to_v", "to_out.0"):
+            P[f"{n}.attentions.0.{k}.weight"], P[f"{n}.attentions.0.{k}.bias"] = (ch, ch), (ch,)
+        resnet(n + ".resnets.1", ch, ch)
+
+    conv("encoder.conv_in", ic, boc[0])
+    prev = boc[0]
+    for i, ch in enumerate(boc):
+        for j in range(L):
+            resnet(f"encoder.down_blocks.{i}.resnets.{j}", prev, ch)
+            prev = ch
+        if i + 1 < len(boc):
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", ch, ch)
+    mid("encoder.mid_block", boc[-1])
+    vec("encoder.conv_norm_out", boc[-1]), conv("encoder.conv_out", boc[-1], 2 * zc)
+    conv("quant_conv", 2 * zc, 2 * zc, 1), conv("post_quant_conv", zc, zc, 1)
+    rev = boc[::-1]
+    conv("decoder.conv_in", zc, rev[0])
+    mid("decoder.mid_block", rev[0])
+    prev = rev[0]
+    for i, ch in enumerate(rev):
+        for j in range(L + 1):
+            resnet(f"decoder.up_blocks.{i}.resnets.{j}", prev, ch)
+            prev = ch
+        if i + 1 < len(rev):
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", ch, ch)
+    vec("decoder.conv_norm_out", rev[-1]), conv("decoder.conv_out", rev[-1], ic)
+    return P
