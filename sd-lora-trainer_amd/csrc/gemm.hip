@@ -19,6 +19,7 @@
 // * global->LDS via global_load_lds (16 B/lane, no VGPR round trip), LDS image XOR-swizzled through
 //   the per-lane SOURCE address (chunk ^= row&7) -> conflict-free ds_read_b128; double-buffered,
 //   one barrier per K step, next tile's DMA in flight under the MFMAs.
+#include <type_traits>
 #include "common.h"
 #include "../../include/sdlt_kernels.h"
 
@@ -31,11 +32,16 @@ struct ConvGeom {
   int Hin, Win, Cin, Hout, Wout, stride, ups, flip, tr;
 };
 
-// MI x NI 16x16 fragments per wave; waves are laid out 2 (m) x WN (n): WN = 2 -> 256 threads, WN = 4 -> 512 threads
-// (two waves per SIMD: the second half of the waves computes first and issues its DMA afterwards, so one wave's DMA
-// issue stalls overlap the other's MFMAs on every SIMD).
-template <int MI, int NI, int WN, int MODE, int R16, int NSTAGE, int KG = 0, int BT = 0>
-__global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p) {
+// MI x NI 16x16 fragments per wave; waves are laid out WM (m) x WN (n), WM = 2 by default: WN = 2 -> 256 threads, WN = 4 -> 512
+// threads (two waves per SIMD: the second half of the waves computes first and issues its DMA afterwards, so one wave's DMA
+// issue stalls overlap the other's MFMAs on every SIMD).  WM = 4, WN = 2, NI = 5 are the 160-column tiles (256x160, 128x160):
+// every SDXL / SD1.5 width is a multiple of 320, so they cut 1024 x 10240, 1024 x 5120, 4096 x 2560, 16384 x 320 ... into exactly
+// 256 workgroups of wave tiles wide enough (64x80 / 32x80) for the MFMAs not to starve on LDS reads.
+template <int N_>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+
+template <int MI, int NI, int WN, int MODE, int R16, int NSTAGE, int KG = 0, int BT = 0, int WM = 2>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_params p) {
   // batched launch: blockIdx.y picks the problem; its operand pointers replace the launch-wide ones (wave-uniform scalar loads)
   // (BT is a template switch so that ordinary launches do not pay the extra kernarg loads and selects in their prologue)
   const sdlt_gemm_batch_item* bi = BT ? p.batch + blockIdx.y : nullptr;
@@ -47,8 +53,9 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   void* pC = (bi && bi->C) ? bi->C : p.C;
   void* pCt = (bi && bi->Ct) ? bi->Ct : p.Ct;
   const float* pBias = (bi && bi->bias) ? bi->bias : p.bias;
-  constexpr int NW = 2 * WN, NTHR = NW * 64;
-  constexpr int BM = 2 * MI * 16, BN = WN * NI * 16;
+  constexpr int NW = WM * WN, NTHR = NW * 64;
+  constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
+  static_assert(WM == 2 || WM == 4, "wave rows");
   constexpr int XT = BM * ROW_BYTES, WT = BN * ROW_BYTES, AT = (R16 ? R16 * 16 : 0) * ROW_BYTES;
   constexpr int STAGE = XT + WT + AT;
   constexpr int S = NSTAGE;                        // LDS ring depth: S-1 K-steps of DMA in flight under the MFMAs
@@ -61,7 +68,7 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   char* tsh = smem + (S == 1 ? 2 : S) * STAGE;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it in an SGPR
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave & (WM - 1), wn = wave / WM;
   const int frow = lane & 15, fk = lane >> 4;
   // XCD-aware remap: consecutive tile ids (sharing an X panel) land on the same XCD/L2.
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
@@ -99,8 +106,11 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   // ---------------- per-lane staging geometry (fixed rows, fixed swizzled chunk) ----------------
   const int srow = lane >> 3;                       // row within an 8-row DMA piece
   const int schunk = (lane & 7) ^ (srow & 7);       // source chunk so that LDS holds chunk^(row&7)
-  constexpr int XI = BM / 8 / NW, WI = BN / 8 / NW;  // DMA pieces (8 rows x 128 B) per wave
-  static_assert(XI >= 1 && WI >= 1 && XI * 8 * NW == BM && WI * 8 * NW == BN, "tile does not split evenly over the waves");
+  // DMA pieces (8 rows x 128 B): X pieces split evenly over the waves; W pieces WF each plus one more for the first W_REM waves
+  // (160 columns = 20 pieces over 8 waves), which then run with their own DMA count (see the counted waits)
+  constexpr int XI = BM / 8 / NW, WF = BN / 8 / NW, W_REM = (BN / 8) % NW, WI = WF + (W_REM ? 1 : 0);
+  static_assert(XI >= 1 && WI >= 1 && XI * 8 * NW == BM, "tile does not split evenly over the waves");
+  const bool w_extra = W_REM && wave < W_REM;
   const bf16_t* xptr[XI];
   int xb[XI], xh[XI], xw[XI];                       // conv: decoded output pixel (b<0 => row invalid)
 #pragma unroll
@@ -126,7 +136,7 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   const bf16_t* wptr[WI];
 #pragma unroll
   for (int i = 0; i < WI; ++i) {
-    int n = n0 + (wave + NW * i) * 8 + srow;
+    int n = n0 + (wave + NW * i) * 8 + srow;     // (i == WF: only used by the first W_REM waves)
     int nc = n < p.N ? n : p.N - 1;
     wptr[i] = (const bf16_t*)pW + (size_t)nc * p.ldw + schunk * 8;
   }
@@ -168,9 +178,17 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   // a 64x128 stage on the texture-address path that bounds the K loop.)
   constexpr bool A_FEW = R16 && 2 * R16 < NW;
   constexpr int AI = R16 ? (A_FEW ? 1 : (2 * R16 + NW - 1) / NW) : 0;   // LoRA-down DMA instructions per (loading) wave and stage
-  constexpr int LPS = XI + WI + AI;                         // DMA instructions per wave and stage (a_loader waves)
-  constexpr int LPS0 = XI + WI;                             // ... of the waves that move no LoRA-down piece
+  constexpr int LPS = XI + WI + AI;                         // most DMA instructions any wave issues per stage (S == 1 register path)
+  constexpr int LPSB = XI + WF + (A_FEW ? 0 : AI);          // DMA instructions per stage every wave issues ...
   const bool a_loader = !A_FEW || wave < 2 * R16;
+  const int lps_extra = (w_extra ? 1 : 0) + ((A_FEW && a_loader) ? 1 : 0);   // ... plus this wave's own extras (wave-uniform)
+  // "at most MULT stages of this wave's DMA still in flight"
+  auto wait_stages = [&](auto mult) {
+    constexpr int MULT = decltype(mult)::value;
+    if (lps_extra == 0) wait_vmcnt<MULT * LPSB>();
+    else if (lps_extra == 1) wait_vmcnt<MULT * (LPSB + 1)>();
+    else wait_vmcnt<MULT * (LPSB + 2)>();
+  };
 
   // this workgroup's share of the K steps (split-K: contiguous ranges of the combined segment-1 + segment-2 steps)
   const int kbeg = splitk == 1 ? 0 : nk * split / splitk, kend = splitk == 1 ? nk : nk * (split + 1) / splitk;   // 32-bit: nk < 2^15
@@ -225,9 +243,15 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
       }
     }
 #pragma unroll
-    for (int i = 0; i < WI; ++i) {
+    for (int i = 0; i < WF; ++i) {
       const bf16_t* src = (!TWOSEG || seg1) ? wptr[i] : w2ptr[i];
       f(XI + i, src + k0, XT + (wave + NW * i) * 1024);
+    }
+    if constexpr (W_REM > 0) {
+      if (w_extra) {
+        const bf16_t* src = (!TWOSEG || seg1) ? wptr[WF] : w2ptr[WF];
+        f(XI + WF, src + k0, XT + (wave + NW * WF) * 1024);
+      }
     }
     if (R16) {
       // (LoRA excludes a second segment.)  Every wave moves the SAME number of pieces per stage (the counted vmcnt of the
@@ -404,7 +428,7 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
 #pragma unroll
   for (int t = 0; t < S - 1; ++t)
     if (kbeg + t < kend) stage(kbeg + t, t);
-  const bool early = WN == 2 || wave < NW / 2;
+  const bool early = NW <= 4 || wave < NW / 2;
   auto kg_flush = [&](int kt) {
     if constexpr (KG > 0) {
       const int gsteps = p.lora_group_k / BK;
@@ -431,8 +455,7 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   int kt = kbeg;
   int rd = 0, wr = S - 1;                           // ring slot being consumed / being filled
   for (; kt + S - 1 < kend; ++kt) {
-    if (a_loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * LPS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * LPS0) : "memory");
+    wait_stages(std::integral_constant<int, S - 2>{});
     __builtin_amdgcn_s_barrier();   // stage kt visible to all waves; everyone is done reading stage kt-1's buffer
     asm volatile("" ::: "memory");
     if (early) stage(kt + S - 1, wr);
@@ -445,13 +468,9 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   // Drain: the last (up to) S-1 stages are in flight, nothing left to issue.
   for (; kt < kend; ++kt) {
     const int ahead = kend - 1 - kt;                // stages issued after stage kt
-    if (S >= 4 && ahead >= 2) {
-      if (a_loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS0) : "memory");
-    } else if (S >= 3 && ahead >= 1) {
-      if (a_loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS0) : "memory");
-    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (S >= 4 && ahead >= 2) wait_stages(std::integral_constant<int, 2>{});
+    else if (S >= 3 && ahead >= 1) wait_stages(std::integral_constant<int, 1>{});
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     compute(smem + rd * STAGE, kt);
@@ -698,10 +717,10 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(const sdlt_gemm_params p
   }
 }
 
-template <int MI, int NI, int WN, int MODE, int R16, int NSREQ, int KG = 0, int BT = 0>
+template <int MI, int NI, int WN, int MODE, int R16, int NSREQ, int KG = 0, int BT = 0, int WM = 2>
 int launch(const sdlt_gemm_params& p, hipStream_t stream) {
-  constexpr int NTHR = 128 * WN;
-  constexpr int BM = 2 * MI * 16, BN = WN * NI * 16;
+  constexpr int NTHR = 64 * WM * WN;
+  constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
   constexpr int STAGE = (BM + BN + R16 * 16) * ROW_BYTES;
   constexpr int TSH = R16 ? BM * ((KG ? KG : R16) * 16 + 4) * 2 : 0;
   // LDS ring depth: NSREQ == 2 keeps the footprint small (several workgroups per CU overlap each other);
@@ -714,7 +733,7 @@ int launch(const sdlt_gemm_params& p, hipStream_t stream) {
   const int smem = NBUF * STAGE + TSH;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_kernel<MI, NI, WN, MODE, R16, NS, KG, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute((const void*)gemm_kernel<MI, NI, WN, MODE, R16, NS, KG, BT, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
@@ -725,15 +744,17 @@ int launch(const sdlt_gemm_params& p, hipStream_t stream) {
     if (!p.ws_slab || !p.ws_cnt || (size_t)nbm * nbn * splitk * slab_bytes > (size_t)p.ws_slab_bytes || nbm * nbn > p.ws_cnt_len)
       SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: split-K workspace too small (%d tiles x %d splits x %zu B)", nbm * nbn, splitk, slab_bytes);
   }
-  hipLaunchKernelGGL((gemm_kernel<MI, NI, WN, MODE, R16, NS, KG, BT>), dim3(nbm * nbn * splitk, BT ? p.n_batch : 1), dim3(NTHR), smem, stream, p);
+  hipLaunchKernelGGL((gemm_kernel<MI, NI, WN, MODE, R16, NS, KG, BT, WM>), dim3(nbm * nbn * splitk, BT ? p.n_batch : 1), dim3(NTHR), smem, stream, p);
   }
   return SDLT_OK;
 }
 
 // tile ids: 1 = 128x128 (8 waves), 2 = 64x128 (8 waves), 3 = 64x64 (4 waves), 4 = 256x128 (8 waves), 5 = 128x128 (4 waves),
-//           6 = 256x256 (8 waves)
+//           6 = 256x256 (8 waves), 7 = 256x160 (8 waves, 4x2), 8 = 128x160 (8 waves, 4x2)
 void tile_dims(int tile, int& bm, int& bn) {
   switch (tile) {
+    case 7: bm = 256; bn = 160; break;
+    case 8: bm = 128; bn = 160; break;
     case 1: case 5: bm = 128; bn = 128; break;
     case 2: bm = 64; bn = 128; break;
     case 4: bm = 256; bn = 128; break;
@@ -828,6 +849,8 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
     case 4: return launch<8, 2, 4, MODE, R16, NSV>(p, s);            \
     case 5: return launch<4, 4, 2, MODE, R16, NSV>(p, s);            \
     case 6: return launch<8, 4, 4, MODE, R16, NSV>(p, s);            \
+    case 7: if constexpr (R16 <= 1) return launch<4, 5, 2, MODE, R16, NSV, 0, 0, 4>(p, s); else break; \
+    case 8: if constexpr (R16 <= 1) return launch<2, 5, 2, MODE, R16, NSV, 0, 0, 4>(p, s); else break; \
   }
   // (stages == 1, the register-staged loader, is kept in the kernel source but not instantiated: hipcc places its
   //  staging registers in scratch - measured 3-6x slower than the LDS-DMA ring on every SDXL shape.)

@@ -211,10 +211,12 @@ def load_data(config, models, rt, h, w):
         vsd = models.vae_state()
         if vsd is None:
             raise ValueError("an image folder needs the VAE weights: pretrained_model['vae_path']")
-        enc = V.VaeEncoder(M.Runtime(rt.device, 1), vsd)
-        lc = LatentCache.from_folder(src, enc, size=(8 * w, 8 * h), scaling_factor=cfg["scaling_factor"], substitute_caption_map=config.token_dict)
+        enc = V.VaeEncoder(M.Runtime(rt.device, 1, act_dtype=rt.act, ops=rt.ops), vsd)
+        f = 2 ** (len(enc.downs) - 1)          # 8 for the SD / SDXL VAE (4 levels); the toy VAE of the tests has 3
+        lc = LatentCache.from_folder(src, enc, size=(f * w, f * h), scaling_factor=cfg["scaling_factor"], substitute_caption_map=config.token_dict)
         del enc, vsd
-        torch.cuda.empty_cache() if rt.device.type == "cuda" else None
+        if rt.device.type == "cuda":
+            torch.cuda.empty_cache()
         ids, lists = _tokenize(models.tokenizers, lc.captions)
         cache = dict(posterior=torch.cat([d.parameters for d in lc.dists], 0), masks=torch.stack(lc.masks), input_ids=ids, token_lists=lists, captions=lc.captions)
     else:

@@ -1,0 +1,130 @@
+"""train() as a job driver for a reference-style config (main.py:34-551), on CPU through the op emulation: a preprocessed image
+FOLDER (captions.csv + images + masks) -> VAE-encoded latent cache, CLIP BPE tokenizer files -> ids / token lists, trigger
+tokens added and initialised, checkpoint cadence (`checkpointing_steps`, also at step 0) and the final-directory rule,
+`disable_ti` with the captions still encoded by the (frozen) text encoders, and the refusal of fields this engine does not build."""
+import csv
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+import sd_lora_trainer_amd.unet as unet_mod
+from sd_lora_trainer_amd.config import TrainingConfig
+from tests import emu_ops
+from tests.test_tokenizer_cpu import _train_bpe
+
+
+def _dataset(tmp_path, n=5, size=64):
+    d = tmp_path / "images_out"
+    os.makedirs(d)
+    rng = np.random.RandomState(0)
+    rows = []
+    for i in range(n):
+        Image.fromarray(rng.randint(0, 255, (size, size, 3), dtype=np.uint8)).save(d / f"{i}.src.jpg")
+        Image.fromarray(rng.randint(0, 255, (size, size), dtype=np.uint8)).save(d / f"{i}.mask.jpg")
+        rows.append(dict(image_path=f"{i}.src.jpg", caption=f"a photo of TOK on the grass, number {i}" if i != 2 else "a dog in front of a house", mask_path=f"{i}.mask.jpg"))
+    with open(d / "captions.csv", "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=["image_path", "caption", "mask_path"])
+        w.writeheader()
+        w.writerows(rows)
+    return str(d)
+
+
+def _tokenizer_dir(tmp_path):
+    vocab, merges = _train_bpe(200)
+    d = tmp_path / "tokenizer"
+    os.makedirs(d)
+    json.dump(vocab, open(d / "vocab.json", "w", encoding="utf-8"), ensure_ascii=False)
+    open(d / "merges.txt", "w", encoding="utf-8").write("#version: 0.2\n" + "\n".join(f"{a} {b}" for a, b in merges) + "\n")
+    return str(d), len(vocab)
+
+
+def _run(gen):
+    progress = []
+    try:
+        while True:
+            progress.append(next(gen))
+    except StopIteration as e:
+        return progress, e.value
+
+
+@pytest.mark.parametrize("version,disable_ti", [("tinyxl", False), ("tiny15", True)])
+def test_train_from_folder_with_tokenizer(tmp_path, monkeypatch, version, disable_ti):
+    monkeypatch.chdir(tmp_path)
+    from sd_lora_trainer_amd import train as T
+    data, (tok_dir, vocab_size) = _dataset(tmp_path), _tokenizer_dir(tmp_path)
+    cfg = TrainingConfig(lora_training_urls=data, concept_mode="object", name="my run", seed=2, resolution=64, train_batch_size=2, max_train_steps=60,
+                         checkpointing_steps=20, lora_rank=4, disable_ti=disable_ti, unet_lr=1e-3, ti_lr=1e-3, caption_dropout=0.3,
+                         pretrained_model={"path": f"synthetic:{version}", "tokenizer_path": tok_dir})
+    seen = {}
+    real_set = None
+
+    import sd_lora_trainer_amd.step as S
+    real_set = S.TrainStep.set_batch
+
+    def spy(self, latent, noise, timesteps, mask, ctx=None, pooled=None, time_ids=None, ids=None, caption_token_lists=None):
+        seen.setdefault("calls", []).append(dict(ctx=None if ctx is None else ctx.clone(), ids=ids, lists=caption_token_lists, mask=mask.clone(), latent=latent.clone()))
+        return real_set(self, latent, noise, timesteps, mask, ctx, pooled, time_ids, ids, caption_token_lists)
+    monkeypatch.setattr(S.TrainStep, "set_batch", spy)
+    rt = unet_mod.Runtime("cpu", 2, act_dtype=torch.float32, ops=emu_ops)
+    progress, (config, out_dir) = _run(T.train(cfg, runtime=rt))
+    assert progress[-1] == 1.0 and config.num_train_epochs == 20                    # ceil(5 / 2) = 3 batches per epoch (drop_last=False)
+    ck = os.path.dirname(out_dir)
+    # cadence (main.py:399): steps 0 and 20 (40 is not < 60 - 25); 20 epochs x 3 batches end the loop at 60 steps; final (466-470): 60 - 20 > 26 -> checkpoint-60
+    assert sorted(os.listdir(ck)) == ["checkpoint-0", "checkpoint-20", "checkpoint-60"] and out_dir.endswith("checkpoint-60")
+    names = os.listdir(out_dir)
+    assert f"my_run_{version}_lora.safetensors" in names and f"my_run_{version}_embeddings.safetensors" in names and "training_args.json" in names
+    ta = json.load(open(os.path.join(out_dir, "training_args.json")))
+    assert ta["training_attributes"]["images_per_second"] > 0 and all(np.isfinite(ta["training_attributes"]["losses"]["tot_loss"]))
+    calls = seen["calls"]
+    assert len(calls) == 60
+    lat = torch.stack([c["latent"] for c in calls])
+    assert lat.shape[1:] == (2, 4, 8, 8) and float(lat.std()) > 0
+    m = calls[0]["mask"]
+    assert m.shape == (2, 4, 8, 8) and torch.equal(m[:, 0], m[:, 3]) and 0.0 <= float(m.min()) and float(m.max()) <= 1.0 and float(m.std()) > 0   # latent-resolution masks from the jpgs
+    tok_ids = [vocab_size, vocab_size + 1, vocab_size + 2]
+    if disable_ti:
+        # captions are encoded by the frozen text encoders (no random conditioning): the conditioning only takes the values of the
+        # 5 captions + the caption-dropout caption
+        uniq = {tuple(c["ctx"][b][3:9].flatten()[:128].tolist()) for c in calls for b in range(2)}     # (position 0 only sees BOS: causal)
+        assert 2 <= len(uniq) <= 6 and all(c["ids"] is None for c in calls)
+    else:
+        ids = torch.cat([c["ids"][0] for c in calls])
+        assert ids.shape[1] == 77 and all(len(c["ids"]) == 2 for c in calls)
+        with_tok = [(row[:12].tolist(), l) for c in calls for row, l in zip(c["ids"][0], c["lists"])]
+        assert any(all(t in l for t in tok_ids) for _, l in with_tok)                # "tok" -> <s0><s1><s2> substitution reached the tokenizer
+        assert any(not any(t in l for t in tok_ids) for _, l in with_tok)            # the caption without the trigger word
+        drop = [l for _, l in with_tok if len(l) == 5 and l[1:4] == tok_ids]         # caption dropout -> the bare trigger string
+        assert 0 < len(drop) < len(with_tok)
+        from safetensors.torch import load_file
+        emb = load_file(os.path.join(out_dir, f"my_run_{version}_embeddings.safetensors"))
+        e0 = load_file(os.path.join(ck, "checkpoint-0", f"my_run_{version}_embeddings.safetensors"))
+        assert set(emb) == {"clip_l", "clip_g"} and not torch.equal(emb["clip_l"], e0["clip_l"])     # the token rows were trained
+
+
+@pytest.mark.parametrize("kw", [dict(use_dora=True), dict(tok_cond_reg_w=0.1), dict(aspect_ratio_bucketing=True)])
+def test_unbuilt_fields_raise(tmp_path, monkeypatch, kw):
+    monkeypatch.chdir(tmp_path)
+    from sd_lora_trainer_amd import train as T
+    cfg = TrainingConfig(lora_training_urls="synthetic:4", concept_mode="object", pretrained_model={"path": "synthetic:tiny15"}, seed=1, resolution=128,
+                         train_batch_size=1, max_train_steps=3, **kw)
+    with pytest.raises(NotImplementedError):
+        next(T.train(cfg, runtime=unet_mod.Runtime("cpu", 1, act_dtype=torch.float32, ops=emu_ops)))
+
+
+def test_real_unet_without_text_encoder_weights_is_an_error(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    from safetensors.torch import save_file
+    from sd_lora_trainer_amd import topology
+    from sd_lora_trainer_amd import train as T
+    sd = {k: torch.zeros(s) for k, s in topology.param_shapes(topology.CONFIGS["tiny15"]).items()}
+    save_file(sd, str(tmp_path / "unet.safetensors"))
+    topology.CONFIGS["sd15_test_alias"] = topology.CONFIGS["tiny15"]
+    cfg = TrainingConfig(lora_training_urls="synthetic:4", concept_mode="object", pretrained_model={"path": str(tmp_path / "unet.safetensors")}, seed=1, resolution=128,
+                         train_batch_size=1, max_train_steps=3)
+    monkeypatch.setitem(topology.CONFIGS, "sd15", topology.CONFIGS["tiny15"])
+    with pytest.raises(ValueError, match="text_encoder_path"):
+        next(T.train(cfg, runtime=unet_mod.Runtime("cpu", 1, act_dtype=torch.float32, ops=emu_ops)))
