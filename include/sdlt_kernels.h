@@ -189,10 +189,14 @@ typedef struct sdlt_groupnorm_params {
   const void* dres; int64_t lddres;
   void* dx; int64_t lddx;
   float* bstats;
-  int32_t stats_zeroed;   /* 1: the caller already cleared stats (fwd) / bstats (bwd) - e.g. one fill over an arena of all
-                             GroupNorm statistics per pass instead of one zero launch per layer */
+  /* statistics are reduced in a FIXED order (bitwise reproducible, no float atomics): every block leaves 64 partial sums in
+     `ws` and the last block of a batch element to arrive combines them (counters `cnt`, one per batch element, zero on entry
+     and re-armed by the kernel).  ws / cnt are scratch: only live inside the call; ws_floats >= sdlt_groupnorm_ws_floats(). */
+  float* ws; int64_t ws_floats;
+  int32_t* cnt; int32_t cnt_len;
   int32_t pad_;
 } sdlt_groupnorm_params;
+int sdlt_groupnorm_ws_floats(int32_t B, int32_t HW, int32_t C);
 int sdlt_groupnorm_fwd(const sdlt_groupnorm_params* p, void* stream);
 int sdlt_groupnorm_bwd(const sdlt_groupnorm_params* p, void* stream);
 

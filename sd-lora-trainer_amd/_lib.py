@@ -81,7 +81,8 @@ class GroupNormParams(C.Structure):
         ("dres", vp), ("lddres", i64),
         ("dx", vp), ("lddx", i64),
         ("bstats", vp),
-        ("stats_zeroed", i32), ("pad_", i32),
+        ("ws", vp), ("ws_floats", i64),
+        ("cnt", vp), ("cnt_len", i32), ("pad_", i32),
     ]
 
 
@@ -100,6 +101,7 @@ SYMBOLS = {
     "sdlt_lora_grad_block_cols": (i32, []),
     "sdlt_attn_fwd": (i32, [C.POINTER(AttnParams), vp]),
     "sdlt_attn_bwd": (i32, [C.POINTER(AttnParams), vp]),
+    "sdlt_groupnorm_ws_floats": (i32, [i32, i32, i32]),
     "sdlt_groupnorm_fwd": (i32, [C.POINTER(GroupNormParams), vp]),
     "sdlt_groupnorm_bwd": (i32, [C.POINTER(GroupNormParams), vp]),
     "sdlt_layernorm_fwd": (i32, [vp, i64, i32, i32, vp, vp, f32, vp, i64, vp, vp]),

@@ -782,7 +782,27 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     const int nk = ktot / BK;
     const bool ws = p.ws_slab && p.ws_cnt;
-    if (p.M <= 64) p.tile = p.N > 64 ? 2 : 3;
+    // 160-column tiles (tools/tile160_probe.py on MI355X): every UNet width is a multiple of 320, so 256x160 / 128x160 tiles cut
+    // the wide feed-forward products and the top-resolution convolutions into exactly 256 (or 512, 1024) workgroups with no
+    // padded columns, and their 64x80 / 32x80 wave tiles read fewer LDS bytes per MFMA than the 32x32 ones of the 64x128 tile.
+    //   1024 x 10240 x 1280: 48.5 -> 34.0 us (256x160);  1024 x 5120 x 1280: 24.4 -> 19.8 (128x160);  4096 x 2560 x 640: 25.7 -> 19.4;
+    //   16384 x 320 conv K 2880: 56.1 -> 42.6, K 8640: 156.6 -> 118.6;  4096 x 640 conv: 63.0 -> 56.2 with 2 splits.
+    // Not for the attention projections (1024 x 1280 x 1280: 64 tiles) nor the long-K / narrow-N products (split-K 128x128 is as good).
+    if (R16 <= 1 && !p.batch && !p.lora_group_k && p.N % 160 == 0 && p.M > 128 && !p.throughput_hint) {
+      const long t7 = (long)((p.M + 255) / 256) * (p.N / 160), t8 = (long)((p.M + 127) / 128) * (p.N / 160);
+      if (MODE == 0 && R16 == 0 && ktot <= 2560) {
+        if (t7 >= 256) p.tile = 7;
+        else if (t8 >= 224) p.tile = 8;
+      } else if (MODE == 0 && R16 == 1 && !p.lora_group_n && ktot <= 640 && t8 >= 224 && t8 <= 320) {
+        p.tile = 8;
+      } else if (MODE == 1 && (t8 == 256 || t8 == 128 || t8 == 64)) {
+        const int sk = (int)(256 / t8);
+        if (sk == 1 || (ws && !p.splitk && nk / sk >= 16)) { p.tile = 8; if (sk > 1) p.splitk = sk; }
+      }
+      if (p.tile && !p.splitk) p.splitk = 1;
+    }
+    if (p.tile) {}
+    else if (p.M <= 64) p.tile = p.N > 64 ? 2 : 3;
     else if (p.N <= 64) p.tile = 3;
     else if (p.M <= 128) {
       // text encoders / text-conditioning projections (M = 128): a few 64x64 tiles, latency-bound; split K only while the

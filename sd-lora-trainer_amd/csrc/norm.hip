@@ -37,18 +37,69 @@ struct CatIn {
   }
 };
 
+
+// Deterministic two-stage reduction of the per-(batch, group) statistics (no float atomics: a fixed summation order makes
+// two runs - and a hipGraph replay vs the eager pass - bitwise identical).
+//   stage 1: the block's 4 waves leave their per-channel sums in LDS; thread t < 64 (statistic slot t = group * 2 + kind) adds the
+//            channels of its group that fall into this block, waves 0..3, in a fixed order, and the 64 slots go to the
+//            block's row of the workspace  ws[((b * rs + by) * cb + bx) * 64 + t];
+//   stage 2: the LAST block of batch b to arrive (agent-scope counter, re-armed for the next launch) sums, per slot, the rows
+//            of the blocks that cover the slot's group: 4 fixed quarters of the row splits by the 4 waves, combined in order.
+__device__ __forceinline__ void gn_reduce_finalize(float (&s)[8], float (&q)[8], int C, float* __restrict__ out, float* __restrict__ ws, int* __restrict__ cnt) {
+  __shared__ float sch[4][64][2];
+  __shared__ float part[4][64];
+  __shared__ int ticket;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, cb = gridDim.x, rs = gridDim.y;
+  const int cpg = C / G;
+  // lanes with the same (lane&7) hold the same channels: reduce over lane>>3 (xor 8,16,32)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) { s[j] += __shfl_xor(s[j], o, 64); q[j] += __shfl_xor(q[j], o, 64); }
+  }
+  if ((lane >> 3) == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sch[wave][(lane & 7) * 8 + j][0] = s[j]; sch[wave][(lane & 7) * 8 + j][1] = q[j]; }
+  }
+  __syncthreads();
+  const int slot = tid & 63, g = slot >> 1, kind = slot & 1;
+  if (tid < 64) {
+    const int blo = (int)blockIdx.x * 64;
+    const int clo = g * cpg > blo ? g * cpg : blo, chi = (g + 1) * cpg < blo + 64 ? (g + 1) * cpg : blo + 64;
+    float a = 0.f;
+    for (int c = clo; c < chi; ++c) {
+      const int cl = c - blockIdx.x * 64;
+      a += ((sch[0][cl][kind] + sch[1][cl][kind]) + (sch[2][cl][kind] + sch[3][cl][kind]));
+    }
+    ws[(((size_t)b * rs + blockIdx.y) * cb + blockIdx.x) * 64 + slot] = a;
+  }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) ticket = __hip_atomic_fetch_add(cnt + b, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (ticket != cb * rs - 1) return;
+  __threadfence();
+  // blocks whose 64 channels intersect group g
+  const int bxlo = (g * cpg) / 64, bxhi = ((g + 1) * cpg - 1) / 64;
+  const int q0 = (rs * wave) / 4, q1 = (rs * (wave + 1)) / 4;
+  float a = 0.f;
+  for (int by = q0; by < q1; ++by)
+    for (int bx = bxlo; bx <= bxhi; ++bx) a += ws[(((size_t)b * rs + by) * cb + bx) * 64 + slot];
+  part[wave][slot] = a;
+  __syncthreads();
+  if (tid < 64) out[b * 64 + slot] = (part[0][slot] + part[1][slot]) + (part[2][slot] + part[3][slot]);
+  if (tid == 0) __hip_atomic_store(cnt + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---------------------------------------------------------------------------------- GroupNorm
 // grid (C/64, rowsplit, B), block 256 = 4 waves; thread: fixed chunk c0 = bx*64 + (lane&7)*8,
 // rows r = ry*32.. step gridDim.y*32, sub-row = wave*8 + lane/8.
 // stats[b][g] = {sum, sumsq} accumulated with atomics (zeroed by the entry point).
-__global__ __launch_bounds__(256) void gn_stats_kernel(CatIn in, int HW, int C, float* stats) {
-  __shared__ float sg[G * 2];
+__global__ __launch_bounds__(256) void gn_stats_kernel(CatIn in, int HW, int C, float* stats, float* ws, int* cnt) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z;
   const int c0 = blockIdx.x * 64 + (lane & 7) * 8;
-  const int cpg = C / G;
-  if (tid < G * 2) sg[tid] = 0.f;
-  __syncthreads();
   float s[8], q[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
@@ -58,26 +109,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(CatIn in, int HW, int C, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
   }
-  // lanes with the same (lane&7) hold the same channels: reduce over lane>>3 (xor 8,16,32)
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-#pragma unroll
-    for (int o = 8; o < 64; o <<= 1) { s[j] += __shfl_xor(s[j], o, 64); q[j] += __shfl_xor(q[j], o, 64); }
-  }
-  if ((lane >> 3) == 0) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      int g = (c0 + j) / cpg;
-      atomicAdd(&sg[g * 2], s[j]);
-      atomicAdd(&sg[g * 2 + 1], q[j]);
-    }
-  }
-  __syncthreads();
-  if (tid < G * 2) {
-    int g = tid >> 1;
-    int glo = (blockIdx.x * 64) / cpg, ghi = (blockIdx.x * 64 + 63) / cpg;
-    if (g >= glo && g <= ghi) atomicAdd(&stats[(b * G) * 2 + tid], sg[tid]);
-  }
+  gn_reduce_finalize(s, q, C, stats, ws, cnt);
 }
 
 template <bool SILU>
@@ -116,15 +148,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(CatIn in, int HW, int C, 
 template <bool SILU>
 __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(CatIn in, const bf16_t* dy, int64_t lddy, int HW, int C,
                                                             const float* stats, const float* gamma, const float* beta,
-                                                            float eps, float* bstats) {
-  __shared__ float sg[G * 2];
+                                                            float eps, float* bstats, float* ws, int* cnt) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z;
   const int c0 = blockIdx.x * 64 + (lane & 7) * 8;
   const int cpg = C / G;
   const float inv_n = 1.0f / ((float)HW * (float)cpg);
-  if (tid < G * 2) sg[tid] = 0.f;
-  __syncthreads();
   float mean[8], rstd[8], gm[8], bt[8], s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -149,25 +178,7 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(CatIn in, const bf16_
       s1[j] += dxh; s2[j] += dxh * xh;
     }
   }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-#pragma unroll
-    for (int o = 8; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
-  }
-  if ((lane >> 3) == 0) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      int g = (c0 + j) / cpg;
-      atomicAdd(&sg[g * 2], s1[j]);
-      atomicAdd(&sg[g * 2 + 1], s2[j]);
-    }
-  }
-  __syncthreads();
-  if (tid < G * 2) {
-    int g = tid >> 1;
-    int glo = (blockIdx.x * 64) / cpg, ghi = (blockIdx.x * 64 + 63) / cpg;
-    if (g >= glo && g <= ghi) atomicAdd(&bstats[(b * G) * 2 + tid], sg[tid]);
-  }
+  gn_reduce_finalize(s1, s2, C, bstats, ws, cnt);
 }
 
 template <bool SILU>
@@ -317,7 +328,21 @@ dim3 gn_grid(const sdlt_groupnorm_params& p) {
   return dim3(cb, rs, p.B);
 }
 
+int gn_ws_check(const sdlt_groupnorm_params& p, dim3 grid, const char* fn) {
+  const int64_t need = (int64_t)grid.x * grid.y * grid.z * 64;
+  if (!p.ws || !p.cnt || p.ws_floats < need || p.B > p.cnt_len)
+    SDLT_FAIL(SDLT_ERR_SHAPE, "%s: statistics workspace too small (%lld floats / %d counters needed)", fn, (long long)need, p.B);
+  return SDLT_OK;
+}
+
 }  // namespace
+
+extern "C" int sdlt_groupnorm_ws_floats(int32_t B, int32_t HW, int32_t C) {
+  sdlt_groupnorm_params p{};
+  p.B = B; p.HW = HW; p.C = C;
+  dim3 g = gn_grid(p);
+  return (int)(g.x * g.y * g.z * 64);
+}
 
 extern "C" int sdlt_groupnorm_fwd(const sdlt_groupnorm_params* pp, void* stream) {
   const sdlt_groupnorm_params& p = *pp;
@@ -326,9 +351,10 @@ extern "C" int sdlt_groupnorm_fwd(const sdlt_groupnorm_params* pp, void* stream)
   if (rc) return rc;
   if (p.ldy % 8) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_groupnorm_fwd: ldy %% 8");
   CatIn in{(const bf16_t*)p.x1, p.ldx1, p.C1, (const bf16_t*)p.x2, p.ldx2};
-  if (!p.stats_zeroed) sdlt_zero_async(p.stats, sizeof(float) * p.B * G * 2, s);
   dim3 grid = gn_grid(p);
-  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, s, in, p.HW, p.C, p.stats);
+  rc = gn_ws_check(p, grid, "sdlt_groupnorm_fwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, s, in, p.HW, p.C, p.stats, p.ws, p.cnt);
   if (p.silu)
     hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(256), 0, s, in, p.HW, p.C, p.stats, p.gamma, p.beta, p.eps, (bf16_t*)p.y, p.ldy);
   else
@@ -344,13 +370,14 @@ extern "C" int sdlt_groupnorm_bwd(const sdlt_groupnorm_params* pp, void* stream)
   if (rc) return rc;
   if ((p.lddy % 8) || (p.lddx % 8) || (p.dres && (p.lddres % 8))) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_groupnorm_bwd: ld %% 8");
   CatIn in{(const bf16_t*)p.x1, p.ldx1, p.C1, (const bf16_t*)p.x2, p.ldx2};
-  if (!p.stats_zeroed) sdlt_zero_async(p.bstats, sizeof(float) * p.B * G * 2, s);
   dim3 grid = gn_grid(p);
+  rc = gn_ws_check(p, grid, "sdlt_groupnorm_bwd");
+  if (rc) return rc;
   if (p.silu) {
-    hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.gamma, p.beta, p.eps, p.bstats);
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.gamma, p.beta, p.eps, p.bstats, p.ws, p.cnt);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.bstats, p.gamma, p.beta, p.eps, (const bf16_t*)p.dres, p.lddres, (bf16_t*)p.dx, p.lddx);
   } else {
-    hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.gamma, p.beta, p.eps, p.bstats);
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.gamma, p.beta, p.eps, p.bstats, p.ws, p.cnt);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.bstats, p.gamma, p.beta, p.eps, (const bf16_t*)p.dres, p.lddres, (bf16_t*)p.dx, p.lddx);
   }
   SDLT_CHECK_LAUNCH();

@@ -294,8 +294,24 @@ def attn_bwd(Q, K, V, Kt, Qt, O, L, dO, dOt, D, dQ, dK, dV, *, B, H, Nq, Nk, Nqp
     _lib.check(lib.sdlt_attn_bwd(C.byref(p), _stream()), "sdlt_attn_bwd")
 
 
+_GN_WS = {}
+
+
+def gn_workspace(device):
+    """Scratch of the deterministic GroupNorm reductions (per-block partial sums + one counter per batch element), one per
+    (device, workspace owner): only live inside a call, but two jobs replaying their graphs concurrently must not share it."""
+    key = (device, ("owner", _ws_owner) if _ws_owner is not None else torch.cuda.current_stream(device).cuda_stream)
+    ws = _GN_WS.get(key)
+    if ws is None:
+        ws = (torch.empty(1 << 20, dtype=F32, device=device), torch.zeros(256, dtype=torch.int32, device=device))
+        _GN_WS[key] = ws
+    return ws
+
+
 def _gn_params(x1, x2, B, HW, gamma, beta, eps, silu, stats):
     p = _lib.GroupNormParams()
+    ws, cnt = gn_workspace(x1.device)
+    p.ws, p.ws_floats, p.cnt, p.cnt_len = _p(ws), ws.numel(), _p(cnt), cnt.numel()
     _chk2(x1), _chk2(gamma, F32), _chk2(beta, F32), _chk2(stats, F32)
     C1 = x1.shape[1]
     Ctot = C1 + (x2.shape[1] if x2 is not None else 0)
@@ -311,8 +327,7 @@ def _gn_params(x1, x2, B, HW, gamma, beta, eps, silu, stats):
 
 def groupnorm_fwd(x1, x2, y, stats, *, B, HW, gamma, beta, eps, silu, stats_zeroed=False):
     lib = _lib.load()
-    p = _gn_params(x1, x2, B, HW, gamma, beta, eps, silu, stats)
-    p.stats_zeroed = int(stats_zeroed)
+    p = _gn_params(x1, x2, B, HW, gamma, beta, eps, silu, stats)      # (stats_zeroed: kept for callers; the reduction overwrites)
     _chk2(y)
     p.y, p.ldy = _p(y), _ld(y)
     _lib.check(lib.sdlt_groupnorm_fwd(C.byref(p), _stream()), "sdlt_groupnorm_fwd")
@@ -322,7 +337,6 @@ def groupnorm_fwd(x1, x2, y, stats, *, B, HW, gamma, beta, eps, silu, stats_zero
 def groupnorm_bwd(x1, x2, dy, dx, stats, bstats, *, B, HW, gamma, beta, eps, silu, dres=None, stats_zeroed=False):
     lib = _lib.load()
     p = _gn_params(x1, x2, B, HW, gamma, beta, eps, silu, stats)
-    p.stats_zeroed = int(stats_zeroed)
     _chk2(dy), _chk2(dx), _chk2(bstats, F32)
     p.dy, p.lddy, p.dx, p.lddx, p.bstats = _p(dy), _ld(dy), _p(dx), _ld(dx), _p(bstats)
     if dres is not None:

@@ -63,9 +63,8 @@ class Runtime:
         return v
 
     def gn_clear(self, which):
-        ar = self._gn_arena[which]
-        if ar[0] is not None and ar[1]:
-            ar[0][: ar[1]].zero_()
+        """(no-op: the GroupNorm statistics are produced by a fixed-order two-stage reduction that overwrites its output -
+        sdlt_groupnorm_fwd / _bwd - so nothing has to be cleared between passes any more)"""
 
     def scratch(self, key, nfloats):
         """fp32 scratch shared by every layer: valid only inside the op call that receives it (all ops run on one stream)."""
