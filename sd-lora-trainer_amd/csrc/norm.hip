@@ -47,7 +47,6 @@ struct CatIn {
 //            of the blocks that cover the slot's group: 4 fixed quarters of the row splits by the 4 waves, combined in order.
 __device__ __forceinline__ void gn_reduce_finalize(float (&s)[8], float (&q)[8], int C, float* __restrict__ out, float* __restrict__ ws, int* __restrict__ cnt) {
   __shared__ float sch[4][64][2];
-  __shared__ float part[4][64];
   __shared__ int ticket;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z, cb = gridDim.x, rs = gridDim.y;
@@ -80,15 +79,33 @@ __device__ __forceinline__ void gn_reduce_finalize(float (&s)[8], float (&q)[8],
   __syncthreads();
   if (ticket != cb * rs - 1) return;
   __threadfence();
-  // blocks whose 64 channels intersect group g
-  const int bxlo = (g * cpg) / 64, bxhi = ((g + 1) * cpg - 1) / 64;
-  const int q0 = (rs * wave) / 4, q1 = (rs * (wave + 1)) / 4;
-  float a = 0.f;
-  for (int by = q0; by < q1; ++by)
-    for (int bx = bxlo; bx <= bxhi; ++bx) a += ws[(((size_t)b * rs + by) * cb + bx) * 64 + slot];
-  part[wave][slot] = a;
+  // every block wrote all 64 slots (zeros for the groups it does not touch), so the final sum simply runs over ALL rs * cb rows:
+  // 16 lanes take a row as four float4 (256 B), the 16 lane-groups of the block take rows r = part, part + 16, ... - 8 independent
+  // loads in flight per thread - and the 16 parts are combined in a fixed order.
+  __shared__ f32x4 fin[16][16];
+  {
+    const int quad = tid & 15, prt = tid >> 4;
+    const int rows = rs * cb;
+    const f32x4* base = (const f32x4*)(ws + (size_t)b * rows * 64) + quad;
+    f32x4 acc8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc8[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int r = prt; r < rows; r += 16 * 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int rr = r + 16 * u;
+        if (rr < rows) acc8[u] += base[(size_t)rr * 16];
+      }
+    }
+    fin[prt][quad] = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
+  }
   __syncthreads();
-  if (tid < 64) out[b * 64 + slot] = (part[0][slot] + part[1][slot]) + (part[2][slot] + part[3][slot]);
+  if (tid < 16) {
+    f32x4 t = fin[0][tid];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += fin[k][tid];
+    *(f32x4*)(out + b * 64 + tid * 4) = t;
+  }
   if (tid == 0) __hip_atomic_store(cnt + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -322,7 +339,8 @@ int gn_check(const sdlt_groupnorm_params& p, const char* fn) {
 
 dim3 gn_grid(const sdlt_groupnorm_params& p) {
   int cb = p.C / 64;
-  int want = 2048 / (cb * p.B);                 // ~8 workgroups per CU in total
+  int want = 768 / (cb * p.B);                  // ~3 workgroups per CU in total: every block leaves a row of partial sums that the
+                                                // last block to arrive has to read (gn_reduce_finalize), so not too many
   int maxsplit = (p.HW + 31) / 32;
   int rs = want < 1 ? 1 : (want > maxsplit ? maxsplit : want);
   return dim3(cb, rs, p.B);
