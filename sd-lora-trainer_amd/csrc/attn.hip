@@ -49,6 +49,19 @@ __device__ __forceinline__ bf16x8 lds_tr_frag(const char* p, int stride) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// LDS tile geometry.  d = 64 (every SDXL head; DP = 64): 128-byte rows with the 16-byte chunk index XOR-ed by row bits 1 and 3,
+//   chunk' = chunk ^ (((row >> 1) & 1) * 2 + ((row >> 3) & 1) * 4).
+// With the +16-byte padded rows used before (and still for the other head widths) the two 16-lane halves of a transposing read
+// (rows r..r+3 and r+8..r+11, 32 B each) overlap in 8 of their 16 bank groups for EVERY pitch that keeps rows 16-byte aligned -
+// 38-41 % of the attention kernels' LDS cycles were bank-conflict cycles (PMC, round 1).  Under the XOR the 8 rows of such a half
+// land in 8 different 32-byte bank groups, the 16 lanes of a ds_read_b128 lane group (rows {0-3, 24-27} chunk c / rows {8-11,
+// 16-19} chunk c+1 of the permuted fragments, or 16 consecutive rows) in 16 different 16-byte groups, and a row's eight 16-byte
+// stores stay a permutation of one 128-byte line.
+template <int DP>
+__device__ __host__ constexpr int tile_stride() { return DP == 64 ? 128 : DP * 2 + 16; }
+template <int DP>
+__device__ __forceinline__ int row_sw(int row) { return DP == 64 ? ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2)) : 0; }
+
 // Tiles are staged global -> registers -> LDS in two halves so the HBM/L2 latency of tile t+1 hides under the MFMAs
 // of tile t (registers are loaded before the compute phase and written to the other LDS buffer after it).
 // natural tile: [64 rows][DP] (row stride NSTR bytes) <- src[(row0+row)*ld + col0 + c]; rows >= nrows or c >= d read as 0
@@ -67,18 +80,18 @@ __device__ __forceinline__ void gload_nat(TileRegs<DP>& t, const bf16_t* src, in
 }
 template <int DP>
 __device__ __forceinline__ void sstore_nat(const TileRegs<DP>& t, char* dst) {
-  constexpr int NSTR = DP * 2 + 16, CH = DP / 8;
+  constexpr int NSTR = tile_stride<DP>(), CH = DP / 8;
 #pragma unroll
   for (int i = 0; i < DP / 32; ++i) {
     int c = threadIdx.x + 256 * i;
     int row = c / CH, ch = c - row * CH;
-    *(uint4*)(dst + row * NSTR + ch * 16) = t.r[i];
+    *(uint4*)(dst + row * NSTR + ((ch ^ row_sw<DP>(row)) << 4)) = t.r[i];
   }
 }
 // =============================================================================== forward
 template <int DP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const sdlt_attn_params p) {
-  constexpr int NSTR = DP * 2 + 16;
+  constexpr int NSTR = tile_stride<DP>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
@@ -104,6 +117,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const sdlt_attn_params p)
   sstore_nat<DP>(kr, smem);
   sstore_nat<DP>(vr, smem + 64 * NSTR);
   const int troff = (8 * g + (i >> 2)) * NSTR + (i & 3) * 8;   // transposing-read lane offset inside a natural tile
+  const int tsw = row_sw<DP>(8 * g + (i >> 2)) >> 1;   // this lane's XOR on the 32-byte column block of a transposing read
   __syncthreads();
   int it = 0;
   for (int k0 = 0; k0 < kend; k0 += 64, ++it) {
@@ -122,7 +136,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const sdlt_attn_params p)
       const int krow = (kf >> 1) * 32 + prow(i, kf & 1);
 #pragma unroll
       for (int kk = 0; kk < DP / 32; ++kk) {
-        bf16x8 kfr = *(const bf16x8*)(Ks + krow * NSTR + (kk * 32 + g * 8) * 2);
+        bf16x8 kfr = *(const bf16x8*)(Ks + krow * NSTR + (((kk * 4 + g) ^ row_sw<DP>(krow)) << 4));
         s[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[kk], s[kf], 0, 0, 0);
       }
     }
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const sdlt_attn_params p)
       bf16x8 pf = pack8(a4, b4);
 #pragma unroll
       for (int df = 0; df < DP / 16; ++df) {
-        bf16x8 vf = lds_tr_frag(Vs + troff + kb * 32 * NSTR + df * 32, NSTR);   // V[key block kb][columns df*16..]^T
+        bf16x8 vf = lds_tr_frag(Vs + troff + kb * 32 * NSTR + ((df ^ tsw) << 5), NSTR);   // V[key block kb][columns df*16..]^T
         o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[df], 0, 0, 0);
       }
     }
@@ -198,7 +212,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const sdlt_attn_params p)
 // =============================================================================== backward dQ (per 64-query tile)
 template <int DP, bool WRITE_D>
 __device__ __forceinline__ void attn_bwd_dq_body(const sdlt_attn_params& p, char* smem, const int bx) {
-  constexpr int NSTR = DP * 2 + 16;
+  constexpr int NSTR = tile_stride<DP>();
   const int b = blockIdx.z, h = blockIdx.y, q0 = bx * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
   const int d = p.d, hc = h * d;
@@ -234,6 +248,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const sdlt_attn_params& p, char
   constexpr int QBUF = 2 * 64 * NSTR;   // K, V natural
   TileRegs<DP> kr, vr;
   const int troff = (8 * g + (i >> 2)) * NSTR + (i & 3) * 8;
+  const int tsw = row_sw<DP>(8 * g + (i >> 2)) >> 1;   // this lane's XOR on the 32-byte column block of a transposing read
   {
     const int nk = min(64, p.Nkp);
     gload_nat<DP>(kr, (const bf16_t*)p.K, p.ldk, (int64_t)b * p.Nkp, nk, hc, d);
@@ -260,9 +275,9 @@ __device__ __forceinline__ void attn_bwd_dq_body(const sdlt_attn_params& p, char
       const int krow = (kf >> 1) * 32 + prow(i, kf & 1);
 #pragma unroll
       for (int kk = 0; kk < DP / 32; ++kk) {
-        bf16x8 kfr = *(const bf16x8*)(Ks + krow * NSTR + (kk * 32 + g * 8) * 2);
+        bf16x8 kfr = *(const bf16x8*)(Ks + krow * NSTR + (((kk * 4 + g) ^ row_sw<DP>(krow)) << 4));
         s[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[kk], s[kf], 0, 0, 0);
-        bf16x8 vfr = *(const bf16x8*)(Vs + krow * NSTR + (kk * 32 + g * 8) * 2);
+        bf16x8 vfr = *(const bf16x8*)(Vs + krow * NSTR + (((kk * 4 + g) ^ row_sw<DP>(krow)) << 4));
         dp[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, gf[kk], dp[kf], 0, 0, 0);
       }
     }
@@ -294,7 +309,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const sdlt_attn_params& p, char
       bf16x8 dsf = pack8(a4, b4);
 #pragma unroll
       for (int df = 0; df < DP / 16; ++df) {
-        bf16x8 ktf = lds_tr_frag(Ks + troff + kb * 32 * NSTR + df * 32, NSTR);
+        bf16x8 ktf = lds_tr_frag(Ks + troff + kb * 32 * NSTR + ((df ^ tsw) << 5), NSTR);
         dq[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dq[df], 0, 0, 0);
       }
     }
@@ -322,7 +337,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const sdlt_attn_params& p, char
 // =============================================================================== backward dK,dV (per 64-key tile, optional query split)
 template <int DP>
 __device__ __forceinline__ void attn_bwd_dkdv_body(const sdlt_attn_params& p, char* smem, const int bx) {
-  constexpr int NSTR = DP * 2 + 16;
+  constexpr int NSTR = tile_stride<DP>();
   const int b = blockIdx.z, h = blockIdx.y;
   const int ktile = bx / p.qsplit, split = bx - ktile * p.qsplit;
   const int k0 = ktile * 64;
@@ -353,6 +368,7 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const sdlt_attn_params& p, ch
   constexpr bool DB = 2 * KBUF <= 160 * 1024;                 // double-buffered unless it would not fit the LDS
   TileRegs<DP> qr, gr;
   const int troff = (8 * g + (i >> 2)) * NSTR + (i & 3) * 8;
+  const int tsw = row_sw<DP>(8 * g + (i >> 2)) >> 1;   // this lane's XOR on the 32-byte column block of a transposing read
   float lreg = 0.f, dreg = 0.f;
   auto gload_all = [&](int qt) {
     const int q0 = qt * 64;
@@ -395,9 +411,9 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const sdlt_attn_params& p, ch
       const int qrow = (qf >> 1) * 32 + prow(i, qf & 1);
 #pragma unroll
       for (int kk = 0; kk < DP / 32; ++kk) {
-        bf16x8 qfr = *(const bf16x8*)(Qs + qrow * NSTR + (kk * 32 + g * 8) * 2);
+        bf16x8 qfr = *(const bf16x8*)(Qs + qrow * NSTR + (((kk * 4 + g) ^ row_sw<DP>(qrow)) << 4));
         s[qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kk], s[qf], 0, 0, 0);
-        bf16x8 gfr = *(const bf16x8*)(Gs + qrow * NSTR + (kk * 32 + g * 8) * 2);
+        bf16x8 gfr = *(const bf16x8*)(Gs + qrow * NSTR + (((kk * 4 + g) ^ row_sw<DP>(qrow)) << 4));
         dp[qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gfr, vf[kk], dp[qf], 0, 0, 0);
       }
     }
@@ -438,9 +454,9 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const sdlt_attn_params& p, ch
       bf16x8 dsf = pack8(c4, e4);
 #pragma unroll
       for (int df = 0; df < DP / 16; ++df) {
-        bf16x8 gtf = lds_tr_frag(Gs + troff + qb * 32 * NSTR + df * 32, NSTR);
+        bf16x8 gtf = lds_tr_frag(Gs + troff + qb * 32 * NSTR + ((df ^ tsw) << 5), NSTR);
         dv[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gtf, pf, dv[df], 0, 0, 0);
-        bf16x8 qtf = lds_tr_frag(Qs + troff + qb * 32 * NSTR + df * 32, NSTR);
+        bf16x8 qtf = lds_tr_frag(Qs + troff + qb * 32 * NSTR + ((df ^ tsw) << 5), NSTR);
         dk[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf, dk[df], 0, 0, 0);
       }
     }
@@ -528,7 +544,7 @@ __global__ void attn_prep_kernel(const bf16_t* O, int64_t ldo, const bf16_t* dO,
 // prep + dQ + query-split dK/dV launches of the generic path for the UNet's cross-attention.
 template <int DP>
 __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_params p) {
-  constexpr int NSTR = DP * 2 + 16;
+  constexpr int NSTR = tile_stride<DP>();
   constexpr int QBUF = 2 * 64 * NSTR;                   // Q, dO natural
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;                                      // [128][NSTR], resident
@@ -540,6 +556,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
   const int d = p.d, hc = h * d;
   const float sl2 = p.scale * LOG2E;
   const int troff = (8 * g + (i >> 2)) * NSTR + (i & 3) * 8;
+  const int tsw = row_sw<DP>(8 * g + (i >> 2)) >> 1;   // this lane's XOR on the 32-byte column block of a transposing read
 
   TileRegs<DP> qr, gr;
 #pragma unroll
@@ -605,8 +622,8 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
 #pragma unroll
       for (int kk = 0; kk < DP / 32; ++kk) {
         const int col = kk * 32 + g * 8;
-        qf[kk] = *(const bf16x8*)(Qs + ql * NSTR + col * 2);
-        gf[kk] = *(const bf16x8*)(Gs + ql * NSTR + col * 2);
+        qf[kk] = *(const bf16x8*)(Qs + ql * NSTR + (((kk * 4 + g) ^ row_sw<DP>(ql)) << 4));
+        gf[kk] = *(const bf16x8*)(Gs + ql * NSTR + (((kk * 4 + g) ^ row_sw<DP>(ql)) << 4));
         bf16x8 of = ld_frag_global((const bf16_t*)p.O + ((int64_t)b * p.Nqp + q) * p.ldo + hc + col, qok && col < d);
 #pragma unroll
         for (int j = 0; j < 8; ++j) Dq += (float)gf[kk][j] * (float)of[j];
@@ -632,9 +649,9 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
           const int krow = half * 64 + (f >> 1) * 32 + prow(i, f & 1);
 #pragma unroll
           for (int kk = 0; kk < DP / 32; ++kk) {
-            bf16x8 kfr = *(const bf16x8*)(Ks + krow * NSTR + (kk * 32 + g * 8) * 2);
+            bf16x8 kfr = *(const bf16x8*)(Ks + krow * NSTR + (((kk * 4 + g) ^ row_sw<DP>(krow)) << 4));
             s2[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[kk], s2[f], 0, 0, 0);
-            bf16x8 vfr = *(const bf16x8*)(Vs + krow * NSTR + (kk * 32 + g * 8) * 2);
+            bf16x8 vfr = *(const bf16x8*)(Vs + krow * NSTR + (((kk * 4 + g) ^ row_sw<DP>(krow)) << 4));
             dp2[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, gf[kk], dp2[f], 0, 0, 0);
           }
         }
@@ -654,7 +671,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
           bf16x8 dsf = pack8(a4, b4);
 #pragma unroll
           for (int df = 0; df < DP / 16; ++df) {
-            bf16x8 ktf = lds_tr_frag(Ks + troff + (half * 64 + kb * 32) * NSTR + df * 32, NSTR);
+            bf16x8 ktf = lds_tr_frag(Ks + troff + (half * 64 + kb * 32) * NSTR + ((df ^ tsw) << 5), NSTR);
             dq[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dq[df], 0, 0, 0);
           }
         }
@@ -695,8 +712,8 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
         const int qrow = (f >> 1) * 32 + prow(i, f & 1);
 #pragma unroll
         for (int kk = 0; kk < DP / 32; ++kk) {
-          bf16x8 qfr = *(const bf16x8*)(Qs + qrow * NSTR + (kk * 32 + g * 8) * 2);
-          bf16x8 gfr = *(const bf16x8*)(Gs + qrow * NSTR + (kk * 32 + g * 8) * 2);
+          bf16x8 qfr = *(const bf16x8*)(Qs + qrow * NSTR + (((kk * 4 + g) ^ row_sw<DP>(qrow)) << 4));
+          bf16x8 gfr = *(const bf16x8*)(Gs + qrow * NSTR + (((kk * 4 + g) ^ row_sw<DP>(qrow)) << 4));
 #pragma unroll
           for (int w = 0; w < 2; ++w) {
             s[w][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[w][kk], s[w][f], 0, 0, 0);
@@ -730,8 +747,8 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
         }
 #pragma unroll
         for (int df = 0; df < DP / 16; ++df) {
-          bf16x8 gtf = lds_tr_frag(Gs + troff + qb * 32 * NSTR + df * 32, NSTR);
-          bf16x8 qtf = lds_tr_frag(Qs + troff + qb * 32 * NSTR + df * 32, NSTR);
+          bf16x8 gtf = lds_tr_frag(Gs + troff + qb * 32 * NSTR + ((df ^ tsw) << 5), NSTR);
+          bf16x8 qtf = lds_tr_frag(Qs + troff + qb * 32 * NSTR + ((df ^ tsw) << 5), NSTR);
 #pragma unroll
           for (int w = 0; w < 2; ++w) {
             dv[w][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gtf, pf[w], dv[w][df], 0, 0, 0);
@@ -851,7 +868,8 @@ extern "C" int sdlt_attn_fwd(const sdlt_attn_params* pp, void* stream) {
   if (p.ldo % 4) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_attn_fwd: ldo %% 4");
   const int dp = attn_dp(p.d);
   dim3 grid((p.Nq + 63) / 64, p.H, p.B);
-#define SMEM_FWD(D_) (2 * (2 * 64 * ((D_) * 2 + 16)))
+#define NSTRH(D_) ((D_) == 64 ? 128 : (D_) * 2 + 16)
+#define SMEM_FWD(D_) (2 * (2 * 64 * NSTRH(D_)))
   ATTN_DISPATCH(dp, attn_fwd_kernel, grid, SMEM_FWD)
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
@@ -885,7 +903,7 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
     // cross-attention: prep + dQ + dK/dV in one kernel (see attn_bwd_cross_kernel); qsplit = workgroups along the queries,
     // dK32 / dV32 = [qsplit][B*Nkp][ld32] partial slabs (any contents)
     dim3 gx(p.qsplit, p.H, p.B);
-#define SMEM_X(D_) (2 * 128 * ((D_) * 2 + 16) + 2 * (2 * 64 * ((D_) * 2 + 16)) + 512)
+#define SMEM_X(D_) (2 * 128 * NSTRH(D_) + 2 * (2 * 64 * NSTRH(D_)) + 512)
     if (dp == 64) { set_smem(attn_bwd_cross_kernel<64>, SMEM_X(64)); hipLaunchKernelGGL(attn_bwd_cross_kernel<64>, gx, dim3(256), SMEM_X(64), s, p); }
     else { set_smem(attn_bwd_cross_kernel<96>, SMEM_X(96)); hipLaunchKernelGGL(attn_bwd_cross_kernel<96>, gx, dim3(256), SMEM_X(96), s, p); }
     {
@@ -905,18 +923,18 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(attn_prep_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)p.O, p.ldo, (const bf16_t*)p.dO, p.lddo, p.B, p.H, p.Nq, p.Nqp, p.d, p.D);
     dim3 gb((p.Nq + 63) / 64 + (p.Nk + 63) / 64, p.H, p.B);
-#define SMEM_BOTH(D_) (2 * (2 * 64 * ((D_) * 2 + 16) + 512))
+#define SMEM_BOTH(D_) (2 * (2 * 64 * NSTRH(D_) + 512))
     ATTN_DISPATCH(dp, attn_bwd_both_kernel, gb, SMEM_BOTH)
     SDLT_CHECK_LAUNCH();
     return SDLT_OK;
   }
   if (p.accumulate_dq || p.accumulate_dk) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_attn_bwd: accumulate_dq/dk exist for the single-pass cross-attention kernel only");
   dim3 gq((p.Nq + 63) / 64, p.H, p.B);
-#define SMEM_DQ(D_) (2 * (2 * 64 * ((D_) * 2 + 16)))
+#define SMEM_DQ(D_) (2 * (2 * 64 * NSTRH(D_)))
   ATTN_DISPATCH(dp, attn_bwd_dq_kernel, gq, SMEM_DQ)
   if (p.qsplit > 1) zero32();
   dim3 gk(((p.Nk + 63) / 64) * p.qsplit, p.H, p.B);
-#define SMEM_DKV(D_) (2 * (2 * 64 * ((D_) * 2 + 16) + 512))
+#define SMEM_DKV(D_) (2 * (2 * 64 * NSTRH(D_) + 512))
   ATTN_DISPATCH(dp, attn_bwd_dkdv_kernel, gk, SMEM_DKV)
   if (p.qsplit > 1) cvt32();
   SDLT_CHECK_LAUNCH();

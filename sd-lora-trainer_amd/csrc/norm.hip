@@ -38,16 +38,19 @@ struct CatIn {
 };
 
 
-// Deterministic two-stage reduction of the per-(batch, group) statistics (no float atomics: a fixed summation order makes
-// two runs - and a hipGraph replay vs the eager pass - bitwise identical).
-//   stage 1: the block's 4 waves leave their per-channel sums in LDS; thread t < 64 (statistic slot t = group * 2 + kind) adds the
-//            channels of its group that fall into this block, waves 0..3, in a fixed order, and the 64 slots go to the
-//            block's row of the workspace  ws[((b * rs + by) * cb + bx) * 64 + t];
-//   stage 2: the LAST block of batch b to arrive (agent-scope counter, re-armed for the next launch) sums, per slot, the rows
-//            of the blocks that cover the slot's group: 4 fixed quarters of the row splits by the 4 waves, combined in order.
-__device__ __forceinline__ void gn_reduce_finalize(float (&s)[8], float (&q)[8], int C, float* __restrict__ out, float* __restrict__ ws, int* __restrict__ cnt) {
+// Deterministic two-stage reduction of the per-(batch, group) statistics (no float atomics, no zero fills, no fences: a fixed
+// summation order makes two runs - and a hipGraph replay vs the eager pass - bitwise identical).
+//   stage 1 (the statistics kernel): the block's 4 waves leave their per-channel sums in LDS; thread t < 64 (statistic slot
+//            t = group * 2 + kind) adds the channels of its group that fall into this block, waves 0..3, in a fixed order, and the
+//            64 slots (zeros for groups the block does not touch) go to the block's row of the workspace
+//            ws[((b * rs + by) * cb + bx) * 64 + t];
+//   stage 2 (the PROLOGUE of the kernel that consumes the statistics - it exists anyway, and the launch boundary publishes the rows):
+//            every block sums, for the slots of the groups its 64 channels belong to, the rows of all row splits of the blocks
+//            covering the group - the 256 threads split (slot, part-of-the-rows), all of a thread's loads in flight at once, the
+//            parts combined in order - into LDS.  Every block computes the same bits; the blocks of row split 0 also store them
+//            to `out` for later kernels (backward, affine gradients).
+__device__ __forceinline__ void gn_block_partials(float (&s)[8], float (&q)[8], int C, float* __restrict__ ws) {
   __shared__ float sch[4][64][2];
-  __shared__ int ticket;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z, cb = gridDim.x, rs = gridDim.y;
   const int cpg = C / G;
@@ -62,58 +65,67 @@ __device__ __forceinline__ void gn_reduce_finalize(float (&s)[8], float (&q)[8],
     for (int j = 0; j < 8; ++j) { sch[wave][(lane & 7) * 8 + j][0] = s[j]; sch[wave][(lane & 7) * 8 + j][1] = q[j]; }
   }
   __syncthreads();
-  const int slot = tid & 63, g = slot >> 1, kind = slot & 1;
   if (tid < 64) {
+    const int g = tid >> 1, kind = tid & 1;
     const int blo = (int)blockIdx.x * 64;
     const int clo = g * cpg > blo ? g * cpg : blo, chi = (g + 1) * cpg < blo + 64 ? (g + 1) * cpg : blo + 64;
     float a = 0.f;
     for (int c = clo; c < chi; ++c) {
-      const int cl = c - blockIdx.x * 64;
+      const int cl = c - blo;
       a += ((sch[0][cl][kind] + sch[1][cl][kind]) + (sch[2][cl][kind] + sch[3][cl][kind]));
     }
-    ws[(((size_t)b * rs + blockIdx.y) * cb + blockIdx.x) * 64 + slot] = a;
+    ws[(((size_t)b * rs + blockIdx.y) * cb + blockIdx.x) * 64 + tid] = a;
   }
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) ticket = __hip_atomic_fetch_add(cnt + b, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (ticket != cb * rs - 1) return;
-  __threadfence();
-  // every block wrote all 64 slots (zeros for the groups it does not touch), so the final sum simply runs over ALL rs * cb rows:
-  // 16 lanes take a row as four float4 (256 B), the 16 lane-groups of the block take rows r = part, part + 16, ... - 8 independent
-  // loads in flight per thread - and the 16 parts are combined in a fixed order.
-  __shared__ f32x4 fin[16][16];
-  {
-    const int quad = tid & 15, prt = tid >> 4;
-    const int rows = rs * cb;
-    const f32x4* base = (const f32x4*)(ws + (size_t)b * rows * 64) + quad;
-    f32x4 acc8[8];
+}
+
+// stage 2: -> fin[64] (LDS; valid for the slots of the groups this block's 64 channels belong to) [+ out, row split 0]
+__device__ __forceinline__ void gn_combine_partials(int C, const float* __restrict__ ws, float* __restrict__ fin, float* __restrict__ out) {
+  __shared__ float parts[256];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z, cb = gridDim.x, rs = gridDim.y;
+  const int cpg = C / G;
+  const int glo = ((int)blockIdx.x * 64) / cpg, ghi = ((int)blockIdx.x * 64 + 63) / cpg;
+  const int ns = (ghi - glo + 1) * 2;                       // slots this block needs
+  int p2 = 2;
+  while (p2 < ns) p2 <<= 1;                                  // <= 64
+  const int sl = tid & (p2 - 1), part = tid / p2, nparts = 256 / p2;
+  const int slot = glo * 2 + sl, g = slot >> 1;
+  float acc = 0.f;
+  if (sl < ns) {
+    const int bxlo = (g * cpg) / 64, bxhi = ((g + 1) * cpg - 1) / 64;
+    const int nbx = bxhi - bxlo + 1, rows = rs * nbx;
+    const float* base = ws + (size_t)b * rs * cb * 64 + slot;
+    float a8[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc8[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int r = prt; r < rows; r += 16 * 8) {
+    for (int u = 0; u < 8; ++u) a8[u] = 0.f;
+    for (int r = part; r < rows; r += nparts * 8) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int rr = r + 16 * u;
-        if (rr < rows) acc8[u] += base[(size_t)rr * 16];
+        const int rr = r + nparts * u;
+        if (rr < rows) {
+          const int by = rr / nbx, bx = bxlo + (rr - by * nbx);
+          a8[u] += base[((size_t)by * cb + bx) * 64];
+        }
       }
     }
-    fin[prt][quad] = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
+    acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+  }
+  parts[tid] = acc;
+  __syncthreads();
+  if (tid < p2 && tid < ns) {
+    float t = parts[tid];
+    for (int k = 1; k < nparts; ++k) t += parts[k * p2 + tid];
+    fin[slot] = t;
+    if (out && blockIdx.y == 0) out[b * 64 + slot] = t;
   }
   __syncthreads();
-  if (tid < 16) {
-    f32x4 t = fin[0][tid];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) t += fin[k][tid];
-    *(f32x4*)(out + b * 64 + tid * 4) = t;
-  }
-  if (tid == 0) __hip_atomic_store(cnt + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------- GroupNorm
 // grid (C/64, rowsplit, B), block 256 = 4 waves; thread: fixed chunk c0 = bx*64 + (lane&7)*8,
 // rows r = ry*32.. step gridDim.y*32, sub-row = wave*8 + lane/8.
 // stats[b][g] = {sum, sumsq} accumulated with atomics (zeroed by the entry point).
-__global__ __launch_bounds__(256) void gn_stats_kernel(CatIn in, int HW, int C, float* stats, float* ws, int* cnt) {
+__global__ __launch_bounds__(256) void gn_stats_kernel(CatIn in, int HW, int C, float* ws) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z;
   const int c0 = blockIdx.x * 64 + (lane & 7) * 8;
@@ -126,13 +138,15 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(CatIn in, int HW, int C, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
   }
-  gn_reduce_finalize(s, q, C, stats, ws, cnt);
+  gn_block_partials(s, q, C, ws);
 }
 
 template <bool SILU>
-__global__ __launch_bounds__(256) void gn_apply_kernel(CatIn in, int HW, int C, const float* stats,
+__global__ __launch_bounds__(256) void gn_apply_kernel(CatIn in, int HW, int C, float* stats_out, const float* ws,
                                                         const float* gamma, const float* beta, float eps,
                                                         bf16_t* y, int64_t ldy) {
+  __shared__ float stats[G * 2];
+  gn_combine_partials(C, ws, stats, stats_out);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z;
   const int c0 = blockIdx.x * 64 + (lane & 7) * 8;
@@ -142,8 +156,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(CatIn in, int HW, int C, 
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     int g = (c0 + j) / cpg;
-    float mean = stats[(b * G + g) * 2] * inv_n;
-    float var = fmaxf(stats[(b * G + g) * 2 + 1] * inv_n - mean * mean, 0.f);
+    float mean = stats[g * 2] * inv_n;
+    float var = fmaxf(stats[g * 2 + 1] * inv_n - mean * mean, 0.f);
     float rstd = rsqrtf(var + eps);
     sc[j] = rstd * gamma[c0 + j];
     sh[j] = beta[c0 + j] - mean * sc[j];
@@ -165,7 +179,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(CatIn in, int HW, int C, 
 template <bool SILU>
 __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(CatIn in, const bf16_t* dy, int64_t lddy, int HW, int C,
                                                             const float* stats, const float* gamma, const float* beta,
-                                                            float eps, float* bstats, float* ws, int* cnt) {
+                                                            float eps, float* ws) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z;
   const int c0 = blockIdx.x * 64 + (lane & 7) * 8;
@@ -195,14 +209,16 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(CatIn in, const bf16_
       s1[j] += dxh; s2[j] += dxh * xh;
     }
   }
-  gn_reduce_finalize(s1, s2, C, bstats, ws, cnt);
+  gn_block_partials(s1, s2, C, ws);
 }
 
 template <bool SILU>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(CatIn in, const bf16_t* dy, int64_t lddy, int HW, int C,
-                                                            const float* stats, const float* bstats, const float* gamma,
+                                                            const float* stats, float* bstats_out, const float* ws, const float* gamma,
                                                             const float* beta, float eps, const bf16_t* dres, int64_t lddres,
                                                             bf16_t* dx, int64_t lddx) {
+  __shared__ float bstats[G * 2];
+  gn_combine_partials(C, ws, bstats, bstats_out);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z;
   const int c0 = blockIdx.x * 64 + (lane & 7) * 8;
@@ -216,8 +232,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(CatIn in, const bf16_
     float var = fmaxf(stats[(b * G + g) * 2 + 1] * inv_n - mean[j] * mean[j], 0.f);
     rstd[j] = rsqrtf(var + eps);
     gm[j] = gamma[c0 + j]; bt[j] = beta[c0 + j];
-    m1[j] = bstats[(b * G + g) * 2] * inv_n;
-    m2[j] = bstats[(b * G + g) * 2 + 1] * inv_n;
+    m1[j] = bstats[g * 2] * inv_n;
+    m2[j] = bstats[g * 2 + 1] * inv_n;
   }
   for (int r = blockIdx.y * 32 + wave * 8 + (lane >> 3); r < HW; r += gridDim.y * 32) {
     float v[8], d[8], o[8];
@@ -348,7 +364,7 @@ dim3 gn_grid(const sdlt_groupnorm_params& p) {
 
 int gn_ws_check(const sdlt_groupnorm_params& p, dim3 grid, const char* fn) {
   const int64_t need = (int64_t)grid.x * grid.y * grid.z * 64;
-  if (!p.ws || !p.cnt || p.ws_floats < need || p.B > p.cnt_len)
+  if (!p.ws || p.ws_floats < need)
     SDLT_FAIL(SDLT_ERR_SHAPE, "%s: statistics workspace too small (%lld floats / %d counters needed)", fn, (long long)need, p.B);
   return SDLT_OK;
 }
@@ -372,11 +388,11 @@ extern "C" int sdlt_groupnorm_fwd(const sdlt_groupnorm_params* pp, void* stream)
   dim3 grid = gn_grid(p);
   rc = gn_ws_check(p, grid, "sdlt_groupnorm_fwd");
   if (rc) return rc;
-  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, s, in, p.HW, p.C, p.stats, p.ws, p.cnt);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, s, in, p.HW, p.C, p.ws);
   if (p.silu)
-    hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(256), 0, s, in, p.HW, p.C, p.stats, p.gamma, p.beta, p.eps, (bf16_t*)p.y, p.ldy);
+    hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(256), 0, s, in, p.HW, p.C, p.stats, p.ws, p.gamma, p.beta, p.eps, (bf16_t*)p.y, p.ldy);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(256), 0, s, in, p.HW, p.C, p.stats, p.gamma, p.beta, p.eps, (bf16_t*)p.y, p.ldy);
+    hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(256), 0, s, in, p.HW, p.C, p.stats, p.ws, p.gamma, p.beta, p.eps, (bf16_t*)p.y, p.ldy);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }
@@ -392,11 +408,11 @@ extern "C" int sdlt_groupnorm_bwd(const sdlt_groupnorm_params* pp, void* stream)
   rc = gn_ws_check(p, grid, "sdlt_groupnorm_bwd");
   if (rc) return rc;
   if (p.silu) {
-    hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.gamma, p.beta, p.eps, p.bstats, p.ws, p.cnt);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.bstats, p.gamma, p.beta, p.eps, (const bf16_t*)p.dres, p.lddres, (bf16_t*)p.dx, p.lddx);
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.gamma, p.beta, p.eps, p.ws);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.bstats, p.ws, p.gamma, p.beta, p.eps, (const bf16_t*)p.dres, p.lddres, (bf16_t*)p.dx, p.lddx);
   } else {
-    hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.gamma, p.beta, p.eps, p.bstats, p.ws, p.cnt);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.bstats, p.gamma, p.beta, p.eps, (const bf16_t*)p.dres, p.lddres, (bf16_t*)p.dx, p.lddx);
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.gamma, p.beta, p.eps, p.ws);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.bstats, p.ws, p.gamma, p.beta, p.eps, (const bf16_t*)p.dres, p.lddres, (bf16_t*)p.dx, p.lddx);
   }
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
