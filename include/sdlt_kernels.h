@@ -189,9 +189,9 @@ typedef struct sdlt_groupnorm_params {
   const void* dres; int64_t lddres;
   void* dx; int64_t lddx;
   float* bstats;
-  /* statistics are reduced in a FIXED order (bitwise reproducible, no float atomics): every block leaves 64 partial sums in
-     `ws` and the last block of a batch element to arrive combines them (counters `cnt`, one per batch element, zero on entry
-     and re-armed by the kernel).  ws / cnt are scratch: only live inside the call; ws_floats >= sdlt_groupnorm_ws_floats(). */
+  /* statistics are reduced in a FIXED order (bitwise reproducible; no float atomics, zero fills or fences): the statistics
+     kernel leaves 64 partial sums per block in `ws`, the kernel that consumes them (apply / dX) adds the rows in its
+     prologue.  ws is scratch, only live inside the call: ws_floats >= sdlt_groupnorm_ws_floats(); cnt / cnt_len: reserved. */
   float* ws; int64_t ws_floats;
   int32_t* cnt; int32_t cnt_len;
   int32_t pad_;
@@ -324,10 +324,10 @@ int sdlt_ti_std_reg(const float* rows, int32_t n, int32_t D, float target_mean, 
 
 /* dX of nearest-2x upsampling: out[b,h,w,:] = sum of the 2x2 block of in [B,2H,2W,C]. */
 int sdlt_sum2x2(const void* in, int32_t B, int32_t H, int32_t W, int32_t C, void* out, void* stream);
-/* out[b,c] = sum_r x[b*R + r, c]: fp32 [B,C] (always written; doubles as the reduction scratch) and optionally a bf16 copy -
- * gradient of the per-batch
- * time-embedding bias of a ResnetBlock2D (h + time_emb_proj(silu(temb))[:, :, None, None]). */
-int sdlt_colsum(const void* x, int64_t ldx, int32_t B, int32_t R, int32_t C, float* out, void* out_bf16, void* stream);
+/* out[b,c] = sum_r x[b*R + r, c] as fp32 [B,C] and / or bf16 [B,C] (either may be NULL) - gradient of the per-batch time-embedding
+ * bias of a ResnetBlock2D (h + time_emb_proj(silu(temb))[:, :, None, None]).  Row splits meet in the scratch `ws`
+ * (>= min(32, ceil(R/256)) * B * C floats, any contents) and are added in a fixed order: bitwise reproducible. */
+int sdlt_colsum(const void* x, int64_t ldx, int32_t B, int32_t R, int32_t C, float* ws, int64_t ws_floats, float* out, void* out_bf16, void* stream);
 
 #ifdef __cplusplus
 }

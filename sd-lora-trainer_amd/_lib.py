@@ -124,7 +124,7 @@ SYMBOLS = {
     "sdlt_lora_shadow_refresh": (i32, [vp, vp, vp, i32, vp, vp]),
     "sdlt_adamw_shadow_refresh": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
     "sdlt_sum2x2": (i32, [vp, i32, i32, i32, i32, vp, vp]),
-    "sdlt_colsum": (i32, [vp, i64, i32, i32, i32, vp, vp, vp]),
+    "sdlt_colsum": (i32, [vp, i64, i32, i32, i32, vp, i64, vp, vp, vp]),
     "sdlt_embed_gather": (i32, [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp]),
     "sdlt_embed_grad": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
     "sdlt_ti_std_reg": (i32, [vp, i32, i32, f32, f32, f32, vp, vp, vp]),

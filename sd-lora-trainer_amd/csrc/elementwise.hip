@@ -309,9 +309,10 @@ __global__ void sum2x2_kernel(const bf16_t* in, int B, int H, int W, int C, bf16
 }
 
 // ------------------------------------------------------------------ column sums per batch: out[b, c] = sum_r x[b*R + r, c]
-// grid (C/64, rowsplit, B); same 8 rows x 64 channels wave footprint as the norms; partial sums meet in an fp32 scratch
-// through atomics (zeroed by the entry point), a second tiny kernel converts when a bf16 result is wanted.
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* x, int64_t ldx, int R, int C, float* acc) {
+// grid (C/64, rowsplit, B); same 8 rows x 64 channels wave footprint as the norms.  Every row split leaves its partial sums in its
+// own row of an fp32 scratch ws[split][B*C] (plain stores: no atomics, no zero fill); the second kernel adds the rows in a fixed
+// order (bitwise reproducible) and writes the fp32 and / or bf16 result.
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* x, int64_t ldx, int R, int C, float* ws) {
   __shared__ float sh[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.z, c0 = blockIdx.x * 64 + (lane & 7) * 8;
@@ -331,10 +332,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* x, int64_t ld
     for (int j = 0; j < 8; ++j) sh[wave][(lane & 7) * 8 + j] = s[j];
   __syncthreads();
   if (threadIdx.x < 64)
-    atomicAdd(&acc[(int64_t)b * C + blockIdx.x * 64 + threadIdx.x], sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    ws[((int64_t)blockIdx.y * gridDim.z + b) * C + blockIdx.x * 64 + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
-__global__ void colsum_cvt_kernel(const float* acc, bf16_t* out, int n) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = f2bf(acc[i]);
+__global__ void colsum_finish_kernel(const float* ws, int nsplit, float* out32, bf16_t* out16, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float a = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) a += ws[(int64_t)sp * n + i];
+    if (out32) out32[i] = a;
+    if (out16) out16[i] = f2bf(a);
+  }
 }
 
 inline int grid_for(int64_t work_items, int block = 256) {
@@ -425,14 +431,14 @@ extern "C" int sdlt_sum2x2(const void* in, int32_t B, int32_t H, int32_t W, int3
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }
-extern "C" int sdlt_colsum(const void* x, int64_t ldx, int32_t B, int32_t R, int32_t C, float* out, void* out_bf16, void* stream) {
-  if (B <= 0 || R <= 0 || C <= 0 || (C % 64) || (ldx % 8) || !out) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_colsum: B=%d R=%d C=%d (fp32 out/scratch required)", B, R, C);
+extern "C" int sdlt_colsum(const void* x, int64_t ldx, int32_t B, int32_t R, int32_t C, float* ws, int64_t ws_floats, float* out, void* out_bf16, void* stream) {
+  if (B <= 0 || R <= 0 || C <= 0 || (C % 64) || (ldx % 8) || (!out && !out_bf16)) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_colsum: B=%d R=%d C=%d", B, R, C);
   hipStream_t s = (hipStream_t)stream;
-  sdlt_zero_async(out, sizeof(float) * (size_t)B * C, s);
   int rs = (R + 255) / 256;
-  if (rs > 64) rs = 64;
-  hipLaunchKernelGGL(colsum_kernel, dim3(C / 64, rs, B), dim3(256), 0, s, (const bf16_t*)x, ldx, R, C, out);
-  if (out_bf16) hipLaunchKernelGGL(colsum_cvt_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, (const float*)out, (bf16_t*)out_bf16, B * C);
+  if (rs > 32) rs = 32;
+  if (!ws || ws_floats < (int64_t)rs * B * C) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_colsum: scratch too small (%lld floats needed)", (long long)rs * B * C);
+  hipLaunchKernelGGL(colsum_kernel, dim3(C / 64, rs, B), dim3(256), 0, s, (const bf16_t*)x, ldx, R, C, ws);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, (const float*)ws, rs, out, (bf16_t*)out_bf16, B * C);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }

@@ -618,16 +618,9 @@ def colsum(x, out, *, B, R):
     lib = _lib.load()
     _chk2(x)
     assert out.is_cuda and out.dtype in (F32, BF16) and out.is_contiguous()
-    if out.dtype == F32:
-        f, h = _p(out), C.c_void_p(0)
-    else:
-        key = (x.device, out.data_ptr())
-        sc = _colsum_scratch.get(key)
-        if sc is None:
-            sc = torch.empty(out.shape, dtype=F32, device=x.device)
-            _colsum_scratch[key] = sc
-        f, h = _p(sc), _p(out)
-    _lib.check(lib.sdlt_colsum(_p(x), _ld(x), B, R, x.shape[1], f, h, _stream()), "sdlt_colsum")
+    ws, _ = gn_workspace(x.device)          # the same per-(device, owner) fp32 scratch as the GroupNorm reductions: only live inside a call
+    f, h = (_p(out), C.c_void_p(0)) if out.dtype == F32 else (C.c_void_p(0), _p(out))
+    _lib.check(lib.sdlt_colsum(_p(x), _ld(x), B, R, x.shape[1], _p(ws), ws.numel(), f, h, _stream()), "sdlt_colsum")
     return out
 
 
