@@ -42,6 +42,13 @@ class WeightTrainer:
         self.defer = True
         self._jobs, self._wplan = [], None
         self._affine_jobs, self._aplan = [], None
+        # Data parallel: the matrix region of the arena is laid out CLASS BY CLASS (kind, shape) - the unit the deferred
+        # weight-gradient plan works in - and cut into contiguous buckets of >= bucket_floats; flush(bucket=i) produces exactly
+        # the gradients of bucket i, so its all-reduce can be launched (in place, on the collective's stream) while the next
+        # bucket's weight-gradient GEMMs run (step.TrainStep with a process group).
+        self.bucket_floats = 64 << 20          # 256 MB of fp32 gradients per bucket
+        self.buckets = []                      # [(off0, off1)] over the matrix region, in flush order
+        self.defer_flush = False               # True: UNet.backward leaves the flush to the caller (bucket by bucket)
 
     # ------------------------------------------------------------------ registration (layer constructors)
     def add(self, name, init, kind="matrix"):
@@ -53,10 +60,8 @@ class WeightTrainer:
             self.nv = (self.nv + 3) // 4 * 4
             e = dict(name=name, voff=self.nv, off=None, shape=tuple(init.shape), kind=kind, init=init.detach().to(F32))
             self.nv += init.numel()
-        else:
-            self.n = (self.n + 3) // 4 * 4
-            e = dict(name=name, off=self.n, shape=tuple(init.shape), kind=kind, init=init.detach().to(F32))
-            self.n += init.numel()
+        else:               # the offset is assigned at finalize(): matrices are laid out class by class (see buckets)
+            e = dict(name=name, off=None, seq=len(self.entries), shape=tuple(init.shape), kind=kind, init=init.detach().to(F32))
         self.entries.append(e)
         self.by_name[name] = e
         return e
@@ -69,7 +74,24 @@ class WeightTrainer:
 
     def finalize(self):
         rt = self.rt
+        # matrix region: classes (kind, shape) in order of first registration, members in registration order (stacked q|k|v
+        # projections are registered back to back with one shape, so they stay adjacent); buckets = runs of whole classes
+        classes = {}
+        for e in self.entries:
+            if e["kind"] != "vector":
+                classes.setdefault((e["kind"], e["shape"]), []).append(e)
+        self.n, start = 0, 0
+        for members in classes.values():
+            for e in members:
+                self.n = (self.n + 3) // 4 * 4
+                e["off"] = self.n
+                self.n += int(torch.tensor(e["shape"]).prod())
+            if self.n - start >= self.bucket_floats:
+                self.buckets.append((start, (self.n + 3) // 4 * 4))
+                start = (self.n + 3) // 4 * 4
         self.n_mat = (self.n + 3) // 4 * 4
+        if self.n_mat > start:
+            self.buckets.append((start, self.n_mat))
         for e in self.entries:
             if e["kind"] == "vector":
                 e["off"] = self.n_mat + e.pop("voff")
@@ -179,20 +201,31 @@ class WeightTrainer:
         return [self.rt.ops.AffineGradBatch(m, self.rt.device, groupnorm=m[0]["gn"], B=m[0]["B"], HW=m[0]["HW"], eps=m[0]["eps"], silu=m[0]["silu"])
                 for m in groups.values()]
 
-    def flush(self):
-        """End of a backward pass: run the weight-gradient plan recorded during the first one."""
+    def bucket_of(self, off):
+        for i, (o0, o1) in enumerate(self.buckets):
+            if o0 <= off < o1:
+                return i
+        raise ValueError(off)
+
+    def flush(self, bucket=None):
+        """End of a backward pass: run the weight-gradient plan recorded during the first one.  bucket=None: everything (affine
+        gradients first).  bucket=i: the norm-affine gradients with i == 0, then only the layers whose weights lie in arena bucket i
+        - afterwards grads[buckets[i]] is final (the vector region - biases, norm affine - only after the LAST bucket)."""
         if not self.defer:
             return
-        if self._aplan is None:
-            self._aplan = self._build_aplan(self._affine_jobs)
-            self._affine_jobs = None
-        for ab in self._aplan:
-            ab.run()
+        if bucket in (None, 0):
+            if self._aplan is None:
+                self._aplan = self._build_aplan(self._affine_jobs)
+                self._affine_jobs = None
+            for ab in self._aplan:
+                ab.run()
         if self._wplan is None:
             self._wplan = self._build_wplan(self._jobs)
             self._jobs = None
         ops = self.rt.ops
-        for panels, gemms in self._wplan:
+        for bidx, panels, gemms in self._wplan:
+            if bucket is not None and bidx != bucket:
+                continue
             for pb in panels:
                 pb.run()
             for (X, W, C_, batch, tile) in gemms:
@@ -237,7 +270,10 @@ class WeightTrainer:
                 else:               # a few long-K problems (the 128x128-resolution convs): individual launches keep their split-K
                     gemms += [(dyT[i], xT[i], outs[i], None, 0) for i in range(n)]
             assert k0 == K, (went0["name"], k0, K)
-            plan.append((panels, gemms))
+            bidx = self.bucket_of(went0["off"])
+            assert all(self.bucket_of(m[0]["off"]) == bidx for m in members), "a weight-gradient group spans two arena buckets"
+            plan.append((bidx, panels, gemms))
+        plan.sort(key=lambda t: t[0])          # bucket by bucket (stable: first-appearance order inside a bucket)
         return plan
 
     # ------------------------------------------------------------------ host side: checkpoint layouts

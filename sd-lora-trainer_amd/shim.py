@@ -1,0 +1,213 @@
+"""Call-compatible seams - what makes the C-ABI kernels a DROP-IN behind the reference's own loop body rather than only
+a parallel trainer.  The reference (/root/reference) talks to its model through duck-typed third-party interfaces; this module
+presents the same ones over the engine:
+
+  (1) model call          `unet(sample, timesteps, encoder_hidden_states=..., timestep_cond=None, added_cond_kwargs={"text_embeds",
+                          "time_ids"}, return_dict=False)[0]`  (main.py:329-336), differentiable: `loss.backward()` (main.py:363)
+                          reaches the adapters' `.grad` and the gradient w.r.t. the text conditioning through a
+                          torch.autograd.Function whose backward is the engine's explicit backward plan;
+                          `.parameters()`, `.requires_grad_()`, `.device`, `.dtype`, `.save_pretrained()` (main.py:109,146,375;
+                          checkpoint.py:175,212)
+  (2) processor seam      `DAAMScores`: per hooked attn2 layer an object with `.cross_attention_scores [B, N, 77]`, in the order
+                          `find_attnprocessor2_0` walks them (ti_cross_attn_loss.py:88-112, 244-246) - read-only (heat maps, a
+                          torch-side token-attention loss on detached maps); the differentiable token-attention loss lives in
+                          step.TrainStep, where the 60 layers share one dS per resolution
+  (3) adapter API         `LoraConfig` + `get_peft_model` + `get_peft_model_state_dict` with peft's key names
+                          `base_model.model.<module path>.lora_A.weight / lora_B.weight` (optimizer.py:86-95, checkpoint.py:183-184)
+  (4) optimizer API       any `torch.optim.Optimizer` over `unet.parameters()`: the parameters ARE the fp32 master copies of the
+                          adapter arena (shared storage), the bf16 compute copies are refreshed at the next forward
+                          (the fused device-side AdamW of `optimizer.OptimizerCollection` is the fast path, this is the compatible one)
+
+The fused single-graph step (step.TrainStep) stays the fast path; this one pays torch's autograd bookkeeping and a few copies
+per call, and exists so that reference-shaped code runs unchanged.
+"""
+import dataclasses
+import json
+import os
+from typing import List
+
+import torch
+
+from . import topology
+from .unet import CTX_PAD, F32, Runtime, UNet
+
+
+@dataclasses.dataclass
+class LoraConfig:
+    """peft.LoraConfig's fields the reference sets (optimizer.py:86-95)."""
+    r: int = 16
+    lora_alpha: float = 16.0
+    init_lora_weights: str = "gaussian"
+    target_modules: List[str] = dataclasses.field(default_factory=lambda: ["to_k", "to_q", "to_v", "to_out.0", "conv2"])
+    use_dora: bool = False
+
+
+class DAAMScores:
+    """Stand-in for an installed `DAAMLossAttnProcessor2_0` (ti_cross_attn_loss.py:114-230): after a forward,
+    `.cross_attention_scores` is sum_heads(Q K^T / sqrt(d)) [B, N, 77] of that layer (fp32, detached)."""
+
+    def __init__(self, name):
+        self.name, self.cross_attention_scores = name, None
+
+
+class _UNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, sample, timesteps, ehs, text_embeds, time_ids, *params):
+        rt, u = mod.rt, mod.unet
+        B, _, h, w = sample.shape
+        assert B == rt.B, f"the module was built for batch {rt.B}"
+        if mod._dirty:                  # an optimizer stepped the fp32 masters since the last forward
+            u.arena.refresh_shadows()
+            mod._dirty = False
+        x64 = mod._buf("x64", B * h * w, 64)
+        x64.zero_()
+        x64[:, :4] = sample.detach().permute(0, 2, 3, 1).reshape(B * h * w, 4).to(x64.dtype)
+        ctxb = mod._buf("ctx", B * CTX_PAD, u.cfg["cross_dim"])
+        ctxb.zero_()
+        ctxb.view(B, CTX_PAD, -1)[:, :77] = ehs.detach().to(ctxb.dtype)
+        pooled = tid = None
+        if u.cfg["addition"]:
+            pooled = text_embeds.detach().to(rt.act)
+            tid = time_ids.detach().reshape(-1).to(device=rt.device, dtype=F32)
+        rt.want_dpooled = bool(u.cfg["addition"] and text_embeds is not None and text_embeds.requires_grad)
+        rt.keep_daam_maps = mod.keep_daam_maps
+        pred = u.forward(x64, timesteps.detach().to(device=rt.device, dtype=F32), ctxb, pooled, tid, B=B, H=h, W=w)
+        if mod.keep_daam_maps:
+            for proc, (_, S) in zip(mod.daam_processors, rt.daam):
+                proc.cross_attention_scores = S[:, :, :77].clone()
+        ctx.mod, ctx.shape = mod, (B, h, w)
+        ctx.ehs_dtype, ctx.te_dtype = ehs.dtype, (text_embeds.dtype if text_embeds is not None else None)
+        return pred.view(B, h, w, 4).permute(0, 3, 1, 2).to(sample.dtype).contiguous()
+
+    @staticmethod
+    def backward(ctx, dpred):
+        mod = ctx.mod
+        rt, u = mod.rt, mod.unet
+        B, h, w = ctx.shape
+        d64 = mod._buf("dpred64", B * h * w, 64)
+        d64.zero_()
+        d64[:, :4] = dpred.permute(0, 2, 3, 1).reshape(B * h * w, 4).to(d64.dtype)
+        dctx = mod._buf("dctx", B * CTX_PAD, u.cfg["cross_dim"])
+        dctx.zero_()
+        rt.daam_grads, rt.daam_applied = None, False
+        with torch.enable_grad():       # (irrelevant to the HIP ops; the CPU op emulation of the tests differentiates with autograd inside)
+            u.backward(d64, dctx)
+        g_ehs = dctx.view(B, CTX_PAD, -1)[:, :77].to(ctx.ehs_dtype).clone()
+        g_te = None
+        if rt.want_dpooled:
+            P = u.cfg["proj_class_in"] - 6 * u.cfg["addition_time_embed_dim"]
+            g_te = u.dadd_in[:, :P].to(ctx.te_dtype).clone()
+        grads = []
+        for e in u.arena.entries:       # same order as UNetModule.parameters(): A then B of every adapted layer
+            grads += [e["gA"].clone(), e["gB"].clone()]
+        return (None, None, None, g_ehs, g_te, None, *grads)
+
+
+class UNetModule:
+    """UNet2DConditionModel-shaped object over the engine's UNet plan (see the module docstring)."""
+
+    def __init__(self, version_or_cfg, state_dict, lora_config: LoraConfig = None, *, batch_size=1, device="cuda:0", runtime=None):
+        cfg = topology.CONFIGS[version_or_cfg] if isinstance(version_or_cfg, str) else version_or_cfg
+        self.rt = runtime or Runtime(device, batch_size)
+        lc = lora_config or LoraConfig()
+        if lc.use_dora:
+            raise NotImplementedError("DoRA adapters are not built in this engine")
+        assert sorted(lc.target_modules) == sorted(["to_k", "to_q", "to_v", "to_out.0", "conv2"]), "the fused kernels adapt the reference's target set"
+        self.peft_config = lc
+        self.unet = UNet(self.rt, cfg, state_dict, lora_rank=lc.r, lora_alpha_multiplier=lc.lora_alpha / lc.r)
+        self.config = dict(cfg)
+        self.keep_daam_maps = False
+        hooked = [a for a in self.unet.cross_attns if a.hooked]
+        self.daam_processors = [DAAMScores(a.name + ".processor") for a in hooked]
+        self._params, self._names = [], []
+        for e in self.unet.arena.entries:
+            for key, nm in (("A", "lora_A"), ("B", "lora_B")):
+                p = torch.nn.Parameter(e[key], requires_grad=True)      # shares storage with the arena's fp32 master
+                self._params.append(p)
+                self._names.append(f"base_model.model.{e['name']}.{nm}.weight")
+        self._dirty, self._bufs = True, {}
+
+    # ---- nn.Module-shaped surface ------------------------------------------------------------------------------------
+    device = property(lambda self: self.rt.device)
+    dtype = property(lambda self: self.rt.act)
+
+    def parameters(self):
+        return iter(self._params)
+
+    def named_parameters(self):
+        return iter(zip(self._names, self._params))
+
+    def requires_grad_(self, flag=True):
+        for p in self._params:
+            p.requires_grad_(flag)
+        return self
+
+    def train(self, mode=True):
+        return self
+
+    def eval(self):
+        return self
+
+    def init_lora_weights(self, generator=None):
+        """peft init_lora_weights="gaussian": A ~ N(0, (1/r)^2), B = 0."""
+        r = self.peft_config.r
+        with torch.no_grad():
+            for e in self.unet.arena.entries:
+                e["A"].copy_(torch.randn(e["A"].shape, generator=generator, device=e["A"].device) / r)
+                e["B"].zero_()
+        self._dirty = True
+
+    def _buf(self, key, *shape):
+        t = self._bufs.get(key)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = self.rt.zeros(*shape)
+            self._bufs[key] = t
+        return t
+
+    def __call__(self, sample, timestep, encoder_hidden_states=None, timestep_cond=None, added_cond_kwargs=None, return_dict=False, **kw):
+        assert timestep_cond is None, "timestep_cond is None in the reference's call (main.py:333)"
+        add = added_cond_kwargs or {}
+        te, tid = add.get("text_embeds"), add.get("time_ids")
+        if self.unet.cfg["addition"]:
+            assert te is not None and tid is not None, "SDXL needs added_cond_kwargs = {'text_embeds', 'time_ids'}"
+        else:
+            te = tid = None
+        vers = [p._version for p in self._params]          # an optimizer step (in-place update of a parameter) bumps its version
+        if vers != getattr(self, "_versions", None):
+            self._dirty = True
+        self._versions = vers
+        if not torch.is_tensor(timestep):
+            timestep = torch.tensor([timestep] * sample.shape[0])
+        out = _UNetFn.apply(self, sample, timestep, encoder_hidden_states, te, tid, *self._params)
+        if return_dict:
+            import types
+            return types.SimpleNamespace(sample=out)
+        return (out,)
+
+    # ---- adapter API (peft) ------------------------------------------------------------------------------------------------
+    def get_peft_model_state_dict(self):
+        """peft.get_peft_model_state_dict: {base_model.model.<path>.lora_A.weight: [r, Cin(,3,3)], ...lora_B.weight: [Cout, r(,1,1)]}."""
+        out = {}
+        for name, (A, B) in self.unet.arena.export().items():
+            out[f"base_model.model.{name}.lora_A.weight"] = A
+            out[f"base_model.model.{name}.lora_B.weight"] = B
+        return out
+
+    def save_pretrained(self, output_dir):
+        """peft `save_pretrained` (checkpoint.py:175): adapter_config.json + adapter_model.safetensors."""
+        from safetensors.torch import save_file
+        os.makedirs(output_dir, exist_ok=True)
+        lc = self.peft_config
+        with open(os.path.join(output_dir, "adapter_config.json"), "w") as f:
+            json.dump({"peft_type": "LORA", "r": lc.r, "lora_alpha": lc.lora_alpha, "init_lora_weights": lc.init_lora_weights,
+                       "target_modules": list(lc.target_modules), "use_dora": lc.use_dora}, f, indent=2)
+        save_file({k: v.contiguous() for k, v in self.get_peft_model_state_dict().items()}, os.path.join(output_dir, "adapter_model.safetensors"))
+
+
+def get_peft_model(version_or_cfg, state_dict, lora_config, **kw):
+    """optimizer.py:86-95 `get_peft_model(unet, LoraConfig(...))` for this engine: the adapted model is built from the frozen weights."""
+    return UNetModule(version_or_cfg, state_dict, lora_config, **kw)
+
+
+def get_peft_model_state_dict(model):
+    return model.get_peft_model_state_dict()

@@ -170,6 +170,10 @@ class TrainStep:
             assert self.full_ft, "LoRA / TI jobs are independent per GPU (no collective); only the full fine-tune is data parallel"
             self.pg = None if process_group is True else process_group
             self.world = dist.get_world_size(self.pg)
+            # bucketed, overlapped gradient exchange: the weight gradients are produced bucket by bucket at the end of the
+            # backward (fullft.WeightTrainer.flush(bucket=i)), each bucket's all-reduce starts as soon as its gradients exist
+            self.bucketed = self.world > 1 and grad_accum == 1
+            unet.trainer.defer_flush = self.bucketed
         self.text, self.ta_w, self.ti_wd = text, token_attention_loss_w, ti_weight_decay
         self.ti = TiState(rt, text.encoders, n_tokens, ti_std_loss_w) if text is not None else None
         self.ta = TokenAttentionLoss(rt, n_tokens) if text is not None else None
@@ -352,11 +356,28 @@ class TrainStep:
         a.refresh_shadows()
 
     def sync_gradients(self):
-        """Data-parallel full fine-tune: ONE all-reduce (sum) of the flat fp32 gradient arena per optimiser step - the only
-        exchange step of the whole path.  RCCL over xGMI on the GPU (backend "nccl"), gloo in the CPU tests."""
-        if self.world > 1:
+        """Data-parallel full fine-tune, unbucketed form (gradient accumulation): ONE all-reduce (sum) of the flat fp32 gradient
+        arena per optimiser step.  RCCL over xGMI on the GPU (backend "nccl"), gloo in the CPU tests."""
+        if self.world > 1 and not getattr(self, "bucketed", False):
             import torch.distributed as dist
             dist.all_reduce(self.group.grads, group=self.pg)
+
+    def flush_and_reduce(self, flush_fns=None):
+        """Data-parallel full fine-tune, the exchange step of the path: the deferred weight-gradient plan runs bucket
+        by bucket (contiguous >= 256 MB ranges of the fp32 gradient arena, fullft.WeightTrainer.buckets); after bucket i's GEMMs are
+        queued its all-reduce (sum, in place) is launched asynchronously - torch.distributed makes the collective's stream wait for
+        the work queued so far and runs it beside bucket i+1's GEMMs - then the small vector region (biases, norm affine), then all
+        are waited for before the optimizer.  flush_fns: per-bucket callables (the captured hipGraphs' replays); default eager."""
+        import torch.distributed as dist
+        tr = self.group
+        works = []
+        for b, (o0, o1) in enumerate(tr.buckets):
+            (flush_fns[b] if flush_fns is not None else (lambda b=b: tr.flush(bucket=b)))()
+            works.append(dist.all_reduce(tr.grads[o0:o1], group=self.pg, async_op=True))
+        if tr.n > tr.n_mat:
+            works.append(dist.all_reduce(tr.grads[tr.n_mat:], group=self.pg, async_op=True))
+        for w in works:
+            w.wait()
 
     def optimizer_step(self):
         self._unet_optimizer()
@@ -387,11 +408,17 @@ class TrainStep:
 
     def body(self):
         self.forward_backward()
-        self._accumulate(True)
-        self.sync_gradients()
+        if getattr(self, "bucketed", False):
+            self.flush_and_reduce()
+        else:
+            self._accumulate(True)
+            self.sync_gradients()
         self.optimizer_step()
 
     def _phases(self):
+        if self.world > 1 and self.bucketed:   # forward+backward | per bucket: weight gradients, all-reduce (outside the graphs) | optimizer
+            tr = self.group
+            return [self.forward_backward] + [(lambda b=b: tr.flush(bucket=b)) for b in range(len(tr.buckets))] + [self.optimizer_step]
         if self.world > 1:         # the collective stays outside the graphs: forward+backward | all-reduce | optimizer
             return [lambda: (self.forward_backward(), self._accumulate(True)), self.optimizer_step]
         if self._acc is not None:
@@ -551,7 +578,11 @@ class TrainStep:
         # gradients need the text backward for the whole run
         frozen = self.text is not None and lr_ti == 0.0 and self.te_arena is None and self._acc is None
         self._frozen_last = frozen
-        if self.graph is not None and self.world > 1:
+        if self.graph is not None and self.world > 1 and self.bucketed:
+            self.graphs[0].replay()
+            self.flush_and_reduce([g.replay for g in self.graphs[1:-1]])
+            self.graphs[-1].replay()
+        elif self.graph is not None and self.world > 1:
             self.graphs[0].replay()
             self.sync_gradients()
             self.graphs[1].replay()

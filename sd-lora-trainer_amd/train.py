@@ -494,7 +494,10 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
                             pooled[b] = cond_tok[1][0]
                 ts.set_batch(latent, noise, timesteps, mask, ctx, pooled, time_ids)
             if not captured and rt.device.type == "cuda":
+                t0 = time.time()
                 ts.capture(warmup=1)
+                torch.cuda.synchronize()
+                pause += time.time() - t0                        # one-off graph capture: not part of the step loop's rate
                 captured = True
             optimizers.step(last_batch=step_in_epoch + 1 == spe)
             optimizers.zero_grad()

@@ -266,9 +266,13 @@ class StackedLinear(_Module):
             # the members' master weights are consecutive in the trainer's arena: one [G*N, K] gradient, one dW GEMM
             assert self.bias is None, "stacked projections with biases are not part of the UNet"
             e0 = members[0].went
-            for g, m in enumerate(members):
-                assert m.went["off"] == e0["off"] + g * N * K, "stacked members must be registered back to back"
-            self.went = dict(name=name + ".weight", off=e0["off"], shape=(self.G * N, K), kind="matrix")
+            self.went = dict(name=name + ".weight", off=None, shape=(self.G * N, K), kind="matrix")
+
+            def _bind_stack():          # arena offsets exist once the trainer is finalized
+                for g, m in enumerate(members):
+                    assert m.went["off"] == e0["off"] + g * N * K, "stacked members must be registered back to back"
+                self.went["off"] = e0["off"]
+            self.trainer.on_finalize(_bind_stack)
             self.Wt = self.W.t().contiguous()
             for g, m in enumerate(members):
                 m.Wt = self.Wt[:, g * N:(g + 1) * N]
@@ -945,8 +949,8 @@ class UNet(_Module):
             if tr is not None:
                 de1s = self.t2.backward(demb)
                 self.t1.weight_grad(rt.ops.map_bf16(_ops.MAP_DSILU, self.t1._b["y"], de1s, self.buf("de1", *de1s.shape)))
-        if tr is not None:
-            tr.flush()             # every weight gradient of this pass, batched by layer shape
+        if tr is not None and not tr.defer_flush:
+            tr.flush()             # every weight gradient of this pass, batched by layer shape (data parallel: the step flushes bucket by bucket)
         self._cross_kv_backward(dctx)
         if self.arena is not None:
             if self._grad_plan is None:

@@ -83,8 +83,11 @@ def _ddp_worker(rank, world, port, out):
     mask = torch.ones_like(mask)        # per-sample losses independent of the rest of the batch (gamma = 0 branch normalises by the batch mask mean)
     rt = unet_mod.Runtime("cpu", 1, act_dtype=torch.float32, ops=emu_ops)
     tr = fullft.WeightTrainer(rt)
+    tr.bucket_floats = 150_000          # several buckets on the toy model: weight gradients + all-reduce bucket by bucket
     unet = unet_mod.UNet(rt, topology.CONFIGS["tiny15"], sd, trainer=tr)
     ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=0.0, process_group=True)
+    assert ts.bucketed and len(tr.buckets) >= 4 and tr.buckets[0][0] == 0 and tr.buckets[-1][1] == tr.n_mat
+    assert all(a[1] == b[0] for a, b in zip(tr.buckets, tr.buckets[1:]))          # contiguous cover of the matrix region
     s = slice(rank, rank + 1)
     for _ in range(2):
         ts.set_batch(latent[s], noise[s], t[s], mask[s], ctx[s])

@@ -255,7 +255,7 @@ def _case_full_size_properties(version, B, h):
     torch.cuda.synchronize()
     assert abs(float(ts.loss) - loss_eager) <= 2e-3 * abs(loss_eager), (float(ts.loss), loss_eager)
     cos, rel = _cos_rel(unet.arena.grads, g_eager)
-    assert cos >= 0.995 and rel <= 5e-2, f"graph replay vs eager LoRA gradients: cos {cos} rel {rel}"
+    assert cos >= 0.9999 and rel <= 1e-2, f"graph replay vs eager LoRA gradients: cos {cos} rel {rel}"      # (fixed-order reductions; round 1: 5e-2)
     for a, e in zip(ts.ti.grad_rows, rows_eager):
         cos, rel = _cos_rel(a, e)
         assert cos >= 0.99, f"graph replay vs eager token-row gradients: cos {cos} rel {rel}"

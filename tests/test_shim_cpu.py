@@ -1,0 +1,125 @@
+"""the reference-shaped loop body (main.py:311-382) runs UNCHANGED on the call-compatible shim
+(sd_lora_trainer_amd.shim.UNetModule): `unet(noisy, t, encoder_hidden_states=..., timestep_cond=None, added_cond_kwargs=...,
+return_dict=False)[0]`, a torch-side loss, `loss.backward()`, `torch.optim.AdamW(unet.parameters())`, `optimizer.step()`.
+Here on CPU through the op emulation against the fp32 oracle; tests/test_shim_gpu.py drives the same body over the HIP kernels."""
+import pytest
+import torch
+
+from oracle import loss_ref as L
+from oracle import unet_ref as U
+from sd_lora_trainer_amd import shim
+from tests import emu_ops
+import sd_lora_trainer_amd.unet as unet_mod
+
+
+def reference_loop_body(unet, optimizer, noise_acp, vae_latent, mask, prompt_embeds, pooled, add_time_ids, noise, timesteps, snr_gamma=5.0):
+    """main.py:326-382 with the tensors the loop has at that point (noise / timesteps injected instead of drawn)."""
+    noisy_latent = L.add_noise(noise_acp, vae_latent, noise, timesteps)
+    model_pred = unet(noisy_latent, timesteps, encoder_hidden_states=prompt_embeds, timestep_cond=None,
+                      added_cond_kwargs={"text_embeds": pooled, "time_ids": add_time_ids}, return_dict=False)[0]
+    loss = L.diffusion_loss(model_pred, noise, noisy_latent, mask, noise_acp, timesteps, snr_gamma=snr_gamma)
+    loss.backward()
+    grads = [p.grad.clone() for p in unet.parameters()]
+    optimizer.step()
+    optimizer.zero_grad()
+    return model_pred.detach(), float(loss.detach()), grads
+
+
+def run_shim_vs_oracle(version, B, h, rt, tol, steps=4):
+    cfg = U.CONFIGS[version]
+    sd = {k: v.to(torch.bfloat16).float() for k, v in U.init_unet_state(cfg, seed=0).items()}
+    lora = U.init_lora(cfg, 8, seed=1, b_std=0.03)
+    dev = rt.device
+    g = torch.Generator().manual_seed(5)
+    latent = (torch.randn(B, 4, h, h, generator=g) * cfg["scaling_factor"]).to(dev)
+    mask = (torch.rand(B, 1, h, h, generator=g) * 0.95 + 0.05).repeat(1, 4, 1, 1).to(dev)
+    pe = torch.randn(B, 77, cfg["cross_dim"], generator=g).to(dev).requires_grad_(True)
+    pooled = tid = None
+    if cfg["addition"]:
+        pooled = torch.randn(B, cfg["proj_class_in"] - 6 * cfg["addition_time_embed_dim"], generator=g).to(dev).requires_grad_(True)
+        tid = torch.tensor([[1024., 1024, 0, 0, 8. * h, 8. * h]] * B).to(dev)
+    acp = L.ddpm_alphas_cumprod().to(dev)
+
+    unet = shim.get_peft_model(version, sd, shim.LoraConfig(r=8, lora_alpha=8.0), batch_size=B, runtime=rt)
+    assert unet.device == rt.device and len(list(unet.parameters())) == 2 * len(lora)
+    unet.unet.arena.load(lora)
+    unet.requires_grad_(True)
+    opt = torch.optim.AdamW(list(unet.parameters()), lr=1e-3, weight_decay=0.004)
+    # oracle twin: same loop body over the oracle's functional UNet
+    o_params = {k: (A.clone().requires_grad_(True), Bm.clone().requires_grad_(True)) for k, (A, Bm) in lora.items()}
+    o_opt = torch.optim.AdamW([t for ab in o_params.values() for t in ab], lr=1e-3, weight_decay=0.004)
+    o_pe = pe.detach().cpu().clone().requires_grad_(True)
+    o_pooled = pooled.detach().cpu().clone().requires_grad_(True) if pooled is not None else None
+
+    class OracleUNet:
+        def parameters(self):
+            return iter([t for ab in o_params.values() for t in ab])
+
+        def __call__(self, sample, timestep, encoder_hidden_states=None, timestep_cond=None, added_cond_kwargs=None, return_dict=False):
+            add = added_cond_kwargs if cfg["addition"] else None
+            return (U.unet_forward(cfg, sd, sample, timestep, encoder_hidden_states, add, lora=o_params),)
+    losses = []
+    for step in range(steps):
+        gs = torch.Generator().manual_seed(100 + step)
+        noise = torch.randn(B, 4, h, h, generator=gs)
+        t = torch.randint(0, 1000, (B,), generator=gs)
+        pred, loss, grads = reference_loop_body(unet, opt, acp, latent, mask, pe, pooled, tid, noise.to(dev), t.to(dev))
+        pred_o, loss_o, grads_o = reference_loop_body(OracleUNet(), o_opt, acp.cpu(), latent.cpu(), mask.cpu(), o_pe, o_pooled, tid.cpu() if tid is not None else None, noise, t)
+        assert float((pred.cpu() - pred_o).abs().max()) <= tol["pred"] * float(pred_o.abs().max()), f"step {step}: prediction"
+        assert abs(loss - loss_o) <= tol["loss"] * abs(loss_o), (step, loss, loss_o)
+        # conv adapters: the module's parameters are the engine's 2-D (tap-major) layout; compare through the peft-layout export
+        ga, gb = torch.cat([x.reshape(-1).cpu() for x in grads]), torch.cat([x.reshape(-1) for x in grads_o])
+        assert ga.numel() == gb.numel()
+        if step == 0:
+            exp = unet.unet.arena.export("grads")
+            flat = torch.cat([t_.reshape(-1) for k in lora for t_ in exp[k]])
+            cos = float(flat.double() @ gb.double() / (flat.double().norm() * gb.double().norm()))
+            assert cos >= tol["cos"], f"LoRA gradient cosine {cos}"
+            ge, geo = pe.grad.cpu(), o_pe.grad
+            cos = float(ge.reshape(-1).double() @ geo.reshape(-1).double() / (ge.double().norm() * geo.double().norm()))
+            assert cos >= tol["cos"], f"encoder_hidden_states gradient cosine {cos}"
+            if pooled is not None:
+                gp, gpo = pooled.grad.cpu(), o_pooled.grad
+                cos = float(gp.reshape(-1).double() @ gpo.reshape(-1).double() / (gp.double().norm() * gpo.double().norm()))
+                assert cos >= tol["cos"], f"text_embeds gradient cosine {cos}"
+        pe.grad = None
+        o_pe.grad = None
+        if pooled is not None:
+            pooled.grad = None
+            o_pooled.grad = None
+        losses.append((loss, loss_o))
+    # the torch optimizer moved the engine's adapters: exported weights equal the oracle twin's
+    got = unet.get_peft_model_state_dict()
+    for k, (A, Bm) in o_params.items():
+        a, b_ = got[f"base_model.model.{k}.lora_A.weight"], got[f"base_model.model.{k}.lora_B.weight"]
+        assert a.shape == A.shape and b_.shape == Bm.shape
+        assert float((a - A.detach()).abs().max()) <= tol["param"] and float((b_ - Bm.detach()).abs().max()) <= tol["param"], k
+    return unet, losses
+
+
+@pytest.mark.parametrize("version,B", [("tinyxl", 1), ("tiny15", 2)])
+def test_reference_loop_body_on_shim_cpu(version, B, tmp_path):
+    rt = unet_mod.Runtime("cpu", B, act_dtype=torch.float32, ops=emu_ops)
+    unet, losses = run_shim_vs_oracle(version, B, 16, rt, dict(pred=2e-3, loss=1e-3, cos=0.9999, param=3e-4))
+    unet.save_pretrained(str(tmp_path / "ad"))
+    import json
+    import os
+    from safetensors.torch import load_file
+    assert json.load(open(tmp_path / "ad" / "adapter_config.json"))["r"] == 8
+    sd = load_file(os.path.join(tmp_path / "ad", "adapter_model.safetensors"))
+    assert any(k.endswith("conv2.lora_A.weight") and v.dim() == 4 for k, v in sd.items()) and all(k.startswith("base_model.model.") for k in sd)
+    # processor seam: per hooked attn2 layer a `.cross_attention_scores` [B, N, 77] after a forward with keep_daam_maps
+    unet.keep_daam_maps = True
+    cfg = U.CONFIGS[version]
+    add = {"text_embeds": torch.zeros(B, cfg["proj_class_in"] - 6 * cfg["addition_time_embed_dim"]), "time_ids": torch.tensor([[1024., 1024, 0, 0, 128, 128]] * B)} if cfg["addition"] else None
+    with torch.no_grad():
+        ehs = torch.randn(B, 77, cfg["cross_dim"])
+        x = torch.randn(B, 4, 16, 16)
+        t = torch.tensor([500] * B)
+        unet(x, t, encoder_hidden_states=ehs, added_cond_kwargs=add)
+        _, daam = U.unet_forward(cfg, {k: v.to(torch.bfloat16).float() for k, v in U.init_unet_state(cfg, seed=0).items()}, x, t, ehs, add,
+                                 lora={k: (a, b_) for k, (a, b_) in unet.unet.arena.export().items()}, return_daam=True)
+    assert len(unet.daam_processors) == len(daam) > 0
+    for proc, (name, s) in zip(unet.daam_processors, daam):
+        assert proc.name == name + ".processor"
+        torch.testing.assert_close(proc.cross_attention_scores, s, rtol=2e-3, atol=2e-3)

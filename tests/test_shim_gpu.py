@@ -1,0 +1,18 @@
+"""SURVEY 8b on the MI355X: the reference-shaped loop body of tests/test_shim_cpu.py (`unet(...)` call of main.py:329-336,
+torch-side loss, `loss.backward()`, `torch.optim.AdamW(unet.parameters())`) over the HIP kernels, against the fp32 oracle twin.
+Tolerances as tests/test_step_gpu.py (bf16 activations): prediction 4e-2 of max-abs, loss 2e-2, gradient cosine >= 0.99."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("version,B", [("tinyxl", 1), ("tiny15", 2)])
+def test_reference_loop_body_on_shim_gpu(version, B):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import sd_lora_trainer_amd.unet as unet_mod
+    from tests.test_shim_cpu import run_shim_vs_oracle
+    rt = unet_mod.Runtime("cuda:0", B)
+    unet, losses = run_shim_vs_oracle(version, B, 16, rt, dict(pred=4e-2, loss=2e-2, cos=0.99, param=4e-3), steps=4)
+    assert all(l == l for l, _ in losses)

@@ -86,18 +86,16 @@ def test_step_matches_fp32_oracle(version, B, gamma, rank):
     assert cos >= 0.99 and rel <= 8e-2, f"dctx cos {cos} rel {rel}"
     assert float(gctx[:, 77:].abs().max()) == 0.0
 
-    # hipGraph capture: replaying the captured step from the same state reproduces the eager gradients.
-    # (Compared on the gradients, not on the parameter update: Adam's first step is ~lr*sign(g), so the float-atomic
-    # reduction order in the GroupNorm / split-K reductions may flip the sign of near-zero elements.)
+    # hipGraph capture: replaying the captured step from the same state reproduces the eager gradients - every reduction on the
+    # path (GroupNorm statistics, split-K, cross-attention dK/dV slabs, column sums) runs in a fixed order, so "reproduces" is
+    # bitwise up to nothing: the tolerance below is 5e4 x tighter than round 1's (which had float atomics in the GroupNorms).
     g_eager = unet.arena.grads.clone()
     ts.capture(warmup=1)
     unet.arena.grads.zero_()
     ts.run(1e-3)
     torch.cuda.synchronize()
     cos, rel = _cos_rel(unet.arena.grads, g_eager)
-    # float-atomic reductions (GroupNorm statistics, split-query dK/dV) make two runs differ in the last bf16 bit of
-    # a few activations; through ~40 bf16 layers that decorrelates to the bf16 noise floor - hence 5e-2, not 1e-6.
-    assert cos >= 0.995 and rel <= 5e-2, f"graph replay vs eager gradients: cos {cos} rel {rel}"
+    assert cos >= 0.999999 and rel <= 1e-6, f"graph replay vs eager gradients: cos {cos} rel {rel}"
     losses = []
     for i in range(5):
         ts.run(1e-3)
@@ -263,5 +261,6 @@ def test_bench_json_contract():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and len(c["step_seconds"]) >= 1
+    assert d["train_loop"]["value"] > 0 and d["train_loop"]["unit"] == "images/s"          # the train() generator's own loop, extra object
     assert d["two_jobs_per_gpu"]["value"] > 0 and d["two_jobs_per_gpu"]["unit"] == "images/s"
