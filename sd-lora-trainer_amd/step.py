@@ -201,7 +201,8 @@ class TrainStep:
         self.sums, self.loss, self.l1_sum = z(B * 2), z(1), z(1)
         self.hyper = z(16)
         self.opt_step = 0
-        self.graph, self.graphs, self.graphs_frozen = None, [], None
+        self.graph, self.graphs, self.graphs_frozen, self.graphs_frozen_cached = None, [], None, None
+        self._cond_cached = False
         # optional Prodigy groups (trainer/optimizer.py:24-34: growth_rate = unet_prodigy_growth_factor, d_coef = prodigy_d_coef;
         # :135-145 for the token rows: d_coef 1, unbounded growth)
         self.prodigy = ProdigyState(rt, self.group.params, d_coef=prodigy_d_coef, growth_rate=prodigy_growth_rate,
@@ -240,7 +241,15 @@ class TrainStep:
             if self.pooled is not None:
                 self.pooled.copy_(pooled)
         else:
-            self.text.set_ids(ids)
+            # cached conditioning (f4): once the token rows are frozen (ti lr == 0) and the text encoders carry no adapters, the
+            # conditioning of a caption is a constant of the job - the caller may hand it over instead of having it re-encoded
+            self._cond_cached = ctx is not None
+            if self._cond_cached:
+                self.ctx.view(self.B, CTX_PAD, -1)[:, :77].copy_(ctx)
+                if self.pooled is not None:
+                    self.pooled.copy_(pooled)
+            else:
+                self.text.set_ids(ids)
             train_ids = self.text.encoders[0].train_ids.tolist()
             self.ta.set_captions(caption_token_lists, train_ids)
         if self.time_ids is not None:
@@ -427,6 +436,11 @@ class TrainStep:
             return [self.body]
         return [self._phase_text_fwd, self._phase_unet, lambda: (self._phase_text_bwd(), self.optimizer_step())]
 
+    def _phase_unet_cached(self):
+        """UNet phase on a conditioning the caller placed in self.ctx / self.pooled (frozen token rows: no text-encoder forward)."""
+        self._pooled_live = self.pooled
+        self._phase_unet()
+
     def _phase_opt_frozen_ti(self):
         """Last phase once the token embeddings are frozen (ti lr == 0, main.py:273-274): the reference still back-propagates
         through both text encoders and runs AdamW with lr 0 on the tables; with lr == 0 that changes no parameter (decoupled
@@ -538,6 +552,8 @@ class TrainStep:
                     frozen = graphs[:2] + [cap([self._phase_opt_frozen_ti], pool)]
                 else:
                     frozen = [cap([self._phase_text_fwd, self._phase_unet, self._phase_opt_frozen_ti], pool)]
+                pool = frozen[-1].pool()
+                self.graphs_frozen_cached = [cap([self._phase_unet_cached, self._phase_opt_frozen_ti], pool)]   # + cached conditioning
             return graphs, frozen, pool
 
         self.graphs, self.graphs_frozen, pool = cap_set(None)
@@ -587,11 +603,16 @@ class TrainStep:
             self.sync_gradients()
             self.graphs[1].replay()
         elif self.graph is not None:
-            for g in (self.graphs_frozen if frozen else self.graphs):
+            cached = frozen and self._cond_cached and self.graphs_frozen_cached is not None
+            assert not self._cond_cached or frozen, "a cached conditioning is only valid while the token rows are frozen (ti lr == 0, no text-encoder LoRA)"
+            for g in (self.graphs_frozen_cached if cached else (self.graphs_frozen if frozen else self.graphs)):
                 g.replay()
         elif frozen:
-            self._phase_text_fwd()
-            self._phase_unet()
+            if self._cond_cached:
+                self._phase_unet_cached()
+            else:
+                self._phase_text_fwd()
+                self._phase_unet()
             self._phase_opt_frozen_ti()
         else:
             self.body()

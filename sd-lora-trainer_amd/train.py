@@ -403,18 +403,19 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
     # ---- frozen text encoders (disable_ti): the conditioning of every caption is a constant of the job - encode each caption
     # (and the caption-dropout caption) ONCE instead of once per step (the reference re-encodes, main.py:306-308; same values)
     cond = None
+
+    def encode_rows(ids_per_enc):
+        n = ids_per_enc[0].shape[0]
+        ctxs, pools = [], []
+        for s in range(0, n, B):
+            chunk = [torch.cat([i[s:s + B], i[-1:].expand(B - min(B, n - s), 77)]) if n - s < B else i[s:s + B] for i in ids_per_enc]
+            models.text.set_ids([c.to(rt.device) for c in chunk])
+            pooled = models.text.forward(ts.ctx)
+            ctxs.append(ts.ctx.view(B, M.CTX_PAD, -1)[:, :77].clone())
+            if pooled is not None:
+                pools.append(pooled.clone())
+        return torch.cat(ctxs)[:n], (torch.cat(pools)[:n] if pools else None)
     if not ti_on:
-        def encode_rows(ids_per_enc):
-            n = ids_per_enc[0].shape[0]
-            ctxs, pools = [], []
-            for s in range(0, n, B):
-                chunk = [torch.cat([i[s:s + B], i[-1:].expand(B - min(B, n - s), 77)]) if n - s < B else i[s:s + B] for i in ids_per_enc]
-                models.text.set_ids([c.to(rt.device) for c in chunk])
-                pooled = models.text.forward(ts.ctx)
-                ctxs.append(ts.ctx.view(B, M.CTX_PAD, -1)[:, :77].clone())
-                if pooled is not None:
-                    pools.append(pooled.clone())
-            return torch.cat(ctxs)[:n], (torch.cat(pools)[:n] if pools else None)
         with torch.no_grad():
             cond = encode_rows(cache["input_ids"])
             cond_tok = encode_rows([t.view(1, 77) for t in cache["tok_ids"]]) if cache.get("tok_ids") is not None else None
@@ -483,7 +484,24 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
                         lists[b] = list(cache["tok_list"])
                         for t, tok in zip(ids, cache["tok_ids"]):
                             t[b] = tok
-                ts.set_batch(latent, noise, timesteps, mask, time_ids=time_ids, ids=ids, caption_token_lists=lists)
+                kw = {}
+                if lrs["textual_inversion"] == 0.0 and ts.te_arena is None and ts.prodigy_ti is None and (captured or rt.device.type != "cuda") and ts._acc is None \
+                        and completion_f > config.freeze_ti_after_completion_f:
+                    # f4: the token rows are frozen for the rest of the run (main.py:273-274) -> every caption's conditioning is a
+                    # constant; encode each caption (and the dropout caption) once with the final rows, then skip the text encoders
+                    if cond is None:
+                        with torch.no_grad():
+                            cond = encode_rows(cache["input_ids"])
+                            cond_tok = encode_rows([t.view(1, 77) for t in cache["tok_ids"]]) if cache.get("tok_ids") is not None else None
+                    ctx = cond[0][idx.to(cond[0].device)].clone()
+                    pooled = cond[1][idx.to(cond[0].device)].clone() if cond[1] is not None else None
+                    for b in range(B):
+                        if drop[b]:
+                            ctx[b] = cond_tok[0][0]
+                            if pooled is not None:
+                                pooled[b] = cond_tok[1][0]
+                    kw = dict(ctx=ctx, pooled=pooled)
+                ts.set_batch(latent, noise, timesteps, mask, time_ids=time_ids, ids=ids, caption_token_lists=lists, **kw)
             else:
                 ctx = cond[0][idx.to(cond[0].device)].clone()
                 pooled = cond[1][idx.to(cond[0].device)].clone() if cond[1] is not None else None

@@ -71,8 +71,21 @@ def _unet_state(version):
     return _CACHE[version]
 
 
+_HF = {}
+
+
 def _hf_clip(kind, seed, legacy_eos=None):
-    """Hugging Face CLIP text tower of the real size with the 3 new token rows appended (embedding_handler.py:157-223)."""
+    """Hugging Face CLIP text tower of the real size with the 3 new token rows appended (embedding_handler.py:157-223); built once
+    per (kind, seed) - transformers' parameter initialisation of the 695 M-parameter bigG tower takes a minute - and copied per use
+    (the oracle trains its copy's token table in place)."""
+    import copy
+    key = (kind, seed, legacy_eos)
+    if key not in _HF:
+        _HF[key] = _hf_clip_build(kind, seed, legacy_eos)
+    return copy.deepcopy(_HF[key])
+
+
+def _hf_clip_build(kind, seed, legacy_eos=None):
     from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
     from sd_lora_trainer_amd import topology
     c = topology.CLIP_CONFIGS[kind]

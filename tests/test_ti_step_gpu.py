@@ -109,6 +109,25 @@ def test_ti_step_gpu_matches_oracle(version, B, concurrent):
     assert all(torch.equal(a, b) for a, b in zip(rows0, [ts.ti.params]))
     assert not torch.equal(lora0, unet.arena.params)
     assert ts.grad_norm() > 0.0 and math.isfinite(ts.total_loss())
+    # cached conditioning (f4): with frozen rows the conditioning of a caption is a constant - the same frozen step with the
+    # conditioning handed over (no text-encoder forward in the replayed graph) gives the same loss and the same update
+    if not concurrent:
+        a = unet.arena
+        ctx_c = ts.ctx.view(B, unet_mod.CTX_PAD, -1)[:, :77].clone()
+        pooled_c = ts._pooled_live.clone() if xl else None
+        snap, step0 = [t_.clone() for t_ in (a.params, a.m, a.v)], ts.opt_step
+        ts.run(1e-3, lr_ti=0.0)
+        torch.cuda.synchronize()
+        l_ref, p_ref = float(ts.loss), a.params.clone()
+        for t_, c_ in zip((a.params, a.m, a.v), snap):
+            t_.copy_(c_)
+        a.refresh_shadows()
+        ts.opt_step = step0
+        ts.set_batch(latent.cuda(), noise.cuda(), t.cuda(), mask.cuda(), time_ids=tid.cuda() if xl else None, ids=[ids] * len(encs),
+                     caption_token_lists=lists, ctx=ctx_c, pooled=pooled_c)
+        ts.run(1e-3, lr_ti=0.0)
+        torch.cuda.synchronize()
+        assert ts._cond_cached and float(ts.loss) == l_ref and torch.equal(a.params, p_ref)
 
 
 @pytest.mark.parametrize("version,B,rank", [("tiny15", 2, 16), ("tinyxl", 2, 8)])
