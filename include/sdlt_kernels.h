@@ -263,11 +263,13 @@ int sdlt_add_noise_nhwc(const float* x0, const float* noise, const int64_t* time
                         int32_t B, int32_t C, int32_t HW, int32_t Cpad, void* out_nhwc, float* noisy_nchw, void* stream);
 
 /* compute_diffusion_loss + compute_snr (trainer/loss.py:127-170, 83-106) forward AND d(loss)/d(pred).
- * pred: NHWC fp32 [B*HW, ldp]; noise/noisy/mask: NCHW fp32; dpred: NHWC bf16 [B*HW, Cpad]; sums: [B,2] scratch. */
+ * pred: NHWC fp32 [B*HW, ldp]; noise/noisy/mask: NCHW fp32; dpred: NHWC bf16 [B*HW, Cpad]; sums: scratch of sums_floats >=
+ * 2*B*(1 + min(64, ceil(C*HW/1024))) floats - [B,2] per-sample {mean e, mean mask} followed by the per-slice partial sums the
+ * reduction combines in a fixed order. */
 int sdlt_masked_mse_fwd_bwd(const float* pred, int64_t ldp, const float* noise, const float* noisy, const float* mask,
                             const int64_t* timesteps, const float* alphas_cumprod, int32_t B, int32_t C, int32_t HW,
                             int32_t Cpad, float snr_gamma, int32_t v_prediction, float loss_scale, float* sums,
-                            float* loss_out, void* dpred, void* stream);
+                            int32_t sums_floats, float* loss_out, void* dpred, void* stream);
 
 /* torch.optim.AdamW step (trainer/optimizer.py:18,113-150; stepped optimizer.py:270-275) over a flat fp32 arena,
  * with the L1 penalty of main.py:353-356 folded in as a subgradient.  hyper (device fp32[9]):

@@ -111,7 +111,7 @@ SYMBOLS = {
     "sdlt_map_bf16": (i32, [i32, vp, vp, vp, i64, vp]),
     "sdlt_timestep_embedding": (i32, [vp, i32, i32, vp, i64, vp]),
     "sdlt_add_noise_nhwc": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
-    "sdlt_masked_mse_fwd_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, f32, vp, vp, vp, vp]),
+    "sdlt_masked_mse_fwd_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, f32, vp, i32, vp, vp, vp]),
     "sdlt_adamw_fused": (i32, [vp, vp, vp, vp, i64, vp, vp, vp]),
     "sdlt_prodigy_step": (i32, [vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp]),
     "sdlt_wgrad_transpose": (i32, [vp, i64, i32, i32, vp, i64, i32, vp, vp]),

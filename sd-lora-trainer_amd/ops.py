@@ -519,7 +519,7 @@ def masked_mse_fwd_bwd(pred, noise, noisy, mask, timesteps, alphas_cumprod, sums
     assert mask.is_contiguous() and noise.is_contiguous() and dpred.is_contiguous()
     _lib.check(lib.sdlt_masked_mse_fwd_bwd(_p(pred), _ld(pred), _p(noise), _p(noisy), _p(mask), _p(timesteps), _p(alphas_cumprod),
                                            B, Cc, H * W, dpred.shape[1], float(snr_gamma or 0.0), int(v_prediction), float(loss_scale),
-                                           _p(sums), _p(loss_out), _p(dpred), _stream()), "sdlt_masked_mse_fwd_bwd")
+                                           _p(sums), sums.numel(), _p(loss_out), _p(dpred), _stream()), "sdlt_masked_mse_fwd_bwd")
 
 
 def adamw_fused(p, g, m, v, hyper, l1_sum=None):

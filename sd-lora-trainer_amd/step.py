@@ -198,7 +198,7 @@ class TrainStep:
         self.acp = ddpm_alphas_cumprod().to(dev)
         self.x64 = rt.zeros(B * h * w, 64)
         self.dpred64 = rt.zeros(B * h * w, 64)
-        self.sums, self.loss, self.l1_sum = z(B * 2), z(1), z(1)
+        self.sums, self.loss, self.l1_sum = z(B * 2 * 65), z(1), z(1)      # sums: [B,2] finals + up to 64 partial slices per sample
         self.hyper = z(16)
         self.opt_step = 0
         self.graph, self.graphs, self.graphs_frozen, self.graphs_frozen_cached = None, [], None, None

@@ -448,7 +448,7 @@ def test_add_noise_and_masked_mse(ops, B, gamma, vpred):
                                 prediction_type="v_prediction" if vpred else "epsilon")
     lo_e, dp_e = torch.zeros(1), torch.zeros(B * h * h, 64, dtype=BF)
     E.masked_mse_fwd_bwd(pred, noise, noisy_ref, mask, t, acp, None, lo_e, dp_e, snr_gamma=gamma, v_prediction=vpred)
-    sums, lo, dp = torch.zeros(2 * B, device="cuda"), torch.zeros(1, device="cuda"), torch.empty(B * h * h, 64, dtype=BF, device="cuda")
+    sums, lo, dp = torch.full((2 * B * 65,), 9.0, device="cuda"), torch.zeros(1, device="cuda"), torch.empty(B * h * h, 64, dtype=BF, device="cuda")   # finals + partial slices, any contents
     ops.masked_mse_fwd_bwd(pred.cuda(), noise.cuda(), noisy, mask.cuda(), t.cuda(), acp.cuda(), sums, lo, dp, snr_gamma=gamma, v_prediction=vpred)
     close(lo, loss_ref.reshape(1), tol=1e-5, what="masked mse loss vs oracle")
     close(dp, dp_e, tol=1e-2, what="masked mse grad")
