@@ -92,6 +92,18 @@ typedef struct sdlt_gemm_params {
   int32_t throughput_hint;            /* 1: several independent jobs share the device (train_concurrent): the other jobs fill idle CUs,
                                          so the tile heuristics trade workgroup count for per-tile efficiency (256x128 tiles
                                          for the >= 320-tile classes and the mid-size convs).  0: one job - fill the chip. */
+  /* GEGLU of the transformer feed-forward (diffusers GEGLU: ff.net.0.proj -> hidden * gelu(gate)) fused into the GEMMs on either
+     side of it.  Both use the INTERLEAVED-16 layout of the [M, 2H] projection output F1: hidden column j lives at
+     (j / 16) * 32 + j % 16, its gate 16 columns further (the rows of ff.net.0.proj's weight are permuted accordingly at load), so
+     that a hidden value and its gate sit in the same output tile.
+       epi_op = 1 (forward, this GEMM IS ff.net.0.proj, N = 2H): C = F1 as usual, and epi_out [M, H] bf16 = hidden * gelu(gate).
+       epi_op = 2 (backward, this GEMM is the dX of ff.net.2, N = H): with dG the product that would have gone to C,
+                  epi_out [M, 2H] bf16 (interleaved) = d F1 = [dG * gelu(gate) | dG * hidden * gelu'(gate)], hidden / gate read
+                  from epi_in = F1 [M, 2H]; C is not written (may be NULL).
+     bf16 outputs only, no Ct, N % 32 == 0 (op 1) / N % 16 == 0 (op 2). */
+  int32_t epi_op; int32_t pad_epi_;
+  void* epi_out; int64_t ld_epi_out;
+  const void* epi_in; int64_t ld_epi_in;
 } sdlt_gemm_params;
 int sdlt_gemm_bf16(const sdlt_gemm_params* p, void* stream);
 

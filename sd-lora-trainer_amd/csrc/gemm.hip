@@ -320,8 +320,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
   constexpr bool RPRE = RIT <= 4 && QPP * NTHR == CROWS * NCH;   // residual prefetch: at most 4 x 16 B per lane
   const bool vec_ok = ((p.ldc & 3) == 0) && (p.R == nullptr || (p.ldr & 3) == 0) &&
                       (p.rowbias == nullptr || (p.ld_rowbias & 3) == 0);
-  const bool staged = (long)p.M * p.N >= (1l << 20) && !p.out_fp32 && pCt == nullptr && vec_ok && (p.ldc & 7) == 0 && (p.N & 7) == 0 &&
-                      (p.R == nullptr || (p.ldr & 7) == 0) && (((uintptr_t)pC | (uintptr_t)p.R) & 15) == 0;
+  const bool staged = p.epi_op != 0 ||      // (the fused GEGLU epilogues live in the staged store loop; the host checked their alignment)
+                      ((long)p.M * p.N >= (1l << 20) && !p.out_fp32 && pCt == nullptr && vec_ok && (p.ldc & 7) == 0 && (p.N & 7) == 0 &&
+                       (p.R == nullptr || (p.ldr & 7) == 0) && (((uintptr_t)pC | (uintptr_t)p.R) & 15) == 0);
   uint4 rpre[RPRE ? RIT : 1];
   const bool rpre_on = RPRE && staged && p.R != nullptr && splitk == 1;   // (split-K: only the last arriver of a tile would use it)
   if (rpre_on) {
@@ -655,8 +656,36 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
           hi[0] += bf2f(rv.z & 0xffff); hi[1] += bf2f(rv.z >> 16); hi[2] += bf2f(rv.w & 0xffff); hi[3] += bf2f(rv.w >> 16);
         }
         uint4 o;
+        if (p.epi_op == 2) {
+          // dX of ff.net.2 fused with GEGLU's backward: lo/hi = dG[m, n..n+7] (hidden index n); hidden / gate of the forward from F1
+          const size_t fo = (size_t)m * p.ld_epi_in + (n >> 4) * 32 + (n & 15);
+          const uint4 hv = *(const uint4*)((const bf16_t*)p.epi_in + fo), gv = *(const uint4*)((const bf16_t*)p.epi_in + fo + 16);
+          const uint32_t* hp = (const uint32_t*)&hv;
+          const uint32_t* gp = (const uint32_t*)&gv;
+          float dgl[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, dh[8], dgt[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float hh = bf2f((hp[j >> 1] >> ((j & 1) * 16)) & 0xffff), gg = bf2f((gp[j >> 1] >> ((j & 1) * 16)) & 0xffff);
+            dh[j] = dgl[j] * gelu_f(gg);
+            dgt[j] = dgl[j] * hh * dgelu_f(gg);
+          }
+          bf16_t* dst = (bf16_t*)p.epi_out + (size_t)m * p.ld_epi_out + (n >> 4) * 32 + (n & 15);
+          o.x = pack2bf(dh[0], dh[1]); o.y = pack2bf(dh[2], dh[3]); o.z = pack2bf(dh[4], dh[5]); o.w = pack2bf(dh[6], dh[7]);
+          *(uint4*)dst = o;
+          o.x = pack2bf(dgt[0], dgt[1]); o.y = pack2bf(dgt[2], dgt[3]); o.z = pack2bf(dgt[4], dgt[5]); o.w = pack2bf(dgt[6], dgt[7]);
+          *(uint4*)(dst + 16) = o;
+          continue;
+        }
         o.x = pack2bf(lo[0], lo[1]); o.y = pack2bf(lo[2], lo[3]); o.z = pack2bf(hi[0], hi[1]); o.w = pack2bf(hi[2], hi[3]);
         *(uint4*)((bf16_t*)pC + (size_t)m * p.ldc + n) = o;
+        if (p.epi_op == 1 && ((n >> 4) & 1) == 0) {
+          // ff.net.0.proj fused with GEGLU: this chunk holds 8 hidden columns, their gates sit 16 columns further in the same staged row
+          const f32x4 glo = *(const f32x4*)(src + 16), ghi = *(const f32x4*)(src + 20);
+          uint4 q;
+          q.x = pack2bf(lo[0] * gelu_f(glo[0]), lo[1] * gelu_f(glo[1])); q.y = pack2bf(lo[2] * gelu_f(glo[2]), lo[3] * gelu_f(glo[3]));
+          q.z = pack2bf(hi[0] * gelu_f(ghi[0]), hi[1] * gelu_f(ghi[1])); q.w = pack2bf(hi[2] * gelu_f(ghi[2]), hi[3] * gelu_f(ghi[3]));
+          *(uint4*)((bf16_t*)p.epi_out + (size_t)m * p.ld_epi_out + (n >> 5) * 16 + (n & 15)) = q;
+        }
       }
       if (pass + 1 < BM / CROWS) __syncthreads();
     }
@@ -941,6 +970,15 @@ extern "C" int sdlt_gemm_bf16(const sdlt_gemm_params* pp, void* stream) {
     if (p.M % (p.Hout * p.Wout)) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: conv M %% (Hout*Wout)");
   } else if (p.mode != 0) {
     SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: mode %d", p.mode);
+  }
+  if (p.epi_op) {
+    if (p.epi_op != 1 && p.epi_op != 2) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: epi_op %d", p.epi_op);
+    if (p.out_fp32 || p.Ct || p.batch || p.rowbias || !p.epi_out || (p.ld_epi_out & 7) || ((uintptr_t)p.epi_out & 15) || (p.N % (p.epi_op == 1 ? 32 : 16)))
+      SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: fused GEGLU epilogue needs a bf16 output, no Ct / batch / row bias, N %% %d == 0, 16-byte aligned rows", p.epi_op == 1 ? 32 : 16);
+    if (p.epi_op == 1 && (!p.C || (p.ldc & 7) || ((uintptr_t)p.C & 15) || (p.R && ((p.ldr & 7) || ((uintptr_t)p.R & 15)))))
+      SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_gemm_bf16: fused GEGLU forward: C / R rows must be 16-byte aligned");
+    if (p.epi_op == 2 && (!p.epi_in || (p.ld_epi_in & 7) || ((uintptr_t)p.epi_in & 15) || p.R))
+      SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_gemm_bf16: fused GEGLU backward: F1 rows must be 16-byte aligned, no residual");
   }
   if (p.accumulate && !p.out_fp32) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: accumulate needs an fp32 output (use R for bf16)");
   int r16 = 0;

@@ -96,8 +96,11 @@ def set_throughput_hint(flag):
 
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
-         residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0, batch=None):
+         residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0, batch=None,
+         geglu_out=None, geglu_bwd=None):
     """out[M,N] = alpha*(X.W^T [+ X2.W2^T] [+ s*(X.Adown^T).Bup^T]) + bias + rowbias[m//rows_per_batch] + residual.
+    geglu_out [M, N/2]: this GEMM is ff.net.0.proj in the interleaved-16 layout (geglu_perm) - also writes hidden * gelu(gate).
+    geglu_bwd = (F1 [M, 2N], dF1 [M, 2N]): this GEMM is the dX of ff.net.2 - writes GEGLU's input gradient instead of `out` (None).
     lora = (Adown [Rp,K], Bup [N,Rp], scale, T_out [M,Rp] or None).  out dtype bf16 or fp32.  Ct: optional
     transposed bf16 copy [N, >=M].  conv: ConvGeom -> X is the NHWC activation [B*Hin*Win, Cin].
     lora_group_n > 0: W is a stack of G = N / lora_group_n projections with one adapter each:
@@ -162,8 +165,18 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
         _chk2(residual)
         assert tuple(residual.shape) == (M, N)
         p.R, p.ldr = _p(residual), _ld(residual)
-    assert out.is_cuda and tuple(out.shape) == (M, N) and out.dtype in (BF16, F32)
-    p.C, p.ldc, p.out_fp32 = _p(out), _ld(out), int(out.dtype == F32)
+    if geglu_bwd is not None:
+        f1, df1 = geglu_bwd
+        _chk2(f1), _chk2(df1)
+        assert out is None and tuple(f1.shape) == (M, 2 * N) and tuple(df1.shape) == (M, 2 * N)
+        p.epi_op, p.epi_in, p.ld_epi_in, p.epi_out, p.ld_epi_out = 2, _p(f1), _ld(f1), _p(df1), _ld(df1)
+    else:
+        assert out.is_cuda and tuple(out.shape) == (M, N) and out.dtype in (BF16, F32)
+        p.C, p.ldc, p.out_fp32 = _p(out), _ld(out), int(out.dtype == F32)
+    if geglu_out is not None:
+        _chk2(geglu_out)
+        assert tuple(geglu_out.shape) == (M, N // 2) and geglu_bwd is None
+        p.epi_op, p.epi_out, p.ld_epi_out = 1, _p(geglu_out), _ld(geglu_out)
     if Ct is not None:
         _chk2(Ct)
         assert Ct.shape[0] == N and Ct.shape[1] >= M
@@ -174,7 +187,18 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
     slab, cnt = splitk_workspace(X.device)
     p.ws_slab, p.ws_slab_bytes, p.ws_cnt, p.ws_cnt_len = _p(slab), slab.numel(), _p(cnt), cnt.numel()
     _lib.check(lib.sdlt_gemm_bf16(C.byref(p), _stream()), "sdlt_gemm_bf16")
-    return out
+    return out if geglu_bwd is None else geglu_bwd[1]
+
+
+def geglu_perm(H, device=None):
+    """Row permutation of ff.net.0.proj's weight ([2H, K]: hidden rows then gate rows) into the interleaved-16 layout of the fused
+    GEGLU epilogues: new row (j // 16) * 32 + j % 16 = hidden j, 16 rows further its gate."""
+    j = torch.arange(H, device=device)
+    pos_h = (j // 16) * 32 + j % 16
+    perm = torch.empty(2 * H, dtype=torch.int64, device=device)
+    perm[pos_h] = j
+    perm[pos_h + 16] = H + j
+    return perm
 
 
 class GemmBatch:
@@ -475,6 +499,7 @@ def geglu_fwd(inp, out):
 
 
 def geglu_bwd(inp, dout, din):
+    """(halves layout [hidden | gate]; the interleaved-16 layout only exists inside the fused GEMM epilogues)"""
     lib = _lib.load()
     _chk2(inp), _chk2(dout), _chk2(din)
     M, C2 = inp.shape

@@ -211,7 +211,7 @@ class Linear(_Module):
     def weight_grad(self, dy, xs=None):
         self.trainer.linear(self.went, self.bent, xs if xs is not None else [self._x], dy)
 
-    def forward(self, x, *, residual=None, Ct=None, key="y", out=None, train=True):
+    def forward(self, x, *, residual=None, Ct=None, key="y", out=None, train=True, geglu_out=None):
         M = x.shape[0]
         y = out if out is not None else self.buf(key, M, self.N)
         lora = None
@@ -221,7 +221,10 @@ class Linear(_Module):
             self._x = x
         if self.trainer is not None:
             self._x = x
-        self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, residual=residual, Ct=Ct)
+        if geglu_out is not None:
+            self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, residual=residual, Ct=Ct, geglu_out=geglu_out)
+        else:
+            self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, residual=residual, Ct=Ct)
         return y
 
     def backward(self, dy, *, dres=None, Ct=None, key="dx", out=None):
@@ -645,18 +648,37 @@ class TransformerBlock(_Module):
         self.norm3 = LayerNorm(rt, name + ".norm3", sd)
         self.ff1 = Linear(rt, name + ".ff.net.0.proj", sd)
         self.ff2 = Linear(rt, name + ".ff.net.2", sd)
+        # GEGLU fused into the GEMMs on either side (sdlt_gemm_params.epi_op): ff.net.0.proj's rows are permuted into the
+        # interleaved-16 layout so that a hidden column and its gate share an output tile; hidden * gelu(gate) leaves the forward
+        # GEMM's epilogue and GEGLU's backward is the epilogue of ff.net.2's dX GEMM - two launches fewer per block and direction.
+        # (Not with the full fine-tune: its master weights / weight gradients keep the checkpoint's row order.)
+        H = self.ff2.K
+        self.fused_geglu = self.ff1.trainer is None and H % 16 == 0 and hasattr(rt.ops, "geglu_perm")
+        if self.fused_geglu:
+            perm = rt.ops.geglu_perm(H, self.ff1.W.device)
+            self.ff1.W = self.ff1.W[perm].contiguous()
+            self.ff1.Wt = self.ff1.W.t().contiguous()
+            self.ff1.bias = self.ff1.bias[perm].contiguous()
 
     def forward(self, x, ctx, B, N):
         x1 = self.attn1.forward(self.norm1.forward(x), None, B, N, residual=x)
         x2 = self.attn2.forward(self.norm2.forward(x1), ctx, B, N, residual=x1)
-        f1 = self.ff1.forward(self.norm3.forward(x2))
-        g = self.rt.ops.geglu_fwd(f1, self.buf("g", x.shape[0], f1.shape[1] // 2))
+        if self.fused_geglu:
+            g = self.buf("g", x.shape[0], self.ff2.K)
+            self.ff1.forward(self.norm3.forward(x2), geglu_out=g)
+        else:
+            f1 = self.ff1.forward(self.norm3.forward(x2))
+            g = self.rt.ops.geglu_fwd(f1, self.buf("g", x.shape[0], f1.shape[1] // 2))
         return self.ff2.forward(g, residual=x2)
 
     def backward(self, dx3, dctx):
         rt = self.rt
-        dg = self.ff2.backward(dx3)
-        df1 = rt.ops.geglu_bwd(self.ff1._b["y"], dg, self.buf("df1", *self.ff1._b["y"].shape))
+        if self.fused_geglu:
+            f1 = self.ff1._b["y"]
+            df1 = rt.ops.gemm(dx3, self.ff2.Wt, None, geglu_bwd=(f1, self.buf("df1", *f1.shape)))
+        else:
+            dg = self.ff2.backward(dx3)
+            df1 = rt.ops.geglu_bwd(self.ff1._b["y"], dg, self.buf("df1", *self.ff1._b["y"].shape))
         dx2 = self.norm3.backward(self.ff1.backward(df1), dres=dx3)
         dx1 = self.norm2.backward(self.attn2.backward(dx2, dctx), dres=dx2)
         return self.norm1.backward(self.attn1.backward(dx1), dres=dx1)

@@ -47,7 +47,20 @@ def set_throughput_hint(flag):
 
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
-         residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0, batch=None):
+         residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0, batch=None,
+         geglu_out=None, geglu_bwd=None):
+    if geglu_bwd is not None:     # dX of ff.net.2 fused with GEGLU's backward; F1 / dF1 in the interleaved-16 layout
+        f1, df1 = geglu_bwd
+        H = W.shape[0]
+        perm = geglu_perm(H)
+        dG = (X.float() @ W.float().t()) * alpha
+        halves = torch.empty_like(f1, dtype=F32)
+        halves[:, perm] = f1.float()                   # interleaved position p holds original row perm[p]
+        x = halves.clone().requires_grad_(True)
+        h, g_ = x.chunk(2, dim=1)
+        (gr,) = torch.autograd.grad(h * F.gelu(g_), x, dG)
+        df1.copy_(gr[:, perm].to(df1.dtype))
+        return df1
     if batch is not None:     # batched launch: every problem with its own operands, same options
         for it in batch.items:
             lo = None if lora is None else (it.get("Adown", lora[0]) if it.get("Adown") is not None else lora[0], it.get("Bup") if it.get("Bup") is not None else lora[1], lora[2], it.get("T_out") if it.get("T_out") is not None else lora[3])
@@ -89,7 +102,22 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
     out.copy_(acc.to(out.dtype))
     if Ct is not None:
         Ct[:, : acc.shape[0]].copy_(acc.t().to(Ct.dtype))
+    if geglu_out is not None:     # ff.net.0.proj in the interleaved-16 layout: hidden * gelu(gate)
+        H = acc.shape[1] // 2
+        halves = torch.empty_like(acc)
+        halves[:, geglu_perm(H)] = acc
+        h, g_ = halves.chunk(2, dim=1)
+        geglu_out.copy_((h * F.gelu(g_)).to(geglu_out.dtype))
     return out
+
+
+def geglu_perm(H, device=None):
+    j = torch.arange(H)
+    pos_h = (j // 16) * 32 + j % 16
+    perm = torch.empty(2 * H, dtype=torch.int64)
+    perm[pos_h] = j
+    perm[pos_h + 16] = H + j
+    return perm
 
 
 class GemmBatch:

@@ -40,6 +40,34 @@ def dev(*ts):
 
 
 # --------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,H,K,tile,splitk", [(300, 320, 128, 0, 0), (1024, 640, 320, 7, 0), (1024, 640, 320, 8, 0), (256, 64, 512, 3, 2),
+                                                 (1000, 1280, 320, 1, 0), (128, 160, 1024, 2, 4)])
+def test_gemm_fused_geglu_epilogues(ops, M, H, K, tile, splitk):
+    """sdlt_gemm_params.epi_op: ff.net.0.proj with the GEGLU product as a side output (1) and the dX of ff.net.2 with GEGLU's
+    backward as its epilogue (2), both on the interleaved-16 layout; 160-column tiles, split-K, ragged M included."""
+    g = torch.Generator().manual_seed(M + H)
+    x, w1, b1 = rnd(M, K, g=g), rnd(2 * H, K, g=g, scale=K ** -0.5), torch.randn(2 * H, generator=g)
+    perm = E.geglu_perm(H)
+    w1p, b1p = w1[perm].contiguous(), b1[perm].contiguous()
+    f1_ref, g_ref = torch.empty(M, 2 * H, dtype=BF), torch.empty(M, H, dtype=BF)
+    E.gemm(x, w1p, f1_ref, bias=b1p, geglu_out=g_ref)
+    # the interleaved layout is a pure column permutation of the ordinary projection
+    plain = torch.empty(M, 2 * H, dtype=BF)
+    E.gemm(x, w1, plain, bias=b1)
+    assert torch.equal(plain[:, perm], f1_ref) and torch.allclose(g_ref.float(), E.geglu_fwd(plain, torch.empty(M, H, dtype=BF)).float(), atol=2e-2, rtol=2e-2)
+    xd, wd, bd = dev(x, w1p, b1p)
+    f1, gg = torch.empty(M, 2 * H, dtype=BF, device="cuda"), torch.empty(M, H, dtype=BF, device="cuda")
+    ops.gemm(xd, wd, f1, bias=bd, geglu_out=gg, tile=tile, splitk=splitk)
+    close(f1, f1_ref, what="fused geglu: projection")
+    close(gg, g_ref, what="fused geglu: hidden * gelu(gate)")
+    dy, w2t = rnd(M, K, g=g), rnd(H, K, g=g, scale=K ** -0.5)          # dX of ff.net.2: dG = dy . W2 with W2^T [H, K]
+    df1_ref = torch.empty(M, 2 * H, dtype=BF)
+    E.gemm(dy, w2t, None, geglu_bwd=(f1_ref, df1_ref))
+    df1 = torch.full((M, 2 * H), 7.0, dtype=BF, device="cuda")
+    ops.gemm(dy.cuda(), w2t.cuda(), None, geglu_bwd=(f1_ref.cuda(), df1), tile=tile if tile not in (7, 8) or H % 160 == 0 else 0, splitk=splitk)
+    close(df1, df1_ref, tol=2e-2, what="fused geglu backward")
+
+
 @pytest.mark.parametrize("M,N,K,tile", [(256, 256, 128, 1), (200, 136, 64, 1), (77, 320, 192, 2), (1000, 77, 128, 3),
                                         (1, 1280, 320, 0), (4096, 640, 640, 0), (300, 4, 576, 3), (700, 300, 256, 4),
                                         (333, 260, 320, 5)])
