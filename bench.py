@@ -71,6 +71,51 @@ def lr_at(step, max_steps, unet_lr=1e-3, base=5e-5):
     return base * (unet_lr / base) ** (step / max_steps)
 
 
+def usable_cores():
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota (a container that shows 256 CPUs but
+    is allowed 32 makes a 256-thread OpenMP team crawl), then halved when SMT siblings are counted twice."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False)
+        if phys:
+            n = min(n, phys)
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def run_guarded(argv, timeout_s):
+    """Run `python bench.py <argv>` as a child with a wall-clock limit; returns the JSON objects it printed (one per line) - whatever
+    was complete when it ended or was killed.  The extras of the default run (CPU baseline, train() loop) must never be able to keep
+    the one JSON line from being printed."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, capture_output=True, text=True, timeout=timeout_s).stdout
+    except subprocess.TimeoutExpired as e:
+        out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+    res = []
+    for line in out.splitlines():
+        if line.startswith("{"):
+            try:
+                res.append(json.loads(line))
+            except Exception:
+                pass
+    return res
+
+
 def cpu_baseline(version, rank, full_hw, budget_s=45.0):
     """The fp32 oracle (oracle/: CPU port of the reference path - diffusers-style UNet + peft LoRA restatement, the reference's
     loss) timed on this host's cores: forward + backward to every LoRA tensor and to the text conditioning, 1 warm-up + timed
@@ -80,7 +125,7 @@ def cpu_baseline(version, rank, full_hw, budget_s=45.0):
     from oracle import unet_ref as U
     from sd_lora_trainer_amd import topology
     cfg = U.CONFIGS[version]
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     sd = {}
@@ -120,6 +165,7 @@ def cpu_baseline(version, rank, full_hw, budget_s=45.0):
     small = max(full_hw // 4, 8)
     one_step(small)                                      # cold pass (page-in, thread pools)
     t_small = one_step(small)
+    print(json.dumps(dict(times=[t_small], hw=small, flops=flops(small), cores=cores)), flush=True)     # (child mode: a first, complete answer)
     h = small
     for cand in (full_hw, full_hw // 2):
         if cand > small and 3.0 * t_small * flops(cand) / flops(small) <= budget_s:
@@ -130,6 +176,37 @@ def cpu_baseline(version, rank, full_hw, budget_s=45.0):
         one_step(h)                                      # warm-up at the chosen size
         times = [one_step(h), one_step(h)]
     return dict(times=times, hw=h, flops=flops(h), cores=cores)
+
+
+def train_loop_measure(args):
+    """The workload driven by the train() generator (sd_lora_trainer_amd.train, the main.py:34-551 mirror): per step LR schedules,
+    posterior sampling, noise / timestep draws, caption dropout, host->device copies of the batch (set_batch), then the graph replay;
+    images_per_second as the loop itself measures it (checkpoint writes and the one-off graph capture excluded)."""
+    import shutil
+    import tempfile
+    from sd_lora_trainer_amd.config import TrainingConfig
+    from sd_lora_trainer_amd.train import train
+    version = args.config
+    res = args.res or (1024 if "xl" in version else 512)
+    B = args.batch or (1 if "xl" in version else 4)
+    tmp = tempfile.mkdtemp(prefix="sdlt_bench_")
+    try:
+        n_loop = max(args.steps, 20) + 5
+        cfg_t = TrainingConfig(lora_training_urls="synthetic:8", concept_mode="object", pretrained_model={"path": f"synthetic:{version}"}, seed=0,
+                               resolution=res, train_batch_size=B, max_train_steps=n_loop, lora_rank=args.rank, output_dir=tmp, n_sample_imgs=0,
+                               unet_lr=1e-3, ti_lr=1e-3)
+        gen = train(cfg_t)
+        try:
+            while True:
+                next(gen)
+        except StopIteration as e:
+            cfg_done, _ = e.value
+        ips = cfg_done.training_attributes["images_per_second"]
+        return {"value": ips, "unit": "images/s", "ms_per_step": 1e3 * B / ips, "steps": n_loop + 1,
+                "note": "extra measurement, not `value`: the train() generator's own loop on the same workload (synthetic 8-image latent cache), "
+                        "host work of every step included"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -149,9 +226,19 @@ def main():
                     "text encoders and hipGraph each, one stream per job); a 'step' then advances every job once")
     ap.add_argument("--no-concurrent", action="store_true", help="skip the extra two-jobs-per-GPU measurement of the default run")
     ap.add_argument("--no-train-loop", action="store_true", help="skip the extra measurement of the train() generator's own step loop")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)      # child modes of the guarded extras
+    ap.add_argument("--train-loop-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--full-ft", action="store_true", help="full-UNet fine-tune (BASELINE configs[4], train_configs/full_finetuning_example.json: "
                     "SDXL 512 px, batch 4 per GPU, AdamW over every UNet parameter); data parallel with one gradient all-reduce per step when --gpus > 1")
     args = ap.parse_args()
+    if args.cpu_baseline_only:          # child of the default run: prints one JSON object per completed measurement
+        version = args.config
+        res = args.res or (1024 if "xl" in version else 512)
+        print(json.dumps(cpu_baseline(version, args.rank, res // 8)), flush=True)
+        return
+    if args.train_loop_only:
+        print(json.dumps(train_loop_measure(args)), flush=True)
+        return
 
     from sd_lora_trainer_amd import parallel
     rank, world, local_rank = parallel.init_distributed("nccl")
@@ -327,44 +414,31 @@ def main():
                                  "rocprofv3 PMC passes of this command (profiles/r0x_sdxl1024_ti_hbm_traffic_pmc.json, collected with the kernels of the commit named "
                                  "in that file), null for other configs"},
         }
+        print(f"[bench] timed region done: {t_step * 1e3:.2f} ms/step; extras follow", file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline and not full_ft:
-            cb = cpu_baseline(version, args.rank, h)
-            dt = sum(cb["times"]) / len(cb["times"])
-            scaled = dt * (f_step / B) / cb["flops"]     # seconds per full-size image on this host (== dt when the sample IS the full size)
-            same = cb["hw"] == h
-            out["cpu_baseline"] = {"value": 1.0 / scaled, "unit": "images/s", "cores": cb["cores"], "kind": "port",
-                                   "step_seconds": [round(x, 3) for x in cb["times"]],
-                                   "sample": f"fp32 oracle (CPU port of the reference path) fwd+bwd steps at {cb['hw'] * 8}x{cb['hw'] * 8} B=1 after a warm-up: "
-                                             + ", ".join(f"{x:.2f} s" for x in cb["times"]) + f" ({cb['flops'] / 1e12:.2f} TFLOP each, {cb['cores']} threads)"
-                                             + ("" if same else f"; scaled by the FLOP ratio to the {res}x{res} workload (the full size did not fit the time budget of the default run)")}
+            # measured in a CHILD process with a wall-clock limit: nothing on the host side may keep the JSON line from being printed
+            child = run_guarded(["--cpu-baseline-only", "--config", version, "--res", str(res), "--rank", str(args.rank)], 420)
+            if child:
+                cb = child[-1]                  # the last complete measurement (full size if it finished, else the calibration sample)
+                dt = sum(cb["times"]) / len(cb["times"])
+                scaled = dt * (f_step / B) / cb["flops"]     # seconds per full-size image on this host (== dt when the sample IS the full size)
+                same = cb["hw"] == h
+                out["cpu_baseline"] = {"value": 1.0 / scaled, "unit": "images/s", "cores": cb["cores"], "kind": "port",
+                                       "step_seconds": [round(x, 3) for x in cb["times"]],
+                                       "sample": f"fp32 oracle (CPU port of the reference path) fwd+bwd steps at {cb['hw'] * 8}x{cb['hw'] * 8} B=1 after a warm-up: "
+                                                 + ", ".join(f"{x:.2f} s" for x in cb["times"]) + f" ({cb['flops'] / 1e12:.2f} TFLOP each, {cb['cores']} threads)"
+                                                 + ("" if same else f"; scaled by the FLOP ratio to the {res}x{res} workload (the full size did not fit the time budget of the default run)")}
+            print("[bench] cpu baseline done", file=sys.stderr, flush=True)
+            if not child:
+                out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": usable_cores(), "kind": "port", "step_seconds": [],
+                                       "sample": "the CPU oracle did not complete a step within the 420 s guard of the default run"}
         if world == 1 and J == 1 and not full_ft and not args.no_graph and not args.no_train_loop and text is not None:
-            # Extra measurement (never `value`): the SAME workload driven by the train() generator (sd_lora_trainer_amd.train, the
-            # main.py:34-551 mirror) - per step: LR schedules, posterior sampling, noise / timestep draws, caption dropout, host->device
-            # copies of the batch (set_batch), then the graph replay; images_per_second as the loop itself measures it (checkpoint
-            # writes and the one-off graph capture excluded).
-            import shutil
-            import tempfile
-            from sd_lora_trainer_amd.config import TrainingConfig
-            from sd_lora_trainer_amd.train import train
-            tmp = tempfile.mkdtemp(prefix="sdlt_bench_")
-            try:
-                n_loop = max(args.steps, 20) + 5
-                cfg_t = TrainingConfig(lora_training_urls="synthetic:8", concept_mode="object", pretrained_model={"path": f"synthetic:{version}"}, seed=0,
-                                       resolution=res, train_batch_size=B, max_train_steps=n_loop, lora_rank=args.rank, output_dir=tmp, n_sample_imgs=0,
-                                       unet_lr=1e-3, ti_lr=1e-3)
-                gen = train(cfg_t)
-                try:
-                    while True:
-                        next(gen)
-                except StopIteration as e:
-                    cfg_done, _ = e.value
-                ips = cfg_done.training_attributes["images_per_second"]
-                out["train_loop"] = {"value": ips, "unit": "images/s", "ms_per_step": 1e3 * B / ips, "steps": n_loop + 1,
-                                     "note": "extra measurement, not `value`: the train() generator's own loop on the same workload (synthetic 8-image "
-                                             "latent cache), host work of every step included"}
-            finally:
-                shutil.rmtree(tmp, ignore_errors=True)
-                torch.cuda.empty_cache()
+            # Extra measurement (never `value`), in a child process with a wall-clock limit (see train_loop_measure)
+            child = run_guarded(["--train-loop-only", "--config", version, "--res", str(res), "--rank", str(args.rank), "--steps", str(args.steps)]
+                                + (["--batch", str(args.batch)] if args.batch else []), 420)
+            if child:
+                out["train_loop"] = child[-1]
+            print("[bench] train loop done", file=sys.stderr, flush=True)
         if world == 1 and J == 1 and not full_ft and not args.no_graph and not args.no_concurrent:
             # Extra measurement (never `value`): the same workload with TWO independent jobs stepped concurrently on this GPU,
             # each on its own stream with its own hipGraph (train.train_concurrent).

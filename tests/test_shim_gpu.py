@@ -14,5 +14,5 @@ def test_reference_loop_body_on_shim_gpu(version, B):
     import sd_lora_trainer_amd.unet as unet_mod
     from tests.test_shim_cpu import run_shim_vs_oracle
     rt = unet_mod.Runtime("cuda:0", B)
-    unet, losses = run_shim_vs_oracle(version, B, 16, rt, dict(pred=4e-2, loss=2e-2, cos=0.99, param=4e-3), steps=4)
+    unet, losses = run_shim_vs_oracle(version, B, 16, rt, dict(pred=4e-2, loss=2e-2, cos=0.99, param=1.5e-2), steps=4)
     assert all(l == l for l, _ in losses)
