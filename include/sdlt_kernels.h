@@ -100,8 +100,11 @@ typedef struct sdlt_gemm_params {
        epi_op = 2 (backward, this GEMM is the dX of ff.net.2, N = H): with dG the product that would have gone to C,
                   epi_out [M, 2H] bf16 (interleaved) = d F1 = [dG * gelu(gate) | dG * hidden * gelu'(gate)], hidden / gate read
                   from epi_in = F1 [M, 2H]; C is not written (may be NULL).
-     bf16 outputs only, no Ct, N % 32 == 0 (op 1) / N % 16 == 0 (op 2). */
-  int32_t epi_op; int32_t pad_epi_;
+       epi_op = 3 (activation side output, the CLIP MLP's fc1): C = pre-activation as usual, epi_out [M, N] bf16 = act(C).
+       epi_op = 4 (activation backward, the dX of fc2): C = product * act'(epi_in), epi_in [M, N] bf16 = the forward pre-activation.
+       epi_act: 0 = gelu (erf), 1 = quick_gelu x*sigmoid(1.702x)  (ops 3, 4).
+     bf16 outputs only, no Ct, N % 32 == 0 (op 1) / N % 16 == 0 (op 2) / N % 8 == 0 (ops 3, 4). */
+  int32_t epi_op; int32_t epi_act;
   void* epi_out; int64_t ld_epi_out;
   const void* epi_in; int64_t ld_epi_in;
 } sdlt_gemm_params;

@@ -37,7 +37,7 @@ class GemmParams(C.Structure):
         ("splitk", i32), ("ws_cnt_len", i32), ("ws_slab", vp), ("ws_slab_bytes", i64), ("stages", i32), ("accumulate", i32), ("ws_cnt", vp),
         ("lora_group_n", i32), ("lora_group_k", i32),
         ("batch", vp), ("n_batch", i32), ("throughput_hint", i32),
-        ("epi_op", i32), ("pad_epi_", i32), ("epi_out", vp), ("ld_epi_out", i64), ("epi_in", vp), ("ld_epi_in", i64),
+        ("epi_op", i32), ("epi_act", i32), ("epi_out", vp), ("ld_epi_out", i64), ("epi_in", vp), ("ld_epi_in", i64),
     ]
 
 

@@ -54,6 +54,7 @@ class ClipLayer(_Module):
         self.d = self.D // heads
         self.scale = 1.0 / math.sqrt(self.d)
         self.act, self.dact = (_ops.MAP_QGELU, _ops.MAP_DQGELU) if act == "quick_gelu" else (_ops.MAP_GELU, _ops.MAP_DGELU)
+        self.act_kind = "quick_gelu" if act == "quick_gelu" else "gelu"
 
     def _akw(self, B):
         return dict(B=B, H=self.heads, Nq=T_TOKENS, Nk=T_TOKENS, Nqp=TP, Nkp=TP, d=self.d, scale=self.scale, causal=True)
@@ -65,16 +66,16 @@ class ClipLayer(_Module):
         O, L = self.buf("O", M, D), self.buf("L", B * self.heads * T_TOKENS, dtype=F32)
         rt.ops.attn_fwd(q, k, v, None, O, L, **self._akw(B))
         x1 = self.o.forward(O, residual=x)
-        f = self.fc1.forward(self.ln2.forward(x1))
-        a = rt.ops.map_bf16(self.act, f, None, self.buf("a", *f.shape))
+        # the activation leaves fc1's epilogue (sdlt_gemm_params.epi_op 3), its derivative is the epilogue of fc2's dX GEMM (4)
+        a = self.buf("a", M, self.fc1.N)
+        self.fc1.forward(self.ln2.forward(x1), act_out=(self.act_kind, a))
         self._B = B
         return self.fc2.forward(a, residual=x1, out=out)
 
     def backward(self, dx2):
         rt, B, D = self.rt, self._B, self.D
         M = B * TP
-        da = self.fc2.backward(dx2)
-        df = rt.ops.map_bf16(self.dact, self.fc1._b["y"], da, self.buf("df", *da.shape))
+        df = self.fc2.backward(dx2, dact_in=(self.act_kind, self.fc1._b["y"]))
         dx1 = self.ln2.backward(self.fc1.backward(df), dres=dx2)
         dO = self.o.backward(dx1)
         dqkv, (dq, dk, dv) = self.qkv.grad_slices(M)

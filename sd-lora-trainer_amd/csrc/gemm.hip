@@ -676,8 +676,31 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
           *(uint4*)(dst + 16) = o;
           continue;
         }
+        if (p.epi_op == 4) {      // dX of the MLP's second projection times act'(pre-activation of the first)
+          const uint4 pv = *(const uint4*)((const bf16_t*)p.epi_in + (size_t)m * p.ld_epi_in + n);
+          const uint32_t* pp = (const uint32_t*)&pv;
+          float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float x = bf2f((pp[j >> 1] >> ((j & 1) * 16)) & 0xffff);
+            float d;
+            if (p.epi_act == 1) { const float sg = 1.f / (1.f + __expf(-1.702f * x)); d = sg + 1.702f * x * sg * (1.f - sg); }
+            else d = dgelu_f(x);
+            v8[j] *= d;
+          }
+          lo = (f32x4){v8[0], v8[1], v8[2], v8[3]};
+          hi = (f32x4){v8[4], v8[5], v8[6], v8[7]};
+        }
         o.x = pack2bf(lo[0], lo[1]); o.y = pack2bf(lo[2], lo[3]); o.z = pack2bf(hi[0], hi[1]); o.w = pack2bf(hi[2], hi[3]);
         *(uint4*)((bf16_t*)pC + (size_t)m * p.ldc + n) = o;
+        if (p.epi_op == 3) {      // activation side output (from the fp32 values, before the bf16 rounding of C)
+          float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v8[j] = p.epi_act == 1 ? v8[j] / (1.f + __expf(-1.702f * v8[j])) : gelu_f(v8[j]);
+          uint4 q;
+          q.x = pack2bf(v8[0], v8[1]); q.y = pack2bf(v8[2], v8[3]); q.z = pack2bf(v8[4], v8[5]); q.w = pack2bf(v8[6], v8[7]);
+          *(uint4*)((bf16_t*)p.epi_out + (size_t)m * p.ld_epi_out + n) = q;
+        }
         if (p.epi_op == 1 && ((n >> 4) & 1) == 0) {
           // ff.net.0.proj fused with GEGLU: this chunk holds 8 hidden columns, their gates sit 16 columns further in the same staged row
           const f32x4 glo = *(const f32x4*)(src + 16), ghi = *(const f32x4*)(src + 20);
@@ -972,9 +995,14 @@ extern "C" int sdlt_gemm_bf16(const sdlt_gemm_params* pp, void* stream) {
     SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: mode %d", p.mode);
   }
   if (p.epi_op) {
-    if (p.epi_op != 1 && p.epi_op != 2) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: epi_op %d", p.epi_op);
-    if (p.out_fp32 || p.Ct || p.batch || p.rowbias || !p.epi_out || (p.ld_epi_out & 7) || ((uintptr_t)p.epi_out & 15) || (p.N % (p.epi_op == 1 ? 32 : 16)))
-      SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: fused GEGLU epilogue needs a bf16 output, no Ct / batch / row bias, N %% %d == 0, 16-byte aligned rows", p.epi_op == 1 ? 32 : 16);
+    if (p.epi_op < 1 || p.epi_op > 4) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: epi_op %d", p.epi_op);
+    const int nmul = p.epi_op == 1 ? 32 : (p.epi_op == 2 ? 16 : 8);
+    if (p.out_fp32 || p.Ct || p.batch || p.rowbias || (p.N % nmul) || (p.epi_op != 4 && (!p.epi_out || (p.ld_epi_out & 7) || ((uintptr_t)p.epi_out & 15))))
+      SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: fused epilogue %d needs a bf16 output, no Ct / batch / row bias, N %% %d == 0, 16-byte aligned rows", p.epi_op, nmul);
+    if ((p.epi_op == 3 || p.epi_op == 4) && (!p.C || (p.ldc & 7) || ((uintptr_t)p.C & 15) || (p.R && ((p.ldr & 7) || ((uintptr_t)p.R & 15)))))
+      SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_gemm_bf16: fused activation epilogue: C / R rows must be 16-byte aligned");
+    if (p.epi_op == 4 && (!p.epi_in || (p.ld_epi_in & 7) || ((uintptr_t)p.epi_in & 15)))
+      SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_gemm_bf16: fused activation backward: pre-activation rows must be 16-byte aligned");
     if (p.epi_op == 1 && (!p.C || (p.ldc & 7) || ((uintptr_t)p.C & 15) || (p.R && ((p.ldr & 7) || ((uintptr_t)p.R & 15)))))
       SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_gemm_bf16: fused GEGLU forward: C / R rows must be 16-byte aligned");
     if (p.epi_op == 2 && (!p.epi_in || (p.ld_epi_in & 7) || ((uintptr_t)p.epi_in & 15) || p.R))

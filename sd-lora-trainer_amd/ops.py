@@ -97,8 +97,10 @@ def set_throughput_hint(flag):
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
          residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0, batch=None,
-         geglu_out=None, geglu_bwd=None):
+         geglu_out=None, geglu_bwd=None, act_out=None, dact_in=None):
     """out[M,N] = alpha*(X.W^T [+ X2.W2^T] [+ s*(X.Adown^T).Bup^T]) + bias + rowbias[m//rows_per_batch] + residual.
+    act_out = (kind, A [M,N]): also writes A = act(out), kind "gelu" | "quick_gelu" (the CLIP MLP's fc1).
+    dact_in = (kind, P [M,N]): out = (...) * act'(P), P = the forward pre-activation (the dX of the CLIP MLP's fc2).
     geglu_out [M, N/2]: this GEMM is ff.net.0.proj in the interleaved-16 layout (geglu_perm) - also writes hidden * gelu(gate).
     geglu_bwd = (F1 [M, 2N], dF1 [M, 2N]): this GEMM is the dX of ff.net.2 - writes GEGLU's input gradient instead of `out` (None).
     lora = (Adown [Rp,K], Bup [N,Rp], scale, T_out [M,Rp] or None).  out dtype bf16 or fp32.  Ct: optional
@@ -173,6 +175,16 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
     else:
         assert out.is_cuda and tuple(out.shape) == (M, N) and out.dtype in (BF16, F32)
         p.C, p.ldc, p.out_fp32 = _p(out), _ld(out), int(out.dtype == F32)
+    if act_out is not None or dact_in is not None:
+        assert geglu_out is None and geglu_bwd is None and not (act_out is not None and dact_in is not None)
+        kind, t = act_out if act_out is not None else dact_in
+        _chk2(t)
+        assert tuple(t.shape) == (M, N) and kind in ("gelu", "quick_gelu")
+        p.epi_act = int(kind == "quick_gelu")
+        if act_out is not None:
+            p.epi_op, p.epi_out, p.ld_epi_out = 3, _p(t), _ld(t)
+        else:
+            p.epi_op, p.epi_in, p.ld_epi_in = 4, _p(t), _ld(t)
     if geglu_out is not None:
         _chk2(geglu_out)
         assert tuple(geglu_out.shape) == (M, N // 2) and geglu_bwd is None

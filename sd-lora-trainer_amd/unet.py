@@ -211,7 +211,7 @@ class Linear(_Module):
     def weight_grad(self, dy, xs=None):
         self.trainer.linear(self.went, self.bent, xs if xs is not None else [self._x], dy)
 
-    def forward(self, x, *, residual=None, Ct=None, key="y", out=None, train=True, geglu_out=None):
+    def forward(self, x, *, residual=None, Ct=None, key="y", out=None, train=True, geglu_out=None, act_out=None):
         M = x.shape[0]
         y = out if out is not None else self.buf(key, M, self.N)
         lora = None
@@ -223,11 +223,13 @@ class Linear(_Module):
             self._x = x
         if geglu_out is not None:
             self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, residual=residual, Ct=Ct, geglu_out=geglu_out)
+        elif act_out is not None:
+            self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, residual=residual, Ct=Ct, act_out=act_out)
         else:
             self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, residual=residual, Ct=Ct)
         return y
 
-    def backward(self, dy, *, dres=None, Ct=None, key="dx", out=None):
+    def backward(self, dy, *, dres=None, Ct=None, key="dx", out=None, dact_in=None):
         M = dy.shape[0]
         dx = out if out is not None else self.buf(key, M, self.K)
         lora = None
@@ -242,7 +244,10 @@ class Linear(_Module):
                 self._registered = True
         if self.trainer is not None:
             self.weight_grad(dy)
-        self.rt.ops.gemm(dy, self.Wt, dx, lora=lora, residual=dres, Ct=Ct)
+        if dact_in is not None:
+            self.rt.ops.gemm(dy, self.Wt, dx, lora=lora, residual=dres, Ct=Ct, dact_in=dact_in)
+        else:
+            self.rt.ops.gemm(dy, self.Wt, dx, lora=lora, residual=dres, Ct=Ct)
         return dx
 
 

@@ -48,7 +48,7 @@ def set_throughput_hint(flag):
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
          residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0, batch=None,
-         geglu_out=None, geglu_bwd=None):
+         geglu_out=None, geglu_bwd=None, act_out=None, dact_in=None):
     if geglu_bwd is not None:     # dX of ff.net.2 fused with GEGLU's backward; F1 / dF1 in the interleaved-16 layout
         f1, df1 = geglu_bwd
         H = W.shape[0]
@@ -99,7 +99,16 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
         acc = acc + residual.float()
     if accumulate:
         acc = acc + out.float()
+    if dact_in is not None:       # out = product * act'(pre-activation)
+        kind, pre = dact_in
+        x = pre.detach().float().clone().requires_grad_(True)
+        y = F.gelu(x) if kind == "gelu" else x * torch.sigmoid(1.702 * x)
+        (dx,) = torch.autograd.grad(y, x, acc)
+        acc = dx
     out.copy_(acc.to(out.dtype))
+    if act_out is not None:
+        kind, a_ = act_out
+        a_.copy_((F.gelu(acc) if kind == "gelu" else acc * torch.sigmoid(1.702 * acc)).to(a_.dtype))
     if Ct is not None:
         Ct[:, : acc.shape[0]].copy_(acc.t().to(Ct.dtype))
     if geglu_out is not None:     # ff.net.0.proj in the interleaved-16 layout: hidden * gelu(gate)

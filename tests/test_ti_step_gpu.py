@@ -127,7 +127,8 @@ def test_ti_step_gpu_matches_oracle(version, B, concurrent):
                      caption_token_lists=lists, ctx=ctx_c, pooled=pooled_c)
         ts.run(1e-3, lr_ti=0.0)
         torch.cuda.synchronize()
-        assert ts._cond_cached and float(ts.loss) == l_ref and torch.equal(a.params, p_ref)
+        dl, dp = abs(float(ts.loss) - l_ref) / abs(l_ref), float((a.params - p_ref).abs().max())
+        assert ts._cond_cached and dl <= 1e-6 and dp <= 1e-7, f"cached conditioning: loss rel diff {dl}, max parameter diff {dp} (lr 1e-3)"
 
 
 @pytest.mark.parametrize("version,B,rank", [("tiny15", 2, 16), ("tinyxl", 2, 8)])
