@@ -40,7 +40,9 @@ struct ConvGeom {
 template <int N_>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
-template <int MI, int NI, int WN, int MODE, int R16, int NSTAGE, int KG = 0, int BT = 0, int WM = 2>
+// EPI: the fused epilogue (sdlt_gemm_params.epi_op) as a TEMPLATE parameter - with a run-time switch the GEGLU / activation code sat
+// in every instantiation and the whole GEMM family ran ~6 % slower (code size; the step alternates between ~60 kernels).
+template <int MI, int NI, int WN, int MODE, int R16, int NSTAGE, int KG = 0, int BT = 0, int WM = 2, int EPI = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_params p) {
   // batched launch: blockIdx.y picks the problem; its operand pointers replace the launch-wide ones (wave-uniform scalar loads)
   // (BT is a template switch so that ordinary launches do not pay the extra kernarg loads and selects in their prologue)
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
   constexpr bool RPRE = RIT <= 4 && QPP * NTHR == CROWS * NCH;   // residual prefetch: at most 4 x 16 B per lane
   const bool vec_ok = ((p.ldc & 3) == 0) && (p.R == nullptr || (p.ldr & 3) == 0) &&
                       (p.rowbias == nullptr || (p.ld_rowbias & 3) == 0);
-  const bool staged = p.epi_op != 0 ||      // (the fused GEGLU epilogues live in the staged store loop; the host checked their alignment)
+  const bool staged = EPI != 0 ||      // (the fused GEGLU epilogues live in the staged store loop; the host checked their alignment)
                       ((long)p.M * p.N >= (1l << 20) && !p.out_fp32 && pCt == nullptr && vec_ok && (p.ldc & 7) == 0 && (p.N & 7) == 0 &&
                        (p.R == nullptr || (p.ldr & 7) == 0) && (((uintptr_t)pC | (uintptr_t)p.R) & 15) == 0);
   uint4 rpre[RPRE ? RIT : 1];
@@ -656,7 +658,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
           hi[0] += bf2f(rv.z & 0xffff); hi[1] += bf2f(rv.z >> 16); hi[2] += bf2f(rv.w & 0xffff); hi[3] += bf2f(rv.w >> 16);
         }
         uint4 o;
-        if (p.epi_op == 2) {
+        if constexpr (EPI == 2) {
           // dX of ff.net.2 fused with GEGLU's backward: lo/hi = dG[m, n..n+7] (hidden index n); hidden / gate of the forward from F1
           const size_t fo = (size_t)m * p.ld_epi_in + (n >> 4) * 32 + (n & 15);
           const uint4 hv = *(const uint4*)((const bf16_t*)p.epi_in + fo), gv = *(const uint4*)((const bf16_t*)p.epi_in + fo + 16);
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
           *(uint4*)(dst + 16) = o;
           continue;
         }
-        if (p.epi_op == 4) {      // dX of the MLP's second projection times act'(pre-activation of the first)
+        if constexpr (EPI == 4) {      // dX of the MLP's second projection times act'(pre-activation of the first)
           const uint4 pv = *(const uint4*)((const bf16_t*)p.epi_in + (size_t)m * p.ld_epi_in + n);
           const uint32_t* pp = (const uint32_t*)&pv;
           float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -693,7 +695,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
         }
         o.x = pack2bf(lo[0], lo[1]); o.y = pack2bf(lo[2], lo[3]); o.z = pack2bf(hi[0], hi[1]); o.w = pack2bf(hi[2], hi[3]);
         *(uint4*)((bf16_t*)pC + (size_t)m * p.ldc + n) = o;
-        if (p.epi_op == 3) {      // activation side output (from the fp32 values, before the bf16 rounding of C)
+        if constexpr (EPI == 3) {      // activation side output (from the fp32 values, before the bf16 rounding of C)
           float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
           for (int j = 0; j < 8; ++j) v8[j] = p.epi_act == 1 ? v8[j] / (1.f + __expf(-1.702f * v8[j])) : gelu_f(v8[j]);
@@ -701,7 +703,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
           q.x = pack2bf(v8[0], v8[1]); q.y = pack2bf(v8[2], v8[3]); q.z = pack2bf(v8[4], v8[5]); q.w = pack2bf(v8[6], v8[7]);
           *(uint4*)((bf16_t*)p.epi_out + (size_t)m * p.ld_epi_out + n) = q;
         }
-        if (p.epi_op == 1 && ((n >> 4) & 1) == 0) {
+        if (EPI == 1 && ((n >> 4) & 1) == 0) {
           // ff.net.0.proj fused with GEGLU: this chunk holds 8 hidden columns, their gates sit 16 columns further in the same staged row
           const f32x4 glo = *(const f32x4*)(src + 16), ghi = *(const f32x4*)(src + 20);
           uint4 q;
@@ -769,7 +771,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
   }
 }
 
-template <int MI, int NI, int WN, int MODE, int R16, int NSREQ, int KG = 0, int BT = 0, int WM = 2>
+template <int MI, int NI, int WN, int MODE, int R16, int NSREQ, int KG = 0, int BT = 0, int WM = 2, int EPI = 0>
 int launch(const sdlt_gemm_params& p, hipStream_t stream) {
   constexpr int NTHR = 64 * WM * WN;
   constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
@@ -785,7 +787,7 @@ int launch(const sdlt_gemm_params& p, hipStream_t stream) {
   const int smem = NBUF * STAGE + TSH;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_kernel<MI, NI, WN, MODE, R16, NS, KG, BT, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute((const void*)gemm_kernel<MI, NI, WN, MODE, R16, NS, KG, BT, WM, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
@@ -796,7 +798,7 @@ int launch(const sdlt_gemm_params& p, hipStream_t stream) {
     if (!p.ws_slab || !p.ws_cnt || (size_t)nbm * nbn * splitk * slab_bytes > (size_t)p.ws_slab_bytes || nbm * nbn > p.ws_cnt_len)
       SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: split-K workspace too small (%d tiles x %d splits x %zu B)", nbm * nbn, splitk, slab_bytes);
   }
-  hipLaunchKernelGGL((gemm_kernel<MI, NI, WN, MODE, R16, NS, KG, BT, WM>), dim3(nbm * nbn * splitk, BT ? p.n_batch : 1), dim3(NTHR), smem, stream, p);
+  hipLaunchKernelGGL((gemm_kernel<MI, NI, WN, MODE, R16, NS, KG, BT, WM, EPI>), dim3(nbm * nbn * splitk, BT ? p.n_batch : 1), dim3(NTHR), smem, stream, p);
   }
   return SDLT_OK;
 }
@@ -969,6 +971,27 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
     }
     SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: lora_group_k needs mode 0, padded rank 16 and tile 1..3 (tile %d)", p.tile);
   }
+  if (p.epi_op) {   // fused GEGLU / activation epilogues: plain GEMM mode without LoRA, tiles 1, 2, 3, 7, 8 with the deep ring
+    if constexpr (MODE == 0 && R16 == 0) {
+      if (p.tile == 4 || p.tile == 5 || p.tile == 6) p.tile = 1;
+#define SDLT_EPI_CASES(E)                                                      \
+      switch (p.tile) {                                                        \
+        case 1: return launch<4, 2, 4, 0, 0, 4, 0, 0, 2, E>(p, s);             \
+        case 2: return launch<2, 2, 4, 0, 0, 4, 0, 0, 2, E>(p, s);             \
+        case 3: return launch<2, 2, 2, 0, 0, 4, 0, 0, 2, E>(p, s);             \
+        case 7: return launch<4, 5, 2, 0, 0, 4, 0, 0, 4, E>(p, s);             \
+        case 8: return launch<2, 5, 2, 0, 0, 4, 0, 0, 4, E>(p, s);             \
+      }
+      switch (p.epi_op) {
+        case 1: SDLT_EPI_CASES(1) break;
+        case 2: SDLT_EPI_CASES(2) break;
+        case 3: SDLT_EPI_CASES(3) break;
+        case 4: SDLT_EPI_CASES(4) break;
+      }
+#undef SDLT_EPI_CASES
+    }
+    SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: fused epilogue %d needs mode 0 without LoRA (tile %d)", p.epi_op, p.tile);
+  }
   if (p.stages == 2) { SDLT_TILE_CASES(2) } else { SDLT_TILE_CASES(4) }
 #undef SDLT_TILE_CASES
   SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: tile id %d", p.tile);
@@ -996,6 +1019,7 @@ extern "C" int sdlt_gemm_bf16(const sdlt_gemm_params* pp, void* stream) {
   }
   if (p.epi_op) {
     if (p.epi_op < 1 || p.epi_op > 4) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: epi_op %d", p.epi_op);
+    if (p.mode != 0 || p.lora_R) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: fused epilogues exist for plain GEMMs without LoRA");
     const int nmul = p.epi_op == 1 ? 32 : (p.epi_op == 2 ? 16 : 8);
     if (p.out_fp32 || p.Ct || p.batch || p.rowbias || (p.N % nmul) || (p.epi_op != 4 && (!p.epi_out || (p.ld_epi_out & 7) || ((uintptr_t)p.epi_out & 15))))
       SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: fused epilogue %d needs a bf16 output, no Ct / batch / row bias, N %% %d == 0, 16-byte aligned rows", p.epi_op, nmul);

@@ -34,10 +34,32 @@ class TokenAttentionLoss:
         self.loss = torch.zeros(1, device=dev)
         self._bufs = {}
 
+    def caption_table(self, token_id_lists, train_ids):
+        """The per-caption constants of the loss for a whole set of captions (the job's dataset + the caption-dropout caption), on
+        the device: the step then picks its batch's rows with one device-side gather (`set_from_table`) instead of rebuilding them on
+        the host and copying them up every step."""
+        n = len(token_id_lists)
+        tabs = self._caption_rows(token_id_lists, train_ids, n)
+        return tuple(t.to(self.rt.device) for t in tabs)
+
+    def set_from_table(self, table, sel):
+        """sel: int64 [B] (device) rows of `table`."""
+        tok_w, cnt, onehot, has = table
+        self.tok_w.copy_(tok_w[sel])
+        self.tok_cnt.copy_(cnt[sel])
+        self.ti_onehot.copy_(onehot[sel])
+        self.has_ti.copy_(has[sel])
+
     def set_captions(self, token_id_lists, train_ids):
         """token_id_lists[b] = tokenizer.encode(caption_b) (BOS ... EOS, unpadded) as the reference calls it
         (loss.py:32); train_ids = the textual-inversion token ids."""
-        B = self.rt.B
+        tok_w, cnt, onehot, has = self._caption_rows(token_id_lists, train_ids, self.rt.B)
+        self.tok_w.copy_(tok_w)
+        self.tok_cnt.copy_(cnt)
+        self.ti_onehot.copy_(onehot)
+        self.has_ti.copy_(has)
+
+    def _caption_rows(self, token_id_lists, train_ids, B):
         tok_w = torch.zeros(B, T_TOKENS)
         cnt = torch.ones(B)
         onehot = torch.zeros(B, self.n_tok, T_TOKENS)
@@ -54,10 +76,7 @@ class TokenAttentionLoss:
             has[b] = 1.0
             for j, p in enumerate(pos):
                 onehot[b, j, p] = 1.0
-        self.tok_w.copy_(tok_w)
-        self.tok_cnt.copy_(cnt)
-        self.ti_onehot.copy_(onehot)
-        self.has_ti.copy_(has)
+        return tok_w, cnt, onehot, has
 
     def _bicubic_ops(self, h, w, h_out, w_out, device):
         key = (h, w, h_out, w_out)

@@ -43,11 +43,11 @@ class TextStack:
     def set_ids(self, ids_per_encoder):
         for dst, src in zip(self.ids, ids_per_encoder):
             dst.copy_(src)
-        last = ids_per_encoder[-1].cpu()
+        last = self.ids[-1]              # on the device: no host round trip in the step loop
         # transformers CLIPTextModel pooling: legacy configs (eos_token_id == 2, SDXL's text_encoder_2) take argmax(input_ids),
         # newer ones the first position equal to eos_token_id
         pos = last.argmax(-1) if self.pool_mode == "argmax" else (last == self.eos).int().argmax(-1)
-        self.pool_rows.copy_(torch.arange(last.shape[0]) * TP + pos)
+        self.pool_rows.copy_(torch.arange(last.shape[0], device=last.device) * TP + pos)
 
     def _fan_out(self, jobs):
         """Run one job per encoder, each on its own side stream, joined before returning.  The encoders are
@@ -226,7 +226,7 @@ class TrainStep:
             self._acc = [(g_, torch.zeros_like(g_)) for g_ in gs]
 
     # -------------------------------------------------------------------------------- inputs
-    def set_batch(self, latent, noise, timesteps, mask, ctx=None, pooled=None, time_ids=None, ids=None, caption_token_lists=None):
+    def set_batch(self, latent, noise, timesteps, mask, ctx=None, pooled=None, time_ids=None, ids=None, caption_token_lists=None, caption_table=None):
         """latent/noise/mask [B,4,h,w] fp32, timesteps int64 [B]; SDXL: time_ids [B,6].
         Without text encoders: ctx [B,77,D] (+ pooled [B,P]) are the injected conditioning.
         With text encoders (textual inversion): ids = [input_ids [B,77] per tokenizer] and caption_token_lists[b] =
@@ -250,9 +250,13 @@ class TrainStep:
                     self.pooled.copy_(pooled)
             else:
                 self.text.set_ids(ids)
-            train_ids = self.text.encoders[0].train_ids.tolist()
-            self.ta.set_captions(caption_token_lists, train_ids)
-        if self.time_ids is not None:
+            if caption_table is not None:          # (table, rows): per-caption constants already on the device (train(): no host work per step)
+                self.ta.set_from_table(*caption_table)
+            else:
+                if getattr(self, "_train_ids_host", None) is None:
+                    self._train_ids_host = self.text.encoders[0].train_ids.tolist()
+                self.ta.set_captions(caption_token_lists, self._train_ids_host)
+        if self.time_ids is not None and time_ids is not None:
             self.time_ids.copy_(time_ids.reshape(-1).to(torch.float32))
 
     def set_hyper(self, lr, lr_ti=0.0, lr_te=0.0):

@@ -442,6 +442,28 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
             dist.barrier()
         return out_dir, vp
 
+    # ---- the job's data lives on the device: per step only device-side gathers, no host -> device copies and no host syncs, so the
+    # host prepares step i+1 while the GPU runs step i (round 1 copied pageable tensors every step: the loop ran 15 % below the replay rate)
+    dev = rt.device
+    data = cache["posterior"] if "posterior" in cache else cache["latents"]
+    data_d, masks_d = data.to(dev), cache["masks"].to(dev)
+    has_tok = cache.get("tok_ids") is not None
+    N_TOK_ROW = n_img                                                    # row n_img of the per-caption tables = the caption-dropout caption
+    ids_tab = lists_all = cap_table = None
+    if ti_on:
+        ids_tab = [torch.cat([t, (tok.view(1, 77) if has_tok else t[:1])]).to(dev) for t, tok in zip(cache["input_ids"], cache["tok_ids"] if has_tok else cache["input_ids"])]
+        lists_all = list(cache["token_lists"]) + [list(cache["tok_list"]) if has_tok else list(cache["token_lists"][0])]
+        cap_table = ts.ta.caption_table(lists_all, models.encoders[0].train_ids.tolist())
+    if time_ids is not None:
+        time_ids = time_ids.to(dev)
+
+    def cond_rows(cnd, cnd_tok):
+        """[n_img + 1] conditioning rows (dataset captions + the dropout caption) on the device."""
+        ctx_t = torch.cat([cnd[0], cnd_tok[0][:1] if cnd_tok is not None else cnd[0][:1]]).to(dev)
+        pool_t = torch.cat([cnd[1], cnd_tok[1][:1] if cnd_tok is not None else cnd[1][:1]]).to(dev) if cnd[1] is not None else None
+        return ctx_t, pool_t
+    cond_d = cond_rows(cond, cond_tok) if cond is not None else None
+
     losses = {"img_loss": [], "tot_loss": []}
     global_step, last_save_step, images_done = 0, 0, 0
     start, pause = time.time(), 0.0
@@ -454,6 +476,12 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
         if ddp:
             order = order[rank::world] if len(order) >= world else order
         spe = math.ceil(len(order) / B) if ddp else steps_per_epoch
+        # the epoch's batches: the DataLoader's short last batch wraps around to the start of the epoch's order (fixed-shape step)
+        padded = np.resize(order, spe * B) if len(order) < spe * B else order[: spe * B]
+        order_d = torch.as_tensor(padded).to(dev).view(spe, B)
+        # caption dropout (main.py:300-304): np.random.rand() per sample in loop order - drawn for the whole epoch at once (same stream)
+        drop = (np.random.rand(spe, B) < config.caption_dropout) if (config.caption_dropout > 0.0 and has_tok) else np.zeros((spe, B), dtype=bool)
+        sel_d = torch.where(torch.as_tensor(drop).to(dev), torch.full((spe, B), N_TOK_ROW, device=dev, dtype=order_d.dtype), order_d)
         for step_in_epoch in range(spe):
             completion_f = schedule.completion_fraction(epoch, step_in_epoch, spe, config.num_train_epochs)
             lrs = schedule.learning_rates(config, global_step, completion_f, ti_active=ti_on, text_lora_active=ts.te_arena is not None)
@@ -462,55 +490,31 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
             optimizers.optimizers["unet"].param_groups[0]["lr"] = lrs["unet"]
             if ti_on:
                 optimizers.optimizers["textual_inversion"].param_groups[0]["lr"] = lrs["textual_inversion"]
-            sel = order[step_in_epoch * B:(step_in_epoch + 1) * B]
-            if len(sel) < B:           # the DataLoader's short last batch: the fixed-shape step wraps around to the start of the epoch's order
-                sel = np.concatenate([sel, order[:B - len(sel)]]) if len(order) >= B else np.resize(order, B)
-            idx = torch.as_tensor(sel)
-            mask = cache["masks"][idx].to(rt.device)
+            idx, sel = order_d[step_in_epoch], sel_d[step_in_epoch]
+            mask = masks_d[idx]
             if "posterior" in cache:       # dataset.py:184-187: latent_dist.sample() * scaling_factor on EVERY fetch
-                latent = DiagonalGaussian(cache["posterior"][idx].to(rt.device)).sample(gd) * cfg["scaling_factor"]
+                latent = DiagonalGaussian(data_d[idx]).sample(gd) * cfg["scaling_factor"]
             else:
-                latent = cache["latents"][idx].to(rt.device)
-            noise = torch.randn(latent.shape, generator=gd, device=rt.device)
+                latent = data_d[idx]
+            noise = torch.randn(latent.shape, generator=gd, device=dev)
             if config.noise_offset > 0.0:                                                # main.py:313-317
-                noise += config.noise_offset * torch.randn((B, 4, 1, 1), generator=gd, device=rt.device)
-            timesteps = torch.randint(0, 1000, (B,), generator=gd, device=rt.device)
-            drop = [config.caption_dropout > 0.0 and cache.get("tok_ids") is not None and np.random.rand() < config.caption_dropout for _ in range(B)]   # main.py:300-304
+                noise += config.noise_offset * torch.randn((B, 4, 1, 1), generator=gd, device=dev)
+            timesteps = torch.randint(0, 1000, (B,), generator=gd, device=dev)
             if ti_on:
-                ids = [t[idx].clone() for t in cache["input_ids"]]
-                lists = [cache["token_lists"][int(i)] for i in idx]
-                for b in range(B):
-                    if drop[b]:
-                        lists[b] = list(cache["tok_list"])
-                        for t, tok in zip(ids, cache["tok_ids"]):
-                            t[b] = tok
                 kw = {}
-                if lrs["textual_inversion"] == 0.0 and ts.te_arena is None and ts.prodigy_ti is None and (captured or rt.device.type != "cuda") and ts._acc is None \
+                if lrs["textual_inversion"] == 0.0 and ts.te_arena is None and ts.prodigy_ti is None and (captured or dev.type != "cuda") and ts._acc is None \
                         and completion_f > config.freeze_ti_after_completion_f:
                     # f4: the token rows are frozen for the rest of the run (main.py:273-274) -> every caption's conditioning is a
                     # constant; encode each caption (and the dropout caption) once with the final rows, then skip the text encoders
-                    if cond is None:
+                    if cond_d is None:
                         with torch.no_grad():
                             cond = encode_rows(cache["input_ids"])
-                            cond_tok = encode_rows([t.view(1, 77) for t in cache["tok_ids"]]) if cache.get("tok_ids") is not None else None
-                    ctx = cond[0][idx.to(cond[0].device)].clone()
-                    pooled = cond[1][idx.to(cond[0].device)].clone() if cond[1] is not None else None
-                    for b in range(B):
-                        if drop[b]:
-                            ctx[b] = cond_tok[0][0]
-                            if pooled is not None:
-                                pooled[b] = cond_tok[1][0]
-                    kw = dict(ctx=ctx, pooled=pooled)
-                ts.set_batch(latent, noise, timesteps, mask, time_ids=time_ids, ids=ids, caption_token_lists=lists, **kw)
+                            cond_tok = encode_rows([t.view(1, 77) for t in cache["tok_ids"]]) if has_tok else None
+                        cond_d = cond_rows(cond, cond_tok)
+                    kw = dict(ctx=cond_d[0][sel], pooled=cond_d[1][sel] if cond_d[1] is not None else None)
+                ts.set_batch(latent, noise, timesteps, mask, time_ids=time_ids, ids=[t[sel] for t in ids_tab], caption_table=(cap_table, sel), **kw)
             else:
-                ctx = cond[0][idx.to(cond[0].device)].clone()
-                pooled = cond[1][idx.to(cond[0].device)].clone() if cond[1] is not None else None
-                for b in range(B):
-                    if drop[b]:
-                        ctx[b] = cond_tok[0][0]
-                        if pooled is not None:
-                            pooled[b] = cond_tok[1][0]
-                ts.set_batch(latent, noise, timesteps, mask, ctx, pooled, time_ids)
+                ts.set_batch(latent, noise, timesteps, mask, cond_d[0][sel], cond_d[1][sel] if cond_d[1] is not None else None, time_ids)
             if not captured and rt.device.type == "cuda":
                 t0 = time.time()
                 ts.capture(warmup=1)

@@ -65,9 +65,9 @@ def test_train_from_folder_with_tokenizer(tmp_path, monkeypatch, version, disabl
     import sd_lora_trainer_amd.step as S
     real_set = S.TrainStep.set_batch
 
-    def spy(self, latent, noise, timesteps, mask, ctx=None, pooled=None, time_ids=None, ids=None, caption_token_lists=None):
-        seen.setdefault("calls", []).append(dict(ctx=None if ctx is None else ctx.clone(), ids=ids, lists=caption_token_lists, mask=mask.clone(), latent=latent.clone()))
-        return real_set(self, latent, noise, timesteps, mask, ctx, pooled, time_ids, ids, caption_token_lists)
+    def spy(self, latent, noise, timesteps, mask, ctx=None, pooled=None, time_ids=None, ids=None, caption_token_lists=None, **kw):
+        seen.setdefault("calls", []).append(dict(ctx=None if ctx is None else ctx.clone(), ids=ids, table=kw.get("caption_table"), mask=mask.clone(), latent=latent.clone()))
+        return real_set(self, latent, noise, timesteps, mask, ctx, pooled, time_ids, ids, caption_token_lists, **kw)
     monkeypatch.setattr(S.TrainStep, "set_batch", spy)
     rt = unet_mod.Runtime("cpu", 2, act_dtype=torch.float32, ops=emu_ops)
     progress, (config, out_dir) = _run(T.train(cfg, runtime=rt))
@@ -94,11 +94,14 @@ def test_train_from_folder_with_tokenizer(tmp_path, monkeypatch, version, disabl
     else:
         ids = torch.cat([c["ids"][0] for c in calls])
         assert ids.shape[1] == 77 and all(len(c["ids"]) == 2 for c in calls)
-        with_tok = [(row[:12].tolist(), l) for c in calls for row, l in zip(c["ids"][0], c["lists"])]
-        assert any(all(t in l for t in tok_ids) for _, l in with_tok)                # "tok" -> <s0><s1><s2> substitution reached the tokenizer
-        assert any(not any(t in l for t in tok_ids) for _, l in with_tok)            # the caption without the trigger word
-        drop = [l for _, l in with_tok if len(l) == 5 and l[1:4] == tok_ids]         # caption dropout -> the bare trigger string
-        assert 0 < len(drop) < len(with_tok)
+        rows = [row.tolist() for c in calls for row in c["ids"][0]]
+        assert any(all(t in r for t in tok_ids) for r in rows)                       # "tok" -> <s0><s1><s2> substitution reached the tokenizer
+        assert any(not any(t in r for t in tok_ids) for r in rows)                   # the caption without the trigger word
+        drop = [r for r in rows if r[1:4] == tok_ids and r[4] == r[-1]]              # caption dropout -> the bare trigger string (bos, 3 tokens, eos...)
+        assert 0 < len(drop) < len(rows)
+        # the token-attention loss's per-caption constants come from a device table, row n_img = the dropout caption
+        tabs = [c["table"] for c in calls]
+        assert all(t is not None and t[0][3].shape[0] == 6 for t in tabs) and any(int(x) == 5 for t in tabs for x in t[1])
         from safetensors.torch import load_file
         emb = load_file(os.path.join(out_dir, f"my_run_{version}_embeddings.safetensors"))
         e0 = load_file(os.path.join(ck, "checkpoint-0", f"my_run_{version}_embeddings.safetensors"))
