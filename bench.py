@@ -191,7 +191,7 @@ def train_loop_measure(args):
     B = args.batch or (1 if "xl" in version else 4)
     tmp = tempfile.mkdtemp(prefix="sdlt_bench_")
     try:
-        n_loop = max(args.steps, 20) + 5
+        n_loop = max(5 * args.steps, 100)            # long enough that the loop's own logging (a host sync every n/20 steps) is as rare as in a real run
         cfg_t = TrainingConfig(lora_training_urls="synthetic:8", concept_mode="object", pretrained_model={"path": f"synthetic:{version}"}, seed=0,
                                resolution=res, train_batch_size=B, max_train_steps=n_loop, lora_rank=args.rank, output_dir=tmp, n_sample_imgs=0,
                                unet_lr=1e-3, ti_lr=1e-3)

@@ -113,8 +113,10 @@ def test_ti_step_gpu_matches_oracle(version, B, concurrent):
     # conditioning handed over (no text-encoder forward in the replayed graph) gives the same loss and the same update
     if not concurrent:
         a = unet.arena
+        with torch.no_grad():           # what train() does once when the rows freeze: encode the captions with the final rows
+            pooled_c = ts.text.forward(ts.ctx)
+            pooled_c = pooled_c.clone() if pooled_c is not None else None
         ctx_c = ts.ctx.view(B, unet_mod.CTX_PAD, -1)[:, :77].clone()
-        pooled_c = ts._pooled_live.clone() if xl else None
         snap, step0 = [t_.clone() for t_ in (a.params, a.m, a.v)], ts.opt_step
         ts.run(1e-3, lr_ti=0.0)
         torch.cuda.synchronize()
