@@ -79,7 +79,8 @@ class WeightTrainer:
         classes = {}
         for e in self.entries:
             if e["kind"] != "vector":
-                classes.setdefault((e["kind"], e["shape"]), []).append(e)
+                # (a Linear and a 1x1 conv of one shape are the same kind of weight-gradient job and may share a flush group)
+                classes.setdefault(("conv3x3" if e["kind"] == "conv3x3" else "mat", e["shape"]), []).append(e)
         self.n, start = 0, 0
         for members in classes.values():
             for e in members:
