@@ -118,9 +118,10 @@ class ClipTextEncoder(_Module):
         self.proj = Linear(rt, "text_projection", sd) if with_projection else None
         self.train_ids = torch.arange(self.V - n_train, self.V, dtype=torch.int64, device=rt.device)
 
-    def forward(self, ids, B, hidden_out=None, pool_rows=None):
+    def forward(self, ids, B, hidden_out=None, pool_rows=None, hidden_only=False):
         """ids int64 [B,77] (device).  hidden_out: optional [B*TP, D] (strided) destination of the hidden states.
-        pool_rows int64 [B]: row index b*TP + pool position (HF: argmax / first EOS) for the pooled output."""
+        pool_rows int64 [B]: row index b*TP + pool position (HF: argmax / first EOS) for the pooled output.
+        hidden_only: the caller needs no pooled output - nothing above the hidden state is run."""
         rt = self.rt
         x = rt.ops.embed_gather(self.table, ids, self.pos, self.buf("x0", B * TP, self.D), B=B, T=T_TOKENS, Tp=TP)
         self._ids, self._B = ids, B
@@ -130,12 +131,14 @@ class ClipTextEncoder(_Module):
             x = layer.forward(x, B, out=hidden_out if is_hidden else None)
             if is_hidden:
                 hidden = x
+                if hidden_only:
+                    return hidden, None
         pooled = None
         if self.final_ln is not None:
             fin = self.final_ln.forward(x, out=hidden_out if self.mode == "last" else None)
             if self.mode == "last":
                 hidden = fin
-            if self.with_projection:
+            if self.with_projection and not hidden_only:
                 self._pool_rows = pool_rows
                 pin = self.buf("pool_in", B, self.D)
                 pin.copy_(fin[pool_rows])

@@ -147,7 +147,7 @@ class TrainStep:
                  weight_decay=0.004, grad_accum=1, betas=(0.9, 0.999), eps=1e-8, text: TextStack = None, n_tokens=3,
                  token_attention_loss_w=3e-7, ti_weight_decay=0.0, ti_std_loss_w=0.01, optimizer="adamw", ti_optimizer="adamw",
                  prodigy_d_coef=1.0, prodigy_growth_rate=1.05, text_lora_weight_decay=1e-5, process_group=None,
-                 cond_reg_w=0.0, tok_cov_reg_w=0.0, cond_target_norm=None):
+                 cond_reg_w=0.0, tok_cov_reg_w=0.0, cond_target_norm=None, tok_cond_reg_w=0.0, reg_caption_ids=None):
         """process_group: data-parallel full fine-tune only (`unet.trainer` set) - a torch.distributed group (or True for the
         default one) over which the gradient arena is all-reduced once per optimiser step (RCCL on the GPU)."""
         if optimizer == "AdamW8bit":
@@ -217,6 +217,22 @@ class TrainStep:
         self.cond_reg_w, self.tok_cov_reg_w = cond_reg_w, tok_cov_reg_w
         self.cond_target_norm = cond_target_norm if cond_target_norm is not None else (34.5 if unet.cfg["addition"] else 27.8)   # loss.py:182
         self.cond_reg_loss, self.cond_norm = z(1), z(1)
+        # tok_cond_reg_w (loss.py:207-211, 241-251): the same norm target on the conditioning of FOUR fixed captions around the
+        # trigger ("a photo of TOK", "TOK", ...), encoded with autograd every step -> a second pass of the text encoders at batch
+        # 4 (plan clones sharing the weights and the token tables), its row gradients added to the step's
+        self.tok_cond_reg_w = tok_cond_reg_w if text is not None else 0.0
+        self.tok_reg_loss, self.tok_reg_norm = z(1), z(1)
+        if self.tok_cond_reg_w > 0.0:
+            from .unet import clone_plan
+            assert reg_caption_ids is not None, "tok_cond_reg_w > 0 needs the token ids of the regularisation captions"
+            if text.arena is not None:
+                raise NotImplementedError("tok_cond_reg_w together with text-encoder LoRA")
+            nreg = reg_caption_ids[0].shape[0]
+            self.reg_rt = Runtime(dev, nreg, act_dtype=rt.act, ops=rt.ops)
+            self.reg_encoders = [clone_plan(e, self.reg_rt) for e in text.encoders]
+            self.reg_ids = [i.to(dev, torch.int64).contiguous() for i in reg_caption_ids]
+            self.reg_ctx = rt.zeros(nreg * CTX_PAD, cfg["cross_dim"])
+            self.reg_dctx = rt.zeros(nreg * CTX_PAD, cfg["cross_dim"])
         # gradient accumulation (main.py:362-366): every micro-step back-propagates loss / k; the optimizers step on the k-th
         # (or on the last batch of an epoch).  The kernels overwrite their gradient buffers, so micro-steps add them into
         # accumulators that are handed back at the boundary.
@@ -345,10 +361,32 @@ class TrainStep:
                 dv = self.dctx.view(self.B, CTX_PAD, -1)
                 dv[:, 2:T_TOKENS] += (coef * pe / nrm).to(dv.dtype)
             self.text.backward(self.dctx, d_pooled, self.ti.grad_rows)
+            if self.tok_cond_reg_w > 0.0:
+                self._tok_cond_reg()
             if self.tok_cov_reg_w > 0.0:
                 self.ti.add_covariance(self.tok_cov_reg_w / self.grad_accum)
             # a14 (only the std term is live by default, config.py:75-77); part of the loss, hence / k under accumulation
             self.ti.add_regulariser(std_loss_w=self.ti.std_loss_w / self.grad_accum)
+
+    def _tok_cond_reg(self):
+        """loss += tok_cond_reg_w * (mean_{t >= 2} mean_c |E(caption_c)[t]| - target)^2 over the regularisation captions
+        (ConditioningRegularizer._compute_tok_regularization_loss, loss.py:241-251); back through the encoders into the rows."""
+        nreg, off = self.reg_rt.B, 0
+        for e, ids, w in zip(self.reg_encoders, self.reg_ids, self.text.widths):
+            e.forward(ids, nreg, hidden_out=self.reg_ctx[:, off:off + w], hidden_only=True)
+            off += w
+        pe = self.reg_ctx.view(nreg, CTX_PAD, -1)[:, 2:T_TOKENS].float()
+        nrm = pe.norm(dim=-1, keepdim=True)
+        val = nrm.mean()
+        self.tok_reg_norm.copy_(val.reshape(1))
+        self.tok_reg_loss.copy_((self.tok_cond_reg_w * (val - self.cond_target_norm) ** 2).reshape(1))
+        coef = self.tok_cond_reg_w / self.grad_accum * 2.0 * (val - self.cond_target_norm) / (nreg * (T_TOKENS - 2))
+        self.reg_dctx.zero_()
+        self.reg_dctx.view(nreg, CTX_PAD, -1)[:, 2:T_TOKENS] = (coef * pe / nrm).to(self.reg_dctx.dtype)
+        off = 0
+        for e, w, g in zip(self.reg_encoders, self.text.widths, self.ti.grad_rows):
+            e.backward(self.reg_dctx[:, off:off + w], None, g, accumulate=True)
+            off += w
 
     def forward_backward(self):
         self._phase_text_fwd()
@@ -622,8 +660,17 @@ class TrainStep:
             self.body()
 
     def total_loss(self):
-        """img loss + L1 penalty as the reference logs it (main.py:339-361); forces a device sync."""
+        """img loss + token-attention loss + L1 penalty + the token regularisers as the reference logs it (main.py:339-361);
+        forces a device sync."""
         tot = float(self.loss) + self.l1_penalty * float(self.l1_sum) / self.group.n
         if self.text is not None:
-            tot += self.ta_w * float(self.ta.loss) + (0.0 if getattr(self, "_frozen_last", False) else float(self.ti.reg_loss))
+            tot += self.ta_w * float(self.ta.loss)
+            if not getattr(self, "_frozen_last", False):       # main.py:358: the regularisers only while the TI learning rate is > 0
+                tot += float(self.ti.reg_loss)
+                if self.cond_reg_w > 0.0:
+                    tot += float(self.cond_reg_loss)
+                if self.tok_cond_reg_w > 0.0:
+                    tot += float(self.tok_reg_loss)
+                if self.tok_cov_reg_w > 0.0:
+                    tot += float(self.ti.cov_loss)
         return tot

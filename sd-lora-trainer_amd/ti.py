@@ -32,7 +32,7 @@ class TiState:
         self.set_reference_stats(whole_table=False)
         self._plan = rt.ops.ShadowPlan(sh, rt.device)
         self.std_loss_w = std_loss_w
-        self.reg_loss = rt.zeros(1, dtype=F32)
+        self.reg_loss, self.cov_loss = rt.zeros(1, dtype=F32), rt.zeros(1, dtype=F32)
         self.hyper = rt.zeros(16, dtype=F32)
 
     def set_reference_stats(self, whole_table):
@@ -75,7 +75,7 @@ class TiState:
                 t = e.table[:nv].float()
                 adj = t - t.mean(0)
                 self._target_cov.append(adj.T @ adj / (nv - 1))
-        self.cov_loss = torch.zeros(1, dtype=F32, device=self.rt.device)
+        self.cov_loss.zero_()
         w = weight / len(self.encoders)
         for r, g, T in zip(self.rows, self.grad_rows, self._target_cov):
             n, D = r.shape

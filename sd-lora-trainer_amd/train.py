@@ -193,6 +193,26 @@ def _tokenize(tokenizers, texts):
     return ids, [tokenizers[0].encode(s) for s in texts]
 
 
+REG_CAPTIONS = ["a photo of TOK", "TOK", "a photo of TOK next to TOK", "TOK and TOK"]      # ConditioningRegularizer.reg_captions (loss.py:183)
+
+
+def reg_caption_ids(config, models, cache):
+    """Token ids [4, 77] per tokenizer of the tok_cond_reg_w captions with TOK replaced by the trigger string (loss.py:184, 242).
+    Without tokenizer files (synthetic jobs) the filler words are fixed ids of the synthetic vocabulary."""
+    if models.tokenizers is not None:
+        rep = config.token_dict.get("TOK", "TOK")
+        return _tokenize(models.tokenizers, [c.replace("TOK", rep) for c in REG_CAPTIONS])[0]
+    tl = cache["tok_list"]
+    bos, tok, eos = tl[0], tl[1:-1], tl[-1]
+    word = lambda i: 1 + (i * 37) % (min(bos, eos) - 1)  # noqa: E731
+    caps = [[word(1), word(2), word(3)] + tok, tok, [word(1), word(2), word(3)] + tok + [word(4), word(5)] + tok, tok + [word(6)] + tok]
+    ids = torch.full((len(caps), 77), eos, dtype=torch.int64)
+    for r, c in enumerate(caps):
+        ids[r, 0] = bos
+        ids[r, 1:1 + len(c)] = torch.tensor(c)
+    return [ids] * len(models.encoders)
+
+
 def load_data(config, models, rt, h, w):
     """The job's latent / mask / caption cache -> dict(posterior | latents, masks, input_ids (list per tokenizer), token_lists,
     tok_ids (list per tokenizer), tok_list, description_ids?, captions?)."""
@@ -332,7 +352,7 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
     optimizer call, so that several jobs can be advanced in lock-step by train_concurrent."""
     from . import step as S
     from . import unet as M
-    for flag, what in ((config.use_dora, "use_dora (DoRA adapters)"), (config.tok_cond_reg_w > 0.0, "tok_cond_reg_w > 0 (prompt-norm regulariser on extra captions)"),
+    for flag, what in ((config.use_dora, "use_dora (DoRA adapters)"),
                        (config.aspect_ratio_bucketing, "aspect_ratio_bucketing (broken in the reference as well, README.md:76)")):
         if flag:
             raise NotImplementedError(f"{what} is not built in this engine; refusing to train something else silently")
@@ -367,7 +387,8 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
                      optimizer=config.unet_optimizer_type, ti_optimizer=config.ti_optimizer,
                      prodigy_d_coef=config.prodigy_d_coef, prodigy_growth_rate=config.unet_prodigy_growth_factor,
                      text_lora_weight_decay=config.text_encoder_lora_weight_decay,
-                     cond_reg_w=config.cond_reg_w, tok_cov_reg_w=config.tok_cov_reg_w)
+                     cond_reg_w=config.cond_reg_w, tok_cov_reg_w=config.tok_cov_reg_w, tok_cond_reg_w=config.tok_cond_reg_w,
+                     reg_caption_ids=reg_caption_ids(config, models, cache) if (ti_on and config.tok_cond_reg_w > 0.0) else None)
     # main.py:92-101: the new token rows are initialised whether or not they are trained (with disable_ti they stay as drawn)
     from .ti import TiState
     ti_state = ts.ti if ti_on else TiState(rt, models.encoders, config.n_tokens)

@@ -18,6 +18,7 @@ MI355X-first choices:
 
 Weight names follow the diffusers state dict so real checkpoints and the kohya exporter line up.
 """
+import copy
 import math
 
 import torch
@@ -91,6 +92,23 @@ class _Module:
             t = (self.rt.zeros if zero else self.rt.empty)(*shape, dtype=dtype)
             self._b[key] = t
         return t
+
+
+def clone_plan(mod, rt, _memo=None):
+    """Structural copy of an execution plan for ANOTHER batch size: the clone shares every weight tensor with `mod` but owns
+    its activation buffers and runs on `rt` (used for the text encoders' second, 4-caption pass of the tok_cond_reg_w term)."""
+    memo = {} if _memo is None else _memo
+    if id(mod) in memo:
+        return memo[id(mod)]
+    c = copy.copy(mod)
+    memo[id(mod)] = c
+    c.rt, c._b = rt, {}
+    for k, v in list(vars(c).items()):
+        if isinstance(v, _Module):
+            setattr(c, k, clone_plan(v, rt, memo))
+        elif isinstance(v, (list, tuple)) and v and all(isinstance(x, _Module) for x in v):
+            setattr(c, k, type(v)(clone_plan(x, rt, memo) for x in v))
+    return c
 
 
 # ---------------------------------------------------------------------------------------- LoRA arena

@@ -58,6 +58,7 @@ def test_train_from_folder_with_tokenizer(tmp_path, monkeypatch, version, disabl
     data, (tok_dir, vocab_size) = _dataset(tmp_path), _tokenizer_dir(tmp_path)
     cfg = TrainingConfig(lora_training_urls=data, concept_mode="object", name="my run", seed=2, resolution=64, train_batch_size=2, max_train_steps=60,
                          checkpointing_steps=20, lora_rank=4, disable_ti=disable_ti, unet_lr=1e-3, ti_lr=1e-3, caption_dropout=0.3,
+                         tok_cond_reg_w=0.0 if disable_ti else 1e-3,        # (reg captions through the tokenizer files, loss.py:241-251)
                          pretrained_model={"path": f"synthetic:{version}", "tokenizer_path": tok_dir})
     seen = {}
     real_set = None
@@ -108,7 +109,7 @@ def test_train_from_folder_with_tokenizer(tmp_path, monkeypatch, version, disabl
         assert set(emb) == {"clip_l", "clip_g"} and not torch.equal(emb["clip_l"], e0["clip_l"])     # the token rows were trained
 
 
-@pytest.mark.parametrize("kw", [dict(use_dora=True), dict(tok_cond_reg_w=0.1), dict(aspect_ratio_bucketing=True)])
+@pytest.mark.parametrize("kw", [dict(use_dora=True), dict(aspect_ratio_bucketing=True), dict(tok_cond_reg_w=0.1, text_encoder_lora_optimizer="adamw")])
 def test_unbuilt_fields_raise(tmp_path, monkeypatch, kw):
     monkeypatch.chdir(tmp_path)
     from sd_lora_trainer_amd import train as T

@@ -93,7 +93,7 @@ def test_train_generator_end_to_end(tmp_path, monkeypatch, version, disable_ti):
     from sd_lora_trainer_amd.train import train
     cfg = TrainingConfig(lora_training_urls="synthetic:4", concept_mode="object", pretrained_model={"path": f"synthetic:{version}"}, seed=1,
                          resolution=256 if version == "tinyxl" else 128, train_batch_size=2, max_train_steps=3, lora_rank=4, disable_ti=disable_ti,
-                         unet_lr=1e-3, ti_lr=1e-3, caption_dropout=0.5)
+                         unet_lr=1e-3, ti_lr=1e-3, caption_dropout=0.5, tok_cond_reg_w=0.0 if disable_ti else 1e-3)
     rt = unet_mod.Runtime("cpu", 2, act_dtype=torch.float32, ops=emu_ops)
     gen = train(cfg, runtime=rt)
     progress = []

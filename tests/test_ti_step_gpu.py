@@ -290,3 +290,14 @@ def test_token_warmup_gpu_matches_oracle():
     for r, r0, e in zip(ts.ti.rows, rows0, embs):
         cos, rel = _cos_rel(r - r0, e.detach()[-NTOK:] - r0.cpu())
         assert cos >= 0.9, f"row update direction cos {cos}"        # Adam's first steps are ~lr*sign(g): sign flips of tiny g
+
+
+@pytest.mark.parametrize("version", ["tiny15", "tinyxl"])
+def test_optional_regularisers_gpu_match_oracle(version):
+    """cond_reg_w, tok_cond_reg_w (second, 4-caption pass of the text encoders) and tok_cov_reg_w on the HIP path (bf16 activations)
+    against the fp32 autograd oracle: loss values and the token-row gradients."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from sd_lora_trainer_amd import ops
+    from tests.test_ti_step_cpu import run_optional_regularisers
+    run_optional_regularisers(version, "cuda:0", ops, torch.bfloat16, rel_val=4e-3, rel_grad=4e-2)
