@@ -20,7 +20,7 @@ extern "C" {
 
 const char* sdlt_last_error(void);
 int sdlt_abi_version(void);
-int sdlt_struct_size(int which); /* 0 gemm, 1 lora_grad_desc, 2 attn, 3 groupnorm, 4 shadow_desc */
+int sdlt_struct_size(int which); /* 0 gemm, 1 lora_grad_desc, 2 attn, 3 groupnorm, 4 shadow_desc, 5 gemm_batch_item, 6 dora_desc, 7 dora_wt_desc, 8 dora_grad_desc */
 
 /* ------------------------------------------------------------------------------------------------
  * sdlt_gemm_bf16 : C = alpha*(X.W^T [+ X2.W2^T] [+ s*(X.Adown^T).Bup^T]) + bias + rowbias + R
@@ -47,6 +47,7 @@ typedef struct sdlt_gemm_batch_item {
   const void* Adown; const void* Bup; void* T_out;
   void* C; void* Ct;
   const float* bias;
+  const float* col_scale;
 } sdlt_gemm_batch_item;
 
 typedef struct sdlt_gemm_params {
@@ -107,6 +108,10 @@ typedef struct sdlt_gemm_params {
   int32_t epi_op; int32_t epi_act;
   void* epi_out; int64_t ld_epi_out;
   const void* epi_in; int64_t ld_epi_in;
+  /* DoRA (peft LoraConfig(use_dora=True), trainer/optimizer.py:86-95): fp32 [N] or NULL; the product INCLUDING the adapter term is
+     multiplied per output column before bias / row bias / residual:  C = alpha * col_scale[n] * (X W^T + s X A^T B^T) + bias ...
+     (col_scale = magnitude / || W + s B A ||_row, kept up to date by sdlt_dora_refresh).  LoRA launches (lora_R > 0) only. */
+  const float* col_scale;
 } sdlt_gemm_params;
 int sdlt_gemm_bf16(const sdlt_gemm_params* p, void* stream);
 
@@ -321,6 +326,54 @@ int sdlt_lora_shadow_refresh(const sdlt_shadow_desc* descs_dev, const int32_t* b
  * sdlt_adamw_fused). */
 int sdlt_adamw_shadow_refresh(const sdlt_shadow_desc* descs_dev, const int32_t* block_desc_dev, const int32_t* block_first_dev,
                               int32_t n_blocks, float* p, const float* g, float* m, float* v, const float* hyper, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ DoRA
+ * Weight-decomposed adapters: peft `LoraConfig(use_dora=True)` as the reference requests it (trainer/optimizer.py:86-95; L1 penalty
+ * and weight decay are switched off with it, config.py:153-157).  [3P-unverified: peft 0.10.0 LoraLayer._apply_dora / Conv2d]
+ *     y = (m / ||W + s B A||_row) * (x W^T + s x A^T B^T) + bias          m [N] trained, the norm detached
+ * The forward GEMM applies the factor through sdlt_gemm_params.col_scale; these three batched launches (device descriptor tables,
+ * block_desc[b] = descriptor of block b, block_first[d] = first block of descriptor d) keep everything else in step:
+ *   sdlt_dora_refresh   per adapted layer, ceil(N/64) blocks: scale[n] = mag[n] / ||W_n + s B_n A||  (init != 0: mag := the norm first,
+ *                       peft's dora_init) and Bt = (B32 * scale)^T as bf16 [Rp, N] (the LoRA-down operand of the dX GEMM), K % 32 == 0
+ *   sdlt_dora_scale_wt  per dX weight, ceil(rows/32)*ceil(cols/256) blocks: dst[r, c] = src[r, c] * scale[c % period]
+ *                       (columns with c % period >= nvalid become 0)
+ *   sdlt_dora_mag_grad  stage 1, per layer ceil(N/64)*splits blocks into ws (fp32 [splits, 2, N] at ws_off per layer); stage 2, per
+ *                       layer ceil(N/256) blocks: gmag[n] = sum_rows dY * (Y - bias) / mag  and  gB[n, :] *= scale[n]   (Y = the
+ *                       layer's output BEFORE any residual; dY, Y bf16 with N % 8 == 0 and 16-byte aligned rows) */
+typedef struct sdlt_dora_desc {
+  const void* W; int64_t ldw;        /* bf16 [N, K] forward operand (3x3 conv: tap-major [Cout, 9*Cin]) */
+  const void* A; int64_t lda;        /* bf16 [Rp, K] LoRA-down compute copy (rows >= rank zero) */
+  const void* B; int64_t ldb;        /* bf16 [N, Rp] LoRA-up compute copy (columns >= rank zero) */
+  float* mag;                        /* fp32 [N] trained magnitude */
+  float* scale;                      /* fp32 [N] out */
+  void* Bt; int64_t ldbt;            /* bf16 [Rp, N] out, or NULL */
+  const float* B32; int64_t ldb32;   /* fp32 master of B [N, rank] */
+  int32_t N, K, Rp, rank;
+  float s;                           /* lora_alpha / r */
+  int32_t pad_;
+} sdlt_dora_desc;
+typedef struct sdlt_dora_wt_desc {
+  const void* src; void* dst; int64_t ld;    /* bf16 [rows, cols], same leading dimension */
+  const float* scale;
+  int32_t rows, cols, period, nvalid;
+} sdlt_dora_wt_desc;
+typedef struct sdlt_dora_grad_desc {
+  const void* dY; int64_t lddy;
+  const void* Y; int64_t ldy;
+  const float* bias;                 /* fp32 [N] or NULL */
+  const float* mag; const float* scale;
+  float* gmag;                       /* fp32 [N] out */
+  float* gB;                         /* fp32 [N, rank], scaled in place */
+  int64_t ws_off;
+  int32_t M, N, rank, splits;
+  float grad_scale; int32_t pad_;
+} sdlt_dora_grad_desc;
+int sdlt_dora_refresh(const sdlt_dora_desc* descs_dev, const int32_t* block_desc_dev, const int32_t* block_first_dev, int32_t n_blocks,
+                      int32_t Rp, int32_t init, void* stream);
+int sdlt_dora_scale_wt(const sdlt_dora_wt_desc* descs_dev, const int32_t* block_desc_dev, const int32_t* block_first_dev, int32_t n_blocks,
+                       void* stream);
+int sdlt_dora_mag_grad(const sdlt_dora_grad_desc* descs_dev, const int32_t* block_desc_dev, const int32_t* block_first_dev, int32_t n_blocks,
+                       const int32_t* fin_block_desc_dev, const int32_t* fin_block_first_dev, int32_t n_fin_blocks, float* ws, void* stream);
 
 /* out[M,C] = a + b on strided 2-D bf16 views (gradient fan-in of the UNet skip connections). */
 int sdlt_add2d(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int32_t M, int32_t C, void* stream);

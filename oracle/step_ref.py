@@ -34,7 +34,8 @@ class RefTrainer:
         """cfg/sd: unet_ref config + fp32 state dict; lora: module -> (A, B) (peft layout); text_models: list of HF
         CLIPTextModel[WithProjection] whose token tables already hold the n_tokens new rows LAST (embedding_handler.py:157-223)."""
         self.cfg, self.sd = cfg, sd
-        self.lora = {k: (A.clone().requires_grad_(True), B.clone().requires_grad_(True)) for k, (A, B) in lora.items()}
+        # (A, B) per adapted module, or (A, B, magnitude) for DoRA (unet_ref._Ctx.linear / conv)
+        self.lora = {k: tuple(t.clone().requires_grad_(True) for t in v) for k, v in lora.items()}
         self.lora_params = [t for ab in self.lora.values() for t in ab]
         self.text = text_models
         self.n_tokens, self.train_ids = n_tokens, train_ids

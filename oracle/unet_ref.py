@@ -235,6 +235,26 @@ def init_lora(cfg, rank, seed=0, b_std=0.0, dtype=torch.float32):
     return lora
 
 
+def dora_weight_norm(w, A, B, s):
+    """peft `_get_weight_norm`: per-output-channel L2 norm of W + s * (B A) (conv: B A reshaped to the kernel's shape), detached."""
+    delta = (B.flatten(1) @ A.flatten(1)).reshape(w.shape)
+    return (w + s * delta).flatten(1).norm(dim=1).detach()
+
+
+def init_dora_magnitudes(cfg, sd, lora, lora_scale=1.0, jitter=0.0, seed=0):
+    """(A, B) -> (A, B, m) with m = the weight norm at injection time (peft dora_init); jitter > 0 perturbs m multiplicatively so
+    that tests exercise scale != 1."""
+    g = torch.Generator().manual_seed(seed)
+    out = OrderedDict()
+    for k, (A, B) in lora.items():
+        w = sd[k + ".weight"]
+        m = dora_weight_norm(w.float(), A.float(), B.float(), lora_scale)
+        if jitter:
+            m = m * (1.0 + jitter * torch.randn(m.shape, generator=g))
+        out[k] = (A, B, m.reshape(1, -1, 1, 1) if w.dim() == 4 else m)
+    return out
+
+
 # ----------------------------------------------------------------------------- forward
 
 def timestep_embedding(t, dim):
@@ -250,19 +270,34 @@ class _Ctx:
         self.sd, self.lora, self.s, self.cfg = sd, lora or {}, lora_scale, cfg
         self.daam = []  # (name, scores[B,N,77])
 
+    # DoRA entries are (A, B, magnitude) [3P-unverified: peft 0.10.0 tuners/lora/layer.py, LoraLayer._apply_dora and Conv2d._apply_dora]:
+    #   weight_norm = || W + s * B A ||_2 over every axis but the output one, DETACHED ("treated as a constant", DoRA sec. 4.3)
+    #   result = base(x) + (m / weight_norm - 1) * (x W^T) + (m / weight_norm) * s * B(A(x))          (the bias is not scaled)
+    # magnitude: [N] for Linear, [1, N, 1, 1] for Conv2d; dora_init sets it to the norm at injection time (B = 0: ||W||).
     def linear(self, name, x):
-        y = F.linear(x, self.sd[name + ".weight"], self.sd.get(name + ".bias"))
+        w, b = self.sd[name + ".weight"], self.sd.get(name + ".bias")
+        y = F.linear(x, w, b)
         if name in self.lora:
-            A, B = self.lora[name]
-            y = y + self.s * F.linear(F.linear(x, A), B)
+            A, B, *m = self.lora[name]
+            up = self.s * F.linear(F.linear(x, A), B)
+            if m:
+                scale = m[0].reshape(-1) / dora_weight_norm(w, A, B, self.s)
+                y = y + (scale - 1.0) * F.linear(x, w) + scale * up
+            else:
+                y = y + up
         return y
 
     def conv(self, name, x, stride=1):
         w = self.sd[name + ".weight"]
         y = F.conv2d(x, w, self.sd.get(name + ".bias"), stride=stride, padding=w.shape[-1] // 2)
         if name in self.lora:
-            A, B = self.lora[name]
-            y = y + self.s * F.conv2d(F.conv2d(x, A, None, stride=stride, padding=A.shape[-1] // 2), B)
+            A, B, *m = self.lora[name]
+            up = self.s * F.conv2d(F.conv2d(x, A, None, stride=stride, padding=A.shape[-1] // 2), B)
+            if m:
+                scale = (m[0].reshape(-1) / dora_weight_norm(w, A, B, self.s)).view(1, -1, 1, 1)
+                y = y + (scale - 1.0) * F.conv2d(x, w, None, stride=stride, padding=w.shape[-1] // 2) + scale * up
+            else:
+                y = y + up
         return y
 
     def gn(self, name, x, eps):

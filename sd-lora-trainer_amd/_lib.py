@@ -38,11 +38,26 @@ class GemmParams(C.Structure):
         ("lora_group_n", i32), ("lora_group_k", i32),
         ("batch", vp), ("n_batch", i32), ("throughput_hint", i32),
         ("epi_op", i32), ("epi_act", i32), ("epi_out", vp), ("ld_epi_out", i64), ("epi_in", vp), ("ld_epi_in", i64),
+        ("col_scale", vp),
     ]
 
 
 class GemmBatchItem(C.Structure):
-    _fields_ = [("X", vp), ("W", vp), ("Adown", vp), ("Bup", vp), ("T_out", vp), ("C", vp), ("Ct", vp), ("bias", vp)]
+    _fields_ = [("X", vp), ("W", vp), ("Adown", vp), ("Bup", vp), ("T_out", vp), ("C", vp), ("Ct", vp), ("bias", vp), ("col_scale", vp)]
+
+
+class DoraDesc(C.Structure):
+    _fields_ = [("W", vp), ("ldw", i64), ("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("mag", vp), ("scale", vp), ("Bt", vp), ("ldbt", i64),
+                ("B32", vp), ("ldb32", i64), ("N", i32), ("K", i32), ("Rp", i32), ("rank", i32), ("s", f32), ("pad_", i32)]
+
+
+class DoraWtDesc(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("ld", i64), ("scale", vp), ("rows", i32), ("cols", i32), ("period", i32), ("nvalid", i32)]
+
+
+class DoraGradDesc(C.Structure):
+    _fields_ = [("dY", vp), ("lddy", i64), ("Y", vp), ("ldy", i64), ("bias", vp), ("mag", vp), ("scale", vp), ("gmag", vp), ("gB", vp),
+                ("ws_off", i64), ("M", i32), ("N", i32), ("rank", i32), ("splits", i32), ("grad_scale", f32), ("pad_", i32)]
 
 
 class LoraGradDesc(C.Structure):
@@ -124,6 +139,9 @@ SYMBOLS = {
     "sdlt_groupnorm_affine_grad": (i32, [vp, vp, vp, i32, vp]),
     "sdlt_lora_shadow_refresh": (i32, [vp, vp, vp, i32, vp, vp]),
     "sdlt_adamw_shadow_refresh": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
+    "sdlt_dora_refresh": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "sdlt_dora_scale_wt": (i32, [vp, vp, vp, i32, vp]),
+    "sdlt_dora_mag_grad": (i32, [vp, vp, vp, i32, vp, vp, i32, vp, vp]),
     "sdlt_sum2x2": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "sdlt_colsum": (i32, [vp, i64, i32, i32, i32, vp, i64, vp, vp, vp]),
     "sdlt_embed_gather": (i32, [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp]),
@@ -155,7 +173,7 @@ def load():
             raise KernelLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    for which, cls in enumerate((GemmParams, LoraGradDesc, AttnParams, GroupNormParams, ShadowDesc)):
+    for which, cls in enumerate((GemmParams, LoraGradDesc, AttnParams, GroupNormParams, ShadowDesc, GemmBatchItem, DoraDesc, DoraWtDesc, DoraGradDesc)):
         if lib.sdlt_struct_size(which) != C.sizeof(cls):
             raise KernelLibraryError(f"struct layout mismatch for {cls.__name__}: C {lib.sdlt_struct_size(which)} vs ctypes {C.sizeof(cls)}")
     _lib = lib

@@ -23,6 +23,10 @@ extern "C" int sdlt_struct_size(int which) {
     case 2: return (int)sizeof(sdlt_attn_params);
     case 3: return (int)sizeof(sdlt_groupnorm_params);
     case 4: return (int)sizeof(sdlt_shadow_desc);
+    case 5: return (int)sizeof(sdlt_gemm_batch_item);
+    case 6: return (int)sizeof(sdlt_dora_desc);
+    case 7: return (int)sizeof(sdlt_dora_wt_desc);
+    case 8: return (int)sizeof(sdlt_dora_grad_desc);
   }
   return -1;
 }

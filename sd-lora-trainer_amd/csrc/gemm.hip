@@ -55,6 +55,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
   void* pC = (bi && bi->C) ? bi->C : p.C;
   void* pCt = (bi && bi->Ct) ? bi->Ct : p.Ct;
   const float* pBias = (bi && bi->bias) ? bi->bias : p.bias;
+  const float* pCs = R16 ? ((bi && bi->col_scale) ? bi->col_scale : p.col_scale) : nullptr;     // DoRA: adapter launches only
   constexpr int NW = WM * WN, NTHR = NW * 64;
   constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
   static_assert(WM == 2 || WM == 4, "wave rows");
@@ -627,7 +628,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
         for (int a = 0; a < NI; ++a) {
           const int nl = wn * NI * 16 + a * 16 + fk * 4;
           const int n = n0 + nl;
-          f32x4 v = acc[a][b] * p.alpha + biasf[a];
+          f32x4 v = acc[a][b] * p.alpha;
+          if constexpr (R16 != 0) {
+            if (pCs && n < p.N) v *= *(const f32x4*)(pCs + n);    // (staged: N % 8 == 0)
+          }
+          v += biasf[a];
           if (n < p.N) {
             if (p.rowbias) {
               uint2 rb = *(const uint2*)((const bf16_t*)p.rowbias + (size_t)brow * p.ld_rowbias + n);
@@ -729,6 +734,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] * p.alpha;
+      if constexpr (R16 != 0) {
+        if (pCs) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < p.N) v[r] *= pCs[n + r];
+        }
+      }
       if (vec_ok && n + 3 < p.N) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += biasf[a][r];
@@ -1034,6 +1046,8 @@ extern "C" int sdlt_gemm_bf16(const sdlt_gemm_params* pp, void* stream) {
   }
   if (p.accumulate && !p.out_fp32) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: accumulate needs an fp32 output (use R for bf16)");
   int r16 = 0;
+  if (p.col_scale && !p.lora_R) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: col_scale (DoRA) is an option of adapter launches (lora_R > 0)");
+  if (p.col_scale && (((uintptr_t)p.col_scale) & 15)) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_gemm_bf16: col_scale must be 16-byte aligned");
   if (p.lora_R) {
     if (p.lora_R != 16 && p.lora_R != 32 && p.lora_R != 64) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: padded LoRA rank %d (16/32/64)", p.lora_R);
     if (p.K2) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: LoRA + second segment");

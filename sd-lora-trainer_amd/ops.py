@@ -97,8 +97,9 @@ def set_throughput_hint(flag):
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
          residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0, batch=None,
-         geglu_out=None, geglu_bwd=None, act_out=None, dact_in=None):
-    """out[M,N] = alpha*(X.W^T [+ X2.W2^T] [+ s*(X.Adown^T).Bup^T]) + bias + rowbias[m//rows_per_batch] + residual.
+         geglu_out=None, geglu_bwd=None, act_out=None, dact_in=None, col_scale=None):
+    """out[M,N] = alpha*col_scale[n]*(X.W^T [+ X2.W2^T] [+ s*(X.Adown^T).Bup^T]) + bias + rowbias[m//rows_per_batch] + residual.
+    col_scale fp32 [N]: DoRA's magnitude / norm factor (adapter launches only; DoraPlan keeps it up to date).
     act_out = (kind, A [M,N]): also writes A = act(out), kind "gelu" | "quick_gelu" (the CLIP MLP's fc1).
     dact_in = (kind, P [M,N]): out = (...) * act'(P), P = the forward pre-activation (the dX of the CLIP MLP's fc2).
     geglu_out [M, N/2]: this GEMM is ff.net.0.proj in the interleaved-16 layout (geglu_perm) - also writes hidden * gelu(gate).
@@ -155,6 +156,10 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
             assert tuple(T_out.shape) == (M, G * Rp)
             p.T_out, p.ld_t = _p(T_out), _ld(T_out)
     p.alpha = float(alpha)
+    if col_scale is not None:
+        _chk2(col_scale, F32)
+        assert lora is not None and col_scale.numel() == N
+        p.col_scale = _p(col_scale)
     if bias is not None:
         _chk2(bias, F32)
         assert bias.numel() == N
@@ -216,7 +221,7 @@ def geglu_perm(H, device=None):
 class GemmBatch:
     """Device-resident operand table of a batched sdlt_gemm_bf16 launch (sdlt_gemm_batch_item[]).
     items: list of dict with tensors (or None) under X, W, Adown, Bup, T_out, C, Ct, bias - same shapes and strides per key."""
-    KEYS = ("X", "W", "Adown", "Bup", "T_out", "C", "Ct", "bias")
+    KEYS = ("X", "W", "Adown", "Bup", "T_out", "C", "Ct", "bias", "col_scale")
 
     def __init__(self, items, device):
         arr = (_lib.GemmBatchItem * len(items))()
@@ -617,6 +622,101 @@ class ShadowPlan:
         _chk2(arena, F32)
         _lib.check(lib.sdlt_lora_shadow_refresh(_p(self.descs_dev), _p(self.block_desc_dev), _p(self.block_first_dev), self.n_blocks,
                                                 _p(arena), _stream()), "sdlt_lora_shadow_refresh")
+
+
+def _block_table(counts, device):
+    block_desc, block_first, nb = [], [], 0
+    for i, c in enumerate(counts):
+        block_first.append(nb)
+        block_desc += [i] * c
+        nb += c
+    return nb, torch.tensor(block_desc, dtype=torch.int32, device=device), torch.tensor(block_first, dtype=torch.int32, device=device)
+
+
+def _to_dev(arr, device):
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+
+
+class DoraPlan:
+    """Descriptor tables of the three batched DoRA launches (sdlt_dora_refresh / _scale_wt / _mag_grad) over every adapted layer.
+    layers: dict(W [N,K] bf16, A_s [Rp,K], B_s [N,Rp], B32 fp32 [N,rank], mag fp32 [N], scale fp32 [N], Bt bf16 [Rp,N] view or None, s)
+    wts   : dict(src, dst bf16 [rows, cols] (same strides), scale fp32 [period'], period, nvalid)
+    grads : dict(dY, Y bf16 [M,N], bias fp32 [N] or None, mag, scale, gmag fp32 [N], gB fp32 [N,rank])"""
+
+    def __init__(self, layers, wts, grads, rank, Rp, device):
+        self.rank, self.Rp, self.device = rank, Rp, device
+        self.keep = [layers, wts, grads]
+        arr = (_lib.DoraDesc * max(len(layers), 1))()
+        for d, L in zip(arr, layers):
+            W, A, B = L["W"], L["A_s"], L["B_s"]
+            _chk2(W), _chk2(A), _chk2(B), _chk2(L["B32"], F32), _chk2(L["mag"], F32), _chk2(L["scale"], F32)
+            N, K = W.shape
+            assert K % 32 == 0 and tuple(A.shape) == (Rp, K) and tuple(B.shape) == (N, Rp) and tuple(L["B32"].shape) == (N, rank), (W.shape, A.shape, B.shape)
+            d.W, d.ldw, d.A, d.lda, d.B, d.ldb = _p(W), _ld(W), _p(A), _ld(A), _p(B), _ld(B)
+            d.mag, d.scale, d.B32, d.ldb32 = _p(L["mag"]), _p(L["scale"]), _p(L["B32"]), _ld(L["B32"])
+            if L.get("Bt") is not None:
+                _chk2(L["Bt"])
+                assert tuple(L["Bt"].shape) == (Rp, N)
+                d.Bt, d.ldbt = _p(L["Bt"]), _ld(L["Bt"])
+            d.N, d.K, d.Rp, d.rank, d.s = N, K, Rp, rank, float(L["s"])
+        self.layers_dev = _to_dev(arr, device)
+        self.nb_layers, self.bd_layers, self.bf_layers = _block_table([(L["W"].shape[0] + 63) // 64 for L in layers], device)
+        self.set_wts(wts)
+        self.set_grads(grads)
+
+    def set_wts(self, wts):
+        self.keep[1] = wts
+        arr = (_lib.DoraWtDesc * max(len(wts), 1))()
+        for d, w in zip(arr, wts):
+            src, dst = w["src"], w["dst"]
+            _chk2(src), _chk2(dst), _chk2(w["scale"], F32)
+            assert src.shape == dst.shape and src.stride() == dst.stride()
+            d.src, d.dst, d.ld, d.scale = _p(src), _p(dst), _ld(src), _p(w["scale"])
+            d.rows, d.cols, d.period, d.nvalid = src.shape[0], src.shape[1], w["period"], w["nvalid"]
+        self.wts_dev = _to_dev(arr, self.device)
+        self.nb_wts, self.bd_wts, self.bf_wts = _block_table([((w["src"].shape[0] + 31) // 32) * ((w["src"].shape[1] + 255) // 256) for w in wts], self.device)
+
+    def set_grads(self, grads):
+        self.keep[2] = grads
+        arr = (_lib.DoraGradDesc * max(len(grads), 1))()
+        off, c1, c2 = 0, [], []
+        for d, g in zip(arr, grads):
+            dY, Y = g["dY"], g["Y"]
+            _chk2(dY), _chk2(Y), _chk2(g["gmag"], F32), _chk2(g["gB"], F32)
+            M, N = Y.shape
+            assert tuple(dY.shape[:1]) == (M,) and dY.shape[1] >= N and N % 8 == 0 and g["gB"].is_contiguous()
+            assert dY.data_ptr() % 16 == 0 and Y.data_ptr() % 16 == 0 and _ld(dY) % 8 == 0 and _ld(Y) % 8 == 0
+            d.dY, d.lddy, d.Y, d.ldy = _p(dY), _ld(dY), _p(Y), _ld(Y)
+            if g.get("bias") is not None:
+                _chk2(g["bias"], F32)
+                d.bias = _p(g["bias"])
+            d.mag, d.scale, d.gmag, d.gB = _p(g["mag"]), _p(g["scale"]), _p(g["gmag"]), _p(g["gB"])
+            d.M, d.N, d.rank, d.splits, d.grad_scale = M, N, self.rank, max(1, min(64, (M + 2047) // 2048)), 1.0
+            d.ws_off = off
+            off += d.splits * 2 * N
+            c1.append(((N + 63) // 64) * d.splits)
+            c2.append((N + 255) // 256)
+        self.grads_dev = _to_dev(arr, self.device)
+        self.nb_g1, self.bd_g1, self.bf_g1 = _block_table(c1, self.device)
+        self.nb_g2, self.bd_g2, self.bf_g2 = _block_table(c2, self.device)
+        self.ws = torch.empty(max(off, 1), dtype=F32, device=self.device)
+
+    def refresh(self, init=False):
+        """scale = mag / ||W + s B A||_row (init: mag := the norm first), scaled B^T operands, then the scaled dX weights."""
+        lib = _lib.load()
+        if self.nb_layers:
+            _lib.check(lib.sdlt_dora_refresh(_p(self.layers_dev), _p(self.bd_layers), _p(self.bf_layers), self.nb_layers, self.Rp, int(init), _stream()),
+                       "sdlt_dora_refresh")
+        self.scale_wts()
+
+    def scale_wts(self):
+        if self.nb_wts:
+            _lib.check(_lib.load().sdlt_dora_scale_wt(_p(self.wts_dev), _p(self.bd_wts), _p(self.bf_wts), self.nb_wts, _stream()), "sdlt_dora_scale_wt")
+
+    def mag_grad(self):
+        if self.nb_g1:
+            _lib.check(_lib.load().sdlt_dora_mag_grad(_p(self.grads_dev), _p(self.bd_g1), _p(self.bf_g1), self.nb_g1, _p(self.bd_g2), _p(self.bf_g2),
+                                                      self.nb_g2, _p(self.ws), _stream()), "sdlt_dora_mag_grad")
 
 
 def _shadow_adamw(self, p, g, m, v, hyper):

@@ -95,6 +95,7 @@ class TextStack:
             if self._grad_plan is None:
                 self._grad_plan = self.rt.ops.LoraGradPlan(self.arena.problems, self.arena.Rp, self.rt.device)
             self._grad_plan.run()
+            self.arena.dora_mag_grad()
 
 
 def ddpm_alphas_cumprod(n=1000, beta_start=0.00085, beta_end=0.012):

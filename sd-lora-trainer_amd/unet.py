@@ -116,8 +116,12 @@ def clone_plan(mod, rt, _memo=None):
 class LoraArena:
     """Flat fp32 master copy of every LoRA A/B (plus grads and AdamW moments) and the bf16 compute copies."""
 
-    def __init__(self, rt, rank, alpha_multiplier=1.0, problems=None):
-        self.rt, self.rank = rt, rank
+    def __init__(self, rt, rank, alpha_multiplier=1.0, problems=None, dora=False):
+        """dora: weight-decomposed adapters (peft use_dora, trainer/optimizer.py:86-95): every entry also owns a trained magnitude
+        vector M [N]; y = (M / ||W + s B A||_row) * (x W^T + s x A^T B^T) + bias with the norm detached.  The per-column factor
+        (`scale`), the scaled backward operands and M's gradient are maintained by three batched launches (ops.DoraPlan)."""
+        self.rt, self.rank, self.dora = rt, rank, bool(dora)
+        self.dora_wts, self.dora_grads, self.dora_plan, self._dora_ngrads = [], [], None, 0
         # LoRA-gradient problems of the adapters in this arena, appended by the layers on their first backward.  The UNet
         # arena shares the runtime's list; the text-encoder arena (step.TextStack) keeps its own, run after the text backward.
         self.problems = rt.lora_problems if problems is None else problems
@@ -129,10 +133,15 @@ class LoraArena:
         self._shadow_entries = []
         self.params = self.grads = self.m = self.v = None
 
-    def add(self, name, N, K, conv_cin=None):
+    def add(self, name, N, K, conv_cin=None, W=None):
+        """W: the layer's bf16 forward operand [N, K] (DoRA: its rows enter the norm)."""
         r, Rp, rt = self.rank, self.Rp, self.rt
-        e = dict(name=name, N=N, K=K, conv_cin=conv_cin, offA=self.n, offB=self.n + r * K)
+        e = dict(name=name, N=N, K=K, conv_cin=conv_cin, offA=self.n, offB=self.n + r * K, W=W)
         self.n += r * K + N * r
+        if self.dora:
+            assert W is not None and N % 4 == 0
+            e["offM"] = self.n
+            self.n += N
         e["A_s"] = rt.zeros(Rp, K)          # LoRA-down, forward orientation   [Rp, K]
         e["B_s"] = rt.zeros(N, Rp)          # LoRA-up                          [N, Rp]
         e["Bt_s"] = rt.zeros(Rp, N)         # backward LoRA-down operand       [Rp, N]
@@ -151,6 +160,13 @@ class LoraArena:
         self.v = rt.zeros(self.n, dtype=F32)
         sh = []
         r = self.rank
+        if self.dora:
+            self.dscale = rt.zeros(sum(e["N"] for e in self.entries), dtype=F32)
+            off = 0
+            for e in self.entries:
+                e["offS"] = off
+                e["scale"] = self.dscale[off: off + e["N"]]
+                off += e["N"]
         for e in self.entries:
             N, K = e["N"], e["K"]
             if e["conv_cin"] is None:
@@ -160,21 +176,64 @@ class LoraArena:
                 sh.append((e["offA"], r, K, K, e["A_s"], None))
                 for tap in range(9):   # A[:, tap, :] ([r, Cin], row stride 9*Cin) -> Ab[ci, tap*64 + rank]
                     sh.append((e["offA"] + tap * cin, r, cin, K, None, e["Ab_s"][:, tap * 64: tap * 64 + 64]))
-            sh.append((e["offB"], N, r, r, e["B_s"], e["Bt_s"]))
+            sh.append((e["offB"], N, r, r, e["B_s"], None if self.dora else e["Bt_s"]))      # DoRA: B^T is written scaled by the refresh
             e["A"] = self.params[e["offA"]: e["offA"] + r * K].view(r, K)
             e["B"] = self.params[e["offB"]: e["offB"] + N * r].view(N, r)
             e["gA"] = self.grads[e["offA"]: e["offA"] + r * K].view(r, K)
             e["gB"] = self.grads[e["offB"]: e["offB"] + N * r].view(N, r)
+            if self.dora:
+                e["M"] = self.params[e["offM"]: e["offM"] + N]
+                e["gM"] = self.grads[e["offM"]: e["offM"] + N]
         self._shadow_plan = rt.ops.ShadowPlan(sh, rt.device)
+        if self.dora:
+            self._build_dora_plan()
+            self.dora_plan.refresh(init=True)        # peft dora_init: magnitude = ||W + s B A||_row of the freshly injected adapter (B = 0)
+
+    def _build_dora_plan(self):
+        layers = [dict(W=e["W"], A_s=e["A_s"], B_s=e["B_s"], B32=e["B"], mag=e["M"], scale=e["scale"], Bt=e["Bt_s"], s=self.scale) for e in self.entries]
+        wts = []
+        for w in self.dora_wts:
+            ents = w["entries"]
+            for a, b in zip(ents, ents[1:]):
+                assert b["offS"] == a["offS"] + a["N"], "stacked projections must be consecutive arena entries"
+            n = sum(e_["N"] for e_ in ents)
+            wts.append(dict(src=w["src"], dst=w["dst"], scale=self.dscale[ents[0]["offS"]: ents[0]["offS"] + n], period=w.get("period", n), nvalid=w.get("nvalid", n)))
+        self.dora_plan = self.rt.ops.DoraPlan(layers, wts, self.dora_grads, self.rank, self.Rp, self.rt.device)
+        self._dora_ngrads = len(self.dora_grads)
+
+    def scale_of(self, entries):
+        """fp32 view of the DoRA column factors of consecutive entries (one entry: a layer; several: a stack of projections)."""
+        e0 = entries[0]
+        return self.dscale[e0["offS"]: e0["offS"] + sum(e["N"] for e in entries)]
+
+    def set_scale(self, scale):
+        """lora_alpha / r in effect (the validation renders run the adapters at a reduced scale, checkpoint.py:31-55)."""
+        self.scale = scale
+        if self.dora:
+            self._build_dora_plan()
+            self.dora_plan.refresh()
 
     def refresh_shadows(self):
         self._shadow_plan.run(self.params)
+        if self.dora:
+            self.dora_plan.refresh()
+
+    def dora_mag_grad(self):
+        """Gradient of the magnitudes and the row scaling of dB; after the grouped LoRA-gradient launch of a backward pass."""
+        if not self.dora:
+            return
+        if self._dora_ngrads != len(self.dora_grads):
+            self.dora_plan.set_grads(self.dora_grads)
+            self._dora_ngrads = len(self.dora_grads)
+        self.dora_plan.mag_grad()
 
     # ---- host-side (load / export) in the reference's layouts -------------------------------
     def load(self, lora_dict):
         """lora_dict: module -> (A, B) in peft layout (conv: A [r,Cin,3,3], B [Cout,r,1,1])."""
         for e in self.entries:
-            A, B = lora_dict[e["name"]]
+            A, B, *rest = lora_dict[e["name"]]
+            if rest and self.dora:          # (A, B, magnitude); without it the magnitudes keep their value
+                e["M"].copy_(rest[0].reshape(-1).to(self.rt.device, F32))
             if A.dim() == 4:
                 A = A.permute(0, 2, 3, 1).reshape(A.shape[0], -1)   # [r, (tap, ci)]
                 B = B.reshape(B.shape[0], -1)
@@ -192,6 +251,9 @@ class LoraArena:
                 A = A.reshape(r, 3, 3, e["conv_cin"]).permute(0, 3, 1, 2).contiguous()
                 B = B.reshape(B.shape[0], r, 1, 1)
             out[e["name"]] = (A, B)
+            if self.dora:                   # peft lora_magnitude_vector: [N] (Linear), [1, N, 1, 1] (Conv2d)
+                m = (e["M"] if which == "params" else e["gM"]).detach().float().cpu().clone()
+                out[e["name"]] = (A, B, m.reshape(1, -1, 1, 1) if e["conv_cin"] is not None else m)
         return out
 
 
@@ -210,8 +272,13 @@ class Linear(_Module):
         self.Wt = w.t().to(rt.device, rt.act).contiguous() if need_dx else None
         b = sd.get(name + ".bias")
         self.bias = b.to(rt.device, F32).contiguous() if b is not None else None
-        self.lora = arena.add(name, self.N, self.K) if arena is not None else None
+        self.lora = arena.add(name, self.N, self.K, W=self.W) if arena is not None else None
         self.arena = arena
+        self.dora = arena is not None and arena.dora
+        if self.dora and need_dx:          # dX operand with the DoRA column factor folded into its K axis (refreshed every step)
+            self.Wt_d = torch.empty_like(self.Wt)
+            self._dora_wt = dict(src=self.Wt, dst=self.Wt_d, entries=[self.lora])
+            arena.dora_wts.append(self._dora_wt)
         # full fine-tune: the fp32 master of weight / bias lives in the trainer's arena (fullft.WeightTrainer)
         tr = rt.trainer if (rt.trainer is not None and rt.trainer.registering) else None
         self.trainer = tr
@@ -239,6 +306,14 @@ class Linear(_Module):
             self._x = x
         if self.trainer is not None:
             self._x = x
+        if self.dora:
+            # y = scale * (x W^T + s x A^T B^T) + bias; the residual is added by a second launch because the magnitude gradient
+            # needs the layer's own output (DoraPlan.mag_grad)
+            assert geglu_out is None and act_out is None and not (residual is not None and Ct is not None)
+            y0 = y if residual is None else self.buf(key + "0", M, self.N)
+            self.rt.ops.gemm(x, self.W, y0, lora=lora, bias=self.bias, Ct=Ct, col_scale=self.lora["scale"])
+            self._y0 = y0
+            return y if residual is None else self.rt.ops.add2d(y0, residual, y)
         if geglu_out is not None:
             self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, residual=residual, Ct=Ct, geglu_out=geglu_out)
         elif act_out is not None:
@@ -259,13 +334,17 @@ class Linear(_Module):
                 self.arena.problems += [
                     dict(P=dy, Q=self._b["T"], out=self.lora["gB"], M=M, Cw=self.N, R=r, rank_major=False),
                     dict(P=self._x, Q=U, out=self.lora["gA"], M=M, Cw=self.K, R=r, rank_major=True)]
+                if self.dora:
+                    self.arena.dora_grads.append(dict(dY=dy, Y=self._y0, bias=self.bias, mag=self.lora["M"], scale=self.lora["scale"],
+                                                      gmag=self.lora["gM"], gB=self.lora["gB"]))
                 self._registered = True
         if self.trainer is not None:
             self.weight_grad(dy)
+        Wt = self.Wt_d if self.dora else self.Wt
         if dact_in is not None:
-            self.rt.ops.gemm(dy, self.Wt, dx, lora=lora, residual=dres, Ct=Ct, dact_in=dact_in)
+            self.rt.ops.gemm(dy, Wt, dx, lora=lora, residual=dres, Ct=Ct, dact_in=dact_in)
         else:
-            self.rt.ops.gemm(dy, self.Wt, dx, lora=lora, residual=dres, Ct=Ct)
+            self.rt.ops.gemm(dy, Wt, dx, lora=lora, residual=dres, Ct=Ct)
         return dx
 
 
@@ -284,9 +363,12 @@ class StackedLinear(_Module):
         self.W = torch.cat([m.W for m in members], 0).contiguous()
         for g, m in enumerate(members):
             m.W = self.W[g * N:(g + 1) * N]
+            if m.lora is not None:
+                m.lora["W"] = m.W
         self.bias = torch.cat([m.bias for m in members]).contiguous() if members[0].bias is not None else None
         self.arena = members[0].arena
         self.has_lora = members[0].lora is not None
+        self.dora = self.has_lora and self.arena.dora
         self.trainer = members[0].trainer
         if self.trainer is not None:
             # the members' master weights are consecutive in the trainer's arena: one [G*N, K] gradient, one dW GEMM
@@ -315,6 +397,15 @@ class StackedLinear(_Module):
                 for g, m in enumerate(members):
                     m.lora["Bt_s"] = self.Bt_cat[:, g * N:(g + 1) * N]
                     m.lora["At_s"] = self.At_cat[:, g * Rp:(g + 1) * Rp]
+                if self.dora:       # one scaled dX operand for the stack instead of the members'
+                    self.Wt = self.W.t().contiguous()
+                    self.Wt_d = torch.empty_like(self.Wt)
+                    for m in members:
+                        if getattr(m, "_dora_wt", None) is not None:
+                            self.arena.dora_wts[:] = [w for w in self.arena.dora_wts if w is not m._dora_wt]
+                            m._dora_wt = m.Wt_d = None
+                        m.Wt = None
+                    self.arena.dora_wts.append(dict(src=self.Wt, dst=self.Wt_d, entries=[m.lora for m in members]))
 
     def prepare(self, x):
         """Allocates the stacked output / T buffers for input x and points the members at their slices (no launch)."""
@@ -327,7 +418,7 @@ class StackedLinear(_Module):
         outs = []
         for g, m in enumerate(self.members):
             m._x = x
-            m._b["y"] = y[:, g * N:(g + 1) * N]
+            m._b["y"] = m._y0 = y[:, g * N:(g + 1) * N]
             if self.has_lora:
                 m._b["T"] = T[:, g * Rp:(g + 1) * Rp]
             outs.append(m._b["y"])
@@ -337,8 +428,12 @@ class StackedLinear(_Module):
         """Returns the member outputs as column slices of one [M, G*N] buffer."""
         y, T, outs = self.prepare(x)
         lora = (self.A_cat, self.B_cat, self.arena.scale, T) if self.has_lora else None
-        self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, Ct=Ct, lora_group_n=self.N if self.has_lora else 0)
+        self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, Ct=Ct, lora_group_n=self.N if self.has_lora else 0,
+                         **({"col_scale": self.col_scale()} if self.dora else {}))
         return outs
+
+    def col_scale(self):
+        return self.arena.scale_of([m.lora for m in self.members])
 
     def grad_slices(self, M):
         """One [M, G*N] buffer whose column slices receive the members' output gradients (attention writes them there)."""
@@ -360,7 +455,7 @@ class StackedLinear(_Module):
             return dx
         assert self.kgrouped
         U = self.backward_operands(dy_cat)
-        self.rt.ops.gemm(dy_cat, self.Wt, dx, lora=(self.Bt_cat, self.At_cat, self.arena.scale, U), residual=dres, lora_group_k=N)
+        self.rt.ops.gemm(dy_cat, self.Wt_d if self.dora else self.Wt, dx, lora=(self.Bt_cat, self.At_cat, self.arena.scale, U), residual=dres, lora_group_k=N)
         return dx
 
     def backward_operands(self, dy_cat):
@@ -377,6 +472,9 @@ class StackedLinear(_Module):
                 self.arena.problems += [
                     dict(P=dy_cat[:, g * N:(g + 1) * N], Q=m._b["T"], out=m.lora["gB"], M=M, Cw=N, R=r, rank_major=False),
                     dict(P=m._x, Q=U[:, g * 16:(g + 1) * 16], out=m.lora["gA"], M=M, Cw=self.K, R=r, rank_major=True)]
+                if self.dora:
+                    self.arena.dora_grads.append(dict(dY=dy_cat[:, g * N:(g + 1) * N], Y=m._y0, bias=m.bias, mag=m.lora["M"], scale=m.lora["scale"],
+                                                      gmag=m.lora["gM"], gB=m.lora["gB"]))
             self._registered = True
         return U
 
@@ -400,8 +498,13 @@ class Conv3x3(_Module):
             wb[..., : self.Cout] = w.permute(1, 2, 3, 0)
             self.Wb = wb.reshape(self.Cin, 9 * self.Cout_p).to(rt.device, rt.act).contiguous()
         self.bias = sd[name + ".bias"].to(rt.device, F32).contiguous()
-        self.lora = arena.add(name, self.Cout, 9 * self.Cin, conv_cin=self.Cin) if arena is not None else None
+        self.lora = arena.add(name, self.Cout, 9 * self.Cin, conv_cin=self.Cin, W=self.Wf) if arena is not None else None
         self.arena = arena
+        self.dora = arena is not None and arena.dora
+        if self.dora:
+            assert self.Cin_p == self.Cin and need_dx
+            self.Wb_d = torch.empty_like(self.Wb)
+            arena.dora_wts.append(dict(src=self.Wb, dst=self.Wb_d, entries=[self.lora], period=self.Cout_p, nvalid=self.Cout))
         tr = rt.trainer if (rt.trainer is not None and rt.trainer.registering) else None
         self.trainer = tr
         if tr is not None:         # master weight tap-major [Cout, (ky, kx, ci)], like the forward GEMM operand
@@ -438,9 +541,15 @@ class Conv3x3(_Module):
             self._x, self._g = x, g
         if self.trainer is not None:
             self._x = x
+        self._dims = (B, H, W, Hout, Wout)
+        if self.dora:       # see Linear.forward
+            assert rowbias is None
+            y0 = y if residual is None else self.buf(key + "0", M, self.Cout)
+            self.rt.ops.gemm(x, self.Wf, y0, conv=g, lora=lora, bias=self.bias, col_scale=self.lora["scale"])
+            self._y0 = y0
+            return y if residual is None else self.rt.ops.add2d(y0, residual, y)
         self.rt.ops.gemm(x, self.Wf, y, conv=g, lora=lora, bias=self.bias, rowbias=rowbias, rows_per_batch=Hout * Wout,
                          residual=residual)
-        self._dims = (B, H, W, Hout, Wout)
         return y
 
     def backward(self, dy, *, dres=None, key="dx", out=None):
@@ -467,13 +576,16 @@ class Conv3x3(_Module):
         U64 = self.buf("U64", M, 64, zero=True)
         U = U64[:, : self.arena.Rp]
         rt.ops.gemm(dy, self.lora["Bt_s"], U, alpha=self.arena.scale)
-        rt.ops.gemm(dy, self.Wb, dx, conv=gb, residual=dres)
+        rt.ops.gemm(dy, self.Wb_d if self.dora else self.Wb, dx, conv=gb, residual=dres)
         rt.ops.gemm(U64, self.lora["Ab_s"], dx, conv=_ops.ConvGeom(B, Hout, Wout, 64, H, W, flip=1), residual=dx)
         if not getattr(self, "_registered", False):
             r = self.arena.rank
             self.arena.problems += [
                 dict(P=dy, Q=self._b["T"], out=self.lora["gB"], M=M, Cw=self.Cout, R=r, rank_major=False),
                 dict(P=self._x, Q=U, out=self.lora["gA"], M=M, Cw=9 * self.Cin, R=r, rank_major=True, conv=self._g)]
+            if self.dora:
+                self.arena.dora_grads.append(dict(dY=dy, Y=self._y0, bias=self.bias, mag=self.lora["M"], scale=self.lora["scale"],
+                                                  gmag=self.lora["gM"], gB=self.lora["gB"]))
             self._registered = True
         return dx
 
@@ -792,7 +904,7 @@ class ResnetBlock(_Module):
 class UNet(_Module):
     """forward(noisy NHWC, timesteps, ctx[, pooled, time_ids]) -> eps_hat [B*h*w, 4] fp32;  backward(dpred)."""
 
-    def __init__(self, rt, version, sd, lora_rank=None, lora_alpha_multiplier=1.0, trainer=None):
+    def __init__(self, rt, version, sd, lora_rank=None, lora_alpha_multiplier=1.0, trainer=None, use_dora=False):
         """trainer: a fullft.WeightTrainer -> every parameter of the UNet is registered with it and trained (the
         reference's `is_lora = False` branch, main.py:144-149); lora_rank must then be None."""
         super().__init__(rt, "unet")
@@ -806,7 +918,7 @@ class UNet(_Module):
         boc = cfg["block_out_channels"]
         for c in boc:
             assert c % 64 == 0, "channel counts must be multiples of 64 (GEMM K-step / GroupNorm tiling)"
-        self.arena = LoraArena(rt, lora_rank, lora_alpha_multiplier) if lora_rank else None
+        self.arena = LoraArena(rt, lora_rank, lora_alpha_multiplier, dora=use_dora) if lora_rank else None
         ar, L = self.arena, cfg["layers_per_block"]
         c0 = boc[0]
         self.tdim = c0 * TIME_DIM_MULT
@@ -1001,6 +1113,7 @@ class UNet(_Module):
             if self._grad_plan is None:
                 self._grad_plan = rt.ops.LoraGradPlan(self.arena.problems, self.arena.Rp, rt.device)
             self._grad_plan.run()
+            self.arena.dora_mag_grad()
 
     # ------------------------------------------------------------------------------------ batched score-gradient GEMMs
     def daam_backward(self):
@@ -1055,6 +1168,8 @@ class UNet(_Module):
                     st = a.stack
                     y, T, _ = st.prepare(ctx)
                     it = dict(W=st.W, Adown=st.A_cat, Bup=st.B_cat, T_out=T, C=y)
+                    if st.dora:
+                        it["col_scale"] = st.col_scale()
                     if hooked:      # transposed K for the score side output's backward (see Attention.backward)
                         KVt = a.buf("KVt", 2 * C, _pad_to(Mk, 8))
                         a._b["Kt"] = KVt[:C]
@@ -1064,7 +1179,7 @@ class UNet(_Module):
         for members, items, batch in self._kv_groups:
             st, it = members[0].stack, items[0]
             rt.ops.gemm(ctx, st.W, it["C"], lora=(st.A_cat, st.B_cat, st.arena.scale, it["T_out"]), Ct=it.get("Ct"),
-                        lora_group_n=st.N, batch=batch)
+                        lora_group_n=st.N, batch=batch, **({"col_scale": it["col_scale"]} if st.dora else {}))
 
     def _cross_kv_backward(self, dctx):
         """dctx += sum over all cross-attention layers of [dk | dv] . [Wk ; Wv] (+ their adapters): one batched K-grouped GEMM
@@ -1083,7 +1198,7 @@ class UNet(_Module):
                     st = a.stack
                     dkv, _ = st.grad_slices(Mk)
                     U = st.backward_operands(dkv)
-                    items.append(dict(X=dkv, W=st.Wt, Adown=st.Bt_cat, Bup=st.At_cat, T_out=U, C=part[i]))
+                    items.append(dict(X=dkv, W=st.Wt_d if st.dora else st.Wt, Adown=st.Bt_cat, Bup=st.At_cat, T_out=U, C=part[i]))
                     i += 1
                 self._kv_bwd.append((members, items, rt.ops.GemmBatch(items, rt.device)))
         for members, items, batch in self._kv_bwd:

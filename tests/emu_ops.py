@@ -48,7 +48,7 @@ def set_throughput_hint(flag):
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
          residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0, batch=None,
-         geglu_out=None, geglu_bwd=None, act_out=None, dact_in=None):
+         geglu_out=None, geglu_bwd=None, act_out=None, dact_in=None, col_scale=None):
     if geglu_bwd is not None:     # dX of ff.net.2 fused with GEGLU's backward; F1 / dF1 in the interleaved-16 layout
         f1, df1 = geglu_bwd
         H = W.shape[0]
@@ -66,7 +66,8 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
             lo = None if lora is None else (it.get("Adown", lora[0]) if it.get("Adown") is not None else lora[0], it.get("Bup") if it.get("Bup") is not None else lora[1], lora[2], it.get("T_out") if it.get("T_out") is not None else lora[3])
             gemm(it["X"] if it.get("X") is not None else X, it["W"] if it.get("W") is not None else W, it["C"] if it.get("C") is not None else out, X2=X2, W2=W2, conv=conv, lora=lo,
                  bias=it.get("bias") if it.get("bias") is not None else bias, rowbias=rowbias, rows_per_batch=rows_per_batch, residual=residual, alpha=alpha,
-                 Ct=it.get("Ct") if it.get("Ct") is not None else Ct, accumulate=accumulate, lora_group_n=lora_group_n, lora_group_k=lora_group_k)
+                 Ct=it.get("Ct") if it.get("Ct") is not None else Ct, accumulate=accumulate, lora_group_n=lora_group_n, lora_group_k=lora_group_k,
+                 col_scale=it.get("col_scale") if it.get("col_scale") is not None else col_scale)
         return out
     acc = X.float() @ W.float().t() if conv is None else _conv_apply(X, W, conv)
     if X2 is not None:
@@ -90,6 +91,9 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
         else:
             acc = acc + Tb.float() @ Bup.float().t()
     acc = acc * alpha
+    if col_scale is not None:     # DoRA: magnitude / norm per output column, before bias / residual
+        assert lora is not None
+        acc = acc * col_scale.float()
     if bias is not None:
         acc = acc + bias.float()
     if rowbias is not None:
@@ -132,6 +136,45 @@ def geglu_perm(H, device=None):
 class GemmBatch:
     def __init__(self, items, device):
         self.items, self.n = items, len(items)
+
+
+class DoraPlan:
+    """torch emulation of ops.DoraPlan (sdlt_dora_refresh / _scale_wt / _mag_grad)."""
+
+    def __init__(self, layers, wts, grads, rank, Rp, device):
+        self.layers, self.wts, self.grads, self.rank = layers, wts, grads, rank
+
+    def set_wts(self, wts):
+        self.wts = wts
+
+    def set_grads(self, grads):
+        self.grads = grads
+
+    def refresh(self, init=False):
+        r = self.rank
+        for L in self.layers:
+            weff = L["W"].float() + L["s"] * L["B_s"][:, :r].float() @ L["A_s"][:r].float()
+            nrm = weff.norm(dim=1)
+            if init:
+                L["mag"].copy_(nrm)
+            L["scale"].copy_(L["mag"] / nrm)
+            if L.get("Bt") is not None:
+                L["Bt"].zero_()
+                L["Bt"][:r].copy_((L["B32"] * L["scale"][:, None]).t().to(L["Bt"].dtype))
+        self.scale_wts()
+
+    def scale_wts(self):
+        for w in self.wts:
+            idx = torch.arange(w["src"].shape[1]) % w["period"]
+            sc = torch.where(idx < w["nvalid"], w["scale"][idx.clamp(max=w["scale"].numel() - 1)], torch.zeros(()))
+            w["dst"].copy_((w["src"].float() * sc).to(w["dst"].dtype))
+
+    def mag_grad(self):
+        for g in self.grads:
+            N = g["Y"].shape[1]
+            z = g["Y"].float() - (g["bias"].float() if g.get("bias") is not None else 0.0)
+            g["gmag"].copy_((g["dY"][:, :N].float() * z).sum(0) / g["mag"])
+            g["gB"].mul_(g["scale"][:, None])
 
 
 class LoraGradPlan:

@@ -740,3 +740,113 @@ def test_splitk_workspace_per_owner(ops):
         close(out, E.gemm(X, W, torch.zeros(128, 256, dtype=BF)), what="split-K GEMM under an owner workspace")
     assert len({base[0].data_ptr(), wa[0].data_ptr(), wb[0].data_ptr()}) == 3 and len({base[1].data_ptr(), wa[1].data_ptr(), wb[1].data_ptr()}) == 3
     assert ops.splitk_workspace(torch.device("cuda:0"))[0].data_ptr() == base[0].data_ptr()
+
+
+# --------------------------------------------------------------------------------------------- DoRA
+@pytest.mark.parametrize("M,N,K,r,tile,splitk,conv", [(1024, 1280, 1280, 16, 0, 0, False), (333, 200, 192, 4, 2, 0, False), (256, 256, 1280, 16, 1, 3, False),
+                                                      (300, 256, 384, 64, 2, 0, False), (77, 640, 2048, 16, 3, 0, False), (512, 320, 64, 16, 0, 0, True)])
+def test_gemm_col_scale(ops, M, N, K, r, tile, splitk, conv):
+    """sdlt_gemm_params.col_scale: the product incl. the adapter term times a per-column factor, before bias and residual (DoRA)."""
+    g = torch.Generator().manual_seed(M + N + r)
+    Rp = 16 if r <= 16 else (32 if r <= 32 else 64)
+    geom = None
+    if conv:                                  # K = Cin here; the 3x3 operand is [N, 9*Cin]
+        Bn, H, Wd_ = 2, 16, 16
+        geom = E.ConvGeom(Bn, H, Wd_, K, H, Wd_) if hasattr(E, "ConvGeom") else None
+        M, Kw = Bn * H * Wd_, 9 * K
+    else:
+        Kw = K
+    X, W = rnd(M, K, g=g), rnd(N, Kw, g=g, scale=1 / math.sqrt(Kw))
+    A = torch.zeros(Rp, Kw, dtype=BF)
+    A[:r] = rnd(r, Kw, g=g, scale=1 / math.sqrt(Kw))
+    Bu = torch.zeros(N, Rp, dtype=BF)
+    Bu[:, :r] = rnd(N, r, g=g, scale=0.3)
+    bias, cs = torch.randn(N, generator=g), 0.5 + torch.rand(N, generator=g)
+    R = rnd(M, N, g=g)
+    kw = dict(conv=geom) if conv else {}
+    ref = E.gemm(X, W, torch.empty(M, N, dtype=BF), lora=(A, Bu, 0.75, None), bias=bias, residual=R, col_scale=cs, **kw)
+    Xd, Wd, Ad, Bd, bd, csd, Rd = dev(X, W, A, Bu, bias, cs, R)
+    if conv:
+        kw = dict(conv=ops.ConvGeom(Bn, H, Wd_, K, H, Wd_))
+    out = ops.gemm(Xd, Wd, torch.empty(M, N, dtype=BF, device="cuda"), lora=(Ad, Bd, 0.75, None), bias=bd, residual=Rd, col_scale=csd, tile=tile,
+                   splitk=splitk, **kw)
+    close(out, ref, what=f"col_scale gemm {M}x{N}x{Kw} r{r}")
+    plain = E.gemm(X, W, torch.empty(M, N, dtype=BF), lora=(A, Bu, 0.75, None), bias=bias, residual=R, **(dict(conv=geom) if conv else {}))
+    assert float((ref.float() - plain.float()).abs().max()) > 0.05
+
+
+@pytest.mark.parametrize("r", [4, 16, 24, 64])
+def test_dora_plan_kernels(ops, r):
+    """sdlt_dora_refresh (row norms of W + s B A on the matrix cores, scale, scaled B^T), sdlt_dora_scale_wt (linear and 3x3-conv
+    layouts) and sdlt_dora_mag_grad (magnitude gradient + dB row scaling) against the torch emulation, several layers per launch."""
+    g = torch.Generator().manual_seed(r)
+    Rp = 16 if r <= 16 else (32 if r <= 32 else 64)
+    s = 0.75
+    shapes = [(320, 320, 700), (1280, 2048, 77), (200, 64, 4100), (640, 9 * 64, 1024)]      # (N, K, M); the last one a 3x3 conv, Cin 64
+    cpu, gpu = [], []
+    for li, (N, K, M) in enumerate(shapes):
+        L = dict(W=rnd(N, K, g=g, scale=1 / math.sqrt(K)), A_s=torch.zeros(Rp, K, dtype=BF), B_s=torch.zeros(N, Rp, dtype=BF), s=s,
+                 B32=torch.randn(N, r, generator=g) * 0.2, mag=torch.rand(N, generator=g) + 0.5, scale=torch.zeros(N), Bt=torch.zeros(Rp, N, dtype=BF))
+        L["A_s"][:r] = rnd(r, K, g=g, scale=1 / math.sqrt(K))
+        L["B_s"][:, :r] = L["B32"].to(BF)
+        cpu.append(L)
+        gpu.append({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in L.items()})
+    # transposed dX operands: linear [K, N] (period N) and conv [Cin, 9*Cout_p] (period Cout_p = 640, all valid; one with padding)
+    wts_c, wts_g = [], []
+    for li, (N, K, M) in enumerate(shapes):
+        if li < 3:
+            src = rnd(K, N, g=g)
+            period, nvalid = N, N
+        else:
+            src = rnd(64, 9 * 640, g=g)
+            period, nvalid = 640, 640
+        wts_c.append(dict(src=src, dst=torch.zeros_like(src), scale=cpu[li]["scale"], period=period, nvalid=nvalid))
+        wts_g.append(dict(src=src.cuda(), dst=torch.zeros_like(src).cuda(), scale=gpu[li]["scale"], period=period, nvalid=nvalid))
+    src = rnd(32, 9 * 256, g=g)                 # padded layout: 200 valid of 256 columns per tap
+    wts_c.append(dict(src=src, dst=torch.zeros_like(src), scale=cpu[2]["scale"], period=256, nvalid=200))
+    wts_g.append(dict(src=src.cuda(), dst=torch.zeros_like(src).cuda(), scale=gpu[2]["scale"], period=256, nvalid=200))
+    grads_c, grads_g = [], []
+    for li, (N, K, M) in enumerate(shapes):
+        big = rnd(M, N + 64, g=g)               # dY as a column slice of a wider buffer (stacked projections)
+        e = dict(dY=big[:, 32:32 + N] if N % 8 == 0 and li == 0 else rnd(M, N, g=g), Y=rnd(M, N, g=g), bias=torch.randn(N, generator=g) if li != 1 else None,
+                 mag=cpu[li]["mag"], scale=cpu[li]["scale"], gmag=torch.zeros(N), gB=torch.randn(N, r, generator=g))
+        grads_c.append(e)
+        eg = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in e.items()}
+        if li == 0:
+            bg = big.cuda()
+            eg["dY"] = bg[:, 32:32 + N]
+        eg["mag"], eg["scale"] = gpu[li]["mag"], gpu[li]["scale"]
+        grads_g.append(eg)
+    for init in (True, False):
+        pc = E.DoraPlan(cpu, wts_c, grads_c, r, Rp, "cpu")
+        pg = ops.DoraPlan(gpu, wts_g, grads_g, r, Rp, "cuda")
+        if not init:
+            for Lc, Lg in zip(cpu, gpu):
+                m = torch.rand(Lc["mag"].shape, generator=g) + 0.5
+                Lc["mag"].copy_(m)
+                Lg["mag"].copy_(m)
+        pc.refresh(init=init)
+        pg.refresh(init=init)
+        torch.cuda.synchronize()
+        for li, (Lc, Lg) in enumerate(zip(cpu, gpu)):
+            close(Lg["mag"], Lc["mag"], tol=2e-3, what=f"layer {li} magnitude (init={init})")
+            close(Lg["scale"], Lc["scale"], tol=2e-3, what=f"layer {li} scale")
+            close(Lg["Bt"], Lc["Bt"], tol=1e-2, what=f"layer {li} scaled B^T")
+            if init:
+                assert float((Lg["scale"] - 1).abs().max()) < 1e-6
+        for wi, (wc, wg) in enumerate(zip(wts_c, wts_g)):
+            close(wg["dst"], wc["dst"], tol=1e-2, what=f"scaled dX operand {wi}")
+        if not init:
+            assert float((wts_g[-1]["dst"].view(32, 9, 256)[:, :, 200:]).abs().max()) == 0.0
+    pc.mag_grad()
+    pg.mag_grad()
+    torch.cuda.synchronize()
+    first = [eg["gmag"].clone() for eg in grads_g]
+    for li, (ec, eg) in enumerate(zip(grads_c, grads_g)):
+        close(eg["gmag"], ec["gmag"], tol=1e-2, what=f"layer {li} magnitude gradient")
+        close(eg["gB"], ec["gB"], tol=1e-5, what=f"layer {li} dB row scaling")
+    for ec, eg in zip(grads_c, grads_g):        # fixed-order reduction: bitwise repeatable
+        eg["gB"].copy_(ec["gB"].cuda())
+    pg.mag_grad()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, eg["gmag"]) for a, eg in zip(first, grads_g))

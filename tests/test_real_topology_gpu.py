@@ -129,14 +129,14 @@ def _batch(cfg, B, h, seed, tvals, vc=REAL):
     return dict(latent=latent, noise=noise, mask=mask, t=t, lists=lists, ids=ids)
 
 
-def _build_product(version, B, h, sd, lora, hf, rank, kinds=None, device="cuda:0", ops=None, act_dtype=torch.bfloat16, **step_kw):
+def _build_product(version, B, h, sd, lora, hf, rank, kinds=None, device="cuda:0", ops=None, act_dtype=torch.bfloat16, use_dora=False, **step_kw):
     import sd_lora_trainer_amd.clip as clip_mod
     import sd_lora_trainer_amd.step as step_mod
     import sd_lora_trainer_amd.unet as unet_mod
     from sd_lora_trainer_amd import topology
     xl = topology.CONFIGS[version]["addition"]
     rt = unet_mod.Runtime(device, B, act_dtype=act_dtype, ops=ops)
-    unet = unet_mod.UNet(rt, topology.CONFIGS[version], sd, lora_rank=rank)
+    unet = unet_mod.UNet(rt, topology.CONFIGS[version], sd, lora_rank=rank, use_dora=use_dora)
     unet.arena.load(lora)
     text = None
     if hf is not None:
@@ -164,8 +164,9 @@ TOL_BF16 = dict(pred=4e-2, loss=3e-2, ta=5e-2, reg=5e-2, cos=0.99, rel=8e-2, row
 TOL_FP32 = dict(pred=2e-3, loss=1e-3, ta=2e-3, reg=2e-3, cos=0.9999, rel=5e-3, rows_cos=0.9999, disp_cos=0.99, rows_final=1e-3)
 
 
-def run_step_and_trajectory(version, B, h, sd, kinds, *, device, ops=None, act_dtype=torch.bfloat16, tol=TOL_BF16, rank=16, n_steps=6):
-    """(a) + (b) for one topology; shared with the CPU test of the same flow on the toy topologies (op emulation, fp32)."""
+def run_step_and_trajectory(version, B, h, sd, kinds, *, device, ops=None, act_dtype=torch.bfloat16, tol=TOL_BF16, rank=16, n_steps=6, dora=False):
+    """(a) + (b) for one topology; shared with the CPU test of the same flow on the toy topologies (op emulation, fp32).
+    dora: weight-decomposed adapters (use_dora: magnitudes trained too, no L1 penalty / weight decay, config.py:153-157)."""
     from oracle import step_ref as R
     from oracle import unet_ref as U
     from sd_lora_trainer_amd import topology
@@ -175,15 +176,18 @@ def run_step_and_trajectory(version, B, h, sd, kinds, *, device, ops=None, act_d
     lr, lr_ti = 4e-4, 1e-3
     vc = Vocab(topology.CLIP_CONFIGS[kinds[0]]["vocab"])
     lora = U.init_lora(cfg, rank, seed=1, b_std=0.02)
+    l1, wd = (0.0, 0.0) if dora else (0.03, 0.004)
+    if dora:        # magnitudes = the weight norms at injection, perturbed so that the column factor differs from 1
+        lora = U.init_dora_magnitudes(cfg, sd, lora, jitter=0.05, seed=5)
     hf = [_hf_clip(k, 11 + i) for i, k in enumerate(kinds)]
     batches = [_batch(cfg, B, h, 3, [10, 900, 500, 999], vc), _batch(cfg, B, h, 4, [700, 50, 300, 850], vc)]
     cuda = torch.device(device).type == "cuda"
     sync = torch.cuda.synchronize if cuda else (lambda: None)
 
-    rt, unet, ts = _build_product(version, B, h, sd, lora, hf, rank, kinds=kinds, device=device, ops=ops, act_dtype=act_dtype, snr_gamma=5.0,
-                                  l1_penalty=0.03, weight_decay=0.004, token_attention_loss_w=w_ta, ti_std_loss_w=0.01)
-    ref = R.RefTrainer(cfg, sd, lora, text_models=hf, n_tokens=NTOK, train_ids=vc.train_ids, snr_gamma=5.0, l1_penalty=0.03,
-                       weight_decay=0.004, token_attention_loss_w=w_ta, ti_std_loss_w=0.01)
+    rt, unet, ts = _build_product(version, B, h, sd, lora, hf, rank, kinds=kinds, device=device, ops=ops, act_dtype=act_dtype, use_dora=dora, snr_gamma=5.0,
+                                  l1_penalty=l1, weight_decay=wd, token_attention_loss_w=w_ta, ti_std_loss_w=0.01)
+    ref = R.RefTrainer(cfg, sd, lora, text_models=hf, n_tokens=NTOK, train_ids=vc.train_ids, snr_gamma=5.0, l1_penalty=l1,
+                       weight_decay=wd, token_attention_loss_w=w_ta, ti_std_loss_w=0.01)
     names = list(lora)
     n_enc = len(hf)
     traj = []
@@ -201,6 +205,14 @@ def run_step_and_trajectory(version, B, h, sd, kinds, *, device, ops=None, act_d
             got = unet.arena.export("grads")
             cos, rel = _cos_rel(torch.cat([t.reshape(-1) for k in names for t in got[k]]), o["lora_grads"])
             assert cos >= tol["cos"] and rel <= tol["rel"], f"LoRA grads cos {cos} rel {rel}"
+            if dora:        # the magnitude gradients on their own (a small share of the flat vector above)
+                gm_ref, off = [], 0
+                for k in names:
+                    nA, nB, nM = (t.numel() for t in lora[k])
+                    gm_ref.append(o["lora_grads"][off + nA + nB: off + nA + nB + nM])
+                    off += nA + nB + nM
+                cos, rel = _cos_rel(torch.cat([got[k][2].reshape(-1) for k in names]), torch.cat(gm_ref))
+                assert cos >= tol["cos"] and rel <= tol["rel"], f"DoRA magnitude grads cos {cos} rel {rel}"
             for got_r, ref_r in zip(ts.ti.grad_rows, o["row_grads"]):
                 cos, rel = _cos_rel(got_r, ref_r)
                 assert cos >= tol["rows_cos"], f"token-row grads cos {cos} rel {rel}"
@@ -213,16 +225,16 @@ def run_step_and_trajectory(version, B, h, sd, kinds, *, device, ops=None, act_d
             ts.run(lr, lr_ti=lr_ti)
         sync()
         traj.append((float(ts.loss), o["img_loss"], float(ts.ta.loss), o["token_attention_loss"], float(ts.ti.reg_loss), o["reg"],
-                     float(ts.l1_sum) / unet.arena.n, o["l1"]))
+                     float(ts.l1_sum) / unet.arena.n, o.get("l1", 0.0)))
     for i, (l, lo, ta, tao, rg, rgo, l1, l1o) in enumerate(traj):
         assert abs(l - lo) <= tol["loss"] * abs(lo), f"step {i}: image loss {l} vs oracle {lo}; trajectory {traj}"
         assert abs(ta - tao) <= tol["ta"] * abs(tao), f"step {i}: token-attention loss {ta} vs {tao}; {traj}"
         assert abs(rg - rgo) <= tol["reg"] * abs(rgo) + 1e-7, f"step {i}: token regulariser {rg} vs {rgo}; {traj}"
-        assert abs(l1 - l1o) <= 1e-3 * abs(l1o), f"step {i}: L1 norm {l1} vs {l1o}"
+        assert dora or abs(l1 - l1o) <= 1e-3 * abs(l1o), f"step {i}: L1 norm {l1} vs {l1o}"
     # training moved the loss of the revisited batches (so the comparison above is not a comparison of constants)
     assert traj[n_steps - 2][1] < traj[0][1] and traj[n_steps - 1][1] < traj[1][1], traj
     # final state: the LoRA displacement and the token rows agree with the oracle's
-    start = torch.cat([t.reshape(-1) for k in names for t in lora[k]])
+    start = torch.cat([t.reshape(-1).float() for k in names for t in lora[k]])
     got = unet.arena.export("params")
     cos, rel = _cos_rel(torch.cat([t.reshape(-1) for k in names for t in got[k]]) - start, ref.lora_flat() - start)
     assert cos >= tol["disp_cos"], f"LoRA displacement after {n_steps} AdamW steps: cos {cos} rel {rel}"
@@ -232,14 +244,14 @@ def run_step_and_trajectory(version, B, h, sd, kinds, *, device, ops=None, act_d
     return traj
 
 
-def _case_step_and_trajectory(version, B):
+def _case_step_and_trajectory(version, B, dora=False):
     """(a) + (b): first step in detail, then 5 more optimizer steps; batches alternate between two injected ones so that the
     effect of training on a revisited batch is part of what is compared."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from oracle import unet_ref as U
     kinds = ["clip_l", "clip_g"] if U.CONFIGS[version]["addition"] else ["clip_l"]
-    run_step_and_trajectory(version, B, 32, _unet_state(version), kinds, device="cuda:0")
+    run_step_and_trajectory(version, B, 32, _unet_state(version), kinds, device="cuda:0", dora=dora)
 
 
 def _case_full_size_properties(version, B, h):
@@ -340,10 +352,13 @@ def _case_fullft_real_sdxl_topology():
 
 
 # Ordered so that each 10 GB weight state is built once: all SDXL cases, then all SD1.5 cases.
-@pytest.mark.parametrize("case", ["sdxl-step-trajectory", "sdxl-full-size", "sdxl-fullft-gradients", "sd15-step-trajectory", "sd15-full-size"])
+@pytest.mark.parametrize("case", ["sdxl-step-trajectory", "sdxl-dora-step-trajectory", "sdxl-full-size", "sdxl-fullft-gradients", "sd15-step-trajectory",
+                                  "sd15-full-size"])
 def test_real_topology(case):
     if case == "sdxl-step-trajectory":
         _case_step_and_trajectory("sdxl", 1)
+    elif case == "sdxl-dora-step-trajectory":      # use_dora on all 577 adapted layers (the hyper-parameter sweep's variant, create_hyperparam_sweep.py:77)
+        _case_step_and_trajectory("sdxl", 1, dora=True)
     elif case == "sdxl-full-size":
         _case_full_size_properties("sdxl", 1, 128)
     elif case == "sdxl-fullft-gradients":

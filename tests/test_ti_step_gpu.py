@@ -301,3 +301,15 @@ def test_optional_regularisers_gpu_match_oracle(version):
     from sd_lora_trainer_amd import ops
     from tests.test_ti_step_cpu import run_optional_regularisers
     run_optional_regularisers(version, "cuda:0", ops, torch.bfloat16, rel_val=4e-3, rel_grad=4e-2)
+
+
+@pytest.mark.parametrize("version,B,kinds,rank", [("tiny15", 2, ["tiny_l"], 4), ("tinyxl", 1, ["tiny_l", "tiny_g"], 16), ("tinyxl", 2, ["tiny_l", "tiny_g"], 24)])
+def test_dora_step_and_trajectory_gpu(version, B, kinds, rank):
+    """use_dora (peft weight-decomposed adapters, optimizer.py:86-95) on the HIP path: first step (prediction, A / B / magnitude
+    gradients, token rows) and a 6-step AdamW trajectory under hipGraph replay against the fp32 oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import unet_ref as U
+    from tests.test_real_topology_gpu import TOL_BF16, _bf16_exact, run_step_and_trajectory
+    sd = _bf16_exact(U.init_unet_state(U.CONFIGS[version], seed=0))
+    run_step_and_trajectory(version, B, 32 if U.CONFIGS[version]["addition"] else 16, sd, kinds, device="cuda:0", tol=TOL_BF16, rank=rank, n_steps=6, dora=True)

@@ -17,3 +17,11 @@ def test_trajectory_cpu(version, B, kinds):
     traj = run_step_and_trajectory(version, B, 32 if U.CONFIGS[version]["addition"] else 16, sd, kinds, device="cpu", ops=emu_ops,
                                    act_dtype=torch.float32, tol=TOL_FP32, rank=4, n_steps=6)
     assert len(traj) == 6
+
+
+@pytest.mark.parametrize("version,B,kinds", [("tiny15", 2, ["tiny_l"]), ("tinyxl", 1, ["tiny_l", "tiny_g"])])
+def test_trajectory_dora_cpu(version, B, kinds):
+    """use_dora (optimizer.py:86-95): magnitudes, column factor, scaled backward operands and the magnitude gradient through the same flow."""
+    sd = _bf16_exact(U.init_unet_state(U.CONFIGS[version], seed=0))
+    run_step_and_trajectory(version, B, 32 if U.CONFIGS[version]["addition"] else 16, sd, kinds, device="cpu", ops=emu_ops,
+                            act_dtype=torch.float32, tol=TOL_FP32, rank=4, n_steps=6, dora=True)
