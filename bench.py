@@ -218,6 +218,7 @@ def main():
     ap.add_argument("--res", type=int, default=0, help="image resolution (default 1024 for sdxl, 512 for sd15)")
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--rank", type=int, default=16)
+    ap.add_argument("--dora", action="store_true", help="weight-decomposed adapters (use_dora: trained magnitudes, no L1 penalty / weight decay, config.py:153-157)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-ti", action="store_true", help="inject the text conditioning instead of running the text encoders + TI")
@@ -271,7 +272,7 @@ def main():
             arena = trainer
         else:
             sd = make_state(cfg, device, seed=seed)    # every rank = its own independent job
-            unet = M.UNet(rt, cfg, sd, lora_rank=args.rank)
+            unet = M.UNet(rt, cfg, sd, lora_rank=args.rank, use_dora=args.dora)
             arena = unet.arena
             for e in arena.entries:   # peft "gaussian" init: A ~ N(0, 1/r), B = 0 at step 0 (optimizer.py:89)
                 e["A"].copy_(torch.randn(e["A"].shape, generator=g, device=device) / args.rank)
@@ -295,7 +296,7 @@ def main():
                 clip_flops += topology.clip_fwd_flops(c, B, layers_run=enc.n_run)
                 del csd
             text = S.TextStack(rt, encs, pool_mode="argmax")
-        ts = S.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, l1_penalty=0.03, weight_decay=0.004, text=text, n_tokens=n_tok,
+        ts = S.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, l1_penalty=0.0 if args.dora else 0.03, weight_decay=0.0 if args.dora else 0.004, text=text, n_tokens=n_tok,
                          process_group=True if (full_ft and world > 1) else None)
         rn = lambda *s: torch.randn(*s, generator=g, device=device)  # noqa: E731
         latent = rn(B, 4, h, h) * cfg["scaling_factor"]
@@ -397,8 +398,9 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": (f"{version} {res}x{res} FULL-UNet fine-tune batch {B}/GPU: UNet fwd + bwd (dX and every dW), masked/min-SNR MSE, "
                                     f"AdamW over {arena.n / 1e6:.0f} M parameters, bf16 operand refresh" if full_ft else
-                                    f"{version} {res}x{res} LoRA rank {args.rank} batch {B}" + ("/GPU" if J == 1 else f" per job, {J} concurrent jobs/GPU")
-                                    + ": UNet fwd+bwd, masked/min-SNR MSE, L1, AdamW")
+                                    f"{version} {res}x{res} {'DoRA' if args.dora else 'LoRA'} rank {args.rank} batch {B}" + ("/GPU" if J == 1 else f" per job, {J} concurrent jobs/GPU")
+                                    + (": UNet fwd+bwd, masked/min-SNR MSE, AdamW (adapters + magnitudes; per-step weight-norm / scaled-operand refresh)" if args.dora
+                                       else ": UNet fwd+bwd, masked/min-SNR MSE, L1, AdamW"))
                                    + (", + textual inversion (text encoders fwd+bwd with 3 trainable tokens, token-attention loss, "
                                       "std regulariser, rows-only AdamW)" + (" [ti lr = 0: frozen-TI fast path, no text-encoder backward]" if args.ti_frozen else "") if text is not None else ", text conditioning injected (--no-ti)"),
                        "text_encoder_fwd_gflop_not_in_roofline": clip_flops / 1e9,

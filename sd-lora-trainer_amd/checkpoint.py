@@ -11,6 +11,8 @@ The peft -> diffusers -> kohya key conversion the reference delegates to diffuse
 peft `base_model.model.<path>.lora_A.weight` -> kohya `lora_unet_<path_>.lora_down.weight`, with the reference's own
 `base_model_model_` strip (checkpoint.py:93-100); alpha follows diffusers' `convert_state_dict_to_kohya`
 (= number of rows of lora_down, i.e. the rank) [3P-unverified, SURVEY.md 8f-1].
+DoRA (use_dora): peft's `lora_magnitude_vector` leaves as `<key>.dora_scale` in the parameter's own shape ([Cout] / [1, Cout, 1, 1]),
+the name diffusers' convert_state_dict_to_kohya and the kohya / ComfyUI loaders use for it [3P-unverified, diffusers 0.29.2].
 """
 import json
 import os
@@ -36,13 +38,15 @@ def kohya_text_key(module_path: str) -> str:
 
 
 def lora_to_kohya(lora_dict, dtype=torch.float16, key=kohya_key):
-    """lora_dict: module -> (A, B) in peft layout (LoraArena.export()).  Returns the kohya state dict."""
+    """lora_dict: module -> (A, B) or (A, B, magnitude) in peft layout (LoraArena.export()).  Returns the kohya state dict."""
     sd = {}
-    for mod, (A, B) in lora_dict.items():
+    for mod, (A, B, *m) in lora_dict.items():
         k = key(mod)
         sd[k + ".lora_down.weight"] = A.detach().to(dtype).contiguous()
         sd[k + ".lora_up.weight"] = B.detach().to(dtype).contiguous()
         sd[k + ".alpha"] = torch.tensor(float(A.shape[0]))
+        if m:
+            sd[k + ".dora_scale"] = m[0].detach().to(dtype).contiguous()
     return sd
 
 
@@ -52,7 +56,7 @@ def kohya_to_lora(sd):
     for k in sd:
         if k.endswith(".lora_down.weight"):
             base = k[: -len(".lora_down.weight")]
-            out[base] = (sd[k].float(), sd[base + ".lora_up.weight"].float())
+            out[base] = (sd[k].float(), sd[base + ".lora_up.weight"].float()) + ((sd[base + ".dora_scale"].float(),) if base + ".dora_scale" in sd else ())
     return out
 
 
@@ -78,7 +82,7 @@ def save_checkpoint(output_dir, global_step, arena, ti_rows, token_dict, name, p
         # adapter_config.json (peft `save_pretrained`, checkpoint.py:175) - the fields the reference's loader reads
         with open(os.path.join(output_dir, "adapter_config.json"), "w") as f:
             json.dump({"peft_type": "LORA", "r": arena.rank, "lora_alpha": arena.rank * arena.scale, "init_lora_weights": "gaussian",
-                       "target_modules": ["to_k", "to_q", "to_v", "to_out.0", "conv2"], "use_dora": False}, f, indent=2)
+                       "target_modules": ["to_k", "to_q", "to_v", "to_out.0", "conv2"], "use_dora": bool(getattr(arena, "dora", False))}, f, indent=2)
     if unet_weights is not None:
         # is_lora == False (checkpoint.py:210-212): `unet.save_pretrained(output_dir)` = the whole fine-tuned UNet under its
         # diffusers parameter names in diffusion_pytorch_model.safetensors
@@ -95,6 +99,7 @@ def load_embeddings(path, txt_encoder_keys=("clip_l", "clip_g")):
 
 
 def load_lora(path, targets):
-    """-> module -> (A, B) for the given module paths (topology.lora_targets)."""
+    """-> module -> (A, B) (or (A, B, magnitude) for a DoRA file) for the given module paths (topology.lora_targets)."""
     sd = load_file(path)
-    return {m: (sd[kohya_key(m) + ".lora_down.weight"].float(), sd[kohya_key(m) + ".lora_up.weight"].float()) for m in targets}
+    return {m: (sd[kohya_key(m) + ".lora_down.weight"].float(), sd[kohya_key(m) + ".lora_up.weight"].float())
+            + ((sd[kohya_key(m) + ".dora_scale"].float(),) if kohya_key(m) + ".dora_scale" in sd else ()) for m in targets}

@@ -76,7 +76,7 @@ class LatentSampler:
         if a is not None:
             if not hasattr(a, "_train_scale"):
                 a._train_scale = a.scale if train_scale is None else train_scale
-            a.scale = a._train_scale * lora_scale
+            a.set_scale(a._train_scale * lora_scale)      # (DoRA: the column factors follow the scale in effect)
 
     @torch.no_grad()
     def sample(self, embeds, h, w, *, steps=25, guidance_scale=8.0, generator=None, size=None, latents=None):

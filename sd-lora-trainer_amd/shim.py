@@ -98,8 +98,8 @@ class _UNetFn(torch.autograd.Function):
             P = u.cfg["proj_class_in"] - 6 * u.cfg["addition_time_embed_dim"]
             g_te = u.dadd_in[:, :P].to(ctx.te_dtype).clone()
         grads = []
-        for e in u.arena.entries:       # same order as UNetModule.parameters(): A then B of every adapted layer
-            grads += [e["gA"].clone(), e["gB"].clone()]
+        for e in u.arena.entries:       # same order as UNetModule.parameters(): A then B (then the DoRA magnitude) of every adapted layer
+            grads += [e["gA"].clone(), e["gB"].clone()] + ([e["gM"].clone()] if u.arena.dora else [])
         return (None, None, None, g_ehs, g_te, None, *grads)
 
 
@@ -110,21 +110,19 @@ class UNetModule:
         cfg = topology.CONFIGS[version_or_cfg] if isinstance(version_or_cfg, str) else version_or_cfg
         self.rt = runtime or Runtime(device, batch_size)
         lc = lora_config or LoraConfig()
-        if lc.use_dora:
-            raise NotImplementedError("DoRA adapters are not built in this engine")
         assert sorted(lc.target_modules) == sorted(["to_k", "to_q", "to_v", "to_out.0", "conv2"]), "the fused kernels adapt the reference's target set"
         self.peft_config = lc
-        self.unet = UNet(self.rt, cfg, state_dict, lora_rank=lc.r, lora_alpha_multiplier=lc.lora_alpha / lc.r)
+        self.unet = UNet(self.rt, cfg, state_dict, lora_rank=lc.r, lora_alpha_multiplier=lc.lora_alpha / lc.r, use_dora=lc.use_dora)
         self.config = dict(cfg)
         self.keep_daam_maps = False
         hooked = [a for a in self.unet.cross_attns if a.hooked]
         self.daam_processors = [DAAMScores(a.name + ".processor") for a in hooked]
         self._params, self._names = [], []
         for e in self.unet.arena.entries:
-            for key, nm in (("A", "lora_A"), ("B", "lora_B")):
+            for key, nm in (("A", "lora_A.weight"), ("B", "lora_B.weight")) + ((("M", "lora_magnitude_vector"),) if lc.use_dora else ()):
                 p = torch.nn.Parameter(e[key], requires_grad=True)      # shares storage with the arena's fp32 master
                 self._params.append(p)
-                self._names.append(f"base_model.model.{e['name']}.{nm}.weight")
+                self._names.append(f"base_model.model.{e['name']}.{nm}")
         self._dirty, self._bufs = True, {}
 
     # ---- nn.Module-shaped surface ------------------------------------------------------------------------------------
@@ -188,9 +186,11 @@ class UNetModule:
     def get_peft_model_state_dict(self):
         """peft.get_peft_model_state_dict: {base_model.model.<path>.lora_A.weight: [r, Cin(,3,3)], ...lora_B.weight: [Cout, r(,1,1)]}."""
         out = {}
-        for name, (A, B) in self.unet.arena.export().items():
+        for name, (A, B, *m) in self.unet.arena.export().items():
             out[f"base_model.model.{name}.lora_A.weight"] = A
             out[f"base_model.model.{name}.lora_B.weight"] = B
+            if m:
+                out[f"base_model.model.{name}.lora_magnitude_vector"] = m[0]
         return out
 
     def save_pretrained(self, output_dir):

@@ -103,7 +103,7 @@ class Models:
         if self.synthetic:
             sd = _random_state(topology.param_shapes(cfg), rt.device, seed=config.seed)
         if config.is_lora:
-            self.unet = M.UNet(rt, cfg, sd, lora_rank=config.lora_rank, lora_alpha_multiplier=config.lora_alpha_multiplier)
+            self.unet = M.UNet(rt, cfg, sd, lora_rank=config.lora_rank, lora_alpha_multiplier=config.lora_alpha_multiplier, use_dora=config.use_dora)
         else:                          # main.py:144-149: full fine-tune, every UNet parameter trained
             from . import fullft
             self.unet = M.UNet(rt, cfg, sd, trainer=fullft.WeightTrainer(rt))
@@ -276,7 +276,8 @@ class Renderer:
         cfg = models.cfg
         dev = models.rt.device
         self.rt = M.Runtime(dev, 2)
-        self.unet = M.UNet(self.rt, cfg, models.unet_state(), lora_rank=config.lora_rank, lora_alpha_multiplier=config.lora_alpha_multiplier)
+        self.unet = M.UNet(self.rt, cfg, models.unet_state(), lora_rank=config.lora_rank, lora_alpha_multiplier=config.lora_alpha_multiplier,
+                           use_dora=config.use_dora)
         self.sampler = SM.LatentSampler(self.rt, self.unet)
         self.decoder = V.VaeDecoder(M.Runtime(dev, 1), models.vae_state())
         xl = bool(cfg["addition"])
@@ -352,7 +353,7 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
     optimizer call, so that several jobs can be advanced in lock-step by train_concurrent."""
     from . import step as S
     from . import unet as M
-    for flag, what in ((config.use_dora, "use_dora (DoRA adapters)"),
+    for flag, what in ((config.use_dora and config.text_encoder_lora_optimizer is not None, "use_dora on the text-encoder adapters"),
                        (config.aspect_ratio_bucketing, "aspect_ratio_bucketing (broken in the reference as well, README.md:76)")):
         if flag:
             raise NotImplementedError(f"{what} is not built in this engine; refusing to train something else silently")

@@ -109,7 +109,7 @@ def test_train_from_folder_with_tokenizer(tmp_path, monkeypatch, version, disabl
         assert set(emb) == {"clip_l", "clip_g"} and not torch.equal(emb["clip_l"], e0["clip_l"])     # the token rows were trained
 
 
-@pytest.mark.parametrize("kw", [dict(use_dora=True), dict(aspect_ratio_bucketing=True), dict(tok_cond_reg_w=0.1, text_encoder_lora_optimizer="adamw")])
+@pytest.mark.parametrize("kw", [dict(use_dora=True, text_encoder_lora_optimizer="adamw"), dict(aspect_ratio_bucketing=True), dict(tok_cond_reg_w=0.1, text_encoder_lora_optimizer="adamw")])
 def test_unbuilt_fields_raise(tmp_path, monkeypatch, kw):
     monkeypatch.chdir(tmp_path)
     from sd_lora_trainer_amd import train as T
@@ -132,3 +132,31 @@ def test_real_unet_without_text_encoder_weights_is_an_error(tmp_path, monkeypatc
     monkeypatch.setitem(topology.CONFIGS, "sd15", topology.CONFIGS["tiny15"])
     with pytest.raises(ValueError, match="text_encoder_path"):
         next(T.train(cfg, runtime=unet_mod.Runtime("cpu", 1, act_dtype=torch.float32, ops=emu_ops)))
+
+
+@pytest.mark.parametrize("version", ["tiny15", "tinyxl"])
+def test_train_with_dora(tmp_path, monkeypatch, version):
+    """use_dora=True (optimizer.py:86-95; the hyper-parameter sweep's variant, create_hyperparam_sweep.py:77): the L1 penalty and the
+    weight decay are switched off (config.py:153-157), the magnitudes are trained and leave as `dora_scale` next to down / up / alpha."""
+    monkeypatch.chdir(tmp_path)
+    from safetensors.torch import load_file
+    from sd_lora_trainer_amd import train as T
+    from sd_lora_trainer_amd.checkpoint import kohya_to_lora
+    cfg = TrainingConfig(lora_training_urls="synthetic:4", concept_mode="object", pretrained_model={"path": f"synthetic:{version}"}, seed=1,
+                         resolution=256 if version == "tinyxl" else 128, train_batch_size=2, max_train_steps=6, lora_rank=4, unet_lr=2e-3, ti_lr=1e-3, use_dora=True)
+    assert cfg.l1_penalty == 0.0 and cfg.lora_weight_decay == 0.0
+    rt = unet_mod.Runtime("cpu", 2, act_dtype=torch.float32, ops=emu_ops)
+    _, (config, out_dir) = _run(T.train(cfg, runtime=rt))
+    name = [n for n in os.listdir(out_dir) if n.endswith("_lora.safetensors")][0]
+    sd = load_file(os.path.join(out_dir, name))
+    lora = kohya_to_lora(sd)
+    assert lora and all(len(v) == 3 for v in lora.values())
+    conv = [k for k in lora if k.endswith("conv2")]
+    lin = [k for k in lora if k.endswith("to_q")]
+    assert lora[conv[0]][2].dim() == 4 and lora[conv[0]][2].shape[1] == lora[conv[0]][1].shape[0]      # [1, Cout, 1, 1]
+    assert lora[lin[0]][2].shape == (lora[lin[0]][1].shape[0],)
+    assert all(float(v[2].min()) > 0 for v in lora.values())
+    assert json.load(open(os.path.join(out_dir, "adapter_config.json")))["use_dora"] is True
+    e0 = kohya_to_lora(load_file(os.path.join(os.path.dirname(out_dir), "checkpoint-0", name))) if os.path.basename(out_dir) != "checkpoint-0" else None
+    if e0 is not None:
+        assert any(not torch.equal(e0[k][2], lora[k][2]) for k in lora)       # the magnitudes moved
