@@ -113,7 +113,7 @@ class Models:
         if config.text_encoder_lora_optimizer is not None:
             if config.disable_ti:
                 raise NotImplementedError("text-encoder LoRA without textual inversion: the step's text stack is only built for TI runs")
-            te_arena = M.LoraArena(rt, config.text_encoder_lora_rank, config.lora_alpha_multiplier, problems=[])      # a21
+            te_arena = M.LoraArena(rt, config.text_encoder_lora_rank, config.lora_alpha_multiplier, problems=[], dora=config.use_dora)      # a21
         self.encoders = []
         for i, kd in enumerate(self.kinds):
             c = topology.CLIP_CONFIGS[kd]
@@ -353,8 +353,7 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
     optimizer call, so that several jobs can be advanced in lock-step by train_concurrent."""
     from . import step as S
     from . import unet as M
-    for flag, what in ((config.use_dora and config.text_encoder_lora_optimizer is not None, "use_dora on the text-encoder adapters"),
-                       (config.aspect_ratio_bucketing, "aspect_ratio_bucketing (broken in the reference as well, README.md:76)")):
+    for flag, what in ((config.aspect_ratio_bucketing, "aspect_ratio_bucketing (broken in the reference as well, README.md:76)")):
         if flag:
             raise NotImplementedError(f"{what} is not built in this engine; refusing to train something else silently")
     rank, world = _rank_world()

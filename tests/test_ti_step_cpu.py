@@ -121,8 +121,9 @@ def test_ti_step_matches_oracle(version, B):
         torch.testing.assert_close(enc.table[-NTOK:].float(), p, rtol=1e-5, atol=1e-7)    # gathered table was refreshed
 
 
-@pytest.mark.parametrize("version,B,rank", [("tiny15", 2, 4), ("tinyxl", 1, 16), ("tiny15", 1, 24)])     # rank 24: member-wise dX of q|k|v
-def test_text_encoder_lora_matches_oracle(version, B, rank):
+@pytest.mark.parametrize("version,B,rank,dora", [("tiny15", 2, 4, False), ("tinyxl", 1, 16, False), ("tiny15", 1, 24, False),     # rank 24: member-wise dX of q|k|v
+                                                 ("tinyxl", 1, 16, True), ("tiny15", 2, 24, True)])
+def test_text_encoder_lora_matches_oracle(version, B, rank, dora):
     """a21 (`text_encoder_lora_optimizer`, trainer/optimizer.py:157-202): peft LoRA on q/k/v/out_proj of every text-encoder
     layer, trained by its own AdamW next to TI and the UNet LoRA.  Oracle: Hugging Face CLIP called functionally with
     W + (alpha/r) B A in place of the four projection weights, autograd for dA / dB."""
@@ -149,7 +150,7 @@ def test_text_encoder_lora_matches_oracle(version, B, rank):
     rt = unet_mod.Runtime("cpu", B, act_dtype=torch.float32, ops=emu_ops)
     unet = unet_mod.UNet(rt, topology.CONFIGS[version], sd, lora_rank=4)
     unet.arena.load(lora)
-    te_arena = unet_mod.LoraArena(rt, rank, 1.0, problems=[])
+    te_arena = unet_mod.LoraArena(rt, rank, 1.0, problems=[], dora=dora)      # dora: use_dora reaches the text-encoder adapters too (optimizer.py:157-165)
     sds = [{k: v.detach() for k, v in m.state_dict().items()} for m in hf]
     prefixes = ["text_encoder.", "text_encoder_2."]
     kw = [dict(heads=1, act="quick_gelu", mode="penultimate", with_projection=False), dict(heads=1, act="gelu", mode="penultimate", with_projection=True)] \
@@ -158,6 +159,12 @@ def test_text_encoder_lora_matches_oracle(version, B, rank):
     te_arena.finalize()
     gl = torch.Generator().manual_seed(21)
     te_lora = {e["name"]: (torch.randn(rank, e["K"], generator=gl) / rank, torch.randn(e["N"], rank, generator=gl) * 0.05) for e in te_arena.entries}
+    if dora:       # magnitudes: the weight norm of the merged matrix, perturbed so that the column factor is not 1
+        for i_, pre in enumerate(prefixes[:len(hf)]):
+            for name, (A, Bm, *_) in list(te_lora.items()):
+                if name.startswith(pre) and not (i_ == 0 and name.startswith(prefixes[1])):
+                    w = sds[i_][name[len(pre):] + ".weight"]
+                    te_lora[name] = (A, Bm, (w + te_arena.scale * Bm @ A).norm(dim=1) * (1.0 + 0.05 * torch.randn(w.shape[0], generator=gl)))
     te_arena.load(te_lora)
     n_layers_run = [3 if (not xl or i == 1) else 2 for i in range(len(hf))]            # SDXL CLIP-L: the last layer feeds nothing
     assert len(te_arena.entries) == 4 * sum(n_layers_run)
@@ -171,14 +178,21 @@ def test_text_encoder_lora_matches_oracle(version, B, rank):
     te_g, te_params, outs = {}, [], []
     for i, m in enumerate(hf):
         over = {}
-        for name, (A, Bm) in te_lora.items():
+        for name, (A, Bm, *mag) in te_lora.items():
             if not name.startswith(prefixes[i]) or (i == 0 and name.startswith(prefixes[1])):
                 continue
             A, Bm = A.clone().requires_grad_(True), Bm.clone().requires_grad_(True)
-            te_g[name] = (A, Bm)
-            te_params += [A, Bm]
             key = name[len(prefixes[i]):] + ".weight"
-            over[key] = sds[i][key] + te_arena.scale * Bm @ A
+            merged = sds[i][key] + te_arena.scale * Bm @ A
+            if dora:      # peft _apply_dora, merged form: rows scaled by m / ||W + s B A|| (norm detached); the bias is not scaled
+                mg = mag[0].clone().requires_grad_(True)
+                te_g[name] = (A, Bm, mg)
+                te_params += [A, Bm, mg]
+                merged = (mg / merged.norm(dim=1).detach())[:, None] * merged
+            else:
+                te_g[name] = (A, Bm)
+                te_params += [A, Bm]
+            over[key] = merged
         outs.append(functional_call(m, over, kwargs=dict(input_ids=ids, output_hidden_states=True)))
     embs = [m.get_input_embeddings().weight for m in hf]
     if xl:
@@ -198,8 +212,9 @@ def test_text_encoder_lora_matches_oracle(version, B, rank):
     assert set(got) == set(te_g)
     gmax = max(float(x.abs().max()) for x in grads[:len(te_params)])
     assert gmax > 0
+    npt = 3 if dora else 2
     for i, name in enumerate(te_g):
-        for a, b_ in zip(got[name], (grads[2 * i], grads[2 * i + 1])):
+        for a, b_ in zip(got[name], grads[npt * i: npt * i + npt]):
             assert float((a - b_).abs().max()) <= 3e-3 * float(b_.abs().max()) + 1e-6 * gmax, (name, float((a - b_).abs().max()), float(b_.abs().max()))
     for got_r, ref in zip(ts.ti.grad_rows, [ge[-NTOK:] for ge in grads[len(te_params):]]):
         assert float((got_r - ref).abs().max()) <= 3e-3 * float(ref.abs().max())

@@ -133,8 +133,8 @@ def test_ti_step_gpu_matches_oracle(version, B, concurrent):
         assert ts._cond_cached and dl <= 1e-6 and dp <= 1e-7, f"cached conditioning: loss rel diff {dl}, max parameter diff {dp} (lr 1e-3)"
 
 
-@pytest.mark.parametrize("version,B,rank", [("tiny15", 2, 16), ("tinyxl", 2, 8)])
-def test_text_encoder_lora_gpu_matches_oracle(version, B, rank):
+@pytest.mark.parametrize("version,B,rank,dora", [("tiny15", 2, 16, False), ("tinyxl", 2, 8, False), ("tinyxl", 2, 16, True), ("tiny15", 2, 24, True)])
+def test_text_encoder_lora_gpu_matches_oracle(version, B, rank, dora):
     """a21: LoRA on q/k/v/out_proj of the text encoders (trainer/optimizer.py:157-202) on the HIP path - fused into the
     stacked q|k|v GEMM (N-grouped forward, K-grouped dX) and the out_proj GEMM - against autograd through Hugging Face
     CLIP with merged projections; then graph replays with all three optimizers live."""
@@ -169,7 +169,7 @@ def test_text_encoder_lora_gpu_matches_oracle(version, B, rank):
     rt = unet_mod.Runtime("cuda:0", B)
     unet = unet_mod.UNet(rt, topology.CONFIGS[version], sd, lora_rank=4)
     unet.arena.load(lora)
-    te_arena = unet_mod.LoraArena(rt, rank, 1.0, problems=[])
+    te_arena = unet_mod.LoraArena(rt, rank, 1.0, problems=[], dora=dora)        # dora: use_dora on the text-encoder adapters (optimizer.py:157-165)
     sds = [{k: v.detach() for k, v in m.state_dict().items()} for m in hf]
     prefixes = ["text_encoder.", "text_encoder_2."]
     kw = [dict(heads=1, act="quick_gelu", mode="penultimate", with_projection=False), dict(heads=1, act="gelu", mode="penultimate", with_projection=True)] \
@@ -179,6 +179,12 @@ def test_text_encoder_lora_gpu_matches_oracle(version, B, rank):
     gl = torch.Generator().manual_seed(21)
     bf = lambda x: x.to(torch.bfloat16).float()  # noqa: E731  (the compute copies are bf16)
     te_lora = {e["name"]: (bf(torch.randn(rank, e["K"], generator=gl) / rank), bf(torch.randn(e["N"], rank, generator=gl) * 0.05)) for e in te_arena.entries}
+    if dora:
+        for i_, pre in enumerate(prefixes[:len(hf)]):
+            for name, (A, Bm, *_) in list(te_lora.items()):
+                if name.startswith(pre):
+                    w = sds[i_][name[len(pre):] + ".weight"]
+                    te_lora[name] = (A, Bm, (w + te_arena.scale * Bm @ A).norm(dim=1) * (1.0 + 0.05 * torch.randn(w.shape[0], generator=gl)))
     te_arena.load(te_lora)
     text = step_mod.TextStack(rt, encs, pool_mode="first_eos", eos_token_id=EOS, arena=te_arena)
     ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, l1_penalty=0.0, weight_decay=0.0, text=text, n_tokens=NTOK,
@@ -191,14 +197,19 @@ def test_text_encoder_lora_gpu_matches_oracle(version, B, rank):
     te_params, names, outs = [], [], []
     for i, m in enumerate(hf):
         over = {}
-        for name, (A, Bm) in te_lora.items():
+        for name, (A, Bm, *mag) in te_lora.items():
             if not name.startswith(prefixes[i]):
                 continue
             A, Bm = A.clone().requires_grad_(True), Bm.clone().requires_grad_(True)
             te_params += [A, Bm]
             names.append(name)
             key = name[len(prefixes[i]):] + ".weight"
-            over[key] = sds[i][key] + te_arena.scale * Bm @ A
+            merged = sds[i][key] + te_arena.scale * Bm @ A
+            if dora:
+                mg = mag[0].clone().requires_grad_(True)
+                te_params.append(mg)
+                merged = (mg / merged.norm(dim=1).detach())[:, None] * merged
+            over[key] = merged
         outs.append(functional_call(m, over, kwargs=dict(input_ids=ids, output_hidden_states=True)))
     embs = [m.get_input_embeddings().weight for m in hf]
     if xl:
