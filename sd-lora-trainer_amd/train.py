@@ -353,9 +353,9 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
     optimizer call, so that several jobs can be advanced in lock-step by train_concurrent."""
     from . import step as S
     from . import unet as M
-    for flag, what in ((config.aspect_ratio_bucketing, "aspect_ratio_bucketing (broken in the reference as well, README.md:76)")):
-        if flag:
-            raise NotImplementedError(f"{what} is not built in this engine; refusing to train something else silently")
+    if config.aspect_ratio_bucketing:
+        raise NotImplementedError("aspect_ratio_bucketing (broken in the reference as well, README.md:76) is not built in this engine: the step's "
+                                  "graphs are captured for one latent shape; refusing to train something else silently")
     rank, world = _rank_world()
     ddp = (not config.is_lora) and world > 1
     if ddp and str(config.device).startswith("cuda") and os.environ.get("LOCAL_RANK") is not None and torch.cuda.device_count() > 1:
