@@ -47,6 +47,7 @@ class Runtime:
         self.want_dpooled = False    # SDXL: back-propagate into the pooled text embedding (textual inversion)
         self.dsemb = None
         self.daam_applied = False    # this step's score-gradient GEMMs were issued up front (UNet.daam_backward)
+        self.defer_daam_scores = True  # the hooked layers' score GEMMs run batched after the forward pass (UNet._daam_forward)
         self.trainer = None          # fullft.WeightTrainer when the whole UNet is trained (is_lora = False)
         self._scratch = {}
         # GroupNorm statistics (forward sums, backward sums) of all layers live in two small arenas: the UNet clears each with one
@@ -707,9 +708,12 @@ class Attention(_Module):
             if N not in rt.daam_sums:
                 rt.daam_sums[N] = [rt.zeros(B * N, CTX_PAD, dtype=F32), 0, False]
             ent = rt.daam_sums[N]
-            for b in range(B):
-                rt.ops.gemm(q[b * N:(b + 1) * N], k[b * Nkp:(b + 1) * Nkp], ent[0][b * N:(b + 1) * N], alpha=self.scale,
-                            accumulate=ent[2])
+            if rt.defer_daam_scores:      # all hooked layers of a resolution in one batched launch after the forward (UNet._daam_forward)
+                self._qk = (q, k)
+            else:
+                for b in range(B):
+                    rt.ops.gemm(q[b * N:(b + 1) * N], k[b * Nkp:(b + 1) * Nkp], ent[0][b * N:(b + 1) * N], alpha=self.scale,
+                                accumulate=ent[2])
             ent[2] = True
             ent[1] += 1
             if rt.keep_daam_maps:
@@ -1037,7 +1041,39 @@ class UNet(_Module):
                 ch, cw = ch * 2, cw * 2
         hn = self.norm_out.forward(h, None, B, ch * cw)
         self._dims = (B, H, W)
+        self._daam_forward()
         return self.conv_out.forward(hn, B, ch, cw, out=self.buf("pred", B * H * W, cfg["out_channels"], dtype=F32), train=False)
+
+    def _daam_forward(self):
+        """DAAM side output (ti_cross_attn_loss.py:201-212) of every hooked cross-attention layer: S_l = Q_l K_l^T / sqrt(d) summed
+        over heads is one dense [N, C] x [C, 77] product per layer, and the token-attention loss only uses the mean over layers.
+        One batched GEMM per (resolution, width, batch element) into fp32 partial maps + one sum per resolution, instead of one
+        32-workgroup accumulate launch per layer (60 in SDXL)."""
+        rt = self.rt
+        if not rt.defer_daam_scores or not rt.daam_sums:
+            return
+        if getattr(self, "_daam_fwd", None) is None:
+            groups = {}
+            for a in self.cross_attns:
+                if a.hooked and getattr(a, "_qk", None) is not None:
+                    groups.setdefault((a._dims[1], a.C), []).append(a)
+            plan, parts = [], {}
+            for (N, C), members in groups.items():
+                B, _, Nk, Nkp = members[0]._dims
+                part = self.buf(("daam_part", N, C), len(members), B * N, CTX_PAD, dtype=F32)
+                for b in range(B):
+                    items = [dict(X=a._qk[0][b * N:(b + 1) * N], W=a._qk[1][b * Nkp:(b + 1) * Nkp], C=part[i, b * N:(b + 1) * N]) for i, a in enumerate(members)]
+                    plan.append((members[0].scale, items, rt.ops.GemmBatch(items, rt.device)))
+                parts.setdefault(N, []).append(part)
+            self._daam_fwd = (plan, parts)
+        plan, parts = self._daam_fwd
+        for scale, items, batch in plan:
+            rt.ops.gemm(items[0]["X"], items[0]["W"], items[0]["C"], alpha=scale, batch=batch)
+        for N, ps in parts.items():
+            dst = rt.daam_sums[N][0]
+            torch.sum(ps[0], dim=0, out=dst)
+            for p_ in ps[1:]:
+                dst.add_(p_.sum(0))
 
     # ------------------------------------------------------------------------------------ backward
     def backward(self, dpred64, dctx):
