@@ -116,7 +116,7 @@ def run_guarded(argv, timeout_s):
     return res
 
 
-def cpu_baseline(version, rank, full_hw, budget_s=45.0):
+def cpu_baseline(version, rank, full_hw, budget_s=80.0):
     """The fp32 oracle (oracle/: CPU port of the reference path - diffusers-style UNet + peft LoRA restatement, the reference's
     loss) timed on this host's cores: forward + backward to every LoRA tensor and to the text conditioning, 1 warm-up + timed
     steps at the LARGEST resolution of {full, full/2, full/4} whose three steps fit the time budget (calibrated on a quick pass
@@ -174,7 +174,9 @@ def cpu_baseline(version, rank, full_hw, budget_s=45.0):
     times = [t_small]
     if h != small:
         one_step(h)                                      # warm-up at the chosen size
-        times = [one_step(h), one_step(h)]
+        times = [one_step(h)]
+        print(json.dumps(dict(times=times, hw=h, flops=flops(h), cores=cores)), flush=True)      # (complete answer, should the guard cut the second step)
+        times.append(one_step(h))
     return dict(times=times, hw=h, flops=flops(h), cores=cores)
 
 
