@@ -116,7 +116,7 @@ def run_guarded(argv, timeout_s):
     return res
 
 
-def cpu_baseline(version, rank, full_hw, budget_s=80.0):
+def cpu_baseline(version, rank, full_hw, budget_s=100.0):
     """The fp32 oracle (oracle/: CPU port of the reference path - diffusers-style UNet + peft LoRA restatement, the reference's
     loss) timed on this host's cores: forward + backward to every LoRA tensor and to the text conditioning, 1 warm-up + timed
     steps at the LARGEST resolution of {full, full/2, full/4} whose three steps fit the time budget (calibrated on a quick pass
@@ -166,17 +166,22 @@ def cpu_baseline(version, rank, full_hw, budget_s=80.0):
     one_step(small)                                      # cold pass (page-in, thread pools)
     t_small = one_step(small)
     print(json.dumps(dict(times=[t_small], hw=small, flops=flops(small), cores=cores)), flush=True)     # (child mode: a first, complete answer)
-    h = small
-    for cand in (full_hw, full_hw // 2):
-        if cand > small and 3.0 * t_small * flops(cand) / flops(small) <= budget_s:
-            h = cand
+    # climb small -> full/2 -> full while the next size's warm-up + 2 timed steps still fit what is left of the budget, each estimate
+    # scaled by FLOPs from the LAST size measured (small sizes run at a lower rate, so they over-estimate the big ones)
+    h, t_h, times, spent = small, t_small, [t_small], 2.0 * t_small
+    for cand in (full_hw // 2, full_hw):
+        if cand <= h:
+            continue
+        if spent + 3.0 * t_h * flops(cand) / flops(h) > budget_s:
             break
-    times = [t_small]
-    if h != small:
-        one_step(h)                                      # warm-up at the chosen size
-        times = [one_step(h)]
-        print(json.dumps(dict(times=times, hw=h, flops=flops(h), cores=cores)), flush=True)      # (complete answer, should the guard cut the second step)
-        times.append(one_step(h))
+        t0 = time.time()
+        one_step(cand)                                   # warm-up at this size
+        times = [one_step(cand)]
+        print(json.dumps(dict(times=times, hw=cand, flops=flops(cand), cores=cores)), flush=True)      # (complete answer, should the guard cut the next step)
+        times.append(one_step(cand))
+        h, t_h = cand, sum(times) / 2
+        spent += time.time() - t0
+        print(json.dumps(dict(times=times, hw=h, flops=flops(h), cores=cores)), flush=True)
     return dict(times=times, hw=h, flops=flops(h), cores=cores)
 
 

@@ -865,7 +865,7 @@ class ResnetBlock(_Module):
         rt = self.rt
         HW = H * W
         h = self.norm1.forward(x1, x2, B, HW)
-        tp = self.temb.forward(semb, train=False)
+        tp = self._tp if getattr(self, "_tp", None) is not None else self.temb.forward(semb, train=False)     # (stacked: UNet._forward)
         c1 = self.conv1.forward(h, B, H, W, rowbias=tp)
         h2 = self.norm2.forward(c1, None, B, HW)
         if self.shortcut is None:
@@ -889,8 +889,12 @@ class ResnetBlock(_Module):
         if rt.want_dpooled or self.temb.trainer is not None:
             # h = conv1(.) + time_emb_proj(silu(emb))[b]: d(proj output)[b] = column sums of dc1 over the pixels of image b;
             # accumulated over all resnets into d silu(emb)
-            dtp = rt.ops.colsum(dc1, self.buf("dtp", B, self.cout), B=B, R=H * W)
-            self.temb.backward(dtp, dres=rt.dsemb, out=rt.dsemb)
+            slot = getattr(self, "_dtp_slot", None)
+            if slot is not None:            # stacked: one GEMM for all resnets at the end of UNet._backward
+                rt.ops.colsum(dc1, slot, B=B, R=H * W)
+            else:
+                dtp = rt.ops.colsum(dc1, self.buf("dtp", B, self.cout), B=B, R=H * W)
+                self.temb.backward(dtp, dres=rt.dsemb, out=rt.dsemb)
         dh1 = self.conv1.backward(dc1)
         if self.shortcut is not None and self.shortcut.trainer is not None:      # its forward is issued here, not through Linear.forward
             self.shortcut._x = x1
@@ -970,6 +974,20 @@ class UNet(_Module):
             trainer.registering = False
             trainer.finalize()
         self._grad_plan = None
+        # time_emb_proj of every resnet reads the same silu(emb): ONE GEMM over the stacked weights [sum Cout, tdim] per pass instead of
+        # one M = B launch per resnet (17 in SDXL, 22 in SD1.5); the same for their input gradients (dsemb) when B == 1.  Not with the
+        # full fine-tune (the projections are trained layer by layer there).
+        self.resnets = [r for (res, _, _) in self.down for r in res] + [self.mid[0], self.mid[2]] + [r for (res, _, _) in self.up for r in res]
+        self.temb_W = None
+        if trainer is None:
+            self.temb_W = torch.cat([r.temb.W for r in self.resnets], 0).contiguous()
+            self.temb_b = torch.cat([r.temb.bias for r in self.resnets]).contiguous()
+            self.temb_Wt = self.temb_W.t().contiguous()
+            off = 0
+            for r in self.resnets:                  # the members keep working on views of the stacked operands (B > 1 backward)
+                r.temb_off = off
+                r.temb.W, r.temb.Wt = self.temb_W[off: off + r.cout], self.temb_Wt[:, off: off + r.cout]
+                off += r.cout
         # cross-attention to_k|to_v of every layer read the same text conditioning: one batched launch per (width, hooked)
         # group in forward, and one for all their input gradients in backward (instead of 2 x 70 M = 128 GEMMs)
         tfs = [t for (_, att, _) in self.down for t in att] + [self.mid[1]] + [t for (_, att, _) in self.up for t in att]
@@ -1011,6 +1029,10 @@ class UNet(_Module):
             emb = self.a2.forward(rt.ops.map_bf16(_ops.MAP_SILU, a1, None, self.buf("a1s", *a1.shape)), residual=emb, train=False)
         semb = rt.ops.map_bf16(_ops.MAP_SILU, emb, None, self.buf("semb", *emb.shape))
         self._b["semb_in"] = emb
+        if self.temb_W is not None:
+            tp_all = rt.ops.gemm(semb, self.temb_W, self.buf("tp_all", B, self.temb_W.shape[0]), bias=self.temb_b)
+            for r in self.resnets:
+                r._tp = tp_all[:, r.temb_off: r.temb_off + r.cout]
 
         self._cross_kv_forward(ctx, B)
         h = self.conv_in.forward(x, B, H, W, train=False)
@@ -1097,6 +1119,10 @@ class UNet(_Module):
         if rt.want_dpooled or tr is not None:
             rt.dsemb = self.buf("dsemb", B, self.tdim, zero=True)
             rt.dsemb.zero_()
+            if self.temb_W is not None and "dtp_all" not in self._b:
+                dtp_all = self.buf("dtp_all", B, self.temb_W.shape[0], zero=True)
+                for r in self.resnets:      # [B, cout] slices are contiguous only for B == 1 (sdlt_colsum writes a dense [B, C])
+                    r._dtp_slot = dtp_all[:, r.temb_off: r.temb_off + r.cout] if B == 1 else None
         dh = self.norm_out.backward(self.conv_out.backward(dpred64))
         skip_grads = []
         nlev = len(boc)
@@ -1130,6 +1156,8 @@ class UNet(_Module):
         # conv_in's own skip gradient and dX are not needed (its input is data, no adapter upstream) - unless conv_in itself trains
         if tr is not None:
             self.conv_in.weight_grad(self._add(dh, pop_skip(), ("cin",)))
+        if rt.want_dpooled and self.temb_W is not None and B == 1:
+            rt.ops.gemm(self._b["dtp_all"], self.temb_Wt, rt.dsemb)          # dsemb = sum over the resnets of colsum(dc1) . W_temb
         if rt.want_dpooled or tr is not None:
             # emb = time_embedding(t) + add_embedding([pooled | sinusoid(time_ids)]); with LoRA only the pooled text embedding is
             # trainable upstream (textual inversion through text_encoder_2), so the timestep branch gets no backward; the
