@@ -335,12 +335,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(const sdlt_attn_params& p, char
 }
 
 // =============================================================================== backward dK,dV (per 64-key tile, optional query split)
-template <int DP, bool DIN = false>
+template <int DP>
 __device__ __forceinline__ void attn_bwd_dkdv_body(const sdlt_attn_params& p, char* smem, const int bx) {
-  // DIN: D = rowsum(dO * O) of every query tile is computed here from the dO tile the loop loads anyway and an extra O tile
-  // (one more 8 KB tile per step, L2-resident) instead of being read from p.D - the merged self-attention launch then needs no
-  // attn_prep_kernel in front of it (head width <= 64: the 8 chunks of a row sit in 8 neighbouring lanes).
-  static_assert(!DIN || DP == 64, "in-kernel D: 64-wide tiles");
   constexpr int NSTR = tile_stride<DP>();
   const int b = blockIdx.z, h = blockIdx.y;
   const int ktile = bx / p.qsplit, split = bx - ktile * p.qsplit;
@@ -371,7 +367,6 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const sdlt_attn_params& p, ch
   constexpr int KBUF = 2 * 64 * NSTR + 512;   // Q, dO natural + L, D
   constexpr bool DB = 2 * KBUF <= 160 * 1024;                 // double-buffered unless it would not fit the LDS
   TileRegs<DP> qr, gr;
-  [[maybe_unused]] TileRegs<DP> orr;
   const int troff = (8 * g + (i >> 2)) * NSTR + (i & 3) * 8;
   const int tsw = row_sw<DP>(8 * g + (i >> 2)) >> 1;   // this lane's XOR on the 32-byte column block of a transposing read
   float lreg = 0.f, dreg = 0.f;
@@ -380,33 +375,19 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const sdlt_attn_params& p, ch
     const int nq = min(64, p.Nqp - q0);
     gload_nat<DP>(qr, (const bf16_t*)p.Q, p.ldq, (int64_t)b * p.Nqp + q0, nq, hc, d);
     gload_nat<DP>(gr, (const bf16_t*)p.dO, p.lddo, (int64_t)b * p.Nqp + q0, nq, hc, d);
-    if constexpr (DIN) gload_nat<DP>(orr, (const bf16_t*)p.O, p.ldo, (int64_t)b * p.Nqp + q0, min(nq, max(0, p.Nq - q0)), hc, d);
     if (threadIdx.x < 64) {
       int qq = q0 + threadIdx.x;
       lreg = qq < p.Nq ? p.L[((int64_t)b * p.H + h) * p.Nq + qq] * LOG2E : 0.f;
-      if constexpr (!DIN) dreg = qq < p.Nq ? p.D[((int64_t)b * p.H + h) * p.Nq + qq] : 0.f;
+      dreg = qq < p.Nq ? p.D[((int64_t)b * p.H + h) * p.Nq + qq] : 0.f;
     }
   };
   auto sstore_all = [&](char* base) {
     sstore_nat<DP>(qr, base);
     sstore_nat<DP>(gr, base + 64 * NSTR);
-    float* ls = (float*)(base + 2 * 64 * NSTR);
     if (threadIdx.x < 64) {
+      float* ls = (float*)(base + 2 * 64 * NSTR);
       ls[threadIdx.x] = lreg;
-      if constexpr (!DIN) ls[64 + threadIdx.x] = dreg;
-    }
-    if constexpr (DIN) {           // chunk c = tid + 256 i of the natural tile = row c / 8, columns (c % 8) * 8 .. + 8
-#pragma unroll
-      for (int t = 0; t < DP / 32; ++t) {
-        const uint32_t gw[4] = {gr.r[t].x, gr.r[t].y, gr.r[t].z, gr.r[t].w}, ow[4] = {orr.r[t].x, orr.r[t].y, orr.r[t].z, orr.r[t].w};
-        float a = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a += bf2f(gw[j] & 0xffff) * bf2f(ow[j] & 0xffff) + bf2f(gw[j] >> 16) * bf2f(ow[j] >> 16);
-        a += __shfl_xor(a, 1, 64);
-        a += __shfl_xor(a, 2, 64);
-        a += __shfl_xor(a, 4, 64);
-        if ((threadIdx.x & 7) == 0) ls[64 + ((threadIdx.x + 256 * t) >> 3)] = a;
-      }
+      ls[64 + threadIdx.x] = dreg;
     }
   };
   if (qt_lo < qt_hi) {
@@ -523,12 +504,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const sdlt_attn_para
 // Self-attention: the dQ tiles and the dK/dV tiles of one layer in ONE launch (blockIdx.x < #query tiles: dQ role).  At
 // 1024 tokens x 20 heads either pass alone is 320 workgroups of 16 dependent steps - latency-bound, the chip half empty;
 // together they overlap.  The dK/dV role needs D of every query row, so D comes from attn_prep_kernel here.
-template <int DP, bool DIN = false>
+template <int DP>
 __global__ __launch_bounds__(256) void attn_bwd_both_kernel(const sdlt_attn_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ndq = (p.Nq + 63) / 64;
   if ((int)blockIdx.x < ndq) attn_bwd_dq_body<DP, false>(p, smem, blockIdx.x);
-  else attn_bwd_dkdv_body<DP, DIN>(p, smem, blockIdx.x - ndq);
+  else attn_bwd_dkdv_body<DP>(p, smem, blockIdx.x - ndq);
 }
 // D[b,h,q] = sum_d dO*O (8 lanes per (row, head))
 __global__ void attn_prep_kernel(const bf16_t* O, int64_t ldo, const bf16_t* dO, int64_t lddo, int B, int H, int Nq, int Nqp, int d, float* D) {
@@ -937,15 +918,6 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
   if (p.qsplit == 1 && !p.accumulate_dq && !p.accumulate_dk &&
       (int64_t)((p.Nq + 63) / 64 + (p.Nk + 63) / 64) * p.H * p.B <= 2048) {   // (bigger grids are throughput-bound: two launches are 5 % faster there)
     // self-attention (UNet, text encoders): D, then dQ and dK/dV tiles in one launch (see attn_bwd_both_kernel)
-    dim3 gb0((p.Nq + 63) / 64 + (p.Nk + 63) / 64, p.H, p.B);
-#define SMEM_BOTH0 (2 * (2 * 64 * NSTRH(64) + 512))
-    static const int din_max = getenv("SDLT_ATTN_DIN") ? atoi(getenv("SDLT_ATTN_DIN")) : 1024;
-    if (dp == 64 && p.Nq <= din_max) {      // D computed inside the dK/dV role: no prep launch (see attn_bwd_dkdv_body)
-      set_smem((attn_bwd_both_kernel<64, true>), SMEM_BOTH0);
-      hipLaunchKernelGGL((attn_bwd_both_kernel<64, true>), gb0, dim3(256), SMEM_BOTH0, s, p);
-      SDLT_CHECK_LAUNCH();
-      return SDLT_OK;
-    }
     int64_t groups = (int64_t)p.B * p.Nqp * p.H;
     int blocks = (int)((groups * 8 + 255) / 256);
     if (blocks > 4096) blocks = 4096;
