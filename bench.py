@@ -388,7 +388,7 @@ def main():
         tpath = os.path.join(pdir, "r02_sdxl1024_ti_hbm_traffic_pmc.json")
         if not os.path.exists(tpath):
             tpath = os.path.join(pdir, "r01_sdxl1024_ti_hbm_traffic_pmc.json")
-        if version == "sdxl" and res == 1024 and B == 1 and args.rank == 16 and text is not None and not args.ti_frozen and not full_ft and J == 1 and os.path.exists(tpath):
+        if version == "sdxl" and res == 1024 and B == 1 and args.rank == 16 and text is not None and not args.ti_frozen and not full_ft and not args.dora and J == 1 and os.path.exists(tpath):
             with open(tpath) as fh:
                 traffic = json.load(fh).get("traffic_bytes_per_step")
         fpath = os.path.join(os.path.dirname(tpath), "r01_fullft_hbm_traffic_pmc.json")
