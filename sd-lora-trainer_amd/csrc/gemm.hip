@@ -903,6 +903,18 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
       }
     } else if (ktot <= 2560 && t128 > 32) { p.tile = 2; if (!p.splitk) p.splitk = 1; }
     else if (ktot <= 2560) p.tile = 2;
+    else if (t128 <= 24 && !p.batch && !p.lora_group_k) {
+      // a handful of 128x128 tiles and a long K (SD1.5's 8x8-pixel level at batch 4): 64x128 tiles, split until ~one workgroup per CU
+      // while every split keeps >= 20 K-steps.  tools/gemm_probe4.py: conv 256 x 1280 x 11520 41.7 -> 28.2 us (with adapter 48.5 -> 33.8),
+      // x 23040 61.2 -> 41.2, ff2 256 x 1280 x 5120 31.2 -> 18.0 (the 128x128 tile split 13 ways moved 17 MB of partial slabs).
+      p.tile = 2;
+      if (!p.splitk) {
+        const long t2 = (long)((p.M + 63) / 64) * ((p.N + 127) / 128);
+        int sk = (int)((256 + t2 / 2) / t2);
+        if (sk > nk / 20) sk = nk / 20;
+        p.splitk = (ws && sk > 1) ? sk : 1;
+      }
+    }
     else p.tile = 1;
   }
   int bm, bn;
