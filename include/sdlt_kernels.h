@@ -84,8 +84,8 @@ typedef struct sdlt_gemm_params {
                                  T_out columns [g*lora_R, (g+1)*lora_R); Bup stays [N, lora_R].  Fused to_q|to_k|to_v and
                                  the batched cross-attention to_k|to_v of all blocks.  Must be a multiple of the N tile. */
   int32_t lora_group_k;       /* > 0: K is a concatenation of G <= 4 groups of `lora_group_k` columns (the stacked dY of fused
-                                 projections), each with its own rank-16 adapter: Adown stays [16, K] (the groups' B^T side by
-                                 side), T_out is [M, G*16] and Bup [N, G*16].  lora_R must be 16, mode 0, no split-K. */
+                                 projections), each with its own adapter of padded rank lora_R: Adown stays [lora_R, K] (the groups' B^T
+                                 side by side), T_out is [M, G*lora_R] and Bup [N, G*lora_R].  Mode 0; split-K only as one split per group. */
   const sdlt_gemm_batch_item* batch;   /* device array of n_batch problems sharing this launch (the to_k|to_v projections of
                                           every cross-attention layer read the same text conditioning: one launch for all of
                                           them, and one for all their input gradients); no split-K */

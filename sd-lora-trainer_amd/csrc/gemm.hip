@@ -64,9 +64,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
   constexpr int S = NSTAGE;                        // LDS ring depth: S-1 K-steps of DMA in flight under the MFMAs
   // KG > 0 (K-grouped adapters, the dX of stacked projections): K is G <= KG groups of lora_group_k columns, each with its own
   // rank-16 LoRA-down result; the accumulator is flushed to its 16 columns of Tsh at every group boundary.
-  constexpr int TW = (KG ? KG : R16) * 16;         // T columns held in Tsh
+  constexpr int TW = (KG ? KG * R16 : R16) * 16;   // T columns held in Tsh
   constexpr int TROW = R16 ? (TW + 4) : 4;         // bf16 elements per Tsh row (+4 pad)
-  static_assert(KG == 0 || R16 == 1, "K-grouped adapters: padded rank 16 only");
+  static_assert(KG == 0 || R16 >= 1, "K-grouped adapters need an adapter");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* tsh = smem + (S == 1 ? 2 : S) * STAGE;
 
@@ -284,10 +284,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
   // global-load latencies after the last MFMA of every launch (~1 us each; the K loop of a 1024 x 1280 x 1280 projection is
   // ~7 us).  They are issued here instead - older than every DMA stage, so the counted vmcnt waits of the ring still hold
   // (loads retire in order) - and are long complete when the loop ends.
-  constexpr int NUPMAX = KG ? KG : (R16 ? R16 : 1);
+  constexpr int NUPMAX = KG ? KG * R16 : (R16 ? R16 : 1);
   s16x4 bupf[NUPMAX][NI];
   if (R16) {
-    const int nup_ = KG ? p.K / p.lora_group_k : R16;
+    const int nup_ = KG ? (p.K / p.lora_group_k) * R16 : R16;
 #pragma unroll
     for (int j = 0; j < NUPMAX; ++j)
 #pragma unroll
@@ -440,13 +440,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
         const int grp = kt / gsteps;                 // reduction): park s*T_g in its Tsh columns and restart the accumulator
         if (t_active) {
 #pragma unroll
+          for (int j = 0; j < R16; ++j)
+#pragma unroll
           for (int b = 0; b < TMI; ++b) {
             int ml = wm * MI * 16 + (wn * TMI + b) * 16 + frow;
             uint2 v;
-            v.x = pack2bf(tacc[0][b][0] * p.lora_scale, tacc[0][b][1] * p.lora_scale);
-            v.y = pack2bf(tacc[0][b][2] * p.lora_scale, tacc[0][b][3] * p.lora_scale);
-            *(uint2*)(tsh + ((size_t)ml * TROW + grp * 16 + fk * 4) * 2) = v;
-            tacc[0][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            v.x = pack2bf(tacc[j][b][0] * p.lora_scale, tacc[j][b][1] * p.lora_scale);
+            v.y = pack2bf(tacc[j][b][2] * p.lora_scale, tacc[j][b][3] * p.lora_scale);
+            *(uint2*)(tsh + ((size_t)ml * TROW + (grp * R16 + j) * 16 + fk * 4) * 2) = v;
+            tacc[j][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
         }
       }
@@ -536,13 +538,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
           // K-grouped adapters under split-K: split sp covered exactly adapter group sp, its T goes to its own Tsh columns
           if (t_active) {
 #pragma unroll
+            for (int j = 0; j < R16; ++j)
+#pragma unroll
             for (int b = 0; b < TMI; ++b) {
-              const f32x4 t = o[(NACC + b) * NTHR + tid];
+              const f32x4 t = o[(NACC + j * TMI + b) * NTHR + tid];
               int ml = wm * MI * 16 + (wn * TMI + b) * 16 + frow;
               uint2 v;
               v.x = pack2bf(t[0] * p.lora_scale, t[1] * p.lora_scale);
               v.y = pack2bf(t[2] * p.lora_scale, t[3] * p.lora_scale);
-              *(uint2*)(tsh + ((size_t)ml * TROW + sp * 16 + fk * 4) * 2) = v;
+              *(uint2*)(tsh + ((size_t)ml * TROW + (sp * R16 + j) * 16 + fk * 4) * 2) = v;
             }
           }
         } else {
@@ -572,7 +576,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
         *(uint2*)(tsh + ((size_t)ml * TROW + j * 16 + fk * 4) * 2) = v;
       }
     }
-    const int nup = KG ? p.K / p.lora_group_k : R16;   // 16-column blocks of T (K-grouped: one per adapter)
+    const int nup = KG ? (p.K / p.lora_group_k) * R16 : R16;   // 16-column blocks of T (K-grouped: R16 per adapter)
     __syncthreads();
     if (pTout != nullptr && t_writer) {
       // [BM rows][R] bf16 -> global, 8 B per lane
@@ -584,7 +588,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
       }
     }
 #pragma unroll
-    for (int j = 0; j < (KG ? KG : R16); ++j) {
+    for (int j = 0; j < (KG ? KG * R16 : R16); ++j) {
       if (j >= nup) break;
       s16x4 tf[MI];
 #pragma unroll
@@ -788,7 +792,7 @@ int launch(const sdlt_gemm_params& p, hipStream_t stream) {
   constexpr int NTHR = 64 * WM * WN;
   constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
   constexpr int STAGE = (BM + BN + R16 * 16) * ROW_BYTES;
-  constexpr int TSH = R16 ? BM * ((KG ? KG : R16) * 16 + 4) * 2 : 0;
+  constexpr int TSH = R16 ? BM * ((KG ? KG * R16 : R16) * 16 + 4) * 2 : 0;
   // LDS ring depth: NSREQ == 2 keeps the footprint small (several workgroups per CU overlap each other);
   // otherwise as deep as 160 KB allows, up to 4.
   constexpr int NS = NSREQ <= 2 ? NSREQ : ((4 * STAGE + TSH <= 160 * 1024) ? 4 : ((3 * STAGE + TSH <= 160 * 1024) ? 3 : 2));
@@ -903,7 +907,7 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
       }
     } else if (ktot <= 2560 && t128 > 32) { p.tile = 2; if (!p.splitk) p.splitk = 1; }
     else if (ktot <= 2560) p.tile = 2;
-    else if (t128 <= 24 && !p.batch && !p.lora_group_k) {
+    else if (t128 <= 24 && !p.batch && !p.lora_group_k && !p.out_fp32) {     // (fp32 outputs: the weight-gradient products keep their rule)
       // a handful of 128x128 tiles and a long K (SD1.5's 8x8-pixel level at batch 4): 64x128 tiles, split until ~one workgroup per CU
       // while every split keeps >= 20 K-steps.  tools/gemm_probe4.py: conv 256 x 1280 x 11520 41.7 -> 28.2 us (with adapter 48.5 -> 33.8),
       // x 23040 61.2 -> 41.2, ff2 256 x 1280 x 5120 31.2 -> 18.0 (the 128x128 tile split 13 ways moved 17 MB of partial slabs).
@@ -967,33 +971,33 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
         case 3: return launch<2, 2, 2, 0, 0, 4, 0, 1>(p, s);
       }
     }
-    if constexpr (MODE == 0 && R16 == 1) {
+    if constexpr (MODE == 0 && R16 >= 1) {
       if (p.n_batch < 1 || p.n_batch > 65535) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: n_batch=%d", p.n_batch);
       if (p.lora_group_k > 0) {
         switch (p.tile) {
-          case 1: return launch<4, 2, 4, 0, 1, 4, 4, 1>(p, s);
-          case 2: return launch<2, 2, 4, 0, 1, 4, 4, 1>(p, s);
-          case 3: return launch<2, 2, 2, 0, 1, 4, 4, 1>(p, s);
+          case 1: return launch<4, 2, 4, 0, R16, 4, 4, 1>(p, s);
+          case 2: return launch<2, 2, 4, 0, R16, 4, 4, 1>(p, s);
+          case 3: return launch<2, 2, 2, 0, R16, 4, 4, 1>(p, s);
         }
       } else {
         switch (p.tile) {
-          case 1: return launch<4, 2, 4, 0, 1, 4, 0, 1>(p, s);
-          case 2: return launch<2, 2, 4, 0, 1, 4, 0, 1>(p, s);
-          case 3: return launch<2, 2, 2, 0, 1, 4, 0, 1>(p, s);
+          case 1: return launch<4, 2, 4, 0, R16, 4, 0, 1>(p, s);
+          case 2: return launch<2, 2, 4, 0, R16, 4, 0, 1>(p, s);
+          case 3: return launch<2, 2, 2, 0, R16, 4, 0, 1>(p, s);
         }
       }
     }
-    SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: batched launch needs mode 0, padded LoRA rank 16 and tile 1..3 (tile %d)", p.tile);
+    SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: batched launch needs mode 0 and tile 1..3 (tile %d)", p.tile);
   }
-  if (p.lora_group_k > 0) {   // K-grouped adapters: plain GEMM mode, rank pad 16, tiles 1..3, deep ring
-    if constexpr (MODE == 0 && R16 == 1) {
+  if (p.lora_group_k > 0) {   // K-grouped adapters: plain GEMM mode, tiles 1..3, deep ring (as deep as the G x rank T tile leaves room for)
+    if constexpr (MODE == 0 && R16 >= 1) {
       switch (p.tile) {
-        case 1: return launch<4, 2, 4, 0, 1, 4, 4>(p, s);
-        case 2: return launch<2, 2, 4, 0, 1, 4, 4>(p, s);
-        case 3: return launch<2, 2, 2, 0, 1, 4, 4>(p, s);
+        case 1: return launch<4, 2, 4, 0, R16, 4, 4>(p, s);
+        case 2: return launch<2, 2, 4, 0, R16, 4, 4>(p, s);
+        case 3: return launch<2, 2, 2, 0, R16, 4, 4>(p, s);
       }
     }
-    SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: lora_group_k needs mode 0, padded rank 16 and tile 1..3 (tile %d)", p.tile);
+    SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: lora_group_k needs mode 0 and tile 1..3 (tile %d)", p.tile);
   }
   if (p.epi_op) {   // fused GEGLU / activation epilogues: plain GEMM mode without LoRA, tiles 1, 2, 3, 7, 8 with the deep ring
     if constexpr (MODE == 0 && R16 == 0) {
@@ -1066,8 +1070,8 @@ extern "C" int sdlt_gemm_bf16(const sdlt_gemm_params* pp, void* stream) {
     if ((p.ld_adown % 8) || (p.ld_bup % 4) || (p.T_out && (p.ld_t % 4))) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_gemm_bf16: LoRA operand alignment");
     r16 = p.lora_R / 16;
     if (p.lora_group_k > 0) {
-      if (p.lora_group_n > 0 || p.lora_R != 16 || p.mode != 0 || (p.lora_group_k % BK) || (p.K % p.lora_group_k) || p.K / p.lora_group_k > 4)
-        SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: lora_group_k=%d needs rank pad 16, mode 0, K = G*group_k with G <= 4, group_k %% 64 == 0", p.lora_group_k);
+      if (p.lora_group_n > 0 || p.mode != 0 || (p.lora_group_k % BK) || (p.K % p.lora_group_k) || p.K / p.lora_group_k > 4)
+        SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: lora_group_k=%d needs mode 0, K = G*group_k with G <= 4, group_k %% 64 == 0", p.lora_group_k);
     }
   }
   int rc;

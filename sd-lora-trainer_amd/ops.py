@@ -108,8 +108,8 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
     transposed bf16 copy [N, >=M].  conv: ConvGeom -> X is the NHWC activation [B*Hin*Win, Cin].
     lora_group_n > 0: W is a stack of G = N / lora_group_n projections with one adapter each:
     Adown [G*Rp, K] (group-major), Bup [N, Rp], T_out [M, G*Rp].
-    lora_group_k > 0: X is a stack of G = K / lora_group_k gradients (the dX of such a stack): Adown [16, K], Bup [N, G*16],
-    T_out [M, G*16].
+    lora_group_k > 0: X is a stack of G = K / lora_group_k gradients (the dX of such a stack): Adown [Rp, K], Bup [N, G*Rp],
+    T_out [M, G*Rp].
     batch: a GemmBatch - the launch runs len(batch) problems of identical shape / leading dimensions; the tensor arguments
     describe problem 0 (shapes, strides, options), every problem's operand pointers come from the batch."""
     lib = _lib.load()
@@ -137,10 +137,10 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
     if lora is not None:
         Adown, Bup, scale, T_out = lora
         _chk2(Adown), _chk2(Bup)
-        if lora_group_k:       # K-grouped: one rank-16 adapter per group of input columns
+        if lora_group_k:       # K-grouped: one adapter (padded rank Rp) per group of input columns
             assert K % lora_group_k == 0 and not lora_group_n
-            G, Rp = K // lora_group_k, 16
-            assert tuple(Adown.shape) == (16, K) and tuple(Bup.shape) == (N, G * 16), (Adown.shape, Bup.shape)
+            G, Rp = K // lora_group_k, Adown.shape[0]
+            assert Rp in (16, 32, 64) and tuple(Adown.shape) == (Rp, K) and tuple(Bup.shape) == (N, G * Rp), (Adown.shape, Bup.shape)
             p.lora_group_k = lora_group_k
         else:
             Rp, G = Bup.shape[1], 1

@@ -391,8 +391,8 @@ class StackedLinear(_Module):
             for g, m in enumerate(members):   # the arena's shadow refresh now writes straight into the stacked operands
                 m.lora["A_s"] = self.A_cat[g * Rp:(g + 1) * Rp]
                 m.lora["B_s"] = self.B_cat[g * N:(g + 1) * N]
-            # backward operands of the K-grouped dX GEMM (rank pad 16 only): the members' B^T side by side, their A^T side by side
-            self.kgrouped = Rp == 16 and self.G <= 4 and N % 64 == 0
+            # backward operands of the K-grouped dX GEMM: the members' B^T side by side, their A^T side by side
+            self.kgrouped = self.G <= 4 and N % 64 == 0
             if self.kgrouped:
                 self.Bt_cat, self.At_cat = rt.zeros(Rp, self.G * N), rt.zeros(K, self.G * Rp)
                 for g, m in enumerate(members):
@@ -466,13 +466,14 @@ class StackedLinear(_Module):
             self.Wt = self.W.t().contiguous()
             for m in self.members:
                 m.Wt = None
-        U = self.buf("U", M, G * 16)
+        Rp = self.arena.Rp
+        U = self.buf("U", M, G * Rp)
         if not getattr(self, "_registered", False):
             r = self.arena.rank
             for g, m in enumerate(self.members):
                 self.arena.problems += [
                     dict(P=dy_cat[:, g * N:(g + 1) * N], Q=m._b["T"], out=m.lora["gB"], M=M, Cw=N, R=r, rank_major=False),
-                    dict(P=m._x, Q=U[:, g * 16:(g + 1) * 16], out=m.lora["gA"], M=M, Cw=self.K, R=r, rank_major=True)]
+                    dict(P=m._x, Q=U[:, g * Rp:(g + 1) * Rp], out=m.lora["gA"], M=M, Cw=self.K, R=r, rank_major=True)]
                 if self.dora:
                     self.arena.dora_grads.append(dict(dY=dy_cat[:, g * N:(g + 1) * N], Y=m._y0, bias=m.bias, mag=m.lora["M"], scale=m.lora["scale"],
                                                       gmag=m.lora["gM"], gB=m.lora["gB"]))

@@ -254,36 +254,39 @@ def test_gemm_grouped_lora(ops, M, C, K, G, tile, splitk):
 
 
 @pytest.mark.parametrize("splitk", [0, 1])
-@pytest.mark.parametrize("M,N,C,G,tile", [(200, 128, 128, 3, 0), (1024, 256, 192, 2, 1), (130, 64, 64, 4, 3), (520, 320, 128, 3, 2)])
-def test_gemm_kgrouped_lora(ops, M, N, C, G, tile, splitk):
-    """dX of stacked projections: K = G*C stacked gradients, one rank-16 adapter per K group (+ residual)."""
+@pytest.mark.parametrize("M,N,C,G,tile,Rp", [(200, 128, 128, 3, 0, 16), (1024, 256, 192, 2, 1, 16), (130, 64, 64, 4, 3, 16), (520, 320, 128, 3, 2, 16),
+                                             (1024, 1280, 1280, 3, 0, 32), (200, 128, 128, 3, 2, 32), (520, 320, 128, 4, 1, 32), (130, 64, 64, 2, 3, 64),
+                                             (1024, 256, 192, 3, 1, 64), (128, 2048, 1280, 2, 0, 64)])
+def test_gemm_kgrouped_lora(ops, M, N, C, G, tile, splitk, Rp):
+    """dX of stacked projections: K = G*C stacked gradients, one adapter (padded rank 16 / 32 / 64) per K group (+ residual)."""
     g = torch.Generator().manual_seed(M + N + G)
     K = G * C
     X, W = rnd(M, K, g=g), rnd(N, K, g=g, scale=0.2)
-    Ad, Bu = rnd(16, K, g=g, scale=0.3), rnd(N, G * 16, g=g, scale=0.3)
+    Ad, Bu = rnd(Rp, K, g=g, scale=0.3), rnd(N, G * Rp, g=g, scale=0.3)
     res = rnd(M, N, g=g)
-    out_c, T_c = torch.zeros(M, N, dtype=BF), torch.zeros(M, G * 16, dtype=BF)
+    out_c, T_c = torch.zeros(M, N, dtype=BF), torch.zeros(M, G * Rp, dtype=BF)
     E.gemm(X, W, out_c, lora=(Ad, Bu, 0.7, T_c), residual=res, lora_group_k=C)
-    out_g, T_g = torch.zeros(M, N, dtype=BF, device="cuda"), torch.zeros(M, G * 16, dtype=BF, device="cuda")
+    out_g, T_g = torch.zeros(M, N, dtype=BF, device="cuda"), torch.zeros(M, G * Rp, dtype=BF, device="cuda")
     ops.gemm(X.cuda(), W.cuda(), out_g, lora=(Ad.cuda(), Bu.cuda(), 0.7, T_g), residual=res.cuda(), lora_group_k=C, tile=tile, splitk=splitk)
     close(T_g, T_c, tol=1.5e-2, what="k-grouped lora T_out")
     close(out_g, out_c, tol=1.5e-2, what="k-grouped lora out")
 
 
+@pytest.mark.parametrize("Rp", [16, 32, 64])
 @pytest.mark.parametrize("mode", ["ngroup", "kgroup"])
-def test_gemm_batched(ops, mode):
-    """One launch, several problems of identical shape (the to_k|to_v projections of all cross-attention layers)."""
+def test_gemm_batched(ops, mode, Rp):
+    """One launch, several problems of identical shape (the to_k|to_v projections of all cross-attention layers), any adapter rank pad."""
     g = torch.Generator().manual_seed(77)
     nb, M, C, Kc = 5, 128, 128, 256
     if mode == "ngroup":      # forward: shared X, per-problem stacked W [2C, K] with one adapter per C columns
         N, K, kw = 2 * C, Kc, dict(lora_group_n=C)
-        mk = lambda: dict(W=rnd(N, K, g=g, scale=0.2), Adown=rnd(2 * 16, K, g=g, scale=0.3), Bup=rnd(N, 16, g=g, scale=0.3),
-                          T_out=torch.zeros(M, 32, dtype=BF), C=torch.zeros(M, N, dtype=BF), Ct=torch.zeros(N, M, dtype=BF))
+        mk = lambda: dict(W=rnd(N, K, g=g, scale=0.2), Adown=rnd(2 * Rp, K, g=g, scale=0.3), Bup=rnd(N, Rp, g=g, scale=0.3),
+                          T_out=torch.zeros(M, 2 * Rp, dtype=BF), C=torch.zeros(M, N, dtype=BF), Ct=torch.zeros(N, M, dtype=BF))
         X = rnd(M, K, g=g)
     else:                     # backward: per-problem X = stacked gradients [M, 2C], W^T [N, 2C], one adapter per K group
         N, K, kw = Kc, 2 * C, dict(lora_group_k=C)
-        mk = lambda: dict(X=rnd(M, K, g=g), W=rnd(N, K, g=g, scale=0.2), Adown=rnd(16, K, g=g, scale=0.3), Bup=rnd(N, 32, g=g, scale=0.3),
-                          T_out=torch.zeros(M, 32, dtype=BF), C=torch.zeros(M, N, dtype=BF))
+        mk = lambda: dict(X=rnd(M, K, g=g), W=rnd(N, K, g=g, scale=0.2), Adown=rnd(Rp, K, g=g, scale=0.3), Bup=rnd(N, 2 * Rp, g=g, scale=0.3),
+                          T_out=torch.zeros(M, 2 * Rp, dtype=BF), C=torch.zeros(M, N, dtype=BF))
         X = None
     items_c = [mk() for _ in range(nb)]
     items_g = [{k: v.cuda() for k, v in it.items()} for it in items_c]
