@@ -244,14 +244,14 @@ def run_step_and_trajectory(version, B, h, sd, kinds, *, device, ops=None, act_d
     return traj
 
 
-def _case_step_and_trajectory(version, B, dora=False):
+def _case_step_and_trajectory(version, B, dora=False, h=32, n_steps=6):
     """(a) + (b): first step in detail, then 5 more optimizer steps; batches alternate between two injected ones so that the
     effect of training on a revisited batch is part of what is compared."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from oracle import unet_ref as U
     kinds = ["clip_l", "clip_g"] if U.CONFIGS[version]["addition"] else ["clip_l"]
-    run_step_and_trajectory(version, B, 32, _unet_state(version), kinds, device="cuda:0", dora=dora)
+    run_step_and_trajectory(version, B, h, _unet_state(version), kinds, device="cuda:0", dora=dora, n_steps=n_steps)
 
 
 def _case_full_size_properties(version, B, h):
@@ -358,7 +358,7 @@ def test_real_topology(case):
     if case == "sdxl-step-trajectory":
         _case_step_and_trajectory("sdxl", 1)
     elif case == "sdxl-dora-step-trajectory":      # use_dora on all 577 adapted layers (the hyper-parameter sweep's variant, create_hyperparam_sweep.py:77)
-        _case_step_and_trajectory("sdxl", 1, dora=True)
+        _case_step_and_trajectory("sdxl", 1, dora=True, h=16, n_steps=4)       # (16 x 16 latent, 4 steps: the fp32 oracle's share of the suite's time)
     elif case == "sdxl-full-size":
         _case_full_size_properties("sdxl", 1, 128)
     elif case == "sdxl-fullft-gradients":
