@@ -358,7 +358,7 @@ def test_real_topology(case):
     if case == "sdxl-step-trajectory":
         _case_step_and_trajectory("sdxl", 1)
     elif case == "sdxl-dora-step-trajectory":      # use_dora on all 577 adapted layers (the hyper-parameter sweep's variant, create_hyperparam_sweep.py:77)
-        _case_step_and_trajectory("sdxl", 1, dora=True, h=16, n_steps=4)       # (16 x 16 latent, 4 steps: the fp32 oracle's share of the suite's time)
+        _case_step_and_trajectory("sdxl", 1, dora=True, n_steps=4)       # (4 steps: the fp32 oracle's share of the suite's time)
     elif case == "sdxl-full-size":
         _case_full_size_properties("sdxl", 1, 128)
     elif case == "sdxl-fullft-gradients":
