@@ -8,8 +8,26 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _usable_cores():
+    """Affinity mask capped by the cgroup CPU quota (the GPU boxes show 256 CPUs to a container that may use 16: a 256-thread OpenMP
+    team makes the fp32 oracle of the parity tests crawl) - same rule as bench.usable_cores."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    try:
+        import torch
+        torch.set_num_threads(_usable_cores())
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")
