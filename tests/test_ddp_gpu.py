@@ -43,7 +43,7 @@ def _worker(rank, world, port, out):
     ts.capture(warmup=1)
     assert len(ts.graphs) == len(tr.buckets) + 2          # forward+backward | one per bucket | optimizer
     losses = []
-    for i in range(4):
+    for i in range(6):
         ts.run(2e-4)
         losses.append(float(ts.loss))
     torch.cuda.synchronize()

@@ -5,9 +5,9 @@ SD1.5: 859,520,964), the exact CLIP-L / OpenCLIP-bigG text towers (12 x 768, 32 
 
   (a) ONE LoRA + textual-inversion step at a reduced latent (32 x 32; the CPU fp32 oracle takes seconds) against
       oracle/step_ref.py (main.py:263-382): prediction, image loss, token-attention loss, LoRA gradient, token-row gradients;
-  (b) a 5-step (SD1.5: 6-step) LOSS TRAJECTORY under AdamW (both optimizers live, L1 penalty, regulariser) with injected latents /
-      noise / timesteps / captions: every step's losses against the oracle's, and the final LoRA / token-row state; the same with
-      DoRA adapters (use_dora): SDXL first step in detail (incl. the magnitude gradients), SD1.5 a 4-step trajectory;
+  (b) a 6-step LOSS TRAJECTORY under AdamW (both optimizers live, L1 penalty, regulariser) with injected latents / noise /
+      timesteps / captions: every step's losses against the oracle's, and the final LoRA / token-row state; the same with DoRA
+      adapters (use_dora, incl. the magnitude gradients on their own), and the first step at the sweep's other ranks (24, 64);
   (c) at the FULL BASELINE size (SDXL 128 x 128 batch 1; SD1.5 64 x 64 batch 4) the size-independent properties: finite,
       hipGraph replay == eager gradients, optimizer state advances, loss goes down on a fixed batch;
   (d) the full fine-tune (cfg5) on the SDXL topology: EVERY parameter's gradient against oracle autograd.
@@ -247,14 +247,14 @@ def run_step_and_trajectory(version, B, h, sd, kinds, *, device, ops=None, act_d
     return traj
 
 
-def _case_step_and_trajectory(version, B, dora=False, h=32, n_steps=6):
+def _case_step_and_trajectory(version, B, dora=False, h=32, n_steps=6, rank=16):
     """(a) + (b): first step in detail, then 5 more optimizer steps; batches alternate between two injected ones so that the
     effect of training on a revisited batch is part of what is compared."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from oracle import unet_ref as U
     kinds = ["clip_l", "clip_g"] if U.CONFIGS[version]["addition"] else ["clip_l"]
-    run_step_and_trajectory(version, B, h, _unet_state(version), kinds, device="cuda:0", dora=dora, n_steps=n_steps)
+    run_step_and_trajectory(version, B, h, _unet_state(version), kinds, device="cuda:0", dora=dora, n_steps=n_steps, rank=rank)
 
 
 def _case_full_size_properties(version, B, h):
@@ -355,15 +355,19 @@ def _case_fullft_real_sdxl_topology():
 
 
 # Ordered so that each 10 GB weight state is built once: all SDXL cases, then all SD1.5 cases.
-@pytest.mark.parametrize("case", ["sdxl-step-trajectory", "sdxl-dora-step", "sdxl-full-size", "sdxl-fullft-gradients", "sd15-step-trajectory",
-                                  "sd15-dora-step-trajectory", "sd15-full-size"])
+@pytest.mark.parametrize("case", ["sdxl-step-trajectory", "sdxl-dora-step-trajectory", "sdxl-rank24-step", "sdxl-full-size", "sdxl-fullft-gradients",
+                                  "sd15-step-trajectory", "sd15-dora-step-trajectory", "sd15-rank64-step", "sd15-full-size"])
 def test_real_topology(case):
     if case == "sdxl-step-trajectory":
-        _case_step_and_trajectory("sdxl", 1, n_steps=5)
-    elif case == "sdxl-dora-step":      # use_dora on all 577 adapted layers: the first step in detail + one hipGraph replay (the fp32 oracle's share of the suite's time)
-        _case_step_and_trajectory("sdxl", 1, dora=True, n_steps=2)
-    elif case == "sd15-dora-step-trajectory":      # the hyper-parameter sweep's variant (SD1.5 + use_dora, create_hyperparam_sweep.py:55,77): 4-step trajectory
-        _case_step_and_trajectory("sd15", 4, dora=True, n_steps=4)
+        _case_step_and_trajectory("sdxl", 1)
+    elif case == "sdxl-dora-step-trajectory":      # use_dora on all 577 adapted layers
+        _case_step_and_trajectory("sdxl", 1, dora=True)
+    elif case == "sd15-dora-step-trajectory":      # the hyper-parameter sweep's variant (SD1.5 + use_dora, create_hyperparam_sweep.py:55,77)
+        _case_step_and_trajectory("sd15", 4, dora=True)
+    elif case == "sdxl-rank24-step":               # the sweep's ranks 24 / 64 (rank pads 32 / 64: K-grouped dX and batched K/V launches at the real widths)
+        _case_step_and_trajectory("sdxl", 1, n_steps=2, rank=24)
+    elif case == "sd15-rank64-step":
+        _case_step_and_trajectory("sd15", 4, n_steps=2, rank=64)
     elif case == "sdxl-full-size":
         _case_full_size_properties("sdxl", 1, 128)
     elif case == "sdxl-fullft-gradients":
