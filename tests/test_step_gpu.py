@@ -265,3 +265,40 @@ def test_bench_json_contract():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and len(c["step_seconds"]) >= 1
     assert d["train_loop"]["value"] > 0 and d["train_loop"]["unit"] == "images/s"          # the train() generator's own loop, extra object
     assert d["two_jobs_per_gpu"]["value"] > 0 and d["two_jobs_per_gpu"]["unit"] == "images/s"
+
+
+def test_cfg1_style_sd15_job_on_the_real_topology(tmp_path, monkeypatch):
+    """BASELINE configs[0]: train_configs/training_args_style_sd15.json with SURVEY 8d's overrides (512 px, batch 1, rank 4, 50 steps) - the
+    reference's CPU plumbing config - as a whole job on the REAL SD1.5 topology through train(): style mode, textual inversion on,
+    checkpoints at the reference's cadence, kohya file with all 150 adapters.  (Random-init weights and a synthetic latent cache: there
+    are no checkpoints or datasets offline; max_train_steps < 100 also exercises the guard of main.py:457's modulo.)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import json
+    import os
+    monkeypatch.chdir(tmp_path)
+    from safetensors.torch import load_file
+    from sd_lora_trainer_amd.config import TrainingConfig
+    from sd_lora_trainer_amd.train import train
+    cfg = TrainingConfig(name="twisting_realities_sd15", sd_model_version="sd15", lora_training_urls="synthetic:6", concept_mode="style",
+                         sample_imgs_lora_scale=0.8, seed=0, resolution=512, train_batch_size=1, n_sample_imgs=8, max_train_steps=50,
+                         checkpointing_steps=200, disable_ti=False, caption_model="blip", ti_lr=0.001, unet_lr=0.0003, lora_rank=4, debug=True,
+                         pretrained_model={"path": "synthetic:sd15"})
+    gen = train(cfg)
+    n = 0
+    try:
+        while True:
+            next(gen)
+            n += 1
+    except StopIteration as e:
+        config, out = e.value
+    assert n == 51                                          # max_train_steps + 1 steps (main.py:462)
+    ta = json.load(open(os.path.join(out, "training_args.json")))
+    tot = ta["training_attributes"]["losses"]["tot_loss"]
+    assert all(x == x and abs(x) < 1e4 for x in tot) and len(tot) >= 10
+    assert ta["concept_mode"] == "style" and ta["lora_rank"] == 4 and ta["pretrained_model"]["version"] == "sd15"
+    sd = load_file(os.path.join(out, "twisting_realities_sd15_sd15_lora.safetensors"))
+    downs = [k for k in sd if k.endswith(".lora_down.weight")]
+    assert len(downs) == 150 and all(sd[k].shape[0] == 4 for k in downs)            # 128 linear + 22 conv adapters (SURVEY a7)
+    emb = load_file(os.path.join(out, "twisting_realities_sd15_sd15_embeddings.safetensors"))
+    assert set(emb) == {"clip_l"} and tuple(emb["clip_l"].shape) == (3, 768)
