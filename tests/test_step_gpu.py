@@ -302,3 +302,41 @@ def test_cfg1_style_sd15_job_on_the_real_topology(tmp_path, monkeypatch):
     assert len(downs) == 150 and all(sd[k].shape[0] == 4 for k in downs)            # 128 linear + 22 conv adapters
     emb = load_file(os.path.join(out, "twisting_realities_sd15_sd15_embeddings.safetensors"))
     assert set(emb) == {"clip_l"} and tuple(emb["clip_l"].shape) == (3, 768)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("cfg2", dict(sd_model_version="sd15", concept_mode="face", resolution=512, train_batch_size=4, lora_rank=16, pretrained_model={"path": "synthetic:sd15"})),
+    ("cfg3", dict(sd_model_version="sdxl", concept_mode="object", resolution=1024, train_batch_size=1, lora_rank=16, pretrained_model={"path": "synthetic:sdxl"})),
+    ("sweep", dict(sd_model_version="sd15", concept_mode="style", resolution=512, train_batch_size=8, lora_rank=24, use_dora=True, disable_ti=True,
+                   unet_lr=0.001, pretrained_model={"path": "synthetic:sd15"}))])
+def test_baseline_config_jobs_on_the_real_topologies(tmp_path, monkeypatch, name, kw):
+    """BASELINE configs[1] (SD1.5 512 px face, rank 16 + TI, batch 4), configs[2] (SDXL 1024 px object, rank 16 + TI, batch 1 - the headline) and one
+    draw of configs[3]'s sweep (create_hyperparam_sweep.py:52-90: SD1.5, batch 8, rank 24, DoRA, no TI) as whole jobs through train() on the
+    real topologies: 40 optimizer steps under hipGraph replay, the loss of the synthetic concept falls, checkpoint files complete."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import json
+    import os
+    monkeypatch.chdir(tmp_path)
+    from safetensors.torch import load_file
+    from sd_lora_trainer_amd.config import TrainingConfig
+    from sd_lora_trainer_amd.train import train
+    base = dict(name=name, lora_training_urls="synthetic:8", seed=0, max_train_steps=40, n_sample_imgs=0, unet_lr=1e-3, ti_lr=1e-3)
+    base.update(kw)
+    cfg = TrainingConfig(**base)
+    gen = train(cfg)
+    try:
+        while True:
+            next(gen)
+    except StopIteration as e:
+        config, out = e.value
+    ta = json.load(open(os.path.join(out, "training_args.json")))
+    tot = ta["training_attributes"]["losses"]["tot_loss"]
+    assert all(x == x and abs(x) < 1e4 for x in tot) and len(tot) >= 10
+    assert sum(tot[-5:]) / 5 < sum(tot[:5]) / 5, tot
+    ver = kw["sd_model_version"]
+    sd = load_file(os.path.join(out, f"{name}_{ver}_lora.safetensors"))
+    n_ad = 577 if ver == "sdxl" else 150
+    assert len([k for k in sd if k.endswith(".lora_down.weight")]) == n_ad
+    assert len([k for k in sd if k.endswith(".dora_scale")]) == (n_ad if kw.get("use_dora") else 0)
+    assert ta["training_attributes"].get("images_per_second", 1.0) > 0
