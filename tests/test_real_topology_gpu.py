@@ -8,8 +8,9 @@ SD1.5: 859,520,964), the exact CLIP-L / OpenCLIP-bigG text towers (12 x 768, 32 
   (b) a 6-step LOSS TRAJECTORY under AdamW (both optimizers live, L1 penalty, regulariser) with injected latents / noise /
       timesteps / captions: every step's losses against the oracle's, and the final LoRA / token-row state; the same with DoRA
       adapters (use_dora, incl. the magnitude gradients on their own), and the first step at the sweep's other ranks (24, 64);
-  (c) at the FULL BASELINE size (SDXL 128 x 128 batch 1; SD1.5 64 x 64 batch 4) the size-independent properties: finite,
-      hipGraph replay == eager gradients, optimizer state advances, loss goes down on a fixed batch;
+  (c) at the FULL BASELINE size (SDXL 128 x 128 batch 1; SD1.5 64 x 64 batch 4): ONE whole step against the fp32 oracle (prediction,
+      losses, LoRA gradient, token-row gradients - the oracle step takes ~20 s on the box's 16 cores), and the size-independent properties:
+      finite, hipGraph replay == eager gradients, optimizer state advances, loss goes down on a fixed batch;
   (d) the full fine-tune (cfg5) on the SDXL topology: EVERY parameter's gradient against oracle autograd.
 
 Stated tolerances (bf16 storage of every activation, fp32 accumulation, ~200 GEMMs deep on SDXL):
@@ -355,11 +356,16 @@ def _case_fullft_real_sdxl_topology():
 
 
 # Ordered so that each 10 GB weight state is built once: all SDXL cases, then all SD1.5 cases.
-@pytest.mark.parametrize("case", ["sdxl-step-trajectory", "sdxl-dora-step-trajectory", "sdxl-rank24-step", "sdxl-full-size", "sdxl-fullft-gradients",
-                                  "sd15-step-trajectory", "sd15-dora-step-trajectory", "sd15-rank64-step", "sd15-full-size"])
+@pytest.mark.parametrize("case", ["sdxl-step-trajectory", "sdxl-dora-step-trajectory", "sdxl-rank24-step", "sdxl-full-size", "sdxl-full-size-step-parity",
+                                  "sdxl-fullft-gradients", "sd15-step-trajectory", "sd15-dora-step-trajectory", "sd15-rank64-step", "sd15-full-size",
+                                  "sd15-full-size-step-parity"])
 def test_real_topology(case):
     if case == "sdxl-step-trajectory":
         _case_step_and_trajectory("sdxl", 1)
+    elif case == "sdxl-full-size-step-parity":     # cfg3 at its FULL size (1024 px: 128 x 128 latent, batch 1): one whole step against the fp32 oracle
+        _case_step_and_trajectory("sdxl", 1, h=128, n_steps=1)
+    elif case == "sd15-full-size-step-parity":     # cfg2 at its FULL size (512 px: 64 x 64 latent, batch 4)
+        _case_step_and_trajectory("sd15", 4, h=64, n_steps=1)
     elif case == "sdxl-dora-step-trajectory":      # use_dora on all 577 adapted layers
         _case_step_and_trajectory("sdxl", 1, dora=True)
     elif case == "sd15-dora-step-trajectory":      # the hyper-parameter sweep's variant (SD1.5 + use_dora, create_hyperparam_sweep.py:55,77)
