@@ -25,9 +25,10 @@ def reference_loop_body(unet, optimizer, noise_acp, vae_latent, mask, prompt_emb
     return model_pred.detach(), float(loss.detach()), grads
 
 
-def run_shim_vs_oracle(version, B, h, rt, tol, steps=4):
+def run_shim_vs_oracle(version, B, h, rt, tol, steps=4, sd=None):
     cfg = U.CONFIGS[version]
-    sd = {k: v.to(torch.bfloat16).float() for k, v in U.init_unet_state(cfg, seed=0).items()}
+    if sd is None:
+        sd = {k: v.to(torch.bfloat16).float() for k, v in U.init_unet_state(cfg, seed=0).items()}
     lora = U.init_lora(cfg, 8, seed=1, b_std=0.03)
     dev = rt.device
     g = torch.Generator().manual_seed(5)

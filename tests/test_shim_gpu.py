@@ -7,12 +7,17 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("version,B", [("tinyxl", 1), ("tiny15", 2)])
+@pytest.mark.parametrize("version,B", [("tinyxl", 1), ("tiny15", 2), ("sdxl", 1)])
 def test_reference_loop_body_on_shim_gpu(version, B):
+    """tiny*: toy topologies; sdxl: the REAL topology (random-init weights, 32 x 32 latent) behind the reference-shaped call."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import sd_lora_trainer_amd.unet as unet_mod
     from tests.test_shim_cpu import run_shim_vs_oracle
     rt = unet_mod.Runtime("cuda:0", B)
-    unet, losses = run_shim_vs_oracle(version, B, 16, rt, dict(pred=4e-2, loss=2e-2, cos=0.99, param=1.5e-2), steps=4)
+    sd, h = None, 16
+    if not version.startswith("tiny"):
+        from tests.test_real_topology_gpu import _unet_state
+        sd, h = _unet_state(version), 32
+    unet, losses = run_shim_vs_oracle(version, B, h, rt, dict(pred=4e-2, loss=2e-2, cos=0.99, param=1.5e-2), steps=4, sd=sd)
     assert all(l == l for l, _ in losses)
