@@ -25,11 +25,14 @@ def reference_loop_body(unet, optimizer, noise_acp, vae_latent, mask, prompt_emb
     return model_pred.detach(), float(loss.detach()), grads
 
 
-def run_shim_vs_oracle(version, B, h, rt, tol, steps=4, sd=None):
+def run_shim_vs_oracle(version, B, h, rt, tol, steps=4, sd=None, dora=False):
     cfg = U.CONFIGS[version]
     if sd is None:
         sd = {k: v.to(torch.bfloat16).float() for k, v in U.init_unet_state(cfg, seed=0).items()}
     lora = U.init_lora(cfg, 8, seed=1, b_std=0.03)
+    if dora:          # LoraConfig(use_dora=True): (A, B, magnitude) per module, magnitudes off their initial value
+        lora = U.init_dora_magnitudes(cfg, sd, lora, jitter=0.05, seed=7)
+    npt = 3 if dora else 2
     dev = rt.device
     g = torch.Generator().manual_seed(5)
     latent = (torch.randn(B, 4, h, h, generator=g) * cfg["scaling_factor"]).to(dev)
@@ -41,14 +44,15 @@ def run_shim_vs_oracle(version, B, h, rt, tol, steps=4, sd=None):
         tid = torch.tensor([[1024., 1024, 0, 0, 8. * h, 8. * h]] * B).to(dev)
     acp = L.ddpm_alphas_cumprod().to(dev)
 
-    unet = shim.get_peft_model(version, sd, shim.LoraConfig(r=8, lora_alpha=8.0), batch_size=B, runtime=rt)
-    assert unet.device == rt.device and len(list(unet.parameters())) == 2 * len(lora)
+    unet = shim.get_peft_model(version, sd, shim.LoraConfig(r=8, lora_alpha=8.0, use_dora=dora), batch_size=B, runtime=rt)
+    assert unet.device == rt.device and len(list(unet.parameters())) == npt * len(lora)
     unet.unet.arena.load(lora)
     unet.requires_grad_(True)
-    opt = torch.optim.AdamW(list(unet.parameters()), lr=1e-3, weight_decay=0.004)
+    wd = 0.0 if dora else 0.004
+    opt = torch.optim.AdamW(list(unet.parameters()), lr=1e-3, weight_decay=wd)
     # oracle twin: same loop body over the oracle's functional UNet
-    o_params = {k: (A.clone().requires_grad_(True), Bm.clone().requires_grad_(True)) for k, (A, Bm) in lora.items()}
-    o_opt = torch.optim.AdamW([t for ab in o_params.values() for t in ab], lr=1e-3, weight_decay=0.004)
+    o_params = {k: tuple(t.clone().requires_grad_(True) for t in v) for k, v in lora.items()}
+    o_opt = torch.optim.AdamW([t for ab in o_params.values() for t in ab], lr=1e-3, weight_decay=wd)
     o_pe = pe.detach().cpu().clone().requires_grad_(True)
     o_pooled = pooled.detach().cpu().clone().requires_grad_(True) if pooled is not None else None
 
@@ -91,17 +95,20 @@ def run_shim_vs_oracle(version, B, h, rt, tol, steps=4, sd=None):
         losses.append((loss, loss_o))
     # the torch optimizer moved the engine's adapters: exported weights equal the oracle twin's
     got = unet.get_peft_model_state_dict()
-    for k, (A, Bm) in o_params.items():
+    for k, (A, Bm, *mg) in o_params.items():
         a, b_ = got[f"base_model.model.{k}.lora_A.weight"], got[f"base_model.model.{k}.lora_B.weight"]
         assert a.shape == A.shape and b_.shape == Bm.shape
         assert float((a - A.detach()).abs().max()) <= tol["param"] and float((b_ - Bm.detach()).abs().max()) <= tol["param"], k
+        if mg:
+            m_ = got[f"base_model.model.{k}.lora_magnitude_vector"]
+            assert m_.shape == mg[0].shape and float((m_ - mg[0].detach()).abs().max()) <= tol["param"], k
     return unet, losses
 
 
-@pytest.mark.parametrize("version,B", [("tinyxl", 1), ("tiny15", 2)])
-def test_reference_loop_body_on_shim_cpu(version, B, tmp_path):
+@pytest.mark.parametrize("version,B,dora", [("tinyxl", 1, False), ("tiny15", 2, False), ("tinyxl", 1, True)])
+def test_reference_loop_body_on_shim_cpu(version, B, dora, tmp_path):
     rt = unet_mod.Runtime("cpu", B, act_dtype=torch.float32, ops=emu_ops)
-    unet, losses = run_shim_vs_oracle(version, B, 16, rt, dict(pred=2e-3, loss=1e-3, cos=0.9999, param=3e-4))
+    unet, losses = run_shim_vs_oracle(version, B, 16, rt, dict(pred=2e-3, loss=1e-3, cos=0.9999, param=3e-4), dora=dora)
     unet.save_pretrained(str(tmp_path / "ad"))
     import json
     import os
@@ -119,7 +126,7 @@ def test_reference_loop_body_on_shim_cpu(version, B, tmp_path):
         t = torch.tensor([500] * B)
         unet(x, t, encoder_hidden_states=ehs, added_cond_kwargs=add)
         _, daam = U.unet_forward(cfg, {k: v.to(torch.bfloat16).float() for k, v in U.init_unet_state(cfg, seed=0).items()}, x, t, ehs, add,
-                                 lora={k: (a, b_) for k, (a, b_) in unet.unet.arena.export().items()}, return_daam=True)
+                                 lora=dict(unet.unet.arena.export()), return_daam=True)
     assert len(unet.daam_processors) == len(daam) > 0
     for proc, (name, s) in zip(unet.daam_processors, daam):
         assert proc.name == name + ".processor"
