@@ -20,7 +20,7 @@ extern "C" {
 
 const char* sdlt_last_error(void);
 int sdlt_abi_version(void);
-int sdlt_struct_size(int which); /* 0 gemm, 1 lora_grad_desc, 2 attn, 3 groupnorm, 4 shadow_desc, 5 gemm_batch_item, 6 dora_desc, 7 dora_wt_desc, 8 dora_grad_desc */
+int sdlt_struct_size(int which); /* 0 gemm, 1 lora_grad_desc, 2 attn, 3 groupnorm, 4 shadow_desc, 5 gemm_batch_item, 6 dora_desc, 7 dora_wt_desc, 8 dora_grad_desc, 9 splitsum_desc */
 
 /* ------------------------------------------------------------------------------------------------
  * sdlt_gemm_bf16 : C = alpha*(X.W^T [+ X2.W2^T] [+ s*(X.Adown^T).Bup^T]) + bias + rowbias + R
@@ -185,9 +185,22 @@ typedef struct sdlt_attn_params {
   int32_t causal;
   int32_t accumulate_dq;   /* single-pass cross-attention backward only: dQ += result, dK += result (the buffers already hold */
   int32_t accumulate_dk;   /* the gradient of the score side output, written by one batched GEMM for all hooked layers)    */
+  int32_t defer_splitsum;  /* single-pass cross-attention backward only: leave the per-split partial dK / dV slabs in dK32 / dV32
+                              (they must then be layer-owned, not scratch); sdlt_attn_splitsum_batch sums the slabs of ALL layers in
+                              one launch before their consumer (the batched to_k|to_v input-gradient GEMM) */
+  int32_t pad_;
 } sdlt_attn_params;
 int sdlt_attn_fwd(const sdlt_attn_params* p, void* stream);
 int sdlt_attn_bwd(const sdlt_attn_params* p, void* stream);
+/* out0 / out1 [B*Nkp, C] bf16 = sum over nsplit slabs of s0 / s1 (fp32 [nsplit][B*Nkp][ld32]) in slab order (rows with key >= Nk: zeros;
+ * acc0: out0 += instead of =), for a table of layers: block_desc[b] = descriptor of block b, block_first[d] = first block of descriptor d,
+ * a layer owns ceil(B*Nkp*C/2 / 256) blocks (capped at 64; the kernel strides). */
+typedef struct sdlt_splitsum_desc {
+  const float* s0; const float* s1; int64_t ld32;
+  void* out0; int64_t ldo0; void* out1; int64_t ldo1;
+  int32_t nsplit, B, Nk, Nkp, C, acc0, nblocks, pad_;
+} sdlt_splitsum_desc;
+int sdlt_attn_splitsum_batch(const sdlt_splitsum_desc* descs_dev, const int32_t* block_desc_dev, const int32_t* block_first_dev, int32_t n_blocks, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * sdlt_groupnorm_fwd / _bwd : GroupNorm(32 groups) [+ SiLU] over an NHWC activation, and its dX.

@@ -46,6 +46,11 @@ class GemmBatchItem(C.Structure):
     _fields_ = [("X", vp), ("W", vp), ("Adown", vp), ("Bup", vp), ("T_out", vp), ("C", vp), ("Ct", vp), ("bias", vp), ("col_scale", vp)]
 
 
+class SplitsumDesc(C.Structure):
+    _fields_ = [("s0", vp), ("s1", vp), ("ld32", i64), ("out0", vp), ("ldo0", i64), ("out1", vp), ("ldo1", i64),
+                ("nsplit", i32), ("B", i32), ("Nk", i32), ("Nkp", i32), ("C", i32), ("acc0", i32), ("nblocks", i32), ("pad_", i32)]
+
+
 class DoraDesc(C.Structure):
     _fields_ = [("W", vp), ("ldw", i64), ("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("mag", vp), ("scale", vp), ("Bt", vp), ("ldbt", i64),
                 ("B32", vp), ("ldb32", i64), ("N", i32), ("K", i32), ("Rp", i32), ("rank", i32), ("s", f32), ("pad_", i32)]
@@ -80,7 +85,7 @@ class AttnParams(C.Structure):
         ("dQ", vp), ("lddq", i64), ("dK", vp), ("lddk", i64), ("dV", vp), ("lddv", i64),
         ("dK32", vp), ("dV32", vp), ("ld32", i64),
         ("B", i32), ("H", i32), ("Nq", i32), ("Nk", i32), ("Nqp", i32), ("Nkp", i32), ("d", i32),
-        ("scale", f32), ("qsplit", i32), ("causal", i32), ("accumulate_dq", i32), ("accumulate_dk", i32),
+        ("scale", f32), ("qsplit", i32), ("causal", i32), ("accumulate_dq", i32), ("accumulate_dk", i32), ("defer_splitsum", i32), ("pad_", i32),
     ]
 
 
@@ -117,6 +122,7 @@ SYMBOLS = {
     "sdlt_lora_grad_block_cols": (i32, []),
     "sdlt_attn_fwd": (i32, [C.POINTER(AttnParams), vp]),
     "sdlt_attn_bwd": (i32, [C.POINTER(AttnParams), vp]),
+    "sdlt_attn_splitsum_batch": (i32, [vp, vp, vp, i32, vp]),
     "sdlt_groupnorm_ws_floats": (i32, [i32, i32, i32]),
     "sdlt_groupnorm_fwd": (i32, [C.POINTER(GroupNormParams), vp]),
     "sdlt_groupnorm_bwd": (i32, [C.POINTER(GroupNormParams), vp]),
@@ -173,7 +179,7 @@ def load():
             raise KernelLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    for which, cls in enumerate((GemmParams, LoraGradDesc, AttnParams, GroupNormParams, ShadowDesc, GemmBatchItem, DoraDesc, DoraWtDesc, DoraGradDesc)):
+    for which, cls in enumerate((GemmParams, LoraGradDesc, AttnParams, GroupNormParams, ShadowDesc, GemmBatchItem, DoraDesc, DoraWtDesc, DoraGradDesc, SplitsumDesc)):
         if lib.sdlt_struct_size(which) != C.sizeof(cls):
             raise KernelLibraryError(f"struct layout mismatch for {cls.__name__}: C {lib.sdlt_struct_size(which)} vs ctypes {C.sizeof(cls)}")
     _lib = lib

@@ -805,6 +805,35 @@ __global__ void attn_splitsum_kernel(const float* s0, const float* s1, int nspli
   }
 }
 
+// the same for a table of layers in one launch (sdlt_attn_splitsum_batch): every layer owns d.nblocks consecutive blocks
+__global__ void attn_splitsum_batch_kernel(const sdlt_splitsum_desc* descs, const int32_t* block_desc, const int32_t* block_first) {
+  const sdlt_splitsum_desc d = descs[block_desc[blockIdx.x]];
+  const int blk = blockIdx.x - block_first[block_desc[blockIdx.x]];
+  const int nch = d.C >> 2;
+  const int64_t per = (int64_t)d.B * d.Nkp * nch, sstride = (int64_t)d.B * d.Nkp * d.ld32;
+  for (int64_t t = blk * (int64_t)blockDim.x + threadIdx.x; t < 2 * per; t += (int64_t)d.nblocks * blockDim.x) {
+    const bool second = t >= per;
+    const int64_t u = second ? t - per : t;
+    const int r = u / nch, c = (u - (int64_t)r * nch) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r % d.Nkp < d.Nk) {
+      const float* src = (second ? d.s1 : d.s0) + r * d.ld32 + c;
+      for (int sp = 0; sp < d.nsplit; ++sp) {
+        float4 v = *(const float4*)(src + sp * sstride);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    uint2* dst = (uint2*)((second ? (bf16_t*)d.out1 + r * d.ldo1 : (bf16_t*)d.out0 + r * d.ldo0) + c);
+    if (d.acc0 && !second) {
+      const uint2 old = *dst;
+      acc.x += bf2f(old.x & 0xffff); acc.y += bf2f(old.x >> 16); acc.z += bf2f(old.y & 0xffff); acc.w += bf2f(old.y >> 16);
+    }
+    uint2 w;
+    w.x = pack2bf(acc.x, acc.y); w.y = pack2bf(acc.z, acc.w);
+    *dst = w;
+  }
+}
+
 // fp32 [rows, C] (ld32) -> bf16 [rows, C] (ld) after the atomics of the query-split path
 __global__ void cvt_f32_bf16_kernel(const float* in0, const float* in1, int64_t ldi, bf16_t* out0, int64_t ldo0, bf16_t* out1, int64_t ldo1,
                                     int rows, int C) {
@@ -906,7 +935,7 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
 #define SMEM_X(D_) (2 * 128 * NSTRH(D_) + 2 * (2 * 64 * NSTRH(D_)) + 512)
     if (dp == 64) { set_smem(attn_bwd_cross_kernel<64>, SMEM_X(64)); hipLaunchKernelGGL(attn_bwd_cross_kernel<64>, gx, dim3(256), SMEM_X(64), s, p); }
     else { set_smem(attn_bwd_cross_kernel<96>, SMEM_X(96)); hipLaunchKernelGGL(attn_bwd_cross_kernel<96>, gx, dim3(256), SMEM_X(96), s, p); }
-    {
+    if (!p.defer_splitsum) {
       int blocks = (int)(((int64_t)krows * C / 2 + 255) / 256);
       if (blocks > 4096) blocks = 4096;
       hipLaunchKernelGGL(attn_splitsum_kernel, dim3(blocks), dim3(256), 0, s, p.dK32, p.dV32, p.qsplit, p.ld32, (bf16_t*)p.dK, p.lddk,
@@ -937,6 +966,14 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
 #define SMEM_DKV(D_) (2 * (2 * 64 * NSTRH(D_) + 512))
   ATTN_DISPATCH(dp, attn_bwd_dkdv_kernel, gk, SMEM_DKV)
   if (p.qsplit > 1) cvt32();
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+
+extern "C" int sdlt_attn_splitsum_batch(const sdlt_splitsum_desc* descs_dev, const int32_t* block_desc_dev, const int32_t* block_first_dev, int32_t n_blocks,
+                                        void* stream) {
+  if (n_blocks <= 0) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_attn_splitsum_batch: n_blocks=%d", n_blocks);
+  hipLaunchKernelGGL(attn_splitsum_batch_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, block_desc_dev, block_first_dev);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }

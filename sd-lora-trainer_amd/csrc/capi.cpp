@@ -27,6 +27,7 @@ extern "C" int sdlt_struct_size(int which) {
     case 6: return (int)sizeof(sdlt_dora_desc);
     case 7: return (int)sizeof(sdlt_dora_wt_desc);
     case 8: return (int)sizeof(sdlt_dora_grad_desc);
+    case 9: return (int)sizeof(sdlt_splitsum_desc);
   }
   return -1;
 }

@@ -317,9 +317,12 @@ def attn_fwd(Q, K, V, Vt, O, L, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=Fals
 
 
 def attn_bwd(Q, K, V, Kt, Qt, O, L, dO, dOt, D, dQ, dK, dV, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=False,
-             qsplit=1, dK32=None, dV32=None, accumulate_dq=False, accumulate_dk=False):
+             qsplit=1, dK32=None, dV32=None, accumulate_dq=False, accumulate_dk=False, defer_splitsum=False):
+    """defer_splitsum (single-pass cross-attention backward): dK / dV stay as per-split fp32 slabs in dK32 / dV32 (layer-owned buffers);
+    a SplitsumPlan over all layers sums them in one launch later."""
     lib = _lib.load()
     p = _attn_params(Q, K, V, B=B, H=H, Nq=Nq, Nk=Nk, Nqp=Nqp, Nkp=Nkp, d=d, scale=scale, causal=causal)
+    p.defer_splitsum = int(defer_splitsum)
     for t in (O, dO, dQ, dK, dV):      # Kt / Qt / dOt: accepted and ignored (see attn_fwd)
         _chk2(t)
     _chk2(L, F32), _chk2(D, F32)
@@ -333,6 +336,30 @@ def attn_bwd(Q, K, V, Kt, Qt, O, L, dO, dOt, D, dQ, dK, dV, *, B, H, Nq, Nk, Nqp
             assert dK32.shape[0] >= qsplit * B * Nkp and dV32.shape[0] >= qsplit * B * Nkp, "dK32/dV32 must hold qsplit slabs"
         p.dK32, p.dV32, p.ld32 = _p(dK32), _p(dV32), _ld(dK32)
     _lib.check(lib.sdlt_attn_bwd(C.byref(p), _stream()), "sdlt_attn_bwd")
+
+
+class SplitsumPlan:
+    """One launch for the partial dK / dV slabs of all cross-attention layers (sdlt_attn_splitsum_batch).
+    items: dict(dK32, dV32 fp32 [nsplit*B*Nkp, C], dK, dV bf16 [B*Nkp, C] (strided ok), nsplit, B, Nk, Nkp, acc0)."""
+
+    def __init__(self, items, device):
+        arr = (_lib.SplitsumDesc * len(items))()
+        counts = []
+        for d, it in zip(arr, items):
+            s0, s1, o0, o1 = it["dK32"], it["dV32"], it["dK"], it["dV"]
+            _chk2(s0, F32), _chk2(s1, F32), _chk2(o0), _chk2(o1)
+            Cw = o0.shape[1]
+            assert Cw % 4 == 0 and _ld(s0) == _ld(s1) and s0.shape[0] >= it["nsplit"] * it["B"] * it["Nkp"]
+            d.s0, d.s1, d.ld32, d.out0, d.ldo0, d.out1, d.ldo1 = _p(s0), _p(s1), _ld(s0), _p(o0), _ld(o0), _p(o1), _ld(o1)
+            d.nsplit, d.B, d.Nk, d.Nkp, d.C, d.acc0 = it["nsplit"], it["B"], it["Nk"], it["Nkp"], Cw, int(bool(it.get("acc0")))
+            d.nblocks = max(1, min(64, (it["B"] * it["Nkp"] * Cw // 2 + 255) // 256))
+            counts.append(d.nblocks)
+        self.keep = items
+        self.descs_dev = _to_dev(arr, device)
+        self.n_blocks, self.bd, self.bf = _block_table(counts, device)
+
+    def run(self):
+        _lib.check(_lib.load().sdlt_attn_splitsum_batch(_p(self.descs_dev), _p(self.bd), _p(self.bf), self.n_blocks, _stream()), "sdlt_attn_splitsum_batch")
 
 
 _GN_WS = {}

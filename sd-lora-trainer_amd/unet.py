@@ -745,13 +745,23 @@ class Attention(_Module):
             # cross-attention: ~160 workgroups, each owning all 77 keys of one head and a range of query tiles; the fp32
             # dK/dV accumulators are adjacent so the kernel side zeroes / converts them with one launch each
             qs = max(2, min((N + 63) // 64, 160 // max(1, self.heads * B)))
-            kv32 = rt.scratch("attn_dkv32", 2 * qs * Mk * C).view(2 * qs * Mk, C)    # partial slabs, consumed inside attn_bwd
+            pre_ = self.hooked and rt.daam_grads is not None and rt.daam_applied and self.daam_batched
+            # (a hooked layer whose score-gradient GEMMs still run per layer reads dk right after this kernel: no deferral then)
+            self._defer_sum = self.kv_batched and fused and self.d <= 96 and CTX_PAD <= 128 and (pre_ or not (self.hooked and rt.daam_grads is not None))
+            if self._defer_sum:      # the slabs of ALL layers are summed by one launch in UNet._cross_kv_backward: layer-owned, not scratch
+                kv32 = self.buf("dkv32", 2 * qs * Mk, C, dtype=F32)
+            else:
+                kv32 = rt.scratch("attn_dkv32", 2 * qs * Mk * C).view(2 * qs * Mk, C)    # partial slabs, consumed inside attn_bwd
             kw = dict(qsplit=qs, dK32=kv32[:qs * Mk], dV32=kv32[qs * Mk:])
+            if self._defer_sum:
+                kw["defer_splitsum"] = True
         pre = self.cross and self.hooked and rt.daam_grads is not None and rt.daam_applied and self.daam_batched
         if pre:     # dq / dk already hold the score side output's gradient (UNet.daam_backward, one batched GEMM per group)
             kw.update(accumulate_dq=True, accumulate_dk=True)
         rt.ops.attn_bwd(q, k, v, None, None, self._b["O"], self._b["L"], dO, None, D, dq, dk, dv,
                         B=B, H=self.heads, Nq=N, Nk=Nk, Nqp=N, Nkp=Nkp, d=self.d, scale=self.scale, **kw)
+        if self.cross and getattr(self, "_defer_sum", False):
+            self._sum_item = dict(dK32=kw["dK32"], dV32=kw["dV32"], dK=dk, dV=dv, nsplit=kw["qsplit"], B=B, Nk=Nk, Nkp=Nkp, acc0=bool(kw.get("accumulate_dk")))
         if self.cross and self.hooked and rt.daam_grads is not None and not pre:
             # backward of the score side output: S = a Q K^T  ->  dQ += a dS K,  dK += a dS^T Q   (shared dS per resolution)
             dS, dSt = rt.daam_grads[N]
@@ -1266,6 +1276,11 @@ class UNet(_Module):
                     items.append(dict(X=dkv, W=st.Wt_d if st.dora else st.Wt, Adown=st.Bt_cat, Bup=st.At_cat, T_out=U, C=part[i]))
                     i += 1
                 self._kv_bwd.append((members, items, rt.ops.GemmBatch(items, rt.device)))
+        if getattr(self, "_sum_plan", None) is None:        # partial dK / dV slabs of every layer -> bf16 dk | dv, one launch
+            items = [a._sum_item for a in self.cross_attns if getattr(a, "_sum_item", None) is not None]
+            self._sum_plan = rt.ops.SplitsumPlan(items, rt.device) if items else False
+        if self._sum_plan:
+            self._sum_plan.run()
         for members, items, batch in self._kv_bwd:
             st, it = members[0].stack, items[0]
             rt.ops.gemm(it["X"], it["W"], it["C"], lora=(it["Adown"], it["Bup"], st.arena.scale, it["T_out"]), lora_group_k=st.N, batch=batch)

@@ -229,7 +229,7 @@ def attn_fwd(Q, K, V, Vt, O, L, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=Fals
 
 
 def attn_bwd(Q, K, V, Kt, Qt, O, L, dO, dOt, D, dQ, dK, dV, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=False,
-             qsplit=1, dK32=None, dV32=None, accumulate_dq=False, accumulate_dk=False):
+             qsplit=1, dK32=None, dV32=None, accumulate_dq=False, accumulate_dk=False, defer_splitsum=False):
     C = H * d
     q = _heads(Q[:, :C], B, Nqp, H, d).detach().clone().requires_grad_(True)
     k = _heads(K[:, :C], B, Nkp, H, d).detach().clone().requires_grad_(True)
@@ -239,11 +239,32 @@ def attn_bwd(Q, K, V, Kt, Qt, O, L, dO, dOt, D, dQ, dK, dV, *, B, H, Nq, Nk, Nqp
     go = _heads(dO[:, :C], B, Nqp, H, d).clone()
     go[:, :, Nq:] = 0
     gq, gk, gv = torch.autograd.grad(o, [q, k, v], go)
+    if defer_splitsum:        # dK / dV stay as fp32 slabs (all of it in slab 0 here); SplitsumPlan sums them into dK / dV later
+        for slab, g in ((dK32, gk), (dV32, gv)):
+            slab.zero_()
+            slab[: B * Nkp, :C].copy_(g.permute(0, 2, 1, 3).reshape(B * Nkp, C))
+        val = gq.permute(0, 2, 1, 3).reshape(B * Nqp, C)
+        dQ[:, :C].copy_(((val + dQ[:, :C].float()) if accumulate_dq else val).to(dQ.dtype))
+        return
     for dst, g, Np, acc in ((dQ, gq, Nqp, accumulate_dq), (dK, gk, Nkp, accumulate_dk), (dV, gv, Nkp, False)):
         val = g.permute(0, 2, 1, 3).reshape(B * Np, C)
         if acc:
             val = val + dst[:, :C].float()
         dst[:, :C].copy_(val.to(dst.dtype))
+
+
+class SplitsumPlan:
+    def __init__(self, items, device):
+        self.items = items
+
+    def run(self):
+        for it in self.items:
+            rows = it["B"] * it["Nkp"]
+            Cw = it["dK"].shape[1]
+            live = (torch.arange(rows) % it["Nkp"] < it["Nk"]).float()[:, None]
+            for slab, out, acc in ((it["dK32"], it["dK"], it.get("acc0")), (it["dV32"], it["dV"], False)):
+                val = slab[: it["nsplit"] * rows].reshape(it["nsplit"], rows, -1)[:, :, :Cw].sum(0) * live
+                out.copy_(((val + out.float()) if acc else val).to(out.dtype))
 
 
 def _gn_cat(x1, x2):
