@@ -90,7 +90,7 @@ def main():
         cv = "" if conv is None else f"conv(s{conv.stride}u{conv.ups}f{conv.flip}t{conv.tr})"
         extra = "".join([" +K2" if kw.get("X2") is not None else "", f" lora{lo[1].shape[1] if kw.get('lora_group_k', 0) == 0 else 16}" if lo is not None else "",
                          f" gN{kw['lora_group_n']}" if kw.get("lora_group_n") else "", f" gK{kw['lora_group_k']}" if kw.get("lora_group_k") else "",
-                         " res" if kw.get("residual") is not None else "", " f32" if out.dtype == torch.float32 else "", " Ct" if kw.get("Ct") is not None else "",
+                         " res" if kw.get("residual") is not None else "", " f32" if (out is not None and out.dtype == torch.float32) else "", " geglu-bwd" if kw.get("geglu_bwd") is not None else "", " geglu" if kw.get("geglu_out") is not None else "", " Ct" if kw.get("Ct") is not None else "",
                          f" x{nb}" if nb > 1 else ""])
         K2 = kw["X2"].shape[1] if kw.get("X2") is not None else 0
         return (Mr, N, K + K2, cv + extra), 2.0 * Mr * N * (K + K2) * nb
