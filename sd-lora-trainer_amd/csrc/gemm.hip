@@ -880,7 +880,7 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
       p.tile = 3;
       if (!p.splitk) {
         const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
-        int sk = !ws ? 1 : (tiles >= 100 ? 1 : (tiles >= 60 ? 3 : 4));
+        int sk = !ws ? 1 : (tiles >= 100 ? 1 : (tiles >= 60 ? (nk >= 24 ? 3 : 1) : 4));   // (60+ tiles and a short K, CLIP-L fc1 / qkv: 10.8 -> 6.9 us unsplit)
         while (sk > 1 && nk / sk < 4) --sk;
         p.splitk = sk;
       }
