@@ -324,3 +324,10 @@ def test_dora_step_and_trajectory_gpu(version, B, kinds, rank):
     from tests.test_real_topology_gpu import TOL_BF16, _bf16_exact, run_step_and_trajectory
     sd = _bf16_exact(U.init_unet_state(U.CONFIGS[version], seed=0))
     run_step_and_trajectory(version, B, 32 if U.CONFIGS[version]["addition"] else 16, sd, kinds, device="cuda:0", tol=TOL_BF16, rank=rank, n_steps=6, dora=True)
+
+
+def test_ti_step_gpu_with_fused_geglu_epilogues(monkeypatch):
+    """The GEGLU epilogues of the feed-forward GEMMs (sdlt_gemm_params.epi_op 1 / 2) are off by default (slower than GEMM +
+    element-wise kernel on the final kernels); SDLT_GEGLU_MIN_C opts in - the whole step with them on, against the same oracle."""
+    monkeypatch.setenv("SDLT_GEGLU_MIN_C", "0")
+    test_ti_step_gpu_matches_oracle("tinyxl", 2, False)
