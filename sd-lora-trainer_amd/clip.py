@@ -11,6 +11,7 @@ Weights use the Hugging Face `CLIPTextModel(WithProjection)` state-dict names.  
 batch (77 valid) so the hidden states can be written straight into the UNet's conditioning buffer.
 """
 import math
+import os
 
 import torch
 
@@ -19,6 +20,10 @@ from .unet import F32, LayerNorm, Linear, StackedLinear, _Module
 
 T_TOKENS = 77
 TP = 128
+
+
+# activation of the CLIP MLP as GEMM epilogues (fc1: act side output, fc2 dX: x act') or as element-wise launches; SDLT_CLIP_ACT_EPI=0 / 1
+ACT_EPILOGUE = os.environ.get("SDLT_CLIP_ACT_EPI", "1") != "0"
 
 
 class _Renamed(dict):
@@ -68,14 +73,21 @@ class ClipLayer(_Module):
         x1 = self.o.forward(O, residual=x)
         # the activation leaves fc1's epilogue (sdlt_gemm_params.epi_op 3), its derivative is the epilogue of fc2's dX GEMM (4)
         a = self.buf("a", M, self.fc1.N)
-        self.fc1.forward(self.ln2.forward(x1), act_out=(self.act_kind, a))
+        if ACT_EPILOGUE:
+            self.fc1.forward(self.ln2.forward(x1), act_out=(self.act_kind, a))
+        else:
+            rt.ops.map_bf16(self.act, self.fc1.forward(self.ln2.forward(x1)), None, a)
         self._B = B
         return self.fc2.forward(a, residual=x1, out=out)
 
     def backward(self, dx2):
         rt, B, D = self.rt, self._B, self.D
         M = B * TP
-        df = self.fc2.backward(dx2, dact_in=(self.act_kind, self.fc1._b["y"]))
+        if ACT_EPILOGUE:
+            df = self.fc2.backward(dx2, dact_in=(self.act_kind, self.fc1._b["y"]))
+        else:
+            da = self.fc2.backward(dx2)
+            df = rt.ops.map_bf16(self.dact, self.fc1._b["y"], da, self.buf("df", *da.shape))
         dx1 = self.ln2.backward(self.fc1.backward(df), dres=dx2)
         dO = self.o.backward(dx1)
         dqkv, (dq, dk, dv) = self.qkv.grad_slices(M)
