@@ -6,11 +6,8 @@ rates, bias corrections) live in a small device buffer that is updated before ea
 """
 import math
 
-import os
-
 import torch
 
-from . import ops as _ops
 from .clip import T_TOKENS, TP
 from .daam import TokenAttentionLoss
 from .ti import TiState
