@@ -221,13 +221,16 @@ class TrainStep:
         self.tok_cond_reg_w = tok_cond_reg_w if text is not None else 0.0
         self.tok_reg_loss, self.tok_reg_norm = z(1), z(1)
         if self.tok_cond_reg_w > 0.0:
-            from .unet import clone_plan
+            from .unet import ArenaView, clone_plan
             assert reg_caption_ids is not None, "tok_cond_reg_w > 0 needs the token ids of the regularisation captions"
-            if text.arena is not None:
-                raise NotImplementedError("tok_cond_reg_w together with text-encoder LoRA")
+            if text.arena is not None and text.arena.dora:
+                raise NotImplementedError("tok_cond_reg_w together with DoRA text-encoder adapters")
             nreg = reg_caption_ids[0].shape[0]
             self.reg_rt = Runtime(dev, nreg, act_dtype=rt.act, ops=rt.ops)
-            self.reg_encoders = [clone_plan(e, self.reg_rt) for e in text.encoders]
+            # text-encoder LoRA: the second pass differentiates through the adapters too - its dA / dB problems live in a view of the arena
+            # and are ADDED to the step's by a second grouped launch
+            self.reg_arena, self._reg_grad_plan = (ArenaView(text.arena) if text.arena is not None else None), None
+            self.reg_encoders = [clone_plan(e, self.reg_rt, arena=self.reg_arena) for e in text.encoders]
             self.reg_ids = [i.to(dev, torch.int64).contiguous() for i in reg_caption_ids]
             self.reg_ctx = rt.zeros(nreg * CTX_PAD, cfg["cross_dim"])
             self.reg_dctx = rt.zeros(nreg * CTX_PAD, cfg["cross_dim"])
@@ -385,6 +388,11 @@ class TrainStep:
         for e, w, g in zip(self.reg_encoders, self.text.widths, self.ti.grad_rows):
             e.backward(self.reg_dctx[:, off:off + w], None, g, accumulate=True)
             off += w
+        if self.reg_arena is not None:
+            if self._reg_grad_plan is None:
+                self._reg_grad_plan = self.rt.ops.LoraGradPlan(self.reg_arena.problems, self.reg_arena.Rp, self.rt.device)
+                self._reg_grad_plan.set_accumulate(True)
+            self._reg_grad_plan.run()
 
     def forward_backward(self):
         self._phase_text_fwd()

@@ -96,20 +96,36 @@ class _Module:
         return t
 
 
-def clone_plan(mod, rt, _memo=None):
+class ArenaView:
+    """An adapter arena as seen by a plan clone: same parameters, shadows and gradient tensors, but its OWN list of LoRA-gradient
+    problems (the clone's dY / T / U buffers), to be run as a second, accumulating grouped launch."""
+
+    def __init__(self, arena):
+        self._arena, self.problems, self.dora_grads = arena, [], []
+
+    def __getattr__(self, k):
+        return getattr(self._arena, k)
+
+
+def clone_plan(mod, rt, _memo=None, arena=None):
     """Structural copy of an execution plan for ANOTHER batch size: the clone shares every weight tensor with `mod` but owns
-    its activation buffers and runs on `rt` (used for the text encoders' second, 4-caption pass of the tok_cond_reg_w term)."""
+    its activation buffers and runs on `rt` (used for the text encoders' second, 4-caption pass of the tok_cond_reg_w term).
+    arena: an ArenaView that replaces the adapter arena in the clone's layers (text-encoder LoRA)."""
     memo = {} if _memo is None else _memo
     if id(mod) in memo:
         return memo[id(mod)]
     c = copy.copy(mod)
     memo[id(mod)] = c
     c.rt, c._b = rt, {}
+    if arena is not None and getattr(c, "arena", None) is not None:
+        c.arena = arena
+    if hasattr(c, "_registered"):
+        c._registered = False
     for k, v in list(vars(c).items()):
         if isinstance(v, _Module):
-            setattr(c, k, clone_plan(v, rt, memo))
+            setattr(c, k, clone_plan(v, rt, memo, arena))
         elif isinstance(v, (list, tuple)) and v and all(isinstance(x, _Module) for x in v):
-            setattr(c, k, type(v)(clone_plan(x, rt, memo) for x in v))
+            setattr(c, k, type(v)(clone_plan(x, rt, memo, arena) for x in v))
     return c
 
 

@@ -109,7 +109,7 @@ def test_train_from_folder_with_tokenizer(tmp_path, monkeypatch, version, disabl
         assert set(emb) == {"clip_l", "clip_g"} and not torch.equal(emb["clip_l"], e0["clip_l"])     # the token rows were trained
 
 
-@pytest.mark.parametrize("kw", [dict(aspect_ratio_bucketing=True), dict(tok_cond_reg_w=0.1, text_encoder_lora_optimizer="adamw")])
+@pytest.mark.parametrize("kw", [dict(aspect_ratio_bucketing=True), dict(tok_cond_reg_w=0.1, text_encoder_lora_optimizer="adamw", use_dora=True)])
 def test_unbuilt_fields_raise(tmp_path, monkeypatch, kw):
     monkeypatch.chdir(tmp_path)
     from sd_lora_trainer_amd import train as T

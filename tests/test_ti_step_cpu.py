@@ -121,9 +121,10 @@ def test_ti_step_matches_oracle(version, B):
         torch.testing.assert_close(enc.table[-NTOK:].float(), p, rtol=1e-5, atol=1e-7)    # gathered table was refreshed
 
 
-@pytest.mark.parametrize("version,B,rank,dora", [("tiny15", 2, 4, False), ("tinyxl", 1, 16, False), ("tiny15", 1, 24, False),     # rank 24: member-wise dX of q|k|v
-                                                 ("tinyxl", 1, 16, True), ("tiny15", 2, 24, True)])
-def test_text_encoder_lora_matches_oracle(version, B, rank, dora):
+@pytest.mark.parametrize("version,B,rank,dora,w_tok", [("tiny15", 2, 4, False, 0.0), ("tinyxl", 1, 16, False, 0.0), ("tiny15", 1, 24, False, 0.0),
+                                                       ("tinyxl", 1, 16, True, 0.0), ("tiny15", 2, 24, True, 0.0),
+                                                       ("tinyxl", 1, 16, False, 2e-3), ("tiny15", 2, 24, False, 2e-3)])    # + tok_cond_reg_w: a second pass through the adapters
+def test_text_encoder_lora_matches_oracle(version, B, rank, dora, w_tok):
     """a21 (`text_encoder_lora_optimizer`, trainer/optimizer.py:157-202): peft LoRA on q/k/v/out_proj of every text-encoder
     layer, trained by its own AdamW next to TI and the UNet LoRA.  Oracle: Hugging Face CLIP called functionally with
     W + (alpha/r) B A in place of the four projection weights, autograd for dA / dB."""
@@ -169,13 +170,20 @@ def test_text_encoder_lora_matches_oracle(version, B, rank, dora):
     n_layers_run = [3 if (not xl or i == 1) else 2 for i in range(len(hf))]            # SDXL CLIP-L: the last layer feeds nothing
     assert len(te_arena.entries) == 4 * sum(n_layers_run)
     text = step_mod.TextStack(rt, encs, pool_mode="first_eos", eos_token_id=EOS, arena=te_arena)
+    tok = list(TRAIN_IDS)
+    caps = [[5, 6, 7] + tok, tok, [5, 6, 7] + tok + [8, 9] + tok, tok + [10] + tok]
+    reg_ids = torch.full((4, 77), EOS, dtype=torch.int64)
+    for r_, c_ in enumerate(caps):
+        reg_ids[r_, 0] = BOS
+        reg_ids[r_, 1:1 + len(c_)] = torch.tensor(c_)
     ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, l1_penalty=0.0, weight_decay=0.0, text=text, n_tokens=NTOK,
-                            token_attention_loss_w=w_ta, ti_std_loss_w=w_std, text_lora_weight_decay=1e-5)
+                            token_attention_loss_w=w_ta, ti_std_loss_w=w_std, text_lora_weight_decay=1e-5,
+                            tok_cond_reg_w=w_tok, reg_caption_ids=[reg_ids] * len(encs) if w_tok else None)
     ts.set_batch(latent, noise, t, mask, time_ids=tid, ids=[ids] * len(encs), caption_token_lists=lists)
     ts.forward_backward()
 
     # ------------------------------------------------------------------ oracle (autograd through merged projections)
-    te_g, te_params, outs = {}, [], []
+    te_g, te_params, outs, routs = {}, [], [], []
     for i, m in enumerate(hf):
         over = {}
         for name, (A, Bm, *mag) in te_lora.items():
@@ -194,6 +202,8 @@ def test_text_encoder_lora_matches_oracle(version, B, rank, dora):
                 te_params += [A, Bm]
             over[key] = merged
         outs.append(functional_call(m, over, kwargs=dict(input_ids=ids, output_hidden_states=True)))
+        if w_tok:
+            routs.append(functional_call(m, over, kwargs=dict(input_ids=reg_ids, output_hidden_states=True)))
     embs = [m.get_input_embeddings().weight for m in hf]
     if xl:
         ctx = torch.cat([outs[0].hidden_states[-2], outs[1].hidden_states[-2]], dim=-1)
@@ -206,7 +216,13 @@ def test_text_encoder_lora_matches_oracle(version, B, rank, dora):
     img_loss = L.diffusion_loss(pred, noise, noisy, mask, acp, t, snr_gamma=5.0)
     ta = L.token_attention_loss(L.daam_stack([s for _, s in daam], 1.0), mask, lists, TRAIN_IDS)
     reg = torch.stack([L.DistributionStats(e.detach()[:-NTOK]).std_loss(e[-NTOK:]) for e in embs]).mean()
-    grads = torch.autograd.grad(img_loss + w_ta * ta + w_std * reg, te_params + embs)
+    total = img_loss + w_ta * ta + w_std * reg
+    if w_tok:      # loss.py:207-211, 241-251: the prompt-norm target on the four trigger captions, through the adapted encoders
+        rctx = torch.cat([routs[0].hidden_states[-2], routs[1].hidden_states[-2]], dim=-1) if xl else routs[0].last_hidden_state
+        tokreg, tok_norm = L.prompt_norm_loss(rctx, 34.5 if xl else 27.8)
+        total = total + w_tok * tokreg
+        torch.testing.assert_close(ts.tok_reg_norm[0], tok_norm.detach(), rtol=1e-4, atol=0)
+    grads = torch.autograd.grad(total, te_params + embs)
     torch.testing.assert_close(ts.loss[0], img_loss.detach(), rtol=1e-4, atol=1e-6)
     got = te_arena.export("grads")
     assert set(got) == set(te_g)
