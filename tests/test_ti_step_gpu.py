@@ -77,8 +77,16 @@ def test_ti_step_gpu_matches_oracle(version, B, concurrent):
     else:
         encs = [clip_mod.ClipTextEncoder(rt, "te1", sds[0], heads=2, act="quick_gelu", mode="last", with_projection=False, n_train=NTOK)]
     text = step_mod.TextStack(rt, encs, pool_mode="first_eos", eos_token_id=EOS, concurrent=concurrent)   # forked encoder streams + per-phase graphs
+    from tests.test_ti_step_cpu import BOS
+    tok = list(TRAIN_IDS)
+    caps = [[5, 6, 7] + tok, tok, [5, 6, 7] + tok + [8, 9] + tok, tok + [10] + tok]
+    reg_ids = torch.full((4, 77), EOS, dtype=torch.int64)
+    for r_, c_ in enumerate(caps):
+        reg_ids[r_, 0] = BOS
+        reg_ids[r_, 1:1 + len(c_)] = torch.tensor(c_)
     ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, l1_penalty=0.0, weight_decay=0.0, text=text, n_tokens=NTOK,
-                            token_attention_loss_w=w_ta, ti_std_loss_w=w_std)
+                            token_attention_loss_w=w_ta, ti_std_loss_w=w_std, tok_cond_reg_w=w_tok,
+                            reg_caption_ids=[reg_ids.cuda()] * len(encs) if w_tok else None)
     ts.set_batch(latent.cuda(), noise.cuda(), t.cuda(), mask.cuda(), time_ids=tid.cuda() if xl else None, ids=[ids] * len(encs),
                  caption_token_lists=lists)
     ts.forward_backward()
@@ -133,8 +141,9 @@ def test_ti_step_gpu_matches_oracle(version, B, concurrent):
         assert ts._cond_cached and dl <= 1e-6 and dp <= 1e-7, f"cached conditioning: loss rel diff {dl}, max parameter diff {dp} (lr 1e-3)"
 
 
-@pytest.mark.parametrize("version,B,rank,dora", [("tiny15", 2, 16, False), ("tinyxl", 2, 8, False), ("tinyxl", 2, 16, True), ("tiny15", 2, 24, True)])
-def test_text_encoder_lora_gpu_matches_oracle(version, B, rank, dora):
+@pytest.mark.parametrize("version,B,rank,dora,w_tok", [("tiny15", 2, 16, False, 0.0), ("tinyxl", 2, 8, False, 0.0), ("tinyxl", 2, 16, True, 0.0), ("tiny15", 2, 24, True, 0.0),
+                                                       ("tinyxl", 2, 16, False, 2e-3)])       # + tok_cond_reg_w: second pass through the adapters, accumulating dA / dB launch
+def test_text_encoder_lora_gpu_matches_oracle(version, B, rank, dora, w_tok):
     """a21: LoRA on q/k/v/out_proj of the text encoders (trainer/optimizer.py:157-202) on the HIP path - fused into the
     stacked q|k|v GEMM (N-grouped forward, K-grouped dX) and the out_proj GEMM - against autograd through Hugging Face
     CLIP with merged projections; then graph replays with all three optimizers live."""
@@ -187,14 +196,22 @@ def test_text_encoder_lora_gpu_matches_oracle(version, B, rank, dora):
                     te_lora[name] = (A, Bm, (w + te_arena.scale * Bm @ A).norm(dim=1) * (1.0 + 0.05 * torch.randn(w.shape[0], generator=gl)))
     te_arena.load(te_lora)
     text = step_mod.TextStack(rt, encs, pool_mode="first_eos", eos_token_id=EOS, arena=te_arena)
+    from tests.test_ti_step_cpu import BOS
+    tok = list(TRAIN_IDS)
+    caps = [[5, 6, 7] + tok, tok, [5, 6, 7] + tok + [8, 9] + tok, tok + [10] + tok]
+    reg_ids = torch.full((4, 77), EOS, dtype=torch.int64)
+    for r_, c_ in enumerate(caps):
+        reg_ids[r_, 0] = BOS
+        reg_ids[r_, 1:1 + len(c_)] = torch.tensor(c_)
     ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, l1_penalty=0.0, weight_decay=0.0, text=text, n_tokens=NTOK,
-                            token_attention_loss_w=w_ta, ti_std_loss_w=w_std)
+                            token_attention_loss_w=w_ta, ti_std_loss_w=w_std, tok_cond_reg_w=w_tok,
+                            reg_caption_ids=[reg_ids.cuda()] * len(encs) if w_tok else None)
     ts.set_batch(latent.cuda(), noise.cuda(), t.cuda(), mask.cuda(), time_ids=tid.cuda() if xl else None, ids=[ids] * len(encs),
                  caption_token_lists=lists)
     ts.forward_backward()
     torch.cuda.synchronize()
 
-    te_params, names, outs = [], [], []
+    te_params, names, outs, routs = [], [], [], []
     for i, m in enumerate(hf):
         over = {}
         for name, (A, Bm, *mag) in te_lora.items():
@@ -211,6 +228,8 @@ def test_text_encoder_lora_gpu_matches_oracle(version, B, rank, dora):
                 merged = (mg / merged.norm(dim=1).detach())[:, None] * merged
             over[key] = merged
         outs.append(functional_call(m, over, kwargs=dict(input_ids=ids, output_hidden_states=True)))
+        if w_tok:
+            routs.append(functional_call(m, over, kwargs=dict(input_ids=reg_ids, output_hidden_states=True)))
     embs = [m.get_input_embeddings().weight for m in hf]
     if xl:
         ctx = torch.cat([outs[0].hidden_states[-2], outs[1].hidden_states[-2]], dim=-1)
@@ -223,7 +242,13 @@ def test_text_encoder_lora_gpu_matches_oracle(version, B, rank, dora):
     img_loss = L.diffusion_loss(pred, noise, noisy, mask, acp, t, snr_gamma=5.0)
     ta = L.token_attention_loss(L.daam_stack([s for _, s in daam], 1.0), mask, lists, TRAIN_IDS)
     reg = torch.stack([L.DistributionStats(e.detach()[:-NTOK]).std_loss(e[-NTOK:]) for e in embs]).mean()
-    grads = torch.autograd.grad(img_loss + w_ta * ta + w_std * reg, te_params + embs)
+    total = img_loss + w_ta * ta + w_std * reg
+    if w_tok:
+        rctx = torch.cat([routs[0].hidden_states[-2], routs[1].hidden_states[-2]], dim=-1) if xl else routs[0].last_hidden_state
+        tokreg, tok_norm = L.prompt_norm_loss(rctx, 34.5 if xl else 27.8)
+        total = total + w_tok * tokreg
+        assert abs(float(ts.tok_reg_norm) - float(tok_norm)) <= 1e-2 * float(tok_norm)
+    grads = torch.autograd.grad(total, te_params + embs)
     assert abs(float(ts.loss) - float(img_loss)) <= 2e-2 * float(img_loss)
     got = te_arena.export("grads")
     got_flat = torch.cat([x.reshape(-1) for n in names for x in got[n]])
