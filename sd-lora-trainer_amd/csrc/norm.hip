@@ -261,19 +261,36 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(CatIn in, const bf16_
 // one wave per row; lane handles chunks lane, lane+64, ... (C/8 chunks; C <= 2048)
 constexpr int LN_MAXCH = 4;
 
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, int64_t ldx, int M, int C, const float* gamma,
-                                                      const float* beta, float eps, bf16_t* y, int64_t ldy, float* stats) {
+// Every global load of a row (x, gamma, beta / x, dy, gamma, the residual gradient) is ISSUED before the first reduction: the kernels are
+// one dependent chain per wave (load -> two wave reductions -> store), and a second round of loads after the reductions cost a second
+// L2 / HBM latency per launch - ~600 launches per SDXL step.
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, int64_t ldx, int M, int C, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps, bf16_t* __restrict__ y, int64_t ldy,
+                                                      float* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int nch = C >> 3;
+  uint4 xr[LN_MAXCH];
+  f32x4 g4[LN_MAXCH][2], b4[LN_MAXCH][2];
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    int ch = lane + i * 64;
+    if (ch < nch) {
+      xr[i] = *(const uint4*)(x + (int64_t)row * ldx + ch * 8);
+      g4[i][0] = *(const f32x4*)(gamma + ch * 8); g4[i][1] = *(const f32x4*)(gamma + ch * 8 + 4);
+      b4[i][0] = *(const f32x4*)(beta + ch * 8); b4[i][1] = *(const f32x4*)(beta + ch * 8 + 4);
+    }
+  }
   float v[LN_MAXCH][8];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXCH; ++i) {
     int ch = lane + i * 64;
     if (ch < nch) {
-      load8(x + (int64_t)row * ldx + ch * 8, v[i]);
+      const uint32_t w[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[i][2 * j] = bf2f(w[j] & 0xffff); v[i][2 * j + 1] = bf2f(w[j] >> 16); }
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += v[i][j];
     }
@@ -296,19 +313,32 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, int64_t ld
     if (ch < nch) {
       float o[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * gamma[ch * 8 + j] + beta[ch * 8 + j];
+      for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * g4[i][j >> 2][j & 3] + b4[i][j >> 2][j & 3];
       store8(y + (int64_t)row * ldy + ch * 8, o);
     }
   }
 }
 
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* x, int64_t ldx, const bf16_t* dy, int64_t lddy, int M,
-                                                      int C, const float* gamma, const float* stats, const bf16_t* dres,
-                                                      int64_t lddres, bf16_t* dx, int64_t lddx) {
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t lddy, int M,
+                                                      int C, const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                      const bf16_t* dres, int64_t lddres, bf16_t* dx, int64_t lddx) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int nch = C >> 3;
+  uint4 xr[LN_MAXCH], dr[LN_MAXCH], rr[LN_MAXCH];         // (dres may alias dx: read here, before any store of this row - each wave owns its row)
+  f32x4 g4[LN_MAXCH][2];
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    int ch = lane + i * 64;
+    rr[i] = make_uint4(0, 0, 0, 0);
+    if (ch < nch) {
+      xr[i] = *(const uint4*)(x + (int64_t)row * ldx + ch * 8);
+      dr[i] = *(const uint4*)(dy + (int64_t)row * lddy + ch * 8);
+      g4[i][0] = *(const f32x4*)(gamma + ch * 8); g4[i][1] = *(const f32x4*)(gamma + ch * 8 + 4);
+      if (dres) rr[i] = *(const uint4*)(dres + (int64_t)row * lddres + ch * 8);
+    }
+  }
   const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
   float xh[LN_MAXCH][8], dxh[LN_MAXCH][8];
   float s1 = 0.f, s2 = 0.f;
@@ -316,13 +346,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* x, int64_t ld
   for (int i = 0; i < LN_MAXCH; ++i) {
     int ch = lane + i * 64;
     if (ch < nch) {
-      float v[8], d[8];
-      load8(x + (int64_t)row * ldx + ch * 8, v);
-      load8(dy + (int64_t)row * lddy + ch * 8, d);
+      const uint32_t xw[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w}, dw[4] = {dr[i].x, dr[i].y, dr[i].z, dr[i].w};
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        xh[i][j] = (v[j] - mean) * rstd;
-        dxh[i][j] = d[j] * gamma[ch * 8 + j];
+        const float vx = bf2f((j & 1) ? (xw[j >> 1] >> 16) : (xw[j >> 1] & 0xffff));
+        const float vd = bf2f((j & 1) ? (dw[j >> 1] >> 16) : (dw[j >> 1] & 0xffff));
+        xh[i][j] = (vx - mean) * rstd;
+        dxh[i][j] = vd * g4[i][j >> 2][j & 3];
         s1 += dxh[i][j]; s2 += dxh[i][j] * xh[i][j];
       }
     }
@@ -333,14 +363,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* x, int64_t ld
   for (int i = 0; i < LN_MAXCH; ++i) {
     int ch = lane + i * 64;
     if (ch < nch) {
+      const uint32_t rw[4] = {rr[i].x, rr[i].y, rr[i].z, rr[i].w};
       float o[8];
-      if (dres) load8(dres + (int64_t)row * lddres + ch * 8, o);
-      else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] += rstd * (dxh[i][j] - s1 - xh[i][j] * s2);
+      for (int j = 0; j < 8; ++j)
+        o[j] = bf2f((j & 1) ? (rw[j >> 1] >> 16) : (rw[j >> 1] & 0xffff)) + rstd * (dxh[i][j] - s1 - xh[i][j] * s2);
       store8(dx + (int64_t)row * lddx + ch * 8, o);
     }
   }

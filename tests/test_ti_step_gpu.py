@@ -77,16 +77,8 @@ def test_ti_step_gpu_matches_oracle(version, B, concurrent):
     else:
         encs = [clip_mod.ClipTextEncoder(rt, "te1", sds[0], heads=2, act="quick_gelu", mode="last", with_projection=False, n_train=NTOK)]
     text = step_mod.TextStack(rt, encs, pool_mode="first_eos", eos_token_id=EOS, concurrent=concurrent)   # forked encoder streams + per-phase graphs
-    from tests.test_ti_step_cpu import BOS
-    tok = list(TRAIN_IDS)
-    caps = [[5, 6, 7] + tok, tok, [5, 6, 7] + tok + [8, 9] + tok, tok + [10] + tok]
-    reg_ids = torch.full((4, 77), EOS, dtype=torch.int64)
-    for r_, c_ in enumerate(caps):
-        reg_ids[r_, 0] = BOS
-        reg_ids[r_, 1:1 + len(c_)] = torch.tensor(c_)
     ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, l1_penalty=0.0, weight_decay=0.0, text=text, n_tokens=NTOK,
-                            token_attention_loss_w=w_ta, ti_std_loss_w=w_std, tok_cond_reg_w=w_tok,
-                            reg_caption_ids=[reg_ids.cuda()] * len(encs) if w_tok else None)
+                            token_attention_loss_w=w_ta, ti_std_loss_w=w_std)
     ts.set_batch(latent.cuda(), noise.cuda(), t.cuda(), mask.cuda(), time_ids=tid.cuda() if xl else None, ids=[ids] * len(encs),
                  caption_token_lists=lists)
     ts.forward_backward()
