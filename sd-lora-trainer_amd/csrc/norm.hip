@@ -146,10 +146,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(CatIn in, int HW, int C, 
                                                         const float* gamma, const float* beta, float eps,
                                                         bf16_t* y, int64_t ldy) {
   __shared__ float stats[G * 2];
-  gn_combine_partials(C, ws, stats, stats_out);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z;
   const int c0 = blockIdx.x * 64 + (lane & 7) * 8;
+  // per-channel parameters and the first row are requested BEFORE the statistics are combined (one memory latency instead of three
+  // in a row: partial rows -> gamma / beta -> x); the row loop keeps the next row's load in flight
+  float gm[8], bt[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { gm[j] = gamma[c0 + j]; bt[j] = beta[c0 + j]; }
+  const int rstep = gridDim.y * 32;
+  int r = blockIdx.y * 32 + wave * 8 + (lane >> 3);
+  uint4 xn = make_uint4(0, 0, 0, 0);
+  if (r < HW) xn = *(const uint4*)in.at((int64_t)b * HW + r, c0);
+  gn_combine_partials(C, ws, stats, stats_out);
   const int cpg = C / G;
   const float inv_n = 1.0f / ((float)HW * (float)cpg);
   float sc[8], sh[8];
@@ -159,16 +168,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(CatIn in, int HW, int C, 
     float mean = stats[g * 2] * inv_n;
     float var = fmaxf(stats[g * 2 + 1] * inv_n - mean * mean, 0.f);
     float rstd = rsqrtf(var + eps);
-    sc[j] = rstd * gamma[c0 + j];
-    sh[j] = beta[c0 + j] - mean * sc[j];
+    sc[j] = rstd * gm[j];
+    sh[j] = bt[j] - mean * sc[j];
   }
-  for (int r = blockIdx.y * 32 + wave * 8 + (lane >> 3); r < HW; r += gridDim.y * 32) {
+  while (r < HW) {
+    const uint4 xc = xn;
+    const int64_t row = (int64_t)b * HW + r;
+    r += rstep;
+    if (r < HW) xn = *(const uint4*)in.at((int64_t)b * HW + r, c0);
+    const uint32_t w[4] = {xc.x, xc.y, xc.z, xc.w};
     float v[8];
-    int64_t row = (int64_t)b * HW + r;
-    load8(in.at(row, c0), v);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float z = v[j] * sc[j] + sh[j];
+      float z = bf2f((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffff)) * sc[j] + sh[j];
       v[j] = SILU ? silu_f(z) : z;
     }
     store8(y + row * ldy + c0, v);
@@ -218,12 +230,12 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(CatIn in, const bf16_
                                                             const float* beta, float eps, const bf16_t* dres, int64_t lddres,
                                                             bf16_t* dx, int64_t lddx) {
   __shared__ float bstats[G * 2];
-  gn_combine_partials(C, ws, bstats, bstats_out);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z;
   const int c0 = blockIdx.x * 64 + (lane & 7) * 8;
   const int cpg = C / G;
   const float inv_n = 1.0f / ((float)HW * (float)cpg);
+  // (as gn_apply_kernel: parameters, forward statistics and the first row's three tiles are in flight while the partial sums are combined)
   float mean[8], rstd[8], gm[8], bt[8], m1[8], m2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -232,26 +244,43 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(CatIn in, const bf16_
     float var = fmaxf(stats[(b * G + g) * 2 + 1] * inv_n - mean[j] * mean[j], 0.f);
     rstd[j] = rsqrtf(var + eps);
     gm[j] = gamma[c0 + j]; bt[j] = beta[c0 + j];
+  }
+  const int rstep = gridDim.y * 32;
+  int r = blockIdx.y * 32 + wave * 8 + (lane >> 3);
+  uint4 xn = make_uint4(0, 0, 0, 0), dn = xn, on = xn;
+  if (r < HW) {
+    const int64_t row = (int64_t)b * HW + r;
+    xn = *(const uint4*)in.at(row, c0);
+    dn = *(const uint4*)(dy + row * lddy + c0);
+    if (dres) on = *(const uint4*)(dres + row * lddres + c0);
+  }
+  gn_combine_partials(C, ws, bstats, bstats_out);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int g = (c0 + j) / cpg;
     m1[j] = bstats[g * 2] * inv_n;
     m2[j] = bstats[g * 2 + 1] * inv_n;
   }
-  for (int r = blockIdx.y * 32 + wave * 8 + (lane >> 3); r < HW; r += gridDim.y * 32) {
-    float v[8], d[8], o[8];
-    int64_t row = (int64_t)b * HW + r;
-    load8(in.at(row, c0), v);
-    load8(dy + row * lddy + c0, d);
-    if (dres) load8(dres + row * lddres + c0, o);
-    else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = 0.f;
+  while (r < HW) {
+    const uint4 xc = xn, dc = dn, oc = on;
+    const int64_t row = (int64_t)b * HW + r;
+    r += rstep;
+    if (r < HW) {      // (dres may alias dx: a row is read before it is written, and rows are disjoint between iterations)
+      const int64_t nrow = (int64_t)b * HW + r;
+      xn = *(const uint4*)in.at(nrow, c0);
+      dn = *(const uint4*)(dy + nrow * lddy + c0);
+      if (dres) on = *(const uint4*)(dres + nrow * lddres + c0);
     }
+    const uint32_t xw[4] = {xc.x, xc.y, xc.z, xc.w}, dw[4] = {dc.x, dc.y, dc.z, dc.w}, ow[4] = {oc.x, oc.y, oc.z, oc.w};
+    float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float xh = (v[j] - mean[j]) * rstd[j];
-      float dz = d[j];
+      const float v = bf2f((j & 1) ? (xw[j >> 1] >> 16) : (xw[j >> 1] & 0xffff));
+      float dz = bf2f((j & 1) ? (dw[j >> 1] >> 16) : (dw[j >> 1] & 0xffff));
+      const float xh = (v - mean[j]) * rstd[j];
       if (SILU) dz *= dsilu_f(xh * gm[j] + bt[j]);
-      float dxh = dz * gm[j];
-      o[j] += rstd[j] * (dxh - m1[j] - xh * m2[j]);
+      const float dxh = dz * gm[j];
+      o[j] = bf2f((j & 1) ? (ow[j >> 1] >> 16) : (ow[j >> 1] & 0xffff)) + rstd[j] * (dxh - m1[j] - xh * m2[j]);
     }
     store8(dx + row * lddx + c0, o);
   }
