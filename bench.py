@@ -216,6 +216,49 @@ def train_loop_measure(args):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def relaunch_ranks(n, argv, launch_test=False):
+    """`python bench.py --gpus N` outside a launcher: start N ranks of this script, one per GPU, under torch.distributed.run on this
+    node (the job-parallel sweep of /root/reference scripts/create_hyperparam_sweep.py:135-152 is N processes as well) and pass
+    their exit code on.  Fails loudly when the node has fewer than N GPUs - never a silent 1-GPU number under an N-GPU flag."""
+    import socket
+    import subprocess
+    if not launch_test:
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit(f"bench.py --gpus {n}: this node shows {have} GPU(s); refusing to report an {n}-GPU figure")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def launch_test_rank(args):
+    """`--launch-test` (CPU, gloo): every rank runs the bench's timing protocol - barrier, K 'steps', barrier, MAX over ranks - on a
+    sleep instead of the workload and rank 0 prints the JSON skeleton.  Checks the launcher and the multi-rank contract of the line
+    (n_gpus, whole-job value, parallelism) where there is no GPU; never a measurement."""
+    from sd_lora_trainer_amd import parallel
+    rank, world, _ = parallel.init_distributed("gloo")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    parallel.barrier_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (rank + 1))
+    parallel.barrier_sync()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0)
+    if rank == 0:
+        print(json.dumps({"metric": "launch test (no workload)", "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "scaling": "weak",
+                          "config": {"workload": "sleep", "parallelism": f"job-parallel x{world} ({world} rank(s), no collective)"}}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,7 +281,17 @@ def main():
     ap.add_argument("--train-loop-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--full-ft", action="store_true", help="full-UNet fine-tune (BASELINE configs[4], train_configs/full_finetuning_example.json: "
                     "SDXL 512 px, batch 4 per GPU, AdamW over every UNet parameter); data parallel with one gradient all-reduce per step when --gpus > 1")
+    ap.add_argument("--launch-test", action="store_true", help=argparse.SUPPRESS)            # tests/test_parallel_cpu.py: launcher + timing protocol on CPU
     args = ap.parse_args()
+    world_env = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if args.gpus > 1 and world_env == 0:
+        # not under a launcher: spawn the N ranks ourselves (the driver's `torch.distributed.run ... bench.py --gpus N` sets WORLD_SIZE)
+        sys.exit(relaunch_ranks(args.gpus, sys.argv[1:], launch_test=args.launch_test))
+    if world_env and world_env != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world_env}: the line would misreport n_gpus")
+    if args.launch_test:
+        launch_test_rank(args)
+        return
     if args.cpu_baseline_only:          # child of the default run: prints one JSON object per completed measurement
         version = args.config
         res = args.res or (1024 if "xl" in version else 512)

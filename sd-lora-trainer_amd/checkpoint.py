@@ -37,14 +37,19 @@ def kohya_text_key(module_path: str) -> str:
     raise ValueError(f"not a text-encoder module: {module_path}")
 
 
-def lora_to_kohya(lora_dict, dtype=torch.float16, key=kohya_key):
-    """lora_dict: module -> (A, B) or (A, B, magnitude) in peft layout (LoraArena.export()).  Returns the kohya state dict."""
+DTYPES = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}
+
+
+def lora_to_kohya(lora_dict, dtype=torch.bfloat16, key=kohya_key):
+    """lora_dict: module -> (A, B) or (A, B, magnitude) in peft layout (LoraArena.export()).  Returns the kohya state dict.
+    dtype: the reference saves the adapter tensors as they are trained, i.e. in `config.weight_type` (bf16 by default, config.py:99;
+    peft 0.10 creates the adapters in the base layer's dtype); `.alpha` is diffusers' `torch.tensor(len(lora_down))`: a 0-dim int64."""
     sd = {}
     for mod, (A, B, *m) in lora_dict.items():
         k = key(mod)
         sd[k + ".lora_down.weight"] = A.detach().to(dtype).contiguous()
         sd[k + ".lora_up.weight"] = B.detach().to(dtype).contiguous()
-        sd[k + ".alpha"] = torch.tensor(float(A.shape[0]))
+        sd[k + ".alpha"] = torch.tensor(int(A.shape[0]))
         if m:
             sd[k + ".dora_scale"] = m[0].detach().to(dtype).contiguous()
     return sd
@@ -67,17 +72,20 @@ def save_checkpoint(output_dir, global_step, arena, ti_rows, token_dict, name, p
     os.makedirs(output_dir, exist_ok=True)
     name = remove_delimiter_characters(name)
     files = {}
+    # every tensor leaves in the training dtype of the reference (`weight_type`, bf16 unless the config says otherwise): the token rows
+    # are rows of the text encoders' own tables there (embedding_handler.py:401-422), the adapters peft modules of a bf16 UNet
+    dtype = DTYPES[getattr(config, "weight_type", None) or "bf16"]
     if ti_rows:
-        emb = {txt_encoder_keys[i]: r.detach().float().cpu().contiguous() for i, r in enumerate(ti_rows)}
+        emb = {txt_encoder_keys[i]: r.detach().to(dtype).cpu().contiguous() for i, r in enumerate(ti_rows)}
         files["embeddings"] = os.path.join(output_dir, f"{name}_{pretrained_model_version}_embeddings.safetensors")
         save_file(emb, files["embeddings"])
     with open(os.path.join(output_dir, "special_params.json"), "w") as f:
         json.dump(token_dict, f)
     if arena is not None:
         files["lora"] = os.path.join(output_dir, f"{name}_{pretrained_model_version}_lora.safetensors")
-        sd = lora_to_kohya(arena.export())
+        sd = lora_to_kohya(arena.export(), dtype=dtype)
         if text_arena is not None:
-            sd.update(lora_to_kohya(text_arena.export(), key=kohya_text_key))
+            sd.update(lora_to_kohya(text_arena.export(), dtype=dtype, key=kohya_text_key))
         save_file(sd, files["lora"])
         # adapter_config.json (peft `save_pretrained`, checkpoint.py:175) - the fields the reference's loader reads
         with open(os.path.join(output_dir, "adapter_config.json"), "w") as f:
@@ -87,7 +95,11 @@ def save_checkpoint(output_dir, global_step, arena, ti_rows, token_dict, name, p
         # is_lora == False (checkpoint.py:210-212): `unet.save_pretrained(output_dir)` = the whole fine-tuned UNet under its
         # diffusers parameter names in diffusion_pytorch_model.safetensors
         files["unet"] = os.path.join(output_dir, "diffusion_pytorch_model.safetensors")
-        save_file({k: v.to(torch.float16).contiguous() for k, v in unet_weights.export().items()}, files["unet"])
+        save_file({k: v.to(dtype).contiguous() for k, v in unet_weights.export().items()}, files["unet"])
+        # ... and its config.json (`ModelMixin.save_pretrained` -> `save_config`): what `UNet2DConditionModel.from_pretrained(output_dir)` reads
+        from . import topology
+        with open(os.path.join(output_dir, "config.json"), "w") as f:
+            json.dump(topology.diffusers_unet_config(topology.CONFIGS[pretrained_model_version]), f, indent=2, sort_keys=True)
     if config is not None:
         config.save_as_json(os.path.join(output_dir, "training_args.json"))
     return files

@@ -45,6 +45,25 @@ def zero_page(device):
 
 _workspaces = {}
 _ws_owner = None
+_gn_owner = None
+
+
+class norm_workspace_owner:
+    """`with norm_workspace_owner(key):` - the GroupNorm / column-sum reductions enqueued inside use `key`'s scratch.  These only run on a
+    job's MAIN stream, so the scope is set for every job unconditionally - also for jobs whose text encoders fork onto side streams and
+    therefore keep per-stream split-K workspaces (two such jobs captured on torch's shared capture stream would otherwise bake the same
+    partial-sum rows into both graphs)."""
+
+    def __init__(self, key):
+        self.key = key
+
+    def __enter__(self):
+        global _gn_owner
+        self.prev, _gn_owner = _gn_owner, self.key
+
+    def __exit__(self, *a):
+        global _gn_owner
+        _gn_owner = self.prev
 
 
 class workspace_owner:
@@ -368,7 +387,8 @@ _GN_WS = {}
 def gn_workspace(device):
     """Scratch of the deterministic GroupNorm reductions (per-block partial sums + one counter per batch element), one per
     (device, workspace owner): only live inside a call, but two jobs replaying their graphs concurrently must not share it."""
-    key = (device, ("owner", _ws_owner) if _ws_owner is not None else torch.cuda.current_stream(device).cuda_stream)
+    owner = _ws_owner if _ws_owner is not None else _gn_owner
+    key = (device, ("owner", owner) if owner is not None else torch.cuda.current_stream(device).cuda_stream)
     ws = _GN_WS.get(key)
     if ws is None:
         ws = (torch.empty(1 << 20, dtype=F32, device=device), torch.zeros(256, dtype=torch.int32, device=device))

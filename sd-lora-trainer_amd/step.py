@@ -172,6 +172,11 @@ class TrainStep:
             # backward (fullft.WeightTrainer.flush(bucket=i)), each bucket's all-reduce starts as soon as its gradients exist
             self.bucketed = self.world > 1 and grad_accum == 1
             unet.trainer.defer_flush = self.bucketed
+            if self.world > 1 and (optimizer == "prodigy" or (text is not None and ti_optimizer == "prodigy")):
+                raise NotImplementedError("data-parallel full fine-tune with Prodigy: its d-estimate is not scale free, the summed gradients would "
+                                          "need their own normalisation - use AdamW / AdamW8bit (full_finetuning_example.json does)")
+            if self.world > 1 and text is not None and text.arena is not None:
+                raise NotImplementedError("data-parallel full fine-tune with text-encoder LoRA (the adapter gradients are not exchanged)")
         self.text, self.ta_w, self.ti_wd = text, token_attention_loss_w, ti_weight_decay
         self.ti = TiState(rt, text.encoders, n_tokens, ti_std_loss_w) if text is not None else None
         self.ta = TokenAttentionLoss(rt, n_tokens) if text is not None else None
@@ -289,7 +294,8 @@ class TrainStep:
         rows = [[lr, b1, b2, self.eps, self.wd, *bc, self.l1_penalty / n, 1.0 / self.world] if self.prodigy is None
                 else self.prodigy.hyper_row(lr, self.l1_penalty / n)]
         if self.ti is not None:
-            rows.append([lr_ti, b1, b2, self.eps, self.ti_wd, *bc, 0.0, 1.0] if self.prodigy_ti is None
+            # data parallel: the ranks see different captions, so the token-row gradients are exchanged too (summed; mean via the scale)
+            rows.append([lr_ti, b1, b2, self.eps, self.ti_wd, *bc, 0.0, 1.0 / self.world] if self.prodigy_ti is None
                         else self.prodigy_ti.hyper_row(lr_ti, 0.0))
         dsts = [self.hyper] + ([self.ti.hyper] if self.ti is not None else [])
         if self.te_arena is not None:
@@ -418,6 +424,8 @@ class TrainStep:
         if self.world > 1 and not getattr(self, "bucketed", False):
             import torch.distributed as dist
             dist.all_reduce(self.group.grads, group=self.pg)
+            if self.ti is not None:
+                dist.all_reduce(self.ti.grads, group=self.pg)
 
     def flush_and_reduce(self, flush_fns=None):
         """Data-parallel full fine-tune, the exchange step of the path: the deferred weight-gradient plan runs bucket
@@ -428,6 +436,8 @@ class TrainStep:
         import torch.distributed as dist
         tr = self.group
         works = []
+        if self.ti is not None:      # token-row gradients (a few KB): complete after the backward graph, exchanged beside the first bucket
+            works.append(dist.all_reduce(self.ti.grads, group=self.pg, async_op=True))
         for b, (o0, o1) in enumerate(tr.buckets):
             (flush_fns[b] if flush_fns is not None else (lambda b=b: tr.flush(bucket=b)))()
             works.append(dist.all_reduce(tr.grads[o0:o1], group=self.pg, async_op=True))
@@ -555,9 +565,11 @@ class TrainStep:
     def _ws(self):
         """Scope in which this job's GEMMs use their own split-K workspace (ops.workspace_owner); a no-op for the CPU emulation."""
         own = getattr(self.rt.ops, "workspace_owner", None)
-        if own is None or (self.text is not None and self.text.concurrent):      # forked encoders keep one workspace per stream
+        if own is None:
             import contextlib
             return contextlib.nullcontext()
+        if self.text is not None and self.text.concurrent:      # forked encoders keep one split-K workspace per stream; the norm scratch is per job
+            return self.rt.ops.norm_workspace_owner(id(self))
         return own(id(self))
 
     def capture(self, warmup=2):

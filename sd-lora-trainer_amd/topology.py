@@ -25,6 +25,29 @@ CONFIGS = {
                    scaling_factor=0.13025),
 }
 TIME_DIM_MULT = 4
+
+
+def diffusers_unet_config(cfg):
+    """The topology as the `config.json` diffusers writes beside a saved UNet2DConditionModel (`save_pretrained`, trainer/checkpoint.py:210-212)
+    - the constructor arguments that differ between SD1.5 and SDXL plus the shared ones [3P-unverified: diffusers 0.29.2 field names]."""
+    boc = list(cfg["block_out_channels"])
+    xl = bool(cfg["addition"])
+    heads = list(cfg["heads"])
+    out = {
+        "_class_name": "UNet2DConditionModel", "_diffusers_version": "0.29.2", "act_fn": "silu", "in_channels": cfg["in_channels"],
+        "out_channels": cfg["out_channels"], "block_out_channels": boc, "layers_per_block": cfg["layers_per_block"],
+        "down_block_types": ["CrossAttnDownBlock2D" if a else "DownBlock2D" for a in cfg["down_has_attn"]],
+        "up_block_types": ["CrossAttnUpBlock2D" if a else "UpBlock2D" for a in cfg["up_has_attn"]],
+        "mid_block_type": "UNetMidBlock2DCrossAttn", "cross_attention_dim": cfg["cross_dim"], "norm_num_groups": 32, "norm_eps": 1e-5,
+        "center_input_sample": False, "flip_sin_to_cos": True, "freq_shift": 0, "downsample_padding": 1, "sample_size": 128 if xl else 64,
+        "use_linear_projection": bool(cfg["linear_proj"]), "upcast_attention": None if xl else False, "resnet_time_scale_shift": "default",
+        # diffusers keeps the head COUNT under the historical name attention_head_dim (SD1.5: 8 heads everywhere, SDXL: 5 / 10 / 20)
+        "attention_head_dim": heads if len(set(heads)) > 1 else heads[0],
+        "transformer_layers_per_block": list(cfg["transformer_layers"]) if xl else 1,
+        "addition_embed_type": "text_time" if xl else None, "addition_time_embed_dim": cfg.get("addition_time_embed_dim") if xl else None,
+        "projection_class_embeddings_input_dim": cfg.get("proj_class_in") if xl else None,
+    }
+    return out
 LORA_TARGET_SUFFIXES = ("to_k", "to_q", "to_v", "to_out.0", "conv2")  # trainer/optimizer.py:84
 
 

@@ -282,17 +282,28 @@ class Renderer:
         self.decoder = V.VaeDecoder(M.Runtime(dev, 1), models.vae_state())
         xl = bool(cfg["addition"])
         self.encoders = []
+        # text-encoder LoRA (text_encoder_lora_optimizer): the reference renders with the pipe's own peft-wrapped text encoders
+        # (inference.py:345-356), so the inference encoders carry the same adapters, refreshed from the training arena in sync()
+        self.te_arena = None
+        if models.text.arena is not None:
+            self.te_arena = M.LoraArena(self.rt, config.text_encoder_lora_rank, config.lora_alpha_multiplier, problems=[], dora=config.use_dora)
         for i, kd in enumerate(models.kinds):
             c = topology.CLIP_CONFIGS[kd]
             self.encoders.append(CL.ClipTextEncoder(self.rt, f"rte{i + 1}", models.clip_state(i), heads=c["heads"], act=c["act"],
-                                                    mode="penultimate" if xl else "last", with_projection=bool(c["proj"]), n_train=config.n_tokens))
-        self.text = S.TextStack(self.rt, self.encoders, pool_mode="argmax")
+                                                    mode="penultimate" if xl else "last", with_projection=bool(c["proj"]), n_train=config.n_tokens,
+                                                    arena=self.te_arena, lora_prefix="text_encoder." if i == 0 else "text_encoder_2."))
+        if self.te_arena is not None:
+            self.te_arena.finalize()
+        self.text = S.TextStack(self.rt, self.encoders, pool_mode="argmax", arena=self.te_arena)
         self.ctx = self.rt.zeros(2 * M.CTX_PAD, cfg["cross_dim"])
 
     def sync(self):
         """Current adapters and token rows of the training instance -> the inference instance."""
         self.unet.arena.params.copy_(self.train_unet.arena.params)
         self.unet.arena.refresh_shadows()
+        if self.te_arena is not None:
+            self.te_arena.params.copy_(self.models.text.arena.params)
+            self.te_arena.refresh_shadows()
         n = self.config.n_tokens
         for dst, src in zip(self.encoders, self.models.encoders):
             dst.table[dst.V - n:].copy_(src.table[src.V - n:])
@@ -321,7 +332,9 @@ class Renderer:
         embeds, used = [], []
         for p in raw:
             lora_p, zero_p = P.prompt_pair(p, config.token_dict, trig, config.name, config.concept_mode, use_lora=not config.disable_ti)
-            e, _ = SM.blend_conditions(self.encode(zero_p, P.NEGATIVE_PROMPT), self.encode(lora_p, P.NEGATIVE_PROMPT), config.sample_imgs_lora_scale)
+            # render_images passes token_scale = 0 with disable_ti (inference.py:289-385): the conditioning is the zero prompt's alone
+            e, _ = SM.blend_conditions(self.encode(zero_p, P.NEGATIVE_PROMPT), self.encode(lora_p, P.NEGATIVE_PROMPT), config.sample_imgs_lora_scale,
+                                       token_scale=0.0 if config.disable_ti else None)
             embeds.append(e)
             used.append(lora_p)
         size = config.validation_img_size
@@ -377,7 +390,11 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
     w, h = config.train_img_size[0] // 8, config.train_img_size[1] // 8
     cache = load_data(config, models, rt, h, w)
     n_img = (cache["posterior"] if "posterior" in cache else cache["latents"]).shape[0]
-    steps_per_epoch = math.ceil(n_img / B)                               # DataLoader(drop_last=False): main.py:200-207
+    # DataLoader(drop_last=False): main.py:200-207.  Data parallel: every rank takes ceil(n_img / world) samples of the shared shuffle
+    # (DistributedSampler semantics: the permutation wraps around to a multiple of world), so ALL ranks run the same number of steps -
+    # every step issues collectives and the checkpoint a barrier - and max_train_steps counts optimizer steps, not samples
+    shard = math.ceil(n_img / world) if ddp else n_img
+    steps_per_epoch = math.ceil(shard / B)
     config.num_train_epochs = math.ceil(config.max_train_steps / steps_per_epoch)
 
     ti_on = not config.disable_ti
@@ -495,8 +512,8 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
     for epoch in range(config.num_train_epochs):
         order = perm_rng.permutation(n_img)
         if ddp:
-            order = order[rank::world] if len(order) >= world else order
-        spe = math.ceil(len(order) / B) if ddp else steps_per_epoch
+            order = np.resize(order, shard * world)[rank::world]
+        spe = steps_per_epoch
         # the epoch's batches: the DataLoader's short last batch wraps around to the start of the epoch's order (fixed-shape step)
         padded = np.resize(order, spe * B) if len(order) < spe * B else order[: spe * B]
         order_d = torch.as_tensor(padded).to(dev).view(spe, B)

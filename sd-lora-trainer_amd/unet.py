@@ -226,6 +226,8 @@ class LoraArena:
 
     def set_scale(self, scale):
         """lora_alpha / r in effect (the validation renders run the adapters at a reduced scale, checkpoint.py:31-55)."""
+        if scale == self.scale:          # (the sampler sets the render scale on every call: nothing to rebuild when it has not changed)
+            return
         self.scale = scale
         if self.dora:
             self._build_dora_plan()

@@ -74,15 +74,19 @@ def test_checkpoint_format_roundtrip(tmp_path):
     assert len(sd) == 3 * len(targets)
     k = "lora_unet_down_blocks_1_attentions_0_transformer_blocks_0_attn1_to_q"
     assert sd[k + ".lora_down.weight"].shape == (4, 128) and sd[k + ".lora_up.weight"].shape == (128, 4) and float(sd[k + ".alpha"]) == 4.0
+    # byte fidelity (checkpoint.py:84-102, 183-209 of the reference): alpha = torch.tensor(len(lora_down)) -> 0-dim int64; the adapter
+    # tensors and the token rows leave in the training dtype (weight_type, bf16 by default)
+    assert sd[k + ".alpha"].dtype == torch.int64 and sd[k + ".alpha"].dim() == 0
+    assert sd[k + ".lora_down.weight"].dtype == torch.bfloat16 and sd[k + ".lora_up.weight"].dtype == torch.bfloat16
     kc = "lora_unet_down_blocks_0_resnets_0_conv2"
     assert sd[kc + ".lora_down.weight"].shape == (4, 64, 3, 3) and sd[kc + ".lora_up.weight"].shape == (64, 4, 1, 1)
     assert not any("base_model" in key for key in sd)
     back = ckpt.load_lora(files["lora"], targets)
     for m in targets:
-        torch.testing.assert_close(back[m][0], lora[m][0], rtol=2e-3, atol=1e-4)      # fp16 on disk
-        torch.testing.assert_close(back[m][1], lora[m][1], rtol=2e-3, atol=1e-4)
+        torch.testing.assert_close(back[m][0], lora[m][0], rtol=8e-3, atol=1e-4)      # bf16 on disk
+        torch.testing.assert_close(back[m][1], lora[m][1], rtol=8e-3, atol=1e-4)
     emb = ckpt.load_embeddings(files["embeddings"])
-    assert torch.equal(emb[0], rows[0]) and torch.equal(emb[1], rows[1])
+    assert emb[0].dtype == torch.bfloat16 and torch.equal(emb[0], rows[0].to(torch.bfloat16)) and torch.equal(emb[1], rows[1].to(torch.bfloat16))
     assert json.load(open(tmp_path / "special_params.json")) == {"TOK": "<s0><s1><s2>"}
     assert json.load(open(tmp_path / "adapter_config.json"))["r"] == 4
 

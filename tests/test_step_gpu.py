@@ -168,6 +168,9 @@ def test_train_generator_on_gpu(tmp_path, monkeypatch, extra):
         sd = load_file(os.path.join(out, "diffusion_pytorch_model.safetensors"))
         assert sd["conv_in.weight"].shape == (64, 4, 3, 3) or sd["conv_in.weight"].dim() == 4
         assert "mid_block.attentions.0.transformer_blocks.0.attn1.to_q.weight" in sd and "conv_norm_out.bias" in sd
+        assert sd["conv_in.weight"].dtype == torch.bfloat16                       # saved in weight_type, like unet.save_pretrained of a bf16 UNet
+        cj = json.load(open(os.path.join(out, "config.json")))                    # ... with its config.json (checkpoint.py:210-212)
+        assert cj["_class_name"] == "UNet2DConditionModel" and cj["addition_embed_type"] == "text_time" and cj["cross_attention_dim"] == 128
         return
     lora_files = [n for n in os.listdir(out) if n.endswith("_sdxl_lora.safetensors") or n.endswith("_tinyxl_lora.safetensors")]
     assert lora_files
