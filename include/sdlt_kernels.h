@@ -241,6 +241,11 @@ int sdlt_layernorm_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy,
                        const float* gamma, const float* stats, const void* dres, int64_t lddres, void* dx,
                        int64_t lddx, void* stream);
 
+/* sdlt_layernorm_bwd with dy given as nslab fp32 slabs [nslab][M][lddy32] that are added in slab order (the partial outputs of a K-split
+ * sdlt_strip_gemm: the split's reduction rides in this kernel's prologue). */
+int sdlt_layernorm_bwd_slabs(const void* x, int64_t ldx, const float* dy32, int64_t lddy32, int32_t nslab, int32_t M, int32_t C,
+                             const float* gamma, const float* stats, const void* dres, int64_t lddres, void* dx, int64_t lddx, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ full fine-tune
  * Weight gradients of the full-UNet fine-tune (main.py:144-149, train_configs/full_finetuning_example.json): every
  * nn.Linear / nn.Conv2d weight, bias and norm affine parameter of the UNet receives a gradient.
@@ -404,6 +409,42 @@ int sdlt_embed_grad(const void* dx, int64_t lddx, const int64_t* ids, const int6
  * loss_out += w * mean_j (target_mean - std(row_j))^2 / target_var ; grad += d/d rows.  std is the unbiased std. */
 int sdlt_ti_std_reg(const float* rows, int32_t n, int32_t D, float target_mean, float target_var, float weight,
                     float* grad, float* loss_out, void* stream);
+
+/* Row-strip GEMM of the text encoders:  Y[b*Tp + t, :] = X[b*Tp + t, :] . W^T  for the t < T (<= 80) valid rows of every batch element,
+ * W [N, K] K-contiguous (forward: the weight, input gradient: its transposed copy), K % 256 == 0, N % 16 == 0.  A workgroup owns 16 (32 for
+ * N >= 4096) output columns over the full K, its 8 waves split K; operands go from global memory straight into MFMA fragments (no LDS
+ * staging) - the shape of a weight-streaming product with 77 rows.  Rows t >= T are neither read as results nor written.
+ * Replaces every nn.Linear of CLIPTextModel / CLIPTextModelWithProjection inside pipe.encode_prompt (trainer/inference.py:131-177, called
+ * with autograd from main.py:306-308) and its input gradient in loss.backward() (main.py:363), together with what surrounds it:
+ *   ln = 1   : CLIPEncoderLayer.layer_norm1 / layer_norm2 in front of the product.  X holds the RAW rows, W holds W o gamma (bf16),
+ *              c1[n] = sum_k (W o gamma)[n,k], c2[n] = sum_k beta[k] W[n,k] + bias[n];  Y = rstd (acc - mean c1) + c2 with the row
+ *              statistics taken from the same fragments; stats [B*Tp, 2] = (mean, rstd) is written for sdlt_layernorm_bwd (optional).
+ *   bias, R  : + bias[n] (ln = 0) and + residual R[row, n]
+ *   Y2, act  : second output act(Y) (from the fp32 values): act 1 = quick_gelu (CLIP-L), 2 = gelu (OpenCLIP bigG)  - mlp.fc1
+ *   Z, act   : Y = (acc + bias + R) * act'(Z[row, n])                                                              - input gradient of mlp.fc2 */
+typedef struct sdlt_strip_params {
+  const void* X; int64_t ldx;
+  const void* W; int64_t ldw;
+  const float* bias;
+  const void* R; int64_t ldr;
+  void* Y; int64_t ldy;
+  void* Y2; int64_t ldy2;
+  const void* Z; int64_t ldz;
+  const float* c1; const float* c2;
+  float* stats;
+  int32_t B, T, Tp, N, K, act, ln;
+  float eps;
+  /* splitk = S > 1 (K % (256 S) == 0): S workgroups share a strip and walk K / S columns each; their fp32 tiles meet in `ws` and the last
+     arriver adds them in split order and runs the epilogue (bitwise reproducible).  ws: scratch, only live inside the call, >= B * strips *
+     S * 7680 bytes (strips = N / 16, or N / 32 with 15360); cnt: one zero-initialised int per (batch element, strip), re-armed by the kernel. */
+  int32_t splitk, cnt_len;
+  void* ws; int64_t ws_bytes;
+  int32_t* cnt;
+  /* P != NULL: partial output instead of Y - split s writes its fp32 tile to P[s][row][n] (P: [S][B*Tp][ldp] fp32; rows t >= T untouched) and
+     the consumer adds the S slabs (sdlt_layernorm_bwd_slabs): the K split without an in-kernel seam.  No ln / bias / R / Y2 / Z. */
+  float* P; int64_t ldp;
+} sdlt_strip_params;
+int sdlt_strip_gemm(const sdlt_strip_params* p, void* stream);
 
 /* dX of nearest-2x upsampling: out[b,h,w,:] = sum of the 2x2 block of in [B,2H,2W,C]. */
 int sdlt_sum2x2(const void* in, int32_t B, int32_t H, int32_t W, int32_t C, void* out, void* stream);

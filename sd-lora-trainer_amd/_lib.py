@@ -107,6 +107,13 @@ class GroupNormParams(C.Structure):
     ]
 
 
+class StripParams(C.Structure):
+    _fields_ = [("X", vp), ("ldx", i64), ("W", vp), ("ldw", i64), ("bias", vp), ("R", vp), ("ldr", i64), ("Y", vp), ("ldy", i64),
+                ("Y2", vp), ("ldy2", i64), ("Z", vp), ("ldz", i64), ("c1", vp), ("c2", vp), ("stats", vp),
+                ("B", i32), ("T", i32), ("Tp", i32), ("N", i32), ("K", i32), ("act", i32), ("ln", i32), ("eps", f32),
+                ("splitk", i32), ("cnt_len", i32), ("ws", vp), ("ws_bytes", i64), ("cnt", vp), ("P", vp), ("ldp", i64)]
+
+
 class ShadowDesc(C.Structure):
     _fields_ = [("offset", i64), ("src_ld", i64), ("rows", i32), ("cols", i32), ("dst", vp), ("ld", i64), ("dstT", vp), ("ldT", i64)]
 
@@ -128,6 +135,7 @@ SYMBOLS = {
     "sdlt_groupnorm_bwd": (i32, [C.POINTER(GroupNormParams), vp]),
     "sdlt_layernorm_fwd": (i32, [vp, i64, i32, i32, vp, vp, f32, vp, i64, vp, vp]),
     "sdlt_layernorm_bwd": (i32, [vp, i64, vp, i64, i32, i32, vp, vp, vp, i64, vp, i64, vp]),
+    "sdlt_layernorm_bwd_slabs": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp, vp, i64, vp, i64, vp]),
     "sdlt_geglu_fwd": (i32, [vp, i64, i32, i32, vp, i64, vp]),
     "sdlt_geglu_bwd": (i32, [vp, i64, vp, i64, i32, i32, vp, i64, vp]),
     "sdlt_map_bf16": (i32, [i32, vp, vp, vp, i64, vp]),
@@ -148,6 +156,7 @@ SYMBOLS = {
     "sdlt_dora_refresh": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "sdlt_dora_scale_wt": (i32, [vp, vp, vp, i32, vp]),
     "sdlt_dora_mag_grad": (i32, [vp, vp, vp, i32, vp, vp, i32, vp, vp]),
+    "sdlt_strip_gemm": (i32, [C.POINTER(StripParams), vp]),
     "sdlt_sum2x2": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "sdlt_colsum": (i32, [vp, i64, i32, i32, i32, vp, i64, vp, vp, vp]),
     "sdlt_embed_gather": (i32, [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp]),
@@ -179,7 +188,7 @@ def load():
             raise KernelLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    for which, cls in enumerate((GemmParams, LoraGradDesc, AttnParams, GroupNormParams, ShadowDesc, GemmBatchItem, DoraDesc, DoraWtDesc, DoraGradDesc, SplitsumDesc)):
+    for which, cls in enumerate((GemmParams, LoraGradDesc, AttnParams, GroupNormParams, ShadowDesc, GemmBatchItem, DoraDesc, DoraWtDesc, DoraGradDesc, SplitsumDesc, StripParams)):
         if lib.sdlt_struct_size(which) != C.sizeof(cls):
             raise KernelLibraryError(f"struct layout mismatch for {cls.__name__}: C {lib.sdlt_struct_size(which)} vs ctypes {C.sizeof(cls)}")
     _lib = lib

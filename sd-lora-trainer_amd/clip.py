@@ -102,6 +102,94 @@ class ClipLayer(_Module):
         return self.ln1.backward(dn1, dres=dx1)
 
 
+# Fused text-encoder layers (row-strip products, sdlt_strip_gemm): SDLT_CLIP_FUSED=0 keeps the tiled-GEMM plan above; the strip kernel
+# re-streams the weights once per batch element, so beyond SDLT_CLIP_FUSED_MAXB images per step the tiled plan (M = B * 128 rows) is used
+FUSED = os.environ.get("SDLT_CLIP_FUSED", "1") != "0"
+FUSED_MAXB = int(os.environ.get("SDLT_CLIP_FUSED_MAXB", "4"))
+
+
+def fused_ok(rt, B, D, F_, arena):
+    """The fused plan covers frozen text encoders (no adapters: text-encoder LoRA keeps the fused-LoRA tiled GEMMs) whose widths the
+    strip kernel takes (K % 256 == 0; the CPU emulation of the op contracts takes any)."""
+    if not FUSED or arena is not None or not hasattr(rt.ops, "strip_gemm") or B > FUSED_MAXB:
+        return False
+    return bool(getattr(rt.ops, "STRIP_ANY_SHAPE", False)) or (D % 256 == 0 and F_ % 256 == 0)
+
+
+class FusedClipLayer(_Module):
+    """One CLIPEncoderLayer as 5 launches forward, 7 backward (ClipLayer: 7 / 9 of the tiled kernels, each 9-18 us on 80 rows):
+      forward   [LN1 + q|k|v] -> causal attention -> [out_proj + residual] -> [LN2 + fc1 + act] -> [fc2 + residual]
+      backward  [dX fc2 * act'] -> [dX fc1] -> LN2 backward (+ residual gradient) -> [dX out_proj] -> attention backward
+                -> [dX q|k|v] -> LN1 backward (+ residual gradient)
+    every [...] one sdlt_strip_gemm launch: the LayerNorms in front of q|k|v and fc1 are folded into the products (ops.fold_layernorm),
+    no normalised activations are stored; the LayerNorm backward works from the raw rows and the (mean, rstd) the product left.
+    Only the 77 valid rows of a sequence are computed or written: every buffer is zero-initialised and its pad rows stay zero."""
+
+    def __init__(self, rt, name, sd, heads, act):
+        super().__init__(rt, name)
+        dev, dt = rt.device, rt.act
+        g = lambda k: sd[name + k].to(dev, F32)  # noqa: E731
+        wq, wk, wv = g(".self_attn.q_proj.weight"), g(".self_attn.k_proj.weight"), g(".self_attn.v_proj.weight")
+        wqkv = torch.cat([wq, wk, wv], 0)
+        bqkv = torch.cat([g(".self_attn.q_proj.bias"), g(".self_attn.k_proj.bias"), g(".self_attn.v_proj.bias")])
+        self.g1, self.be1 = g(".layer_norm1.weight").contiguous(), g(".layer_norm1.bias").contiguous()
+        self.g2, self.be2 = g(".layer_norm2.weight").contiguous(), g(".layer_norm2.bias").contiguous()
+        self.eps = 1e-5
+        fold = rt.ops.fold_layernorm
+        self.Wqkv_g, self.qkv_c1, self.qkv_c2 = fold(wqkv, bqkv, self.g1, self.be1, dtype=dt)
+        self.Wqkv_t = wqkv.t().to(dt).contiguous()
+        wo = g(".self_attn.out_proj.weight")
+        self.Wo, self.Wo_t, self.bo = wo.to(dt).contiguous(), wo.t().to(dt).contiguous(), g(".self_attn.out_proj.bias").contiguous()
+        w1, w2 = g(".mlp.fc1.weight"), g(".mlp.fc2.weight")
+        self.W1_g, self.fc1_c1, self.fc1_c2 = fold(w1, g(".mlp.fc1.bias"), self.g2, self.be2, dtype=dt)
+        self.W1_t = w1.t().to(dt).contiguous()
+        self.W2, self.W2_t, self.b2 = w2.to(dt).contiguous(), w2.t().to(dt).contiguous(), g(".mlp.fc2.bias").contiguous()
+        self.D, self.F, self.heads = wo.shape[0], w1.shape[0], heads
+        self.d = self.D // heads
+        self.scale = 1.0 / math.sqrt(self.d)
+        self.act_kind = "quick_gelu" if act == "quick_gelu" else "gelu"
+
+    def _akw(self, B):
+        return dict(B=B, H=self.heads, Nq=T_TOKENS, Nk=T_TOKENS, Nqp=TP, Nkp=TP, d=self.d, scale=self.scale, causal=True)
+
+    def zbuf(self, key, *shape, dtype=None):
+        return self.buf(key, *shape, dtype=dtype, zero=True)
+
+    def forward(self, x, B, out=None):
+        ops, M, D, F_ = self.rt.ops, B * TP, self.D, self.F
+        kw = dict(B=B, T=T_TOKENS, Tp=TP)
+        self._x, self._B = x, B
+        qkv = ops.strip_gemm(x, self.Wqkv_g, self.zbuf("qkv", M, 3 * D), ln=(self.qkv_c1, self.qkv_c2, self.eps),
+                             stats=self.zbuf("st1", M * 2, dtype=F32), **kw)
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        O, L = self.zbuf("O", M, D), self.zbuf("L", B * self.heads * T_TOKENS, dtype=F32)
+        ops.attn_fwd(q, k, v, None, O, L, **self._akw(B))
+        x1 = ops.strip_gemm(O, self.Wo, self.zbuf("x1", M, D), bias=self.bo, residual=x, **kw)
+        a = self.zbuf("a", M, F_)
+        ops.strip_gemm(x1, self.W1_g, self.zbuf("y1", M, F_), ln=(self.fc1_c1, self.fc1_c2, self.eps), stats=self.zbuf("st2", M * 2, dtype=F32),
+                       act_out=(self.act_kind, a), **kw)
+        return ops.strip_gemm(a, self.W2, out if out is not None else self.zbuf("x2", M, D), bias=self.b2, residual=x1, **kw)
+
+    def backward(self, dx2):
+        ops, B, D, F_ = self.rt.ops, self._B, self.D, self.F
+        M = B * TP
+        kw = dict(B=B, T=T_TOKENS, Tp=TP)
+        b = self._b
+        df = ops.strip_gemm(dx2, self.W2_t, self.zbuf("df", M, F_), dact_in=(self.act_kind, b["y1"]), **kw)
+        # the two long-K input gradients (K = mlp width, 3 D) are cut into K slices whose fp32 tiles the LayerNorm backward behind them adds
+        # in its prologue: a split without a seam (an in-kernel last-arriver reduction costs 4 - 5 us, the launch boundary nothing)
+        S2 = ops.strip_partial_splits(D, F_, B)
+        dn2 = ops.strip_gemm(df, self.W1_t, None, partial=self.zbuf("dn2_p", S2, M, D, dtype=F32), **kw)
+        dx1 = ops.layernorm_bwd(b["x1"], None, self.zbuf("dx1", M, D), b["st2"], gamma=self.g2, dres=dx2, dy_slabs=dn2)
+        dO = ops.strip_gemm(dx1, self.Wo_t, self.zbuf("dO", M, D), **kw)
+        qkv, dqkv = b["qkv"], self.zbuf("dqkv", M, 3 * D)
+        ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], None, None, b["O"], b["L"], dO, None,
+                     self.zbuf("Dd", B * self.heads * T_TOKENS, dtype=F32), dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], **self._akw(B))
+        S1 = ops.strip_partial_splits(D, 3 * D, B)
+        dn1 = ops.strip_gemm(dqkv, self.Wqkv_t, None, partial=self.zbuf("dn1_p", S1, M, D, dtype=F32), **kw)
+        return ops.layernorm_bwd(self._x, None, self.zbuf("dx", M, D), b["st1"], gamma=self.g1, dres=dx1, dy_slabs=dn1)
+
+
 class ClipTextEncoder(_Module):
     """mode "last": hidden = final_layer_norm(layer_L)            (SD1.5 prompt embeds)
        mode "penultimate": hidden = output of layer L-1 (HF hidden_states[-2], no final LN)   (SDXL prompt embeds)
@@ -125,7 +213,12 @@ class ClipTextEncoder(_Module):
         # layers whose output is never consumed are not built (SDXL CLIP-L: the last layer only feeds an unused pooled output)
         self.n_run = nl if (mode == "last" or with_projection) else nl - 1
         self.n_hidden = nl if mode == "last" else nl - 1              # hidden state = output of this many layers
-        self.layers = [ClipLayer(rt, f"{pre}encoder.layers.{i}", sd, heads, act, arena, lora_prefix) for i in range(self.n_run)]
+        mlp = sd[f"{pre}encoder.layers.0.mlp.fc1.weight"].shape[0] if nl else 0
+        self.fused = nl > 0 and fused_ok(rt, rt.B, self.D, mlp, arena)
+        if self.fused:
+            self.layers = [FusedClipLayer(rt, f"{pre}encoder.layers.{i}", sd, heads, act) for i in range(self.n_run)]
+        else:
+            self.layers = [ClipLayer(rt, f"{pre}encoder.layers.{i}", sd, heads, act, arena, lora_prefix) for i in range(self.n_run)]
         self.final_ln = LayerNorm(rt, pre + "final_layer_norm", sd) if (mode == "last" or with_projection) else None
         self.proj = Linear(rt, "text_projection", sd) if with_projection else None
         self.train_ids = torch.arange(self.V - n_train, self.V, dtype=torch.int64, device=rt.device)

@@ -28,6 +28,7 @@ extern "C" int sdlt_struct_size(int which) {
     case 7: return (int)sizeof(sdlt_dora_wt_desc);
     case 8: return (int)sizeof(sdlt_dora_grad_desc);
     case 9: return (int)sizeof(sdlt_splitsum_desc);
+    case 10: return (int)sizeof(sdlt_strip_params);
   }
   return -1;
 }

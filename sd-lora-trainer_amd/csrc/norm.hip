@@ -348,14 +348,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t lddy, int M,
+// SLABS: dy arrives as `nslab` fp32 slabs [nslab][M][lddy] (partial outputs of a K-split sdlt_strip_gemm), added here in slab order
+template <bool SLABS>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ x, int64_t ldx, const void* __restrict__ dy_, int64_t lddy, int nslab, int M,
                                                       int C, const float* __restrict__ gamma, const float* __restrict__ stats,
                                                       const bf16_t* dres, int64_t lddres, bf16_t* dx, int64_t lddx) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int nch = C >> 3;
-  uint4 xr[LN_MAXCH], dr[LN_MAXCH], rr[LN_MAXCH];         // (dres may alias dx: read here, before any store of this row - each wave owns its row)
+  const bf16_t* dy = (const bf16_t*)dy_;
+  const float* dy32 = (const float*)dy_;
+  uint4 xr[LN_MAXCH], dr[LN_MAXCH], rr[LN_MAXCH];
+  f32x4 d32[LN_MAXCH][2];         // (dres may alias dx: read here, before any store of this row - each wave owns its row)
   f32x4 g4[LN_MAXCH][2];
 #pragma unroll
   for (int i = 0; i < LN_MAXCH; ++i) {
@@ -363,7 +368,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     rr[i] = make_uint4(0, 0, 0, 0);
     if (ch < nch) {
       xr[i] = *(const uint4*)(x + (int64_t)row * ldx + ch * 8);
-      dr[i] = *(const uint4*)(dy + (int64_t)row * lddy + ch * 8);
+      if constexpr (SLABS) {
+        dr[i] = make_uint4(0, 0, 0, 0);
+        d32[i][0] = *(const f32x4*)(dy32 + (int64_t)row * lddy + ch * 8);
+        d32[i][1] = *(const f32x4*)(dy32 + (int64_t)row * lddy + ch * 8 + 4);
+        for (int sl = 1; sl < nslab; ++sl) {
+          const float* o = dy32 + ((int64_t)sl * M + row) * lddy + ch * 8;
+          d32[i][0] += *(const f32x4*)o;
+          d32[i][1] += *(const f32x4*)(o + 4);
+        }
+      } else {
+        dr[i] = *(const uint4*)(dy + (int64_t)row * lddy + ch * 8);
+      }
       g4[i][0] = *(const f32x4*)(gamma + ch * 8); g4[i][1] = *(const f32x4*)(gamma + ch * 8 + 4);
       if (dres) rr[i] = *(const uint4*)(dres + (int64_t)row * lddres + ch * 8);
     }
@@ -379,7 +395,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float vx = bf2f((j & 1) ? (xw[j >> 1] >> 16) : (xw[j >> 1] & 0xffff));
-        const float vd = bf2f((j & 1) ? (dw[j >> 1] >> 16) : (dw[j >> 1] & 0xffff));
+        const float vd = SLABS ? d32[i][j >> 2][j & 3] : bf2f((j & 1) ? (dw[j >> 1] >> 16) : (dw[j >> 1] & 0xffff));
         xh[i][j] = (vx - mean) * rstd;
         dxh[i][j] = vd * g4[i][j >> 2][j & 3];
         s1 += dxh[i][j]; s2 += dxh[i][j] * xh[i][j];
@@ -488,7 +504,16 @@ extern "C" int sdlt_layernorm_bwd(const void* x, int64_t ldx, const void* dy, in
                                   int64_t lddx, void* stream) {
   if (M <= 0 || C <= 0 || (C % 8) || C > LN_MAXCH * 512) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_layernorm_bwd: M=%d C=%d", M, C);
   if ((ldx % 8) || (lddy % 8) || (lddx % 8) || (dres && (lddres % 8))) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_layernorm_bwd: ld %% 8");
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, M, C, gamma, stats, (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx);
+  hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, dy, lddy, 1, M, C, gamma, stats, (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+
+extern "C" int sdlt_layernorm_bwd_slabs(const void* x, int64_t ldx, const float* dy32, int64_t lddy32, int32_t nslab, int32_t M, int32_t C,
+                                        const float* gamma, const float* stats, const void* dres, int64_t lddres, void* dx, int64_t lddx, void* stream) {
+  if (M <= 0 || C <= 0 || (C % 8) || C > LN_MAXCH * 512 || nslab < 1) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_layernorm_bwd_slabs: M=%d C=%d nslab=%d", M, C, nslab);
+  if ((ldx % 8) || (lddy32 % 4) || (lddx % 8) || (dres && (lddres % 8)) || ((uintptr_t)dy32 & 15)) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_layernorm_bwd_slabs: alignment");
+  hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, dy32, lddy32, nslab, M, C, gamma, stats, (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }

@@ -5,6 +5,7 @@ Conventions: activations are 2-D bf16 matrices [rows, C] with un
 arbitrary row stride (views of wider buffers are fine); "NHWC" means rows = B*H*W.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -224,6 +225,96 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
     p.ws_slab, p.ws_slab_bytes, p.ws_cnt, p.ws_cnt_len = _p(slab), slab.numel(), _p(cnt), cnt.numel()
     _lib.check(lib.sdlt_gemm_bf16(C.byref(p), _stream()), "sdlt_gemm_bf16")
     return out if geglu_bwd is None else geglu_bwd[1]
+
+
+STRIP_SPLITK = int(os.environ.get("SDLT_STRIP_SPLITK", "1"))      # in-kernel K split of strip_gemm: 1 = off (default), n = force where K allows
+
+
+def strip_splitk(N, K, B):
+    """In-kernel K split (last-arriver reduction) of a row-strip product.  Measured (tools/strip_probe.py): the seam - write-through slab
+    stores, drain, ticket, acquire, slab reads - costs 4 - 5 us, more than the shorter K walk saves at every CLIP shape (1280 x 5120: 13.3 us
+    unsplit, 17.7 us with 4 slices; 1280 x 3840: 10.2 vs 10.0), so it stays off; the long-K products of the backward pass are split with
+    their reduction in the consumer's prologue instead (strip_partial_splits)."""
+    s = max(1, STRIP_SPLITK)
+    return s if (K // 256) >= s else 1
+
+
+def strip_partial_splits(N, K, B):
+    """Splits of a row-strip product whose partial tiles are added by its consumer (strip_gemm(partial=...) -> layernorm_bwd(dy_slabs=...)):
+    as many as keep the grid within ONE wave of workgroups (a strip workgroup takes a CU's whole LDS) with at least 3 K steps each."""
+    strips = N // 16
+    s = max(1, min(8, 256 // max(1, strips * B), (K // 256) // 3))
+    return s
+
+
+def strip_gemm(X, W, out, *, B, T, Tp, bias=None, residual=None, act_out=None, dact_in=None, ln=None, stats=None, splitk=None, partial=None):
+    """Row-strip product of the text encoders (sdlt_strip_gemm): out[b*Tp + t] = X[b*Tp + t] . W^T for the t < T valid rows of every batch
+    element; rows t >= T of `out` are left untouched.  W [N, K], K % 256 == 0.
+    ln = (c1 [N], c2 [N], eps): a LayerNorm sits in front of the product - X holds the raw rows, W = (weight o gamma), c1 = rowsum(W),
+    c2 = weight . beta + bias (fold_layernorm); stats [B*Tp, 2] receives (mean, rstd) for layernorm_bwd.
+    act_out = (kind, A): also A = act(out);  dact_in = (kind, P): out = (product + bias + residual) * act'(P)."""
+    lib = _lib.load()
+    p = _lib.StripParams()
+    _chk2(X), _chk2(W)
+    N, K = W.shape
+    assert X.shape[0] == B * Tp and X.shape[1] == K, (X.shape, W.shape)
+    p.X, p.ldx, p.W, p.ldw = _p(X), _ld(X), _p(W), _ld(W)
+    p.B, p.T, p.Tp, p.N, p.K = B, T, Tp, N, K
+    if partial is not None:
+        # partial fp32 [S, B*Tp, N]: the K split's tiles, added by the consumer (layernorm_bwd(dy_slabs=partial)); `out` is not written
+        assert out is None and bias is None and residual is None and act_out is None and dact_in is None and ln is None
+        assert partial.is_cuda and partial.dtype == F32 and partial.is_contiguous() and tuple(partial.shape[1:]) == (B * Tp, N)
+        p.P, p.ldp, p.splitk = _p(partial), N, partial.shape[0]
+        _lib.check(lib.sdlt_strip_gemm(C.byref(p), _stream()), "sdlt_strip_gemm")
+        return partial
+    _chk2(out)
+    assert tuple(out.shape) == (B * Tp, N), (out.shape, W.shape)
+    p.Y, p.ldy = _p(out), _ld(out)
+    if ln is not None:
+        c1, c2, eps = ln
+        _chk2(c1, F32), _chk2(c2, F32)
+        assert c1.numel() == N and c2.numel() == N and bias is None, "with ln the bias is part of c2"
+        p.ln, p.c1, p.c2, p.eps = 1, _p(c1), _p(c2), float(eps)
+        if stats is not None:
+            _chk2(stats, F32)
+            assert stats.numel() >= B * Tp * 2
+            p.stats = _p(stats)
+    elif bias is not None:
+        _chk2(bias, F32)
+        assert bias.numel() == N
+        p.bias = _p(bias)
+    if residual is not None:
+        _chk2(residual)
+        assert tuple(residual.shape) == (B * Tp, N)
+        p.R, p.ldr = _p(residual), _ld(residual)
+    if act_out is not None or dact_in is not None:
+        assert not (act_out is not None and dact_in is not None)
+        kind, t = act_out if act_out is not None else dact_in
+        _chk2(t)
+        assert tuple(t.shape) == (B * Tp, N) and kind in ("gelu", "quick_gelu")
+        p.act = 1 if kind == "quick_gelu" else 2
+        if act_out is not None:
+            p.Y2, p.ldy2 = _p(t), _ld(t)
+        else:
+            p.Z, p.ldz = _p(t), _ld(t)
+    S = strip_splitk(N, K, B) if splitk is None else splitk
+    if S > 1:
+        slab, cnt = splitk_workspace(X.device)
+        p.splitk, p.ws, p.ws_bytes, p.cnt, p.cnt_len = S, _p(slab), slab.numel(), _p(cnt), cnt.numel()
+    _lib.check(lib.sdlt_strip_gemm(C.byref(p), _stream()), "sdlt_strip_gemm")
+    return out
+
+
+def fold_layernorm(W, bias, gamma, beta, dtype=BF16):
+    """Operands of a LayerNorm folded into the Linear behind it (strip_gemm ln=): LN(x) W^T + b = rstd (x (W o gamma)^T - mean c1) + c2
+    with c1[n] = sum_k (W o gamma)[n,k] taken from the ROUNDED operand (so that the mean term cancels exactly what the product adds)
+    and c2 = W beta + b.  W fp32 [N, K].  Returns (W o gamma in `dtype`, c1 fp32, c2 fp32)."""
+    Wg = (W.float() * gamma.float()[None, :]).to(dtype).contiguous()
+    c1 = Wg.float().sum(1).contiguous()
+    c2 = (W.float() @ beta.float()).contiguous()
+    if bias is not None:
+        c2 = (c2 + bias.float()).contiguous()
+    return Wg, c1, c2
 
 
 def geglu_perm(H, device=None):
@@ -545,10 +636,17 @@ def layernorm_fwd(x, y, stats, *, gamma, beta, eps=1e-5):
     return y
 
 
-def layernorm_bwd(x, dy, dx, stats, *, gamma, dres=None):
+def layernorm_bwd(x, dy, dx, stats, *, gamma, dres=None, dy_slabs=None):
+    """dy_slabs fp32 [S, M, C] (instead of dy): the partial outputs of a K-split strip_gemm, added in slab order in the kernel's prologue."""
     lib = _lib.load()
-    _chk2(x), _chk2(dy), _chk2(dx), _chk2(stats, F32), _chk2(gamma, F32)
     M, Cc = x.shape
+    if dy_slabs is not None:
+        assert dy is None and dy_slabs.dtype == F32 and dy_slabs.is_contiguous() and tuple(dy_slabs.shape[1:]) == (M, Cc)
+        _chk2(x), _chk2(dx), _chk2(stats, F32), _chk2(gamma, F32)
+        _lib.check(lib.sdlt_layernorm_bwd_slabs(_p(x), _ld(x), _p(dy_slabs), Cc, dy_slabs.shape[0], M, Cc, _p(gamma), _p(stats), _p(dres),
+                                                _ld(dres) if dres is not None else 0, _p(dx), _ld(dx), _stream()), "sdlt_layernorm_bwd_slabs")
+        return dx
+    _chk2(x), _chk2(dy), _chk2(dx), _chk2(stats, F32), _chk2(gamma, F32)
     _lib.check(lib.sdlt_layernorm_bwd(_p(x), _ld(x), _p(dy), _ld(dy), M, Cc, _p(gamma), _p(stats), _p(dres),
                                       _ld(dres) if dres is not None else 0, _p(dx), _ld(dx), _stream()), "sdlt_layernorm_bwd")
     return dx

@@ -853,3 +853,110 @@ def test_dora_plan_kernels(ops, r):
     pg.mag_grad()
     torch.cuda.synchronize()
     assert all(torch.equal(a, eg["gmag"]) for a, eg in zip(first, grads_g))
+
+
+# --------------------------------------------------------------------------------------------- text-encoder row-strip products
+@pytest.mark.parametrize("B,N,K,mode", [(1, 1280, 1280, "res"), (1, 3840, 1280, "ln"), (1, 5120, 1280, "ln_act"), (1, 1280, 5120, "res"), (1, 5120, 1280, "dact"),
+                                         (1, 1280, 3840, "plain"), (2, 2304, 768, "ln"), (4, 768, 3072, "res"), (1, 3072, 768, "ln_act"), (1, 768, 768, "plain"),
+                                         (3, 512, 256, "ln"), (1, 4096, 2560, "dact"), (1, 64, 512, "res")])
+def test_strip_gemm(ops, B, N, K, mode):
+    _strip_case(ops, B, N, K, mode, None)
+
+
+@pytest.mark.parametrize("B,N,K,mode,splitk", [(1, 1280, 5120, "res", 4), (1, 1280, 3840, "plain", 3), (2, 768, 3072, "res", 3), (1, 5120, 2560, "ln_act", 2),
+                                                (1, 256, 4096, "ln", 16), (1, 1280, 5120, "dact", 5), (1, 1280, 1280, "res", 1)])
+def test_strip_gemm_split_k(ops, B, N, K, mode, splitk):
+    """The K split of the row-strip product: S workgroups per strip leave fp32 tiles (and partial row statistics) in the workspace, the
+    last arriver adds them in split order - same values as the emulation, bitwise identical from launch to launch, counters re-armed."""
+    _strip_case(ops, B, N, K, mode, splitk)
+    _strip_case(ops, B, N, K, mode, splitk)          # a second round on the re-armed counters
+
+
+def _strip_case(ops, B, N, K, mode, splitk):
+    """sdlt_strip_gemm on every CLIP-L / OpenCLIP-bigG product shape (and odd ones: 1 ... 20 K steps per wave, 16- and 32-column strips):
+    plain, + bias + residual, LayerNorm folded in front (statistics from the MFMA side products), activation side output, activation
+    derivative factor.  Checked against the emulation of the contract AND, for the folded LayerNorm, against LayerNorm -> Linear on the
+    unfolded weights (the reference's order of operations); rows t >= 77 of every batch element must stay untouched."""
+    T, Tp = 77, 128
+    g = torch.Generator().manual_seed(N + K + B)
+    M = B * Tp
+    x = rnd(M, K, g=g)
+    x[:, :7] += 3.0                                           # a row mean far from zero: the algebraic LayerNorm must cancel it
+    x[:, 5] *= 12.0                                           # CLIP-style outlier feature
+    w = rnd(N, K, g=g, scale=K ** -0.5).float()
+    bias = torch.randn(N, generator=g)
+    res = rnd(M, N, g=g)
+    pre = rnd(M, N, g=g)
+    kind = "gelu" if (N + K) % 512 == 0 else "quick_gelu"
+    kw = dict(B=B, T=T, Tp=Tp)
+    valid = (torch.arange(M) % Tp) < T
+    sentinel = 7.0
+
+    def run(o, use_dev):
+        cv = (lambda t: t.cuda()) if use_dev else (lambda t: t)
+        out = torch.full((M, N), sentinel, dtype=BF, device="cuda" if use_dev else "cpu")
+        extra = {}
+        if mode in ("ln", "ln_act"):
+            gamma, beta = 1.0 + 0.2 * torch.randn(K, generator=torch.Generator().manual_seed(1)), 0.1 * torch.randn(K, generator=torch.Generator().manual_seed(2))
+            wg, c1, c2 = E.fold_layernorm(w, bias, gamma, beta, dtype=BF)
+            st = torch.zeros(M * 2, dtype=F32, device=out.device)
+            a = torch.full((M, N), sentinel, dtype=BF, device=out.device) if mode == "ln_act" else None
+            o.strip_gemm(cv(x), cv(wg), out, ln=(cv(c1), cv(c2), 1e-5), stats=st, act_out=(kind, a) if a is not None else None, splitk=splitk, **kw)
+            extra = dict(stats=st, a=a, gamma=gamma, beta=beta)
+        elif mode == "res":
+            o.strip_gemm(cv(x), cv(w.to(BF)), out, bias=cv(bias), residual=cv(res), splitk=splitk, **kw)
+        elif mode == "dact":
+            o.strip_gemm(cv(x), cv(w.to(BF)), out, dact_in=(kind, cv(pre)), splitk=splitk, **kw)
+        else:
+            o.strip_gemm(cv(x), cv(w.to(BF)), out, splitk=splitk, **kw)
+        return out, extra
+
+    ref, rex = run(E, False)
+    got, gex = run(ops, True)
+    assert torch.all(got.cpu()[~valid] == sentinel), "rows t >= T were written"
+    close(got.cpu()[valid], ref[valid], what=f"strip {mode}")
+    if mode in ("ln", "ln_act"):
+        xs = x.float()[valid]
+        st = gex["stats"].cpu().view(M, 2)[valid]
+        close(st[:, 0], xs.mean(1), tol=1e-3, what="strip ln mean")
+        close(st[:, 1], torch.rsqrt(xs.var(1, unbiased=False) + 1e-5), tol=2e-3, what="strip ln rstd")
+        # the reference's order: LayerNorm (fp32 statistics), then the Linear on the unfolded weights
+        ln = torch.nn.functional.layer_norm(xs, (K,), rex["gamma"], rex["beta"], 1e-5)
+        plain = ln @ w.to(BF).float().t() + bias
+        close(got.cpu()[valid], plain, tol=2.5e-2, what="strip ln vs LayerNorm -> Linear")
+        if mode == "ln_act":
+            assert torch.all(gex["a"].cpu()[~valid] == sentinel)
+            close(gex["a"].cpu()[valid], rex["a"][valid], what="strip activation output")
+    # bitwise reproducible (fixed-order reduction of the 8 K slices)
+    again, _ = run(ops, True)
+    assert torch.equal(again, got)
+
+
+@pytest.mark.parametrize("B,N,K,S", [(1, 1280, 5120, 3), (1, 1280, 3840, 3), (1, 768, 3072, 4), (2, 768, 2304, 3), (1, 1280, 1280, 1), (1, 512, 768, 2)])
+def test_strip_gemm_partial_into_layernorm_bwd(ops, B, N, K, S):
+    """The seam-less K split: sdlt_strip_gemm leaves S fp32 tiles per output (uneven step counts included), sdlt_layernorm_bwd_slabs adds
+    them in its prologue.  Slabs against the emulation's slices, their sum against the unsplit product, and the LayerNorm backward on
+    the slabs against the LayerNorm backward on the summed gradient."""
+    T, Tp = 77, 128
+    g = torch.Generator().manual_seed(N + K + S)
+    M = B * Tp
+    dy = rnd(M, K, g=g)
+    w = rnd(N, K, g=g, scale=K ** -0.5)
+    kw = dict(B=B, T=T, Tp=Tp)
+    valid = (torch.arange(M) % Tp) < T
+    pr = E.strip_gemm(dy, w, None, partial=torch.zeros(S, M, N), **kw)
+    pg = ops.strip_gemm(dy.cuda(), w.cuda(), None, partial=torch.full((S, M, N), 7.0, device="cuda"), **kw)
+    assert torch.all(pg.cpu()[:, ~valid] == 7.0)
+    for sp in range(S):
+        close(pg[sp].cpu()[valid], pr[sp][valid], tol=2e-3, what=f"partial slab {sp}")
+    close(pg.sum(0).cpu()[valid], (dy.float() @ w.float().t())[valid], tol=2e-3, what="sum of the slabs")
+    assert torch.equal(ops.strip_gemm(dy.cuda(), w.cuda(), None, partial=torch.zeros(S, M, N, device="cuda"), **kw)[:, valid.cuda()], pg[:, valid.cuda()])
+    # consumer: LayerNorm backward with the slabs as its incoming gradient
+    x, gamma, dres = rnd(M, N, g=g), 1.0 + 0.1 * torch.randn(N, generator=g), rnd(M, N, g=g)
+    stats = torch.zeros(M * 2, device="cuda")
+    ops.layernorm_fwd(x.cuda(), torch.empty(M, N, dtype=BF, device="cuda"), stats, gamma=gamma.cuda(), beta=torch.zeros(N, device="cuda"))
+    pz = pg.clone()
+    pz[:, ~valid.cuda()] = 0.0
+    ref = E.layernorm_bwd(x, pz.sum(0).cpu(), torch.empty(M, N, dtype=BF), None, gamma=gamma, dres=dres)
+    got = ops.layernorm_bwd(x.cuda(), None, torch.empty(M, N, dtype=BF, device="cuda"), stats, gamma=gamma.cuda(), dres=dres.cuda(), dy_slabs=pz)
+    close(got, ref, tol=2e-2, what="layernorm bwd on slabs")
