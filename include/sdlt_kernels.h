@@ -446,6 +446,14 @@ typedef struct sdlt_strip_params {
 } sdlt_strip_params;
 int sdlt_strip_gemm(const sdlt_strip_params* p, void* stream);
 
+/* Wave-split-K GEMM for the long-K, 1280-wide products of the batch-1 UNet:  Y[M,N] = X[M,K] . W[N,K]^T + bias[n] + R[m,n]  (bf16 in / out,
+ * fp32 accumulation), M % 64 == 0, N % 640 == 0, K % 256 == 0.  64 x 80 tiles (exactly 256 workgroups for 1024 x 1280), the 4 waves of a
+ * workgroup split K and stage their own operands through private LDS rings - no block barrier in the K loop; the 4 partial tiles are added in
+ * wave order (bitwise reproducible).  Replaces FeedForward.net[2] (nn.Linear(4 C, C)) of the 1280-wide BasicTransformerBlocks (+ the block's
+ * residual) reached from main.py:329-336, where the 128 x 128-tile kernel leaves two thirds of the CUs idle. */
+int sdlt_wsk_gemm(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t M, int32_t N, int32_t K, const float* bias,
+                  const void* R, int64_t ldr, void* Y, int64_t ldy, void* stream);
+
 /* dX of nearest-2x upsampling: out[b,h,w,:] = sum of the 2x2 block of in [B,2H,2W,C]. */
 int sdlt_sum2x2(const void* in, int32_t B, int32_t H, int32_t W, int32_t C, void* out, void* stream);
 /* out[b,c] = sum_r x[b*R + r, c] as fp32 [B,C] and / or bf16 [B,C] (either may be NULL) - gradient of the per-batch time-embedding

@@ -1,0 +1,175 @@
+// Wave-split-K GEMM for the short, wide products of the batch-1 UNet (gfx950):  C[M,N] = X[M,K] . W[N,K]^T (+ bias, + residual),
+// M = 1024 ... 4096 tokens, N = 640 / 1280.
+//
+// The tiled kernel (gemm.hip) needs >= 128 x 128 tiles for its block-synchronous LDS pipeline to run well, which cuts a 1024 x 1280
+// output into 80 workgroups: 80 of 256 CUs stream 655 KB of operands each and the launch takes 14.5 us for 3.4 GFLOP.  What bounds such a
+// product is the bytes each CU pulls through its load path, (BM + BN) K 2 per tile - so the tile count has to match the CU count:
+//   * 64 x 80 tiles: exactly 256 workgroups for 1024 x 1280, 369 KB per CU at K = 1280;
+//   * a workgroup is 4 waves that SPLIT K (interleaved 64-column steps) - every wave owns the whole 64 x 80 tile (20 accumulators), stages
+//     its own operands through a private LDS ring (global_load_lds, full 128-byte rows, XOR-swizzled source side) and never meets a block
+//     barrier in the K loop: 36 KB of loads in flight per CU from the first instruction, counted vmcnt waits;
+//   * the 4 partial tiles are added through LDS once, in wave order (bitwise reproducible), then bias / residual / bf16 store.
+#include "common.h"
+#include "../../include/sdlt_kernels.h"
+
+namespace {
+
+constexpr int NW = 4;
+constexpr int ROWB = 128;
+
+template <int N_>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+
+struct wsk_params {
+  const bf16_t* X; int64_t ldx;
+  const bf16_t* W; int64_t ldw;
+  const float* bias;
+  const bf16_t* R; int64_t ldr;
+  bf16_t* Y; int64_t ldy;
+  int M, N, K, map2d;
+};
+
+// MBK x 16 rows, JN x 16 columns per workgroup; R ring slots per wave
+template <int MBK, int JN, int R>
+__global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
+  constexpr int XR = 16 * MBK, WR = 16 * JN, SROWS = XR + WR, SLOT = SROWS * ROWB, PIECES = SROWS / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int ntn = p.N / WR, ntm = p.M / XR;
+  int tm, tn;
+  {
+    // XCD-aware: the workgroups of one XCD (blockIdx % 8) take neighbouring column tiles over all row tiles, so every weight panel is
+    // fetched into one L2 only and the activation rows are what the L2s share
+    // 8 private L2s: an XCD that owns a (rows / 2) x (columns / 4) block of tiles fetches half of X and a quarter of W - 2.1x the operand
+    // bytes over the fabric in total, against 4x when every XCD reads all of X (measured: the products are fabric-bound at ~5 TB/s)
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    if (p.map2d && (ntm & 1) == 0 && (ntn & 3) == 0) {
+      const int pr = ntm >> 1, pc = ntn >> 2;           // tiles per XCD: pr x pc
+      tm = (xcd >> 2) * pr + idx / pc;
+      tn = (xcd & 3) * pc + idx % pc;
+    } else {
+      const int per = ntn >> 3;                          // column tiles per XCD (ntn % 8 == 0)
+      tn = xcd * per + idx % per;
+      tm = idx / per;
+    }
+  }
+  if (tm >= ntm || tn >= ntn) return;
+  const int m0 = tm * XR, n0 = tn * WR;
+  const int nsteps = p.K >> 8;
+
+  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+  const bf16_t* xsrc = p.X + (int64_t)(m0 + srow) * p.ldx + schunk * 8;
+  const bf16_t* wsrc = p.W + (int64_t)(n0 + srow) * p.ldw + schunk * 8;
+  const int64_t x8 = 8 * p.ldx, w8 = 8 * p.ldw;
+  char* ring = smem + wave * (R * SLOT);
+  const int rot = (int)((unsigned)tn % (unsigned)nsteps);
+  auto issue = [&](int i, int slot) {
+    int ii = i + rot;
+    ii = ii >= nsteps ? ii - nsteps : ii;
+    const int k0 = (wave + NW * ii) * 64;
+    char* dst = ring + slot * SLOT;
+#pragma unroll
+    for (int q = 0; q < XR / 8; ++q) glds16(xsrc + q * x8 + k0, dst + q * 1024);
+#pragma unroll
+    for (int q = 0; q < WR / 8; ++q) glds16(wsrc + q * w8 + k0, dst + XR * ROWB + q * 1024);
+  };
+  const int foff0 = r * ROWB + (((0 * 4 + g) ^ (r & 7)) << 4), foff1 = r * ROWB + (((1 * 4 + g) ^ (r & 7)) << 4);
+
+  f32x4 acc[JN][MBK];
+#pragma unroll
+  for (int j = 0; j < JN; ++j)
+#pragma unroll
+    for (int mb = 0; mb < MBK; ++mb) acc[j][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < R; ++s)
+    if (s < nsteps) issue(s, s);
+  int slot = 0;
+  for (int i = 0; i < nsteps; ++i) {
+    const int after = nsteps - 1 - i;
+    if (after >= R - 1) wait_vmcnt<PIECES * (R - 1)>();
+    else if (R > 2 && after == 1) wait_vmcnt<PIECES>();
+    else wait_vmcnt<0>();
+    const char* base = ring + slot * SLOT;
+    bf16x8 xf[2][MBK], wf[2][JN];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int fo = kk ? foff1 : foff0;
+#pragma unroll
+      for (int mb = 0; mb < MBK; ++mb) xf[kk][mb] = *(const bf16x8*)(base + mb * 16 * ROWB + fo);
+#pragma unroll
+      for (int j = 0; j < JN; ++j) wf[kk][j] = *(const bf16x8*)(base + (XR + 16 * j) * ROWB + fo);
+    }
+    // (spreading the refill's DMA instructions between the MFMAs was measured and LOSES 10-15 %: the ring is one step deep, every cycle
+    // a piece is issued later is a cycle less of its latency hidden)
+    if (i + R < nsteps) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slot is refilled: its fragments must be in registers first
+      issue(i + R, slot);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int mb = 0; mb < MBK; ++mb) acc[j][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][j], xf[kk][mb], acc[j][mb], 0, 0, 0);
+    slot = slot + 1 == R ? 0 : slot + 1;
+  }
+
+  // ---- the 4 partial tiles meet in LDS; unit u = (row block, column block), wave w finishes units w, w + 4, ...
+  constexpr int UNITS = MBK * JN, UPW = (UNITS + NW - 1) / NW;
+  __syncthreads();
+  f32x4* red = (f32x4*)smem;
+#pragma unroll
+  for (int j = 0; j < JN; ++j)
+#pragma unroll
+    for (int mb = 0; mb < MBK; ++mb) red[(wave * UNITS + mb * JN + j) * 64 + lane] = acc[j][mb];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < UPW; ++q) {
+    const int u = wave + q * NW;
+    if (u >= UNITS) break;
+    const int mb = u / JN, j = u - mb * JN, n = n0 + 16 * j + 4 * g, m = m0 + mb * 16 + r;
+    f32x4 v = red[u * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v += red[(w * UNITS + u) * 64 + lane];
+    if (p.bias) {
+      const f32x4 b4 = *(const f32x4*)(p.bias + n);
+      v += b4;
+    }
+    if (p.R) {
+      const uint2 rv = *(const uint2*)(p.R + (int64_t)m * p.ldr + n);
+      v[0] += bf2f(rv.x & 0xffff); v[1] += bf2f(rv.x >> 16); v[2] += bf2f(rv.y & 0xffff); v[3] += bf2f(rv.y >> 16);
+    }
+    *(uint2*)(p.Y + (int64_t)m * p.ldy + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+  }
+}
+
+template <int MBK, int JN, int R>
+int launch_wsk(const wsk_params& p, hipStream_t s) {
+  constexpr int SLOT = (16 * MBK + 16 * JN) * ROWB;
+  constexpr int smem = NW * R * SLOT > NW * MBK * JN * 1024 ? NW * R * SLOT : NW * MBK * JN * 1024;
+  static_assert(smem <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)wsk_kernel<MBK, JN, R>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  const int tiles = (p.M / (16 * MBK)) * (p.N / (16 * JN));
+  hipLaunchKernelGGL((wsk_kernel<MBK, JN, R>), dim3(tiles), dim3(64 * NW), smem, s, p);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+
+}  // namespace
+
+extern "C" int sdlt_wsk_gemm(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t M, int32_t N, int32_t K, const float* bias,
+                             const void* R, int64_t ldr, void* Y, int64_t ldy, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (M % 64) || (N % 80) || ((N / 80) % 8) || (K % 256))
+    SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wsk_gemm: M=%d N=%d K=%d (M %% 64, N %% 640, K %% 256 == 0)", M, N, K);
+  if (!X || !W || !Y || (ldx % 8) || (ldw % 8) || (ldy % 4) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15) || ((uintptr_t)Y & 7) || (R && ((ldr % 4) || ((uintptr_t)R & 7))) ||
+      (bias && ((uintptr_t)bias & 15)))
+    SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_gemm: operand alignment");
+  wsk_params p{(const bf16_t*)X, ldx, (const bf16_t*)W, ldw, bias, (const bf16_t*)R, ldr, (bf16_t*)Y, ldy, M, N, K, 1};
+  return launch_wsk<4, 5, 2>(p, (hipStream_t)stream);
+}

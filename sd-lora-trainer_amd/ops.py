@@ -115,6 +115,16 @@ def set_throughput_hint(flag):
     THROUGHPUT_HINT = bool(flag)
 
 
+WSK = os.environ.get("SDLT_WSK", "1") != "0"
+
+
+def wsk_shape(M, N, K):
+    """Shapes the wave-split-K kernel takes over from the tiled one: 64 x 80 tiles that fill the 256 CUs exactly once (or less) and a K long
+    enough for its flatter per-step cost to pay (tools/wsk_probe.py: 1024 x 1280, K = 3840 / 5120: 19.8 / 23.3 us against 28.4 / 31.1 us;
+    equal at K = 1280 and 10240, slower on wider or taller outputs, which make more than 256 tiles)."""
+    return M % 64 == 0 and N % 640 == 0 and K % 256 == 0 and 2560 <= K <= 8192 and (M // 64) * (N // 80) <= 256
+
+
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
          residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0, batch=None,
          geglu_out=None, geglu_bwd=None, act_out=None, dact_in=None, col_scale=None):
@@ -133,6 +143,19 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
     batch: a GemmBatch - the launch runs len(batch) problems of identical shape / leading dimensions; the tensor arguments
     describe problem 0 (shapes, strides, options), every problem's operand pointers come from the batch."""
     lib = _lib.load()
+    if (WSK and conv is None and X2 is None and lora is None and rowbias is None and alpha == 1.0 and Ct is None and batch is None and geglu_out is None
+            and geglu_bwd is None and act_out is None and dact_in is None and col_scale is None and not accumulate and tile == 0 and splitk == 0
+            and out is not None and out.dtype == BF16 and not THROUGHPUT_HINT and wsk_shape(X.shape[0], W.shape[0], W.shape[1])):
+        # long-K 1280-wide product at batch 1 (ff.net.2 of the 1280-wide blocks): 64 x 80 tiles, K split over the waves (sdlt_wsk_gemm)
+        _chk2(X), _chk2(W), _chk2(out)
+        assert X.shape[1] == W.shape[1] and tuple(out.shape) == (X.shape[0], W.shape[0])
+        if bias is not None:
+            _chk2(bias, F32)
+        if residual is not None:
+            _chk2(residual)
+        _lib.check(lib.sdlt_wsk_gemm(_p(X), _ld(X), _p(W), _ld(W), X.shape[0], W.shape[0], W.shape[1], _p(bias), _p(residual),
+                                     _ld(residual) if residual is not None else 0, _p(out), _ld(out), _stream()), "sdlt_wsk_gemm")
+        return out
     p = _lib.GemmParams()
     _chk2(X), _chk2(W)
     p.X, p.ldx, p.W, p.ldw = _p(X), _ld(X), _p(W), _ld(W)

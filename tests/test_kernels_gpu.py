@@ -960,3 +960,33 @@ def test_strip_gemm_partial_into_layernorm_bwd(ops, B, N, K, S):
     ref = E.layernorm_bwd(x, pz.sum(0).cpu(), torch.empty(M, N, dtype=BF), None, gamma=gamma, dres=dres)
     got = ops.layernorm_bwd(x.cuda(), None, torch.empty(M, N, dtype=BF, device="cuda"), stats, gamma=gamma.cuda(), dres=dres.cuda(), dy_slabs=pz)
     close(got, ref, tol=2e-2, what="layernorm bwd on slabs")
+
+
+@pytest.mark.parametrize("M,N,K,res,bias", [(1024, 1280, 5120, True, True), (1024, 1280, 3840, False, False), (128, 640, 2560, True, False), (2048, 640, 4096, False, True),
+                                            (64, 1280, 256, True, True)])
+def test_wsk_gemm(ops, M, N, K, res, bias):
+    """sdlt_wsk_gemm (64 x 80 tiles, K split over the waves of a workgroup) against fp32 math on the same bf16 operands; both XCD mappings
+    of the tiles (rows x columns even / odd), ragged step counts per wave, bitwise reproducible; and ops.gemm routes the ff.net.2 shape to it."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w = rnd(M, K, g=g), rnd(N, K, g=g, scale=K ** -0.5)
+    b = torch.randn(N, generator=g) if bias else None
+    r = rnd(M, N, g=g) if res else None
+    ref = x.float() @ w.float().t() + (b if bias else 0.0) + (r.float() if res else 0.0)
+    lib = ops._lib.load()
+    xd, wd = x.cuda(), w.cuda()
+    bd, rd = (b.cuda() if bias else None), (r.cuda() if res else None)
+
+    def run():
+        y = torch.full((M, N), 7.0, dtype=BF, device="cuda")
+        rc = lib.sdlt_wsk_gemm(xd.data_ptr(), K, wd.data_ptr(), K, M, N, K, bd.data_ptr() if bias else None, rd.data_ptr() if res else None, N if res else 0,
+                               y.data_ptr(), N, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.sdlt_last_error()
+        return y
+    y = run()
+    close(y, ref, what="wsk gemm")
+    assert torch.equal(run(), y)
+    if ops.wsk_shape(M, N, K):
+        y2 = torch.empty(M, N, dtype=BF, device="cuda")
+        ops.gemm(xd, wd, y2, bias=bd, residual=rd)
+        assert torch.equal(y2, y), "ops.gemm did not take the wave-split-K route for this shape"
