@@ -18,6 +18,7 @@
 // (row i of a 16-row fragment <-> token (i/4)*8 + half*4 + i%4 of a 32-token block) so that the two
 // 16x16 accumulators of a 32-token block are, per lane, exactly the 8 consecutive tokens the next
 // 16x16x32 MFMA wants as its B operand.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/sdlt_kernels.h"
 
@@ -69,32 +70,37 @@ template <int DP>
 struct TileRegs { uint4 r[DP / 32]; };
 
 template <int DP>
-__device__ __forceinline__ void gload_nat(TileRegs<DP>& t, const bf16_t* src, int64_t ld, int64_t row0, int nrows, int col0, int d) {
+__device__ __forceinline__ void gload_nat(TileRegs<DP>& t, const bf16_t* src, int64_t ld, int64_t row0, int nrows, int col0, int d, int tid = threadIdx.x) {
   constexpr int CH = DP / 8;
 #pragma unroll
   for (int i = 0; i < DP / 32; ++i) {
-    int c = threadIdx.x + 256 * i;
+    int c = tid + 256 * i;
     int row = c / CH, ch = c - row * CH;
     t.r[i] = (row < nrows && ch * 8 < d) ? *(const uint4*)(src + (row0 + row) * ld + col0 + ch * 8) : make_uint4(0, 0, 0, 0);
   }
 }
 template <int DP>
-__device__ __forceinline__ void sstore_nat(const TileRegs<DP>& t, char* dst) {
+__device__ __forceinline__ void sstore_nat(const TileRegs<DP>& t, char* dst, int tid = threadIdx.x) {
   constexpr int NSTR = tile_stride<DP>(), CH = DP / 8;
 #pragma unroll
   for (int i = 0; i < DP / 32; ++i) {
-    int c = threadIdx.x + 256 * i;
+    int c = tid + 256 * i;
     int row = c / CH, ch = c - row * CH;
     *(uint4*)(dst + row * NSTR + ((ch ^ row_sw<DP>(row)) << 4)) = t.r[i];
   }
 }
 // =============================================================================== forward
-template <int DP>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const sdlt_attn_params p) {
+// KS = 2: the 64-key tiles of a query tile are dealt out to TWO groups of 4 waves (even / odd tiles), each with its own online softmax
+// state and K / V buffers; the groups' (m, l, O) meet through LDS at the end.  A 1024-token layer is 16 dependent tile steps per
+// workgroup and 1.25 workgroups per CU: with one wave per SIMD the softmax VALU work and the MFMAs of a step run one after the other -
+// two waves per SIMD on half the chain each overlap them (and halve the chain).
+template <int DP, int KS = 1>
+__global__ __launch_bounds__(256 * KS) void attn_fwd_kernel(const sdlt_attn_params p) {
   constexpr int NSTR = tile_stride<DP>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, g = lane >> 4, i = lane & 15;
+  const int grp = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), tid = threadIdx.x & 255;
   const int d = p.d, hc = h * d;
   const int q = q0 + wave * 16 + i;
   bf16x8 qf[DP / 32];
@@ -111,23 +117,30 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const sdlt_attn_params p)
   const int kend = p.causal ? min(p.Nk, q0 + 64) : p.Nk;
 
   constexpr int FBUF = 2 * 64 * NSTR;   // one K tile + one V tile
+  char* gsm = smem + grp * (2 * FBUF);  // this group's two buffers
+  const int ntile = (kend + 63) >> 6, niter = (ntile + KS - 1) / KS;
   TileRegs<DP> kr, vr;
-  gload_nat<DP>(kr, (const bf16_t*)p.K, p.ldk, (int64_t)b * p.Nkp, min(64, p.Nkp), hc, d);
-  gload_nat<DP>(vr, (const bf16_t*)p.V, p.ldv, (int64_t)b * p.Nkp, min(64, p.Nkp), hc, d);
-  sstore_nat<DP>(kr, smem);
-  sstore_nat<DP>(vr, smem + 64 * NSTR);
+  if (grp < ntile) {
+    const int kf0 = grp * 64;
+    gload_nat<DP>(kr, (const bf16_t*)p.K, p.ldk, (int64_t)b * p.Nkp + kf0, min(64, p.Nkp - kf0), hc, d, tid);
+    gload_nat<DP>(vr, (const bf16_t*)p.V, p.ldv, (int64_t)b * p.Nkp + kf0, min(64, p.Nkp - kf0), hc, d, tid);
+    sstore_nat<DP>(kr, gsm, tid);
+    sstore_nat<DP>(vr, gsm + 64 * NSTR, tid);
+  }
   const int troff = (8 * g + (i >> 2)) * NSTR + (i & 3) * 8;   // transposing-read lane offset inside a natural tile
   const int tsw = row_sw<DP>(8 * g + (i >> 2)) >> 1;   // this lane's XOR on the 32-byte column block of a transposing read
   __syncthreads();
-  int it = 0;
-  for (int k0 = 0; k0 < kend; k0 += 64, ++it) {
-    const char* Ks = smem + (it & 1) * FBUF;
+  for (int it = 0; it < niter; ++it) {
+    const int k0 = (it * KS + grp) * 64;
+    if (KS > 1 && k0 >= kend) { __syncthreads(); continue; }     // (the shorter group idles through the last turn; wave-uniform)
+    const char* Ks = gsm + (it & 1) * FBUF;
     const char* Vs = Ks + 64 * NSTR;
-    const bool more = k0 + 64 < kend;
+    const int kn = k0 + 64 * KS;          // this group's next tile
+    const bool more = kn < kend;
     if (more) {   // next tile's loads fly while this tile is computed
-      const int nk = min(64, p.Nkp - (k0 + 64));
-      gload_nat<DP>(kr, (const bf16_t*)p.K, p.ldk, (int64_t)b * p.Nkp + k0 + 64, nk, hc, d);
-      gload_nat<DP>(vr, (const bf16_t*)p.V, p.ldv, (int64_t)b * p.Nkp + k0 + 64, nk, hc, d);
+      const int nk = min(64, p.Nkp - kn);
+      gload_nat<DP>(kr, (const bf16_t*)p.K, p.ldk, (int64_t)b * p.Nkp + kn, nk, hc, d, tid);
+      gload_nat<DP>(vr, (const bf16_t*)p.V, p.ldv, (int64_t)b * p.Nkp + kn, nk, hc, d, tid);
     }
     f32x4 s[4];
 #pragma unroll
@@ -185,14 +198,35 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const sdlt_attn_params p)
       }
     }
     if (more) {
-      char* nb = smem + ((it + 1) & 1) * FBUF;
-      sstore_nat<DP>(kr, nb);
-      sstore_nat<DP>(vr, nb + 64 * NSTR);
+      char* nb = gsm + ((it + 1) & 1) * FBUF;
+      sstore_nat<DP>(kr, nb, tid);
+      sstore_nat<DP>(vr, nb + 64 * NSTR, tid);
     }
     __syncthreads();
   }
   lsum += __shfl_xor(lsum, 16, 64);
   lsum += __shfl_xor(lsum, 32, 64);
+  if constexpr (KS > 1) {
+    // merge the groups' softmax states: (m, l, O) of group 1 -> LDS -> group 0 (every tile buffer is dead after the last barrier)
+    float* mg = (float*)smem + (wave * 64 + lane) * (4 + DP / 4);       // [m, l, -, -, O...]: 16-byte aligned rows
+    if (grp == 1) {
+      mg[0] = m;
+      mg[1] = lsum;
+#pragma unroll
+      for (int df = 0; df < DP / 16; ++df) *(f32x4*)(mg + 4 + df * 4) = o[df];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+    const float m1 = mg[0], l1 = mg[1];
+    const float mn = fmaxf(m, m1), a0 = __builtin_amdgcn_exp2f(m - mn), a1 = __builtin_amdgcn_exp2f(m1 - mn);
+    m = mn;
+    lsum = lsum * a0 + l1 * a1;
+#pragma unroll
+    for (int df = 0; df < DP / 16; ++df) {
+      const f32x4 o1 = *(const f32x4*)(mg + 4 + df * 4);
+      o[df] = o[df] * a0 + o1 * a1;
+    }
+  }
   if (q < p.Nqp) {   // pad rows get finite values too, so no consumer ever reads uninitialised memory
     const float inv = 1.f / lsum;
     if (g == 0 && p.L && q < p.Nq) p.L[((int64_t)b * p.H + h) * p.Nq + q] = (m + log2f(lsum)) / LOG2E;
@@ -899,6 +933,16 @@ extern "C" int sdlt_attn_fwd(const sdlt_attn_params* pp, void* stream) {
   dim3 grid((p.Nq + 63) / 64, p.H, p.B);
 #define NSTRH(D_) ((D_) == 64 ? 128 : (D_) * 2 + 16)
 #define SMEM_FWD(D_) (2 * (2 * 64 * NSTRH(D_)))
+  // the key split (two wave groups per workgroup) pays on latency-bound grids only - less than two workgroups per CU and a chain of >= 4
+  // key tiles (tools/attn_probe.py: 1024 tokens x 20 heads 25.6 -> 22.9 us; 4096 x 10, 640 workgroups: 102 -> 114 us, so not there);
+  // SDLT_ATTN_KS=1 switches it off (A/B)
+  static const int ks_env = getenv("SDLT_ATTN_KS") ? atoi(getenv("SDLT_ATTN_KS")) : 2;
+  if (dp == 64 && ks_env == 2 && p.Nk >= 256 && (int64_t)grid.x * grid.y * grid.z <= 512) {
+    set_smem(attn_fwd_kernel<64, 2>, 2 * SMEM_FWD(64));
+    hipLaunchKernelGGL((attn_fwd_kernel<64, 2>), grid, dim3(512), 2 * SMEM_FWD(64), s, p);
+    SDLT_CHECK_LAUNCH();
+    return SDLT_OK;
+  }
   ATTN_DISPATCH(dp, attn_fwd_kernel, grid, SMEM_FWD)
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
