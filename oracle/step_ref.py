@@ -103,5 +103,37 @@ class RefTrainer:
         self.opt_unet.zero_grad()
         return out
 
+    def gradients(self, latent, noise, timesteps, mask, *, lr_ti=1.0, ids=None, caption_token_lists=None, time_ids=None, ctx=None, added_cond=None,
+                  img_ratio=1.0, bf16_faithful=False):
+        """The loss and its gradients of `step` WITHOUT touching any state (no optimizer step, no .grad): dict(pred, img_loss,
+        token_attention_loss, lora_grads (flat, parameter order), row_grads).  bf16_faithful: the UNet in unet_ref's bf16-faithful mode
+        (every tensor the HIP path stores in bf16 is rounded where it is stored, gradients included) - the second, tighter yardstick of
+        the real-topology parity tests."""
+        out = {}
+        if self.text is not None:
+            ctx, added_cond = self.conditioning(ids, time_ids)
+        noisy = L.add_noise(self.acp, latent, noise, timesteps)
+        pred, daam = U.unet_forward(self.cfg, self.sd, noisy, timesteps, ctx, added_cond, lora=self.lora, lora_scale=self.lora_scale, return_daam=True,
+                                    bf16_faithful=bf16_faithful)
+        loss = L.diffusion_loss(pred, noise, noisy, mask, self.acp, timesteps, snr_gamma=self.snr_gamma)
+        out["img_loss"] = float(loss.detach())
+        if self.text is not None:
+            ta = L.token_attention_loss(L.daam_stack([s for _, s in daam], img_ratio), mask, caption_token_lists, self.train_ids)
+            out["token_attention_loss"] = float(ta.detach())
+            loss = loss + self.ta_w * ta
+        if self.l1 > 0.0:
+            loss = loss + self.l1 * sum(p.abs().sum() for p in self.lora_params) / sum(p.numel() for p in self.lora_params)
+        wrt = list(self.lora_params)
+        if self.opt_ti is not None:
+            if lr_ti > 0.0:
+                loss = loss + self.std_w * torch.stack([st.std_loss(t[-self.n_tokens:]) for st, t in zip(self.stats, self.tables)]).mean()
+            wrt += list(self.tables)
+        grads = torch.autograd.grad(loss, wrt)
+        n = len(self.lora_params)
+        out["pred"] = pred.detach()
+        out["lora_grads"] = torch.cat([g.reshape(-1) for g in grads[:n]])
+        out["row_grads"] = [g[-self.n_tokens:].clone() for g in grads[n:]]
+        return out
+
     def lora_flat(self):
         return torch.cat([p.detach().reshape(-1) for p in self.lora_params])

@@ -265,10 +265,28 @@ def timestep_embedding(t, dim):
     return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
 
 
+class _RoundBF16(torch.autograd.Function):
+    """bf16 storage point of the HIP path, forward AND backward: the value is rounded to bf16 on the way in, the gradient on the way back
+    (the kernels keep every activation and every activation gradient in bf16 between launches and accumulate in fp32 inside)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
 class _Ctx:
-    def __init__(self, sd, lora, lora_scale, cfg):
+    def __init__(self, sd, lora, lora_scale, cfg, bf16_faithful=False):
         self.sd, self.lora, self.s, self.cfg = sd, lora or {}, lora_scale, cfg
         self.daam = []  # (name, scores[B,N,77])
+        # bf16-faithful mode (tests only): same arithmetic, but every tensor the HIP path STORES in bf16 is rounded where it is stored - layer
+        # outputs (after bias / residual / activation epilogues), the rank-r LoRA intermediate, normalised activations, softmax probabilities
+        # and attention outputs, the GEGLU product - and so are their gradients.  Comparing the HIP path with this mode separates rounding
+        # (what is left: summation order, a few double roundings) from logic; the fp32 mode stays the reference.
+        self.q = _RoundBF16.apply if bf16_faithful else (lambda t: t)
 
     # DoRA entries are (A, B, magnitude) [3P-unverified: peft 0.10.0 tuners/lora/layer.py, LoraLayer._apply_dora and Conv2d._apply_dora]:
     #   weight_norm = || W + s * B A ||_2 over every axis but the output one, DETACHED ("treated as a constant", DoRA sec. 4.3)
@@ -279,43 +297,43 @@ class _Ctx:
         y = F.linear(x, w, b)
         if name in self.lora:
             A, B, *m = self.lora[name]
-            up = self.s * F.linear(F.linear(x, A), B)
+            up = F.linear(self.q(self.s * F.linear(x, A)), B)
             if m:
                 scale = m[0].reshape(-1) / dora_weight_norm(w, A, B, self.s)
                 y = y + (scale - 1.0) * F.linear(x, w) + scale * up
             else:
                 y = y + up
-        return y
+        return self.q(y)
 
     def conv(self, name, x, stride=1):
         w = self.sd[name + ".weight"]
         y = F.conv2d(x, w, self.sd.get(name + ".bias"), stride=stride, padding=w.shape[-1] // 2)
         if name in self.lora:
             A, B, *m = self.lora[name]
-            up = self.s * F.conv2d(F.conv2d(x, A, None, stride=stride, padding=A.shape[-1] // 2), B)
+            up = F.conv2d(self.q(self.s * F.conv2d(x, A, None, stride=stride, padding=A.shape[-1] // 2)), B)
             if m:
                 scale = (m[0].reshape(-1) / dora_weight_norm(w, A, B, self.s)).view(1, -1, 1, 1)
                 y = y + (scale - 1.0) * F.conv2d(x, w, None, stride=stride, padding=w.shape[-1] // 2) + scale * up
             else:
                 y = y + up
-        return y
+        return self.q(y)
 
     def gn(self, name, x, eps):
         return F.group_norm(x, 32, self.sd[name + ".weight"], self.sd[name + ".bias"], eps)
 
     def ln(self, name, x):
-        return F.layer_norm(x, (x.shape[-1],), self.sd[name + ".weight"], self.sd[name + ".bias"], 1e-5)
+        return self.q(F.layer_norm(x, (x.shape[-1],), self.sd[name + ".weight"], self.sd[name + ".bias"], 1e-5))
 
 
 def _resnet(c, n, x, temb):
-    h = F.silu(c.gn(n + ".norm1", x, 1e-5))
+    h = c.q(F.silu(c.gn(n + ".norm1", x, 1e-5)))
     h = c.conv(n + ".conv1", h)
-    h = h + c.linear(n + ".time_emb_proj", F.silu(temb))[:, :, None, None]
-    h = F.silu(c.gn(n + ".norm2", h, 1e-5))
+    h = c.q(h + c.linear(n + ".time_emb_proj", F.silu(temb))[:, :, None, None])
+    h = c.q(F.silu(c.gn(n + ".norm2", h, 1e-5)))
     h = c.conv(n + ".conv2", h)
     if (n + ".conv_shortcut.weight") in c.sd:
         x = c.conv(n + ".conv_shortcut", x)
-    return x + h
+    return c.q(x + h)
 
 
 def _attention(c, n, x, ctx, heads, hooked):
@@ -332,7 +350,7 @@ def _attention(c, n, x, ctx, heads, hooked):
     if ctx is not None and hooked:
         # ti_cross_attn_loss.py:201-212: raw QK^T/sqrt(d) summed over heads, kept in graph
         c.daam.append((n, s.sum(dim=1)))
-    o = torch.softmax(s, dim=-1) @ vh
+    o = c.q(c.q(torch.softmax(s, dim=-1)) @ vh)
     o = o.transpose(1, 2).reshape(B, N, C)
     return c.linear(n + ".to_out.0", o)
 
@@ -340,7 +358,7 @@ def _attention(c, n, x, ctx, heads, hooked):
 def _transformer(c, n, x, ctx, heads, nlayers, hooked):
     B, C, H, W = x.shape
     res = x
-    h = c.gn(n + ".norm", x, 1e-6)
+    h = c.q(c.gn(n + ".norm", x, 1e-6))
     if c.cfg["linear_proj"]:
         h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
         h = c.linear(n + ".proj_in", h)
@@ -349,27 +367,29 @@ def _transformer(c, n, x, ctx, heads, nlayers, hooked):
         h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
     for k in range(nlayers):
         b = f"{n}.transformer_blocks.{k}"
-        h = h + _attention(c, b + ".attn1", c.ln(b + ".norm1", h), None, heads, False)
-        h = h + _attention(c, b + ".attn2", c.ln(b + ".norm2", h), ctx, heads, hooked)
+        h = c.q(h + _attention(c, b + ".attn1", c.ln(b + ".norm1", h), None, heads, False))
+        h = c.q(h + _attention(c, b + ".attn2", c.ln(b + ".norm2", h), ctx, heads, hooked))
         f = c.linear(b + ".ff.net.0.proj", c.ln(b + ".norm3", h))
         hid, gate = f.chunk(2, dim=-1)
-        h = h + c.linear(b + ".ff.net.2", hid * F.gelu(gate))
+        h = c.q(h + c.linear(b + ".ff.net.2", c.q(hid * F.gelu(gate))))
     if c.cfg["linear_proj"]:
         h = c.linear(n + ".proj_out", h)
         h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
     else:
         h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
         h = c.conv(n + ".proj_out", h)
-    return h + res
+    return c.q(h + res)
 
 
 def unet_forward(cfg, sd, sample, timesteps, ctx, added_cond=None, lora=None, lora_scale=1.0,
-                 return_daam=False):
+                 return_daam=False, bf16_faithful=False):
     """sample [B,4,h,w], timesteps int64[B], ctx [B,77,D]; added_cond = {"text_embeds":[B,P],
     "time_ids":[B,6]} for SDXL.  Returns eps_hat [B,4,h,w] (and the list of hooked attn2 score
     maps in the reference's hook order: down_blocks then up_blocks, mid_block never hooked,
     ti_cross_attn_loss.py:97)."""
-    c = _Ctx(sd, lora, lora_scale, cfg)
+    c = _Ctx(sd, lora, lora_scale, cfg, bf16_faithful)
+    if bf16_faithful:        # the engine's inputs are bf16 tensors too (noisy latent, text conditioning)
+        sample, ctx = c.q(sample), c.q(ctx)
     boc = cfg["block_out_channels"]
     L = cfg["layers_per_block"]
 
@@ -410,7 +430,7 @@ def unet_forward(cfg, sd, sample, timesteps, ctx, added_cond=None, lora=None, lo
             h = F.interpolate(h, scale_factor=2.0, mode="nearest")
             h = c.conv(f"up_blocks.{i}.upsamplers.0.conv", h)
 
-    h = F.silu(c.gn("conv_norm_out", h, 1e-5))
+    h = c.q(F.silu(c.gn("conv_norm_out", h, 1e-5)))
     out = c.conv("conv_out", h)
     if return_daam:
         return out, c.daam

@@ -18,6 +18,7 @@ Stated tolerances (bf16 storage of every activation, fp32 accumulation, ~200 GEM
   relative L2 <= 8e-2; token-row gradients cosine >= 0.985; trajectory: per-step image loss <= 3e-2 relative.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -162,11 +163,73 @@ def _set(ts, b, xl, h, n_enc):
     return tid
 
 
-TOL_BF16 = dict(pred=4e-2, loss=3e-2, ta=5e-2, reg=5e-2, cos=0.99, rel=8e-2, rows_cos=0.985, disp_cos=0.9, rows_final=2e-2)
-TOL_FP32 = dict(pred=2e-3, loss=1e-3, ta=2e-3, reg=2e-3, cos=0.9999, rel=5e-3, rows_cos=0.9999, disp_cos=0.99, rows_final=1e-3)
+# Two yardsticks (stated tolerances, bf16 storage / fp32 accumulation on the HIP side):
+#   TOL_BF16      against the fp32 oracle (THE reference): what bf16 storage through ~40 layers leaves, plus any logic error
+#   TOL_FAITHFUL  against the same oracle in its bf16-faithful mode (oracle/unet_ref.py: every tensor the HIP path stores in bf16 is rounded
+#                 where it is stored, gradients included): rounding is (mostly) common to both sides, so the bars are 3-6x tighter and a
+#                 wrong eps / bias / scale in ONE small adapter no longer hides in the noise of a 25 M-vector
+# per-adapter: the gradient of EVERY adapter tensor on its own (577 / 150 adapted layers), worst adjusted relative error ceiling `ada_rel` (see _per_adapter)
+# Measured on the real topologies (profiles/r03_parity_report.json): prediction 1.3-2.2 % of max-abs, flat LoRA gradient cos 0.99994-0.99998 /
+# rel-L2 0.7-1.1 %, median adapter 0.6-1.1 %, worst adapter 1.4-10 % (the 10 %: self-attention q / k adapters whose gradient is 1 % of the
+# median), token rows cos >= 0.9999 / rel-L2 0.6-1.3 %, image loss within 0.25 %.  Both oracle modes give the same figures to +-0.3 %: what
+# separates the HIP path from the fp32 reference is NOT dominated by where activations are rounded, so the bars below sit 2-3x above the
+# measurements for both (round 2: cos 0.99 / rel 8 % on the flat vector only).  LoRA displacement after 6 AdamW steps: cos 0.970 (SDXL: Adam turns the
+# noise of the near-zero gradients into +-lr moves) / 0.9995 (SD1.5); floor 0.95 (round 2: 0.9).
+TOL_BF16 = dict(pred=3e-2, loss=2e-2, ta=5e-2, reg=5e-2, cos=0.9995, rel=3e-2, rows_cos=0.999, rows_rel=5e-2, disp_cos=0.95, rows_final=2e-2, ada_rel=0.2)
+TOL_FAITHFUL = dict(pred=3e-2, loss=8e-3, cos=0.9995, rel=3e-2, rows_cos=0.999, rows_rel=5e-2, ada_rel=0.2)
+TOL_FP32 = dict(pred=2e-3, loss=1e-3, ta=2e-3, reg=2e-3, cos=0.9999, rel=5e-3, rows_cos=0.9999, rows_rel=1e-2, disp_cos=0.99, rows_final=1e-3, ada_rel=2e-2)
+TOL_FP32_FAITHFUL = dict(pred=3e-2, loss=2e-2, cos=0.99, rel=8e-2, rows_cos=0.985, rows_rel=0.2, ada_rel=0.45)     # (fp32 engine vs rounded oracle: the bf16 bars)
+REPORT = {}        # case -> worst adapters etc., written to gpurun_out/parity_report.json when that directory exists
 
 
-def run_step_and_trajectory(version, B, h, sd, kinds, *, device, ops=None, act_dtype=torch.bfloat16, tol=TOL_BF16, rank=16, n_steps=6, dora=False):
+def _per_adapter(names, lora, got, flat_ref):
+    """[(adjusted relative error, cosine, name.A|B|M, rms / median rms)] of every adapter tensor's gradient against its slice of the oracle's
+    flat gradient, worst first.  adjusted relative error = |got - ref| / sqrt(|ref|^2 + (0.1 median)^2): the plain relative L2 error for
+    every adapter with a normal-sized gradient; adapters whose gradient is (numerically) nothing - self-attention q / k at 64 tokens reach
+    1 % of the median rms - are judged against a tenth of the median adapter instead of against their own noise."""
+    res, off = [], 0
+    for k in names:
+        for t, tag, g in zip(lora[k], ("A", "B", "M"), got[k]):
+            n = t.numel()
+            ref = flat_ref[off:off + n]
+            c, _ = _cos_rel(g.reshape(-1), ref)
+            res.append([float((g.reshape(-1).float().cpu() - ref.float()).norm()) / math.sqrt(n), c, f"{k}.{tag}", float(ref.norm()) / math.sqrt(n)])
+            off += n
+    assert off == flat_ref.numel()
+    med = sorted(x[3] for x in res)[len(res) // 2]
+    for x in res:
+        x[0] = x[0] / math.sqrt(x[3] ** 2 + (0.1 * med) ** 2)
+        x[3] = x[3] / med
+    return sorted((tuple(x) for x in res), reverse=True)
+
+
+def _check_first_step(tag, tol, names, lora, pred, got, rows, o, dora):
+    """-> (report, failures): every first-step comparison against one oracle mode; the caller records the report, THEN raises."""
+    fails = []
+    err = float((pred - o["pred"]).abs().max()) / float(o["pred"].abs().max())
+    if err > tol["pred"]:
+        fails.append(f"[{tag}] prediction error {err}")
+    flat = torch.cat([t.reshape(-1) for k in names for t in got[k]])
+    cos, rel = _cos_rel(flat, o["lora_grads"])
+    if not (cos >= tol["cos"] and rel <= tol["rel"]):
+        fails.append(f"[{tag}] LoRA grads cos {cos} rel {rel}")
+    per = _per_adapter(names, lora, got, o["lora_grads"])
+    rep = dict(pred_err=err, lora_cos=cos, lora_rel=rel, worst_adapters=[dict(adj_rel=round(r, 4), cos=round(c, 5), name=n, rms_over_median=round(w, 4)) for r, c, n, w in per[:5]],
+               median_adapter_rel=per[len(per) // 2][0], n_adapter_tensors=len(per))
+    if per[0][0] > tol["ada_rel"]:
+        fails.append(f"[{tag}] worst adapter gradients (adjusted rel, cos, name, rms / median) {per[:5]}")
+    rr = []
+    for got_r, ref_r in zip(rows, o["row_grads"]):
+        cos, rel = _cos_rel(got_r, ref_r)
+        rr.append((cos, rel))
+        if not (cos >= tol["rows_cos"] and rel <= tol["rows_rel"]):
+            fails.append(f"[{tag}] token-row grads cos {cos} rel {rel}")
+    rep["token_rows"] = rr
+    return rep, fails
+
+
+def run_step_and_trajectory(version, B, h, sd, kinds, *, device, ops=None, act_dtype=torch.bfloat16, tol=TOL_BF16, rank=16, n_steps=6, dora=False,
+                            tol_faithful=TOL_FAITHFUL, case=None):
     """(a) + (b) for one topology; shared with the CPU test of the same flow on the toy topologies (op emulation, fp32).
     dora: weight-decomposed adapters (use_dora: magnitudes trained too, no L1 penalty / weight decay, config.py:153-157)."""
     from oracle import step_ref as R
@@ -196,17 +259,34 @@ def run_step_and_trajectory(version, B, h, sd, kinds, *, device, ops=None, act_d
     for step in range(n_steps):
         b = batches[step % 2]
         tid = _set(ts, b, xl, h, n_enc)
+        if step == 0 and tol_faithful is not None:      # the second yardstick, before the oracle's first optimizer step moves its parameters
+            ob = ref.gradients(b["latent"], b["noise"], b["t"], b["mask"], lr_ti=lr_ti, ids=b["ids"], caption_token_lists=b["lists"], time_ids=tid, bf16_faithful=True)
         o = ref.step(b["latent"], b["noise"], b["t"], b["mask"], lr=lr, lr_ti=lr_ti, ids=b["ids"], caption_token_lists=b["lists"], time_ids=tid)
         if step == 0:
             # eager first step: everything the oracle exposes
             pred = ts.forward_backward().float().cpu().reshape(B, h, h, 4).permute(0, 3, 1, 2)
             sync()
             assert torch.isfinite(pred).all()
-            err = float((pred - o["pred"]).abs().max()) / float(o["pred"].abs().max())
-            assert err <= tol["pred"], f"prediction error {err}"
             got = unet.arena.export("grads")
+            rows = [r.clone() for r in ts.ti.grad_rows]
+            rep, fails = {}, []
+            rep["fp32_oracle"], f1 = _check_first_step("fp32 oracle", tol, names, lora, pred, got, rows, o, dora)
+            fails += f1
+            if tol_faithful is not None:
+                rep["bf16_faithful_oracle"], f2 = _check_first_step("bf16-faithful oracle", tol_faithful, names, lora, pred, got, rows, ob, dora)
+                fails += f2
+                rep["bf16_faithful_oracle"]["loss_rel"] = abs(float(ts.loss) - ob["img_loss"]) / abs(ob["img_loss"])
+                if rep["bf16_faithful_oracle"]["loss_rel"] > tol_faithful["loss"]:
+                    fails.append(f"[bf16-faithful oracle] image loss {float(ts.loss)} vs {ob['img_loss']}")
+            if case is not None:
+                REPORT[case] = rep
+                out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+                if os.path.isdir(out_dir):
+                    import json
+                    with open(os.path.join(out_dir, "parity_report.json"), "w") as fh:
+                        json.dump(REPORT, fh, indent=1)
+            assert not fails, "\n".join(fails)
             cos, rel = _cos_rel(torch.cat([t.reshape(-1) for k in names for t in got[k]]), o["lora_grads"])
-            assert cos >= tol["cos"] and rel <= tol["rel"], f"LoRA grads cos {cos} rel {rel}"
             if dora:        # the magnitude gradients on their own (a small share of the flat vector above)
                 gm_ref, off = [], 0
                 for k in names:
@@ -215,9 +295,6 @@ def run_step_and_trajectory(version, B, h, sd, kinds, *, device, ops=None, act_d
                     off += nA + nB + nM
                 cos, rel = _cos_rel(torch.cat([got[k][2].reshape(-1) for k in names]), torch.cat(gm_ref))
                 assert cos >= tol["cos"] and rel <= tol["rel"], f"DoRA magnitude grads cos {cos} rel {rel}"
-            for got_r, ref_r in zip(ts.ti.grad_rows, o["row_grads"]):
-                cos, rel = _cos_rel(got_r, ref_r)
-                assert cos >= tol["rows_cos"], f"token-row grads cos {cos} rel {rel}"
             ts.sync_gradients()
             ts.set_hyper(lr, lr_ti)
             ts.optimizer_step()
@@ -241,6 +318,13 @@ def run_step_and_trajectory(version, B, h, sd, kinds, *, device, ops=None, act_d
     start = torch.cat([t.reshape(-1).float() for k in names for t in lora[k]])
     got = unet.arena.export("params")
     cos, rel = _cos_rel(torch.cat([t.reshape(-1) for k in names for t in got[k]]) - start, ref.lora_flat() - start)
+    if case is not None and case in REPORT:
+        REPORT[case]["displacement_after_steps"] = dict(steps=n_steps, cos=cos, rel=rel)
+        out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        if os.path.isdir(out_dir):
+            import json
+            with open(os.path.join(out_dir, "parity_report.json"), "w") as fh:
+                json.dump(REPORT, fh, indent=1)
     assert cos >= tol["disp_cos"], f"LoRA displacement after {n_steps} AdamW steps: cos {cos} rel {rel}"
     for rows, table in zip(ts.ti.rows, ref.tables):
         cos, rel = _cos_rel(rows, table.detach()[-NTOK:])
@@ -248,14 +332,14 @@ def run_step_and_trajectory(version, B, h, sd, kinds, *, device, ops=None, act_d
     return traj
 
 
-def _case_step_and_trajectory(version, B, dora=False, h=32, n_steps=6, rank=16):
+def _case_step_and_trajectory(version, B, dora=False, h=32, n_steps=6, rank=16, case=None):
     """(a) + (b): first step in detail, then 5 more optimizer steps; batches alternate between two injected ones so that the
     effect of training on a revisited batch is part of what is compared."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from oracle import unet_ref as U
     kinds = ["clip_l", "clip_g"] if U.CONFIGS[version]["addition"] else ["clip_l"]
-    run_step_and_trajectory(version, B, h, _unet_state(version), kinds, device="cuda:0", dora=dora, n_steps=n_steps, rank=rank)
+    run_step_and_trajectory(version, B, h, _unet_state(version), kinds, device="cuda:0", dora=dora, n_steps=n_steps, rank=rank, case=case)
 
 
 def _case_full_size_properties(version, B, h):
@@ -361,24 +445,24 @@ def _case_fullft_real_sdxl_topology():
                                   "sd15-full-size-step-parity"])
 def test_real_topology(case):
     if case == "sdxl-step-trajectory":
-        _case_step_and_trajectory("sdxl", 1)
+        _case_step_and_trajectory("sdxl", 1, case=case)
     elif case == "sdxl-full-size-step-parity":     # cfg3 at its FULL size (1024 px: 128 x 128 latent, batch 1): one whole step against the fp32 oracle
-        _case_step_and_trajectory("sdxl", 1, h=128, n_steps=1)
+        _case_step_and_trajectory("sdxl", 1, h=128, n_steps=1, case=case)
     elif case == "sd15-full-size-step-parity":     # cfg2 at its FULL size (512 px: 64 x 64 latent, batch 4)
-        _case_step_and_trajectory("sd15", 4, h=64, n_steps=1)
+        _case_step_and_trajectory("sd15", 4, h=64, n_steps=1, case=case)
     elif case == "sdxl-dora-step-trajectory":      # use_dora on all 577 adapted layers
-        _case_step_and_trajectory("sdxl", 1, dora=True)
+        _case_step_and_trajectory("sdxl", 1, dora=True, case=case)
     elif case == "sd15-dora-step-trajectory":      # the hyper-parameter sweep's variant (SD1.5 + use_dora, create_hyperparam_sweep.py:55,77)
-        _case_step_and_trajectory("sd15", 4, dora=True)
+        _case_step_and_trajectory("sd15", 4, dora=True, case=case)
     elif case == "sdxl-rank24-step":               # the sweep's ranks 24 / 64 (rank pads 32 / 64: K-grouped dX and batched K/V launches at the real widths)
-        _case_step_and_trajectory("sdxl", 1, n_steps=2, rank=24)
+        _case_step_and_trajectory("sdxl", 1, n_steps=2, rank=24, case=case)
     elif case == "sd15-rank64-step":
-        _case_step_and_trajectory("sd15", 4, n_steps=2, rank=64)
+        _case_step_and_trajectory("sd15", 4, n_steps=2, rank=64, case=case)
     elif case == "sdxl-full-size":
         _case_full_size_properties("sdxl", 1, 128)
     elif case == "sdxl-fullft-gradients":
         _case_fullft_real_sdxl_topology()
     elif case == "sd15-step-trajectory":
-        _case_step_and_trajectory("sd15", 4)
+        _case_step_and_trajectory("sd15", 4, case=case)
     else:
         _case_full_size_properties("sd15", 4, 64)

@@ -6,7 +6,7 @@ import torch
 
 from oracle import unet_ref as U
 from tests import emu_ops
-from tests.test_real_topology_gpu import TOL_FP32, _bf16_exact, run_step_and_trajectory
+from tests.test_real_topology_gpu import TOL_FP32, TOL_FP32_FAITHFUL, _bf16_exact, run_step_and_trajectory
 
 pytest.importorskip("transformers")
 
@@ -15,7 +15,7 @@ pytest.importorskip("transformers")
 def test_trajectory_cpu(version, B, kinds):
     sd = _bf16_exact(U.init_unet_state(U.CONFIGS[version], seed=0))
     traj = run_step_and_trajectory(version, B, 32 if U.CONFIGS[version]["addition"] else 16, sd, kinds, device="cpu", ops=emu_ops,
-                                   act_dtype=torch.float32, tol=TOL_FP32, rank=4, n_steps=6)
+                                   act_dtype=torch.float32, tol=TOL_FP32, tol_faithful=TOL_FP32_FAITHFUL, rank=4, n_steps=6)
     assert len(traj) == 6
 
 
@@ -24,4 +24,4 @@ def test_trajectory_dora_cpu(version, B, kinds):
     """use_dora (optimizer.py:86-95): magnitudes, column factor, scaled backward operands and the magnitude gradient through the same flow."""
     sd = _bf16_exact(U.init_unet_state(U.CONFIGS[version], seed=0))
     run_step_and_trajectory(version, B, 32 if U.CONFIGS[version]["addition"] else 16, sd, kinds, device="cpu", ops=emu_ops,
-                            act_dtype=torch.float32, tol=TOL_FP32, rank=4, n_steps=6, dora=True)
+                            act_dtype=torch.float32, tol=TOL_FP32, tol_faithful=TOL_FP32_FAITHFUL, rank=4, n_steps=6, dora=True)
