@@ -9,9 +9,12 @@ presents the same ones over the engine:
                           `.parameters()`, `.requires_grad_()`, `.device`, `.dtype`, `.save_pretrained()` (main.py:109,146,375;
                           checkpoint.py:175,212)
   (2) processor seam      `DAAMScores`: per hooked attn2 layer an object with `.cross_attention_scores [B, N, 77]`, in the order
-                          `find_attnprocessor2_0` walks them (ti_cross_attn_loss.py:88-112, 244-246) - read-only (heat maps, a
-                          torch-side token-attention loss on detached maps); the differentiable token-attention loss lives in
-                          step.TrainStep, where the 60 layers share one dS per resolution
+                          `find_attnprocessor2_0` walks them (ti_cross_attn_loss.py:88-112, 244-246).  With `keep_daam_maps` the maps are
+                          OUTPUTS of the same autograd node as the prediction ("kept in graph", ti_cross_attn_loss.py:201-212): the
+                          reference's `DAAMLoss` / `compute_token_attention_loss` (ti_cross_attn_loss.py:239-268, loss.py:10-80) run on
+                          them unchanged and `loss.backward()` carries every layer's own dS back into that layer's Q and K
+                          (S = Q K^T / sqrt(d): dQ += dS K / sqrt(d), dK += dS^T Q / sqrt(d), two GEMMs per hooked layer in the
+                          backward plan).  The fused step (step.TrainStep) shares ONE dS per resolution instead - same values
   (3) adapter API         `LoraConfig` + `get_peft_model` + `get_peft_model_state_dict` with peft's key names
                           `base_model.model.<module path>.lora_A.weight / lora_B.weight` (optimizer.py:86-95, checkpoint.py:183-184)
   (4) optimizer API       any `torch.optim.Optimizer` over `unet.parameters()`: the parameters ARE the fp32 master copies of the
@@ -44,7 +47,8 @@ class LoraConfig:
 
 class DAAMScores:
     """Stand-in for an installed `DAAMLossAttnProcessor2_0` (ti_cross_attn_loss.py:114-230): after a forward,
-    `.cross_attention_scores` is sum_heads(Q K^T / sqrt(d)) [B, N, 77] of that layer (fp32, detached)."""
+    `.cross_attention_scores` is sum_heads(Q K^T / sqrt(d)) [B, N, 77] of that layer - fp32 and, like the reference's, part of the
+    autograd graph of the call that produced it."""
 
     def __init__(self, name):
         self.name, self.cross_attention_scores = name, None
@@ -72,18 +76,37 @@ class _UNetFn(torch.autograd.Function):
         rt.want_dpooled = bool(u.cfg["addition"] and text_embeds is not None and text_embeds.requires_grad)
         rt.keep_daam_maps = mod.keep_daam_maps
         pred = u.forward(x64, timesteps.detach().to(device=rt.device, dtype=F32), ctxb, pooled, tid, B=B, H=h, W=w)
-        if mod.keep_daam_maps:
-            for proc, (_, S) in zip(mod.daam_processors, rt.daam):
-                proc.cross_attention_scores = S[:, :, :77].clone()
+        maps = []
+        if mod.keep_daam_maps:          # the score maps leave as further outputs of this node: a loss on them back-propagates (seam 2)
+            maps = [S[:, :, :77].clone() for _, S in rt.daam]
+            ctx.map_names = [name for name, _ in rt.daam]
+        ctx.n_maps = len(maps)
         ctx.mod, ctx.shape = mod, (B, h, w)
         ctx.ehs_dtype, ctx.te_dtype = ehs.dtype, (text_embeds.dtype if text_embeds is not None else None)
-        return pred.view(B, h, w, 4).permute(0, 3, 1, 2).to(sample.dtype).contiguous()
+        return (pred.view(B, h, w, 4).permute(0, 3, 1, 2).to(sample.dtype).contiguous(), *maps)
 
     @staticmethod
-    def backward(ctx, dpred):
+    def backward(ctx, dpred, *dmaps):
         mod = ctx.mod
         rt, u = mod.rt, mod.unet
         B, h, w = ctx.shape
+        if dpred is None:               # (a loss on the maps alone)
+            dpred = torch.zeros(B, 4, h, w, device=rt.device)
+        # gradients of the score maps -> per-layer (dS, dS^T) operands of the backward plan's score-gradient GEMMs
+        rt.daam_layer_grads = None
+        if ctx.n_maps and any(g is not None for g in dmaps):
+            lay = {}
+            for name, g in zip(ctx.map_names, dmaps):
+                if g is None:
+                    continue
+                N = g.shape[1]
+                dS = mod._buf(("dS", name), B * N, CTX_PAD)
+                dS.zero_()
+                dS.view(B, N, CTX_PAD)[:, :, :77] = g.to(dS.dtype)
+                dSt = mod._buf(("dSt", name), B * CTX_PAD, N)
+                dSt.view(B, CTX_PAD, N).copy_(dS.view(B, N, CTX_PAD).transpose(1, 2))
+                lay[name] = (dS, dSt)
+            rt.daam_layer_grads = lay
         d64 = mod._buf("dpred64", B * h * w, 64)
         d64.zero_()
         d64[:, :4] = dpred.permute(0, 2, 3, 1).reshape(B * h * w, 4).to(d64.dtype)
@@ -92,6 +115,7 @@ class _UNetFn(torch.autograd.Function):
         rt.daam_grads, rt.daam_applied = None, False
         with torch.enable_grad():       # (irrelevant to the HIP ops; the CPU op emulation of the tests differentiates with autograd inside)
             u.backward(d64, dctx)
+        rt.daam_layer_grads = None
         g_ehs = dctx.view(B, CTX_PAD, -1)[:, :77].to(ctx.ehs_dtype).clone()
         g_te = None
         if rt.want_dpooled:
@@ -176,7 +200,9 @@ class UNetModule:
         self._versions = vers
         if not torch.is_tensor(timestep):
             timestep = torch.tensor([timestep] * sample.shape[0])
-        out = _UNetFn.apply(self, sample, timestep, encoder_hidden_states, te, tid, *self._params)
+        out, *maps = _UNetFn.apply(self, sample, timestep, encoder_hidden_states, te, tid, *self._params)
+        for proc, S in zip(self.daam_processors, maps):
+            proc.cross_attention_scores = S
         if return_dict:
             import types
             return types.SimpleNamespace(sample=out)

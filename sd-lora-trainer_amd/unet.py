@@ -47,6 +47,7 @@ class Runtime:
         self.daam_grads = None       # N -> (dS bf16 [B*N, CTX_PAD], dS^T bf16 [B*CTX_PAD, N]) set by the token-attention loss
         self.want_dpooled = False    # SDXL: back-propagate into the pooled text embedding (textual inversion)
         self.dsemb = None
+        self.daam_layer_grads = None  # attention name -> (dS, dS^T) of ONE hooked layer (shim: autograd hands every layer its own score gradient)
         self.daam_applied = False    # this step's score-gradient GEMMs were issued up front (UNet.daam_backward)
         self.defer_daam_scores = True  # the hooked layers' score GEMMs run batched after the forward pass (UNet._daam_forward)
         self.trainer = None          # fullft.WeightTrainer when the whole UNet is trained (is_lora = False)
@@ -764,9 +765,10 @@ class Attention(_Module):
             # cross-attention: ~160 workgroups, each owning all 77 keys of one head and a range of query tiles; the fp32
             # dK/dV accumulators are adjacent so the kernel side zeroes / converts them with one launch each
             qs = max(2, min((N + 63) // 64, 160 // max(1, self.heads * B)))
-            pre_ = self.hooked and rt.daam_grads is not None and rt.daam_applied and self.daam_batched
+            lay_ = rt.daam_layer_grads.get(self.name) if (self.hooked and rt.daam_layer_grads) else None
+            pre_ = self.hooked and rt.daam_grads is not None and rt.daam_applied and self.daam_batched and lay_ is None
             # (a hooked layer whose score-gradient GEMMs still run per layer reads dk right after this kernel: no deferral then)
-            self._defer_sum = self.kv_batched and fused and self.d <= 96 and CTX_PAD <= 128 and (pre_ or not (self.hooked and rt.daam_grads is not None))
+            self._defer_sum = self.kv_batched and fused and self.d <= 96 and CTX_PAD <= 128 and lay_ is None and (pre_ or not (self.hooked and rt.daam_grads is not None))
             if self._defer_sum:      # the slabs of ALL layers are summed by one launch in UNet._cross_kv_backward: layer-owned, not scratch
                 kv32 = self.buf("dkv32", 2 * qs * Mk, C, dtype=F32)
             else:
@@ -774,16 +776,18 @@ class Attention(_Module):
             kw = dict(qsplit=qs, dK32=kv32[:qs * Mk], dV32=kv32[qs * Mk:])
             if self._defer_sum:
                 kw["defer_splitsum"] = True
-        pre = self.cross and self.hooked and rt.daam_grads is not None and rt.daam_applied and self.daam_batched
+        lay = rt.daam_layer_grads.get(self.name) if (self.cross and self.hooked and rt.daam_layer_grads) else None
+        pre = self.cross and self.hooked and rt.daam_grads is not None and rt.daam_applied and self.daam_batched and lay is None
         if pre:     # dq / dk already hold the score side output's gradient (UNet.daam_backward, one batched GEMM per group)
             kw.update(accumulate_dq=True, accumulate_dk=True)
         rt.ops.attn_bwd(q, k, v, None, None, self._b["O"], self._b["L"], dO, None, D, dq, dk, dv,
                         B=B, H=self.heads, Nq=N, Nk=Nk, Nqp=N, Nkp=Nkp, d=self.d, scale=self.scale, **kw)
         if self.cross and getattr(self, "_defer_sum", False):
             self._sum_item = dict(dK32=kw["dK32"], dV32=kw["dV32"], dK=dk, dV=dv, nsplit=kw["qsplit"], B=B, Nk=Nk, Nkp=Nkp, acc0=bool(kw.get("accumulate_dk")))
-        if self.cross and self.hooked and rt.daam_grads is not None and not pre:
-            # backward of the score side output: S = a Q K^T  ->  dQ += a dS K,  dK += a dS^T Q   (shared dS per resolution)
-            dS, dSt = rt.daam_grads[N]
+        if self.cross and self.hooked and (lay is not None or (rt.daam_grads is not None and not pre)):
+            # backward of the score side output: S = a Q K^T  ->  dQ += a dS K,  dK += a dS^T Q   (shared dS per resolution, or this
+            # layer's own when the maps are autograd outputs of the call-compatible module, shim._UNetFn)
+            dS, dSt = lay if lay is not None else rt.daam_grads[N]
             Kt, Qt = self._b["Kt"], self._b["Qt"]
             for b in range(B):
                 rt.ops.gemm(dS[b * N:(b + 1) * N], Kt[:, b * Nkp:(b + 1) * Nkp], dq[b * N:(b + 1) * N], residual=dq[b * N:(b + 1) * N],

@@ -131,3 +131,75 @@ def test_reference_loop_body_on_shim_cpu(version, B, dora, tmp_path):
     for proc, (name, s) in zip(unet.daam_processors, daam):
         assert proc.name == name + ".processor"
         torch.testing.assert_close(proc.cross_attention_scores, s, rtol=2e-3, atol=2e-3)
+
+
+def run_shim_token_attention(version, B, h, rt, tol, sd=None):
+    """SURVEY 8b seam 2: the score maps of the hooked attn2 layers are autograd outputs of the module call, so the reference-shaped
+    token-attention loss (DAAMLoss stack + compute_token_attention_loss, ti_cross_attn_loss.py:239-268 / loss.py:10-80, here in their
+    pinned restatement oracle/loss_ref.py) runs on `processor.cross_attention_scores` WITH gradient: image loss + w * token-attention loss,
+    `loss.backward()`; LoRA gradients and the gradient w.r.t. the text conditioning against autograd through the oracle UNet."""
+    cfg = U.CONFIGS[version]
+    if sd is None:
+        sd = {k: v.to(torch.bfloat16).float() for k, v in U.init_unet_state(cfg, seed=0).items()}
+    lora = U.init_lora(cfg, 8, seed=1, b_std=0.03)
+    dev = rt.device
+    g = torch.Generator().manual_seed(9)
+    latent = torch.randn(B, 4, h, h, generator=g) * cfg["scaling_factor"]
+    noise = torch.randn(B, 4, h, h, generator=g)
+    mask = (torch.rand(B, 1, h, h, generator=g) > 0.5).float().repeat(1, 4, 1, 1) * 0.9 + 0.05
+    t = torch.randint(0, 1000, (B,), generator=g)
+    pe = torch.randn(B, 77, cfg["cross_dim"], generator=g)
+    pooled = torch.randn(B, cfg["proj_class_in"] - 6 * cfg["addition_time_embed_dim"], generator=g) if cfg["addition"] else None
+    tid = torch.tensor([[1024., 1024, 0, 0, 8. * h, 8. * h]] * B) if cfg["addition"] else None
+    train_ids = [900, 901, 902]
+    lists = [[1, 5, 6] + (train_ids if b % 2 == 0 else [7]) + [8, 9, 2] for b in range(B)]       # one caption without the trigger tokens
+    acp = L.ddpm_alphas_cumprod()
+    w_ta = 5e-2            # (3e-7 in the reference's config: raised so that the side output's gradient is a visible share of the total)
+    noisy = L.add_noise(acp, latent, noise, t)
+
+    def total_loss(pred, maps, msk):
+        loss = L.diffusion_loss(pred, noise.to(pred.device), noisy.to(pred.device), msk, acp.to(pred.device), t.to(pred.device), snr_gamma=5.0)
+        return loss + w_ta * L.token_attention_loss(L.daam_stack(maps, 1.0), msk, lists, train_ids)
+
+    # oracle
+    o_params = {k: tuple(x.clone().requires_grad_(True) for x in v) for k, v in lora.items()}
+    o_pe = pe.clone().requires_grad_(True)
+    add = {"text_embeds": pooled, "time_ids": tid} if cfg["addition"] else None
+    pred_o, daam_o = U.unet_forward(cfg, sd, noisy, t, o_pe, add, lora=o_params, return_daam=True)
+    loss_o = total_loss(pred_o, [s for _, s in daam_o], mask)
+    flat_params = [x for ab in o_params.values() for x in ab]
+    grads_o = torch.autograd.grad(loss_o, flat_params + [o_pe])
+    # plain image loss only, to show that the side output's gradient matters in this comparison
+    g_img = torch.autograd.grad(L.diffusion_loss(U.unet_forward(cfg, sd, noisy, t, o_pe, add, lora=o_params), noise, noisy, mask, acp, t, snr_gamma=5.0), flat_params)
+
+    # product: the call-compatible module, reference-shaped code on its processors' maps
+    unet = shim.get_peft_model(version, sd, shim.LoraConfig(r=8, lora_alpha=8.0), batch_size=B, runtime=rt)
+    unet.unet.arena.load(lora)
+    unet.requires_grad_(True)
+    unet.keep_daam_maps = True
+    pe_d = pe.to(dev).requires_grad_(True)
+    pred = unet(noisy.to(dev), t.to(dev), encoder_hidden_states=pe_d, timestep_cond=None,
+                added_cond_kwargs={"text_embeds": pooled.to(dev), "time_ids": tid.to(dev)} if cfg["addition"] else None, return_dict=False)[0]
+    maps = [proc.cross_attention_scores for proc in unet.daam_processors]
+    assert len(maps) == len(daam_o) > 0 and all(m.requires_grad for m in maps)
+    loss = total_loss(pred, maps, mask.to(dev))
+    loss.backward()
+    assert abs(float(loss) - float(loss_o)) <= tol["loss"] * abs(float(loss_o)), (float(loss), float(loss_o))
+    exp = unet.unet.arena.export("grads")
+    flat = torch.cat([x.reshape(-1) for k in lora for x in exp[k]]).double().cpu()
+    ref = torch.cat([x.reshape(-1) for x in grads_o[:-1]]).double()
+    img = torch.cat([x.reshape(-1) for x in g_img]).double()
+    cos = float(flat @ ref / (flat.norm() * ref.norm()))
+    cos_img = float(img @ ref / (img.norm() * ref.norm()))
+    assert cos_img < tol["cos"] - 0.02, f"the token-attention term does not show in the gradient (cos of the image-only gradient {cos_img}): raise w_ta"
+    assert cos >= tol["cos"], f"LoRA gradient with the token-attention loss: cos {cos} (image-only gradient: {cos_img})"
+    ge, geo = pe_d.grad.cpu().double().reshape(-1), grads_o[-1].double().reshape(-1)
+    cos = float(ge @ geo / (ge.norm() * geo.norm()))
+    assert cos >= tol["cos"], f"encoder_hidden_states gradient with the token-attention loss: cos {cos}"
+    return unet
+
+
+@pytest.mark.parametrize("version,B", [("tinyxl", 1), ("tiny15", 2)])
+def test_token_attention_loss_through_shim_cpu(version, B):
+    rt = unet_mod.Runtime("cpu", B, act_dtype=torch.float32, ops=emu_ops)
+    run_shim_token_attention(version, B, 16, rt, dict(loss=1e-3, cos=0.9999))

@@ -7,9 +7,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("version,B", [("tinyxl", 1), ("tiny15", 2), ("sdxl", 1)])
-def test_reference_loop_body_on_shim_gpu(version, B):
-    """tiny*: toy topologies; sdxl: the REAL topology (random-init weights, 32 x 32 latent) behind the reference-shaped call."""
+@pytest.mark.parametrize("version,B,dora", [("tinyxl", 1, False), ("tiny15", 2, False), ("sdxl", 1, False), ("tinyxl", 1, True), ("tiny15", 2, True)])
+def test_reference_loop_body_on_shim_gpu(version, B, dora):
+    """tiny*: toy topologies; sdxl: the REAL topology (random-init weights, 32 x 32 latent) behind the reference-shaped call;
+    dora: LoraConfig(use_dora=True) (optimizer.py:86-95) - magnitudes are parameters of the module, trained by the torch optimizer."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import sd_lora_trainer_amd.unet as unet_mod
@@ -22,5 +23,21 @@ def test_reference_loop_body_on_shim_gpu(version, B):
     # (the real topology is ~200 GEMMs deep: prediction 6e-2 of max-abs, loss 3e-2; two steps - AdamW's normalised updates turn bf16-level
     #  gradient differences into +-lr parameter differences, so the twin's max-abs prediction error grows with every update: 8e-2 at the 4th)
     tol = dict(pred=4e-2, loss=2e-2, cos=0.99, param=1.5e-2) if sd is None else dict(pred=6e-2, loss=3e-2, cos=0.985, param=2e-2)
-    unet, losses = run_shim_vs_oracle(version, B, h, rt, tol, steps=4 if sd is None else 2, sd=sd)
+    unet, losses = run_shim_vs_oracle(version, B, h, rt, tol, steps=4 if sd is None else 2, sd=sd, dora=dora)
     assert all(l == l for l, _ in losses)
+
+
+@pytest.mark.parametrize("version,B", [("tinyxl", 1), ("tiny15", 2), ("sdxl", 1)])
+def test_token_attention_loss_through_shim_gpu(version, B):
+    """Seam 2 on the HIP path (tests/test_shim_cpu.run_shim_token_attention): the maps are autograd outputs, the reference-shaped loss on
+    them reaches the adapters and the text conditioning; sdxl = the real topology with its 60 hooked layers."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import sd_lora_trainer_amd.unet as unet_mod
+    from tests.test_shim_cpu import run_shim_token_attention
+    rt = unet_mod.Runtime("cuda:0", B)
+    sd, h = None, 32 if version == "tinyxl" else 16        # (the score-gradient GEMMs contract over the layer's tokens: >= 64 per image)
+    if not version.startswith("tiny"):
+        from tests.test_real_topology_gpu import _unet_state
+        sd, h = _unet_state(version), 32
+    run_shim_token_attention(version, B, h, rt, dict(loss=2e-2, cos=0.99), sd=sd)
