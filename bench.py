@@ -281,6 +281,8 @@ def main():
     ap.add_argument("--train-loop-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--full-ft", action="store_true", help="full-UNet fine-tune (BASELINE configs[4], train_configs/full_finetuning_example.json: "
                     "SDXL 512 px, batch 4 per GPU, AdamW over every UNet parameter); data parallel with one gradient all-reduce per step when --gpus > 1")
+    ap.add_argument("--profile-json", default=None, help="step profile of THIS command (tools/step_profile.py over the rocprofv3 kernel trace + FETCH_SIZE / "
+                    "WRITE_SIZE passes): source of roofline.traffic and roofline.hbm_kernels; default: profiles/r03_sdxl1024_ti_step_profile.json for the default workload")
     ap.add_argument("--launch-test", action="store_true", help=argparse.SUPPRESS)            # tests/test_parallel_cpu.py: launcher + timing protocol on CPU
     args = ap.parse_args()
     world_env = int(os.environ.get("WORLD_SIZE", "0") or 0)
@@ -435,19 +437,35 @@ def main():
         f_step = (3.0 * topology.fwd_flops(cfg, B, h, h, 0)["total"]) if full_ft else 2.0 * topology.fwd_flops(cfg, B, h, h, args.rank)["total"]
         t_step = elapsed / args.steps
         achieved = J * f_step / (ev_ms * 1e-3 / args.steps)
-        # HBM-side bytes per step: measured offline (PMC counters need rocprofv3 around the process), for the default workload only
-        traffic = None
+        # HBM-side bytes per step and per-family kernel time: measured around the process (PMC counters and the kernel trace need rocprofv3), handed
+        # back through --profile-json; the default workload falls back to the committed profile of this round and says which commit it is from
+        traffic = traffic_commit = hbm_kernels = None
         pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        tpath = os.path.join(pdir, "r02_sdxl1024_ti_hbm_traffic_pmc.json")
-        if not os.path.exists(tpath):
-            tpath = os.path.join(pdir, "r01_sdxl1024_ti_hbm_traffic_pmc.json")
-        if version == "sdxl" and res == 1024 and B == 1 and args.rank == 16 and text is not None and not args.ti_frozen and not full_ft and not args.dora and J == 1 and os.path.exists(tpath):
-            with open(tpath) as fh:
-                traffic = json.load(fh).get("traffic_bytes_per_step")
-        fpath = os.path.join(os.path.dirname(tpath), "r01_fullft_hbm_traffic_pmc.json")
+        default_workload = (version == "sdxl" and res == 1024 and B == 1 and args.rank == 16 and text is not None and not args.ti_frozen and not full_ft
+                            and not args.dora and J == 1)
+        ppath = args.profile_json or (os.path.join(pdir, "r03_sdxl1024_ti_step_profile.json") if default_workload else None)
+        if ppath and os.path.exists(ppath):
+            with open(ppath) as fh:
+                prof = json.load(fh)
+            traffic, traffic_commit = prof.get("traffic_bytes_per_step"), prof.get("commit")
+            # families bound by HBM: algorithmic bytes (every operand once, topology.hbm_bytes) / their kernel time in the profiled step
+            alg = topology.hbm_bytes(cfg, B, h, h, args.rank)
+            hbm_kernels = {}
+            for fam in ("layernorm", "groupnorm", "geglu", "adamw", "lora_grad"):
+                ms = prof.get("family_ms", {}).get(fam)
+                if ms:
+                    moved = prof.get("fetch_bytes_by_family", {}).get(fam, 0.0) + prof.get("write_bytes_by_family", {}).get(fam, 0.0)
+                    hbm_kernels[fam] = {"algorithmic_GB": alg[fam] / 1e9, "ms": ms, "GB_per_s": alg[fam] / ms / 1e6, "frac_of_8TBps": alg[fam] / (ms * 1e-3) / 8e12,
+                                        "launches": prof.get("family_launches", {}).get(fam), "measured_GB": moved / 1e9 if moved else None}
+        elif default_workload:
+            tpath = os.path.join(pdir, "r02_sdxl1024_ti_hbm_traffic_pmc.json")
+            if os.path.exists(tpath):
+                with open(tpath) as fh:
+                    traffic, traffic_commit = json.load(fh).get("traffic_bytes_per_step"), "round 2 final"
+        fpath = os.path.join(pdir, "r01_fullft_hbm_traffic_pmc.json")
         if full_ft and version == "sdxl" and res == 512 and B == 4 and os.path.exists(fpath):
             with open(fpath) as fh:
-                traffic = json.load(fh).get("traffic_bytes_per_step")
+                traffic, traffic_commit = json.load(fh).get("traffic_bytes_per_step"), "round 1"
         out = {
             "metric": "training images/sec, SDXL 1024px rank-16 LoRA, 1/2/4/8 GPU (job-parallel)",
             "value": world * J * B * args.steps / elapsed,
@@ -470,11 +488,12 @@ def main():
                                             + (f"; a step advances every job once ({J} images per GPU and step), ms_per_step is per such step" if J > 1 else "")),
                        "trained_params": arena.n, "graph": not args.no_graph, "final_loss": loss},
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_DENSE, "traffic": traffic,
+                         "frac": achieved / PEAK_BF16_DENSE, "traffic": traffic, "traffic_commit": traffic_commit,
+                         "traffic_GB_per_s": (traffic / (ev_ms * 1e-3 / args.steps) / 1e9) if traffic else None, "hbm_kernels": hbm_kernels,
                          "note": f"algorithmic {J} x {f_step / 1e12:.3f} TFLOP per step (2 x fwd census) / {ev_ms / args.steps:.3f} ms "
-                                 "per step (HIP events on the replay stream); traffic = HBM-side bytes per step from the committed "
-                                 "rocprofv3 PMC passes of this command (profiles/r0x_sdxl1024_ti_hbm_traffic_pmc.json, collected with the kernels of the commit named "
-                                 "in that file), null for other configs"},
+                                 "per step (HIP events on the replay stream); traffic = HBM-side bytes per step (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, "
+                                 "separate passes) of this command at commit `traffic_commit` (--profile-json, default profiles/r03_sdxl1024_ti_step_profile.json); "
+                                 "hbm_kernels: the HBM-bound kernel families - algorithmic bytes (topology.hbm_bytes) / their time in the profiled step, against 8 TB/s"},
         }
         print(f"[bench] timed region done: {t_step * 1e3:.2f} ms/step; extras follow", file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline and not full_ft:

@@ -197,6 +197,57 @@ def fwd_flops(cfg, B, H, W, rank=16, n_ctx=77):
     return tot
 
 
+def hbm_bytes(cfg, B, H, W, rank=16, n_ctx=77):
+    """ALGORITHMIC bytes per training step (forward + backward, LoRA training: dX only) of the kernel families that are bound by HBM, not by
+    MFMA - every operand touched once, bf16 activations: what `bench.py`'s roofline.hbm_kernels divides by the families' measured time.
+      groupnorm  forward 2 reads + 1 write of [B,HW,C] (statistics pass + apply), backward 4 reads + 1 write
+      layernorm  forward 1 read + 1 write of [N,C], backward 3 reads (x, dy, residual gradient) + 1 write
+      geglu      forward reads [N,8C] writes [N,4C]; backward reads [N,8C] + [N,4C], writes [N,8C]
+      adamw      7 fp32 words per adapter parameter (p, g, m, v read; p, m, v written) + the bf16 operand refresh (4 B read, 2 x 2 B written)
+      lora_grad  the rows the grouped dA / dB launch contracts over tokens: dY [M,N] + T [M,r] and X [M,K] + U [M,r] per adapter
+    """
+    tot = {"groupnorm": 0.0, "layernorm": 0.0, "geglu": 0.0, "lora_grad": 0.0}
+    Rp = 16 if rank <= 16 else (32 if rank <= 32 else 64)
+
+    def px(lvl):
+        return B * (H >> lvl) * (W >> lvl)
+
+    def gn(m, c):
+        tot["groupnorm"] += 8.0 * m * c * 2
+
+    def resnet(n, i, o, lvl):
+        gn(px(lvl), i)
+        gn(px(lvl), o)
+        tot["lora_grad"] += 2.0 * px(lvl) * (o + o + 2 * Rp)            # conv2 adapter: dY, X (each tap of the 3x3 window re-reads cached rows), T, U
+
+    def transformer(n, c, nlayers, heads, lvl):
+        N = px(lvl)
+        gn(N, c)
+        for _ in range(nlayers):
+            tot["layernorm"] += 3 * 6.0 * N * c * 2
+            tot["geglu"] += 32.0 * N * c * 2
+            tot["lora_grad"] += 6 * 2.0 * N * (2 * c + 2 * Rp) + 2 * 2.0 * B * n_ctx * (cfg["cross_dim"] + c + 2 * Rp)
+
+    def norm(n, c):
+        gn(px(0), c)
+
+    _walk(cfg, resnet, transformer, lambda *a: None, lambda *a: None, norm)
+    n_lora = sum((rank * (9 * k if conv else k) + n * rank) for (k, n, conv) in _lora_shapes(cfg))
+    tot["adamw"] = 36.0 * n_lora
+    tot["n_lora_params"] = n_lora
+    return tot
+
+
+def _lora_shapes(cfg):
+    """(K, N, is_conv) of every adapted layer (trainer/optimizer.py:84 target set)."""
+    shapes = param_shapes(cfg)
+    out = []
+    for n in lora_targets(cfg):
+        w = shapes[n + ".weight"]
+        out.append((w[1], w[0], len(w) == 4 and w[-1] == 3))
+    return out
+
+
 def n_params(cfg):
     return sum(math.prod(s) for s in param_shapes(cfg).values())
 
