@@ -281,6 +281,8 @@ def main():
     ap.add_argument("--train-loop-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--full-ft", action="store_true", help="full-UNet fine-tune (BASELINE configs[4], train_configs/full_finetuning_example.json: "
                     "SDXL 512 px, batch 4 per GPU, AdamW over every UNet parameter); data parallel with one gradient all-reduce per step when --gpus > 1")
+    ap.add_argument("--ddp-wire", default=None, choices=["fp32", "bf16"], help="--full-ft --gpus N: dtype of the matrix gradients on the xGMI wire "
+                    "(TrainStep(ddp_wire_dtype=); default fp32 = exact)")
     ap.add_argument("--profile-json", default=None, help="step profile of THIS command (tools/step_profile.py over the rocprofv3 kernel trace + FETCH_SIZE / "
                     "WRITE_SIZE passes): source of roofline.traffic and roofline.hbm_kernels; default: profiles/r03_sdxl1024_ti_step_profile.json for the default workload")
     ap.add_argument("--launch-test", action="store_true", help=argparse.SUPPRESS)            # tests/test_parallel_cpu.py: launcher + timing protocol on CPU
@@ -359,7 +361,7 @@ def main():
                 del csd
             text = S.TextStack(rt, encs, pool_mode="argmax")
         ts = S.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, l1_penalty=0.0 if args.dora else 0.03, weight_decay=0.0 if args.dora else 0.004, text=text, n_tokens=n_tok,
-                         process_group=True if (full_ft and world > 1) else None)
+                         process_group=True if (full_ft and world > 1) else None, ddp_wire_dtype=args.ddp_wire if (full_ft and world > 1) else None)
         rn = lambda *s: torch.randn(*s, generator=g, device=device)  # noqa: E731
         latent = rn(B, 4, h, h) * cfg["scaling_factor"]
         noise = rn(B, 4, h, h)
@@ -483,7 +485,7 @@ def main():
                                       "std regulariser, rows-only AdamW)" + (" [ti lr = 0: frozen-TI fast path, no text-encoder backward]" if args.ti_frozen else "") if text is not None else ", text conditioning injected (--no-ti)"),
                        "text_encoder_fwd_gflop_not_in_roofline": clip_flops / 1e9,
                        "jobs_per_gpu": J, "global_batch": world * J * B,
-                       "parallelism": (f"dp{world}: one fp32 gradient all-reduce of {arena.n * 4 / 1e9:.1f} GB per step (RCCL)" if (full_ft and world > 1)
+                       "parallelism": (f"dp{world}: bucketed {args.ddp_wire or 'fp32'} gradient all-reduce of {arena.n * (2 if args.ddp_wire == 'bf16' else 4) / 1e9:.1f} GB per step (RCCL), overlapped with the weight-gradient GEMMs" if (full_ft and world > 1)
                                        else f"job-parallel x{world * J} ({world} GPU(s) x {J} independent job(s) per GPU, no collective)"
                                             + (f"; a step advances every job once ({J} images per GPU and step), ms_per_step is per such step" if J > 1 else "")),
                        "trained_params": arena.n, "graph": not args.no_graph, "final_loss": loss},

@@ -145,7 +145,7 @@ class TrainStep:
                  weight_decay=0.004, grad_accum=1, betas=(0.9, 0.999), eps=1e-8, text: TextStack = None, n_tokens=3,
                  token_attention_loss_w=3e-7, ti_weight_decay=0.0, ti_std_loss_w=0.01, optimizer="adamw", ti_optimizer="adamw",
                  prodigy_d_coef=1.0, prodigy_growth_rate=1.05, text_lora_weight_decay=1e-5, process_group=None,
-                 cond_reg_w=0.0, tok_cov_reg_w=0.0, cond_target_norm=None, tok_cond_reg_w=0.0, reg_caption_ids=None):
+                 cond_reg_w=0.0, tok_cov_reg_w=0.0, cond_target_norm=None, tok_cond_reg_w=0.0, reg_caption_ids=None, ddp_wire_dtype=None):
         """process_group: data-parallel full fine-tune only (`unet.trainer` set) - a torch.distributed group (or True for the
         default one) over which the gradient arena is all-reduced once per optimiser step (RCCL on the GPU)."""
         if optimizer == "AdamW8bit":
@@ -172,6 +172,14 @@ class TrainStep:
             # backward (fullft.WeightTrainer.flush(bucket=i)), each bucket's all-reduce starts as soon as its gradients exist
             self.bucketed = self.world > 1 and grad_accum == 1
             unet.trainer.defer_flush = self.bucketed
+            # ddp_wire_dtype "bf16" (or SDLT_DDP_WIRE=bf16): the matrix gradients cross xGMI as bf16 - half the wire bytes (per GPU 2 (N-1)/N x 5.1
+            # instead of 10.3 GB for SDXL) for two more HBM passes per bucket (pack after its weight-gradient GEMMs, unpack after its
+            # all-reduce: ~15 GB of traffic each way per step) and a bf16 sum over the ranks; the vector region (biases, norm affine)
+            # and the token rows stay fp32.  Default fp32: exact, and no multi-GPU box was available to measure which side wins.
+            import os as _os
+            wire = ddp_wire_dtype or _os.environ.get("SDLT_DDP_WIRE", "fp32")
+            assert wire in ("fp32", "bf16"), wire
+            self.wire = torch.empty(unet.trainer.n_mat, dtype=torch.bfloat16, device=rt.device) if (wire == "bf16" and self.bucketed) else None
             if self.world > 1 and (optimizer == "prodigy" or (text is not None and ti_optimizer == "prodigy")):
                 raise NotImplementedError("data-parallel full fine-tune with Prodigy: its d-estimate is not scale free, the summed gradients would "
                                           "need their own normalisation - use AdamW / AdamW8bit (full_finetuning_example.json does)")
@@ -437,14 +445,22 @@ class TrainStep:
         tr = self.group
         works = []
         if self.ti is not None:      # token-row gradients (a few KB): complete after the backward graph, exchanged beside the first bucket
-            works.append(dist.all_reduce(self.ti.grads, group=self.pg, async_op=True))
+            works.append((dist.all_reduce(self.ti.grads, group=self.pg, async_op=True), None, None))
+        wire = getattr(self, "wire", None)
         for b, (o0, o1) in enumerate(tr.buckets):
             (flush_fns[b] if flush_fns is not None else (lambda b=b: tr.flush(bucket=b)))()
-            works.append(dist.all_reduce(tr.grads[o0:o1], group=self.pg, async_op=True))
+            if wire is not None:
+                o1w = min(o1, tr.n_mat)
+                wire[o0:o1w].copy_(tr.grads[o0:o1w])           # pack: fp32 -> bf16, queued behind the bucket's GEMMs
+                works.append((dist.all_reduce(wire[o0:o1w], group=self.pg, async_op=True), o0, o1w))
+            else:
+                works.append((dist.all_reduce(tr.grads[o0:o1], group=self.pg, async_op=True), None, None))
         if tr.n > tr.n_mat:
-            works.append(dist.all_reduce(tr.grads[tr.n_mat:], group=self.pg, async_op=True))
-        for w in works:
+            works.append((dist.all_reduce(tr.grads[tr.n_mat:], group=self.pg, async_op=True), None, None))
+        for w, o0, o1w in works:
             w.wait()
+            if o0 is not None:
+                tr.grads[o0:o1w].copy_(wire[o0:o1w])            # unpack: the optimizer reads fp32 sums
 
     def optimizer_step(self):
         self._unet_optimizer()
