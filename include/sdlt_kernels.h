@@ -450,9 +450,14 @@ int sdlt_strip_gemm(const sdlt_strip_params* p, void* stream);
  * fp32 accumulation), M % 64 == 0, N % 640 == 0, K % 256 == 0.  64 x 80 tiles (exactly 256 workgroups for 1024 x 1280), the 4 waves of a
  * workgroup split K and stage their own operands through private LDS rings - no block barrier in the K loop; the 4 partial tiles are added in
  * wave order (bitwise reproducible).  Replaces FeedForward.net[2] (nn.Linear(4 C, C)) of the 1280-wide BasicTransformerBlocks (+ the block's
- * residual) reached from main.py:329-336, where the 128 x 128-tile kernel leaves two thirds of the CUs idle. */
+ * residual) reached from main.py:329-336, where the 128 x 128-tile kernel leaves two thirds of the CUs idle.
+ * Adown != NULL: a rank-16 adapter rides along (peft LoRA on to_q / to_out.0 ..., trainer/optimizer.py:84-95) -
+ *   Y += bf16(lora_scale * X Adown^T) . Bup^T,  Adown [16, K], Bup [N, 16] (bf16 shadows, rank padded with zeros); the LoRA-down product uses 16
+ *   more MFMA rows of the same K walk, the LoRA-up is one 16x16x16 MFMA per output block in the epilogue; T_out [M, 16] (optional) receives
+ *   bf16(lora_scale * X Adown^T), the operand of the adapter-gradient launch - the contract of sdlt_gemm_bf16's lora_R = 16 path. */
 int sdlt_wsk_gemm(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t M, int32_t N, int32_t K, const float* bias,
-                  const void* R, int64_t ldr, void* Y, int64_t ldy, void* stream);
+                  const void* R, int64_t ldr, void* Y, int64_t ldy, const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup,
+                  float lora_scale, void* T_out, int64_t ld_t, void* stream);
 
 /* dX of nearest-2x upsampling: out[b,h,w,:] = sum of the 2x2 block of in [B,2H,2W,C]. */
 int sdlt_sum2x2(const void* in, int32_t B, int32_t H, int32_t W, int32_t C, void* out, void* stream);

@@ -27,12 +27,18 @@ struct wsk_params {
   const bf16_t* R; int64_t ldr;
   bf16_t* Y; int64_t ldy;
   int M, N, K, map2d;
+  // rank-16 adapter (LORA kernels): Y += bf16(s * X Adown^T) . Bup^T;  Adown [16, K], Bup [N, 16] (bf16 shadows, rank padded with zero rows /
+  // columns); T_out [M, 16] receives bf16(s * X Adown^T) for the adapter-gradient launch (or NULL)
+  const bf16_t* Adown; int64_t ld_adown;
+  const bf16_t* Bup; int64_t ld_bup;
+  bf16_t* T_out; int64_t ld_t;
+  float lora_scale;
 };
 
 // MBK x 16 rows, JN x 16 columns per workgroup; R ring slots per wave
-template <int MBK, int JN, int R>
+template <int MBK, int JN, int R, bool LORA = false>
 __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
-  constexpr int XR = 16 * MBK, WR = 16 * JN, SROWS = XR + WR, SLOT = SROWS * ROWB, PIECES = SROWS / 8;
+  constexpr int XR = 16 * MBK, WR = 16 * JN, SROWS = XR + WR + (LORA ? 16 : 0), SLOT = SROWS * ROWB, PIECES = SROWS / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
@@ -61,7 +67,8 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
   const bf16_t* xsrc = p.X + (int64_t)(m0 + srow) * p.ldx + schunk * 8;
   const bf16_t* wsrc = p.W + (int64_t)(n0 + srow) * p.ldw + schunk * 8;
-  const int64_t x8 = 8 * p.ldx, w8 = 8 * p.ldw;
+  const bf16_t* asrc = LORA ? p.Adown + (int64_t)srow * p.ld_adown + schunk * 8 : nullptr;
+  const int64_t x8 = 8 * p.ldx, w8 = 8 * p.ldw, a8 = 8 * p.ld_adown;
   char* ring = smem + wave * (R * SLOT);
   const int rot = (int)((unsigned)tn % (unsigned)nsteps);
   auto issue = [&](int i, int slot) {
@@ -73,14 +80,20 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
     for (int q = 0; q < XR / 8; ++q) glds16(xsrc + q * x8 + k0, dst + q * 1024);
 #pragma unroll
     for (int q = 0; q < WR / 8; ++q) glds16(wsrc + q * w8 + k0, dst + XR * ROWB + q * 1024);
+    if constexpr (LORA) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) glds16(asrc + q * a8 + k0, dst + (XR + WR) * ROWB + q * 1024);
+    }
   };
   const int foff0 = r * ROWB + (((0 * 4 + g) ^ (r & 7)) << 4), foff1 = r * ROWB + (((1 * 4 + g) ^ (r & 7)) << 4);
 
-  f32x4 acc[JN][MBK];
+  f32x4 acc[JN][MBK], tacc[MBK];
 #pragma unroll
-  for (int j = 0; j < JN; ++j)
+  for (int mb = 0; mb < MBK; ++mb) {
+    tacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int mb = 0; mb < MBK; ++mb) acc[j][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < JN; ++j) acc[j][mb] = tacc[mb];
+  }
 
 #pragma unroll
   for (int s = 0; s < R; ++s)
@@ -92,7 +105,7 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
     else if (R > 2 && after == 1) wait_vmcnt<PIECES>();
     else wait_vmcnt<0>();
     const char* base = ring + slot * SLOT;
-    bf16x8 xf[2][MBK], wf[2][JN];
+    bf16x8 xf[2][MBK], wf[2][JN], af[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int fo = kk ? foff1 : foff0;
@@ -100,6 +113,7 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
       for (int mb = 0; mb < MBK; ++mb) xf[kk][mb] = *(const bf16x8*)(base + mb * 16 * ROWB + fo);
 #pragma unroll
       for (int j = 0; j < JN; ++j) wf[kk][j] = *(const bf16x8*)(base + (XR + 16 * j) * ROWB + fo);
+      if constexpr (LORA) af[kk] = *(const bf16x8*)(base + (XR + WR) * ROWB + fo);
     }
     // (spreading the refill's DMA instructions between the MFMAs was measured and LOSES 10-15 %: the ring is one step deep, every cycle
     // a piece is issued later is a cycle less of its latency hidden)
@@ -113,18 +127,52 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
       for (int j = 0; j < JN; ++j)
 #pragma unroll
         for (int mb = 0; mb < MBK; ++mb) acc[j][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][j], xf[kk][mb], acc[j][mb], 0, 0, 0);
+    if constexpr (LORA) {      // the LoRA-down product rides the same K walk: 16 more MFMA rows, D[r][m] = sum_k Adown[r,k] x[m,k]
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int mb = 0; mb < MBK; ++mb) tacc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk], xf[kk][mb], tacc[mb], 0, 0, 0);
+    }
     slot = slot + 1 == R ? 0 : slot + 1;
   }
 
   // ---- the 4 partial tiles meet in LDS; unit u = (row block, column block), wave w finishes units w, w + 4, ...
-  constexpr int UNITS = MBK * JN, UPW = (UNITS + NW - 1) / NW;
+  constexpr int UNITS = MBK * JN, UALL = UNITS + (LORA ? MBK : 0), UPW = (UNITS + NW - 1) / NW;
   __syncthreads();
-  f32x4* red = (f32x4*)smem;
+  f32x4* red = (f32x4*)smem;                                  // [NW][UALL][64 lanes]
+  uint2* tsh = (uint2*)(smem + (size_t)NW * UALL * 1024);     // [MBK][64 lanes]: bf16(s T) in the 16x16x16 B-operand layout
 #pragma unroll
   for (int j = 0; j < JN; ++j)
 #pragma unroll
-    for (int mb = 0; mb < MBK; ++mb) red[(wave * UNITS + mb * JN + j) * 64 + lane] = acc[j][mb];
+    for (int mb = 0; mb < MBK; ++mb) red[(wave * UALL + mb * JN + j) * 64 + lane] = acc[j][mb];
+  if constexpr (LORA) {
+#pragma unroll
+    for (int mb = 0; mb < MBK; ++mb) red[(wave * UALL + UNITS + mb) * 64 + lane] = tacc[mb];
+  }
+  // adapter operands of this wave's units, requested before the barrier
+  uint2 bupf[UPW];
+  if constexpr (LORA) {
+#pragma unroll
+    for (int q = 0; q < UPW; ++q) {
+      const int u = wave + q * NW;
+      bupf[q] = make_uint2(0u, 0u);
+      if (u < UNITS) bupf[q] = *(const uint2*)(p.Bup + (int64_t)(n0 + 16 * (u % JN) + r) * p.ld_bup + 4 * g);
+    }
+  }
   __syncthreads();
+  if constexpr (LORA) {
+    // T = s * X Adown^T of row block `wave` (MBK <= NW): summed over the waves, rounded to bf16 - the accumulator layout D[r][m] (lane: m,
+    // rows 4g..4g+3) IS the B-operand layout of the 16x16x16 MFMA, so the LoRA-up below needs no data movement beyond this LDS word pair
+    if (wave < MBK) {
+      f32x4 t = red[(UNITS + wave) * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) t += red[(w * UALL + UNITS + wave) * 64 + lane];
+      const uint2 tb = make_uint2(pack2bf(t[0] * p.lora_scale, t[1] * p.lora_scale), pack2bf(t[2] * p.lora_scale, t[3] * p.lora_scale));
+      tsh[wave * 64 + lane] = tb;
+      if (p.T_out && tn == 0) *(uint2*)(p.T_out + (int64_t)(m0 + wave * 16 + r) * p.ld_t + 4 * g) = tb;
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int q = 0; q < UPW; ++q) {
     const int u = wave + q * NW;
@@ -132,7 +180,11 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
     const int mb = u / JN, j = u - mb * JN, n = n0 + 16 * j + 4 * g, m = m0 + mb * 16 + r;
     f32x4 v = red[u * 64 + lane];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) v += red[(w * UNITS + u) * 64 + lane];
+    for (int w = 1; w < NW; ++w) v += red[(w * UALL + u) * 64 + lane];
+    if constexpr (LORA) {
+      const uint2 tb = tsh[mb * 64 + lane];
+      v = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, bupf[q]), __builtin_bit_cast(s16x4, tb), v, 0, 0, 0);
+    }
     if (p.bias) {
       const f32x4 b4 = *(const f32x4*)(p.bias + n);
       v += b4;
@@ -145,18 +197,20 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   }
 }
 
-template <int MBK, int JN, int R>
+template <int MBK, int JN, int R, bool LORA>
 int launch_wsk(const wsk_params& p, hipStream_t s) {
-  constexpr int SLOT = (16 * MBK + 16 * JN) * ROWB;
-  constexpr int smem = NW * R * SLOT > NW * MBK * JN * 1024 ? NW * R * SLOT : NW * MBK * JN * 1024;
+  constexpr int SLOT = (16 * MBK + 16 * JN + (LORA ? 16 : 0)) * ROWB;
+  constexpr int RED = NW * (MBK * JN + (LORA ? MBK : 0)) * 1024 + (LORA ? MBK * 64 * 8 : 0);
+  constexpr int smem = NW * R * SLOT > RED ? NW * R * SLOT : RED;
   static_assert(smem <= 160 * 1024, "LDS budget");
+  static_assert(MBK <= NW, "one wave per T row block");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)wsk_kernel<MBK, JN, R>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)wsk_kernel<MBK, JN, R, LORA>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   const int tiles = (p.M / (16 * MBK)) * (p.N / (16 * JN));
-  hipLaunchKernelGGL((wsk_kernel<MBK, JN, R>), dim3(tiles), dim3(64 * NW), smem, s, p);
+  hipLaunchKernelGGL((wsk_kernel<MBK, JN, R, LORA>), dim3(tiles), dim3(64 * NW), smem, s, p);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }
@@ -164,12 +218,16 @@ int launch_wsk(const wsk_params& p, hipStream_t s) {
 }  // namespace
 
 extern "C" int sdlt_wsk_gemm(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t M, int32_t N, int32_t K, const float* bias,
-                             const void* R, int64_t ldr, void* Y, int64_t ldy, void* stream) {
+                             const void* R, int64_t ldr, void* Y, int64_t ldy, const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup,
+                             float lora_scale, void* T_out, int64_t ld_t, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (M % 64) || (N % 80) || ((N / 80) % 8) || (K % 256))
     SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wsk_gemm: M=%d N=%d K=%d (M %% 64, N %% 640, K %% 256 == 0)", M, N, K);
   if (!X || !W || !Y || (ldx % 8) || (ldw % 8) || (ldy % 4) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15) || ((uintptr_t)Y & 7) || (R && ((ldr % 4) || ((uintptr_t)R & 7))) ||
       (bias && ((uintptr_t)bias & 15)))
     SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_gemm: operand alignment");
-  wsk_params p{(const bf16_t*)X, ldx, (const bf16_t*)W, ldw, bias, (const bf16_t*)R, ldr, (bf16_t*)Y, ldy, M, N, K, 1};
-  return launch_wsk<4, 5, 2>(p, (hipStream_t)stream);
+  if (Adown && (!Bup || (ld_adown % 8) || ((uintptr_t)Adown & 15) || (ld_bup % 4) || ((uintptr_t)Bup & 7) || (T_out && ((ld_t % 4) || ((uintptr_t)T_out & 7)))))
+    SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_gemm: adapter operands (Adown [16, K] 16-byte rows, Bup [N, 16] / T_out [M, 16] 8-byte rows)");
+  wsk_params p{(const bf16_t*)X, ldx, (const bf16_t*)W, ldw, bias, (const bf16_t*)R, ldr, (bf16_t*)Y, ldy, M, N, K, 1,
+               (const bf16_t*)Adown, ld_adown, (const bf16_t*)Bup, ld_bup, (bf16_t*)T_out, ld_t, lora_scale};
+  return Adown ? launch_wsk<4, 5, 2, true>(p, (hipStream_t)stream) : launch_wsk<4, 5, 2, false>(p, (hipStream_t)stream);
 }

@@ -118,11 +118,19 @@ def set_throughput_hint(flag):
 WSK = os.environ.get("SDLT_WSK", "1") != "0"
 
 
-def wsk_shape(M, N, K):
-    """Shapes the wave-split-K kernel takes over from the tiled one: 64 x 80 tiles that fill the 256 CUs exactly once (or less) and a K long
-    enough for its flatter per-step cost to pay (tools/wsk_probe.py: 1024 x 1280, K = 3840 / 5120: 19.8 / 23.3 us against 28.4 / 31.1 us;
-    equal at K = 1280 and 10240, slower on wider or taller outputs, which make more than 256 tiles)."""
-    return M % 64 == 0 and N % 640 == 0 and K % 256 == 0 and 2560 <= K <= 8192 and (M // 64) * (N // 80) <= 256
+WSK_LORA = os.environ.get("SDLT_WSK_LORA", "1") != "0"
+
+
+def wsk_shape(M, N, K, lora=False):
+    """Shapes the wave-split-K kernel takes over from the tiled one: 64 x 80 tiles that fill the 256 CUs exactly once (or less).  Without an
+    adapter: a K long enough for its flatter per-step cost to pay (tools/wsk_probe.py: 1024 x 1280, K = 3840 / 5120: 19.8 / 23.3 us against 28.4 /
+    31.1 us; equal at K = 1280 and 10240, slower on wider or taller outputs, which make more than 256 tiles).  With a rank-16 adapter: the
+    1024 x 1280 x 1280 projections (to_q / to_out.0 and their input gradients, 310 launches of an SDXL step)."""
+    if not (M % 64 == 0 and N % 640 == 0 and K % 256 == 0 and (M // 64) * (N // 80) <= 256):
+        return False
+    if lora:
+        return WSK_LORA and 1024 <= K <= 8192 and (M // 64) * (N // 80) >= 128
+    return 2560 <= K <= 8192
 
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
@@ -143,18 +151,30 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
     batch: a GemmBatch - the launch runs len(batch) problems of identical shape / leading dimensions; the tensor arguments
     describe problem 0 (shapes, strides, options), every problem's operand pointers come from the batch."""
     lib = _lib.load()
-    if (WSK and conv is None and X2 is None and lora is None and rowbias is None and alpha == 1.0 and Ct is None and batch is None and geglu_out is None
+    if (WSK and conv is None and X2 is None and rowbias is None and alpha == 1.0 and Ct is None and batch is None and geglu_out is None
             and geglu_bwd is None and act_out is None and dact_in is None and col_scale is None and not accumulate and tile == 0 and splitk == 0
-            and out is not None and out.dtype == BF16 and not THROUGHPUT_HINT and wsk_shape(X.shape[0], W.shape[0], W.shape[1])):
-        # long-K 1280-wide product at batch 1 (ff.net.2 of the 1280-wide blocks): 64 x 80 tiles, K split over the waves (sdlt_wsk_gemm)
+            and not lora_group_n and not lora_group_k and out is not None and out.dtype == BF16 and not THROUGHPUT_HINT
+            and (lora is None or (lora[0].shape[0] == 16 and lora[1].shape[1] == 16)) and wsk_shape(X.shape[0], W.shape[0], W.shape[1], lora is not None)):
+        # 1280-wide product at batch 1 with exactly one 64 x 80 tile per CU: K split over the waves, rank-16 adapter fused (sdlt_wsk_gemm)
         _chk2(X), _chk2(W), _chk2(out)
-        assert X.shape[1] == W.shape[1] and tuple(out.shape) == (X.shape[0], W.shape[0])
+        M_, N_, K_ = X.shape[0], W.shape[0], W.shape[1]
+        assert X.shape[1] == K_ and tuple(out.shape) == (M_, N_)
         if bias is not None:
             _chk2(bias, F32)
         if residual is not None:
             _chk2(residual)
-        _lib.check(lib.sdlt_wsk_gemm(_p(X), _ld(X), _p(W), _ld(W), X.shape[0], W.shape[0], W.shape[1], _p(bias), _p(residual),
-                                     _ld(residual) if residual is not None else 0, _p(out), _ld(out), _stream()), "sdlt_wsk_gemm")
+        A_ = B_ = T_ = None
+        scale_ = 0.0
+        if lora is not None:
+            A_, B_, scale_, T_ = lora
+            _chk2(A_), _chk2(B_)
+            assert tuple(A_.shape) == (16, K_) and tuple(B_.shape) == (N_, 16)
+            if T_ is not None:
+                _chk2(T_)
+                assert tuple(T_.shape) == (M_, 16)
+        _lib.check(lib.sdlt_wsk_gemm(_p(X), _ld(X), _p(W), _ld(W), M_, N_, K_, _p(bias), _p(residual), _ld(residual) if residual is not None else 0,
+                                     _p(out), _ld(out), _p(A_), _ld(A_) if A_ is not None else 0, _p(B_), _ld(B_) if B_ is not None else 0, float(scale_),
+                                     _p(T_), _ld(T_) if T_ is not None else 0, _stream()), "sdlt_wsk_gemm")
         return out
     p = _lib.GemmParams()
     _chk2(X), _chk2(W)

@@ -980,7 +980,7 @@ def test_wsk_gemm(ops, M, N, K, res, bias):
     def run():
         y = torch.full((M, N), 7.0, dtype=BF, device="cuda")
         rc = lib.sdlt_wsk_gemm(xd.data_ptr(), K, wd.data_ptr(), K, M, N, K, bd.data_ptr() if bias else None, rd.data_ptr() if res else None, N if res else 0,
-                               y.data_ptr(), N, torch.cuda.current_stream().cuda_stream)
+                               y.data_ptr(), N, None, 0, None, 0, 0.0, None, 0, torch.cuda.current_stream().cuda_stream)
         assert rc == 0, lib.sdlt_last_error()
         return y
     y = run()
@@ -990,3 +990,35 @@ def test_wsk_gemm(ops, M, N, K, res, bias):
         y2 = torch.empty(M, N, dtype=BF, device="cuda")
         ops.gemm(xd, wd, y2, bias=bd, residual=rd)
         assert torch.equal(y2, y), "ops.gemm did not take the wave-split-K route for this shape"
+
+
+@pytest.mark.parametrize("M,N,K,res,bias,rank", [(1024, 1280, 1280, True, True, 16), (1024, 1280, 1280, False, False, 8), (512, 1280, 2560, True, False, 4), (128, 640, 256, False, True, 16)])
+def test_wsk_gemm_fused_lora(ops, M, N, K, res, bias, rank):
+    """sdlt_wsk_gemm with a rank-<=16 adapter riding along, against the emulation of the tiled kernel's LoRA contract (T rounded to bf16
+    before the up-projection, T_out = bf16(s X Adown^T)) and against sdlt_gemm_bf16 itself; ops.gemm routes the 1024 x 1280 x 1280 projections here."""
+    g = torch.Generator().manual_seed(M + N + K + rank)
+    x, w = rnd(M, K, g=g), rnd(N, K, g=g, scale=K ** -0.5)
+    A, Bu = torch.zeros(16, K, dtype=BF), torch.zeros(N, 16, dtype=BF)
+    A[:rank], Bu[:, :rank] = rnd(rank, K, g=g, scale=1.0 / rank), rnd(N, rank, g=g, scale=0.05)
+    b = torch.randn(N, generator=g) if bias else None
+    r = rnd(M, N, g=g) if res else None
+    scale = 1.5
+    ref, tref = torch.empty(M, N, dtype=BF), torch.empty(M, 16, dtype=BF)
+    E.gemm(x, w, ref, lora=(A, Bu, scale, tref), bias=b, residual=r)
+    lib = ops._lib.load()
+    xd, wd, Ad, Bd = x.cuda(), w.cuda(), A.cuda(), Bu.cuda()
+    bd, rd = (b.cuda() if bias else None), (r.cuda() if res else None)
+    y, T = torch.full((M, N), 7.0, dtype=BF, device="cuda"), torch.full((M, 16), 7.0, dtype=BF, device="cuda")
+    rc = lib.sdlt_wsk_gemm(xd.data_ptr(), K, wd.data_ptr(), K, M, N, K, bd.data_ptr() if bias else None, rd.data_ptr() if res else None, N if res else 0,
+                           y.data_ptr(), N, Ad.data_ptr(), K, Bd.data_ptr(), 16, scale, T.data_ptr(), 16, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.sdlt_last_error()
+    close(y, ref, what="wsk gemm + lora")
+    close(T, tref, what="wsk T_out")
+    y2, T2 = torch.empty(M, N, dtype=BF, device="cuda"), torch.empty(M, 16, dtype=BF, device="cuda")
+    ops.gemm(xd, wd, y2, lora=(Ad, Bd, scale, T2), bias=bd, residual=rd, tile=2)            # the tiled kernel (an explicit tile keeps it there)
+    close(y, y2, tol=1e-2, what="wsk vs tiled kernel")
+    close(T, T2, tol=1e-2, what="wsk vs tiled T_out")
+    if ops.wsk_shape(M, N, K, True):
+        y3, T3 = torch.empty(M, N, dtype=BF, device="cuda"), torch.empty(M, 16, dtype=BF, device="cuda")
+        ops.gemm(xd, wd, y3, lora=(Ad, Bd, scale, T3), bias=bd, residual=rd)
+        assert torch.equal(y3, y) and torch.equal(T3, T), "ops.gemm did not take the wave-split-K route for this shape"
