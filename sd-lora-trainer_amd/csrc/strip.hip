@@ -4,19 +4,26 @@
 // 80-row product whose cost is streaming its weights once - 39 MB per OpenCLIP-bigG layer, 1.4 GB per encoder pass and direction.
 // The tiled GEMM (gemm.hip) cuts such a product into 64x64 tiles + split-K: 10-40 workgroups, 9-18 us per launch, 30-150 TFLOP/s.
 // Here the roles are turned round:
-//   * a workgroup owns a STRIP of 16*J output columns over the full K; its 8 waves split K in interleaved 32-column steps
-//     (wave w takes steps w, w+8, ...), so 8 waves read 512 contiguous bytes of every weight row;
-//   * no LDS staging and no barrier in the K loop: both MFMA operands are loaded straight from global memory in fragment layout
-//     (16 B per lane; the weight rows come from HBM exactly once, the 80 activation rows from L2) with a 5-deep register ring -
-//     every wave has up to 30 KB of loads in flight from its first instruction, which is what a weight-streaming kernel needs;
-//   * the 8 partial 80 x 16J tiles meet in LDS once, at the end (fixed order: bitwise reproducible);
-//   * N / (16 J) workgroups (80 ... 320 for the CLIP widths) - every launch covers most of the chip without split-K seams.
+//   * a workgroup owns a STRIP of 16*J output columns over the full K; its 4 waves split K in interleaved 64-column steps
+//     (wave w takes steps w, w+4, ...), so the 4 waves read 512 contiguous bytes of every row;
+//   * every wave stages its own operands - the 80 activation rows and its 16 J weight rows of a step - through a PRIVATE LDS ring with
+//     global_load_lds in full 128-byte rows (source-side XOR swizzle, conflict-free ds_read_b128 fragments): no block barrier in the K
+//     loop, counted vmcnt waits, 24 KB of loads in flight per wave.  (A first version loaded both MFMA operands straight from global
+//     memory in fragment layout - 16 rows x 64 B per instruction - and ran at 30 GB/s per CU: the texture path serves one row per quad
+//     and cycle; full-line staging is 2-3x faster, tools/strip_probe.py.)
+//   * the 4 partial 80 x 16J tiles meet in LDS once, at the end (fixed order: bitwise reproducible);
+//   * N / (16 J) workgroups (48 ... 320 for the CLIP widths).  Long-K products can be cut into K slices whose fp32 tiles the CONSUMER adds in
+//     its prologue (P != NULL -> sdlt_layernorm_bwd_slabs): a reduction at the launch boundary is free, while the in-kernel last-arriver
+//     seam (splitk > 1: write-through slab stores, drain, ticket, acquire, slab reads) costs 4-5 us - more than the shorter K walk saves
+//     at every CLIP shape, so it stays an option.
 // Fused around it:
 //   * LayerNorm in front (ln = 1): the product runs on the RAW rows with pre-scaled weights W' = W o gamma; the row statistics
 //     come from the same fragments through two more MFMAs per fragment (ones . x -> row sums, x . x^T -> its diagonal = row sums
 //     of squares), and the epilogue applies  y = rstd (acc - mean c1[n]) + c2[n],  c1 = rowsum(W'), c2 = W beta + bias.
 //     No normalised copy of the activations exists; (mean, rstd) are written for the LayerNorm backward.
 //   * bias, residual, the MLP activation as a second output (act = 1 quick_gelu, 2 gelu) or its derivative as a factor (Z given).
+// Measured (tools/strip_probe.py, weights rotating through HBM): 1280 x 1280 5.3 us (tiled 9.9), 3840 x 1280 + LayerNorm 8.0 (13.7),
+// 5120 x 1280 + LayerNorm + gelu 10.8 (15.7), 1280 x 5120 13.0 (15.1), 768 x 768 3.7 (7.9).
 #include "common.h"
 #include "../../include/sdlt_kernels.h"
 
