@@ -454,10 +454,13 @@ int sdlt_strip_gemm(const sdlt_strip_params* p, void* stream);
  * Adown != NULL: a rank-16 adapter rides along (peft LoRA on to_q / to_out.0 ..., trainer/optimizer.py:84-95) -
  *   Y += bf16(lora_scale * X Adown^T) . Bup^T,  Adown [16, K], Bup [N, 16] (bf16 shadows, rank padded with zeros); the LoRA-down product uses 16
  *   more MFMA rows of the same K walk, the LoRA-up is one 16x16x16 MFMA per output block in the epilogue; T_out [M, 16] (optional) receives
- *   bf16(lora_scale * X Adown^T), the operand of the adapter-gradient launch - the contract of sdlt_gemm_bf16's lora_R = 16 path. */
+ *   bf16(lora_scale * X Adown^T), the operand of the adapter-gradient launch - the contract of sdlt_gemm_bf16's lora_R = 16 path.
+ * lora_group_k > 0: K is 2 or 3 groups of lora_group_k columns with one adapter each (the input gradient of the stacked to_q|to_k|to_v):
+ *   T_g = X[:, group g] . Adown[:, group g]^T, Y += sum_g bf16(s T_g) . Bup[:, 16 g ..]^T, Bup [N, 16 G], T_out [M, 16 G] - sdlt_gemm_bf16's
+ *   lora_group_k contract. */
 int sdlt_wsk_gemm(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t M, int32_t N, int32_t K, const float* bias,
                   const void* R, int64_t ldr, void* Y, int64_t ldy, const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup,
-                  float lora_scale, void* T_out, int64_t ld_t, void* stream);
+                  float lora_scale, void* T_out, int64_t ld_t, int32_t lora_group_k, void* stream);
 
 /* dX of nearest-2x upsampling: out[b,h,w,:] = sum of the 2x2 block of in [B,2H,2W,C]. */
 int sdlt_sum2x2(const void* in, int32_t B, int32_t H, int32_t W, int32_t C, void* out, void* stream);

@@ -157,7 +157,7 @@ SYMBOLS = {
     "sdlt_dora_scale_wt": (i32, [vp, vp, vp, i32, vp]),
     "sdlt_dora_mag_grad": (i32, [vp, vp, vp, i32, vp, vp, i32, vp, vp]),
     "sdlt_strip_gemm": (i32, [C.POINTER(StripParams), vp]),
-    "sdlt_wsk_gemm": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp, i64, vp, i64, vp, i64, vp, i64, f32, vp, i64, vp]),
+    "sdlt_wsk_gemm": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp, i64, vp, i64, vp, i64, vp, i64, f32, vp, i64, i32, vp]),
     "sdlt_sum2x2": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "sdlt_colsum": (i32, [vp, i64, i32, i32, i32, vp, i64, vp, vp, vp]),
     "sdlt_embed_gather": (i32, [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp]),

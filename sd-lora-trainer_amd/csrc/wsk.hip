@@ -33,11 +33,16 @@ struct wsk_params {
   const bf16_t* Bup; int64_t ld_bup;
   bf16_t* T_out; int64_t ld_t;
   float lora_scale;
+  // K-grouped adapters (group_k > 0; the input gradient of stacked projections): K is G = K / group_k groups of group_k columns, group g has
+  // its own rank-16 adapter: T_g = X[:, group g] . Adown[:, group g]^T, Y += sum_g bf16(s T_g) . Bup[:, 16 g .. 16 g + 15]^T; T_out [M, 16 G]
+  int group_k;
 };
 
 // MBK x 16 rows, JN x 16 columns per workgroup; R ring slots per wave
-template <int MBK, int JN, int R, bool LORA = false>
+// KG: 0 no adapter, 1 one rank-16 adapter, 2..3 that many K groups with an adapter each
+template <int MBK, int JN, int R, int KG = 0>
 __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
+  constexpr bool LORA = KG > 0;
   constexpr int XR = 16 * MBK, WR = 16 * JN, SROWS = XR + WR + (LORA ? 16 : 0), SLOT = SROWS * ROWB, PIECES = SROWS / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   const int64_t x8 = 8 * p.ldx, w8 = 8 * p.ldw, a8 = 8 * p.ld_adown;
   char* ring = smem + wave * (R * SLOT);
   const int rot = (int)((unsigned)tn % (unsigned)nsteps);
-  auto issue = [&](int i, int slot) {
+  auto issue = [&](int i, int slot) -> int {
     int ii = i + rot;
     ii = ii >= nsteps ? ii - nsteps : ii;
     const int k0 = (wave + NW * ii) * 64;
@@ -84,22 +89,30 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) glds16(asrc + q * a8 + k0, dst + (XR + WR) * ROWB + q * 1024);
     }
+    return k0;
   };
   const int foff0 = r * ROWB + (((0 * 4 + g) ^ (r & 7)) << 4), foff1 = r * ROWB + (((1 * 4 + g) ^ (r & 7)) << 4);
 
-  f32x4 acc[JN][MBK], tacc[MBK];
+  constexpr int TG = KG > 0 ? KG : 1;
+  f32x4 acc[JN][MBK], tacc[TG][MBK];
 #pragma unroll
   for (int mb = 0; mb < MBK; ++mb) {
-    tacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < JN; ++j) acc[j][mb] = tacc[mb];
+    for (int tg = 0; tg < TG; ++tg) tacc[tg][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < JN; ++j) acc[j][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  static_assert(R == 2 || KG <= 1, "the K-grouped bookkeeping below tracks a 2-slot ring");
 
+  int kq[R];               // (a small FIFO in registers: slot s holds the step whose first column is kq[s]; R is 2)
+#pragma unroll
+  for (int s = 0; s < R; ++s) kq[s] = 0;
 #pragma unroll
   for (int s = 0; s < R; ++s)
-    if (s < nsteps) issue(s, s);
+    if (s < nsteps) kq[s] = issue(s, s);
   int slot = 0;
   for (int i = 0; i < nsteps; ++i) {
+    const int kcur = slot == 0 ? kq[0] : kq[R - 1];
     const int after = nsteps - 1 - i;
     if (after >= R - 1) wait_vmcnt<PIECES * (R - 1)>();
     else if (R > 2 && after == 1) wait_vmcnt<PIECES>();
@@ -119,7 +132,8 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
     // a piece is issued later is a cycle less of its latency hidden)
     if (i + R < nsteps) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slot is refilled: its fragments must be in registers first
-      issue(i + R, slot);
+      const int kn = issue(i + R, slot);
+      if (slot == 0) kq[0] = kn; else kq[R - 1] = kn;
     }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
@@ -128,48 +142,60 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
 #pragma unroll
         for (int mb = 0; mb < MBK; ++mb) acc[j][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][j], xf[kk][mb], acc[j][mb], 0, 0, 0);
     if constexpr (LORA) {      // the LoRA-down product rides the same K walk: 16 more MFMA rows, D[r][m] = sum_k Adown[r,k] x[m,k]
+      const int tgrp = KG > 1 ? kcur / p.group_k : 0;          // (wave-uniform; a 64-column step never straddles a group: group_k % 64 == 0)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
+      for (int tg = 0; tg < TG; ++tg)
+        if (tg == tgrp) {
 #pragma unroll
-        for (int mb = 0; mb < MBK; ++mb) tacc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk], xf[kk][mb], tacc[mb], 0, 0, 0);
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mb = 0; mb < MBK; ++mb) tacc[tg][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk], xf[kk][mb], tacc[tg][mb], 0, 0, 0);
+        }
     }
     slot = slot + 1 == R ? 0 : slot + 1;
   }
 
   // ---- the 4 partial tiles meet in LDS; unit u = (row block, column block), wave w finishes units w, w + 4, ...
-  constexpr int UNITS = MBK * JN, UALL = UNITS + (LORA ? MBK : 0), UPW = (UNITS + NW - 1) / NW;
+  constexpr int UNITS = MBK * JN, TUN = LORA ? TG * MBK : 0, UALL = UNITS + TUN, UPW = (UNITS + NW - 1) / NW;
   __syncthreads();
   f32x4* red = (f32x4*)smem;                                  // [NW][UALL][64 lanes]
-  uint2* tsh = (uint2*)(smem + (size_t)NW * UALL * 1024);     // [MBK][64 lanes]: bf16(s T) in the 16x16x16 B-operand layout
+  uint2* tsh = (uint2*)(smem + (size_t)NW * UALL * 1024);     // [TG][MBK][64 lanes]: bf16(s T_g) in the 16x16x16 B-operand layout
 #pragma unroll
   for (int j = 0; j < JN; ++j)
 #pragma unroll
     for (int mb = 0; mb < MBK; ++mb) red[(wave * UALL + mb * JN + j) * 64 + lane] = acc[j][mb];
   if constexpr (LORA) {
 #pragma unroll
-    for (int mb = 0; mb < MBK; ++mb) red[(wave * UALL + UNITS + mb) * 64 + lane] = tacc[mb];
+    for (int tg = 0; tg < TG; ++tg)
+#pragma unroll
+      for (int mb = 0; mb < MBK; ++mb) red[(wave * UALL + UNITS + tg * MBK + mb) * 64 + lane] = tacc[tg][mb];
   }
   // adapter operands of this wave's units, requested before the barrier
-  uint2 bupf[UPW];
+  const int ngrp = KG > 1 ? p.K / p.group_k : 1;            // groups in use (<= TG; the unused accumulators stay zero)
+  uint2 bupf[UPW][TG];
   if constexpr (LORA) {
 #pragma unroll
     for (int q = 0; q < UPW; ++q) {
       const int u = wave + q * NW;
-      bupf[q] = make_uint2(0u, 0u);
-      if (u < UNITS) bupf[q] = *(const uint2*)(p.Bup + (int64_t)(n0 + 16 * (u % JN) + r) * p.ld_bup + 4 * g);
+#pragma unroll
+      for (int tg = 0; tg < TG; ++tg) {
+        bupf[q][tg] = make_uint2(0u, 0u);
+        if (u < UNITS && tg < ngrp) bupf[q][tg] = *(const uint2*)(p.Bup + (int64_t)(n0 + 16 * (u % JN) + r) * p.ld_bup + 16 * tg + 4 * g);
+      }
     }
   }
   __syncthreads();
   if constexpr (LORA) {
-    // T = s * X Adown^T of row block `wave` (MBK <= NW): summed over the waves, rounded to bf16 - the accumulator layout D[r][m] (lane: m,
+    // T_g = s * X_g Adown_g^T of every (group, row block): summed over the waves, rounded to bf16 - the accumulator layout D[r][m] (lane: m,
     // rows 4g..4g+3) IS the B-operand layout of the 16x16x16 MFMA, so the LoRA-up below needs no data movement beyond this LDS word pair
-    if (wave < MBK) {
-      f32x4 t = red[(UNITS + wave) * 64 + lane];
+    for (int tu = wave; tu < ngrp * MBK; tu += NW) {
+      const int tg = tu / MBK, mb = tu - tg * MBK;
+      f32x4 t = red[(UNITS + tu) * 64 + lane];
 #pragma unroll
-      for (int w = 1; w < NW; ++w) t += red[(w * UALL + UNITS + wave) * 64 + lane];
+      for (int w = 1; w < NW; ++w) t += red[(w * UALL + UNITS + tu) * 64 + lane];
       const uint2 tb = make_uint2(pack2bf(t[0] * p.lora_scale, t[1] * p.lora_scale), pack2bf(t[2] * p.lora_scale, t[3] * p.lora_scale));
-      tsh[wave * 64 + lane] = tb;
-      if (p.T_out && tn == 0) *(uint2*)(p.T_out + (int64_t)(m0 + wave * 16 + r) * p.ld_t + 4 * g) = tb;
+      tsh[tu * 64 + lane] = tb;
+      if (p.T_out && tn == 0) *(uint2*)(p.T_out + (int64_t)(m0 + mb * 16 + r) * p.ld_t + 16 * tg + 4 * g) = tb;
     }
     __syncthreads();
   }
@@ -182,8 +208,12 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
 #pragma unroll
     for (int w = 1; w < NW; ++w) v += red[(w * UALL + u) * 64 + lane];
     if constexpr (LORA) {
-      const uint2 tb = tsh[mb * 64 + lane];
-      v = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, bupf[q]), __builtin_bit_cast(s16x4, tb), v, 0, 0, 0);
+#pragma unroll
+      for (int tg = 0; tg < TG; ++tg) {
+        if (tg >= ngrp) break;
+        const uint2 tb = tsh[(tg * MBK + mb) * 64 + lane];
+        v = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, bupf[q][tg]), __builtin_bit_cast(s16x4, tb), v, 0, 0, 0);
+      }
     }
     if (p.bias) {
       const f32x4 b4 = *(const f32x4*)(p.bias + n);
@@ -197,20 +227,20 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   }
 }
 
-template <int MBK, int JN, int R, bool LORA>
+template <int MBK, int JN, int R, int KG>
 int launch_wsk(const wsk_params& p, hipStream_t s) {
+  constexpr bool LORA = KG > 0;
   constexpr int SLOT = (16 * MBK + 16 * JN + (LORA ? 16 : 0)) * ROWB;
-  constexpr int RED = NW * (MBK * JN + (LORA ? MBK : 0)) * 1024 + (LORA ? MBK * 64 * 8 : 0);
+  constexpr int RED = NW * (MBK * JN + KG * MBK) * 1024 + KG * MBK * 64 * 8;
   constexpr int smem = NW * R * SLOT > RED ? NW * R * SLOT : RED;
   static_assert(smem <= 160 * 1024, "LDS budget");
-  static_assert(MBK <= NW, "one wave per T row block");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)wsk_kernel<MBK, JN, R, LORA>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)wsk_kernel<MBK, JN, R, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   const int tiles = (p.M / (16 * MBK)) * (p.N / (16 * JN));
-  hipLaunchKernelGGL((wsk_kernel<MBK, JN, R, LORA>), dim3(tiles), dim3(64 * NW), smem, s, p);
+  hipLaunchKernelGGL((wsk_kernel<MBK, JN, R, KG>), dim3(tiles), dim3(64 * NW), smem, s, p);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }
@@ -219,7 +249,7 @@ int launch_wsk(const wsk_params& p, hipStream_t s) {
 
 extern "C" int sdlt_wsk_gemm(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t M, int32_t N, int32_t K, const float* bias,
                              const void* R, int64_t ldr, void* Y, int64_t ldy, const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup,
-                             float lora_scale, void* T_out, int64_t ld_t, void* stream) {
+                             float lora_scale, void* T_out, int64_t ld_t, int32_t lora_group_k, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (M % 64) || (N % 80) || ((N / 80) % 8) || (K % 256))
     SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wsk_gemm: M=%d N=%d K=%d (M %% 64, N %% 640, K %% 256 == 0)", M, N, K);
   if (!X || !W || !Y || (ldx % 8) || (ldw % 8) || (ldy % 4) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15) || ((uintptr_t)Y & 7) || (R && ((ldr % 4) || ((uintptr_t)R & 7))) ||
@@ -228,6 +258,11 @@ extern "C" int sdlt_wsk_gemm(const void* X, int64_t ldx, const void* W, int64_t 
   if (Adown && (!Bup || (ld_adown % 8) || ((uintptr_t)Adown & 15) || (ld_bup % 4) || ((uintptr_t)Bup & 7) || (T_out && ((ld_t % 4) || ((uintptr_t)T_out & 7)))))
     SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_gemm: adapter operands (Adown [16, K] 16-byte rows, Bup [N, 16] / T_out [M, 16] 8-byte rows)");
   wsk_params p{(const bf16_t*)X, ldx, (const bf16_t*)W, ldw, bias, (const bf16_t*)R, ldr, (bf16_t*)Y, ldy, M, N, K, 1,
-               (const bf16_t*)Adown, ld_adown, (const bf16_t*)Bup, ld_bup, (bf16_t*)T_out, ld_t, lora_scale};
-  return Adown ? launch_wsk<4, 5, 2, true>(p, (hipStream_t)stream) : launch_wsk<4, 5, 2, false>(p, (hipStream_t)stream);
+               (const bf16_t*)Adown, ld_adown, (const bf16_t*)Bup, ld_bup, (bf16_t*)T_out, ld_t, lora_scale, lora_group_k};
+  hipStream_t s = (hipStream_t)stream;
+  if (!Adown) return launch_wsk<4, 5, 2, 0>(p, s);
+  if (lora_group_k <= 0) return launch_wsk<4, 5, 2, 1>(p, s);
+  const int G = K / lora_group_k;
+  if ((lora_group_k % 64) || G * lora_group_k != K || G < 2 || G > 3) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_wsk_gemm: lora_group_k=%d with K=%d (2 or 3 groups of a multiple of 64 columns)", lora_group_k, K);
+  return launch_wsk<4, 5, 2, 3>(p, s);
 }

@@ -153,8 +153,10 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
     lib = _lib.load()
     if (WSK and conv is None and X2 is None and rowbias is None and alpha == 1.0 and Ct is None and batch is None and geglu_out is None
             and geglu_bwd is None and act_out is None and dact_in is None and col_scale is None and not accumulate and tile == 0 and splitk == 0
-            and not lora_group_n and not lora_group_k and out is not None and out.dtype == BF16 and not THROUGHPUT_HINT
-            and (lora is None or (lora[0].shape[0] == 16 and lora[1].shape[1] == 16)) and wsk_shape(X.shape[0], W.shape[0], W.shape[1], lora is not None)):
+            and not lora_group_n and out is not None and out.dtype == BF16 and not THROUGHPUT_HINT
+            and (lora is None or (lora[0].shape[0] == 16 and ((not lora_group_k and lora[1].shape[1] == 16) or
+                                                                (lora_group_k and lora_group_k % 64 == 0 and W.shape[1] // lora_group_k in (2, 3)))))
+            and wsk_shape(X.shape[0], W.shape[0], W.shape[1], lora is not None)):
         # 1280-wide product at batch 1 with exactly one 64 x 80 tile per CU: K split over the waves, rank-16 adapter fused (sdlt_wsk_gemm)
         _chk2(X), _chk2(W), _chk2(out)
         M_, N_, K_ = X.shape[0], W.shape[0], W.shape[1]
@@ -168,13 +170,14 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
         if lora is not None:
             A_, B_, scale_, T_ = lora
             _chk2(A_), _chk2(B_)
-            assert tuple(A_.shape) == (16, K_) and tuple(B_.shape) == (N_, 16)
+            G_ = K_ // lora_group_k if lora_group_k else 1
+            assert tuple(A_.shape) == (16, K_) and tuple(B_.shape) == (N_, 16 * G_)
             if T_ is not None:
                 _chk2(T_)
-                assert tuple(T_.shape) == (M_, 16)
+                assert tuple(T_.shape) == (M_, 16 * G_)
         _lib.check(lib.sdlt_wsk_gemm(_p(X), _ld(X), _p(W), _ld(W), M_, N_, K_, _p(bias), _p(residual), _ld(residual) if residual is not None else 0,
                                      _p(out), _ld(out), _p(A_), _ld(A_) if A_ is not None else 0, _p(B_), _ld(B_) if B_ is not None else 0, float(scale_),
-                                     _p(T_), _ld(T_) if T_ is not None else 0, _stream()), "sdlt_wsk_gemm")
+                                     _p(T_), _ld(T_) if T_ is not None else 0, int(lora_group_k) if lora is not None else 0, _stream()), "sdlt_wsk_gemm")
         return out
     p = _lib.GemmParams()
     _chk2(X), _chk2(W)

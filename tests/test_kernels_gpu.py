@@ -980,7 +980,7 @@ def test_wsk_gemm(ops, M, N, K, res, bias):
     def run():
         y = torch.full((M, N), 7.0, dtype=BF, device="cuda")
         rc = lib.sdlt_wsk_gemm(xd.data_ptr(), K, wd.data_ptr(), K, M, N, K, bd.data_ptr() if bias else None, rd.data_ptr() if res else None, N if res else 0,
-                               y.data_ptr(), N, None, 0, None, 0, 0.0, None, 0, torch.cuda.current_stream().cuda_stream)
+                               y.data_ptr(), N, None, 0, None, 0, 0.0, None, 0, 0, torch.cuda.current_stream().cuda_stream)
         assert rc == 0, lib.sdlt_last_error()
         return y
     y = run()
@@ -1010,7 +1010,7 @@ def test_wsk_gemm_fused_lora(ops, M, N, K, res, bias, rank):
     bd, rd = (b.cuda() if bias else None), (r.cuda() if res else None)
     y, T = torch.full((M, N), 7.0, dtype=BF, device="cuda"), torch.full((M, 16), 7.0, dtype=BF, device="cuda")
     rc = lib.sdlt_wsk_gemm(xd.data_ptr(), K, wd.data_ptr(), K, M, N, K, bd.data_ptr() if bias else None, rd.data_ptr() if res else None, N if res else 0,
-                           y.data_ptr(), N, Ad.data_ptr(), K, Bd.data_ptr(), 16, scale, T.data_ptr(), 16, torch.cuda.current_stream().cuda_stream)
+                           y.data_ptr(), N, Ad.data_ptr(), K, Bd.data_ptr(), 16, scale, T.data_ptr(), 16, 0, torch.cuda.current_stream().cuda_stream)
     assert rc == 0, lib.sdlt_last_error()
     close(y, ref, what="wsk gemm + lora")
     close(T, tref, what="wsk T_out")
@@ -1022,3 +1022,31 @@ def test_wsk_gemm_fused_lora(ops, M, N, K, res, bias, rank):
         y3, T3 = torch.empty(M, N, dtype=BF, device="cuda"), torch.empty(M, 16, dtype=BF, device="cuda")
         ops.gemm(xd, wd, y3, lora=(Ad, Bd, scale, T3), bias=bd, residual=rd)
         assert torch.equal(y3, y) and torch.equal(T3, T), "ops.gemm did not take the wave-split-K route for this shape"
+
+
+@pytest.mark.parametrize("M,N,gk,G,res", [(1024, 1280, 1280, 3, False), (1024, 1280, 640, 2, True), (256, 640, 256, 3, True)])
+def test_wsk_gemm_k_grouped_lora(ops, M, N, gk, G, res):
+    """The input gradient of stacked projections on the wave-split-K kernel: K = G groups of gk columns, one rank-16 adapter per group
+    (sdlt_gemm_bf16's lora_group_k contract) - against the emulation, the tiled kernel, and through ops.gemm's routing."""
+    K = gk * G
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w = rnd(M, K, g=g), rnd(N, K, g=g, scale=K ** -0.5)
+    A, Bu = rnd(16, K, g=g, scale=1.0 / 16), rnd(N, 16 * G, g=g, scale=0.05)
+    r = rnd(M, N, g=g) if res else None
+    ref, tref = torch.empty(M, N, dtype=BF), torch.empty(M, 16 * G, dtype=BF)
+    E.gemm(x, w, ref, lora=(A, Bu, 0.75, tref), residual=r, lora_group_k=gk)
+    xd, wd, Ad, Bd, rd = x.cuda(), w.cuda(), A.cuda(), Bu.cuda(), (r.cuda() if res else None)
+    y, T = torch.full((M, N), 7.0, dtype=BF, device="cuda"), torch.full((M, 16 * G), 7.0, dtype=BF, device="cuda")
+    lib = ops._lib.load()
+    rc = lib.sdlt_wsk_gemm(xd.data_ptr(), K, wd.data_ptr(), K, M, N, K, None, rd.data_ptr() if res else None, N if res else 0, y.data_ptr(), N,
+                           Ad.data_ptr(), K, Bd.data_ptr(), 16 * G, 0.75, T.data_ptr(), 16 * G, gk, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.sdlt_last_error()
+    close(y, ref, what="wsk K-grouped lora")
+    close(T, tref, what="wsk K-grouped T_out")
+    y2, T2 = torch.empty(M, N, dtype=BF, device="cuda"), torch.empty(M, 16 * G, dtype=BF, device="cuda")
+    ops.gemm(xd, wd, y2, lora=(Ad, Bd, 0.75, T2), residual=rd, lora_group_k=gk, tile=2)
+    close(y, y2, tol=1e-2, what="wsk vs tiled kernel (K-grouped)")
+    if ops.wsk_shape(M, N, K, True):
+        y3, T3 = torch.empty(M, N, dtype=BF, device="cuda"), torch.empty(M, 16 * G, dtype=BF, device="cuda")
+        ops.gemm(xd, wd, y3, lora=(Ad, Bd, 0.75, T3), residual=rd, lora_group_k=gk)
+        assert torch.equal(y3, y) and torch.equal(T3, T)
