@@ -9,6 +9,7 @@
 //     its own operands through a private LDS ring (global_load_lds, full 128-byte rows, XOR-swizzled source side) and never meets a block
 //     barrier in the K loop: 36 KB of loads in flight per CU from the first instruction, counted vmcnt waits;
 //   * the 4 partial tiles are added through LDS once, in wave order (bitwise reproducible), then bias / residual / bf16 store.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/sdlt_kernels.h"
 
@@ -36,6 +37,7 @@ struct wsk_params {
   // K-grouped adapters (group_k > 0; the input gradient of stacked projections): K is G = K / group_k groups of group_k columns, group g has
   // its own rank-16 adapter: T_g = X[:, group g] . Adown[:, group g]^T, Y += sum_g bf16(s T_g) . Bup[:, 16 g .. 16 g + 15]^T; T_out [M, 16 G]
   int group_k;
+  int stagger;
 };
 
 // MBK x 16 rows, JN x 16 columns per workgroup; R ring slots per wave
@@ -130,7 +132,11 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
     }
     // (spreading the refill's DMA instructions between the MFMAs was measured and LOSES 10-15 %: the ring is one step deep, every cycle
     // a piece is issued later is a cycle less of its latency hidden)
-    if (i + R < nsteps) {
+    // The CU's texture path takes 1 KB of DMA per 16 cycles, shared by the 4 waves: when all of them refill at once each sits ~1100 cycles in
+    // DMA issue and then all run their 680 cycles of MFMAs with the path idle (PMC: 49 % of the wave cycles are issue stalls).  Odd waves
+    // therefore refill AFTER their MFMAs: the two halves of the workgroup alternate between the two resources.
+    const bool refill_first = !p.stagger || (wave & 1) == 0;
+    if (refill_first && i + R < nsteps) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slot is refilled: its fragments must be in registers first
       const int kn = issue(i + R, slot);
       if (slot == 0) kq[0] = kn; else kq[R - 1] = kn;
@@ -151,6 +157,10 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
 #pragma unroll
             for (int mb = 0; mb < MBK; ++mb) tacc[tg][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk], xf[kk][mb], tacc[tg][mb], 0, 0, 0);
         }
+    }
+    if (!refill_first && i + R < nsteps) {
+      const int kn = issue(i + R, slot);
+      if (slot == 0) kq[0] = kn; else kq[R - 1] = kn;
     }
     slot = slot + 1 == R ? 0 : slot + 1;
   }
@@ -258,7 +268,7 @@ extern "C" int sdlt_wsk_gemm(const void* X, int64_t ldx, const void* W, int64_t 
   if (Adown && (!Bup || (ld_adown % 8) || ((uintptr_t)Adown & 15) || (ld_bup % 4) || ((uintptr_t)Bup & 7) || (T_out && ((ld_t % 4) || ((uintptr_t)T_out & 7)))))
     SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_gemm: adapter operands (Adown [16, K] 16-byte rows, Bup [N, 16] / T_out [M, 16] 8-byte rows)");
   wsk_params p{(const bf16_t*)X, ldx, (const bf16_t*)W, ldw, bias, (const bf16_t*)R, ldr, (bf16_t*)Y, ldy, M, N, K, 1,
-               (const bf16_t*)Adown, ld_adown, (const bf16_t*)Bup, ld_bup, (bf16_t*)T_out, ld_t, lora_scale, lora_group_k};
+               (const bf16_t*)Adown, ld_adown, (const bf16_t*)Bup, ld_bup, (bf16_t*)T_out, ld_t, lora_scale, lora_group_k, getenv("SDLT_WSK_STAGGER") ? atoi(getenv("SDLT_WSK_STAGGER")) : 1};
   hipStream_t s = (hipStream_t)stream;
   if (!Adown) return launch_wsk<4, 5, 2, 0>(p, s);
   if (lora_group_k <= 0) return launch_wsk<4, 5, 2, 1>(p, s);

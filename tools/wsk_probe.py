@@ -1,25 +1,14 @@
-"""Correctness + hot-loop timing of the wave-split-K GEMM lab kernel against ops.gemm on the M = 1024 / 4096 transformer shapes."""
-import ctypes as C
+"""Hot-loop timing of the wave-split-K GEMM (sdlt_wsk_gemm through ops.gemm) against the tiled kernel on the M = 1024 transformer shapes, plain and with a
+rank-16 adapter; SDLT_WSK_STAGGER=0/1 A/B (odd waves refill after their MFMAs)."""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from sd_lora_trainer_amd import _lib, ops as O
+from sd_lora_trainer_amd import ops as O
 
 BF = torch.bfloat16
-lib = _lib.load()
-fn = lib.sdlt_wsk_gemm_lab
-fn.restype = C.c_int32
-i32, i64, vp = C.c_int32, C.c_int64, C.c_void_p
-fn.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp, vp, i64, vp, i64, i32, vp]
 NROT = 12
-
-
-def wsk(x, w, y, bias, res, variant):
-    rc = fn(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), x.shape[0], w.shape[0], w.shape[1], bias.data_ptr() if bias is not None else None,
-            res.data_ptr() if res is not None else None, res.stride(0) if res is not None else 0, y.data_ptr(), y.stride(0), variant, torch.cuda.current_stream().cuda_stream)
-    assert rc == 0, lib.sdlt_last_error()
 
 
 def bench(f, n=48, reps=5):
@@ -38,21 +27,28 @@ def bench(f, n=48, reps=5):
     return best
 
 
-for M, N, K in [(1024, 1280, 1280), (1024, 1280, 3840), (1024, 1280, 5120), (1024, 1280, 10240), (4096, 640, 2560), (4096, 640, 5120), (1024, 5120, 1280), (1024, 3840, 1280)]:
+for M, N, K, lora, gk in [(1024, 1280, 1280, False, 0), (1024, 1280, 1280, True, 0), (1024, 1280, 3840, True, 1280), (1024, 1280, 3840, False, 0), (1024, 1280, 5120, False, 0), (1024, 1280, 10240, False, 0)]:
     x = torch.randn(M, K, device="cuda").to(BF)
     ws = [(torch.randn(N, K, device="cuda") * K ** -0.5).to(BF) for _ in range(NROT)]
     bias = torch.randn(N, device="cuda")
     res = torch.randn(M, N, device="cuda").to(BF)
-    y, y2 = torch.zeros(M, N, device="cuda", dtype=BF), torch.zeros(M, N, device="cuda", dtype=BF)
-    ref = (x.float() @ ws[0].float().t() + bias + res.float())
-    line = f"M{M:5d} N{N:5d} K{K:6d}: "
-    for v, name in ((0, "64x80"), (16, "64x80/2d"), (17, "64x64/2d")):
-        tile_n = 80 if (v & 15) == 0 else 64
-        if N % tile_n or (N // tile_n) % 8:
+    G = K // gk if gk else 1
+    A, Bu = torch.randn(16, K, device="cuda").to(BF) / 16, (torch.randn(N, 16 * G, device="cuda") * 0.05).to(BF)
+    T = torch.zeros(M, 16 * G, device="cuda", dtype=BF)
+    y = torch.zeros(M, N, device="cuda", dtype=BF)
+    kw = dict(bias=bias, residual=res)
+    if lora:
+        kw.update(lora=(A, Bu, 1.0, T), lora_group_k=gk)
+    line = f"M{M} N{N} K{K:6d} {'lora' if lora else 'plain'}{' gK' if gk else ''}: "
+    for st in ("0", "1"):
+        os.environ["SDLT_WSK_STAGGER"] = st
+        O.WSK, O.WSK_LORA = True, True
+        if not O.wsk_shape(M, N, K, lora):
+            line += f"wsk(stagger {st}) n/a  "
             continue
-        wsk(x, ws[0], y, bias, res, v)
-        err = float((y.float() - ref).abs().max() / ref.abs().max())
-        t = bench(lambda i: wsk(x, ws[i % NROT], y, bias, res, v))
-        line += f"wsk {name} {t:6.2f} us (err {err:.1e}, {2 * M * N * K / t * 1e-6:5.0f} TF/s)  "
-    tt = bench(lambda i: O.gemm(x, ws[i % NROT], y2, bias=bias, residual=res))
+        t = bench(lambda i: O.gemm(x, ws[i % NROT], y, **kw))
+        line += f"wsk(stagger {st}) {t:6.2f} us ({2 * M * N * K / t * 1e-6:5.0f} TF/s)  "
+    O.WSK = False
+    tt = bench(lambda i: O.gemm(x, ws[i % NROT], y, **kw))
+    O.WSK = True
     print(line + f"tiled {tt:6.2f} us ({2 * M * N * K / tt * 1e-6:5.0f} TF/s)", flush=True)
