@@ -10,3 +10,4 @@ cp $(ls /tmp/prof_$TAG/*/*kernel_stats.csv | head -1) $R/gpurun_out/$TAG/kernel_
 T=$(ls /tmp/prof_$TAG/*/*kernel_trace.csv | head -1)
 python $R/tools/last_step_auto.py $T 70 > $R/gpurun_out/$TAG/last_step.txt 2>&1
 python $R/tools/text_phase.py $T > $R/gpurun_out/$TAG/text_phase.txt 2>&1
+python $R/tools/step_gaps.py $T 25 > $R/gpurun_out/$TAG/gaps.txt 2>&1
