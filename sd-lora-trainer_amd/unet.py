@@ -826,12 +826,12 @@ class TransformerBlock(_Module):
         # GEMM's epilogue and GEGLU's backward is the epilogue of ff.net.2's dX GEMM - two launches fewer per block and direction.
         # (Not with the full fine-tune: its master weights / weight gradients keep the checkpoint's row order.)
         H = self.ff2.K
-        # Measured on the final kernels the fused epilogues do NOT pay: at C = 320 / 640 (short K, 4096+ rows) the fused launches cost more than
-        # GEMM + element-wise kernel (census, SDXL C = 640: 65.8 + 50.7 us fused vs 50 + 32 unfused; SD1.5 C = 320: 101 + 90 vs 77 + 67), at
-        # C = 1280 they are even per launch pair, and the whole SDXL step is 49.65 ms unfused vs 49.97 ms fused at C >= 1280 vs 50.6 ms fused
-        # everywhere - the two extra launches per block are cheaper than the wider epilogue.  Default: unfused; SDLT_GEGLU_MIN_C=<width> opts in.
+        # Round 2 measured the fused epilogues as a net LOSS (49.65 ms unfused vs 50.6 ms fused) and left them off: the library erff inside
+        # a GEMM epilogue is ~40 serial VALU instructions per element.  With the one-exponential GELU of round 3 (common.h) they pay: SDXL 46.52 ms
+        # unfused, 46.10 fused at C >= 1280, 45.96 everywhere; SD1.5 25.59 -> 25.30.  Default: fused; SDLT_GEGLU_MIN_C=<width> restricts them to
+        # transformer widths >= the value (a huge value = the element-wise kernels).
         self.fused_geglu = (self.ff1.trainer is None and H % 16 == 0 and hasattr(rt.ops, "geglu_perm")
-                            and self.ff2.N >= int(os.environ.get("SDLT_GEGLU_MIN_C", "1000000")))
+                            and self.ff2.N >= int(os.environ.get("SDLT_GEGLU_MIN_C", "0")))
         if self.fused_geglu:
             perm = rt.ops.geglu_perm(H, self.ff1.W.device)
             self.ff1.W = self.ff1.W[perm].contiguous()
