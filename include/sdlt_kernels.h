@@ -462,6 +462,32 @@ int sdlt_wsk_gemm(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_
                   const void* R, int64_t ldr, void* Y, int64_t ldy, const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup,
                   float lora_scale, void* T_out, int64_t ld_t, int32_t lora_group_k, void* stream);
 
+/* Token-attention (DAAM) loss and its gradient w.r.t. the hooked cross-attention score maps: trainer/ti_cross_attn_loss.py:239-268
+ * (process_and_stack_attention_scores) + trainer/loss.py:10-80 (compute_token_attention_loss), main.py:342-345.  The loss depends on the
+ * stacked maps only through their mean over layers, so the inputs are ONE fp32 sum of raw score maps per resolution (groups sorted by size,
+ * g[0] the smallest; S [B*h*w, 128], 77 valid columns) and the outputs one gradient per resolution, d(weight * loss)/dS as bf16 [B*h*w, 128]
+ * (dS) and transposed [B*128, h*w] (dSt) - the operands of the score-gradient GEMMs.  Wh [h0, h] / Ww [w0, w]: the 1-D operators of the
+ * bicubic resize to the smallest map (F.interpolate, align_corners=False), ch / cw their column sums; NULL for g[0].  mask [B,4,mH,mW] fp32
+ * (channel 0, nearest-resized to h0 x w0), tok_w [B,77] / tok_cnt [B] / ti_onehot [B,n_tok,77] / has_ti [B]: the per-caption constants
+ * (which columns are caption tokens, their count, where the trained tokens sit, whether all of them are present).  loss[0] = the un-weighted
+ * loss.  dheat [B, n_tok, h*w] fp32 and ws (>= sdlt_token_attention_ws_floats floats) are scratch.  n_layers = stacked layers in total. */
+typedef struct sdlt_ta_group {
+  const float* S; const float* Wh; const float* Ww; const float* ch; const float* cw;
+  void* dS; void* dSt; float* dheat;
+  int32_t h, w;
+} sdlt_ta_group;
+typedef struct sdlt_ta_params {
+  sdlt_ta_group g[4];
+  const float* mask; const float* tok_w; const float* tok_cnt; const float* ti_onehot; const float* has_ti;
+  float* ws; int64_t ws_floats;
+  float* loss;
+  int32_t ngroups, B, n_tok, n_layers, mH, mW;
+  float weight;
+  int32_t max_px, max_tmp, max_w, pad_;      /* filled in by the entry point */
+} sdlt_ta_params;
+int64_t sdlt_token_attention_ws_floats(const sdlt_ta_params* p);
+int sdlt_token_attention_loss(const sdlt_ta_params* p, void* stream);
+
 /* dX of nearest-2x upsampling: out[b,h,w,:] = sum of the 2x2 block of in [B,2H,2W,C]. */
 int sdlt_sum2x2(const void* in, int32_t B, int32_t H, int32_t W, int32_t C, void* out, void* stream);
 /* out[b,c] = sum_r x[b*R + r, c] as fp32 [B,C] and / or bf16 [B,C] (either may be NULL) - gradient of the per-batch time-embedding

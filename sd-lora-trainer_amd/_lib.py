@@ -114,6 +114,16 @@ class StripParams(C.Structure):
                 ("splitk", i32), ("cnt_len", i32), ("ws", vp), ("ws_bytes", i64), ("cnt", vp), ("P", vp), ("ldp", i64)]
 
 
+class TaGroup(C.Structure):
+    _fields_ = [("S", vp), ("Wh", vp), ("Ww", vp), ("ch", vp), ("cw", vp), ("dS", vp), ("dSt", vp), ("dheat", vp), ("h", i32), ("w", i32)]
+
+
+class TaParams(C.Structure):
+    _fields_ = [("g", TaGroup * 4), ("mask", vp), ("tok_w", vp), ("tok_cnt", vp), ("ti_onehot", vp), ("has_ti", vp), ("ws", vp), ("ws_floats", i64),
+                ("loss", vp), ("ngroups", i32), ("B", i32), ("n_tok", i32), ("n_layers", i32), ("mH", i32), ("mW", i32), ("weight", f32),
+                ("max_px", i32), ("max_tmp", i32), ("max_w", i32), ("pad_", i32)]
+
+
 class ShadowDesc(C.Structure):
     _fields_ = [("offset", i64), ("src_ld", i64), ("rows", i32), ("cols", i32), ("dst", vp), ("ld", i64), ("dstT", vp), ("ldT", i64)]
 
@@ -158,6 +168,8 @@ SYMBOLS = {
     "sdlt_dora_mag_grad": (i32, [vp, vp, vp, i32, vp, vp, i32, vp, vp]),
     "sdlt_strip_gemm": (i32, [C.POINTER(StripParams), vp]),
     "sdlt_wsk_gemm": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp, i64, vp, i64, vp, i64, vp, i64, f32, vp, i64, i32, vp]),
+    "sdlt_token_attention_ws_floats": (i64, [C.POINTER(TaParams)]),
+    "sdlt_token_attention_loss": (i32, [C.POINTER(TaParams), vp]),
     "sdlt_sum2x2": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "sdlt_colsum": (i32, [vp, i64, i32, i32, i32, vp, i64, vp, vp, vp]),
     "sdlt_embed_gather": (i32, [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp]),
@@ -189,7 +201,7 @@ def load():
             raise KernelLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    for which, cls in enumerate((GemmParams, LoraGradDesc, AttnParams, GroupNormParams, ShadowDesc, GemmBatchItem, DoraDesc, DoraWtDesc, DoraGradDesc, SplitsumDesc, StripParams)):
+    for which, cls in enumerate((GemmParams, LoraGradDesc, AttnParams, GroupNormParams, ShadowDesc, GemmBatchItem, DoraDesc, DoraWtDesc, DoraGradDesc, SplitsumDesc, StripParams, TaParams)):
         if lib.sdlt_struct_size(which) != C.sizeof(cls):
             raise KernelLibraryError(f"struct layout mismatch for {cls.__name__}: C {lib.sdlt_struct_size(which)} vs ctypes {C.sizeof(cls)}")
     _lib = lib

@@ -29,6 +29,7 @@ extern "C" int sdlt_struct_size(int which) {
     case 8: return (int)sizeof(sdlt_dora_grad_desc);
     case 9: return (int)sizeof(sdlt_splitsum_desc);
     case 10: return (int)sizeof(sdlt_strip_params);
+    case 11: return (int)sizeof(sdlt_ta_params);
   }
   return -1;
 }

@@ -14,6 +14,7 @@ The remaining arithmetic is on [B, 32, 32, 77]-sized tensors (a few hundred KB) 
 device - plumbing-sized work; the FLOPs of this loss (the score GEMMs and their backward) run in sdlt_gemm_bf16.
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -21,6 +22,7 @@ import torch.nn.functional as F
 from .unet import CTX_PAD
 
 T_TOKENS = 77
+FUSED = os.environ.get("SDLT_TA_FUSED", "1") != "0"      # 0: the torch-op form below on the GPU too (A/B, and the oracle of the kernel's test)
 
 
 class TokenAttentionLoss:
@@ -91,10 +93,44 @@ class TokenAttentionLoss:
             ops = self._bic[key] = (Wh, Ww)
         return ops
 
+    def _fused_plan(self, mask, img_ratio):
+        """The same arithmetic as three HIP launches (csrc/daam.hip, sdlt_token_attention_loss) instead of ~90 torch ones; built once per
+        (set of resolutions, mask buffer).  None when the ops table has no such kernel (CPU op emulation) or the maps do not fit it."""
+        rt, B = self.rt, self.rt.B
+        if not hasattr(rt.ops, "TokenAttentionPlan") or not mask.is_cuda or B > 16 or self.n_tok > 8 or len(rt.daam_sums) > 4:
+            return None
+        key = (tuple(sorted(rt.daam_sums)), mask.data_ptr(), tuple(ent[0].data_ptr() for _, ent in sorted(rt.daam_sums.items())), img_ratio)
+        if getattr(self, "_plan_key", None) != key:
+            groups_, n_layers = [], 0
+            srt = sorted(rt.daam_sums.items())
+            n_min = srt[0][0]
+            w0 = round(math.sqrt(n_min * img_ratio))
+            h0 = round(w0 / img_ratio)
+            for N, (ssum, nl, _) in srt:
+                w = round(math.sqrt(N * img_ratio))
+                h = round(w / img_ratio)
+                Wh = Ww = None
+                if N != n_min:
+                    Wh, Ww = self._bicubic_ops(h, w, h0, w0, ssum.device)
+                groups_.append((ssum, h, w, Wh, Ww))
+                n_layers += nl
+            if max(h * w for _, h, w, _, _ in groups_) > 128 * 128 or h0 * w0 > 64 * 64:
+                self._plan, self._plan_key = None, key
+                return None
+            self._plan = rt.ops.TokenAttentionPlan(groups_, B, self.n_tok, n_layers, mask, self.tok_w, self.tok_cnt, self.ti_onehot, self.has_ti, self.loss,
+                                                   act_dtype=rt.act)
+            self._plan_key = key
+        return self._plan
+
     def forward_backward(self, mask, img_ratio, weight):
         """mask [B,4,H,W] fp32.  Reads rt.daam_sums, writes rt.daam_grads (d (weight*loss) / d S per resolution) and
         self.loss (the un-weighted loss value, as losses['token_attention_loss'] logs it)."""
         rt, B = self.rt, self.rt.B
+        if FUSED and mask.dtype == torch.float32 and mask.is_contiguous():
+            plan = self._fused_plan(mask, img_ratio)
+            if plan is not None:
+                rt.daam_grads = plan.run(weight)
+                return self.loss
         groups = sorted(rt.daam_sums.items())      # smallest map first
         leaves, maps, n_layers = [], [], 0
         n_min = groups[0][0]

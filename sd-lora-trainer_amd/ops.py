@@ -351,6 +351,44 @@ def strip_gemm(X, W, out, *, B, T, Tp, bias=None, residual=None, act_out=None, d
     return out
 
 
+class TokenAttentionPlan:
+    """sdlt_token_attention_loss on persistent buffers: groups = [(S fp32 [B*h*w, 128], h, w, Wh [h0,h] | None, Ww [w0,w] | None)] sorted by size
+    (smallest first); owns the gradient operands dS / dSt per group, the scratch and the loss scalar."""
+
+    def __init__(self, groups, B, n_tok, n_layers, mask, tok_w, tok_cnt, ti_onehot, has_ti, loss, act_dtype=BF16):
+        dev = mask.device
+        p = _lib.TaParams()
+        self.keep, self.out = [groups, mask, tok_w, tok_cnt, ti_onehot, has_ti, loss], {}
+        for gi, (S, h, w, Wh, Ww) in enumerate(groups):
+            N = h * w
+            _chk2(S, F32)
+            assert S.shape == (B * N, 128)
+            dS, dSt = torch.zeros(B * N, 128, dtype=act_dtype, device=dev), torch.zeros(B * 128, N, dtype=act_dtype, device=dev)
+            dheat = torch.zeros(B * n_tok * N, dtype=F32, device=dev)
+            g = p.g[gi]
+            g.S, g.dS, g.dSt, g.dheat, g.h, g.w = _p(S), _p(dS), _p(dSt), _p(dheat), h, w
+            if gi > 0:
+                Wh, Ww = Wh.to(dev, F32).contiguous(), Ww.to(dev, F32).contiguous()
+                ch, cw = Wh.sum(0).contiguous(), Ww.sum(0).contiguous()
+                g.Wh, g.Ww, g.ch, g.cw = _p(Wh), _p(Ww), _p(ch), _p(cw)
+                self.keep += [Wh, Ww, ch, cw]
+            self.keep += [dS, dSt, dheat]
+            self.out[N] = (dS, dSt)
+        for t in (mask, tok_w, tok_cnt, ti_onehot, has_ti, loss):
+            assert t.is_cuda and t.dtype == F32 and t.is_contiguous()
+        p.mask, p.tok_w, p.tok_cnt, p.ti_onehot, p.has_ti, p.loss = _p(mask), _p(tok_w), _p(tok_cnt), _p(ti_onehot), _p(has_ti), _p(loss)
+        p.ngroups, p.B, p.n_tok, p.n_layers, p.mH, p.mW = len(groups), B, n_tok, n_layers, mask.shape[2], mask.shape[3]
+        nws = _lib.load().sdlt_token_attention_ws_floats(C.byref(p))
+        self.ws = torch.zeros(nws, dtype=F32, device=dev)
+        p.ws, p.ws_floats = _p(self.ws), nws
+        self.p = p
+
+    def run(self, weight):
+        self.p.weight = float(weight)
+        _lib.check(_lib.load().sdlt_token_attention_loss(C.byref(self.p), _stream()), "sdlt_token_attention_loss")
+        return self.out
+
+
 def fold_layernorm(W, bias, gamma, beta, dtype=BF16):
     """Operands of a LayerNorm folded into the Linear behind it (strip_gemm ln=): LN(x) W^T + b = rstd (x (W o gamma)^T - mean c1) + c2
     with c1[n] = sum_k (W o gamma)[n,k] taken from the ROUNDED operand (so that the mean term cancels exactly what the product adds)

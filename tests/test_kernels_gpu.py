@@ -1050,3 +1050,46 @@ def test_wsk_gemm_k_grouped_lora(ops, M, N, gk, G, res):
         y3, T3 = torch.empty(M, N, dtype=BF, device="cuda"), torch.empty(M, 16 * G, dtype=BF, device="cuda")
         ops.gemm(xd, wd, y3, lora=(Ad, Bd, 0.75, T3), residual=rd, lora_group_k=gk)
         assert torch.equal(y3, y) and torch.equal(T3, T)
+
+
+@pytest.mark.parametrize("B,sizes,ratio,has", [(1, [(64, 64, 10), (32, 32, 50)], 1.0, [1]), (2, [(64, 64, 3), (32, 32, 6), (16, 16, 6)], 1.0, [1, 0]),
+                                               (2, [(32, 32, 4)], 1.0, [1, 1]), (1, [(32, 64, 2), (16, 32, 5)], 2.0, [1]), (2, [(32, 32, 2), (16, 16, 2)], 1.0, [0, 0])])
+def test_token_attention_loss_fused(ops, B, sizes, ratio, has):
+    """sdlt_token_attention_loss (three launches) against the torch-op form of the same loss (daam.TokenAttentionLoss with FUSED off - the
+    arithmetic tests/test_oracle_golden.py pins to the reference's compute_token_attention_loss): loss value and d(weight loss)/dS of every
+    resolution, row-major and transposed; SDXL's two and SD1.5's three resolutions, a non-square latent, captions without the trained tokens."""
+    import sd_lora_trainer_amd.daam as D
+    import sd_lora_trainer_amd.unet as M
+    g = torch.Generator().manual_seed(B + len(sizes))
+    ntok, train_ids = 3, [900, 901, 902]
+    lists = [[1, 5, 6] + (train_ids if has[b] else [7]) + [8, 9, 11, 2] for b in range(B)]
+    Hm, Wm = sizes[0][0] * 2, sizes[0][1] * 2
+    mask = ((torch.rand(B, 1, Hm, Wm, generator=g) > 0.5).float() * 0.9 + 0.05).repeat(1, 4, 1, 1).contiguous().cuda()
+    res = {}
+    for fused in (False, True):
+        rt = M.Runtime("cuda:0", B)
+        ta = D.TokenAttentionLoss(rt, ntok)
+        ta.set_captions(lists, train_ids)
+        gs = torch.Generator().manual_seed(7)
+        for (h, w, nl) in sizes:
+            S = torch.zeros(B * h * w, 128)
+            S[:, :77] = torch.randn(B * h * w, 77, generator=gs) * 3.0 * nl
+            rt.daam_sums[h * w] = [S.cuda(), nl, True]
+        D.FUSED = fused
+        try:
+            loss = ta.forward_backward(mask, ratio, 0.05)
+        finally:
+            D.FUSED = True
+        torch.cuda.synchronize()
+        assert (ta._fused_plan(mask, ratio) is not None) if fused else True
+        res[fused] = (float(loss), {N: (a.float().cpu().clone(), b_.float().cpu().clone()) for N, (a, b_) in rt.daam_grads.items()})
+    l0, g0 = res[False]
+    l1, g1 = res[True]
+    assert abs(l1 - l0) <= 1e-4 * abs(l0) + 1e-7, (l1, l0)
+    for N in g0:
+        for a, b_, nm in ((g1[N][0], g0[N][0], "dS"), (g1[N][1], g0[N][1], "dSt")):
+            assert a.shape == b_.shape
+            err = float((a - b_).abs().max())
+            assert err <= 1.5e-2 * float(b_.abs().max()) + 1e-12, f"{nm} N={N}: {err} vs {float(b_.abs().max())}"
+    if not any(has):
+        assert l1 == 0.0 and all(float(a.abs().max()) == 0.0 for a, _ in g1.values())
