@@ -34,6 +34,8 @@ def _pad_to(x, m):
     return (x + m - 1) // m * m
 
 
+XATTN_WGS = int(os.environ.get("SDLT_XATTN_WGS", "160"))     # workgroups of a cross-attention backward launch (query splits x heads x batch)
+
 class Runtime:
     """Execution context shared by all layers: device, batch, activation dtype and the op table."""
 
@@ -764,7 +766,7 @@ class Attention(_Module):
         if self.cross:
             # cross-attention: ~160 workgroups, each owning all 77 keys of one head and a range of query tiles; the fp32
             # dK/dV accumulators are adjacent so the kernel side zeroes / converts them with one launch each
-            qs = max(2, min((N + 63) // 64, 160 // max(1, self.heads * B)))
+            qs = max(2, min((N + 63) // 64, XATTN_WGS // max(1, self.heads * B)))
             lay_ = rt.daam_layer_grads.get(self.name) if (self.hooked and rt.daam_layer_grads) else None
             pre_ = self.hooked and rt.daam_grads is not None and rt.daam_applied and self.daam_batched and lay_ is None
             # (a hooked layer whose score-gradient GEMMs still run per layer reads dk right after this kernel: no deferral then)
