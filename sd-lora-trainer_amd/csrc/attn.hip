@@ -24,6 +24,13 @@
 
 namespace {
 
+// -DSDLT_ATTN_TRACE (tools/attn_trace.py): thread 0 of workgroup 0 stamps clock64() into p.D at the phase boundaries of a kernel
+#ifdef SDLT_ATTN_TRACE
+#define TR() do { if (tr) trb[trn++] = clock64(); } while (0)
+#else
+#define TR() do {} while (0)
+#endif
+
 constexpr float LOG2E = 1.4426950408889634f;
 
 __device__ __forceinline__ bf16x8 pack8(const float* a, const float* b) {
@@ -48,6 +55,25 @@ __device__ __forceinline__ bf16x8 lds_tr_frag(const char* p, int stride) {
   bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)p);
   bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p + 4 * stride));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// Workgroups are dealt to the 8 XCDs round-robin by linear id and every XCD has its own L2.  Renumber them so that XCD k runs a
+// CONTIGUOUS range of the (tile fastest, then head, then batch) order: the tiles of one head - which all stream the same K / V (forward,
+// dQ) or Q / dO (dK / dV) rows - then sit on one or two XCDs instead of all eight, and those rows are fetched into one L2, not eight.
+struct WgId { int x, y, z; };
+__device__ int g_attn_xcd = 1;          // SDLT_ATTN_XCD=0 (A/B): plain blockIdx order
+__device__ __forceinline__ WgId xcd_wg() {
+  if (!g_attn_xcd) { WgId w; w.x = blockIdx.x; w.y = blockIdx.y; w.z = blockIdx.z; return w; }
+  const int gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
+  const int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const int k = L & 7, slot = L >> 3, q = n >> 3, r = n & 7;
+  const int logical = (k < r ? k * (q + 1) : r * (q + 1) + (k - r) * q) + slot;
+  WgId w;
+  w.x = logical % gx;
+  const int t = logical / gx;
+  w.y = t % gy;
+  w.z = t / gy;
+  return w;
 }
 
 // LDS tile geometry.  d = 64 (every SDXL head; DP = 64): 128-byte rows with the 16-byte chunk index XOR-ed by row bits 1 and 3,
@@ -95,10 +121,11 @@ __device__ __forceinline__ void sstore_nat(const TileRegs<DP>& t, char* dst, int
 // workgroup and 1.25 workgroups per CU: with one wave per SIMD the softmax VALU work and the MFMAs of a step run one after the other -
 // two waves per SIMD on half the chain each overlap them (and halve the chain).
 template <int DP, int KS = 1>
-__global__ __launch_bounds__(256 * KS) void attn_fwd_kernel(const sdlt_attn_params p) {
+__global__ __launch_bounds__(256 * KS) __attribute__((amdgpu_waves_per_eu(DP == 64 ? 4 : 1, DP == 64 ? 4 : 8))) void attn_fwd_kernel(const sdlt_attn_params p) {
   constexpr int NSTR = tile_stride<DP>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const WgId wg = xcd_wg();
+  const int b = wg.z, h = wg.y, q0 = wg.x * 64;
   const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, g = lane >> 4, i = lane & 15;
   const int grp = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), tid = threadIdx.x & 255;
   const int d = p.d, hc = h * d;
@@ -130,7 +157,14 @@ __global__ __launch_bounds__(256 * KS) void attn_fwd_kernel(const sdlt_attn_para
   const int troff = (8 * g + (i >> 2)) * NSTR + (i & 3) * 8;   // transposing-read lane offset inside a natural tile
   const int tsw = row_sw<DP>(8 * g + (i >> 2)) >> 1;   // this lane's XOR on the 32-byte column block of a transposing read
   __syncthreads();
+#ifdef SDLT_ATTN_TRACE
+  const bool tr = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && p.D;
+  long long* trb = (long long*)p.D;
+  int trn = 0;
+  TR();
+#endif
   for (int it = 0; it < niter; ++it) {
+    TR();
     const int k0 = (it * KS + grp) * 64;
     if (KS > 1 && k0 >= kend) { __syncthreads(); continue; }     // (the shorter group idles through the last turn; wave-uniform)
     const char* Ks = gsm + (it & 1) * FBUF;
@@ -184,6 +218,7 @@ __global__ __launch_bounds__(256 * KS) void attn_fwd_kernel(const sdlt_attn_para
         rs += pv;
       }
     lsum = lsum * alpha + rs;
+    TR();
 #pragma unroll
     for (int df = 0; df < DP / 16; ++df) o[df] *= alpha;
 #pragma unroll
@@ -197,13 +232,16 @@ __global__ __launch_bounds__(256 * KS) void attn_fwd_kernel(const sdlt_attn_para
         o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[df], 0, 0, 0);
       }
     }
+    TR();
     if (more) {
       char* nb = gsm + ((it + 1) & 1) * FBUF;
       sstore_nat<DP>(kr, nb, tid);
       sstore_nat<DP>(vr, nb + 64 * NSTR, tid);
     }
+    TR();
     __syncthreads();
   }
+  TR();
   lsum += __shfl_xor(lsum, 16, 64);
   lsum += __shfl_xor(lsum, 32, 64);
   if constexpr (KS > 1) {
@@ -245,9 +283,9 @@ __global__ __launch_bounds__(256 * KS) void attn_fwd_kernel(const sdlt_attn_para
 
 // =============================================================================== backward dQ (per 64-query tile)
 template <int DP, bool WRITE_D>
-__device__ __forceinline__ void attn_bwd_dq_body(const sdlt_attn_params& p, char* smem, const int bx) {
+__device__ __forceinline__ void attn_bwd_dq_body(const sdlt_attn_params& p, char* smem, const int bx, const WgId wg) {
   constexpr int NSTR = tile_stride<DP>();
-  const int b = blockIdx.z, h = blockIdx.y, q0 = bx * 64;
+  const int b = wg.z, h = wg.y, q0 = bx * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
   const int d = p.d, hc = h * d;
   const int q = q0 + wave * 16 + i;
@@ -370,9 +408,9 @@ __device__ __forceinline__ void attn_bwd_dq_body(const sdlt_attn_params& p, char
 
 // =============================================================================== backward dK,dV (per 64-key tile, optional query split)
 template <int DP>
-__device__ __forceinline__ void attn_bwd_dkdv_body(const sdlt_attn_params& p, char* smem, const int bx) {
+__device__ __forceinline__ void attn_bwd_dkdv_body(const sdlt_attn_params& p, char* smem, const int bx, const WgId wg) {
   constexpr int NSTR = tile_stride<DP>();
-  const int b = blockIdx.z, h = blockIdx.y;
+  const int b = wg.z, h = wg.y;
   const int ktile = bx / p.qsplit, split = bx - ktile * p.qsplit;
   const int k0 = ktile * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
@@ -526,24 +564,27 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const sdlt_attn_params& p, ch
 
 // =============================================================================== backward launch forms
 template <int DP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const sdlt_attn_params p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DP == 64 ? 3 : 1, DP == 64 ? 3 : 8))) void attn_bwd_dq_kernel(const sdlt_attn_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  attn_bwd_dq_body<DP, true>(p, smem, blockIdx.x);
+  const WgId wg = xcd_wg();
+  attn_bwd_dq_body<DP, true>(p, smem, wg.x, wg);
 }
 template <int DP>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const sdlt_attn_params p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DP == 64 ? 3 : 1, DP == 64 ? 3 : 8))) void attn_bwd_dkdv_kernel(const sdlt_attn_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  attn_bwd_dkdv_body<DP>(p, smem, blockIdx.x);
+  const WgId wg = xcd_wg();
+  attn_bwd_dkdv_body<DP>(p, smem, wg.x, wg);
 }
 // Self-attention: the dQ tiles and the dK/dV tiles of one layer in ONE launch (blockIdx.x < #query tiles: dQ role).  At
 // 1024 tokens x 20 heads either pass alone is 320 workgroups of 16 dependent steps - latency-bound, the chip half empty;
 // together they overlap.  The dK/dV role needs D of every query row, so D comes from attn_prep_kernel here.
 template <int DP>
-__global__ __launch_bounds__(256) void attn_bwd_both_kernel(const sdlt_attn_params p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DP == 64 ? 3 : 1, DP == 64 ? 3 : 8))) void attn_bwd_both_kernel(const sdlt_attn_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ndq = (p.Nq + 63) / 64;
-  if ((int)blockIdx.x < ndq) attn_bwd_dq_body<DP, false>(p, smem, blockIdx.x);
-  else attn_bwd_dkdv_body<DP>(p, smem, blockIdx.x - ndq);
+  const WgId wg = xcd_wg();
+  if (wg.x < ndq) attn_bwd_dq_body<DP, false>(p, smem, wg.x, wg);
+  else attn_bwd_dkdv_body<DP>(p, smem, wg.x - ndq, wg);
 }
 // D[b,h,q] = sum_d dO*O (8 lanes per (row, head))
 __global__ void attn_prep_kernel(const bf16_t* O, int64_t ldo, const bf16_t* dO, int64_t lddo, int B, int H, int Nq, int Nqp, int d, float* D) {
@@ -576,7 +617,11 @@ __global__ void attn_prep_kernel(const bf16_t* O, int64_t ldo, const bf16_t* dO,
 // written once, plus D = rowsum(dO * O), which replaces the separate prep kernel) and key-major (its 2 x 16 keys x
 // the 64 queries -> dK / dV accumulated in registers over the whole query range, then fp32 atomics).  Replaces the
 // prep + dQ + query-split dK/dV launches of the generic path for the UNet's cross-attention.
-template <int DP>
+// FIVE (64 < Nk <= 80, the 77 text tokens): the keys are FIVE 16-key blocks.  Wave w owns block w against all 64 queries of a tile as
+// before; the fifth block (keys 64..79) is shared - wave w takes it against one 16-query set of the tile and the four partial dK / dV
+// blocks meet through LDS at the end (the two-blocks-per-wave layout spent half of every wave's key-major work on keys 80..127, which
+// do not exist, and gave wave 0 twice the live work of the others); the q-major pass skips the dead 32-key blocks of its second half.
+template <int DP, bool FIVE>
 __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_params p) {
   constexpr int NSTR = tile_stride<DP>();
   constexpr int QBUF = 2 * 64 * NSTR;                   // Q, dO natural
@@ -586,12 +631,18 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
   char* ring = Vs + 128 * NSTR;                         // 2 x QBUF
   float* LD = (float*)(ring + 2 * QBUF);                // L*log2e [64], D [64] of the current tile
   const int b = blockIdx.z, h = blockIdx.y, split = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, i = lane & 15;
   const int d = p.d, hc = h * d;
   const float sl2 = p.scale * LOG2E;
   const int troff = (8 * g + (i >> 2)) * NSTR + (i & 3) * 8;
   const int tsw = row_sw<DP>(8 * g + (i >> 2)) >> 1;   // this lane's XOR on the 32-byte column block of a transposing read
 
+#ifdef SDLT_ATTN_TRACE
+  const bool tr = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && p.D;
+  long long* trb = (long long*)p.D;
+  int trn = 0;
+  TR();
+#endif
   TileRegs<DP> qr, gr;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {                         // resident K / V tiles (rows >= Nkp read as zero)
@@ -608,7 +659,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
   f32x4 dk[2][DP / 16], dv[2][DP / 16];
 #pragma unroll
   for (int w = 0; w < 2; ++w) {
-    key[w] = w * 64 + wave * 16 + i;
+    key[w] = (FIVE && w == 1) ? 64 + i : w * 64 + wave * 16 + i;
     kok[w] = key[w] < p.Nk;
 #pragma unroll
     for (int kk = 0; kk < DP / 32; ++kk) {
@@ -635,17 +686,40 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
     sstore_nat<DP>(qr, base);
     sstore_nat<DP>(gr, base + 64 * NSTR);
   };
+  // O fragments and L of this lane's q-major row, fetched one tile ahead like the Q / dO tiles (as plain loads at their point of use they
+  // put two exposed global round trips at the head of every tile)
+  bf16x8 ofn[DP / 32];
+  float Lqn = 0.f;
+  auto gload_ol = [&](int qt) {
+    const int q = qt * 64 + wave * 16 + i;
+    const bool qok = q < p.Nq;
+#pragma unroll
+    for (int kk = 0; kk < DP / 32; ++kk) {
+      const int col = kk * 32 + g * 8;
+      ofn[kk] = ld_frag_global((const bf16_t*)p.O + ((int64_t)b * p.Nqp + q) * p.ldo + hc + col, qok && col < d);
+    }
+    Lqn = qok ? p.L[((int64_t)b * p.H + h) * p.Nq + q] * LOG2E : 0.f;
+  };
   if (qt_lo < qt_hi) {
     gload_all(qt_lo);
+    gload_ol(qt_lo);
     sstore_all(ring);
   }
   __syncthreads();
+  TR();
   for (int qt = qt_lo; qt < qt_hi; ++qt) {
     const int q0 = qt * 64;
     const char* Qs = ring + ((qt - qt_lo) & 1) * QBUF;
     const char* Gs = Qs + 64 * NSTR;
     const bool more = qt + 1 < qt_hi;
-    if (more) gload_all(qt + 1);
+    bf16x8 of[DP / 32];
+#pragma unroll
+    for (int kk = 0; kk < DP / 32; ++kk) of[kk] = ofn[kk];
+    const float Lq = Lqn;
+    if (more) {
+      gload_all(qt + 1);
+      gload_ol(qt + 1);
+    }
 
     // ---------------- q-major: this wave's rows q0 + wave*16 + i against all 128 keys -> D, dQ
     {
@@ -655,16 +729,13 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
       float Dq = 0.f;
 #pragma unroll
       for (int kk = 0; kk < DP / 32; ++kk) {
-        const int col = kk * 32 + g * 8;
         qf[kk] = *(const bf16x8*)(Qs + ql * NSTR + (((kk * 4 + g) ^ row_sw<DP>(ql)) << 4));
         gf[kk] = *(const bf16x8*)(Gs + ql * NSTR + (((kk * 4 + g) ^ row_sw<DP>(ql)) << 4));
-        bf16x8 of = ld_frag_global((const bf16_t*)p.O + ((int64_t)b * p.Nqp + q) * p.ldo + hc + col, qok && col < d);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Dq += (float)gf[kk][j] * (float)of[j];
+        for (int j = 0; j < 8; ++j) Dq += (float)gf[kk][j] * (float)of[kk][j];
       }
       Dq += __shfl_xor(Dq, 16, 64);
       Dq += __shfl_xor(Dq, 32, 64);
-      const float Lq = qok ? p.L[((int64_t)b * p.H + h) * p.Nq + q] * LOG2E : 0.f;
       if (g == 0) {
         LD[ql] = Lq;
         LD[64 + ql] = Dq;
@@ -680,6 +751,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
         for (int f = 0; f < 4; ++f) {
           s2[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
           dp2[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (FIVE && half == 1 && f >= 2) continue;          // keys 96..127
           const int krow = half * 64 + (f >> 1) * 32 + prow(i, f & 1);
 #pragma unroll
           for (int kk = 0; kk < DP / 32; ++kk) {
@@ -693,6 +765,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
         for (int f = 0; f < 4; ++f)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
+            if (FIVE && half == 1 && f >= 2) continue;
             const int kx = half * 64 + (f >> 1) * 32 + g * 8 + (f & 1) * 4 + r;
             const bool ok = qok && kx < p.Nk;
             const float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s2[f][r], sl2, -Lq)) : 0.f;
@@ -700,6 +773,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
           }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+          if (FIVE && half == 1 && kb == 1) continue;
           float a4[4] = {s2[2 * kb][0], s2[2 * kb][1], s2[2 * kb][2], s2[2 * kb][3]};
           float b4[4] = {s2[2 * kb + 1][0], s2[2 * kb + 1][1], s2[2 * kb + 1][2], s2[2 * kb + 1][3]};
           bf16x8 dsf = pack8(a4, b4);
@@ -729,17 +803,21 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
         }
       }
     }
+    TR();
     __syncthreads();   // L, D of all 64 rows visible
+    TR();
 
     // ---------------- key-major: this wave's 2 x 16 keys against the tile's 64 queries -> dK, dV
     {
       const float* Ls = LD;
       const float* Ds = LD + 64;
-      f32x4 s[2][4], dp[2][4];
+      constexpr int NWK = FIVE ? 1 : 2;      // 64-query key blocks of this wave
+      f32x4 s[NWK][4], dp[NWK][4];
+      f32x4 s5 = (f32x4){0.f, 0.f, 0.f, 0.f}, dp5 = (f32x4){0.f, 0.f, 0.f, 0.f};     // FIVE: block 4 x this wave's 16-query set (f == wave)
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
 #pragma unroll
-        for (int w = 0; w < 2; ++w) {
+        for (int w = 0; w < NWK; ++w) {
           s[w][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
           dp[w][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
@@ -749,14 +827,28 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
           bf16x8 qfr = *(const bf16x8*)(Qs + qrow * NSTR + (((kk * 4 + g) ^ row_sw<DP>(qrow)) << 4));
           bf16x8 gfr = *(const bf16x8*)(Gs + qrow * NSTR + (((kk * 4 + g) ^ row_sw<DP>(qrow)) << 4));
 #pragma unroll
-          for (int w = 0; w < 2; ++w) {
+          for (int w = 0; w < NWK; ++w) {
             s[w][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[w][kk], s[w][f], 0, 0, 0);
             dp[w][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gfr, vf[w][kk], dp[w][f], 0, 0, 0);
           }
+          if (FIVE && f == wave) {
+            s5 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[1][kk], s5, 0, 0, 0);
+            dp5 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gfr, vf[1][kk], dp5, 0, 0, 0);
+          }
+        }
+      }
+      if constexpr (FIVE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ql2 = (wave >> 1) * 32 + g * 8 + (wave & 1) * 4 + r;
+          const bool ok = kok[1] && q0 + ql2 < p.Nq;
+          const float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s5[r], sl2, -Ls[ql2])) : 0.f;
+          s5[r] = pv;
+          dp5[r] = pv * (dp5[r] - Ds[ql2]) * p.scale;
         }
       }
 #pragma unroll
-      for (int w = 0; w < 2; ++w)
+      for (int w = 0; w < NWK; ++w)
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
@@ -769,9 +861,9 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
           }
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
-        bf16x8 pf[2], dsf[2];
+        bf16x8 pf[NWK], dsf[NWK];
 #pragma unroll
-        for (int w = 0; w < 2; ++w) {
+        for (int w = 0; w < NWK; ++w) {
           float a4[4] = {s[w][2 * qb][0], s[w][2 * qb][1], s[w][2 * qb][2], s[w][2 * qb][3]};
           float b4[4] = {s[w][2 * qb + 1][0], s[w][2 * qb + 1][1], s[w][2 * qb + 1][2], s[w][2 * qb + 1][3]};
           pf[w] = pack8(a4, b4);
@@ -784,18 +876,50 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
           bf16x8 gtf = lds_tr_frag(Gs + troff + qb * 32 * NSTR + ((df ^ tsw) << 5), NSTR);
           bf16x8 qtf = lds_tr_frag(Qs + troff + qb * 32 * NSTR + ((df ^ tsw) << 5), NSTR);
 #pragma unroll
-          for (int w = 0; w < 2; ++w) {
+          for (int w = 0; w < NWK; ++w) {
             dv[w][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gtf, pf[w], dv[w][df], 0, 0, 0);
             dk[w][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf[w], dk[w][df], 0, 0, 0);
+          }
+          if (FIVE && qb == (wave >> 1)) {      // this wave's 16 queries sit in the (wave & 1) half of the 32-query contraction; the other half is zero
+            const float z4[4] = {0.f, 0.f, 0.f, 0.f};
+            const float p4[4] = {s5[0], s5[1], s5[2], s5[3]}, e4[4] = {dp5[0], dp5[1], dp5[2], dp5[3]};
+            const bf16x8 pf5 = (wave & 1) ? pack8(z4, p4) : pack8(p4, z4), dsf5 = (wave & 1) ? pack8(z4, e4) : pack8(e4, z4);
+            dv[1][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gtf, pf5, dv[1][df], 0, 0, 0);
+            dk[1][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf5, dk[1][df], 0, 0, 0);
           }
         }
       }
     }
+    TR();
     if (more) sstore_all(ring + ((qt - qt_lo + 1) & 1) * QBUF);
     __syncthreads();
+    TR();
   }
   // partial dK / dV of this query range -> slab[split][b*Nkp + key][C] (plain 16-byte stores; attn_splitsum_kernel adds the
   // slabs and converts).  Float atomics on the 77 x C block shared by every split were the whole cost of the old path.
+  if constexpr (FIVE) {
+    // the four waves' partial dK / dV of key block 4 -> LDS (the tile ring is dead) -> wave w adds and keeps column block df == w
+    f32x4* red = (f32x4*)ring;             // [wave][dk | dv][df][lane]
+#pragma unroll
+    for (int df = 0; df < DP / 16; ++df) {
+      red[((wave * 2 + 0) * (DP / 16) + df) * 64 + lane] = dk[1][df];
+      red[((wave * 2 + 1) * (DP / 16) + df) * 64 + lane] = dv[1][df];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int df = 0; df < DP / 16; ++df) {
+      f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f}, c = a;
+      if (df == wave || (DP / 16 > 4 && df == wave + 4)) {
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {
+          a += red[((w2 * 2 + 0) * (DP / 16) + df) * 64 + lane];
+          c += red[((w2 * 2 + 1) * (DP / 16) + df) * 64 + lane];
+        }
+      }
+      dk[1][df] = a;
+      dv[1][df] = c;
+    }
+  }
 #pragma unroll
   for (int w = 0; w < 2; ++w)
     if (kok[w]) {
@@ -803,12 +927,14 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
 #pragma unroll
       for (int df = 0; df < DP / 16; ++df) {
         int col = df * 16 + g * 4;
+        if (FIVE && w == 1 && df != wave && !(DP / 16 > 4 && df == wave + 4)) continue;     // (another wave holds this column block's sum)
         if (col < d) {
           *(f32x4*)(p.dK32 + row * p.ld32 + hc + col) = dk[w][df];
           *(f32x4*)(p.dV32 + row * p.ld32 + hc + col) = dv[w][df];
         }
       }
     }
+  TR();
 }
 
 // out[b*Nkp + key][c] = bf16(sum over splits of slab[split][b*Nkp + key][c]); pad keys [Nk, Nkp) get zeros
@@ -923,7 +1049,18 @@ int set_smem(F f, int bytes) {
 
 }  // namespace
 
+static void attn_env_once() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  if (getenv("SDLT_ATTN_XCD") && atoi(getenv("SDLT_ATTN_XCD")) == 0) {
+    const int zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_xcd), &zero, sizeof(int));
+  }
+}
+
 extern "C" int sdlt_attn_fwd(const sdlt_attn_params* pp, void* stream) {
+  attn_env_once();
   const sdlt_attn_params& p = *pp;
   hipStream_t s = (hipStream_t)stream;
   int rc = attn_check(p, "sdlt_attn_fwd");
@@ -949,6 +1086,7 @@ extern "C" int sdlt_attn_fwd(const sdlt_attn_params* pp, void* stream) {
 }
 
 extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
+  attn_env_once();
   const sdlt_attn_params& p = *pp;
   hipStream_t s = (hipStream_t)stream;
   int rc = attn_check(p, "sdlt_attn_bwd");
@@ -977,8 +1115,11 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
     // dK32 / dV32 = [qsplit][B*Nkp][ld32] partial slabs (any contents)
     dim3 gx(p.qsplit, p.H, p.B);
 #define SMEM_X(D_) (2 * 128 * NSTRH(D_) + 2 * (2 * 64 * NSTRH(D_)) + 512)
-    if (dp == 64) { set_smem(attn_bwd_cross_kernel<64>, SMEM_X(64)); hipLaunchKernelGGL(attn_bwd_cross_kernel<64>, gx, dim3(256), SMEM_X(64), s, p); }
-    else { set_smem(attn_bwd_cross_kernel<96>, SMEM_X(96)); hipLaunchKernelGGL(attn_bwd_cross_kernel<96>, gx, dim3(256), SMEM_X(96), s, p); }
+    static const bool five_env = !(getenv("SDLT_XATTN_FIVE") && atoi(getenv("SDLT_XATTN_FIVE")) == 0);
+    const bool five = five_env && p.Nk > 64 && p.Nk <= 80;
+#define XLAUNCH(D_, F_) do { set_smem(attn_bwd_cross_kernel<D_, F_>, SMEM_X(D_)); hipLaunchKernelGGL((attn_bwd_cross_kernel<D_, F_>), gx, dim3(256), SMEM_X(D_), s, p); } while (0)
+    if (dp == 64) { if (five) XLAUNCH(64, true); else XLAUNCH(64, false); }
+    else { if (five) XLAUNCH(96, true); else XLAUNCH(96, false); }
     if (!p.defer_splitsum) {
       int blocks = (int)(((int64_t)krows * C / 2 + 255) / 256);
       if (blocks > 4096) blocks = 4096;

@@ -40,6 +40,14 @@ struct wsk_params {
   int stagger;
 };
 
+// -DSDLT_WSK_TRACE (tools/wsk_trace.py): thread 0 of workgroup 0 stamps clock64() at the phase boundaries; sdlt_wsk_trace_read copies them out
+#ifdef SDLT_WSK_TRACE
+__device__ long long g_wsk_tr[16];
+#define WTR(i_) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_wsk_tr[i_] = clock64(); } while (0)
+#else
+#define WTR(i_) do {} while (0)
+#endif
+
 // MBK x 16 rows, JN x 16 columns per workgroup; R ring slots per wave
 // KG: 0 no adapter, 1 one rank-16 adapter, 2..3 that many K groups with an adapter each
 template <int MBK, int JN, int R, int KG = 0>
@@ -47,6 +55,7 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   constexpr bool LORA = KG > 0;
   constexpr int XR = 16 * MBK, WR = 16 * JN, SROWS = XR + WR + (LORA ? 16 : 0), SLOT = SROWS * ROWB, PIECES = SROWS / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  WTR(0);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int ntn = p.N / WR, ntm = p.M / XR;
@@ -104,6 +113,22 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
 #pragma unroll
     for (int j = 0; j < JN; ++j) acc[j][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  constexpr int UNITS_ = MBK * JN, UPW_ = (UNITS_ + NW - 1) / NW;
+  // residual and bias of the units this wave finishes, requested before anything else (loads at their point of use sit exposed behind the
+  // last barrier: +1.1 us per launch; being the OLDEST loads in flight they only make the counted waits below wait for them too)
+  uint2 rpre[UPW_];
+  f32x4 bpre[UPW_];
+#pragma unroll
+  for (int q = 0; q < UPW_; ++q) {
+    const int u = wave + q * NW;
+    rpre[q] = make_uint2(0u, 0u);
+    bpre[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (u < UNITS_) {
+      const int mb = u / JN, j = u - mb * JN, n = n0 + 16 * j + 4 * g, m = m0 + mb * 16 + r;
+      if (p.R) rpre[q] = *(const uint2*)(p.R + (int64_t)m * p.ldr + n);
+      if (p.bias) bpre[q] = *(const f32x4*)(p.bias + n);
+    }
+  }
   static_assert(R == 2 || KG <= 1, "the K-grouped bookkeeping below tracks a 2-slot ring");
 
   int kq[R];               // (a small FIFO in registers: slot s holds the step whose first column is kq[s]; R is 2)
@@ -113,12 +138,14 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   for (int s = 0; s < R; ++s)
     if (s < nsteps) kq[s] = issue(s, s);
   int slot = 0;
+  WTR(1);
   for (int i = 0; i < nsteps; ++i) {
     const int kcur = slot == 0 ? kq[0] : kq[R - 1];
     const int after = nsteps - 1 - i;
     if (after >= R - 1) wait_vmcnt<PIECES * (R - 1)>();
     else if (R > 2 && after == 1) wait_vmcnt<PIECES>();
     else wait_vmcnt<0>();
+    if (i < 6) WTR(2 + i);
     const char* base = ring + slot * SLOT;
     bf16x8 xf[2][MBK], wf[2][JN], af[2];
 #pragma unroll
@@ -167,7 +194,9 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
 
   // ---- the 4 partial tiles meet in LDS; unit u = (row block, column block), wave w finishes units w, w + 4, ...
   constexpr int UNITS = MBK * JN, TUN = LORA ? TG * MBK : 0, UALL = UNITS + TUN, UPW = (UNITS + NW - 1) / NW;
+  WTR(8);
   __syncthreads();
+  WTR(9);
   f32x4* red = (f32x4*)smem;                                  // [NW][UALL][64 lanes]
   uint2* tsh = (uint2*)(smem + (size_t)NW * UALL * 1024);     // [TG][MBK][64 lanes]: bf16(s T_g) in the 16x16x16 B-operand layout
 #pragma unroll
@@ -209,6 +238,7 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
     }
     __syncthreads();
   }
+  WTR(10);
 #pragma unroll
   for (int q = 0; q < UPW; ++q) {
     const int u = wave + q * NW;
@@ -225,16 +255,14 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
         v = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, bupf[q][tg]), __builtin_bit_cast(s16x4, tb), v, 0, 0, 0);
       }
     }
-    if (p.bias) {
-      const f32x4 b4 = *(const f32x4*)(p.bias + n);
-      v += b4;
-    }
-    if (p.R) {
-      const uint2 rv = *(const uint2*)(p.R + (int64_t)m * p.ldr + n);
+    v += bpre[q];
+    {
+      const uint2 rv = rpre[q];
       v[0] += bf2f(rv.x & 0xffff); v[1] += bf2f(rv.x >> 16); v[2] += bf2f(rv.y & 0xffff); v[3] += bf2f(rv.y >> 16);
     }
     *(uint2*)(p.Y + (int64_t)m * p.ldy + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
   }
+  WTR(11);
 }
 
 template <int MBK, int JN, int R, int KG>
@@ -256,6 +284,10 @@ int launch_wsk(const wsk_params& p, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef SDLT_WSK_TRACE
+extern "C" int sdlt_wsk_trace_read(long long* out16) { return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_wsk_tr), sizeof(long long) * 16); }
+#endif
 
 extern "C" int sdlt_wsk_gemm(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t M, int32_t N, int32_t K, const float* bias,
                              const void* R, int64_t ldr, void* Y, int64_t ldy, const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup,
