@@ -446,6 +446,27 @@ typedef struct sdlt_strip_params {
 } sdlt_strip_params;
 int sdlt_strip_gemm(const sdlt_strip_params* p, void* stream);
 
+/* Paired launches (reference: none - launch structure only).  SDXL conditions on TWO text encoders (trainer/inference.py:131-177 through
+ * diffusers' encode_prompt): layer i of CLIP-L and layer i of OpenCLIP-bigG are independent chains of launch-bound 77-row kernels, and a
+ * launch costs more than CLIP-L's share of it.  Each *_pair entry runs problem a and problem b of the same kernel in ONE launch, with the
+ * results of the two single calls (bit for bit: the per-workgroup arithmetic is the same code).
+ *   sdlt_strip_gemm_pair: both with or both without a LayerNorm fold; no in-kernel K split (partial outputs are fine).
+ *   sdlt_attn_fwd_pair / sdlt_attn_bwd_pair: self-attention (qsplit 1) with head width <= 64 and < 256 keys each (sdlt_attn_pair_ok).
+ *   sdlt_layernorm_bwd_slabs_pair: two sdlt_layernorm_bwd_slabs problems. */
+int sdlt_strip_gemm_pair(const sdlt_strip_params* a, const sdlt_strip_params* b, void* stream);
+int sdlt_attn_pair_ok(const sdlt_attn_params* a, const sdlt_attn_params* b);
+int sdlt_attn_fwd_pair(const sdlt_attn_params* a, const sdlt_attn_params* b, void* stream);
+int sdlt_attn_bwd_pair(const sdlt_attn_params* a, const sdlt_attn_params* b, void* stream);
+typedef struct sdlt_ln_slabs_params {
+  const void* x; int64_t ldx;
+  const float* dy32; int64_t lddy32;
+  const float* gamma; const float* stats;
+  const void* dres; int64_t lddres;
+  void* dx; int64_t lddx;
+  int32_t nslab, M, C, pad_;
+} sdlt_ln_slabs_params;
+int sdlt_layernorm_bwd_slabs_pair(const sdlt_ln_slabs_params* a, const sdlt_ln_slabs_params* b, void* stream);
+
 /* Wave-split-K GEMM for the long-K, 1280-wide products of the batch-1 UNet:  Y[M,N] = X[M,K] . W[N,K]^T + bias[n] + R[m,n]  (bf16 in / out,
  * fp32 accumulation), M % 64 == 0, N % 640 == 0, K % 256 == 0.  64 x 80 tiles (exactly 256 workgroups for 1024 x 1280), the 4 waves of a
  * workgroup split K and stage their own operands through private LDS rings - no block barrier in the K loop; the 4 partial tiles are added in

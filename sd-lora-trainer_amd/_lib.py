@@ -118,6 +118,11 @@ class TaGroup(C.Structure):
     _fields_ = [("S", vp), ("Wh", vp), ("Ww", vp), ("ch", vp), ("cw", vp), ("dS", vp), ("dSt", vp), ("dheat", vp), ("h", i32), ("w", i32)]
 
 
+class LnSlabsParams(C.Structure):
+    _fields_ = [("x", vp), ("ldx", i64), ("dy32", vp), ("lddy32", i64), ("gamma", vp), ("stats", vp), ("dres", vp), ("lddres", i64),
+                ("dx", vp), ("lddx", i64), ("nslab", i32), ("M", i32), ("C", i32), ("pad_", i32)]
+
+
 class TaParams(C.Structure):
     _fields_ = [("g", TaGroup * 4), ("mask", vp), ("tok_w", vp), ("tok_cnt", vp), ("ti_onehot", vp), ("has_ti", vp), ("ws", vp), ("ws_floats", i64),
                 ("loss", vp), ("ngroups", i32), ("B", i32), ("n_tok", i32), ("n_layers", i32), ("mH", i32), ("mW", i32), ("weight", f32),
@@ -167,6 +172,11 @@ SYMBOLS = {
     "sdlt_dora_scale_wt": (i32, [vp, vp, vp, i32, vp]),
     "sdlt_dora_mag_grad": (i32, [vp, vp, vp, i32, vp, vp, i32, vp, vp]),
     "sdlt_strip_gemm": (i32, [C.POINTER(StripParams), vp]),
+    "sdlt_strip_gemm_pair": (i32, [C.POINTER(StripParams), C.POINTER(StripParams), vp]),
+    "sdlt_attn_pair_ok": (i32, [C.POINTER(AttnParams), C.POINTER(AttnParams)]),
+    "sdlt_attn_fwd_pair": (i32, [C.POINTER(AttnParams), C.POINTER(AttnParams), vp]),
+    "sdlt_attn_bwd_pair": (i32, [C.POINTER(AttnParams), C.POINTER(AttnParams), vp]),
+    "sdlt_layernorm_bwd_slabs_pair": (i32, [C.POINTER(LnSlabsParams), C.POINTER(LnSlabsParams), vp]),
     "sdlt_wsk_gemm": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp, i64, vp, i64, vp, i64, vp, i64, f32, vp, i64, i32, vp]),
     "sdlt_token_attention_ws_floats": (i64, [C.POINTER(TaParams)]),
     "sdlt_token_attention_loss": (i32, [C.POINTER(TaParams), vp]),

@@ -155,39 +155,78 @@ class FusedClipLayer(_Module):
     def zbuf(self, key, *shape, dtype=None):
         return self.buf(key, *shape, dtype=dtype, zero=True)
 
-    def forward(self, x, B, out=None):
+    def forward_steps(self, x, B, out=None):
+        """Generator form of forward: yields after every launch (ops.run_paired pairs the launches of two encoders' layers)."""
         ops, M, D, F_ = self.rt.ops, B * TP, self.D, self.F
         kw = dict(B=B, T=T_TOKENS, Tp=TP)
         self._x, self._B = x, B
         qkv = ops.strip_gemm(x, self.Wqkv_g, self.zbuf("qkv", M, 3 * D), ln=(self.qkv_c1, self.qkv_c2, self.eps),
                              stats=self.zbuf("st1", M * 2, dtype=F32), **kw)
+        yield
         q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
         O, L = self.zbuf("O", M, D), self.zbuf("L", B * self.heads * T_TOKENS, dtype=F32)
         ops.attn_fwd(q, k, v, None, O, L, **self._akw(B))
+        yield
         x1 = ops.strip_gemm(O, self.Wo, self.zbuf("x1", M, D), bias=self.bo, residual=x, **kw)
+        yield
         a = self.zbuf("a", M, F_)
         ops.strip_gemm(x1, self.W1_g, self.zbuf("y1", M, F_), ln=(self.fc1_c1, self.fc1_c2, self.eps), stats=self.zbuf("st2", M * 2, dtype=F32),
                        act_out=(self.act_kind, a), **kw)
-        return ops.strip_gemm(a, self.W2, out if out is not None else self.zbuf("x2", M, D), bias=self.b2, residual=x1, **kw)
+        yield
+        y = ops.strip_gemm(a, self.W2, out if out is not None else self.zbuf("x2", M, D), bias=self.b2, residual=x1, **kw)
+        yield
+        return y
 
-    def backward(self, dx2):
+    def forward(self, x, B, out=None):
+        return _drain(self.forward_steps(x, B, out))
+
+    def backward_steps(self, dx2):
         ops, B, D, F_ = self.rt.ops, self._B, self.D, self.F
         M = B * TP
         kw = dict(B=B, T=T_TOKENS, Tp=TP)
         b = self._b
         df = ops.strip_gemm(dx2, self.W2_t, self.zbuf("df", M, F_), dact_in=(self.act_kind, b["y1"]), **kw)
+        yield
         # the two long-K input gradients (K = mlp width, 3 D) are cut into K slices whose fp32 tiles the LayerNorm backward behind them adds
         # in its prologue: a split without a seam (an in-kernel last-arriver reduction costs 4 - 5 us, the launch boundary nothing)
         S2 = ops.strip_partial_splits(D, F_, B)
         dn2 = ops.strip_gemm(df, self.W1_t, None, partial=self.zbuf("dn2_p", S2, M, D, dtype=F32), **kw)
+        yield
         dx1 = ops.layernorm_bwd(b["x1"], None, self.zbuf("dx1", M, D), b["st2"], gamma=self.g2, dres=dx2, dy_slabs=dn2)
+        yield
         dO = ops.strip_gemm(dx1, self.Wo_t, self.zbuf("dO", M, D), **kw)
+        yield
         qkv, dqkv = b["qkv"], self.zbuf("dqkv", M, 3 * D)
         ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], None, None, b["O"], b["L"], dO, None,
                      self.zbuf("Dd", B * self.heads * T_TOKENS, dtype=F32), dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], **self._akw(B))
+        yield
         S1 = ops.strip_partial_splits(D, 3 * D, B)
         dn1 = ops.strip_gemm(dqkv, self.Wqkv_t, None, partial=self.zbuf("dn1_p", S1, M, D, dtype=F32), **kw)
-        return ops.layernorm_bwd(self._x, None, self.zbuf("dx", M, D), b["st1"], gamma=self.g1, dres=dx1, dy_slabs=dn1)
+        yield
+        dx = ops.layernorm_bwd(self._x, None, self.zbuf("dx", M, D), b["st1"], gamma=self.g1, dres=dx1, dy_slabs=dn1)
+        yield
+        return dx
+
+    def backward(self, dx2):
+        return _drain(self.backward_steps(dx2))
+
+
+def _drain(gen):
+    while True:
+        try:
+            next(gen)
+        except StopIteration as e:
+            return e.value
+
+
+def _sub(gen, key):
+    """Re-yield the steps of a layer generator tagged with `key` (the layer index); evaluates to the layer's result."""
+    while True:
+        try:
+            next(gen)
+        except StopIteration as e:
+            return e.value
+        yield key
 
 
 class ClipTextEncoder(_Module):
@@ -224,7 +263,11 @@ class ClipTextEncoder(_Module):
         self.train_ids = torch.arange(self.V - n_train, self.V, dtype=torch.int64, device=rt.device)
 
     def forward(self, ids, B, hidden_out=None, pool_rows=None, hidden_only=False):
-        """ids int64 [B,77] (device).  hidden_out: optional [B*TP, D] (strided) destination of the hidden states.
+        return _drain(self.forward_steps(ids, B, hidden_out=hidden_out, pool_rows=pool_rows, hidden_only=hidden_only))
+
+    def forward_steps(self, ids, B, hidden_out=None, pool_rows=None, hidden_only=False):
+        """Generator (yields the layer index after every launch of a fused layer; ops.run_paired pairs two encoders' launches).
+        ids int64 [B,77] (device).  hidden_out: optional [B*TP, D] (strided) destination of the hidden states.
         pool_rows int64 [B]: row index b*TP + pool position (HF: argmax / first EOS) for the pooled output.
         hidden_only: the caller needs no pooled output - nothing above the hidden state is run."""
         rt = self.rt
@@ -233,7 +276,10 @@ class ClipTextEncoder(_Module):
         hidden = None
         for i, layer in enumerate(self.layers):
             is_hidden = (i + 1 == self.n_hidden) and self.mode == "penultimate"
-            x = layer.forward(x, B, out=hidden_out if is_hidden else None)
+            if self.fused:
+                x = yield from _sub(layer.forward_steps(x, B, out=hidden_out if is_hidden else None), i)
+            else:
+                x = layer.forward(x, B, out=hidden_out if is_hidden else None)
             if is_hidden:
                 hidden = x
                 if hidden_only:
@@ -251,7 +297,10 @@ class ClipTextEncoder(_Module):
         return hidden, pooled
 
     def backward(self, d_hidden, d_pooled, grad_rows, accumulate=False):
-        """d_hidden [B*TP, D] (strided view ok; pad rows must be zero), d_pooled [B,P] or None -> grad_rows fp32 [n_train, D]."""
+        return _drain(self.backward_steps(d_hidden, d_pooled, grad_rows, accumulate=accumulate))
+
+    def backward_steps(self, d_hidden, d_pooled, grad_rows, accumulate=False):
+        """Generator form (see forward_steps).  d_hidden [B*TP, D] (strided view ok; pad rows must be zero), d_pooled [B,P] or None -> grad_rows fp32 [n_train, D]."""
         rt, B = self.rt, self._B
         dx = None
         if self.final_ln is not None:
@@ -270,7 +319,10 @@ class ClipTextEncoder(_Module):
                 dx = d_hidden if dx is None else rt.ops.add2d(dx, d_hidden, self.buf("dxh", B * TP, self.D))
             if dx is None:
                 continue      # layers above the hidden state with no pooled gradient: nothing flows
-            dx = self.layers[i].backward(dx)
+            if self.fused:
+                dx = yield from _sub(self.layers[i].backward_steps(dx), i)
+            else:
+                dx = self.layers[i].backward(dx)
         return rt.ops.embed_grad(dx, self._ids, self.train_ids, grad_rows, B=B, T=T_TOKENS, Tp=TP, accumulate=accumulate)
 
 

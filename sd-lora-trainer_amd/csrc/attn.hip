@@ -120,11 +120,9 @@ __device__ __forceinline__ void sstore_nat(const TileRegs<DP>& t, char* dst, int
 // state and K / V buffers; the groups' (m, l, O) meet through LDS at the end.  A 1024-token layer is 16 dependent tile steps per
 // workgroup and 1.25 workgroups per CU: with one wave per SIMD the softmax VALU work and the MFMAs of a step run one after the other -
 // two waves per SIMD on half the chain each overlap them (and halve the chain).
-template <int DP, int KS = 1>
-__global__ __launch_bounds__(256 * KS) __attribute__((amdgpu_waves_per_eu(DP == 64 ? 4 : 1, DP == 64 ? 4 : 8))) void attn_fwd_kernel(const sdlt_attn_params p) {
+template <int DP, int KS>
+__device__ __forceinline__ void attn_fwd_body(const sdlt_attn_params& p, char* smem, const WgId wg) {
   constexpr int NSTR = tile_stride<DP>();
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const WgId wg = xcd_wg();
   const int b = wg.z, h = wg.y, q0 = wg.x * 64;
   const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, g = lane >> 4, i = lane & 15;
   const int grp = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), tid = threadIdx.x & 255;
@@ -278,6 +276,25 @@ __global__ __launch_bounds__(256 * KS) __attribute__((amdgpu_waves_per_eu(DP == 
         *(uint2*)((bf16_t*)p.O + ((int64_t)b * p.Nqp + q) * p.ldo + hc + col) = w;
       }
     }
+  }
+}
+
+template <int DP, int KS = 1>
+__global__ __launch_bounds__(256 * KS) __attribute__((amdgpu_waves_per_eu(DP == 64 ? 4 : 1, DP == 64 ? 4 : 8))) void attn_fwd_kernel(const sdlt_attn_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  attn_fwd_body<DP, KS>(p, smem, xcd_wg());
+}
+// Two independent attention problems of the same head width in ONE launch: the heads of p1 follow the heads of p0 along grid y (the text
+// encoders' layer i of CLIP-L and of OpenCLIP-bigG; see strip_pair_kernel).
+template <int DP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DP == 64 ? 4 : 1, DP == 64 ? 4 : 8))) void attn_fwd_pair_kernel(const sdlt_attn_params p0, const sdlt_attn_params p1) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  WgId wg = xcd_wg();
+  if (wg.y < p0.H) {
+    if (wg.x * 64 < p0.Nq && wg.z < p0.B) attn_fwd_body<DP, 1>(p0, smem, wg);
+  } else {
+    wg.y -= p0.H;
+    if (wg.x * 64 < p1.Nq && wg.z < p1.B) attn_fwd_body<DP, 1>(p1, smem, wg);
   }
 }
 
@@ -587,10 +604,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DP == 64 ? 
   else attn_bwd_dkdv_body<DP>(p, smem, wg.x - ndq, wg);
 }
 // D[b,h,q] = sum_d dO*O (8 lanes per (row, head))
-__global__ void attn_prep_kernel(const bf16_t* O, int64_t ldo, const bf16_t* dO, int64_t lddo, int B, int H, int Nq, int Nqp, int d, float* D) {
+__device__ __forceinline__ void attn_prep_body(const bf16_t* O, int64_t ldo, const bf16_t* dO, int64_t lddo, int B, int H, int Nq, int Nqp, int d, float* D, const int bx, const int gx) {
   const int64_t total = (int64_t)B * Nqp * H;
   const int sub = threadIdx.x & 7;
-  for (int64_t idx = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 3; idx < total; idx += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+  for (int64_t idx = (bx * (int64_t)blockDim.x + threadIdx.x) >> 3; idx < total; idx += ((int64_t)gx * blockDim.x) >> 3) {
     int h = idx % H;
     int64_t row = idx / H;  // b*Nqp + q
     const int b = row / Nqp, q = row - (int64_t)b * Nqp;
@@ -608,6 +625,30 @@ __global__ void attn_prep_kernel(const bf16_t* O, int64_t ldo, const bf16_t* dO,
     acc += __shfl_xor(acc, 2, 64);
     acc += __shfl_xor(acc, 4, 64);
     if (sub == 0) D[((int64_t)b * H + h) * Nq + q] = acc;
+  }
+}
+__global__ void attn_prep_kernel(const bf16_t* O, int64_t ldo, const bf16_t* dO, int64_t lddo, int B, int H, int Nq, int Nqp, int d, float* D) {
+  attn_prep_body(O, ldo, dO, lddo, B, H, Nq, Nqp, d, D, blockIdx.x, gridDim.x);
+}
+__global__ void attn_prep_pair_kernel(const sdlt_attn_params p0, const sdlt_attn_params p1) {
+  const sdlt_attn_params& p = blockIdx.y == 0 ? p0 : p1;
+  attn_prep_body((const bf16_t*)p.O, p.ldo, (const bf16_t*)p.dO, p.lddo, p.B, p.H, p.Nq, p.Nqp, p.d, p.D, blockIdx.x, gridDim.x);
+}
+template <int DP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DP == 64 ? 3 : 1, DP == 64 ? 3 : 8))) void attn_bwd_both_pair_kernel(const sdlt_attn_params p0, const sdlt_attn_params p1) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  WgId wg = xcd_wg();
+  if (wg.y < p0.H) {
+    const int ndq = (p0.Nq + 63) / 64, nkv = (p0.Nk + 63) / 64;
+    if (wg.x >= ndq + nkv || wg.z >= p0.B) return;
+    if (wg.x < ndq) attn_bwd_dq_body<DP, false>(p0, smem, wg.x, wg);
+    else attn_bwd_dkdv_body<DP>(p0, smem, wg.x - ndq, wg);
+  } else {
+    wg.y -= p0.H;
+    const int ndq = (p1.Nq + 63) / 64, nkv = (p1.Nk + 63) / 64;
+    if (wg.x >= ndq + nkv || wg.z >= p1.B) return;
+    if (wg.x < ndq) attn_bwd_dq_body<DP, false>(p1, smem, wg.x, wg);
+    else attn_bwd_dkdv_body<DP>(p1, smem, wg.x - ndq, wg);
   }
 }
 
@@ -1159,6 +1200,55 @@ extern "C" int sdlt_attn_splitsum_batch(const sdlt_splitsum_desc* descs_dev, con
                                         void* stream) {
   if (n_blocks <= 0) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_attn_splitsum_batch: n_blocks=%d", n_blocks);
   hipLaunchKernelGGL(attn_splitsum_batch_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, block_desc_dev, block_first_dev);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+
+// reference: none (launch structure only).  Two causal / plain self-attention problems of head width <= 64 in one launch each way; the
+// caller falls back to two single calls when sdlt_attn_pair_ok says no.
+static bool attn_pair_shape_ok(const sdlt_attn_params& a, const sdlt_attn_params& b) {
+  return attn_dp(a.d) == 64 && attn_dp(b.d) == 64 && a.Nk < 256 && b.Nk < 256 && a.qsplit == 1 && b.qsplit == 1 && !a.accumulate_dq && !b.accumulate_dq &&
+         !a.accumulate_dk && !b.accumulate_dk && (a.Nq + 63) / 64 + (a.Nk + 63) / 64 <= 64 && (b.Nq + 63) / 64 + (b.Nk + 63) / 64 <= 64;
+}
+extern "C" int sdlt_attn_pair_ok(const sdlt_attn_params* a, const sdlt_attn_params* b) { return attn_pair_shape_ok(*a, *b) ? 1 : 0; }
+
+extern "C" int sdlt_attn_fwd_pair(const sdlt_attn_params* pa, const sdlt_attn_params* pb, void* stream) {
+  attn_env_once();
+  const sdlt_attn_params &a = *pa, &b = *pb;
+  int rc = attn_check(a, "sdlt_attn_fwd_pair");
+  if (rc) return rc;
+  rc = attn_check(b, "sdlt_attn_fwd_pair");
+  if (rc) return rc;
+  if ((a.ldo % 4) || (b.ldo % 4)) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_attn_fwd_pair: ldo %% 4");
+  if (!attn_pair_shape_ok(a, b)) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_attn_fwd_pair: shapes (d <= 64, Nk < 256 both)");
+  const int ta = (a.Nq + 63) / 64, tb = (b.Nq + 63) / 64;
+  dim3 grid(ta > tb ? ta : tb, a.H + b.H, a.B > b.B ? a.B : b.B);
+  set_smem(attn_fwd_pair_kernel<64>, SMEM_FWD(64));
+  hipLaunchKernelGGL(attn_fwd_pair_kernel<64>, grid, dim3(256), SMEM_FWD(64), (hipStream_t)stream, a, b);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+
+extern "C" int sdlt_attn_bwd_pair(const sdlt_attn_params* pa, const sdlt_attn_params* pb, void* stream) {
+  attn_env_once();
+  const sdlt_attn_params &a = *pa, &b = *pb;
+  hipStream_t s = (hipStream_t)stream;
+  for (const sdlt_attn_params* q : {pa, pb}) {
+    const sdlt_attn_params& p = *q;
+    int rc = attn_check(p, "sdlt_attn_bwd_pair");
+    if (rc) return rc;
+    if (!p.L || !p.D || !p.O || !p.dO || !p.dQ || !p.dK || !p.dV) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_attn_bwd_pair: missing operand");
+    if ((p.lddo % 8) || (p.ldo % 8) || (p.lddq % 4) || (p.lddk % 4) || (p.lddv % 4)) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_attn_bwd_pair: ld alignment");
+  }
+  if (!attn_pair_shape_ok(a, b)) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_attn_bwd_pair: shapes");
+  const int64_t ga = (int64_t)a.B * a.Nqp * a.H, gb = (int64_t)b.B * b.Nqp * b.H;
+  int blocks = (int)(((ga > gb ? ga : gb) * 8 + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(attn_prep_pair_kernel, dim3(blocks, 2), dim3(256), 0, s, a, b);
+  const int xa = (a.Nq + 63) / 64 + (a.Nk + 63) / 64, xb = (b.Nq + 63) / 64 + (b.Nk + 63) / 64;
+  dim3 grid(xa > xb ? xa : xb, a.H + b.H, a.B > b.B ? a.B : b.B);
+  set_smem(attn_bwd_both_pair_kernel<64>, SMEM_BOTH(64));
+  hipLaunchKernelGGL(attn_bwd_both_pair_kernel<64>, grid, dim3(256), SMEM_BOTH(64), s, a, b);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }

@@ -350,11 +350,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 
 // SLABS: dy arrives as `nslab` fp32 slabs [nslab][M][lddy] (partial outputs of a K-split sdlt_strip_gemm), added here in slab order
 template <bool SLABS>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ x, int64_t ldx, const void* __restrict__ dy_, int64_t lddy, int nslab, int M,
-                                                      int C, const float* __restrict__ gamma, const float* __restrict__ stats,
-                                                      const bf16_t* dres, int64_t lddres, bf16_t* dx, int64_t lddx) {
+__device__ __forceinline__ void ln_bwd_body(const bf16_t* __restrict__ x, int64_t ldx, const void* __restrict__ dy_, int64_t lddy, int nslab, int M,
+                                            int C, const float* __restrict__ gamma, const float* __restrict__ stats,
+                                            const bf16_t* dres, int64_t lddres, bf16_t* dx, int64_t lddx, const int bx) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row = bx * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int nch = C >> 3;
   const bf16_t* dy = (const bf16_t*)dy_;
@@ -416,6 +416,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       store8(dx + (int64_t)row * lddx + ch * 8, o);
     }
   }
+}
+
+template <bool SLABS>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ x, int64_t ldx, const void* __restrict__ dy_, int64_t lddy, int nslab, int M,
+                                                      int C, const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                      const bf16_t* dres, int64_t lddres, bf16_t* dx, int64_t lddx) {
+  ln_bwd_body<SLABS>(x, ldx, dy_, lddy, nslab, M, C, gamma, stats, dres, lddres, dx, lddx, blockIdx.x);
+}
+// two independent problems in one launch (blockIdx.y picks): see strip_pair_kernel
+__global__ __launch_bounds__(256) void ln_bwd_slabs_pair_kernel(const sdlt_ln_slabs_params a, const sdlt_ln_slabs_params b) {
+  const sdlt_ln_slabs_params& p = blockIdx.y == 0 ? a : b;
+  ln_bwd_body<true>((const bf16_t*)p.x, p.ldx, p.dy32, p.lddy32, p.nslab, p.M, p.C, p.gamma, p.stats, (const bf16_t*)p.dres, p.lddres, (bf16_t*)p.dx, p.lddx, blockIdx.x);
 }
 
 int gn_check(const sdlt_groupnorm_params& p, const char* fn) {
@@ -514,6 +526,19 @@ extern "C" int sdlt_layernorm_bwd_slabs(const void* x, int64_t ldx, const float*
   if (M <= 0 || C <= 0 || (C % 8) || C > LN_MAXCH * 512 || nslab < 1) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_layernorm_bwd_slabs: M=%d C=%d nslab=%d", M, C, nslab);
   if ((ldx % 8) || (lddy32 % 4) || (lddx % 8) || (dres && (lddres % 8)) || ((uintptr_t)dy32 & 15)) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_layernorm_bwd_slabs: alignment");
   hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, dy32, lddy32, nslab, M, C, gamma, stats, (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+
+// reference: none (launch structure only): two sdlt_layernorm_bwd_slabs problems in one launch
+extern "C" int sdlt_layernorm_bwd_slabs_pair(const sdlt_ln_slabs_params* pa, const sdlt_ln_slabs_params* pb, void* stream) {
+  for (const sdlt_ln_slabs_params* q : {pa, pb}) {
+    const sdlt_ln_slabs_params& p = *q;
+    if (p.M <= 0 || p.C <= 0 || (p.C % 8) || p.C > LN_MAXCH * 512 || p.nslab < 1) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_layernorm_bwd_slabs_pair: M=%d C=%d nslab=%d", p.M, p.C, p.nslab);
+    if ((p.ldx % 8) || (p.lddy32 % 4) || (p.lddx % 8) || (p.dres && (p.lddres % 8)) || ((uintptr_t)p.dy32 & 15)) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_layernorm_bwd_slabs_pair: alignment");
+  }
+  const int ma = (pa->M + 3) / 4, mb = (pb->M + 3) / 4;
+  hipLaunchKernelGGL(ln_bwd_slabs_pair_kernel, dim3(ma > mb ? ma : mb, 2), dim3(256), 0, (hipStream_t)stream, *pa, *pb);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }

@@ -24,6 +24,7 @@
 //   * bias, residual, the MLP activation as a second output (act = 1 quick_gelu, 2 gelu) or its derivative as a factor (Z given).
 // Measured (tools/strip_probe.py, weights rotating through HBM): 1280 x 1280 5.3 us (tiled 9.9), 3840 x 1280 + LayerNorm 8.0 (13.7),
 // 5120 x 1280 + LayerNorm + gelu 10.8 (15.7), 1280 x 5120 13.0 (15.1), 768 x 768 3.7 (7.9).
+#include <cstdlib>
 #include "common.h"
 #include "../../include/sdlt_kernels.h"
 
@@ -50,19 +51,19 @@ __device__ __forceinline__ float dact_f(int act, float x) {
 }
 
 // J: 16-column blocks per workgroup; LN: LayerNorm folded in front; R: ring slots per wave (R - 1 K steps of DMA in flight)
+// (bx, by, gx: this workgroup's place in ITS problem's grid - blockIdx / gridDim of a single launch, a share of the grid of a paired one)
 template <int J, bool LN, int R>
-__global__ __launch_bounds__(64 * NW) void strip_kernel(const sdlt_strip_params p) {
+__device__ __forceinline__ void strip_body(const sdlt_strip_params& p, char* smem, const int bx, const int by, const int gx) {
   constexpr int SROWS = XROWS + 16 * J, SLOT = SROWS * ROWB;          // a ring slot: 80 activation rows + 16 J weight rows of one K step
   constexpr int PIECES = SROWS / 8;                                   // DMA instructions per step (8 rows x 128 B each)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
   // split-K (p.splitk = S > 1): S neighbouring workgroups share a strip, each walks K / S columns; the last one to arrive adds the S
   // partial tiles in split order and runs the epilogue (fixed order: bitwise reproducible)
   const int S = p.splitk > 1 ? p.splitk : 1;
-  const int strip = S == 1 ? (int)blockIdx.x : (int)blockIdx.x / S, split = S == 1 ? 0 : (int)blockIdx.x - strip * S;
+  const int strip = S == 1 ? bx : bx / S, split = S == 1 ? 0 : bx - strip * S;
   const int n0 = strip * (16 * J);
-  const int64_t row0 = (int64_t)blockIdx.y * p.Tp;
+  const int64_t row0 = (int64_t)by * p.Tp;
   // 64-column steps of THIS wave: the K / 256 steps are dealt out to the splits as evenly as they go (the first `rem` splits take one more)
   const int tsteps = p.K >> 8, sbase = tsteps / S, srem = tsteps - sbase * S;
   const int nsteps = sbase + (split < srem ? 1 : 0);
@@ -224,8 +225,8 @@ __global__ __launch_bounds__(64 * NW) void strip_kernel(const sdlt_strip_params 
     // slabs: [batch][strip][split][unit][lane] f32x4 (+ float2 statistics behind them); hand-off as MI355X_MICROARCH.md prescribes:
     // write-through (sc1) stores -> every wave drains them -> barrier -> ticket; the last arriver: ONE agent-scope acquire, plain loads
     constexpr int UB = UNITS * 64 * (LN ? 24 : 16);
-    const int nstrips = (int)gridDim.x / S;
-    char* slab0 = (char*)p.ws + ((size_t)((int)blockIdx.y * nstrips + strip) * S) * UB;
+    const int nstrips = gx / S;
+    char* slab0 = (char*)p.ws + ((size_t)(by * nstrips + strip) * S) * UB;
     char* mine = slab0 + (size_t)split * UB;
 #pragma unroll
     for (int q = 0; q < UPW; ++q) {
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(64 * NW) void strip_kernel(const sdlt_strip_params 
     __syncthreads();
     int* flag = (int*)smem;                 // (the reduction scratch is dead: `part` holds what this workgroup needs of it)
     if (threadIdx.x == 0) {
-      int* cnt = p.cnt + (int)blockIdx.y * nstrips + strip;
+      int* cnt = p.cnt + by * nstrips + strip;
       const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (ticket == S - 1) {
         __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
@@ -306,6 +307,25 @@ __global__ __launch_bounds__(64 * NW) void strip_kernel(const sdlt_strip_params 
 }
 
 template <int J, bool LN, int R>
+__global__ __launch_bounds__(64 * NW) void strip_kernel(const sdlt_strip_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  strip_body<J, LN, R>(p, smem, blockIdx.x, blockIdx.y, gridDim.x);
+}
+// Two independent problems of the same kernel variant in ONE launch (blockIdx.z picks the problem): layer i of CLIP-L rides along layer i of
+// OpenCLIP-bigG - each is a chain of launch-bound 77-row products, neither fills the chip, and a launch costs more than CLIP-L's share of it.
+template <int J, bool LN, int R>
+__global__ __launch_bounds__(64 * NW) void strip_pair_kernel(const sdlt_strip_params p0, const sdlt_strip_params p1) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (blockIdx.z == 0) {
+    const int gx = (p0.N / (16 * J)) * (p0.splitk > 1 ? p0.splitk : 1);
+    if ((int)blockIdx.x < gx && (int)blockIdx.y < p0.B) strip_body<J, LN, R>(p0, smem, blockIdx.x, blockIdx.y, gx);
+  } else {
+    const int gx = (p1.N / (16 * J)) * (p1.splitk > 1 ? p1.splitk : 1);
+    if ((int)blockIdx.x < gx && (int)blockIdx.y < p1.B) strip_body<J, LN, R>(p1, smem, blockIdx.x, blockIdx.y, gx);
+  }
+}
+
+template <int J, bool LN, int R>
 int launch_strip(const sdlt_strip_params& p, hipStream_t s) {
   constexpr int SLOT = (XROWS + 16 * J) * ROWB;
   const int smem = NW * R * SLOT;          // >= the reduction scratch NW * MB * J * 64 * 16 + statistics
@@ -327,10 +347,32 @@ int launch_strip(const sdlt_strip_params& p, hipStream_t s) {
   return SDLT_OK;
 }
 
-}  // namespace
+template <int J, bool LN, int R>
+int launch_strip_pair(const sdlt_strip_params& a, const sdlt_strip_params& b, hipStream_t s) {
+  constexpr int SLOT = (XROWS + 16 * J) * ROWB;
+  const int smem = NW * R * SLOT;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)strip_pair_kernel<J, LN, R>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  const int ga = (a.N / (16 * J)) * (a.splitk > 1 ? a.splitk : 1), gb = (b.N / (16 * J)) * (b.splitk > 1 ? b.splitk : 1);
+  hipLaunchKernelGGL((strip_pair_kernel<J, LN, R>), dim3(ga > gb ? ga : gb, a.B > b.B ? a.B : b.B, 2), dim3(64 * NW), smem, s, a, b);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
 
-extern "C" int sdlt_strip_gemm(const sdlt_strip_params* pp, void* stream) {
-  const sdlt_strip_params& p = *pp;
+// 32-column strips for the q|k|v- and mlp-wide products (N >= 2304; SDLT_STRIP_WIDE_MIN for A/B): 16-column ones would exceed one wave of
+// workgroups at 5120, and the two text encoders' launches pair only when both take the same width - q|k|v 2304 / 32 + 3840 / 32 = 192
+// workgroups, fc1 3072 / 32 + 5120 / 32 = 256.  Whole step: 2304 -> 44.9 ms, 3072 -> 45.0, 4096 (the rule before pairing) -> 45.1; SD1.5
+// 24.83 / 24.85 / 24.99.  The strip width fixes the order of the fp32 K summation, so single and paired launches agree bit for bit only
+// because both use this one rule.
+bool strip_wide(int N) {
+  static const int wmin = getenv("SDLT_STRIP_WIDE_MIN") ? atoi(getenv("SDLT_STRIP_WIDE_MIN")) : 2304;
+  return N >= wmin && (N % 32) == 0;
+}
+
+int strip_check(const sdlt_strip_params& p) {
   const int S_ = p.splitk > 1 ? p.splitk : 1;
   if (p.B <= 0 || p.T <= 0 || p.T > 16 * MB || p.Tp < 16 * MB || p.N <= 0 || (p.N % 16) || p.K <= 0 || (p.K % 256) || S_ > 16 || S_ > (p.K >> 8))
     SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_strip_gemm: B=%d T=%d Tp=%d N=%d K=%d (T <= 80 <= Tp, N %% 16 == 0, K %% 256 == 0)", p.B, p.T, p.Tp, p.N, p.K);
@@ -342,8 +384,35 @@ extern "C" int sdlt_strip_gemm(const sdlt_strip_params* pp, void* stream) {
   if ((p.Y2 || p.Z) && p.act != 1 && p.act != 2) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_strip_gemm: act %d", p.act);
   if (p.ln && (!p.c1 || !p.c2 || ((uintptr_t)p.c1 & 15) || ((uintptr_t)p.c2 & 15))) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_strip_gemm: ln needs c1 / c2");
   if (!p.ln && p.bias && ((uintptr_t)p.bias & 15)) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_strip_gemm: bias alignment");
+  return SDLT_OK;
+}
+
+}  // namespace
+
+extern "C" int sdlt_strip_gemm(const sdlt_strip_params* pp, void* stream) {
+  const sdlt_strip_params& p = *pp;
+  const int rc = strip_check(p);
+  if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  const bool wide = p.N >= 4096 && (p.N % 32) == 0;       // 32-column strips where 16-column ones would exceed one wave of workgroups
+  const bool wide = strip_wide(p.N);
   if (p.ln) return wide ? launch_strip<2, true, 2>(p, s) : launch_strip<1, true, 3>(p, s);
   return wide ? launch_strip<2, false, 2>(p, s) : launch_strip<1, false, 3>(p, s);
+}
+
+// reference: none (launch structure only) - see strip_pair_kernel.  Both problems must ask for the same kernel variant (LayerNorm fold or
+// not, strip width) and neither may use the in-kernel K split
+// (its workspace is one per stream).
+extern "C" int sdlt_strip_gemm_pair(const sdlt_strip_params* pa, const sdlt_strip_params* pb, void* stream) {
+  const sdlt_strip_params &a = *pa, &b = *pb;
+  int rc = strip_check(a);
+  if (rc) return rc;
+  rc = strip_check(b);
+  if (rc) return rc;
+  if ((a.ln != 0) != (b.ln != 0)) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_strip_gemm_pair: one problem folds a LayerNorm, the other does not");
+  if ((a.splitk > 1 && !a.P) || (b.splitk > 1 && !b.P)) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_strip_gemm_pair: in-kernel K split");
+  hipStream_t s = (hipStream_t)stream;
+  if (strip_wide(a.N) != strip_wide(b.N)) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_strip_gemm_pair: N = %d and N = %d want different strip widths", a.N, b.N);
+  const bool wide = strip_wide(a.N);
+  if (a.ln) return wide ? launch_strip_pair<2, true, 2>(a, b, s) : launch_strip_pair<1, true, 3>(a, b, s);
+  return wide ? launch_strip_pair<2, false, 2>(a, b, s) : launch_strip_pair<1, false, 3>(a, b, s);
 }

@@ -293,6 +293,121 @@ def strip_partial_splits(N, K, B):
     return s
 
 
+# ---- paired launches (sdlt_*_pair): two independent chains of the same kernels - the two text encoders of SDXL - issued in lockstep.
+# Inside `with pairing() as pq:` the four pairable ops below do not launch: they leave ONE pending (kind, params) record per call in pq;
+# the driver (step.TextStack) advances chain a by one op, chain b by one op, then calls pq.flush(), which launches the two records as one
+# paired launch when the C side takes the combination and as two single launches otherwise.
+STRIP_WIDE_MIN = int(os.environ.get("SDLT_STRIP_WIDE_MIN", "2304"))
+
+
+class _PairQueue:
+    def __init__(self):
+        self.pending = []
+        self.launches = 0
+
+    def take(self):
+        """The records left since the last take() (the ops of the chain that was just advanced)."""
+        rec, self.pending = self.pending, []
+        return rec
+
+    def launch(self, recs):
+        """One paired launch when `recs` is two records of one kind the C side takes together, else one single launch per record."""
+        lib, st = _lib.load(), _stream()
+        if len(recs) == 2 and recs[0][0] == recs[1][0] and _pair_ok(lib, recs[0], recs[1]):
+            kind = recs[0][0]
+            _lib.check(getattr(lib, _PAIR_FN[kind])(C.byref(recs[0][1]), C.byref(recs[1][1]), st), _PAIR_FN[kind])
+            self.launches += 1
+            return
+        for kind, p, _ in recs:
+            _launch_single(lib, kind, p, st)
+            self.launches += 1
+
+    def flush(self):
+        self.launch(self.take())
+
+
+def run_paired(gens, prefer):
+    """Drive two generators (each yields a key after every pairable op it issued, other work runs inline) in lockstep: ops with equal keys
+    go out as one paired launch; with unequal keys the chain `prefer(key_a, key_b)` names goes first alone.  Returns the generators' values."""
+    vals, keys, pend, done = [None, None], [None, None], [None, None], [False, False]
+    with pairing() as pq:
+        while True:
+            for i in (0, 1):
+                if not done[i] and pend[i] is None:
+                    try:
+                        keys[i] = next(gens[i])
+                    except StopIteration as e:
+                        vals[i], done[i] = e.value, True
+                    rec = pq.take()
+                    if len(rec) > 1 or (done[i] and rec):      # a chain must yield after every pairable op
+                        pq.launch(rec)
+                        raise AssertionError("run_paired: a chain issued a pairable op without yielding")
+                    pend[i] = rec[0] if rec else None
+            if pend[0] is not None and pend[1] is not None:
+                if keys[0] == keys[1]:
+                    pq.launch([pend[0], pend[1]])
+                    pend = [None, None]
+                else:
+                    i = 0 if prefer(keys[0], keys[1]) == keys[0] else 1
+                    pq.launch([pend[i]])
+                    pend[i] = None
+            elif pend[0] is not None or pend[1] is not None:
+                i = 0 if pend[0] is not None else 1
+                pq.launch([pend[i]])
+                pend[i] = None
+            elif done[0] and done[1]:
+                return vals
+
+
+_PAIR_FN = {"strip": "sdlt_strip_gemm_pair", "attn_fwd": "sdlt_attn_fwd_pair", "attn_bwd": "sdlt_attn_bwd_pair", "ln_slabs": "sdlt_layernorm_bwd_slabs_pair"}
+_pair_queue = None
+
+
+class pairing:
+    def __enter__(self):
+        global _pair_queue
+        assert _pair_queue is None
+        _pair_queue = _PairQueue()
+        return _pair_queue
+
+    def __exit__(self, *exc):
+        global _pair_queue
+        q, _pair_queue = _pair_queue, None
+        if exc[0] is None:
+            q.flush()
+        return False
+
+
+def _pair_ok(lib, a, b):
+    kind, pa, pb = a[0], a[1], b[1]
+    if kind == "strip":
+        wide = lambda n: n >= STRIP_WIDE_MIN and n % 32 == 0  # noqa: E731  (strip.hip strip_wide)
+        return bool(pa.ln) == bool(pb.ln) and wide(pa.N) == wide(pb.N) and not (pa.splitk > 1 and not pa.P) and not (pb.splitk > 1 and not pb.P)
+    if kind in ("attn_fwd", "attn_bwd"):
+        return bool(lib.sdlt_attn_pair_ok(C.byref(pa), C.byref(pb)))
+    return True
+
+
+def _launch_single(lib, kind, p, st):
+    if kind == "strip":
+        _lib.check(lib.sdlt_strip_gemm(C.byref(p), st), "sdlt_strip_gemm")
+    elif kind == "attn_fwd":
+        _lib.check(lib.sdlt_attn_fwd(C.byref(p), st), "sdlt_attn_fwd")
+    elif kind == "attn_bwd":
+        _lib.check(lib.sdlt_attn_bwd(C.byref(p), st), "sdlt_attn_bwd")
+    else:
+        _lib.check(lib.sdlt_layernorm_bwd_slabs(p.x, p.ldx, p.dy32, p.lddy32, p.nslab, p.M, p.C, p.gamma, p.stats, p.dres, p.lddres, p.dx, p.lddx, st),
+                   "sdlt_layernorm_bwd_slabs")
+
+
+def _issue(kind, p, keep=None):
+    """Launch now, or leave the record with the active pairing queue (keep: tensors the record's pointers refer to)."""
+    if _pair_queue is not None:
+        _pair_queue.pending.append((kind, p, keep))
+    else:
+        _launch_single(_lib.load(), kind, p, _stream())
+
+
 def strip_gemm(X, W, out, *, B, T, Tp, bias=None, residual=None, act_out=None, dact_in=None, ln=None, stats=None, splitk=None, partial=None):
     """Row-strip product of the text encoders (sdlt_strip_gemm): out[b*Tp + t] = X[b*Tp + t] . W^T for the t < T valid rows of every batch
     element; rows t >= T of `out` are left untouched.  W [N, K], K % 256 == 0.
@@ -311,7 +426,7 @@ def strip_gemm(X, W, out, *, B, T, Tp, bias=None, residual=None, act_out=None, d
         assert out is None and bias is None and residual is None and act_out is None and dact_in is None and ln is None
         assert partial.is_cuda and partial.dtype == F32 and partial.is_contiguous() and tuple(partial.shape[1:]) == (B * Tp, N)
         p.P, p.ldp, p.splitk = _p(partial), N, partial.shape[0]
-        _lib.check(lib.sdlt_strip_gemm(C.byref(p), _stream()), "sdlt_strip_gemm")
+        _issue("strip", p)
         return partial
     _chk2(out)
     assert tuple(out.shape) == (B * Tp, N), (out.shape, W.shape)
@@ -347,7 +462,7 @@ def strip_gemm(X, W, out, *, B, T, Tp, bias=None, residual=None, act_out=None, d
     if S > 1:
         slab, cnt = splitk_workspace(X.device)
         p.splitk, p.ws, p.ws_bytes, p.cnt, p.cnt_len = S, _p(slab), slab.numel(), _p(cnt), cnt.numel()
-    _lib.check(lib.sdlt_strip_gemm(C.byref(p), _stream()), "sdlt_strip_gemm")
+    _issue("strip", p)
     return out
 
 
@@ -506,7 +621,7 @@ def attn_fwd(Q, K, V, Vt, O, L, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=Fals
     p = _attn_params(Q, K, V, B=B, H=H, Nq=Nq, Nk=Nk, Nqp=Nqp, Nkp=Nkp, d=d, scale=scale, causal=causal)
     _chk2(O), _chk2(L, F32)      # Vt is accepted for call compatibility and ignored: the kernel transposes V tiles in LDS
     p.O, p.ldo, p.L = _p(O), _ld(O), _p(L)
-    _lib.check(lib.sdlt_attn_fwd(C.byref(p), _stream()), "sdlt_attn_fwd")
+    _issue("attn_fwd", p)
     return O
 
 
@@ -529,7 +644,7 @@ def attn_bwd(Q, K, V, Kt, Qt, O, L, dO, dOt, D, dQ, dK, dV, *, B, H, Nq, Nk, Nqp
         if not causal and Nkp <= 128 and d <= 96:   # single-pass cross-attention kernel: one partial slab per query split
             assert dK32.shape[0] >= qsplit * B * Nkp and dV32.shape[0] >= qsplit * B * Nkp, "dK32/dV32 must hold qsplit slabs"
         p.dK32, p.dV32, p.ld32 = _p(dK32), _p(dV32), _ld(dK32)
-    _lib.check(lib.sdlt_attn_bwd(C.byref(p), _stream()), "sdlt_attn_bwd")
+    _issue("attn_bwd", p)
 
 
 class SplitsumPlan:
@@ -727,8 +842,10 @@ def layernorm_bwd(x, dy, dx, stats, *, gamma, dres=None, dy_slabs=None):
     if dy_slabs is not None:
         assert dy is None and dy_slabs.dtype == F32 and dy_slabs.is_contiguous() and tuple(dy_slabs.shape[1:]) == (M, Cc)
         _chk2(x), _chk2(dx), _chk2(stats, F32), _chk2(gamma, F32)
-        _lib.check(lib.sdlt_layernorm_bwd_slabs(_p(x), _ld(x), _p(dy_slabs), Cc, dy_slabs.shape[0], M, Cc, _p(gamma), _p(stats), _p(dres),
-                                                _ld(dres) if dres is not None else 0, _p(dx), _ld(dx), _stream()), "sdlt_layernorm_bwd_slabs")
+        q = _lib.LnSlabsParams()
+        q.x, q.ldx, q.dy32, q.lddy32, q.nslab, q.M, q.C = _p(x), _ld(x), _p(dy_slabs), Cc, dy_slabs.shape[0], M, Cc
+        q.gamma, q.stats, q.dres, q.lddres, q.dx, q.lddx = _p(gamma), _p(stats), _p(dres), _ld(dres) if dres is not None else 0, _p(dx), _ld(dx)
+        _issue("ln_slabs", q)
         return dx
     _chk2(x), _chk2(dy), _chk2(dx), _chk2(stats, F32), _chk2(gamma, F32)
     _lib.check(lib.sdlt_layernorm_bwd(_p(x), _ld(x), _p(dy), _ld(dy), M, Cc, _p(gamma), _p(stats), _p(dres),

@@ -5,6 +5,7 @@ once into a hipGraph (torch.cuda.CUDAGraph is hipGraph on ROCm) and replayed; pe
 rates, bias corrections) live in a small device buffer that is updated before each replay.
 """
 import math
+import os
 
 import torch
 
@@ -14,6 +15,9 @@ from .ti import TiState
 from .unet import CTX_PAD, F32, Runtime, UNet
 
 assert TP == CTX_PAD
+
+
+TEXT_PAIR = os.environ.get("SDLT_TEXT_PAIR", "1") != "0"
 
 
 class TextStack:
@@ -36,6 +40,9 @@ class TextStack:
         # (2.6 ms, mostly hidden) saves - so the default is one stream, one graph.
         self.concurrent = bool(concurrent) and torch.device(rt.device).type == "cuda"
         self.side = [torch.cuda.Stream(device=rt.device) for _ in encoders] if self.concurrent else []
+        # two fused encoders (SDXL): layer i of CLIP-L rides in the launches of layer i of bigG (ops.run_paired; SDLT_TEXT_PAIR=0: one after the other)
+        self.paired = (TEXT_PAIR and len(encoders) == 2 and all(getattr(e, "fused", False) for e in encoders) and not self.concurrent
+                       and torch.device(rt.device).type == "cuda")
 
     def set_ids(self, ids_per_encoder):
         for dst, src in zip(self.ids, ids_per_encoder):
@@ -68,6 +75,16 @@ class TextStack:
 
     def forward(self, ctx):
         out = [None] * len(self.encoders)
+        if self.paired:
+            gens, off = [], 0
+            for e, ids, w in zip(self.encoders, self.ids, self.widths):
+                gens.append(e.forward_steps(ids, self.rt.B, hidden_out=ctx[:, off:off + w], pool_rows=self.pool_rows))
+                off += w
+            vals = self.rt.ops.run_paired(gens, min)          # both start at layer 0: in lockstep until the shorter encoder is done
+            pooled = None
+            for _, p in vals:
+                pooled = p if p is not None else pooled
+            return pooled
         jobs, off = [], 0
         for i, (e, ids, w) in enumerate(zip(self.encoders, self.ids, self.widths)):
             def job(i=i, e=e, ids=ids, off=off, w=w):
@@ -82,12 +99,19 @@ class TextStack:
 
     def backward(self, dctx, d_pooled, grad_rows):
         jobs, off = [], 0
-        for e, w, g in zip(self.encoders, self.widths, grad_rows):
-            def job(e=e, off=off, w=w, g=g):
-                e.backward(dctx[:, off:off + w], d_pooled if e.with_projection else None, g)
-            jobs.append(job)
-            off += w
-        self._fan_out(jobs)
+        if self.paired:
+            gens = []
+            for e, w, g in zip(self.encoders, self.widths, grad_rows):
+                gens.append(e.backward_steps(dctx[:, off:off + w], d_pooled if e.with_projection else None, g))
+                off += w
+            self.rt.ops.run_paired(gens, max)                 # the deeper encoder runs alone down to the other's top layer, then in lockstep
+        else:
+            for e, w, g in zip(self.encoders, self.widths, grad_rows):
+                def job(e=e, off=off, w=w, g=g):
+                    e.backward(dctx[:, off:off + w], d_pooled if e.with_projection else None, g)
+                jobs.append(job)
+                off += w
+            self._fan_out(jobs)
         if self.arena is not None:                     # dA / dB of every text-encoder adapter in one grouped launch
             if self._grad_plan is None:
                 self._grad_plan = self.rt.ops.LoraGradPlan(self.arena.problems, self.arena.Rp, self.rt.device)

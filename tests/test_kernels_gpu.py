@@ -1093,3 +1093,77 @@ def test_token_attention_loss_fused(ops, B, sizes, ratio, has):
             assert err <= 1.5e-2 * float(b_.abs().max()) + 1e-12, f"{nm} N={N}: {err} vs {float(b_.abs().max())}"
     if not any(has):
         assert l1 == 0.0 and all(float(a.abs().max()) == 0.0 for a, _ in g1.values())
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_text_encoders_paired_launches_bitwise(B):
+    """sdlt_*_pair (strip GEMM, attention forward / backward, slab LayerNorm backward): the two SDXL text encoders issued in lockstep
+    (ops.run_paired - layer i of the 768-wide / 12-head encoder in the launches of layer i of the 1280-wide / 20-head one, quick-GELU vs GELU,
+    16- vs 32-column strips on fc1) give the bits of the one-after-the-other launches, forward and backward."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import bench as B_
+    import sd_lora_trainer_amd.clip as CL
+    import sd_lora_trainer_amd.unet as M
+    from sd_lora_trainer_amd import ops
+    dev = torch.device("cuda", 0)
+    rt = M.Runtime(dev, B)
+    cfgs = [dict(vocab=600, width=768, layers=3, heads=12, mlp=3072, act="quick_gelu", proj=None),
+            dict(vocab=600, width=1280, layers=5, heads=20, mlp=5120, act="gelu", proj=1280)]
+    encs = []
+    for i, c in enumerate(cfgs):
+        sd = B_.make_clip_state(c, dev, seed=40 + i, n_new=3)
+        encs.append(CL.ClipTextEncoder(rt, f"pe{i}", sd, heads=c["heads"], act=c["act"], mode="penultimate", with_projection=bool(c["proj"]), n_train=3))
+        assert encs[-1].fused
+    g = torch.Generator(device=dev).manual_seed(5)
+    ids = [torch.randint(0, 600, (B, CL.T_TOKENS), generator=g, device=dev) for _ in encs]
+    for t in ids:
+        t[:, 1:4] = torch.arange(600, 603, device=dev)          # the trained rows
+    pool = torch.arange(B, device=dev) * CL.TP + 7
+    W = [c["width"] for c in cfgs]
+
+    def run(paired):
+        ctx = torch.zeros(B * CL.TP, sum(W), dtype=rt.act, device=dev)
+        fw = [e.forward_steps(i_, B, hidden_out=ctx[:, o:o + w], pool_rows=pool) for e, i_, o, w in zip(encs, ids, (0, W[0]), W)]
+        vals = ops.run_paired(fw, min) if paired else [CL._drain(f) for f in fw]
+        pooled = vals[1][1].clone()
+        gg = torch.Generator(device=dev).manual_seed(6)
+        dctx = (torch.randn(B * CL.TP, sum(W), generator=gg, device=dev) * 0.1).to(rt.act)
+        dctx.view(B, CL.TP, -1)[:, CL.T_TOKENS:] = 0
+        dpool = (torch.randn(B, 1280, generator=gg, device=dev) * 0.1).to(rt.act)
+        grads = [torch.zeros(3, w, device=dev) for w in W]
+        bw = [e.backward_steps(dctx[:, o:o + w], dpool if e.with_projection else None, g_) for e, o, w, g_ in zip(encs, (0, W[0]), W, grads)]
+        if paired:
+            ops.run_paired(bw, max)
+        else:
+            [CL._drain(b) for b in bw]
+        torch.cuda.synchronize()
+        return ctx.clone(), pooled, [g_.clone() for g_ in grads]
+
+    ref = run(False)
+    got = run(True)
+    assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
+    for a, b in zip(ref[2], got[2]):
+        assert torch.equal(a, b) and float(a.abs().max()) > 0
+    # and the launch count: every op of the shorter encoder rode along
+    with ops.pairing() as pq:
+        pass
+    fw = [e.forward_steps(i_, B, hidden_out=torch.zeros(B * CL.TP, w, dtype=rt.act, device=dev), pool_rows=pool) for e, i_, w in zip(encs, ids, W)]
+    n0 = _count_paired(ops, fw, min)
+    assert n0 == 5 * max(e.n_run for e in encs), n0
+
+
+def _count_paired(ops, gens, prefer):
+    """Launches ops.run_paired issues for two chains (pairable ops only)."""
+    orig = ops._PairQueue.launch
+    n = [0]
+
+    def counting(self, recs):
+        n[0] += 1 if (len(recs) == 2 and recs[0][0] == recs[1][0] and ops._pair_ok(ops._lib.load(), recs[0], recs[1])) else len(recs)
+        return orig(self, recs)
+    ops._PairQueue.launch = counting
+    try:
+        ops.run_paired(gens, prefer)
+    finally:
+        ops._PairQueue.launch = orig
+    return n[0]
