@@ -19,7 +19,7 @@ def clean(k):
 def family(k):
     if k.startswith(("gemm_kernel", "wsk_kernel")):
         return "gemm"
-    if k.startswith("strip_kernel"):
+    if k.startswith("strip_"):        # strip_kernel and strip_pair_kernel
         return "text_gemm"
     if k.startswith("attn"):
         return "attention"
