@@ -42,8 +42,27 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 
 // EPI: the fused epilogue (sdlt_gemm_params.epi_op) as a TEMPLATE parameter - with a run-time switch the GEGLU / activation code sat
 // in every instantiation and the whole GEMM family ran ~6 % slower (code size; the step alternates between ~60 kernels).
+// a / b for 0 <= a < 2^22, 0 < b: reciprocal multiply + one correction step (~8 instructions; the ISA has no integer divide and the
+// compiler's expansion is ~40 dependent instructions - the kernel's prologue did five of them before its first load was issued)
+__device__ __forceinline__ int div_small(int a, int b) {
+  int q = (int)((float)a * __builtin_amdgcn_rcpf((float)b));
+  const int r = a - q * b;
+  q += (r >= b ? 1 : 0) - (r < 0 ? 1 : 0);
+  return q;
+}
+__device__ __forceinline__ int div_small_u(int a, int b) { return __builtin_amdgcn_readfirstlane(div_small(a, b)); }   // wave-uniform operands
+
+// -DSDLT_GEMM_TRACE (tools/gemm_trace.py): thread 0 of workgroup 0 stamps clock64() at the phase boundaries; sdlt_gemm_trace_read copies them out
+#ifdef SDLT_GEMM_TRACE
+__device__ long long g_gemm_tr[16];
+#define GTR(i_) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_gemm_tr[i_] = clock64(); } while (0)
+#else
+#define GTR(i_) do {} while (0)
+#endif
+
 template <int MI, int NI, int WN, int MODE, int R16, int NSTAGE, int KG = 0, int BT = 0, int WM = 2, int EPI = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_params p) {
+  GTR(0);
   // batched launch: blockIdx.y picks the problem; its operand pointers replace the launch-wide ones (wave-uniform scalar loads)
   // (BT is a template switch so that ordinary launches do not pay the extra kernarg loads and selects in their prologue)
   const sdlt_gemm_batch_item* bi = BT ? p.batch + blockIdx.y : nullptr;
@@ -82,7 +101,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
   }
   const int splitk = p.splitk > 1 ? p.splitk : 1;
   // (integer divisions are ~40 scalar instructions each on this ISA: the common no-split case skips them)
-  const int tile_id = splitk == 1 ? bid : bid / splitk, split = splitk == 1 ? 0 : bid - tile_id * splitk;   // splits of one tile are neighbours -> same XCD
+  const int tile_id = splitk == 1 ? bid : div_small_u(bid, splitk), split = splitk == 1 ? 0 : bid - tile_id * splitk;   // splits of one tile are neighbours -> same XCD
   // Grouped rasterisation inside each XCD's contiguous chunk of tiles: walk GROUP_M row-tiles before moving to the next
   // column-tile, so the ~32 workgroups an XCD runs concurrently form a compact super-tile (they share X panels AND W
   // panels in that XCD's 4 MB L2 instead of streaming every W panel once per row of tiles).
@@ -92,20 +111,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
     // g_n W panels.  A fixed 8 made every XCD stream ALL of X when M is 8 row-tiles (1024 x 1280 x 5120 split 3: 97 MB of L2
     // misses for 23.6 MB of operands).
     const int per_xcd = (nbm * nbn + 7) >> 3;
-    int live = 32 / splitk;                          // tiles of the ~32 workgroups an XCD runs concurrently
+    int live = splitk == 1 ? 32 : div_small_u(32, splitk);                          // tiles of the ~32 workgroups an XCD runs concurrently
     live = live < 1 ? 1 : live;
     live = per_xcd < live ? per_xcd : live;
     int GROUP_M = (int)(sqrtf((float)live * BN / BM) + 0.5f);
     GROUP_M = GROUP_M < 1 ? 1 : (GROUP_M > nbm ? nbm : GROUP_M);
     const int per_group = GROUP_M * nbn;
-    const int grp = tile_id / per_group, first_m = grp * GROUP_M;
+    const int grp = div_small_u(tile_id, per_group), first_m = grp * GROUP_M;
     const int gsz = nbm - first_m < GROUP_M ? nbm - first_m : GROUP_M;
     const int in_grp = tile_id - grp * per_group;
-    bm = first_m + in_grp % gsz;
-    bn = in_grp / gsz;
+    bn = div_small_u(in_grp, gsz);
+    bm = first_m + in_grp - bn * gsz;
   }
   const int m0 = bm * BM, n0 = bn * BN;
 
+  GTR(12);
   // ---------------- per-lane staging geometry (fixed rows, fixed swizzled chunk) ----------------
   const int srow = lane >> 3;                       // row within an 8-row DMA piece
   const int schunk = (lane & 7) ^ (srow & 7);       // source chunk so that LDS holds chunk^(row&7)
@@ -126,9 +146,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
     } else {
       if (m < p.M) {
         int hw = p.Hout * p.Wout;
-        xb[i] = m / hw;
+        xb[i] = div_small(m, hw);
         int rem = m - xb[i] * hw;
-        xh[i] = rem / p.Wout;
+        xh[i] = div_small(rem, p.Wout);
         xw[i] = rem - xh[i] * p.Wout;
       } else {
         xb[i] = -1; xh[i] = xw[i] = 0;
@@ -170,7 +190,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
     aptr = (const bf16_t*)pAdown + schunk * 8;
   }
   // grouped adapters (fused projections): this tile's column group selects the Adown rows and the T_out columns
-  const int lgrp = (R16 && p.lora_group_n > 0) ? n0 / p.lora_group_n : 0;
+  const int lgrp = (R16 && p.lora_group_n > 0) ? div_small_u(n0, p.lora_group_n) : 0;
   const bool t_writer = R16 && (p.lora_group_n > 0 ? n0 == lgrp * p.lora_group_n : bn == 0);
   if (R16) aptr += (size_t)lgrp * (R16 * 16) * p.ld_adown;
 
@@ -194,12 +214,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
   };
 
   // this workgroup's share of the K steps (split-K: contiguous ranges of the combined segment-1 + segment-2 steps)
-  const int kbeg = splitk == 1 ? 0 : nk * split / splitk, kend = splitk == 1 ? nk : nk * (split + 1) / splitk;   // 32-bit: nk < 2^15
+  const int kbeg = splitk == 1 ? 0 : div_small_u(nk * split, splitk), kend = splitk == 1 ? nk : div_small_u(nk * (split + 1), splitk);   // 32-bit: nk < 2^15
 
   // implicit-GEMM conv: tap / channel offset of the NEXT stage to be issued (stages are issued strictly in K order from kbeg)
   int cv_tap = 0, cv_ci0 = 0;
   if (MODE == 1) {
-    cv_tap = (kbeg * BK) / p.Cin;
+    cv_tap = kbeg == 0 ? 0 : div_small_u(kbeg * BK, p.Cin);
     cv_ci0 = kbeg * BK - cv_tap * p.Cin;
   }
   // Enumerates the 8-row x 128-byte pieces this wave moves for K-step kt: f(j, src, lds_off) with j in [0, LPS).
@@ -279,15 +299,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
 #endif
   };
 
+  GTR(13);
+  // the first K step's DMA goes out as soon as its addresses exist (clock stamps, tools/gemm_trace.py: the ~600 instructions of index
+  // math, staging geometry and epilogue prefetch in front of it were 1.5 us of every launch with no load in flight)
+  if (S > 1 && kbeg < kend) stage(kbeg, 0);
   // ---------------- epilogue operands, fetched BEFORE the K loop ----------------
   // LoRA-up fragments, bias and (staged epilogue) the residual tile used to be loaded where they are consumed: three dependent
   // global-load latencies after the last MFMA of every launch (~1 us each; the K loop of a 1024 x 1280 x 1280 projection is
-  // ~7 us).  They are issued here instead - older than every DMA stage, so the counted vmcnt waits of the ring still hold
-  // (loads retire in order) - and are long complete when the loop ends.
+  // ~7 us).  They are issued here instead - right behind the first DMA stage and older than every other one, so the counted vmcnt
+  // waits of the ring still hold (loads retire in order: "stage kt landed" only ever waits for MORE than it names) - and are long
+  // complete when the loop ends.
   constexpr int NUPMAX = KG ? KG * R16 : (R16 ? R16 : 1);
   s16x4 bupf[NUPMAX][NI];
   if (R16) {
-    const int nup_ = KG ? (p.K / p.lora_group_k) * R16 : R16;
+    const int nup_ = KG ? div_small_u(p.K, p.lora_group_k) * R16 : R16;
 #pragma unroll
     for (int j = 0; j < NUPMAX; ++j)
 #pragma unroll
@@ -338,6 +363,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
     }
   }
 
+  GTR(14);
   // ---------------- accumulators ----------------
   f32x4 acc[NI][MI];
 #pragma unroll
@@ -429,15 +455,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
     }
   } else {
   // prologue: S-1 stages in flight
+  GTR(1);
 #pragma unroll
-  for (int t = 0; t < S - 1; ++t)
+  for (int t = 1; t < S - 1; ++t)          // (stage kbeg went out in front of the epilogue prefetch)
     if (kbeg + t < kend) stage(kbeg + t, t);
+  GTR(2);
   const bool early = NW <= 4 || wave < NW / 2;
   auto kg_flush = [&](int kt) {
     if constexpr (KG > 0) {
       const int gsteps = p.lora_group_k / BK;
-      if (splitk == 1 && (kt + 1) % gsteps == 0) {   // last K-step of adapter group g (under split-K a split IS a group, see the
-        const int grp = kt / gsteps;                 // reduction): park s*T_g in its Tsh columns and restart the accumulator
+      const int grp = div_small_u(kt, gsteps);
+      if (splitk == 1 && kt + 1 == (grp + 1) * gsteps) {   // last K-step of adapter group g (under split-K a split IS a group, see the
+                                                     // reduction): park s*T_g in its Tsh columns and restart the accumulator
         if (t_active) {
 #pragma unroll
           for (int j = 0; j < R16; ++j)
@@ -464,6 +493,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
     wait_stages(std::integral_constant<int, S - 2>{});
     __builtin_amdgcn_s_barrier();   // stage kt visible to all waves; everyone is done reading stage kt-1's buffer
     asm volatile("" ::: "memory");
+    if (kt - kbeg < 4) GTR(3 + kt - kbeg);
     if (early) stage(kt + S - 1, wr);
     compute(smem + rd * STAGE, kt);
     if (!early) stage(kt + S - 1, wr);
@@ -485,6 +515,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
   }
   }
 
+  GTR(8);
   // ---------------- split-K: publish the partial tile, last arriver reduces (agent-scope release/acquire) ----------------
   if (splitk > 1) {
     constexpr int NACC = NI * MI, NT = R16 ? R16 * TMI : 0;
@@ -560,6 +591,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
     __syncthreads();
   }
 
+  GTR(9);
   // ---------------- fused LoRA-up ----------------
   if (R16) {
     // tacc[j][b][r] = T[m = wm*MI*16 + (wn*TMI+b)*16 + (lane&15)][rank = j*16 + (lane>>4)*4 + r]
@@ -576,7 +608,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
         *(uint2*)(tsh + ((size_t)ml * TROW + j * 16 + fk * 4) * 2) = v;
       }
     }
-    const int nup = KG ? (p.K / p.lora_group_k) * R16 : R16;   // 16-column blocks of T (K-grouped: R16 per adapter)
+    const int nup = KG ? div_small_u(p.K, p.lora_group_k) * R16 : R16;   // 16-column blocks of T (K-grouped: R16 per adapter)
     __syncthreads();
     if (pTout != nullptr && t_writer) {
       // [BM rows][R] bf16 -> global, 8 B per lane
@@ -605,6 +637,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
     }
   }
 
+  GTR(10);
   // ---------------- epilogue ----------------
 #ifdef SDLT_LAB_NO_EPILOGUE
   if (acc[0][0][0] == 12345.f) ((float*)pC)[0] = 1.f;
@@ -723,6 +756,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
       }
       if (pass + 1 < BM / CROWS) __syncthreads();
     }
+    GTR(11);
     return;
   }
 #endif
@@ -785,6 +819,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
       }
     }
   }
+  GTR(11);
 }
 
 template <int MI, int NI, int WN, int MODE, int R16, int NSREQ, int KG = 0, int BT = 0, int WM = 2, int EPI = 0>
@@ -1026,6 +1061,10 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef SDLT_GEMM_TRACE
+extern "C" int sdlt_gemm_trace_read(long long* out16) { return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_gemm_tr), sizeof(long long) * 16); }
+#endif
 
 extern "C" int sdlt_gemm_bf16(const sdlt_gemm_params* pp, void* stream) {
   const sdlt_gemm_params& p = *pp;
