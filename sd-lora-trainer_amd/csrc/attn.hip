@@ -69,10 +69,10 @@ __device__ __forceinline__ WgId xcd_wg() {
   const int k = L & 7, slot = L >> 3, q = n >> 3, r = n & 7;
   const int logical = (k < r ? k * (q + 1) : r * (q + 1) + (k - r) * q) + slot;
   WgId w;
-  w.x = logical % gx;
-  const int t = logical / gx;
-  w.y = t % gy;
-  w.z = t / gy;
+  const int t = div_small_u(logical, gx);
+  w.x = logical - t * gx;
+  w.z = gridDim.z == 1 ? 0 : div_small_u(t, gy);
+  w.y = t - w.z * gy;
   return w;
 }
 
@@ -605,17 +605,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DP == 64 ? 
 }
 // D[b,h,q] = sum_d dO*O (8 lanes per (row, head))
 __device__ __forceinline__ void attn_prep_body(const bf16_t* O, int64_t ldo, const bf16_t* dO, int64_t lddo, int B, int H, int Nq, int Nqp, int d, float* D, const int bx, const int gx) {
-  const int64_t total = (int64_t)B * Nqp * H;
+  const int total = B * Nqp * H;                 // (< 2^22: the launcher checks; 64-bit divisions were ~300 of the kernel's ~450 instructions)
   const int sub = threadIdx.x & 7;
-  for (int64_t idx = (bx * (int64_t)blockDim.x + threadIdx.x) >> 3; idx < total; idx += ((int64_t)gx * blockDim.x) >> 3) {
-    int h = idx % H;
-    int64_t row = idx / H;  // b*Nqp + q
-    const int b = row / Nqp, q = row - (int64_t)b * Nqp;
+  for (int idx = (bx * (int)blockDim.x + (int)threadIdx.x) >> 3; idx < total; idx += (gx * (int)blockDim.x) >> 3) {
+    const int row = div_small(idx, H);   // b*Nqp + q
+    const int h = idx - row * H;
+    const int b = div_small(row, Nqp), q = row - b * Nqp;
     if (q >= Nq) continue;   // uniform within the 8-lane group
     float acc = 0.f;
     for (int c = sub * 8; c < d; c += 64) {
-      uint4 a = *(const uint4*)(O + row * ldo + h * d + c);
-      uint4 g = *(const uint4*)(dO + row * lddo + h * d + c);
+      uint4 a = *(const uint4*)(O + (int64_t)row * ldo + h * d + c);
+      uint4 g = *(const uint4*)(dO + (int64_t)row * lddo + h * d + c);
       const uint32_t* ap = (const uint32_t*)&a;
       const uint32_t* gp = (const uint32_t*)&g;
 #pragma unroll
@@ -1174,6 +1174,7 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
       (int64_t)((p.Nq + 63) / 64 + (p.Nk + 63) / 64) * p.H * p.B <= 2048) {   // (bigger grids are throughput-bound: two launches are 5 % faster there)
     // self-attention (UNet, text encoders): D, then dQ and dK/dV tiles in one launch (see attn_bwd_both_kernel)
     int64_t groups = (int64_t)p.B * p.Nqp * p.H;
+    if (groups >= (1 << 22)) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_attn_bwd: B * Nq * H = %lld rows (the D pre-pass indexes < 2^22)", (long long)groups);
     int blocks = (int)((groups * 8 + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(attn_prep_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)p.O, p.ldo, (const bf16_t*)p.dO, p.lddo, p.B, p.H, p.Nq, p.Nqp, p.d, p.D);

@@ -97,3 +97,13 @@ void sdlt_set_error(const char* fmt, ...);
     hipError_t e_ = hipGetLastError();                                           \
     if (e_ != hipSuccess) SDLT_FAIL(SDLT_ERR_LAUNCH, "%s: %s", __func__, hipGetErrorString(e_)); \
   } while (0)
+
+// a / b for 0 <= a < 2^22, 0 < b: reciprocal multiply + one correction step (~8 instructions; the ISA has no integer divide and the
+// compiler's expansion is ~40 dependent instructions - the tiled GEMM's prologue did five of them before its first load was issued)
+__device__ __forceinline__ int div_small(int a, int b) {
+  int q = (int)((float)a * __builtin_amdgcn_rcpf((float)b));
+  const int r = a - q * b;
+  q += (r >= b ? 1 : 0) - (r < 0 ? 1 : 0);
+  return q;
+}
+__device__ __forceinline__ int div_small_u(int a, int b) { return __builtin_amdgcn_readfirstlane(div_small(a, b)); }   // wave-uniform operands

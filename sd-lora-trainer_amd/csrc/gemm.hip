@@ -42,16 +42,6 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 
 // EPI: the fused epilogue (sdlt_gemm_params.epi_op) as a TEMPLATE parameter - with a run-time switch the GEGLU / activation code sat
 // in every instantiation and the whole GEMM family ran ~6 % slower (code size; the step alternates between ~60 kernels).
-// a / b for 0 <= a < 2^22, 0 < b: reciprocal multiply + one correction step (~8 instructions; the ISA has no integer divide and the
-// compiler's expansion is ~40 dependent instructions - the kernel's prologue did five of them before its first load was issued)
-__device__ __forceinline__ int div_small(int a, int b) {
-  int q = (int)((float)a * __builtin_amdgcn_rcpf((float)b));
-  const int r = a - q * b;
-  q += (r >= b ? 1 : 0) - (r < 0 ? 1 : 0);
-  return q;
-}
-__device__ __forceinline__ int div_small_u(int a, int b) { return __builtin_amdgcn_readfirstlane(div_small(a, b)); }   // wave-uniform operands
-
 // -DSDLT_GEMM_TRACE (tools/gemm_trace.py): thread 0 of workgroup 0 stamps clock64() at the phase boundaries; sdlt_gemm_trace_read copies them out
 #ifdef SDLT_GEMM_TRACE
 __device__ long long g_gemm_tr[16];

@@ -61,7 +61,7 @@ __device__ __forceinline__ void strip_body(const sdlt_strip_params& p, char* sme
   // split-K (p.splitk = S > 1): S neighbouring workgroups share a strip, each walks K / S columns; the last one to arrive adds the S
   // partial tiles in split order and runs the epilogue (fixed order: bitwise reproducible)
   const int S = p.splitk > 1 ? p.splitk : 1;
-  const int strip = S == 1 ? bx : bx / S, split = S == 1 ? 0 : bx - strip * S;
+  const int strip = S == 1 ? bx : div_small_u(bx, S), split = S == 1 ? 0 : bx - strip * S;
   const int n0 = strip * (16 * J);
   const int64_t row0 = (int64_t)by * p.Tp;
   // 64-column steps of THIS wave: the K / 256 steps are dealt out to the splits as evenly as they go (the first `rem` splits take one more)
@@ -101,7 +101,7 @@ __device__ __forceinline__ void strip_body(const sdlt_strip_params& p, char* sme
   char* ring = smem + wave * (R * SLOT);
   // every workgroup reads the same 80 activation rows: each starts its K walk at a different step (a fixed function of its index, so
   // the summation order of a given output is the same in every run), otherwise all of them hit the same L2 channels at the same time
-  const int rot = (int)((unsigned)strip % (unsigned)nsteps);
+  const int rot = strip - div_small_u(strip, nsteps) * nsteps;
   auto issue = [&](int i, int slot) {
     int ii = i + rot;
     ii = ii >= nsteps ? ii - nsteps : ii;

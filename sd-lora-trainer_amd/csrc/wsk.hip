@@ -68,12 +68,13 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
     const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
     if (p.map2d && (ntm & 1) == 0 && (ntn & 3) == 0) {
       const int pr = ntm >> 1, pc = ntn >> 2;           // tiles per XCD: pr x pc
-      tm = (xcd >> 2) * pr + idx / pc;
-      tn = (xcd & 3) * pc + idx % pc;
+      const int dq = div_small_u(idx, pc);
+      tm = (xcd >> 2) * pr + dq;
+      tn = (xcd & 3) * pc + idx - dq * pc;
     } else {
       const int per = ntn >> 3;                          // column tiles per XCD (ntn % 8 == 0)
-      tn = xcd * per + idx % per;
-      tm = idx / per;
+      tm = div_small_u(idx, per);
+      tn = xcd * per + idx - tm * per;
     }
   }
   if (tm >= ntm || tn >= ntn) return;
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   const bf16_t* asrc = LORA ? p.Adown + (int64_t)srow * p.ld_adown + schunk * 8 : nullptr;
   const int64_t x8 = 8 * p.ldx, w8 = 8 * p.ldw, a8 = 8 * p.ld_adown;
   char* ring = smem + wave * (R * SLOT);
-  const int rot = (int)((unsigned)tn % (unsigned)nsteps);
+  const int rot = tn - div_small_u(tn, nsteps) * nsteps;
   auto issue = [&](int i, int slot) -> int {
     int ii = i + rot;
     ii = ii >= nsteps ? ii - nsteps : ii;
