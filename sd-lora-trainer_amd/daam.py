@@ -25,6 +25,14 @@ T_TOKENS = 77
 FUSED = os.environ.get("SDLT_TA_FUSED", "1") != "0"      # 0: the torch-op form below on the GPU too (A/B, and the oracle of the kernel's test)
 
 
+def _gather_rows(tab, sel, dst):
+    """dst[...] = tab[sel] as ONE launch (an indexing temporary + copy_ are two) when the buffer has the table's row shape and dtype."""
+    if dst.dtype == tab.dtype and dst.is_contiguous() and tuple(dst.shape) == (sel.numel(), *tab.shape[1:]):
+        torch.index_select(tab, 0, sel, out=dst)
+    else:
+        dst.copy_(tab[sel].reshape(dst.shape))
+
+
 class TokenAttentionLoss:
     def __init__(self, rt, n_tok):
         self.rt, self.n_tok = rt, n_tok
@@ -46,11 +54,8 @@ class TokenAttentionLoss:
 
     def set_from_table(self, table, sel):
         """sel: int64 [B] (device) rows of `table`."""
-        tok_w, cnt, onehot, has = table
-        self.tok_w.copy_(tok_w[sel])
-        self.tok_cnt.copy_(cnt[sel])
-        self.ti_onehot.copy_(onehot[sel])
-        self.has_ti.copy_(has[sel])
+        for dst, tab in zip((self.tok_w, self.tok_cnt, self.ti_onehot, self.has_ti), table):
+            _gather_rows(tab, sel, dst)
 
     def set_captions(self, token_id_lists, train_ids):
         """token_id_lists[b] = tokenizer.encode(caption_b) (BOS ... EOS, unpadded) as the reference calls it

@@ -44,6 +44,21 @@ class TextStack:
         self.paired = (TEXT_PAIR and len(encoders) == 2 and all(getattr(e, "fused", False) for e in encoders) and not self.concurrent
                        and torch.device(rt.device).type == "cuda")
 
+    def pool_position_table(self, ids_table):
+        """Pooling position of every row of an id table [n, 77] (device) - train() gathers the batch's positions from it per step."""
+        return ids_table.argmax(-1) if self.pool_mode == "argmax" else (ids_table == self.eos).int().argmax(-1)
+
+    def set_ids_from_tables(self, tables, sel, pool_pos_table):
+        """The step's ids as gathers from per-caption tables on the device (train()): one launch per encoder + two for the pooling rows
+        (set_ids: a copy per encoder and five launches for argmax / arange / scale / add / copy)."""
+        for dst, tab in zip(self.ids, tables):
+            torch.index_select(tab, 0, sel, out=dst)
+        if getattr(self, "_pool_base", None) is None:
+            self._pool_base = torch.arange(self.pool_rows.shape[0], device=self.pool_rows.device) * TP
+            self._pool_tmp = torch.zeros_like(self.pool_rows)
+        torch.index_select(pool_pos_table, 0, sel, out=self._pool_tmp)
+        torch.add(self._pool_base, self._pool_tmp, out=self.pool_rows)
+
     def set_ids(self, ids_per_encoder):
         for dst, src in zip(self.ids, ids_per_encoder):
             dst.copy_(src)
@@ -285,11 +300,11 @@ class TrainStep:
         Without text encoders: ctx [B,77,D] (+ pooled [B,P]) are the injected conditioning.
         With text encoders (textual inversion): ids = [input_ids [B,77] per tokenizer] and caption_token_lists[b] =
         tokenizer.encode(caption_b) (unpadded, for the token-attention loss, loss.py:32)."""
-        self.latent.copy_(latent)
-        self.noise.copy_(noise)
-        self.mask.copy_(mask)
-        self.timesteps.copy_(timesteps)
-        self.timesteps_f.copy_(timesteps.to(torch.float32))
+        # (train() fills the step's own buffers in place - `x is self.x` - and those copies fall away)
+        for dst, src in ((self.latent, latent), (self.noise, noise), (self.mask, mask), (self.timesteps, timesteps)):
+            if src is not dst:
+                dst.copy_(src)
+        self.timesteps_f.copy_(timesteps)              # (the copy converts: no float temporary)
         if self.text is None:
             self.ctx.view(self.B, CTX_PAD, -1)[:, :77].copy_(ctx)
             if self.pooled is not None:
@@ -302,6 +317,8 @@ class TrainStep:
                 self.ctx.view(self.B, CTX_PAD, -1)[:, :77].copy_(ctx)
                 if self.pooled is not None:
                     self.pooled.copy_(pooled)
+            elif isinstance(ids, tuple):               # (tables, rows, pooling-position table): gathers on the device
+                self.text.set_ids_from_tables(*ids)
             else:
                 self.text.set_ids(ids)
             if caption_table is not None:          # (table, rows): per-caption constants already on the device (train(): no host work per step)
@@ -310,8 +327,9 @@ class TrainStep:
                 if getattr(self, "_train_ids_host", None) is None:
                     self._train_ids_host = self.text.encoders[0].train_ids.tolist()
                 self.ta.set_captions(caption_token_lists, self._train_ids_host)
-        if self.time_ids is not None and time_ids is not None:
-            self.time_ids.copy_(time_ids.reshape(-1).to(torch.float32))
+        if self.time_ids is not None and time_ids is not None and time_ids is not getattr(self, "_time_ids_src", None):
+            self.time_ids.copy_(time_ids.reshape(-1))  # (a job passes the same tensor every step: copied once)
+            self._time_ids_src = time_ids
 
     def set_hyper(self, lr, lr_ti=0.0, lr_te=0.0):
         """Host scalars of this optimiser step -> device buffers (see sdlt_adamw_fused).

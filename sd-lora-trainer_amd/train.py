@@ -494,6 +494,13 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
         cap_table = ts.ta.caption_table(lists_all, models.encoders[0].train_ids.tolist())
     if time_ids is not None:
         time_ids = time_ids.to(dev)
+    post_mean = post_std = pool_tab = None
+    if "posterior" in cache:
+        # dataset.DiagonalGaussian's clamp / exp on the whole table once instead of on the batch's rows every step (same values)
+        g_all = DiagonalGaussian(data_d)
+        post_mean, post_std = g_all.mean.contiguous(), g_all.std.contiguous()
+    if ti_on:
+        pool_tab = ts.text.pool_position_table(ids_tab[-1])
 
     def cond_rows(cnd, cnd_tok):
         """[n_img + 1] conditioning rows (dataset captions + the dropout caption) on the device."""
@@ -529,15 +536,19 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
             if ti_on:
                 optimizers.optimizers["textual_inversion"].param_groups[0]["lr"] = lrs["textual_inversion"]
             idx, sel = order_d[step_in_epoch], sel_d[step_in_epoch]
-            mask = masks_d[idx]
+            # the batch is written straight into the step's buffers (set_batch skips `x is self.x`): ~25 small launches between two graph
+            # replays instead of 53 (tools/train_loop_gaps.py); same draws from the generator in the same order, same arithmetic
+            mask = torch.index_select(masks_d, 0, idx, out=ts.mask) if masks_d.dtype == ts.mask.dtype and masks_d.shape[1:] == ts.mask.shape[1:] else masks_d[idx]
             if "posterior" in cache:       # dataset.py:184-187: latent_dist.sample() * scaling_factor on EVERY fetch
-                latent = DiagonalGaussian(data_d[idx]).sample(gd) * cfg["scaling_factor"]
+                eps = torch.randn(ts.latent.shape, generator=gd, device=dev, dtype=post_mean.dtype)
+                smp = post_std[idx].mul_(eps).add_(post_mean[idx])                      # mean + std * noise (separately rounded, as DiagonalGaussian.sample)
+                latent = torch.mul(smp, cfg["scaling_factor"], out=ts.latent)
             else:
-                latent = data_d[idx]
-            noise = torch.randn(latent.shape, generator=gd, device=dev)
+                latent = torch.index_select(data_d, 0, idx, out=ts.latent) if data_d.dtype == ts.latent.dtype else data_d[idx]
+            noise = torch.randn(ts.noise.shape, generator=gd, device=dev, out=ts.noise)
             if config.noise_offset > 0.0:                                                # main.py:313-317
                 noise += config.noise_offset * torch.randn((B, 4, 1, 1), generator=gd, device=dev)
-            timesteps = torch.randint(0, 1000, (B,), generator=gd, device=dev)
+            timesteps = torch.randint(0, 1000, (B,), generator=gd, device=dev, out=ts.timesteps)
             if ti_on:
                 kw = {}
                 if lrs["textual_inversion"] == 0.0 and ts.te_arena is None and ts.prodigy_ti is None and (captured or dev.type != "cuda") and ts._acc is None \
@@ -550,7 +561,7 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
                             cond_tok = encode_rows([t.view(1, 77) for t in cache["tok_ids"]]) if has_tok else None
                         cond_d = cond_rows(cond, cond_tok)
                     kw = dict(ctx=cond_d[0][sel], pooled=cond_d[1][sel] if cond_d[1] is not None else None)
-                ts.set_batch(latent, noise, timesteps, mask, time_ids=time_ids, ids=[t[sel] for t in ids_tab], caption_table=(cap_table, sel), **kw)
+                ts.set_batch(latent, noise, timesteps, mask, time_ids=time_ids, ids=(ids_tab, sel, pool_tab), caption_table=(cap_table, sel), **kw)
             else:
                 ts.set_batch(latent, noise, timesteps, mask, cond_d[0][sel], cond_d[1][sel] if cond_d[1] is not None else None, time_ids)
             if not captured and rt.device.type == "cuda":

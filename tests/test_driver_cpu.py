@@ -67,7 +67,9 @@ def test_train_from_folder_with_tokenizer(tmp_path, monkeypatch, version, disabl
     real_set = S.TrainStep.set_batch
 
     def spy(self, latent, noise, timesteps, mask, ctx=None, pooled=None, time_ids=None, ids=None, caption_token_lists=None, **kw):
-        seen.setdefault("calls", []).append(dict(ctx=None if ctx is None else ctx.clone(), ids=ids, table=kw.get("caption_table"), mask=mask.clone(), latent=latent.clone()))
+        # train() hands the ids over as (per-encoder tables, batch rows, pooling-position table): the batch's ids are the gathered rows
+        ids_seen = [t[ids[1]] for t in ids[0]] if isinstance(ids, tuple) else ids
+        seen.setdefault("calls", []).append(dict(ctx=None if ctx is None else ctx.clone(), ids=ids_seen, table=kw.get("caption_table"), mask=mask.clone(), latent=latent.clone()))
         return real_set(self, latent, noise, timesteps, mask, ctx, pooled, time_ids, ids, caption_token_lists, **kw)
     monkeypatch.setattr(S.TrainStep, "set_batch", spy)
     rt = unet_mod.Runtime("cpu", 2, act_dtype=torch.float32, ops=emu_ops)
