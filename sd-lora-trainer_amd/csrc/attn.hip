@@ -662,16 +662,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DP == 64 ? 
 // before; the fifth block (keys 64..79) is shared - wave w takes it against one 16-query set of the tile and the four partial dK / dV
 // blocks meet through LDS at the end (the two-blocks-per-wave layout spent half of every wave's key-major work on keys 80..127, which
 // do not exist, and gave wave 0 twice the live work of the others); the q-major pass skips the dead 32-key blocks of its second half.
-template <int DP, bool FIVE>
-__global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_params p) {
+// ROLE 0: both orientations in one workgroup (as described above).  ROLE 1 / 2: the q-major pass (dQ) and the key-major pass (dK / dV slabs) as
+// SEPARATE workgroups of one launch (attn_bwd_cross_roles_kernel).  One workgroup doing both needs 346 registers - one wave per SIMD, every
+// LDS / MFMA latency of its ~11 k clocks per 64-query tile exposed (tools/attn_trace.py); split, each role fits 256 registers, two workgroups
+// share a CU and a tile costs each of them one orientation.  The key-major role computes D = rowsum(dO * O) itself (it stages the O tile too).
+template <int DP, bool FIVE, int ROLE>
+__device__ __forceinline__ void attn_bwd_cross_body(const sdlt_attn_params& p, char* smem, const int split) {
   constexpr int NSTR = tile_stride<DP>();
-  constexpr int QBUF = 2 * 64 * NSTR;                   // Q, dO natural
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem;                                      // [128][NSTR], resident
+  constexpr bool QM = ROLE != 2, KM = ROLE != 1;        // q-major / key-major pass present
+  constexpr int QBUF = (ROLE == 2 ? 3 : 2) * 64 * NSTR; // Q, dO (+ O for ROLE 2) natural
+  char* Ks = smem;                                      // [128][NSTR], resident (q-major only)
   char* Vs = Ks + 128 * NSTR;
-  char* ring = Vs + 128 * NSTR;                         // 2 x QBUF
+  char* ring = QM ? Vs + 128 * NSTR : smem;             // 2 x QBUF
   float* LD = (float*)(ring + 2 * QBUF);                // L*log2e [64], D [64] of the current tile
-  const int b = blockIdx.z, h = blockIdx.y, split = blockIdx.x;
+  const int b = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, i = lane & 15;
   const int d = p.d, hc = h * d;
   const float sl2 = p.scale * LOG2E;
@@ -684,14 +688,16 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
   int trn = 0;
   TR();
 #endif
-  TileRegs<DP> qr, gr;
+  TileRegs<DP> qr, gr, orr;
+  if constexpr (QM) {
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {                         // resident K / V tiles (rows >= Nkp read as zero)
-    const int nk = min(64, max(0, p.Nkp - t * 64));
-    gload_nat<DP>(qr, (const bf16_t*)p.K, p.ldk, (int64_t)b * p.Nkp + t * 64, nk, hc, d);
-    gload_nat<DP>(gr, (const bf16_t*)p.V, p.ldv, (int64_t)b * p.Nkp + t * 64, nk, hc, d);
-    sstore_nat<DP>(qr, Ks + t * 64 * NSTR);
-    sstore_nat<DP>(gr, Vs + t * 64 * NSTR);
+    for (int t = 0; t < 2; ++t) {                       // resident K / V tiles (rows >= Nkp read as zero)
+      const int nk = min(64, max(0, p.Nkp - t * 64));
+      gload_nat<DP>(qr, (const bf16_t*)p.K, p.ldk, (int64_t)b * p.Nkp + t * 64, nk, hc, d);
+      gload_nat<DP>(gr, (const bf16_t*)p.V, p.ldv, (int64_t)b * p.Nkp + t * 64, nk, hc, d);
+      sstore_nat<DP>(qr, Ks + t * 64 * NSTR);
+      sstore_nat<DP>(gr, Vs + t * 64 * NSTR);
+    }
   }
   // key-major operands: this wave's keys w*64 + wave*16 + i
   int key[2];
@@ -705,8 +711,8 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
 #pragma unroll
     for (int kk = 0; kk < DP / 32; ++kk) {
       int col = kk * 32 + g * 8;
-      kf[w][kk] = ld_frag_global((const bf16_t*)p.K + ((int64_t)b * p.Nkp + key[w]) * p.ldk + hc + col, kok[w] && col < d);
-      vf[w][kk] = ld_frag_global((const bf16_t*)p.V + ((int64_t)b * p.Nkp + key[w]) * p.ldv + hc + col, kok[w] && col < d);
+      kf[w][kk] = ld_frag_global((const bf16_t*)p.K + ((int64_t)b * p.Nkp + key[w]) * p.ldk + hc + col, KM && kok[w] && col < d);
+      vf[w][kk] = ld_frag_global((const bf16_t*)p.V + ((int64_t)b * p.Nkp + key[w]) * p.ldv + hc + col, KM && kok[w] && col < d);
     }
 #pragma unroll
     for (int df = 0; df < DP / 16; ++df) {
@@ -717,21 +723,31 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
   const int nqt = (p.Nq + 63) / 64;
   const int per = (nqt + p.qsplit - 1) / p.qsplit;
   const int qt_lo = split * per, qt_hi = min(nqt, qt_lo + per);
+  float lreg2 = 0.f;                                   // ROLE 2: L of the tile whose loads are in flight (threads 0..63)
   auto gload_all = [&](int qt) {
     const int q0 = qt * 64;
     const int nq = min(64, p.Nqp - q0);
     gload_nat<DP>(qr, (const bf16_t*)p.Q, p.ldq, (int64_t)b * p.Nqp + q0, nq, hc, d);
     gload_nat<DP>(gr, (const bf16_t*)p.dO, p.lddo, (int64_t)b * p.Nqp + q0, nq, hc, d);
+    if constexpr (ROLE == 2) {
+      gload_nat<DP>(orr, (const bf16_t*)p.O, p.ldo, (int64_t)b * p.Nqp + q0, nq, hc, d);
+      if (threadIdx.x < 64) {
+        const int qq = q0 + threadIdx.x;
+        lreg2 = qq < p.Nq ? p.L[((int64_t)b * p.H + h) * p.Nq + qq] * LOG2E : 0.f;
+      }
+    }
   };
   auto sstore_all = [&](char* base) {
     sstore_nat<DP>(qr, base);
     sstore_nat<DP>(gr, base + 64 * NSTR);
+    if constexpr (ROLE == 2) sstore_nat<DP>(orr, base + 2 * 64 * NSTR);
   };
   // O fragments and L of this lane's q-major row, fetched one tile ahead like the Q / dO tiles (as plain loads at their point of use they
   // put two exposed global round trips at the head of every tile)
   bf16x8 ofn[DP / 32];
   float Lqn = 0.f;
   auto gload_ol = [&](int qt) {
+    if constexpr (!QM) return;
     const int q = qt * 64 + wave * 16 + i;
     const bool qok = q < p.Nq;
 #pragma unroll
@@ -753,6 +769,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
     const char* Qs = ring + ((qt - qt_lo) & 1) * QBUF;
     const char* Gs = Qs + 64 * NSTR;
     const bool more = qt + 1 < qt_hi;
+    const float lcur = lreg2;                          // (ROLE 2) L of THIS tile, loaded a tile ahead
     bf16x8 of[DP / 32];
 #pragma unroll
     for (int kk = 0; kk < DP / 32; ++kk) of[kk] = ofn[kk];
@@ -762,8 +779,26 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
       gload_ol(qt + 1);
     }
 
+    if constexpr (ROLE == 2) {
+      // D = rowsum(dO * O) and L of the tile's 64 rows: four lanes per row, 16 columns each, straight from the staged tiles
+      const char* Os = Gs + 64 * NSTR;
+      const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < DP / 32; ++c) {
+        const int ch = part * (DP / 32) + c;                                  // 16-byte chunk of the row
+        const bf16x8 gv = *(const bf16x8*)(Gs + row * NSTR + ((ch ^ row_sw<DP>(row)) << 4));
+        const bf16x8 ov = *(const bf16x8*)(Os + row * NSTR + ((ch ^ row_sw<DP>(row)) << 4));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += (float)gv[j] * (float)ov[j];
+      }
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      if (part == 0) LD[64 + row] = acc;
+      if (threadIdx.x < 64) LD[threadIdx.x] = lcur;
+    }
     // ---------------- q-major: this wave's rows q0 + wave*16 + i against all 128 keys -> D, dQ
-    {
+    if constexpr (QM) {
       const int ql = wave * 16 + i, q = q0 + ql;
       const bool qok = q < p.Nq;
       bf16x8 qf[DP / 32], gf[DP / 32];
@@ -777,7 +812,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
       }
       Dq += __shfl_xor(Dq, 16, 64);
       Dq += __shfl_xor(Dq, 32, 64);
-      if (g == 0) {
+      if (ROLE == 0 && g == 0) {
         LD[ql] = Lq;
         LD[64 + ql] = Dq;
       }
@@ -849,7 +884,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
     TR();
 
     // ---------------- key-major: this wave's 2 x 16 keys against the tile's 64 queries -> dK, dV
-    {
+    if constexpr (KM) {
       const float* Ls = LD;
       const float* Ds = LD + 64;
       constexpr int NWK = FIVE ? 1 : 2;      // 64-query key blocks of this wave
@@ -938,6 +973,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
   }
   // partial dK / dV of this query range -> slab[split][b*Nkp + key][C] (plain 16-byte stores; attn_splitsum_kernel adds the
   // slabs and converts).  Float atomics on the 77 x C block shared by every split were the whole cost of the old path.
+  if constexpr (!KM) return;
   if constexpr (FIVE) {
     // the four waves' partial dK / dV of key block 4 -> LDS (the tile ring is dead) -> wave w adds and keeps column block df == w
     f32x4* red = (f32x4*)ring;             // [wave][dk | dv][df][lane]
@@ -976,6 +1012,19 @@ __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_par
       }
     }
   TR();
+}
+
+template <int DP, bool FIVE>
+__global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  attn_bwd_cross_body<DP, FIVE, 0>(p, smem, blockIdx.x);
+}
+// grid.x = 2 * qsplit: the first qsplit workgroups of a (head, batch element) are the q-major role, the others the key-major role
+template <int DP, bool FIVE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DP == 64 ? 2 : 1, DP == 64 ? 2 : 8))) void attn_bwd_cross_roles_kernel(const sdlt_attn_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x < p.qsplit) attn_bwd_cross_body<DP, FIVE, 1>(p, smem, blockIdx.x);
+  else attn_bwd_cross_body<DP, FIVE, 2>(p, smem, blockIdx.x - p.qsplit);
 }
 
 // out[b*Nkp + key][c] = bf16(sum over splits of slab[split][b*Nkp + key][c]); pad keys [Nk, Nkp) get zeros
@@ -1158,7 +1207,12 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
 #define SMEM_X(D_) (2 * 128 * NSTRH(D_) + 2 * (2 * 64 * NSTRH(D_)) + 512)
     static const bool five_env = !(getenv("SDLT_XATTN_FIVE") && atoi(getenv("SDLT_XATTN_FIVE")) == 0);
     const bool five = five_env && p.Nk > 64 && p.Nk <= 80;
-#define XLAUNCH(D_, F_) do { set_smem(attn_bwd_cross_kernel<D_, F_>, SMEM_X(D_)); hipLaunchKernelGGL((attn_bwd_cross_kernel<D_, F_>), gx, dim3(256), SMEM_X(D_), s, p); } while (0)
+    // SDLT_XATTN_ROLES=0: both orientations in one workgroup (the single-role kernel)
+    static const bool roles_env = !(getenv("SDLT_XATTN_ROLES") && atoi(getenv("SDLT_XATTN_ROLES")) == 0);
+#define SMEM_XR(D_) (3 * 2 * 64 * NSTRH(D_) > 2 * 128 * NSTRH(D_) + 2 * 2 * 64 * NSTRH(D_) ? 3 * 2 * 64 * NSTRH(D_) + 512 : 2 * 128 * NSTRH(D_) + 2 * 2 * 64 * NSTRH(D_) + 512)
+#define XLAUNCH(D_, F_) do { \
+      if (roles_env && (D_) == 64) {       /* (head width 96: the split roles spill) */  set_smem(attn_bwd_cross_roles_kernel<D_, F_>, SMEM_XR(D_)); hipLaunchKernelGGL((attn_bwd_cross_roles_kernel<D_, F_>), dim3(2 * p.qsplit, p.H, p.B), dim3(256), SMEM_XR(D_), s, p); } \
+      else { set_smem(attn_bwd_cross_kernel<D_, F_>, SMEM_X(D_)); hipLaunchKernelGGL((attn_bwd_cross_kernel<D_, F_>), gx, dim3(256), SMEM_X(D_), s, p); } } while (0)
     if (dp == 64) { if (five) XLAUNCH(64, true); else XLAUNCH(64, false); }
     else { if (five) XLAUNCH(96, true); else XLAUNCH(96, false); }
     if (!p.defer_splitsum) {
