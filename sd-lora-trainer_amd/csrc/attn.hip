@@ -667,7 +667,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DP == 64 ? 
 // LDS / MFMA latency of its ~11 k clocks per 64-query tile exposed (tools/attn_trace.py); split, each role fits 256 registers, two workgroups
 // share a CU and a tile costs each of them one orientation.  The key-major role computes D = rowsum(dO * O) itself (it stages the O tile too).
 template <int DP, bool FIVE, int ROLE>
-__device__ __forceinline__ void attn_bwd_cross_body(const sdlt_attn_params& p, char* smem, const int split) {
+__device__ __forceinline__ void attn_bwd_cross_body(const sdlt_attn_params& p, char* smem, const int split, const int nsplit) {
   constexpr int NSTR = tile_stride<DP>();
   constexpr bool QM = ROLE != 2, KM = ROLE != 1;        // q-major / key-major pass present
   constexpr int QBUF = (ROLE == 2 ? 3 : 2) * 64 * NSTR; // Q, dO (+ O for ROLE 2) natural
@@ -683,8 +683,8 @@ __device__ __forceinline__ void attn_bwd_cross_body(const sdlt_attn_params& p, c
   const int tsw = row_sw<DP>(8 * g + (i >> 2)) >> 1;   // this lane's XOR on the 32-byte column block of a transposing read
 
 #ifdef SDLT_ATTN_TRACE
-  const bool tr = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && p.D;
-  long long* trb = (long long*)p.D;
+  const bool tr = (ROLE == 2 ? (int)blockIdx.x == (int)gridDim.x - p.qsplit : blockIdx.x == 0) && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && p.D;
+  long long* trb = (long long*)p.D + (ROLE == 2 ? 64 : 0);      // (the key-major role's stamps sit 64 slots further)
   int trn = 0;
   TR();
 #endif
@@ -721,7 +721,7 @@ __device__ __forceinline__ void attn_bwd_cross_body(const sdlt_attn_params& p, c
     }
   }
   const int nqt = (p.Nq + 63) / 64;
-  const int per = (nqt + p.qsplit - 1) / p.qsplit;
+  const int per = (nqt + nsplit - 1) / nsplit;          // (nsplit: workgroups of this role along the queries; the key-major role's is p.qsplit = the slab count)
   const int qt_lo = split * per, qt_hi = min(nqt, qt_lo + per);
   float lreg2 = 0.f;                                   // ROLE 2: L of the tile whose loads are in flight (threads 0..63)
   auto gload_all = [&](int qt) {
@@ -1017,14 +1017,16 @@ __device__ __forceinline__ void attn_bwd_cross_body(const sdlt_attn_params& p, c
 template <int DP, bool FIVE>
 __global__ __launch_bounds__(256) void attn_bwd_cross_kernel(const sdlt_attn_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  attn_bwd_cross_body<DP, FIVE, 0>(p, smem, blockIdx.x);
+  attn_bwd_cross_body<DP, FIVE, 0>(p, smem, blockIdx.x, p.qsplit);
 }
-// grid.x = 2 * qsplit: the first qsplit workgroups of a (head, batch element) are the q-major role, the others the key-major role
+// grid.x = nq + qsplit: the first nq workgroups of a (head, batch element) are the q-major role, the other qsplit the key-major role (one
+// dK / dV slab each).  A key-major tile costs ~1.6x a q-major one and that role also writes the slabs, so it gets the finer split.
 template <int DP, bool FIVE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DP == 64 ? 2 : 1, DP == 64 ? 2 : 8))) void attn_bwd_cross_roles_kernel(const sdlt_attn_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if ((int)blockIdx.x < p.qsplit) attn_bwd_cross_body<DP, FIVE, 1>(p, smem, blockIdx.x);
-  else attn_bwd_cross_body<DP, FIVE, 2>(p, smem, blockIdx.x - p.qsplit);
+  const int nq = (int)gridDim.x - p.qsplit;
+  if ((int)blockIdx.x < nq) attn_bwd_cross_body<DP, FIVE, 1>(p, smem, blockIdx.x, nq);
+  else attn_bwd_cross_body<DP, FIVE, 2>(p, smem, blockIdx.x - nq, p.qsplit);
 }
 
 // out[b*Nkp + key][c] = bf16(sum over splits of slab[split][b*Nkp + key][c]); pad keys [Nk, Nkp) get zeros
@@ -1209,9 +1211,11 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
     const bool five = five_env && p.Nk > 64 && p.Nk <= 80;
     // SDLT_XATTN_ROLES=0: both orientations in one workgroup (the single-role kernel)
     static const bool roles_env = !(getenv("SDLT_XATTN_ROLES") && atoi(getenv("SDLT_XATTN_ROLES")) == 0);
+    static const int qdiv_env = getenv("SDLT_XATTN_QDIV") ? atoi(getenv("SDLT_XATTN_QDIV")) : 1;      // q-major workgroups = qsplit / this
+    const int nq_roles = p.qsplit / (qdiv_env > 0 ? qdiv_env : 1) > 0 ? p.qsplit / (qdiv_env > 0 ? qdiv_env : 1) : 1;
 #define SMEM_XR(D_) (3 * 2 * 64 * NSTRH(D_) > 2 * 128 * NSTRH(D_) + 2 * 2 * 64 * NSTRH(D_) ? 3 * 2 * 64 * NSTRH(D_) + 512 : 2 * 128 * NSTRH(D_) + 2 * 2 * 64 * NSTRH(D_) + 512)
 #define XLAUNCH(D_, F_) do { \
-      if (roles_env && (D_) == 64) {       /* (head width 96: the split roles spill) */  set_smem(attn_bwd_cross_roles_kernel<D_, F_>, SMEM_XR(D_)); hipLaunchKernelGGL((attn_bwd_cross_roles_kernel<D_, F_>), dim3(2 * p.qsplit, p.H, p.B), dim3(256), SMEM_XR(D_), s, p); } \
+      if (roles_env && (D_) == 64) {       /* (head width 96: the split roles spill) */  set_smem(attn_bwd_cross_roles_kernel<D_, F_>, SMEM_XR(D_)); hipLaunchKernelGGL((attn_bwd_cross_roles_kernel<D_, F_>), dim3(nq_roles + p.qsplit, p.H, p.B), dim3(256), SMEM_XR(D_), s, p); } \
       else { set_smem(attn_bwd_cross_kernel<D_, F_>, SMEM_X(D_)); hipLaunchKernelGGL((attn_bwd_cross_kernel<D_, F_>), gx, dim3(256), SMEM_X(D_), s, p); } } while (0)
     if (dp == 64) { if (five) XLAUNCH(64, true); else XLAUNCH(64, false); }
     else { if (five) XLAUNCH(96, true); else XLAUNCH(96, false); }

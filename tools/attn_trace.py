@@ -46,6 +46,8 @@ for (name, B, H, Nq) in [("cross N1024 H20", 1, 20, 1024), ("cross N4096 H10", 1
         D.zero_()
         ops.attn_bwd(Q, K, V, None, None, O, L, dO, None, D.view(torch.float32), dQ, dK, dV, qsplit=qs, dK32=dK32, dV32=dV32, **kw)
         torch.cuda.synchronize()
-    t = [x for x in D.cpu().tolist() if x]
-    rel = [x - t[0] for x in t]
-    print(name, "qsplit", qs, "stamps (cycles):", rel)
+    allst = D.cpu().tolist()
+    for role, seg in (("q-major role / single", allst[:64]), ("key-major role", allst[64:128])):
+        t = [x for x in seg if x]
+        if t:
+            print(name, "qsplit", qs, role, "stamps (clock64 ticks, ~1.5 per ns):", [x - t[0] for x in t])
