@@ -3,6 +3,7 @@
 reference's max-abs (one bf16 ulp is 0.4-0.8 %; accumulation is fp32 on both sides) - written in `close`.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -1167,3 +1168,24 @@ def _count_paired(ops, gens, prefer):
     finally:
         ops._PairQueue.launch = orig
     return n[0]
+
+
+@pytest.mark.parametrize("env,select", [(dict(SDLT_XATTN_ROLES="0"), "test_attention_fwd_bwd"), (dict(SDLT_XATTN_ROLES="0", SDLT_XATTN_FIVE="0"), "test_attention_fwd_bwd"),
+                                        (dict(SDLT_ATTN_XCD="0", SDLT_ATTN_KS="1"), "test_attention_fwd_bwd"),
+                                        (dict(SDLT_WSK_STAGGER="0", SDLT_STRIP_WIDE_MIN="4096"), "test_wsk or test_strip")],
+                         ids=["single-role", "single-role-128-keys", "plain-order-unsplit", "unstaggered-narrow-strips"])
+def test_fallback_kernel_paths_in_a_subprocess(env, select):
+    """The A/B switches are read once per process, so the non-default kernels behind them (single-role / 128-key cross-attention backward,
+    plain workgroup order, unsplit attention forward, unstaggered wave-split-K refills, 16-column strips) run in a child pytest: the same
+    checks must pass on them too."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", f"({select}) and not subprocess"],       # (never this test itself: a child that selects it spawns children for ever)
+                       env=e, cwd=root, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
