@@ -378,7 +378,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const sdlt_attn_params& p, char
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][r], sl2, -Lq));
-          s[kf][r] = pv * (dp[kf][r] - Dq) * p.scale;  // dS
+          s[kf][r] = pv * (dp[kf][r] - Dq);            // dS / scale (the softmax scale multiplies the finished dQ rows once instead of every score)
         }
     } else {
 #pragma unroll
@@ -388,7 +388,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const sdlt_attn_params& p, char
           int key = k0 + (kf >> 1) * 32 + g * 8 + (kf & 1) * 4 + r;
           bool ok = qok && key < p.Nk && !(p.causal && key > q);
           float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][r], sl2, -Lq)) : 0.f;
-          s[kf][r] = pv * (dp[kf][r] - Dq) * p.scale;  // dS
+          s[kf][r] = pv * (dp[kf][r] - Dq);            // dS / scale (the softmax scale multiplies the finished dQ rows once instead of every score)
         }
     }
 #pragma unroll
@@ -415,8 +415,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(const sdlt_attn_params& p, char
       int col = df * 16 + g * 4;
       if (col < d) {
         uint2 w;
-        w.x = pack2bf(dq[df][0], dq[df][1]);
-        w.y = pack2bf(dq[df][2], dq[df][3]);
+        w.x = pack2bf(dq[df][0] * p.scale, dq[df][1] * p.scale);
+        w.y = pack2bf(dq[df][2] * p.scale, dq[df][3] * p.scale);
         *(uint2*)((bf16_t*)p.dQ + ((int64_t)b * p.Nqp + q) * p.lddq + hc + col) = w;
       }
     }
@@ -517,7 +517,7 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const sdlt_attn_params& p, ch
         for (int r = 0; r < 4; ++r) {
           float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qf][r], sl2, -l4[r]));
           s[qf][r] = pv;
-          dp[qf][r] = pv * (dp[qf][r] - d4[r]) * p.scale;
+          dp[qf][r] = pv * (dp[qf][r] - d4[r]);          // dS / scale (applied to the finished dK rows)
         }
       }
     } else {
@@ -530,7 +530,7 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const sdlt_attn_params& p, ch
           bool ok = kok && qq < p.Nq && !(p.causal && key > qq);
           float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[qf][r], sl2, -Ls[ql])) : 0.f;
           s[qf][r] = pv;
-          dp[qf][r] = pv * (dp[qf][r] - Ds[ql]) * p.scale;
+          dp[qf][r] = pv * (dp[qf][r] - Ds[ql]);
         }
     }
 #pragma unroll
@@ -564,12 +564,12 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const sdlt_attn_params& p, ch
         if (p.qsplit > 1) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            atomicAdd(p.dK32 + row * p.ld32 + hc + col + r, dk[df][r]);
+            atomicAdd(p.dK32 + row * p.ld32 + hc + col + r, dk[df][r] * p.scale);
             atomicAdd(p.dV32 + row * p.ld32 + hc + col + r, dv[df][r]);
           }
         } else {
           uint2 w;
-          w.x = pack2bf(dk[df][0], dk[df][1]); w.y = pack2bf(dk[df][2], dk[df][3]);
+          w.x = pack2bf(dk[df][0] * p.scale, dk[df][1] * p.scale); w.y = pack2bf(dk[df][2] * p.scale, dk[df][3] * p.scale);
           *(uint2*)((bf16_t*)p.dK + row * p.lddk + hc + col) = w;
           w.x = pack2bf(dv[df][0], dv[df][1]); w.y = pack2bf(dv[df][2], dv[df][3]);
           *(uint2*)((bf16_t*)p.dV + row * p.lddv + hc + col) = w;
