@@ -121,16 +121,19 @@ WSK = os.environ.get("SDLT_WSK", "1") != "0"
 WSK_LORA = os.environ.get("SDLT_WSK_LORA", "1") != "0"
 
 
+WSK_KMAX = int(os.environ.get("SDLT_WSK_KMAX", "10240"))      # longest plain K on the wave-split-K kernel (whole-step A/B: 10240 -> -0.14 ms against 8192)
+
+
 def wsk_shape(M, N, K, lora=False):
     """Shapes the wave-split-K kernel takes over from the tiled one: 64 x 80 tiles that fill the 256 CUs exactly once (or less).  Without an
     adapter: a K long enough for its flatter per-step cost to pay (tools/wsk_probe.py: 1024 x 1280, K = 3840 / 5120: 19.8 / 23.3 us against 28.4 /
-    31.1 us; equal at K = 1280 and 10240, slower on wider or taller outputs, which make more than 256 tiles).  With a rank-16 adapter: the
+    31.1 us; equal at K = 1280 and, in the probe, at 10240 - in the step the dX of ff.net.0 (K = 10240) is 2 us faster here; slower on wider or taller outputs, which make more than 256 tiles).  With a rank-16 adapter: the
     1024 x 1280 x 1280 projections (to_q / to_out.0 and their input gradients, 310 launches of an SDXL step)."""
     if not (M % 64 == 0 and N % 640 == 0 and K % 256 == 0 and (M // 64) * (N // 80) <= 256):
         return False
     if lora:
         return WSK_LORA and 1024 <= K <= 8192 and (M // 64) * (N // 80) >= 128
-    return 2560 <= K <= 8192
+    return 2560 <= K <= WSK_KMAX
 
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
