@@ -6,7 +6,7 @@ import collections, csv, json, re, sys
 
 def fam_of(name):
     k = re.sub(r"\(anonymous namespace\)::", "", name).replace("void ", "")
-    return "gemm" if k.startswith("gemm_kernel") else "attn" if k.startswith("attn") else "lora_grad" if "lora_grad" in k else \
+    return "gemm" if k.startswith(("gemm_kernel", "wsk_kernel")) else "text_gemm" if k.startswith("strip_") else "attn" if k.startswith("attn") else "lora_grad" if "lora_grad" in k else \
         "norm" if k.startswith(("gn_", "ln_")) else "torch" if "at::" in k else "other"
 
 
