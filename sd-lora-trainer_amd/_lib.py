@@ -211,11 +211,19 @@ def load():
             raise KernelLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    for which, cls in enumerate((GemmParams, LoraGradDesc, AttnParams, GroupNormParams, ShadowDesc, GemmBatchItem, DoraDesc, DoraWtDesc, DoraGradDesc, SplitsumDesc, StripParams, TaParams)):
-        if lib.sdlt_struct_size(which) != C.sizeof(cls):
-            raise KernelLibraryError(f"struct layout mismatch for {cls.__name__}: C {lib.sdlt_struct_size(which)} vs ctypes {C.sizeof(cls)}")
+    for which, (name, size) in enumerate(struct_sizes()):
+        if lib.sdlt_struct_size(which) != size:
+            raise KernelLibraryError(f"struct layout mismatch for {name}: C {lib.sdlt_struct_size(which)} vs binding {size}")
     _lib = lib
     return lib
+
+
+def struct_sizes():
+    """(name, bytes) of every struct of include/sdlt_kernels.h as this binding lays it out, in sdlt_struct_size()'s order.  The two item tables that
+    ops.py packs with `struct` (8 / 3 pointers) are listed by their packed size."""
+    mirrored = (GemmParams, LoraGradDesc, AttnParams, GroupNormParams, ShadowDesc, GemmBatchItem, DoraDesc, DoraWtDesc, DoraGradDesc, SplitsumDesc, StripParams,
+                TaParams, LnSlabsParams, TaGroup)
+    return [(c.__name__, C.sizeof(c)) for c in mirrored] + [("sdlt_affine_grad_item", 8 * 8), ("sdlt_wgrad_tr_item", 3 * 8)]
 
 
 def check(rc, what):

@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include "common.h"
 #include "../../include/sdlt_kernels.h"
+#include "attn32.h"
 
 namespace {
 
@@ -1120,16 +1121,7 @@ int attn_check(const sdlt_attn_params& p, const char* fn) {
 }
 
 template <typename F>
-int set_smem(F f, int bytes) {
-  // one attribute call per kernel instantiation, keyed by function pointer
-  static const void* done[32];
-  static int ndone = 0;
-  for (int i = 0; i < ndone; ++i)
-    if (done[i] == (const void*)f) return 0;
-  hipError_t e = hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (ndone < 32) done[ndone++] = (const void*)f;
-  return e == hipSuccess ? 0 : -1;
-}
+int set_smem(F f, int bytes) { return sdlt_raise_smem((const void*)f, bytes); }   // once per (kernel, device), thread-safe (capi.cpp)
 
 #define ATTN_DISPATCH(DPV, KERNEL, GRID, SMEM)                                                  \
   switch (DPV) {                                                                                \
@@ -1141,6 +1133,10 @@ int set_smem(F f, int bytes) {
 
 }  // namespace
 
+static bool attn32_on() {
+  static const bool on = !(getenv("SDLT_ATTN_R32") && atoi(getenv("SDLT_ATTN_R32")) == 0);
+  return on;
+}
 static void attn_env_once() {
   static bool done = false;
   if (done) return;
@@ -1160,6 +1156,13 @@ extern "C" int sdlt_attn_fwd(const sdlt_attn_params* pp, void* stream) {
   if (p.ldo % 4) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_attn_fwd: ldo %% 4");
   const int dp = attn_dp(p.d);
   dim3 grid((p.Nq + 63) / 64, p.H, p.B);
+  // head width 64, whole 64-row tiles, no mask: 32 rows per wave on the 32x32x16 MFMA (attn32.hip).  SDLT_ATTN_R32=0 keeps the 16-row kernels (A/B);
+  // the key split follows the grid: two wave groups per workgroup while a launch is less than two workgroups per CU
+  if (attn32_on() && sdlt_attn32_ok(p) && ((uintptr_t)p.O % 8) == 0) {
+    static const int ks_env = getenv("SDLT_ATTN32_KS_FWD") ? atoi(getenv("SDLT_ATTN32_KS_FWD")) : 0;
+    const int64_t nwg = (int64_t)grid.x * grid.y * grid.z;
+    return sdlt_attn32_fwd(p, ks_env > 0 ? ks_env : (nwg <= 512 && p.Nk >= 256 ? 2 : 1), s);
+  }
 #define NSTRH(D_) ((D_) == 64 ? 128 : (D_) * 2 + 16)
 #define SMEM_FWD(D_) (2 * (2 * 64 * NSTRH(D_)))
   // the key split (two wave groups per workgroup) pays on latency-bound grids only - less than two workgroups per CU and a chain of >= 4
@@ -1236,6 +1239,11 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
     int blocks = (int)((groups * 8 + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(attn_prep_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)p.O, p.ldo, (const bf16_t*)p.dO, p.lddo, p.B, p.H, p.Nq, p.Nqp, p.d, p.D);
+    if (attn32_on() && sdlt_attn32_ok(p) && ((uintptr_t)p.L % 16) == 0 && ((uintptr_t)p.D % 16) == 0) {
+      static const int ks_env = getenv("SDLT_ATTN32_KS_BWD") ? atoi(getenv("SDLT_ATTN32_KS_BWD")) : 0;
+      const int64_t nwg = (int64_t)(p.Nq / 64 + p.Nk / 64) * p.H * p.B;
+      return sdlt_attn32_bwd_both(p, ks_env > 0 ? ks_env : (nwg <= 1024 && p.Nk >= 256 && p.Nq >= 256 ? 2 : 1), s);
+    }
     dim3 gb((p.Nq + 63) / 64 + (p.Nk + 63) / 64, p.H, p.B);
 #define SMEM_BOTH(D_) (2 * (2 * 64 * NSTRH(D_) + 512))
     ATTN_DISPATCH(dp, attn_bwd_both_kernel, gb, SMEM_BOTH)

@@ -87,6 +87,7 @@ static inline void sdlt_zero_async(void* p, size_t bytes, hipStream_t s) {
 }
 
 void sdlt_set_error(const char* fmt, ...);
+int sdlt_raise_smem(const void* fn, int bytes);   // capi.cpp: dynamic-LDS limit of a kernel, once per (kernel, device), thread-safe; 0 / -1
 #define SDLT_FAIL(code, ...)      \
   do {                            \
     sdlt_set_error(__VA_ARGS__);  \

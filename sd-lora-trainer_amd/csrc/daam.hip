@@ -324,12 +324,8 @@ extern "C" int sdlt_token_attention_loss(const sdlt_ta_params* pp, void* stream)
   if (!p.ws || p.ws_floats < sdlt_token_attention_ws_floats(&p) || !p.loss || !p.mask || !p.tok_w || !p.tok_cnt || !p.ti_onehot || !p.has_ti)
     SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_token_attention_loss: workspace / operands");
   hipStream_t s = (hipStream_t)stream;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)ta_heat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute((const void*)ta_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr_set = true;
-  }
+  if (sdlt_raise_smem((const void*)ta_heat_kernel, 150 * 1024) || sdlt_raise_smem((const void*)ta_grad_kernel, 150 * 1024))
+    SDLT_FAIL(SDLT_ERR_LAUNCH, "sdlt_token_attention_loss: cannot raise the dynamic LDS limit");
   hipLaunchKernelGGL(ta_colsum_kernel, dim3(nch, p.B), dim3(256), 0, s, p, nch);
   hipLaunchKernelGGL(ta_heat_kernel, dim3(p.n_tok, p.B), dim3(256), smem, s, p, nch);
   hipLaunchKernelGGL(ta_grad_kernel, dim3(p.n_tok, p.B), dim3(256), smem, s, p, nch);

@@ -826,11 +826,8 @@ int launch(const sdlt_gemm_params& p, hipStream_t stream) {
     SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: tile %dx%d with LoRA rank pad %d does not fit the 160 KB LDS", BM, BN, R16 * 16);
   } else {
   const int smem = NBUF * STAGE + TSH;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_kernel<MI, NI, WN, MODE, R16, NS, KG, BT, WM, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  if (sdlt_raise_smem((const void*)gemm_kernel<MI, NI, WN, MODE, R16, NS, KG, BT, WM, EPI>, smem))
+    SDLT_FAIL(SDLT_ERR_LAUNCH, "sdlt_gemm_bf16: cannot raise the dynamic LDS limit to %d bytes", smem);
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   const int splitk = p.splitk > 1 ? p.splitk : 1;
   if (splitk > 1) {

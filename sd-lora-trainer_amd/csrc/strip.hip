@@ -330,11 +330,7 @@ int launch_strip(const sdlt_strip_params& p, hipStream_t s) {
   constexpr int SLOT = (XROWS + 16 * J) * ROWB;
   const int smem = NW * R * SLOT;          // >= the reduction scratch NW * MB * J * 64 * 16 + statistics
   static_assert(NW * R * SLOT >= NW * MB * J * 64 * 16 + NW * MB * 16 * 2 * 4 && NW * R * SLOT <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)strip_kernel<J, LN, R>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  if (sdlt_raise_smem((const void*)strip_kernel<J, LN, R>, smem)) SDLT_FAIL(SDLT_ERR_LAUNCH, "sdlt_strip_gemm: cannot raise the dynamic LDS limit to %d bytes", smem);
   const int S = p.splitk > 1 ? p.splitk : 1;
   if (S > 1 && !p.P) {
     const size_t need = (size_t)p.B * (p.N / (16 * J)) * S * (MB * J * 64 * (LN ? 24 : 16));
@@ -351,11 +347,7 @@ template <int J, bool LN, int R>
 int launch_strip_pair(const sdlt_strip_params& a, const sdlt_strip_params& b, hipStream_t s) {
   constexpr int SLOT = (XROWS + 16 * J) * ROWB;
   const int smem = NW * R * SLOT;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)strip_pair_kernel<J, LN, R>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  if (sdlt_raise_smem((const void*)strip_pair_kernel<J, LN, R>, smem)) SDLT_FAIL(SDLT_ERR_LAUNCH, "sdlt_strip_gemm_pair: cannot raise the dynamic LDS limit to %d bytes", smem);
   const int ga = (a.N / (16 * J)) * (a.splitk > 1 ? a.splitk : 1), gb = (b.N / (16 * J)) * (b.splitk > 1 ? b.splitk : 1);
   hipLaunchKernelGGL((strip_pair_kernel<J, LN, R>), dim3(ga > gb ? ga : gb, a.B > b.B ? a.B : b.B, 2), dim3(64 * NW), smem, s, a, b);
   SDLT_CHECK_LAUNCH();

@@ -273,11 +273,7 @@ int launch_wsk(const wsk_params& p, hipStream_t s) {
   constexpr int RED = NW * (MBK * JN + KG * MBK) * 1024 + KG * MBK * 64 * 8;
   constexpr int smem = NW * R * SLOT > RED ? NW * R * SLOT : RED;
   static_assert(smem <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)wsk_kernel<MBK, JN, R, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  if (sdlt_raise_smem((const void*)wsk_kernel<MBK, JN, R, KG>, smem)) SDLT_FAIL(SDLT_ERR_LAUNCH, "sdlt_wsk_gemm: cannot raise the dynamic LDS limit to %d bytes", smem);
   const int tiles = (p.M / (16 * MBK)) * (p.N / (16 * JN));
   hipLaunchKernelGGL((wsk_kernel<MBK, JN, R, KG>), dim3(tiles), dim3(64 * NW), smem, s, p);
   SDLT_CHECK_LAUNCH();
@@ -300,8 +296,9 @@ extern "C" int sdlt_wsk_gemm(const void* X, int64_t ldx, const void* W, int64_t 
     SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_gemm: operand alignment");
   if (Adown && (!Bup || (ld_adown % 8) || ((uintptr_t)Adown & 15) || (ld_bup % 4) || ((uintptr_t)Bup & 7) || (T_out && ((ld_t % 4) || ((uintptr_t)T_out & 7)))))
     SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_gemm: adapter operands (Adown [16, K] 16-byte rows, Bup [N, 16] / T_out [M, 16] 8-byte rows)");
+  static const int stagger_env = getenv("SDLT_WSK_STAGGER") ? atoi(getenv("SDLT_WSK_STAGGER")) : 1;   // (read once: A/B switch)
   wsk_params p{(const bf16_t*)X, ldx, (const bf16_t*)W, ldw, bias, (const bf16_t*)R, ldr, (bf16_t*)Y, ldy, M, N, K, 1,
-               (const bf16_t*)Adown, ld_adown, (const bf16_t*)Bup, ld_bup, (bf16_t*)T_out, ld_t, lora_scale, lora_group_k, getenv("SDLT_WSK_STAGGER") ? atoi(getenv("SDLT_WSK_STAGGER")) : 1};
+               (const bf16_t*)Adown, ld_adown, (const bf16_t*)Bup, ld_bup, (bf16_t*)T_out, ld_t, lora_scale, lora_group_k, stagger_env};
   hipStream_t s = (hipStream_t)stream;
   if (!Adown) return launch_wsk<4, 5, 2, 0>(p, s);
   if (lora_group_k <= 0) return launch_wsk<4, 5, 2, 1>(p, s);

@@ -27,8 +27,14 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match():
     lib = _lib.load()
-    for which, cls in enumerate((_lib.GemmParams, _lib.LoraGradDesc, _lib.AttnParams, _lib.GroupNormParams, _lib.ShadowDesc)):
-        assert lib.sdlt_struct_size(which) == ctypes.sizeof(cls)
+    sizes = _lib.struct_sizes()
+    # every `typedef struct` of the header has an entry (16 at the time of writing), and nothing beyond the table answers
+    import re
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sdlt_kernels.h")).read()
+    assert len(sizes) == len(set(re.findall(r"typedef struct (sdlt_\w+)", header))), "a struct of the header is missing from sdlt_struct_size / _lib.struct_sizes"
+    for which, (name, size) in enumerate(sizes):
+        assert lib.sdlt_struct_size(which) == size, name
+    assert lib.sdlt_struct_size(len(sizes)) == -1
 
 
 def test_errors_are_reported_not_swallowed():

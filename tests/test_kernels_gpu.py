@@ -344,6 +344,11 @@ ATTN_CASES = [
     dict(B=1, H=2, Nq=128, Nk=128, Nkp=128, d=160, causal=False, qsplit=1),
     dict(B=1, H=4, Nq=128, Nk=128, Nkp=128, d=80, causal=False, qsplit=1),
     dict(B=2, H=2, Nq=77, Nk=77, Nkp=80, d=64, causal=True, qsplit=1),
+    # whole 64-row tiles at head width 64: the 32-rows-per-wave kernels (attn32.hip) - odd tile counts per wave group, one tile, more keys than queries
+    dict(B=1, H=3, Nq=128, Nk=320, Nkp=320, d=64, causal=False, qsplit=1),
+    dict(B=1, H=2, Nq=192, Nk=64, Nkp=64, d=64, causal=False, qsplit=1),
+    dict(B=2, H=1, Nq=576, Nk=576, Nkp=576, d=64, causal=False, qsplit=1),
+    dict(B=1, H=20, Nq=1024, Nk=1024, Nkp=1024, d=64, causal=False, qsplit=1),
 ]
 
 
@@ -1171,9 +1176,11 @@ def _count_paired(ops, gens, prefer):
 
 
 @pytest.mark.parametrize("env,select", [(dict(SDLT_XATTN_ROLES="0"), "test_attention_fwd_bwd"), (dict(SDLT_XATTN_ROLES="0", SDLT_XATTN_FIVE="0"), "test_attention_fwd_bwd"),
-                                        (dict(SDLT_ATTN_XCD="0", SDLT_ATTN_KS="1"), "test_attention_fwd_bwd"),
+                                        (dict(SDLT_ATTN_XCD="0", SDLT_ATTN_KS="1", SDLT_ATTN_R32="0"), "test_attention_fwd_bwd"),
+                                        (dict(SDLT_ATTN32_KS_FWD="4", SDLT_ATTN32_KS_BWD="4"), "test_attention_fwd_bwd"),
+                                        (dict(SDLT_ATTN32_KS_FWD="1", SDLT_ATTN32_KS_BWD="1"), "test_attention_fwd_bwd"),
                                         (dict(SDLT_WSK_STAGGER="0", SDLT_STRIP_WIDE_MIN="4096"), "test_wsk or test_strip")],
-                         ids=["single-role", "single-role-128-keys", "plain-order-unsplit", "unstaggered-narrow-strips"])
+                         ids=["single-role", "single-role-128-keys", "plain-order-unsplit-16-rows", "attn32-four-groups", "attn32-one-group", "unstaggered-narrow-strips"])
 def test_fallback_kernel_paths_in_a_subprocess(env, select):
     """The A/B switches are read once per process, so the non-default kernels behind them (single-role / 128-key cross-attention backward,
     plain workgroup order, unsplit attention forward, unstaggered wave-split-K refills, 16-column strips) run in a child pytest: the same

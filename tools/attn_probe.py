@@ -18,6 +18,7 @@ def timeit(fn, reps=10):
     return e0.elapsed_time(e1) * 1e3 / (5 * reps)
 for (name, B, H, Nq, Nk, Nkp, d) in [("self N1024 H20", 1, 20, 1024, 1024, 1024, 64), ("self N4096 H10", 1, 10, 4096, 4096, 4096, 64),
                                      ("cross N1024 H20", 1, 20, 1024, 77, 80, 64), ("cross N4096 H10", 1, 10, 4096, 77, 80, 64),
+                                     ("self N256 H20 (sdxl 512)", 4, 20, 256, 256, 256, 64), ("self N1024 H10 (sdxl 512)", 4, 10, 1024, 1024, 1024, 64),
                                      ("sd15 self N4096 H8 d40", 4, 8, 4096, 4096, 4096, 40)]:
     C = H * d
     r = lambda n: torch.randn(B * n, C, device="cuda").to(BF)
