@@ -87,6 +87,11 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   const bf16_t* asrc = LORA ? p.Adown + (int64_t)srow * p.ld_adown + schunk * 8 : nullptr;
   const int64_t x8 = 8 * p.ldx, w8 = 8 * p.ldw, a8 = 8 * p.ld_adown;
   char* ring = smem + wave * (R * SLOT);
+  // column tile tn starts its K walk `rot` steps in (the 16 tiles of a row block do not ask the L2 for the same X lines at the same time).  The
+  // fp32 K sums are therefore ordered per tile: Y is a fixed function of the operands per tile (bitwise reproducible), but the adapter's
+  // T = s X Adown^T, which every tile recomputes for itself, can differ between tiles in the last bit of its fp32 sum, i.e. rarely by one bf16 ulp
+  // after rounding; T_out (the copy the adapter-gradient launch reads) is tile 0's (rot = 0, the plain K order).  That is inside the
+  // rounding of T itself (2^-9 relative) - the parity tests compare Y and the adapter gradients with that tolerance.
   const int rot = tn - div_small_u(tn, nsteps) * nsteps;
   auto issue = [&](int i, int slot) -> int {
     int ii = i + rot;

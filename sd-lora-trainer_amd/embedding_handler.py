@@ -47,7 +47,9 @@ class TokenEmbeddingsHandler:
         return {f"txt_encoder_{i}": r for i, r in enumerate(self.ti.rows)}
 
     def save_embeddings(self, file_path, txt_encoder_keys=("clip_l", "clip_g")):
-        save_file({txt_encoder_keys[i]: r.detach().float().cpu().contiguous() for i, r in enumerate(self.ti.rows)}, file_path)
+        """The trained rows in the dtype of the encoder's embedding table, as the reference saves `token_embedding.weight.data[train_ids]`
+        (embedding_handler.py:401-422: the table lives in `weight_type`, bf16 by default) - not the fp32 master rows."""
+        save_file({txt_encoder_keys[i]: r.detach().to(self.encoders[i].table.dtype).cpu().contiguous() for i, r in enumerate(self.ti.rows)}, file_path)
 
     def load_embeddings(self, file_path, txt_encoder_keys=("clip_l", "clip_g")):
         self.ti.load_rows(_load_embeddings(file_path, txt_encoder_keys))

@@ -45,13 +45,57 @@ class LoraConfig:
     use_dora: bool = False
 
 
-class DAAMScores:
-    """Stand-in for an installed `DAAMLossAttnProcessor2_0` (ti_cross_attn_loss.py:114-230): after a forward,
-    `.cross_attention_scores` is sum_heads(Q K^T / sqrt(d)) [B, N, 77] of that layer - fp32 and, like the reference's, part of the
-    autograd graph of the call that produced it."""
+try:                                    # with diffusers installed the default processors ARE diffusers' class, so the reference's
+    from diffusers.models.attention_processor import AttnProcessor2_0          # `isinstance(module, AttnProcessor2_0)` holds as it stands
+except Exception:                       # (this image has no diffusers: a class of the same name)
+    class AttnProcessor2_0:
+        """Default processor object of an attention node (diffusers' `AttnProcessor2_0` in name and role): the engine's fused
+        attention kernels do the work, the object only marks the place where a replacement can be installed."""
 
-    def __init__(self, name):
+
+class DAAMScores(AttnProcessor2_0):
+    """What sits at `<...>.attn2.processor` until something else is installed there.  Whatever object is found at that attribute after
+    a forward - this one, or the reference's `DAAMLossAttnProcessor2_0(name)` put there by `init_daam_loss` with `setattr`
+    (ti_cross_attn_loss.py:336-364) - receives `.cross_attention_scores` = sum_heads(Q K^T / sqrt(d)) [B, N, 77] of that layer: fp32 and,
+    like the reference's (ti_cross_attn_loss.py:197-212), part of the autograd graph of the call that produced it."""
+
+    def __init__(self, name=None):
         self.name, self.cross_attention_scores = name, None
+
+
+class _Node:
+    """One level of the module tree the reference walks by dotted names (`get_module_by_name` = reduce(getattr, name.split(".")),
+    ti_cross_attn_loss.py:326-333): children by attribute (`node.attentions`), by string index (`getattr(node, "0")`, what the dotted walk
+    does on an nn.ModuleList) and by `node[0]`; a missing child raises AttributeError like a module would."""
+
+    def __init__(self):
+        object.__setattr__(self, "_children", {})
+
+    def __getattr__(self, name):
+        try:
+            return object.__getattribute__(self, "_children")[name]
+        except KeyError:
+            raise AttributeError(name) from None
+
+    def __setattr__(self, name, value):
+        self._children[name] = value
+
+    def __getitem__(self, i):
+        return self._children[str(i)]
+
+    def __len__(self):
+        return len(self._children)
+
+    def __iter__(self):
+        return iter(self._children.values())
+
+    def _descend(self, path):
+        node = self
+        for part in path:
+            if part not in node._children:
+                node._children[part] = _Node()
+            node = node._children[part]
+        return node
 
 
 class _UNetFn(torch.autograd.Function):
@@ -139,8 +183,15 @@ class UNetModule:
         self.unet = UNet(self.rt, cfg, state_dict, lora_rank=lc.r, lora_alpha_multiplier=lc.lora_alpha / lc.r, use_dora=lc.use_dora)
         self.config = dict(cfg)
         self.keep_daam_maps = False
-        hooked = [a for a in self.unet.cross_attns if a.hooked]
-        self.daam_processors = [DAAMScores(a.name + ".processor") for a in hooked]
+        # seam 2 as the reference installs it: `down_blocks.i.attentions.j.transformer_blocks.k.attn2.processor` (and up_blocks / mid_block)
+        # are real attributes; `find_attnprocessor2_0` / `init_daam_loss` (ti_cross_attn_loss.py:88-112, 336-364) walk and replace them
+        self._tree = _Node()
+        self._hooked_nodes = []
+        for a in self.unet.cross_attns:
+            node = self._tree._descend(a.name.split("."))
+            node.processor = DAAMScores(a.name + ".processor")
+            if a.hooked:                # (the mid block's attn2 exists in the tree but the reference never walks it: no score map is produced there)
+                self._hooked_nodes.append(node)
         self._params, self._names = [], []
         for e in self.unet.arena.entries:
             for key, nm in (("A", "lora_A.weight"), ("B", "lora_B.weight")) + ((("M", "lora_magnitude_vector"),) if lc.use_dora else ()):
@@ -150,6 +201,17 @@ class UNetModule:
         self._dirty, self._bufs = True, {}
 
     # ---- nn.Module-shaped surface ------------------------------------------------------------------------------------
+    def __getattr__(self, name):        # (only reached for names that are not ordinary attributes: the block lists of the module tree)
+        tree = self.__dict__.get("_tree")
+        if tree is not None and name in tree._children:
+            return tree._children[name]
+        raise AttributeError(name)
+
+    @property
+    def daam_processors(self):
+        """The objects currently installed at the hooked attn2 layers' `.processor`, in the order `find_attnprocessor2_0` finds them."""
+        return [n.processor for n in self._hooked_nodes]
+
     device = property(lambda self: self.rt.device)
     dtype = property(lambda self: self.rt.act)
 
@@ -200,8 +262,14 @@ class UNetModule:
         self._versions = vers
         if not torch.is_tensor(timestep):
             timestep = torch.tensor([timestep] * sample.shape[0])
-        out, *maps = _UNetFn.apply(self, sample, timestep, encoder_hidden_states, te, tid, *self._params)
-        for proc, S in zip(self.daam_processors, maps):
+        procs = self.daam_processors
+        installed = any(type(p) is not DAAMScores for p in procs)      # something was put there with setattr (init_daam_loss): it wants its maps
+        keep, self.keep_daam_maps = self.keep_daam_maps, (self.keep_daam_maps or installed)
+        try:
+            out, *maps = _UNetFn.apply(self, sample, timestep, encoder_hidden_states, te, tid, *self._params)
+        finally:
+            self.keep_daam_maps = keep
+        for proc, S in zip(procs, maps):
             proc.cross_attention_scores = S
         if return_dict:
             import types

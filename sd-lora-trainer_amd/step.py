@@ -52,11 +52,17 @@ class TextStack:
         """The step's ids as gathers from per-caption tables on the device (train()): one launch per encoder + two for the pooling rows
         (set_ids: a copy per encoder and five launches for argmax / arange / scale / add / copy)."""
         for dst, tab in zip(self.ids, tables):
-            torch.index_select(tab, 0, sel, out=dst)
+            if tab.dtype == dst.dtype and tab.shape[1:] == dst.shape[1:]:
+                torch.index_select(tab, 0, sel, out=dst)
+            else:                                        # (an id table from a cache that holds int32 ids: index_select's out= does not convert)
+                dst.copy_(tab[sel])
         if getattr(self, "_pool_base", None) is None:
             self._pool_base = torch.arange(self.pool_rows.shape[0], device=self.pool_rows.device) * TP
             self._pool_tmp = torch.zeros_like(self.pool_rows)
-        torch.index_select(pool_pos_table, 0, sel, out=self._pool_tmp)
+        if pool_pos_table.dtype == self._pool_tmp.dtype:
+            torch.index_select(pool_pos_table, 0, sel, out=self._pool_tmp)
+        else:
+            self._pool_tmp.copy_(pool_pos_table[sel])
         torch.add(self._pool_base, self._pool_tmp, out=self.pool_rows)
 
     def set_ids(self, ids_per_encoder):
@@ -327,9 +333,13 @@ class TrainStep:
                 if getattr(self, "_train_ids_host", None) is None:
                     self._train_ids_host = self.text.encoders[0].train_ids.tolist()
                 self.ta.set_captions(caption_token_lists, self._train_ids_host)
-        if self.time_ids is not None and time_ids is not None and time_ids is not getattr(self, "_time_ids_src", None):
-            self.time_ids.copy_(time_ids.reshape(-1))  # (a job passes the same tensor every step: copied once)
-            self._time_ids_src = time_ids
+        if self.time_ids is not None and time_ids is not None:
+            # a job passes the same tensor every step: copied once.  The key is (object, storage, version counter), so a caller that
+            # rewrites its tensor in place between steps (per-batch crop / size conditioning) is seen
+            key = (id(time_ids), time_ids.data_ptr(), time_ids._version)
+            if key != getattr(self, "_time_ids_key", None):
+                self.time_ids.copy_(time_ids.reshape(-1))
+                self._time_ids_key, self._time_ids_src = key, time_ids
 
     def set_hyper(self, lr, lr_ti=0.0, lr_te=0.0):
         """Host scalars of this optimiser step -> device buffers (see sdlt_adamw_fused).

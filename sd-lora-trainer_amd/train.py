@@ -544,7 +544,7 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
                 smp = post_std[idx].mul_(eps).add_(post_mean[idx])                      # mean + std * noise (separately rounded, as DiagonalGaussian.sample)
                 latent = torch.mul(smp, cfg["scaling_factor"], out=ts.latent)
             else:
-                latent = torch.index_select(data_d, 0, idx, out=ts.latent) if data_d.dtype == ts.latent.dtype else data_d[idx]
+                latent = torch.index_select(data_d, 0, idx, out=ts.latent) if data_d.dtype == ts.latent.dtype and data_d.shape[1:] == ts.latent.shape[1:] else data_d[idx]
             noise = torch.randn(ts.noise.shape, generator=gd, device=dev, out=ts.noise)
             if config.noise_offset > 0.0:                                                # main.py:313-317
                 noise += config.noise_offset * torch.randn((B, 4, 1, 1), generator=gd, device=dev)

@@ -203,3 +203,70 @@ def run_shim_token_attention(version, B, h, rt, tol, sd=None):
 def test_token_attention_loss_through_shim_cpu(version, B):
     rt = unet_mod.Runtime("cpu", B, act_dtype=torch.float32, ops=emu_ops)
     run_shim_token_attention(version, B, 16, rt, dict(loss=1e-3, cos=0.9999))
+
+
+def _walk_and_install(unet, make_processor):
+    """What `find_attnprocessor2_0` + `init_daam_loss` do to a diffusers UNet (ti_cross_attn_loss.py:88-112, 336-364), restated: probe the
+    dotted names `<down|up>_blocks.i.attentions.j.transformer_blocks.k.attn2.processor` by getattr (AttributeError = does not exist), require the
+    found object to be an `AttnProcessor2_0`, replace it with setattr on its parent and read it back."""
+    from functools import reduce
+    by_name = lambda root, name: reduce(getattr, name.split("."), root)
+    found = []
+    for kind in ("down_blocks", "up_blocks"):
+        for i in range(6):
+            for j in range(6):
+                for k in range(12):
+                    name = f"{kind}.{i}.attentions.{j}.transformer_blocks.{k}.attn2.processor"
+                    try:
+                        obj = by_name(unet, name)
+                    except AttributeError:
+                        continue
+                    assert type(obj).__mro__[1].__name__ == "AttnProcessor2_0" or type(obj).__name__ == "AttnProcessor2_0", type(obj)
+                    assert isinstance(obj, shim.AttnProcessor2_0)
+                    found.append(name)
+    installed = []
+    for name in found:
+        parent, attr = name.rsplit(".", 1)
+        proc = make_processor(name)
+        setattr(by_name(unet, parent), attr, proc)
+        assert by_name(unet, name) is proc
+        installed.append(proc)
+    return found, installed
+
+
+@pytest.mark.parametrize("version,B", [("tinyxl", 1), ("tiny15", 2)])
+def test_processor_seam_installed_by_module_path_cpu(version, B):
+    """VERDICT r3 'Seam 2 as the reference installs it': the reference's hook installer finds the attn2 processors by module path on the
+    shim and the objects it puts there receive the score maps (in the graph) on the next call - no `keep_daam_maps` flag needed."""
+    class Installed:                 # stands for DAAMLossAttnProcessor2_0(name): a foreign class with the two attributes the reference reads
+        def __init__(self, name):
+            self.name, self.cross_attention_scores = name, None
+
+    rt = unet_mod.Runtime("cpu", B, act_dtype=torch.float32, ops=emu_ops)
+    cfg = U.CONFIGS[version]
+    sd = {k: v.to(torch.bfloat16).float() for k, v in U.init_unet_state(cfg, seed=0).items()}
+    unet = shim.get_peft_model(version, sd, shim.LoraConfig(r=8, lora_alpha=8.0), batch_size=B, runtime=rt)
+    unet.unet.arena.load(U.init_lora(cfg, 8, seed=1, b_std=0.03))
+    unet.requires_grad_(True)
+    hooked = [a.name for a in unet.unet.cross_attns if a.hooked]
+    found, installed = _walk_and_install(unet, Installed)
+    assert found == [n + ".processor" for n in hooked] and len(found) > 0
+    assert not any(n.startswith("mid_block") for n in found)
+    assert unet.down_blocks[int(found[0].split(".")[1])].attentions[0].transformer_blocks[0].attn2.processor is installed[0]      # index access too
+    with pytest.raises(AttributeError):
+        unet.down_blocks.no_such_child
+    add = {"text_embeds": torch.zeros(B, cfg["proj_class_in"] - 6 * cfg["addition_time_embed_dim"]), "time_ids": torch.tensor([[1024., 1024, 0, 0, 128, 128]] * B)} if cfg["addition"] else None
+    ehs = torch.randn(B, 77, cfg["cross_dim"], requires_grad=True)
+    x, t = torch.randn(B, 4, 16, 16), torch.tensor([500] * B)
+    assert unet.keep_daam_maps is False
+    pred = unet(x, t, encoder_hidden_states=ehs, added_cond_kwargs=add)[0]
+    with torch.no_grad():
+        _, daam = U.unet_forward(cfg, sd, x, t, ehs.detach(), add, lora=dict(unet.unet.arena.export()), return_daam=True)
+    assert len(daam) == len(installed)
+    for proc, (name, s) in zip(installed, daam):
+        assert proc.name == name + ".processor" and proc.cross_attention_scores.requires_grad
+        torch.testing.assert_close(proc.cross_attention_scores.detach(), s, rtol=2e-3, atol=2e-3)
+    # a loss on the installed processors' maps alone reaches the text conditioning through the module's backward
+    sum(p.cross_attention_scores.float().pow(2).mean() for p in installed).backward()
+    assert ehs.grad is not None and float(ehs.grad.abs().max()) > 0
+    assert unet.keep_daam_maps is False
