@@ -152,6 +152,16 @@ __device__ __forceinline__ FragOff frag_offsets(int lane) {
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
+// -DSDLT_ATTN32_TRACE (tools/attn32_trace.py): lane 0 of wave 0 of the first workgroup of a role stamps clock64() at the phase boundaries of its
+// loop into `trace_buf` (forward: p.D, backward: p.dK32 - both unused by these kernels otherwise; dQ role slots 0.., dK / dV role 512..)
+#ifdef SDLT_ATTN32_TRACE
+#define TR32_DECL(BUF_, ON_) long long* tr_ = (long long*)(BUF_); int tn_ = 0; const bool tron_ = (ON_) && tr_ != nullptr
+#define TR32() do { if (tron_ && tn_ < 500) { __builtin_amdgcn_sched_barrier(0); tr_[tn_++] = clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define TR32_DECL(BUF_, ON_)
+#define TR32() do { } while (0)
+#endif
+
 // =============================================================================== forward
 template <int KS>
 __global__ __launch_bounds__(128 * KS) void attn32_fwd_kernel(const sdlt_attn_params p) {
@@ -184,8 +194,11 @@ __global__ __launch_bounds__(128 * KS) void attn32_fwd_kernel(const sdlt_attn_pa
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
   const float sl2 = p.scale * LOG2E;
+  TR32_DECL(p.D, wg.x == 0 && wg.y == 0 && wg.z == 0 && threadIdx.x == 0);
+  TR32();
   wait_dma_barrier();
   for (int it = 0; it < niter; ++it) {
+    TR32();
     const int t = it * KS + grp;
     const char* Ks = ring + (it & 1) * (2 * TILE);
     const char* Vs = Ks + TILE;
@@ -194,6 +207,7 @@ __global__ __launch_bounds__(128 * KS) void attn32_fwd_kernel(const sdlt_attn_pa
       tile_dma(Kb + (int64_t)(t + KS) * 64 * p.ldk, p.ldk, nb, w2, lane);
       tile_dma(Vb + (int64_t)(t + KS) * 64 * p.ldv, p.ldv, nb + TILE, w2, lane);
     }
+    TR32();
     if (t < ntile) {
       const uint32_t ka = lds_addr(Ks), va = lds_addr(Vs);
       bf16x8 k0f[4], k1f[4];
@@ -218,6 +232,7 @@ __global__ __launch_bounds__(128 * KS) void attn32_fwd_kernel(const sdlt_attn_pa
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) s[1] = MFMA32(k1f[kk], qf[kk], s[1]);
       __builtin_amdgcn_sched_barrier(0);
+      TR32();
       float tmax = s[0][0];
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk)
@@ -227,6 +242,8 @@ __global__ __launch_bounds__(128 * KS) void attn32_fwd_kernel(const sdlt_attn_pa
       const float mn = fmaxf(m, tmax * sl2);
       const float alpha = __builtin_amdgcn_exp2f(m - mn);
       m = mn;
+      // (v_pk_fma_f32 / v_pk_add_f32 over score pairs and a wave-uniform skip of the rescale were measured: 25 % fewer VALU instructions, the
+      // same time to 0.3 us on every shape - packed f32 issues at half rate next to MFMAs, MI355X_MICROARCH.md)
       float rs = 0.f;
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk)
@@ -242,6 +259,7 @@ __global__ __launch_bounds__(128 * KS) void attn32_fwd_kernel(const sdlt_attn_pa
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
       __builtin_amdgcn_sched_barrier(0);
+      TR32();
       wait_lgkm<0>();
 #pragma unroll
       for (int ch = 0; ch < 4; ++ch) tr_pin(vt[ch]);
@@ -252,8 +270,10 @@ __global__ __launch_bounds__(128 * KS) void attn32_fwd_kernel(const sdlt_attn_pa
         for (int db = 0; db < 2; ++db) o[db] = MFMA32(tr_get(vt[ch], db), pf, o[db]);
       }
     }
+    TR32();
     wait_dma_barrier();
   }
+  TR32();
   lsum = half_sum(lsum);
   if constexpr (KS > 1) {
     // (m, l, O) of groups 1.. -> LDS -> group 0, in group order (the rings are dead after the last barrier)
@@ -334,8 +354,11 @@ __device__ __forceinline__ void attn32_dq_body(const sdlt_attn_params& p, char* 
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
   const float sl2 = p.scale * LOG2E;
+  TR32_DECL(p.dK32, bx == 0 && wg.y == 0 && wg.z == 0 && threadIdx.x == 0);
+  TR32();
   wait_dma_barrier();
   for (int it = 0; it < niter; ++it) {
+    TR32();
     const int t = it * KS + grp;
     const char* Ks = ring + (it & 1) * (2 * TILE);
     const char* Vs = Ks + TILE;
@@ -344,6 +367,7 @@ __device__ __forceinline__ void attn32_dq_body(const sdlt_attn_params& p, char* 
       tile_dma(Kb + (int64_t)(t + KS) * 64 * p.ldk, p.ldk, nb, w2, lane);
       tile_dma(Vb + (int64_t)(t + KS) * 64 * p.ldv, p.ldv, nb + TILE, w2, lane);
     }
+    TR32();
     if (t < ntile) {
       const uint32_t ka = lds_addr(Ks), va = lds_addr(Vs);
       bf16x8 kr[2][4], vr[2][4];
@@ -370,12 +394,14 @@ __device__ __forceinline__ void attn32_dq_body(const sdlt_attn_params& p, char* 
           rows_issue<1>(vr[1], va, fo.row);
         }
         __builtin_amdgcn_sched_barrier(0);
+        TR32();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sl2, -Lq));
           s[r] = pv * (dp[r] - Dq);      // dS / scale (the softmax scale multiplies the finished dQ rows once)
         }
         __builtin_amdgcn_sched_barrier(0);
+        TR32();
         if (blk == 0) wait_lgkm<8>(); else wait_lgkm<0>();
         tr_pin(kt[blk][0]);
         tr_pin(kt[blk][1]);
@@ -389,10 +415,12 @@ __device__ __forceinline__ void attn32_dq_body(const sdlt_attn_params& p, char* 
           tr_issue<2>(kt[1][0], ka, fo.t1, fo.t2);
           tr_issue<3>(kt[1][1], ka, fo.t1, fo.t2);
         }
+        TR32();
       }
     }
     wait_dma_barrier();
   }
+  TR32();
   if constexpr (KS > 1) {
     float* mg = (float*)smem + (((grp - 1) * 2 + w2) * 64 + lane) * 36;
     if (grp > 0) {
@@ -466,14 +494,18 @@ __device__ __forceinline__ void attn32_dkdv_body(const sdlt_attn_params& p, char
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
   const float sl2 = p.scale * LOG2E;
+  TR32_DECL(p.dK32 ? p.dK32 + 1024 : nullptr, bx == 0 && wg.y == 0 && wg.z == 0 && threadIdx.x == 0);
+  TR32();
   wait_dma_barrier();
   for (int it = 0; it < niter; ++it) {
+    TR32();
     const int t = it * KS + grp;
     const char* Qs = ring + (it & 1) * (2 * TILE + 512);
     const char* Gs = Qs + TILE;
     const float* Ls = (const float*)(Gs + TILE);
     const float* Ds = Ls + 64;
     if (t + KS < ntile) stage(t + KS, ring + ((it + 1) & 1) * (2 * TILE + 512));
+    TR32();
     if (t < ntile) {
       const uint32_t qa = lds_addr(Qs), ga = lds_addr(Gs);
       bf16x8 qr[2][4], gr[2][4];
@@ -503,6 +535,7 @@ __device__ __forceinline__ void attn32_dkdv_body(const sdlt_attn_params& p, char
           tr_issue<3>(qt[1][1], qa, fo.t1, fo.t2);
         }
         __builtin_amdgcn_sched_barrier(0);
+        TR32();
         // s[r] = S[query blk*32 + 16*(r>>3) + 8*hl + (r&7)][key]
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
@@ -518,6 +551,7 @@ __device__ __forceinline__ void attn32_dkdv_body(const sdlt_attn_params& p, char
           }
         }
         __builtin_amdgcn_sched_barrier(0);
+        TR32();
         wait_lgkm<8>();           // chunk 0's pieces (chunk 1's are the newest 8)
         tr_pin(gt[blk][0]);
         tr_pin(qt[blk][0]);
@@ -548,10 +582,12 @@ __device__ __forceinline__ void attn32_dkdv_body(const sdlt_attn_params& p, char
             dk[db] = MFMA32(tr_get(qt[blk][1], db), dsf, dk[db]);
           }
         }
+        TR32();
       }
     }
     wait_dma_barrier();
   }
+  TR32();
   if constexpr (KS > 1) {
     float* mg = (float*)smem + (((grp - 1) * 2 + w2) * 64 + lane) * 68;
     if (grp > 0) {
