@@ -116,12 +116,15 @@ def run_guarded(argv, timeout_s):
     return res
 
 
-def cpu_baseline(version, rank, full_hw, budget_s=100.0):
-    """The fp32 oracle (oracle/: CPU port of the reference path - diffusers-style UNet + peft LoRA restatement, the reference's
-    loss) timed on this host's cores: forward + backward to every LoRA tensor and to the text conditioning, 1 warm-up + timed
-    steps at the LARGEST resolution of {full, full/2, full/4} whose three steps fit the time budget (calibrated on a quick pass
-    at the smallest one), torch.set_num_threads(all cores).  Returns a dict for the JSON line."""
-    from oracle import loss_ref as L
+def cpu_baseline(version, rank, full_hw, budget_s=150.0, with_text=True):
+    """The fp32 oracle (oracle/: CPU port of the reference path) timed on this host's cores on THE SAME STEP the GPU line times:
+    `oracle.step_ref.RefTrainer.step` = main.py:263-382 - text encoders forward + backward down to the token tables (the installed Hugging
+    Face CLIP classes at the CLIP-L / OpenCLIP-bigG sizes, random init), add_noise, UNet forward + backward to every LoRA tensor, masked /
+    min-SNR MSE, token-attention loss, L1 penalty, std regulariser, gradient masking of the frozen rows, torch.optim.AdamW over the
+    LoRA tensors and over the token tables.  (`with_text=False`, the --no-ti workload: injected conditioning, no text encoders.)
+    1 warm-up + timed steps at the LARGEST resolution of {full, full/2, full/4} whose three steps fit the time budget (calibrated on a
+    quick pass at the smallest one), torch.set_num_threads(all cores).  Returns a dict for the JSON line."""
+    from oracle import step_ref as R
     from oracle import unet_ref as U
     from sd_lora_trainer_amd import topology
     cfg = U.CONFIGS[version]
@@ -136,12 +139,20 @@ def cpu_baseline(version, rank, full_hw, budget_s=100.0):
             t = 1.0 + t
         sd[n] = t
     lora = U.init_lora(cfg, rank, seed=1, b_std=0.01)
-    params, lg = [], {}
-    for k, (A, Bm) in lora.items():
-        A.requires_grad_(True), Bm.requires_grad_(True)
-        lg[k] = (A, Bm)
-        params += [A, Bm]
-    acp = L.ddpm_alphas_cumprod()
+    n_tok, text_models, vocab = 3, None, None
+    if with_text:
+        from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
+        tiny = version.startswith("tiny")
+        kinds = (["tiny_l", "tiny_g"] if tiny else ["clip_l", "clip_g"]) if cfg["addition"] else (["tiny_l"] if tiny else ["clip_l"])
+        text_models = []
+        for kd in kinds:
+            c = topology.CLIP_CONFIGS[kd]
+            vocab = c["vocab"] + n_tok
+            hc = CLIPTextConfig(vocab_size=vocab, hidden_size=c["width"], intermediate_size=c["mlp"], num_hidden_layers=c["layers"], num_attention_heads=c["heads"],
+                                max_position_embeddings=77, hidden_act=c["act"], projection_dim=c["proj"] or 768, eos_token_id=2, bos_token_id=0, pad_token_id=1)
+            text_models.append((CLIPTextModelWithProjection if c["proj"] else CLIPTextModel)(hc).eval())
+    tr = R.RefTrainer(cfg, sd, lora, text_models=text_models, n_tokens=n_tok, train_ids=[vocab - 3, vocab - 2, vocab - 1] if with_text else None,
+                      snr_gamma=5.0, l1_penalty=0.03, weight_decay=0.004)
 
     def one_step(h):
         g = torch.Generator().manual_seed(1)
@@ -149,23 +160,28 @@ def cpu_baseline(version, rank, full_hw, budget_s=100.0):
         noise = torch.randn(1, 4, h, h, generator=g)
         mask = torch.rand(1, 1, h, h, generator=g).repeat(1, 4, 1, 1) * 0.95 + 0.05
         t = torch.tensor([500])
-        ctx = torch.randn(1, 77, cfg["cross_dim"], generator=g).requires_grad_(True)
-        add = None
-        if cfg["addition"]:
-            add = {"text_embeds": torch.randn(1, cfg["proj_class_in"] - 6 * cfg["addition_time_embed_dim"], generator=g),
-                   "time_ids": torch.tensor([[1024., 1024, 0, 0, 8. * h, 8. * h]])}
+        tid = torch.tensor([[1024., 1024, 0, 0, 8. * h, 8. * h]]) if cfg["addition"] else None
+        kw = {}
+        if with_text:                # the caption of the GPU line: BOS, 8 words, the 3 trained tokens in the middle, EOS, padding
+            words = torch.randint(1000 if vocab > 2000 else 10, min(40000, vocab - 10), (8,), generator=g).tolist()
+            bos, eos = (49406, 49407) if vocab > 49407 else (vocab - 5, vocab - 4)
+            l = [bos] + words[:4] + [vocab - 3, vocab - 2, vocab - 1] + words[4:] + [eos]
+            ids = torch.full((1, 77), eos, dtype=torch.int64)
+            ids[0, :len(l)] = torch.tensor(l)
+            kw = dict(ids=ids, caption_token_lists=[l], time_ids=tid, lr_ti=1e-3)
+        else:
+            kw = dict(ctx=torch.randn(1, 77, cfg["cross_dim"], generator=g),
+                      added_cond={"text_embeds": torch.randn(1, cfg["proj_class_in"] - 6 * cfg["addition_time_embed_dim"], generator=g), "time_ids": tid} if cfg["addition"] else None)
         t0 = time.time()
-        noisy = L.add_noise(acp, latent, noise, t)
-        pred = U.unet_forward(cfg, sd, noisy, t, ctx, add, lora=lg)
-        loss = L.diffusion_loss(pred, noise, noisy, mask, acp, t, snr_gamma=5.0)
-        torch.autograd.grad(loss, params + [ctx])
+        tr.step(latent, noise, t, mask, lr=1e-4, **kw)
         return time.time() - t0
 
     flops = lambda h: 2 * topology.fwd_flops(topology.CONFIGS[version], 1, h, h, rank)["total"]  # noqa: E731
+    what = "text encoders + UNet fwd+bwd + losses + both AdamWs" if with_text else "UNet fwd+bwd + losses + AdamW"
     small = max(full_hw // 4, 8)
-    one_step(small)                                      # cold pass (page-in, thread pools)
+    one_step(small)                                      # cold pass (page-in, thread pools, AdamW state)
     t_small = one_step(small)
-    print(json.dumps(dict(times=[t_small], hw=small, flops=flops(small), cores=cores)), flush=True)     # (child mode: a first, complete answer)
+    print(json.dumps(dict(times=[t_small], hw=small, flops=flops(small), cores=cores, what=what)), flush=True)     # (child mode: a first, complete answer)
     # climb small -> full/2 -> full while the next size's warm-up + 2 timed steps still fit what is left of the budget, each estimate
     # scaled by FLOPs from the LAST size measured (small sizes run at a lower rate, so they over-estimate the big ones)
     h, t_h, times, spent = small, t_small, [t_small], 2.0 * t_small
@@ -177,12 +193,12 @@ def cpu_baseline(version, rank, full_hw, budget_s=100.0):
         t0 = time.time()
         one_step(cand)                                   # warm-up at this size
         times = [one_step(cand)]
-        print(json.dumps(dict(times=times, hw=cand, flops=flops(cand), cores=cores)), flush=True)      # (complete answer, should the guard cut the next step)
+        print(json.dumps(dict(times=times, hw=cand, flops=flops(cand), cores=cores, what=what)), flush=True)      # (complete answer, should the guard cut the next step)
         times.append(one_step(cand))
         h, t_h = cand, sum(times) / 2
         spent += time.time() - t0
-        print(json.dumps(dict(times=times, hw=h, flops=flops(h), cores=cores)), flush=True)
-    return dict(times=times, hw=h, flops=flops(h), cores=cores)
+        print(json.dumps(dict(times=times, hw=h, flops=flops(h), cores=cores, what=what)), flush=True)
+    return dict(times=times, hw=h, flops=flops(h), cores=cores, what=what)
 
 
 def train_loop_measure(args):
@@ -284,7 +300,7 @@ def main():
     ap.add_argument("--ddp-wire", default=None, choices=["fp32", "bf16"], help="--full-ft --gpus N: dtype of the matrix gradients on the xGMI wire "
                     "(TrainStep(ddp_wire_dtype=); default fp32 = exact)")
     ap.add_argument("--profile-json", default=None, help="step profile of THIS command (tools/step_profile.py over the rocprofv3 kernel trace + FETCH_SIZE / "
-                    "WRITE_SIZE passes): source of roofline.traffic and roofline.hbm_kernels; default: profiles/r03_sdxl1024_ti_step_profile.json for the default workload")
+                    "WRITE_SIZE passes): source of roofline.traffic and roofline.hbm_kernels; default: the newest profiles/rNN_sdxl1024_ti_step_profile.json for the default workload")
     ap.add_argument("--launch-test", action="store_true", help=argparse.SUPPRESS)            # tests/test_parallel_cpu.py: launcher + timing protocol on CPU
     args = ap.parse_args()
     world_env = int(os.environ.get("WORLD_SIZE", "0") or 0)
@@ -299,7 +315,7 @@ def main():
     if args.cpu_baseline_only:          # child of the default run: prints one JSON object per completed measurement
         version = args.config
         res = args.res or (1024 if "xl" in version else 512)
-        print(json.dumps(cpu_baseline(version, args.rank, res // 8)), flush=True)
+        print(json.dumps(cpu_baseline(version, args.rank, res // 8, with_text=not args.no_ti)), flush=True)
         return
     if args.train_loop_only:
         print(json.dumps(train_loop_measure(args)), flush=True)
@@ -441,11 +457,13 @@ def main():
         achieved = J * f_step / (ev_ms * 1e-3 / args.steps)
         # HBM-side bytes per step and per-family kernel time: measured around the process (PMC counters and the kernel trace need rocprofv3), handed
         # back through --profile-json; the default workload falls back to the committed profile of this round and says which commit it is from
-        traffic = traffic_commit = hbm_kernels = None
+        traffic = traffic_commit = hbm_kernels = families = None
         pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
         default_workload = (version == "sdxl" and res == 1024 and B == 1 and args.rank == 16 and text is not None and not args.ti_frozen and not full_ft
                             and not args.dora and J == 1)
-        ppath = args.profile_json or (os.path.join(pdir, "r03_sdxl1024_ti_step_profile.json") if default_workload else None)
+        import glob
+        committed = sorted(glob.glob(os.path.join(pdir, "r[0-9][0-9]_sdxl1024_ti_step_profile.json")))     # the newest round's committed profile
+        ppath = args.profile_json or (committed[-1] if (default_workload and committed) else None)
         if ppath and os.path.exists(ppath):
             with open(ppath) as fh:
                 prof = json.load(fh)
@@ -459,6 +477,14 @@ def main():
                     moved = prof.get("fetch_bytes_by_family", {}).get(fam, 0.0) + prof.get("write_bytes_by_family", {}).get(fam, 0.0)
                     hbm_kernels[fam] = {"algorithmic_GB": alg[fam] / 1e9, "ms": ms, "GB_per_s": alg[fam] / ms / 1e6, "frac_of_8TBps": alg[fam] / (ms * 1e-3) / 8e12,
                                         "launches": prof.get("family_launches", {}).get(fam), "measured_GB": moved / 1e9 if moved else None}
+            # the MFMA-bound families of the profiled step: algorithmic FLOPs (2 x forward census, like `achieved`) / their kernel time, against 2.5 PF
+            fl = topology.fwd_flops(cfg, B, h, h, args.rank)
+            fam_flop = {"gemm": 2.0 * (fl["total"] - fl["attn_core"] - fl["daam"]), "attention": 2.0 * fl["attn_core"]}
+            families = {}
+            for fam, fpt in fam_flop.items():
+                ms = prof.get("family_ms", {}).get(fam)
+                if ms:
+                    families[fam] = {"ms": ms, "tflop": fpt / 1e12, "frac": fpt / (ms * 1e-3) / PEAK_BF16_DENSE, "launches": prof.get("family_launches", {}).get(fam)}
         elif default_workload:
             tpath = os.path.join(pdir, "r02_sdxl1024_ti_hbm_traffic_pmc.json")
             if os.path.exists(tpath):
@@ -491,16 +517,17 @@ def main():
                        "trained_params": arena.n, "graph": not args.no_graph, "final_loss": loss},
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_DENSE, "traffic": traffic, "traffic_commit": traffic_commit,
-                         "traffic_GB_per_s": (traffic / (ev_ms * 1e-3 / args.steps) / 1e9) if traffic else None, "hbm_kernels": hbm_kernels,
+                         "traffic_GB_per_s": (traffic / (ev_ms * 1e-3 / args.steps) / 1e9) if traffic else None, "hbm_kernels": hbm_kernels, "families": families,
                          "note": f"algorithmic {J} x {f_step / 1e12:.3f} TFLOP per step (2 x fwd census) / {ev_ms / args.steps:.3f} ms "
                                  "per step (HIP events on the replay stream); traffic = HBM-side bytes per step (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, "
-                                 "separate passes) of this command at commit `traffic_commit` (--profile-json, default profiles/r03_sdxl1024_ti_step_profile.json); "
-                                 "hbm_kernels: the HBM-bound kernel families - algorithmic bytes (topology.hbm_bytes) / their time in the profiled step, against 8 TB/s"},
+                                 f"separate passes) of this command at commit `traffic_commit` (--profile-json, here {os.path.basename(ppath) if ppath else None}: the newest committed profiles/rNN_sdxl1024_ti_step_profile.json by default); "
+                                 "hbm_kernels: the HBM-bound kernel families - algorithmic bytes (topology.hbm_bytes) / their time in the profiled step, against 8 TB/s; "
+                                 "families: the MFMA-bound kernel families of the same profiled step - algorithmic TFLOP (2 x fwd census) / their kernel time, against 2.5 PFLOP/s"},
         }
         print(f"[bench] timed region done: {t_step * 1e3:.2f} ms/step; extras follow", file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline and not full_ft:
             # measured in a CHILD process with a wall-clock limit: nothing on the host side may keep the JSON line from being printed
-            child = run_guarded(["--cpu-baseline-only", "--config", version, "--res", str(res), "--rank", str(args.rank)], 420)
+            child = run_guarded(["--cpu-baseline-only", "--config", version, "--res", str(res), "--rank", str(args.rank)] + (["--no-ti"] if args.no_ti else []), 420)
             if child:
                 cb = child[-1]                  # the last complete measurement (full size if it finished, else the calibration sample)
                 dt = sum(cb["times"]) / len(cb["times"])
@@ -508,7 +535,7 @@ def main():
                 same = cb["hw"] == h
                 out["cpu_baseline"] = {"value": 1.0 / scaled, "unit": "images/s", "cores": cb["cores"], "kind": "port",
                                        "step_seconds": [round(x, 3) for x in cb["times"]],
-                                       "sample": f"fp32 oracle (CPU port of the reference path) fwd+bwd steps at {cb['hw'] * 8}x{cb['hw'] * 8} B=1 after a warm-up: "
+                                       "sample": f"fp32 oracle (CPU port of the reference path, oracle.step_ref.RefTrainer.step: {cb.get('what', 'UNet fwd+bwd')} - the step the GPU line times) at {cb['hw'] * 8}x{cb['hw'] * 8} B=1 after a warm-up: "
                                                  + ", ".join(f"{x:.2f} s" for x in cb["times"]) + f" ({cb['flops'] / 1e12:.2f} TFLOP each, {cb['cores']} threads)"
                                                  + ("" if same else f"; scaled by the FLOP ratio to the {res}x{res} workload (the full size did not fit the time budget of the default run)")}
             print("[bench] cpu baseline done", file=sys.stderr, flush=True)
