@@ -175,8 +175,8 @@ def _set(ts, b, xl, h, n_enc):
 # separates the HIP path from the fp32 reference is NOT dominated by where activations are rounded, so the bars below sit 2-3x above the
 # measurements for both (round 2: cos 0.99 / rel 8 % on the flat vector only).  LoRA displacement after 6 AdamW steps: cos 0.970 (SDXL: Adam turns the
 # noise of the near-zero gradients into +-lr moves) / 0.9995 (SD1.5); floor 0.95 (round 2: 0.9).
-TOL_BF16 = dict(pred=3e-2, loss=2e-2, ta=5e-2, reg=5e-2, cos=0.9995, rel=3e-2, rows_cos=0.999, rows_rel=5e-2, disp_cos=0.95, rows_final=2e-2, ada_rel=0.2)
-TOL_FAITHFUL = dict(pred=3e-2, loss=8e-3, cos=0.9995, rel=3e-2, rows_cos=0.999, rows_rel=5e-2, ada_rel=0.2)
+TOL_BF16 = dict(pred=3e-2, loss=2e-2, ta=5e-2, reg=5e-2, cos=0.9995, rel=3e-2, rows_cos=0.999, rows_rel=5e-2, disp_cos=0.95, rows_final=2e-2, ada_rel=0.12)
+TOL_FAITHFUL = dict(pred=3e-2, loss=8e-3, cos=0.9995, rel=3e-2, rows_cos=0.999, rows_rel=5e-2, ada_rel=0.12)
 TOL_FP32 = dict(pred=2e-3, loss=1e-3, ta=2e-3, reg=2e-3, cos=0.9999, rel=5e-3, rows_cos=0.9999, rows_rel=1e-2, disp_cos=0.99, rows_final=1e-3, ada_rel=2e-2)
 TOL_FP32_FAITHFUL = dict(pred=3e-2, loss=2e-2, cos=0.99, rel=8e-2, rows_cos=0.985, rows_rel=0.2, ada_rel=0.45)     # (fp32 engine vs rounded oracle: the bf16 bars)
 REPORT = {}        # case -> worst adapters etc., written to gpurun_out/parity_report.json when that directory exists
@@ -390,20 +390,48 @@ def _case_full_size_properties(version, B, h):
     assert torch.equal(rows1, ts.ti.params)
 
 
-def _case_fullft_real_sdxl_topology():
-    """(d) cfg5's model: full fine-tune of the real SDXL UNet, batch 2 at a 32 x 32 latent - the gradient of every one of the
-    2,567,463,684 parameters against autograd through the fp32 oracle; then graph replays train."""
-    if not torch.cuda.is_available():
-        pytest.skip("needs a GPU")
+# Full fine-tune, per parameter tensor: gradient cosine against oracle autograd >= FULLFT_TENSOR_COS for every tensor whose gradient is at least
+# FULLFT_WEAK_RMS of the median tensor's rms.  The tensors below that - measured: only self-attention to_q / to_k weights deep in the 1280-wide
+# stacks, whose gradient is 0.4-0.7 % of the median (the softmax of a random-init model is near uniform, so d loss / d scores nearly cancels) - sit on
+# the bf16 noise of the dS that feeds them: floor FULLFT_WEAK_COS, they must match FULLFT_WEAK_NAMES, and every tensor below FULLFT_TENSOR_COS is
+# listed BY NAME with its rms ratio in the parity report (profiles/r04_parity_report.json -> `*fullft*` -> below_099).  Measured: 32 x 32 batch 2 worst
+# tensor 0.9979 (0 below 0.99); 64 x 64 batch 1: 15 such q / k tensors at 0.972-0.99 (rms ratio 0.004-0.007), everything else >= 0.99.
+FULLFT_TENSOR_COS, FULLFT_WEAK_RMS, FULLFT_WEAK_COS = 0.99, 0.01, 0.95
+FULLFT_WEAK_NAMES = (".attn1.to_q.weight", ".attn1.to_k.weight")
+
+
+def _write_report():
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        import json
+        with open(os.path.join(out_dir, "parity_report.json"), "w") as fh:
+            json.dump(REPORT, fh, indent=1)
+
+
+def _fullft_inputs(cfg, B, h, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    latent = torch.randn(B, 4, h, h, generator=g) * cfg["scaling_factor"]
+    noise = torch.randn(B, 4, h, h, generator=g)
+    mask = (torch.rand(B, 1, h, h, generator=g) * 0.95 + 0.05).repeat(1, 4, 1, 1).contiguous()
+    t = torch.tensor([10, 900, 500, 730][:B])
+    ctx = torch.randn(B, 77, cfg["cross_dim"], generator=g)
+    pooled = torch.randn(B, cfg["proj_class_in"] - 6 * cfg["addition_time_embed_dim"], generator=g)
+    tid = torch.tensor([[1024., 1024, 0, 0, 8. * h, 8. * h]] * B)
+    return latent, noise, mask, t, ctx, pooled, tid, {"text_embeds": pooled, "time_ids": tid}
+
+
+def _fullft_compare(version, B, h, case):
+    """One full fine-tune step of the real topology: the gradient of EVERY parameter tensor against autograd through the fp32 oracle - the flat
+    2.57 G-vector (cos, rel L2) and every tensor on its own (cosine >= FULLFT_TENSOR_COS unless named in FULLFT_LOW_COS_OK; the ten worst go to
+    the parity report).  Returns (TrainStep, WeightTrainer) for the caller's replay checks."""
     from oracle import unet_ref as U
     from sd_lora_trainer_amd import fullft, topology
     import sd_lora_trainer_amd.step as S
     import sd_lora_trainer_amd.unet as M
-    from tests.test_fullft_cpu import _inputs, oracle_grads
-    version, B, h = "sdxl", 2, 32
+    from tests.test_fullft_cpu import oracle_grads
     cfg = U.CONFIGS[version]
     sd = _unet_state(version)
-    latent, noise, mask, t, ctx, pooled, tid, add = _inputs(cfg, B, h)
+    latent, noise, mask, t, ctx, pooled, tid, add = _fullft_inputs(cfg, B, h)
     pred_o, loss_o, grads_o = oracle_grads(cfg, sd, latent, noise, t, mask, ctx, add)
     rt = M.Runtime("cuda:0", B)
     tr = fullft.WeightTrainer(rt)
@@ -414,23 +442,39 @@ def _case_fullft_real_sdxl_topology():
     ts.set_batch(dv(latent), dv(noise), dv(t), dv(mask), dv(ctx), dv(pooled), dv(tid))
     pred = ts.forward_backward().float().cpu().reshape(B, h, h, 4).permute(0, 3, 1, 2)
     torch.cuda.synchronize()
-    assert float((pred - pred_o).abs().max()) <= 4e-2 * float(pred_o.abs().max())
-    assert abs(float(ts.loss) - loss_o) <= 2e-2 * abs(loss_o)
+    perr = float((pred - pred_o).abs().max()) / float(pred_o.abs().max())
     got = tr.export("grads")
-    names = list(grads_o)
     num = den_a = den_b = dif = 0.0
-    worst = (1.0, None)
-    for k in names:            # streamed: the flat concatenation would be another 2 x 10 GB
+    per = []
+    for k in list(grads_o):            # streamed: the flat concatenation would be another 2 x 10 GB
         a, b_ = got[k].reshape(-1).double(), grads_o[k].reshape(-1).double()
         ab, aa, bb = float(a @ b_), float(a @ a), float(b_ @ b_)
         num, den_a, den_b, dif = num + ab, den_a + aa, den_b + bb, dif + float((a - b_) @ (a - b_))
         if b_.numel() >= 64 and bb > 0:
-            c = ab / math.sqrt(aa * bb + 1e-300)
-            worst = min(worst, (c, k))
+            per.append((ab / math.sqrt(aa * bb + 1e-300), k, b_.numel(), math.sqrt(bb / b_.numel())))
     cos, rel = num / math.sqrt(den_a * den_b), math.sqrt(dif / den_b)
-    assert cos >= 0.99 and rel <= 8e-2, f"all-parameter gradient: cos {cos} rel {rel}"
-    assert worst[0] >= 0.95, worst
+    per.sort()
+    med_rms = sorted(x[3] for x in per)[len(per) // 2]
+    below = [dict(cos=round(c, 5), name=k, rms_over_median=round(r / med_rms, 4)) for c, k, n, r in per if c < FULLFT_TENSOR_COS]
+    REPORT[case] = dict(below_099=below, B=B, latent=h, pred_err=perr, loss_rel=abs(float(ts.loss) - loss_o) / abs(loss_o), all_parameter_cos=cos, all_parameter_rel=rel, n_tensors=len(per),
+                        n_tensors_below_0999=sum(1 for x in per if x[0] < 0.999), n_tensors_below_099=sum(1 for x in per if x[0] < 0.99),
+                        worst_tensors=[dict(cos=round(c, 5), name=k, numel=n, rms_over_median=round(r / med_rms, 4)) for c, k, n, r in per[:10]])
+    _write_report()
+    assert perr <= 3e-2, perr
+    assert abs(float(ts.loss) - loss_o) <= 1e-2 * abs(loss_o)
+    assert cos >= 0.999 and rel <= 4e-2, f"all-parameter gradient: cos {cos} rel {rel}"
+    low = [(c, k, r / med_rms) for c, k, _, r in per if c < FULLFT_TENSOR_COS and not (r / med_rms < FULLFT_WEAK_RMS and k.endswith(FULLFT_WEAK_NAMES) and c >= FULLFT_WEAK_COS)]
+    assert not low, f"parameter tensors with gradient cosine < {FULLFT_TENSOR_COS} (cos, name, rms / median): {low[:10]}"
     del got, grads_o
+    return ts, tr
+
+
+def _case_fullft_real_sdxl_topology():
+    """(d) cfg5's model: full fine-tune of the real SDXL UNet, batch 2 at a 32 x 32 latent - the gradient of every one of the
+    2,567,463,684 parameters against autograd through the fp32 oracle; then graph replays train."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    ts, _ = _fullft_compare("sdxl", 2, 32, "sdxl-fullft-gradients-32x32-b2")
     ts.capture(warmup=1)
     losses = []
     for i in range(6):
@@ -439,9 +483,43 @@ def _case_fullft_real_sdxl_topology():
     assert all(x == x for x in losses) and losses[-1] < losses[0], losses
 
 
+def _case_fullft_baseline_size():
+    """cfg5 at its BASELINE size (SDXL 512 px = 64 x 64 latent, batch 4 per GPU, full_finetuning_example.json): one whole step - every parameter's
+    gradient against oracle autograd at exactly that size - then the size-independent properties on the same job: the hipGraph replay reproduces
+    the eager gradients, the optimizer state advances, the loss of the fixed batch goes down."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    ts, tr = _fullft_compare("sdxl", 4, 64, "sdxl-fullft-gradients-64x64-b4")
+    nm = tr.n_mat                      # the matrix / conv weights (the vector tail - biases, norm affines - is cleared after the optimizer step)
+    g_eager, loss_eager = tr.grads[:nm].clone(), float(ts.loss)
+    assert torch.isfinite(tr.grads).all() and float(g_eager.abs().max()) > 0
+    ts.capture(warmup=1)
+    p0 = tr.params[:nm].clone()
+    ts.run(2e-5)
+    torch.cuda.synchronize()
+    assert abs(float(ts.loss) - loss_eager) <= 2e-3 * abs(loss_eager), (float(ts.loss), loss_eager)
+    ga = tr.grads[:nm]
+    ab = aa = bb = 0.0
+    for o in range(0, nm, 1 << 28):            # (2.57 G elements: torch.dot indexes with 32 bits)
+        x, y = ga[o:o + (1 << 28)].double(), g_eager[o:o + (1 << 28)].double()
+        ab, aa, bb = ab + float(x @ y), aa + float(x @ x), bb + float(y @ y)
+    cosg = ab / math.sqrt(aa * bb)
+    assert cosg >= 0.9999, f"graph replay vs eager weight gradients: cos {cosg}"
+    del g_eager
+    losses = [loss_eager]
+    for i in range(6):
+        ts.run(2e-5)
+        losses.append(float(ts.loss))
+    torch.cuda.synchronize()
+    assert all(x == x for x in losses) and losses[-1] < losses[0], losses
+    assert float((tr.params[:nm] - p0).abs().max()) > 0
+    REPORT["sdxl-fullft-64x64-b4-properties"] = dict(losses=losses, graph_vs_eager_grad_cos=cosg)
+    _write_report()
+
+
 # Ordered so that each 10 GB weight state is built once: all SDXL cases, then all SD1.5 cases.
 @pytest.mark.parametrize("case", ["sdxl-step-trajectory", "sdxl-dora-step-trajectory", "sdxl-rank24-step", "sdxl-full-size", "sdxl-full-size-step-parity",
-                                  "sdxl-fullft-gradients", "sd15-step-trajectory", "sd15-dora-step-trajectory", "sd15-rank64-step", "sd15-full-size",
+                                  "sdxl-fullft-gradients", "sdxl-fullft-baseline-size", "sd15-step-trajectory", "sd15-dora-step-trajectory", "sd15-rank64-step", "sd15-full-size",
                                   "sd15-full-size-step-parity"])
 def test_real_topology(case):
     if case == "sdxl-step-trajectory":
@@ -462,6 +540,8 @@ def test_real_topology(case):
         _case_full_size_properties("sdxl", 1, 128)
     elif case == "sdxl-fullft-gradients":
         _case_fullft_real_sdxl_topology()
+    elif case == "sdxl-fullft-baseline-size":      # cfg5 at its BASELINE size (64 x 64 latent, batch 4): the whole step against oracle autograd + replay properties
+        _case_fullft_baseline_size()
     elif case == "sd15-step-trajectory":
         _case_step_and_trajectory("sd15", 4, case=case)
     else:

@@ -1,12 +1,13 @@
 """Latent sampler on the MI355X (bf16 HIP UNet in inference mode, batch 2 = negative | positive) against the fp32 oracle loop:
 Euler trailing, guidance 8, LoRA scale 0.75.  Guidance 8 amplifies the bf16 noise of two forwards per step, hence cosine >=
-0.99 / relative L2 <= 0.12 on the final latents after 6 steps."""
+0.999 / relative L2 <= 0.06 on the final latents after 6 steps (the full 25 steps, after training, down to the decoded image: tests/test_e2e_image_gpu.py)."""
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
-TOL_COS, TOL_REL = 0.99, 0.12
+# measured (profiles/r04_parity_report_sampler.json): cos 0.99953-0.99972, rel 2.4-3.1 % on the four topologies; the bars at twice that
+TOL_COS, TOL_REL = 0.999, 0.06
 
 
 @pytest.mark.parametrize("version", ["tiny15", "tinyxl", "sd15", "sdxl"])
