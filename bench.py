@@ -296,7 +296,7 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)      # child modes of the guarded extras
     ap.add_argument("--train-loop-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--full-ft", action="store_true", help="full-UNet fine-tune (BASELINE configs[4], train_configs/full_finetuning_example.json: "
-                    "SDXL 512 px, batch 4 per GPU, AdamW over every UNet parameter); data parallel with one gradient all-reduce per step when --gpus > 1")
+                    "SDXL 512 px, batch 4 per GPU, AdamW over every UNet parameter); data parallel when --gpus > 1: per-bucket reduce-scatter, sharded AdamW, all-gather (SDLT_DDP_ZERO1=0: all-reduce)")
     ap.add_argument("--ddp-wire", default=None, choices=["fp32", "bf16"], help="--full-ft --gpus N: dtype of the matrix gradients on the xGMI wire "
                     "(TrainStep(ddp_wire_dtype=); default fp32 = exact)")
     ap.add_argument("--profile-json", default=None, help="step profile of THIS command (tools/step_profile.py over the rocprofv3 kernel trace + FETCH_SIZE / "
@@ -511,7 +511,8 @@ def main():
                                       "std regulariser, rows-only AdamW)" + (" [ti lr = 0: frozen-TI fast path, no text-encoder backward]" if args.ti_frozen else "") if text is not None else ", text conditioning injected (--no-ti)"),
                        "text_encoder_fwd_gflop_not_in_roofline": clip_flops / 1e9,
                        "jobs_per_gpu": J, "global_batch": world * J * B,
-                       "parallelism": (f"dp{world}: bucketed {args.ddp_wire or 'fp32'} gradient all-reduce of {arena.n * (2 if args.ddp_wire == 'bf16' else 4) / 1e9:.1f} GB per step (RCCL), overlapped with the weight-gradient GEMMs" if (full_ft and world > 1)
+                       "parallelism": ((f"dp{world}: per bucket {args.ddp_wire or 'fp32'} gradient " + ("reduce-scatter, AdamW on 1/" + str(world) + " of the arena per rank, fp32 all-gather of the masters" if getattr(ts, "zero1", False) else "all-reduce")
+                                        + f" ({arena.n * (2 if args.ddp_wire == 'bf16' else 4) / 1e9:.1f} GB of gradients per step, RCCL), overlapped with the weight-gradient GEMMs") if (full_ft and world > 1)
                                        else f"job-parallel x{world * J} ({world} GPU(s) x {J} independent job(s) per GPU, no collective)"
                                             + (f"; a step advances every job once ({J} images per GPU and step), ms_per_step is per such step" if J > 1 else "")),
                        "trained_params": arena.n, "graph": not args.no_graph, "final_loss": loss},

@@ -88,9 +88,12 @@ class WeightTrainer:
                 e["off"] = self.n
                 self.n += int(torch.tensor(e["shape"]).prod())
             if self.n - start >= self.bucket_floats:
-                self.buckets.append((start, (self.n + 3) // 4 * 4))
-                start = (self.n + 3) // 4 * 4
-        self.n_mat = (self.n + 3) // 4 * 4
+                # bucket ends sit on multiples of 64 floats: every bucket splits into equal, 16-byte aligned shards for 2 / 4 / 8 / 16 ranks
+                # (reduce-scatter / all-gather of the sharded optimizer, enable_zero1); the padding belongs to no tensor and stays zero
+                self.n = (self.n + 63) // 64 * 64
+                self.buckets.append((start, self.n))
+                start = self.n
+        self.n_mat = (self.n + 63) // 64 * 64
         if self.n_mat > start:
             self.buckets.append((start, self.n_mat))
         for e in self.entries:
@@ -126,6 +129,46 @@ class WeightTrainer:
         self._plan.adamw(self.params, self.grads, self.m, self.v, hyper)
         if self.nv:
             ops.adamw_fused(self.params[nm:], self.grads[nm:], self.m[nm:], self.v[nm:], hyper, None)
+
+    # ------------------------------------------------------------------ sharded optimizer state (data parallel, ZeRO-1)
+    def enable_zero1(self, rank, world):
+        """Data-parallel full fine-tune with the optimizer sharded over the ranks (the reference has no data parallelism to cite:
+        full_finetuning_example.json names the workload).  Rank r owns the r-th of `world` equal slices of EVERY gradient bucket: the exchange
+        step becomes reduce-scatter (each rank receives the summed gradients of its slices only) -> AdamW over the owned slices (p, g, m, v of
+        1 / world of the matrices: 72 GB -> 72 / world GB of optimizer traffic per step on SDXL) -> all-gather of the updated fp32 masters ->
+        the bf16 operand refresh of all matrices (20 GB).  Wire bytes equal the all-reduce's (which is a reduce-scatter + an all-gather);
+        the moments exist for the owned slices only (2 x 10.3 GB -> 2 x 10.3 / world GB).  Every master element is computed by exactly
+        one rank and copied to the others: replicas are bit-identical by construction.  The vector region (biases, norm affine parameters:
+        0.1 % of the arena) stays replicated: all-reduce + the same AdamW everywhere."""
+        assert self.params is not None and all((o1 - o0) % (4 * world) == 0 for o0, o1 in self.buckets), (world, self.buckets[:3])
+        self.z_rank, self.z_world = rank, world
+        self.z_chunk = [(o1 - o0) // world for o0, o1 in self.buckets]
+        self.z_soff = [0]
+        for c in self.z_chunk:
+            self.z_soff.append(self.z_soff[-1] + c)
+        ns, nm, dev = self.z_soff[-1], self.n_mat, self.rt.device
+        self.m_sh, self.v_sh = torch.zeros(ns, dtype=F32, device=dev), torch.zeros(ns, dtype=F32, device=dev)
+        self.m_vec, self.v_vec = self.m[nm:].clone(), self.v[nm:].clone()
+        self.m = self.v = None           # the full-size moments are released
+
+    def shard_range(self, b):
+        """[s0, s1) of the arena: this rank's slice of bucket b."""
+        o0, c = self.buckets[b][0], self.z_chunk[b]
+        return o0 + self.z_rank * c, o0 + (self.z_rank + 1) * c
+
+    def opt_state(self):
+        return [self.m, self.v] if self.m is not None else [self.m_sh, self.v_sh, self.m_vec, self.v_vec]
+
+    def adamw_shard_step(self, hyper):
+        """AdamW over the owned slices (their summed gradients sit in `grads` after the in-place reduce-scatter) and over the replicated
+        vector region; the masters of the other ranks' slices are stale until the all-gather, the bf16 operands until `refresh`."""
+        ops, nm = self.rt.ops, self.n_mat
+        for b in range(len(self.buckets)):
+            s0, s1 = self.shard_range(b)
+            so = self.z_soff[b]
+            ops.adamw_fused(self.params[s0:s1], self.grads[s0:s1], self.m_sh[so:so + s1 - s0], self.v_sh[so:so + s1 - s0], hyper, None)
+        if self.nv:
+            ops.adamw_fused(self.params[nm:], self.grads[nm:], self.m_vec, self.v_vec, hyper, None)
 
     def zero_vector_grads(self):
         """Once per backward: bias and norm-affine gradients are accumulated (fp32 atomics) by the kernels that produce them."""

@@ -190,7 +190,7 @@ class TrainStep:
                  weight_decay=0.004, grad_accum=1, betas=(0.9, 0.999), eps=1e-8, text: TextStack = None, n_tokens=3,
                  token_attention_loss_w=3e-7, ti_weight_decay=0.0, ti_std_loss_w=0.01, optimizer="adamw", ti_optimizer="adamw",
                  prodigy_d_coef=1.0, prodigy_growth_rate=1.05, text_lora_weight_decay=1e-5, process_group=None,
-                 cond_reg_w=0.0, tok_cov_reg_w=0.0, cond_target_norm=None, tok_cond_reg_w=0.0, reg_caption_ids=None, ddp_wire_dtype=None):
+                 cond_reg_w=0.0, tok_cov_reg_w=0.0, cond_target_norm=None, tok_cond_reg_w=0.0, reg_caption_ids=None, ddp_wire_dtype=None, ddp_zero1=None):
         """process_group: data-parallel full fine-tune only (`unet.trainer` set) - a torch.distributed group (or True for the
         default one) over which the gradient arena is all-reduced once per optimiser step (RCCL on the GPU)."""
         if optimizer == "AdamW8bit":
@@ -225,6 +225,12 @@ class TrainStep:
             wire = ddp_wire_dtype or _os.environ.get("SDLT_DDP_WIRE", "fp32")
             assert wire in ("fp32", "bf16"), wire
             self.wire = torch.empty(unet.trainer.n_mat, dtype=torch.bfloat16, device=rt.device) if (wire == "bf16" and self.bucketed) else None
+            # the exchange step: reduce-scatter -> AdamW on this rank's 1 / world of every bucket -> all-gather of the masters -> operand refresh
+            # (fullft.WeightTrainer.enable_zero1); ddp_zero1=False / SDLT_DDP_ZERO1=0: all-reduce + the full AdamW on every rank (A/B)
+            z = ddp_zero1 if ddp_zero1 is not None else (_os.environ.get("SDLT_DDP_ZERO1", "1") != "0")
+            self.zero1 = bool(z) and self.bucketed and optimizer == "adamw"
+            if self.zero1:
+                unet.trainer.enable_zero1(dist.get_rank(self.pg), self.world)
             if self.world > 1 and (optimizer == "prodigy" or (text is not None and ti_optimizer == "prodigy")):
                 raise NotImplementedError("data-parallel full fine-tune with Prodigy: its d-estimate is not scale free, the summed gradients would "
                                           "need their own normalisation - use AdamW / AdamW8bit (full_finetuning_example.json does)")
@@ -499,9 +505,19 @@ class TrainStep:
         if self.ti is not None:      # token-row gradients (a few KB): complete after the backward graph, exchanged beside the first bucket
             works.append((dist.all_reduce(self.ti.grads, group=self.pg, async_op=True), None, None))
         wire = getattr(self, "wire", None)
+        zero1 = getattr(self, "zero1", False)
         for b, (o0, o1) in enumerate(tr.buckets):
             (flush_fns[b] if flush_fns is not None else (lambda b=b: tr.flush(bucket=b)))()
-            if wire is not None:
+            if zero1:
+                # reduce-scatter IN PLACE (output = this rank's slice of the input: the form RCCL runs without a staging copy): after it
+                # grads[s0:s1] holds the sum over the ranks, the rest of the bucket is scratch until the next backward overwrites it
+                s0, s1 = tr.shard_range(b)
+                if wire is not None:
+                    wire[o0:o1].copy_(tr.grads[o0:o1])       # pack: fp32 -> bf16; only the owned slice is unpacked afterwards
+                    works.append((dist.reduce_scatter_tensor(wire[s0:s1], wire[o0:o1], group=self.pg, async_op=True), s0, s1))
+                else:
+                    works.append((dist.reduce_scatter_tensor(tr.grads[s0:s1], tr.grads[o0:o1], group=self.pg, async_op=True), None, None))
+            elif wire is not None:
                 o1w = min(o1, tr.n_mat)
                 wire[o0:o1w].copy_(tr.grads[o0:o1w])           # pack: fp32 -> bf16, queued behind the bucket's GEMMs
                 works.append((dist.all_reduce(wire[o0:o1w], group=self.pg, async_op=True), o0, o1w))
@@ -514,8 +530,37 @@ class TrainStep:
             if o0 is not None:
                 tr.grads[o0:o1w].copy_(wire[o0:o1w])            # unpack: the optimizer reads fp32 sums
 
+    def gather_params(self):
+        """ZeRO-1, after the sharded AdamW: every bucket's updated master slices -> all ranks (all-gather in place: the input is this rank's slice
+        of the output), outside the hipGraphs like every collective of the path."""
+        import torch.distributed as dist
+        tr = self.group
+        works = []
+        for b, (o0, o1) in enumerate(tr.buckets):
+            s0, s1 = tr.shard_range(b)
+            works.append(dist.all_gather_into_tensor(tr.params[o0:o1], tr.params[s0:s1], group=self.pg, async_op=True))
+        for w in works:
+            w.wait()
+
+    def _opt_shard_phase(self):
+        """ZeRO-1 optimizer, first half (one hipGraph): AdamW over the owned slices + every replicated optimizer of the step."""
+        self.group.adamw_shard_step(self.hyper)
+        self._other_optimizers()
+
+    def _opt_post_phase(self):
+        """ZeRO-1 optimizer, second half (one hipGraph, after gather_params): fp32 masters -> the bf16 W / W^T operands of every matrix."""
+        self.group.refresh()
+
     def optimizer_step(self):
+        if getattr(self, "zero1", False):
+            self._opt_shard_phase()
+            self.gather_params()
+            self._opt_post_phase()
+            return
         self._unet_optimizer()
+        self._other_optimizers()
+
+    def _other_optimizers(self):
         if self.ti is not None:                        # a17: the trainable token rows only
             t = self.ti
             if self.prodigy_ti is not None:
@@ -551,9 +596,10 @@ class TrainStep:
         self.optimizer_step()
 
     def _phases(self):
-        if self.world > 1 and self.bucketed:   # forward+backward | per bucket: weight gradients, all-reduce (outside the graphs) | optimizer
+        if self.world > 1 and self.bucketed:   # forward+backward | per bucket: weight gradients, exchange (outside the graphs) | optimizer
             tr = self.group
-            return [self.forward_backward] + [(lambda b=b: tr.flush(bucket=b)) for b in range(len(tr.buckets))] + [self.optimizer_step]
+            opt = [self._opt_shard_phase, self._opt_post_phase] if getattr(self, "zero1", False) else [self.optimizer_step]     # (the all-gather sits between the two)
+            return [self.forward_backward] + [(lambda b=b: tr.flush(bucket=b)) for b in range(len(tr.buckets))] + opt
         if self.world > 1:         # the collective stays outside the graphs: forward+backward | all-reduce | optimizer
             return [lambda: (self.forward_backward(), self._accumulate(True)), self.optimizer_step]
         if self._acc is not None:
@@ -649,7 +695,7 @@ class TrainStep:
         plan), then captures it: one hipGraph for the whole step (one per phase when the text encoders run on forked
         streams), plus the frozen-TI variant.  AdamW state is restored afterwards so capture does not count as training."""
         a = self.group
-        state = [a.params, a.m, a.v] + ([self.ti.params, self.ti.m, self.ti.v] if self.ti is not None else [])
+        state = [a.params] + (a.opt_state() if hasattr(a, "opt_state") else [a.m, a.v]) + ([self.ti.params, self.ti.m, self.ti.v] if self.ti is not None else [])
         if self.te_arena is not None:
             state += [self.te_arena.params, self.te_arena.m, self.te_arena.v]
         snap = [t.clone() for t in state]
@@ -720,9 +766,16 @@ class TrainStep:
         self.set_hyper(lr, lr_ti, lr_te)
         # frozen-TI fast path (Prodigy with lr 0 is a no-op as well: sdlt_prodigy_step); never with text-encoder LoRA, whose
         # gradients need the text backward for the whole run
-        frozen = self.text is not None and lr_ti == 0.0 and self.te_arena is None and self._acc is None
+        # (not under data parallelism: the exchange step lives in body() / the per-bucket graphs, and the eager frozen branch below would skip it)
+        frozen = self.text is not None and lr_ti == 0.0 and self.te_arena is None and self._acc is None and self.world == 1
         self._frozen_last = frozen
-        if self.graph is not None and self.world > 1 and self.bucketed:
+        if self.graph is not None and self.world > 1 and self.bucketed and getattr(self, "zero1", False):
+            self.graphs[0].replay()
+            self.flush_and_reduce([g.replay for g in self.graphs[1:-2]])
+            self.graphs[-2].replay()
+            self.gather_params()
+            self.graphs[-1].replay()
+        elif self.graph is not None and self.world > 1 and self.bucketed:
             self.graphs[0].replay()
             self.flush_and_reduce([g.replay for g in self.graphs[1:-1]])
             self.graphs[-1].replay()

@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, zero1=True):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     from oracle import unet_ref as U
@@ -35,13 +35,14 @@ def _worker(rank, world, port, out):
     tr = fullft.WeightTrainer(rt)
     tr.bucket_floats = 150_000
     unet = unet_mod.UNet(rt, topology.CONFIGS["tinyxl"], sd, trainer=tr)
-    ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, process_group=True)
-    assert ts.bucketed and len(tr.buckets) >= 3
+    ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, process_group=True, ddp_zero1=zero1)
+    assert ts.bucketed and len(tr.buckets) >= 3 and ts.zero1 == zero1
     s = slice(rank, rank + 1)
     dv = lambda x: x.cuda() if x is not None else None  # noqa: E731
     ts.set_batch(dv(latent[s]), dv(noise[s]), dv(t[s]), dv(mask[s]), dv(ctx[s]), dv(pooled[s]), dv(tid[s]))
     ts.capture(warmup=1)
-    assert len(ts.graphs) == len(tr.buckets) + 2          # forward+backward | one per bucket | optimizer
+    # forward+backward | one per bucket | optimizer  (ZeRO-1: sharded AdamW | all-gather outside the graphs | operand refresh)
+    assert len(ts.graphs) == len(tr.buckets) + (3 if zero1 else 2)
     losses = []
     for i in range(6):
         ts.run(2e-4)
@@ -52,13 +53,16 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_bucketed_ddp_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("zero1", [True, False])
+def test_bucketed_ddp_two_ranks_on_one_gpu(zero1):
+    """zero1 (default): reduce-scatter per bucket -> AdamW on the owned slices -> all-gather of the masters -> operand refresh;
+    zero1 = False: all-reduce per bucket -> the full AdamW on every rank."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     ctx_mp = mp.get_context("spawn")
     q = ctx_mp.Queue()
     port = _free_port()
-    procs = [ctx_mp.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx_mp.Process(target=_worker, args=(r, 2, port, q, zero1)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=600) for _ in procs), key=lambda x: x[0])

@@ -65,7 +65,7 @@ def test_timing_protocol_two_ranks_gloo():
 
 
 # ------------------------------------------------------------------------------------------------ data-parallel full fine-tune
-def _ddp_worker(rank, world, port, out, wire="fp32"):
+def _ddp_worker(rank, world, port, out, wire="fp32", zero1=True):
     """Each rank holds ONE sample of a 2-sample batch; after the gradient all-reduce (sum, mean folded into the optimizer's
     gradient scale) both ranks must hold the parameters a single process gets from the full batch."""
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -85,24 +85,52 @@ def _ddp_worker(rank, world, port, out, wire="fp32"):
     tr = fullft.WeightTrainer(rt)
     tr.bucket_floats = 150_000          # several buckets on the toy model: weight gradients + all-reduce bucket by bucket
     unet = unet_mod.UNet(rt, topology.CONFIGS["tiny15"], sd, trainer=tr)
-    ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=0.0, process_group=True, ddp_wire_dtype=wire)
-    assert (ts.wire is not None) == (wire == "bf16")
+    ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=0.0, process_group=True, ddp_wire_dtype=wire, ddp_zero1=zero1)
+    assert (ts.wire is not None) == (wire == "bf16") and ts.zero1 == zero1
+    if zero1:          # the moments exist for the owned slices only; every bucket splits evenly
+        assert tr.m is None and tr.m_sh.numel() * world == tr.n_mat and all((o1 - o0) % (4 * world) == 0 for o0, o1 in tr.buckets)
     assert ts.bucketed and len(tr.buckets) >= 4 and tr.buckets[0][0] == 0 and tr.buckets[-1][1] == tr.n_mat
     assert all(a[1] == b[0] for a, b in zip(tr.buckets, tr.buckets[1:]))          # contiguous cover of the matrix region
     s = slice(rank, rank + 1)
     for _ in range(2):
         ts.set_batch(latent[s], noise[s], t[s], mask[s], ctx[s])
         ts.run(1e-3)
-    out.put((rank, tr.params.numpy().copy(), float(ts.loss), tr.grads.numpy().copy()))      # numpy: pickled through the pipe (a shared-memory tensor dies with the worker)
+    own = [tr.shard_range(b) for b in range(len(tr.buckets))] if zero1 else None
+    out.put((rank, tr.params.numpy().copy(), float(ts.loss), tr.grads.numpy().copy(), own, tr.n_mat))      # numpy: pickled through the pipe (a shared-memory tensor dies with the worker)
     torch.distributed.destroy_process_group()
 
 
 import pytest
 
 
-@pytest.mark.parametrize("wire", ["fp32", "bf16"])
-def test_fullft_data_parallel_two_ranks_gloo(wire):
-    """wire = bf16: the matrix gradients are packed to bf16 per bucket before the all-reduce and unpacked after it (TrainStep(ddp_wire_dtype=)):
+def _run_ddp(wire, zero1):
+    ctx_mp = mp.get_context("spawn")
+    q = ctx_mp.Queue()
+    port = _free_port()
+    procs = [ctx_mp.Process(target=_ddp_worker, args=(r, 2, port, q, wire, zero1)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_fullft_zero1_equals_allreduce_two_ranks_gloo():
+    """The sharded exchange (reduce-scatter -> AdamW on 1 / world of every bucket -> all-gather of the masters -> operand refresh) leaves the
+    SAME BITS as all-reduce + the full AdamW on every rank: with two ranks the sum a + b has one order, AdamW is element-wise, and the
+    masters of a slice are computed once and copied.  (With more ranks the two collectives may order their sums differently.)"""
+    z, a = _run_ddp("fp32", True), _run_ddp("fp32", False)
+    assert torch.equal(torch.from_numpy(z[0][1]), torch.from_numpy(z[1][1])), "ZeRO-1 replicas diverged"
+    assert torch.equal(torch.from_numpy(z[0][1]), torch.from_numpy(a[0][1])), "sharded optimizer != replicated optimizer"
+    assert z[0][2] == a[0][2] and z[1][2] == a[1][2]
+
+
+@pytest.mark.parametrize("wire,zero1", [("fp32", True), ("bf16", True), ("fp32", False), ("bf16", False)])
+def test_fullft_data_parallel_two_ranks_gloo(wire, zero1):
+    """zero1 (the default): reduce-scatter + sharded AdamW + all-gather; zero1 = False: all-reduce + replicated AdamW.
+    wire = bf16: the matrix gradients are packed to bf16 per bucket before the exchange and unpacked after it (TrainStep(ddp_wire_dtype=)):
     replicas still bit-identical, the reduced gradient equals the full-batch gradient to bf16 precision."""
     from oracle import unet_ref as U
     from sd_lora_trainer_amd import fullft, topology
@@ -110,16 +138,7 @@ def test_fullft_data_parallel_two_ranks_gloo(wire):
     from sd_lora_trainer_amd import unet as unet_mod
     from tests import emu_ops
     from tests.test_fullft_cpu import _inputs
-    ctx_mp = mp.get_context("spawn")
-    q = ctx_mp.Queue()
-    port = _free_port()
-    procs = [ctx_mp.Process(target=_ddp_worker, args=(r, 2, port, q, wire)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted((q.get(timeout=300) for _ in procs), key=lambda x: x[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ddp(wire, zero1)
     # single process, both samples in one batch
     cfg, h = U.CONFIGS["tiny15"], 16
     sd = U.init_unet_state(cfg, seed=0)
@@ -135,7 +154,13 @@ def test_fullft_data_parallel_two_ranks_gloo(wire):
     p0, p1 = torch.from_numpy(res[0][1]), torch.from_numpy(res[1][1])
     assert torch.equal(p0, p1), "ranks diverged"
     # the all-reduced arena holds the SUM of the ranks' gradients = 2 x the gradient of the batch-mean loss
-    g_ddp, g_one = torch.from_numpy(res[0][3]) / 2, tr.grads
+    g_ddp, g_one = torch.from_numpy(res[0][3]).clone(), tr.grads
+    if zero1:           # after the reduce-scatter a rank holds the sums of its own slices only: assemble the reduced arena from the owners
+        for r in range(2):
+            for s0, s1 in res[r][4]:
+                g_ddp[s0:s1] = torch.from_numpy(res[r][3])[s0:s1]
+        assert sum(s1 - s0 for r in range(2) for s0, s1 in res[r][4]) == res[0][5]          # the slices of the two ranks tile the matrix region
+    g_ddp = g_ddp / 2
     if wire == "bf16":      # two bf16 roundings (the pack, the sum over the ranks) of each rank's share: 2^-8 of the addends
         assert float((g_ddp - g_one).norm() / g_one.norm()) <= 6e-3
         assert float((g_ddp - g_one).abs().max()) <= 1e-2 * float(g_one.abs().max())
@@ -176,9 +201,12 @@ def _train_ddp_worker(rank, world, port, out, tmp):
     holder = {}
     real_init = step_mod.TrainStep.__init__
 
+    e_init = {}
+
     def spy_init(self, *a, **k):
         real_init(self, *a, **k)
         holder["ts"] = self
+        e_init["conv_in"] = self.group.view(self.group.by_name["conv_in.weight"]).clone()
     step_mod.TrainStep.__init__ = spy_init
     try:
         while True:
@@ -186,7 +214,10 @@ def _train_ddp_worker(rank, world, port, out, tmp):
     except StopIteration as e:
         config, _ = e.value
     ts = holder["ts"]
-    out.put((rank, n_calls[0], config.num_train_epochs, ts.group.params.numpy().copy(), ts.ti.params.numpy().copy()))
+    # (the weights a frozen-TI step must still train: a matrix weight's master after the run vs its checkpoint value)
+    e = ts.group.by_name["conv_in.weight"]
+    moved = float((ts.group.view(e) - e_init["conv_in"]).abs().max()) if "conv_in" in e_init else -1.0
+    out.put((rank, n_calls[0], config.num_train_epochs, ts.group.params.numpy().copy(), ts.ti.params.numpy().copy(), moved))
     torch.distributed.destroy_process_group()
 
 
@@ -201,7 +232,8 @@ def test_train_data_parallel_uneven_dataset_two_ranks_gloo(tmp_path):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    (_, n0, ep0, p0, t0), (_, n1, ep1, p1, t1) = res
+    (_, n0, ep0, p0, t0, mv0), (_, n1, ep1, p1, t1, mv1) = res
+    assert mv0 > 0 and mv1 > 0, "the matrix weights did not move: the weight-gradient flush / exchange of the step was skipped"
     # 5 images over 2 ranks: 3 per rank and epoch (the shuffle wraps around), max_train_steps + 1 = 8 optimizer steps on BOTH ranks
     assert n0 == n1 == 8 and ep0 == ep1 == 3
     assert (p0 == p1).all(), "UNet replicas diverged"
