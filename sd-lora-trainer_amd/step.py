@@ -231,11 +231,10 @@ class TrainStep:
             self.zero1 = bool(z) and self.bucketed and optimizer == "adamw"
             if self.zero1:
                 unet.trainer.enable_zero1(dist.get_rank(self.pg), self.world)
-            if self.world > 1 and (optimizer == "prodigy" or (text is not None and ti_optimizer == "prodigy")):
-                raise NotImplementedError("data-parallel full fine-tune with Prodigy: its d-estimate is not scale free, the summed gradients would "
-                                          "need their own normalisation - use AdamW / AdamW8bit (full_finetuning_example.json does)")
-            if self.world > 1 and text is not None and text.arena is not None:
-                raise NotImplementedError("data-parallel full fine-tune with text-encoder LoRA (the adapter gradients are not exchanged)")
+            # Prodigy under data parallelism: its step-size estimate d is built from sums of g . (p0 - p) and |s| and is not invariant to the
+            # gradient's scale, so the SUMMED gradients are turned into the mean (one in-place multiply) before its two passes - the state every
+            # rank then holds is the state of one process on the whole batch; AdamW takes the mean through its hyper row instead (no extra pass).
+            # Text-encoder LoRA: the adapter gradients are exchanged like the token rows (the ranks see different captions).
         self.text, self.ta_w, self.ti_wd = text, token_attention_loss_w, ti_weight_decay
         self.ti = TiState(rt, text.encoders, n_tokens, ti_std_loss_w) if text is not None else None
         self.ta = TokenAttentionLoss(rt, n_tokens) if text is not None else None
@@ -365,7 +364,7 @@ class TrainStep:
                         else self.prodigy_ti.hyper_row(lr_ti, 0.0))
         dsts = [self.hyper] + ([self.ti.hyper] if self.ti is not None else [])
         if self.te_arena is not None:
-            rows.append([lr_te, b1, b2, self.eps, self.te_wd, *bc, 0.0, 1.0])
+            rows.append([lr_te, b1, b2, self.eps, self.te_wd, *bc, 0.0, 1.0 / self.world])
             dsts.append(self.te_hyper)
         for pr in (self.prodigy, self.prodigy_ti):
             if pr is not None:
@@ -479,6 +478,8 @@ class TrainStep:
             a.adamw_step(self.hyper)           # optimizer step and operand refresh in one tiled pass over the matrices
             return
         if self.prodigy is not None:
+            if self.world > 1:
+                a.grads.mul_(1.0 / self.world)
             self.prodigy.step(a.grads, a.m, a.v, self.hyper, l1)
         else:
             self.rt.ops.adamw_fused(a.params, a.grads, a.m, a.v, self.hyper, l1)
@@ -492,6 +493,8 @@ class TrainStep:
             dist.all_reduce(self.group.grads, group=self.pg)
             if self.ti is not None:
                 dist.all_reduce(self.ti.grads, group=self.pg)
+            if self.te_arena is not None:
+                dist.all_reduce(self.te_arena.grads, group=self.pg)
 
     def flush_and_reduce(self, flush_fns=None):
         """Data-parallel full fine-tune, the exchange step of the path: the deferred weight-gradient plan runs bucket
@@ -504,6 +507,8 @@ class TrainStep:
         works = []
         if self.ti is not None:      # token-row gradients (a few KB): complete after the backward graph, exchanged beside the first bucket
             works.append((dist.all_reduce(self.ti.grads, group=self.pg, async_op=True), None, None))
+        if self.te_arena is not None:    # text-encoder adapter gradients (a few MB), complete after the backward graph as well
+            works.append((dist.all_reduce(self.te_arena.grads, group=self.pg, async_op=True), None, None))
         wire = getattr(self, "wire", None)
         zero1 = getattr(self, "zero1", False)
         for b, (o0, o1) in enumerate(tr.buckets):
@@ -564,6 +569,8 @@ class TrainStep:
         if self.ti is not None:                        # a17: the trainable token rows only
             t = self.ti
             if self.prodigy_ti is not None:
+                if self.world > 1:
+                    t.grads.mul_(1.0 / self.world)
                 self.prodigy_ti.step(t.grads, t.m, t.v, t.hyper, None)
             else:
                 self.rt.ops.adamw_fused(t.params, t.grads, t.m, t.v, t.hyper, None)

@@ -65,7 +65,7 @@ def test_timing_protocol_two_ranks_gloo():
 
 
 # ------------------------------------------------------------------------------------------------ data-parallel full fine-tune
-def _ddp_worker(rank, world, port, out, wire="fp32", zero1=True):
+def _ddp_worker(rank, world, port, out, wire="fp32", zero1=True, optimizer="adamw"):
     """Each rank holds ONE sample of a 2-sample batch; after the gradient all-reduce (sum, mean folded into the optimizer's
     gradient scale) both ranks must hold the parameters a single process gets from the full batch."""
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -85,8 +85,9 @@ def _ddp_worker(rank, world, port, out, wire="fp32", zero1=True):
     tr = fullft.WeightTrainer(rt)
     tr.bucket_floats = 150_000          # several buckets on the toy model: weight gradients + all-reduce bucket by bucket
     unet = unet_mod.UNet(rt, topology.CONFIGS["tiny15"], sd, trainer=tr)
-    ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=0.0, process_group=True, ddp_wire_dtype=wire, ddp_zero1=zero1)
-    assert (ts.wire is not None) == (wire == "bf16") and ts.zero1 == zero1
+    ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=0.0, process_group=True, ddp_wire_dtype=wire, ddp_zero1=zero1, optimizer=optimizer)
+    assert (ts.wire is not None) == (wire == "bf16") and ts.zero1 == (zero1 and optimizer == "adamw")
+    zero1 = ts.zero1
     if zero1:          # the moments exist for the owned slices only; every bucket splits evenly
         assert tr.m is None and tr.m_sh.numel() * world == tr.n_mat and all((o1 - o0) % (4 * world) == 0 for o0, o1 in tr.buckets)
     assert ts.bucketed and len(tr.buckets) >= 4 and tr.buckets[0][0] == 0 and tr.buckets[-1][1] == tr.n_mat
@@ -96,18 +97,19 @@ def _ddp_worker(rank, world, port, out, wire="fp32", zero1=True):
         ts.set_batch(latent[s], noise[s], t[s], mask[s], ctx[s])
         ts.run(1e-3)
     own = [tr.shard_range(b) for b in range(len(tr.buckets))] if zero1 else None
-    out.put((rank, tr.params.numpy().copy(), float(ts.loss), tr.grads.numpy().copy(), own, tr.n_mat))      # numpy: pickled through the pipe (a shared-memory tensor dies with the worker)
+    extra = dict(state=ts.prodigy.state.numpy().copy(), s=ts.prodigy.s.numpy().copy()) if ts.prodigy is not None else None
+    out.put((rank, tr.params.numpy().copy(), float(ts.loss), tr.grads.numpy().copy(), own, tr.n_mat, extra))      # numpy: pickled through the pipe (a shared-memory tensor dies with the worker)
     torch.distributed.destroy_process_group()
 
 
 import pytest
 
 
-def _run_ddp(wire, zero1):
+def _run_ddp(wire, zero1, optimizer="adamw"):
     ctx_mp = mp.get_context("spawn")
     q = ctx_mp.Queue()
     port = _free_port()
-    procs = [ctx_mp.Process(target=_ddp_worker, args=(r, 2, port, q, wire, zero1)) for r in range(2)]
+    procs = [ctx_mp.Process(target=_ddp_worker, args=(r, 2, port, q, wire, zero1, optimizer)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=300) for _ in procs), key=lambda x: x[0])
@@ -125,6 +127,42 @@ def test_fullft_zero1_equals_allreduce_two_ranks_gloo():
     assert torch.equal(torch.from_numpy(z[0][1]), torch.from_numpy(z[1][1])), "ZeRO-1 replicas diverged"
     assert torch.equal(torch.from_numpy(z[0][1]), torch.from_numpy(a[0][1])), "sharded optimizer != replicated optimizer"
     assert z[0][2] == a[0][2] and z[1][2] == a[1][2]
+
+
+def test_fullft_data_parallel_prodigy_two_ranks_gloo():
+    """Prodigy under data parallelism (refused until round 4): the summed gradients become the mean before Prodigy's two passes, so both ranks
+    hold the state ONE process gets from the whole batch - replicas bit-identical, parameters equal to the single-process run's up to the
+    rounding of (g0 + g1) / 2 against the batch-mean gradient."""
+    from oracle import unet_ref as U
+    from sd_lora_trainer_amd import fullft, topology
+    from sd_lora_trainer_amd import step as step_mod
+    from sd_lora_trainer_amd import unet as unet_mod
+    from tests import emu_ops
+    from tests.test_fullft_cpu import _inputs
+    res = _run_ddp("fp32", True, "prodigy")
+    p0, p1 = torch.from_numpy(res[0][1]), torch.from_numpy(res[1][1])
+    assert torch.equal(p0, p1), "ranks diverged"
+    cfg, h = U.CONFIGS["tiny15"], 16
+    sd = U.init_unet_state(cfg, seed=0)
+    latent, noise, mask, t, ctx, _, _, _ = _inputs(cfg, 2, h)
+    mask = torch.ones_like(mask)
+    rt = unet_mod.Runtime("cpu", 2, act_dtype=torch.float32, ops=emu_ops)
+    tr = fullft.WeightTrainer(rt)
+    unet = unet_mod.UNet(rt, topology.CONFIGS["tiny15"], sd, trainer=tr)
+    ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=0.0, optimizer="prodigy")
+    for _ in range(2):
+        ts.set_batch(latent, noise, t, mask, ctx)
+        ts.run(1e-3)
+    # Prodigy's state is what a wrong gradient scale would corrupt (at d0 = 1e-6 two steps move the parameters by ulps): the scalars
+    # d, d_max, d_numerator, d_denom, d_hat and the per-element s = sum of d-weighted gradients against ONE process on the whole batch
+    st_d, st_1 = torch.from_numpy(res[0][6]["state"]), ts.prodigy.state
+    assert torch.equal(st_d, torch.from_numpy(res[1][6]["state"]))
+    assert float(st_1[3].abs()) > 0 and float(st_1[4]) > 0, st_1
+    torch.testing.assert_close(st_d[:7], st_1[:7], rtol=2e-3, atol=0)
+    s_d, s_1 = torch.from_numpy(res[0][6]["s"]), ts.prodigy.s
+    assert float((s_d - s_1).norm() / s_1.norm()) <= 2e-3
+    # with the SUM instead of the mean the numerator would be 2x, the denominator 2x: d_hat equal - but s itself 2x off
+    assert float((2 * s_d - s_1).norm() / s_1.norm()) > 0.5
 
 
 @pytest.mark.parametrize("wire,zero1", [("fp32", True), ("bf16", True), ("fp32", False), ("bf16", False)])
@@ -174,7 +212,7 @@ def test_fullft_data_parallel_two_ranks_gloo(wire, zero1):
 
 
 # ------------------------------------------------------------------------------------------------ train() under data parallelism
-def _train_ddp_worker(rank, world, port, out, tmp):
+def _train_ddp_worker(rank, world, port, out, tmp, te_lora=False):
     """The whole train() generator (main.py:34-551 mirror) as a 2-rank data-parallel full fine-tune on a dataset whose size is NOT a
     multiple of the world size: every rank must run the same number of steps (each step issues collectives, the checkpoint a barrier)."""
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -188,7 +226,8 @@ def _train_ddp_worker(rank, world, port, out, tmp):
     parallel.init_distributed("gloo")
     cfg = TrainingConfig(lora_training_urls="synthetic:5", concept_mode="object", pretrained_model={"path": "synthetic:tiny15"}, seed=3, resolution=128,
                          train_batch_size=1, max_train_steps=7, is_lora=False, unet_optimizer_type="adamw", unet_lr=1e-4, ti_lr=1e-3,
-                         n_sample_imgs=0, checkpointing_steps=1000, output_dir=os.path.join(tmp, f"out_rank{rank}"))
+                         n_sample_imgs=0, checkpointing_steps=1000, output_dir=os.path.join(tmp, f"out_rank{rank}"),
+                         **(dict(text_encoder_lora_optimizer="adamw", text_encoder_lora_lr=1e-3, text_encoder_lora_rank=4) if te_lora else {}))
     n_calls = [0]
     real = step_mod.TrainStep._run
 
@@ -217,22 +256,31 @@ def _train_ddp_worker(rank, world, port, out, tmp):
     # (the weights a frozen-TI step must still train: a matrix weight's master after the run vs its checkpoint value)
     e = ts.group.by_name["conv_in.weight"]
     moved = float((ts.group.view(e) - e_init["conv_in"]).abs().max()) if "conv_in" in e_init else -1.0
-    out.put((rank, n_calls[0], config.num_train_epochs, ts.group.params.numpy().copy(), ts.ti.params.numpy().copy(), moved))
+    te = None
+    if ts.te_arena is not None:
+        te = (ts.te_arena.params.numpy().copy(), float(ts.te_arena.m.abs().max()))
+    out.put((rank, n_calls[0], config.num_train_epochs, ts.group.params.numpy().copy(), ts.ti.params.numpy().copy(), moved, te))
     torch.distributed.destroy_process_group()
 
 
-def test_train_data_parallel_uneven_dataset_two_ranks_gloo(tmp_path):
+@pytest.mark.parametrize("te_lora", [False, True])
+def test_train_data_parallel_uneven_dataset_two_ranks_gloo(tmp_path, te_lora):
+    """te_lora: text-encoder LoRA next to the data-parallel full fine-tune (refused until round 4): its adapter gradients are exchanged like
+    the token rows, so the adapters stay identical on all ranks and train."""
     ctx_mp = mp.get_context("spawn")
     q = ctx_mp.Queue()
     port = _free_port()
-    procs = [ctx_mp.Process(target=_train_ddp_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    procs = [ctx_mp.Process(target=_train_ddp_worker, args=(r, 2, port, q, str(tmp_path), te_lora)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=600) for _ in procs), key=lambda x: x[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    (_, n0, ep0, p0, t0, mv0), (_, n1, ep1, p1, t1, mv1) = res
+    (_, n0, ep0, p0, t0, mv0, te0), (_, n1, ep1, p1, t1, mv1, te1) = res
+    if te_lora:
+        assert te0 is not None and (te0[0] == te1[0]).all(), "text-encoder adapters diverged"
+        assert te0[1] > 0, "the text-encoder adapters received no gradient"
     assert mv0 > 0 and mv1 > 0, "the matrix weights did not move: the weight-gradient flush / exchange of the step was skipped"
     # 5 images over 2 ranks: 3 per rank and epoch (the shuffle wraps around), max_train_steps + 1 = 8 optimizer steps on BOTH ranks
     assert n0 == n1 == 8 and ep0 == ep1 == 3
