@@ -682,6 +682,22 @@ class TrainStep:
         """Global L2 norm of the LoRA gradients, the reference's debug read-out (loss.py:108-125, main.py:373-379)."""
         return float(self.group.grads.norm())
 
+    def grad_norms(self):
+        """The whole debug read-out of main.py:373-379: {'unet': ..., 'text_encoder_0': ..., 'text_encoder_1': ...} - `compute_grad_norm` over
+        every parameter that has a gradient.  For a text encoder that is its token table AFTER the rows of the frozen vocabulary were zeroed
+        (main.py:368-371: only the trained rows count - this engine never forms the other rows' gradients) plus, with
+        text_encoder_lora_optimizer, that encoder's adapters.  One device sync per entry; not part of the step's graph."""
+        out = {"unet": float(self.group.grads.norm())}
+        if self.ti is not None:
+            sq = [float(r.float().pow(2).sum()) for r in self.ti.grad_rows]
+            if self.te_arena is not None:
+                for e in self.te_arena.entries:
+                    i = 1 if e["name"].startswith("text_encoder_2.") else 0
+                    sq[i] += float(e["gA"].float().pow(2).sum()) + float(e["gB"].float().pow(2).sum())
+            for i, v in enumerate(sq):
+                out[f"text_encoder_{i}"] = math.sqrt(v)
+        return out
+
     # -------------------------------------------------------------------------------- graph capture / replay
     def _ws(self):
         """Scope in which this job's GEMMs use their own split-K workspace (ops.workspace_owner); a no-op for the CPU emulation."""

@@ -270,6 +270,11 @@ def run_step_and_trajectory(version, B, h, sd, kinds, *, device, ops=None, act_d
             got = unet.arena.export("grads")
             rows = [r.clone() for r in ts.ti.grad_rows]
             rep, fails = {}, []
+            # the debug read-out (main.py:373-379): gradient norm of the UNet adapters and of every text encoder (= its trained token rows)
+            gn = ts.grad_norms()
+            assert abs(gn["unet"] - float(o["lora_grads"].norm())) <= tol["rel"] * float(o["lora_grads"].norm()), (gn, float(o["lora_grads"].norm()))
+            for i, ref_r in enumerate(o["row_grads"]):
+                assert abs(gn[f"text_encoder_{i}"] - float(ref_r.norm())) <= tol["rows_rel"] * float(ref_r.norm()), (gn, float(ref_r.norm()))
             rep["fp32_oracle"], f1 = _check_first_step("fp32 oracle", tol, names, lora, pred, got, rows, o, dora)
             fails += f1
             if tol_faithful is not None:
