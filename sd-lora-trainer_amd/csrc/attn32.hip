@@ -152,6 +152,15 @@ __device__ __forceinline__ FragOff frag_offsets(int lane) {
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
+// SDLT_A32_DMA_SPLIT (default 1): the next tile's LDS-DMA pieces are issued in two halves BEHIND MFMA groups of the current tile instead of in one
+// burst at the loop top.  After the per-iteration barrier all waves of a CU issue their 8 pieces at once and each `global_load_lds` blocks its wave
+// while the CU's 64 B/clk texture path takes the 1 KB (tools/attn32_trace.py: 570-1000 of the 2800-4800 cycles of an iteration); behind MFMAs that
+// wait overlaps the matrix pipe.  A/B in one session (tools/attn32_ab.sh): 1024 x 20 forward 17.0 -> 16.4 us, backward 37.0 -> 36.2; 4096 x 10
+// 80 -> 78, 200 -> 196.  -DSDLT_A32_DMA_SPLIT=0 builds the burst form.
+#ifndef SDLT_A32_DMA_SPLIT
+#define SDLT_A32_DMA_SPLIT 1
+#endif
+
 // -DSDLT_ATTN32_TRACE (tools/attn32_trace.py): lane 0 of wave 0 of the first workgroup of a role stamps clock64() at the phase boundaries of its
 // loop into `trace_buf` (forward: p.D, backward: p.dK32 - both unused by these kernels otherwise; dQ role slots 0.., dK / dV role 512..)
 #ifdef SDLT_ATTN32_TRACE
@@ -202,11 +211,14 @@ __global__ __launch_bounds__(128 * KS) void attn32_fwd_kernel(const sdlt_attn_pa
     const int t = it * KS + grp;
     const char* Ks = ring + (it & 1) * (2 * TILE);
     const char* Vs = Ks + TILE;
-    if (t + KS < ntile) {
-      char* nb = ring + ((it + 1) & 1) * (2 * TILE);
+    char* nb = ring + ((it + 1) & 1) * (2 * TILE);
+    const bool more = t + KS < ntile;
+#if SDLT_A32_DMA_SPLIT == 0
+    if (more) {
       tile_dma(Kb + (int64_t)(t + KS) * 64 * p.ldk, p.ldk, nb, w2, lane);
       tile_dma(Vb + (int64_t)(t + KS) * 64 * p.ldv, p.ldv, nb + TILE, w2, lane);
     }
+#endif
     TR32();
     if (t < ntile) {
       const uint32_t ka = lds_addr(Ks), va = lds_addr(Vs);
@@ -225,12 +237,18 @@ __global__ __launch_bounds__(128 * KS) void attn32_fwd_kernel(const sdlt_attn_pa
       rows_pin(k0f);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) s[0] = MFMA32(k0f[kk], qf[kk], s[0]);
+#if SDLT_A32_DMA_SPLIT       // the next tile's DMA pieces go out under the MFMAs just issued (their issue blocks on the CU's texture path)
+      if (more) tile_dma(Kb + (int64_t)(t + KS) * 64 * p.ldk, p.ldk, nb, w2, lane);
+#endif
       tr_issue<2>(vt[2], va, fo.t1, fo.t2);
       tr_issue<3>(vt[3], va, fo.t1, fo.t2);
       wait_lgkm<15>();          // 24 reads issued: the oldest 9 (both row-fragment sets) have landed
       rows_pin(k1f);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) s[1] = MFMA32(k1f[kk], qf[kk], s[1]);
+#if SDLT_A32_DMA_SPLIT
+      if (more) tile_dma(Vb + (int64_t)(t + KS) * 64 * p.ldv, p.ldv, nb + TILE, w2, lane);
+#endif
       __builtin_amdgcn_sched_barrier(0);
       TR32();
       float tmax = s[0][0];
@@ -362,11 +380,14 @@ __device__ __forceinline__ void attn32_dq_body(const sdlt_attn_params& p, char* 
     const int t = it * KS + grp;
     const char* Ks = ring + (it & 1) * (2 * TILE);
     const char* Vs = Ks + TILE;
-    if (t + KS < ntile) {
-      char* nb = ring + ((it + 1) & 1) * (2 * TILE);
+    char* nb = ring + ((it + 1) & 1) * (2 * TILE);
+    const bool more = t + KS < ntile;
+#if SDLT_A32_DMA_SPLIT == 0
+    if (more) {
       tile_dma(Kb + (int64_t)(t + KS) * 64 * p.ldk, p.ldk, nb, w2, lane);
       tile_dma(Vb + (int64_t)(t + KS) * 64 * p.ldv, p.ldv, nb + TILE, w2, lane);
     }
+#endif
     TR32();
     if (t < ntile) {
       const uint32_t ka = lds_addr(Ks), va = lds_addr(Vs);
@@ -393,6 +414,12 @@ __device__ __forceinline__ void attn32_dq_body(const sdlt_attn_params& p, char* 
           rows_issue<1>(kr[1], ka, fo.row);
           rows_issue<1>(vr[1], va, fo.row);
         }
+#if SDLT_A32_DMA_SPLIT
+        if (more) {
+          if (blk == 0) tile_dma(Kb + (int64_t)(t + KS) * 64 * p.ldk, p.ldk, nb, w2, lane);
+          else tile_dma(Vb + (int64_t)(t + KS) * 64 * p.ldv, p.ldv, nb + TILE, w2, lane);
+        }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         TR32();
 #pragma unroll
@@ -471,11 +498,12 @@ __device__ __forceinline__ void attn32_dkdv_body(const sdlt_attn_params& p, char
   const float* Db = p.D + ((int64_t)b * p.H + h) * p.Nq;
   char* ring = smem + grp * RING;
   const int ntile = p.Nq >> 6, niter = (ntile + KS - 1) / KS;
-  auto stage = [&](int t, char* buf) {
-    tile_dma(Qb + (int64_t)t * 64 * p.ldq, p.ldq, buf, w2, lane);
+  auto stage_q = [&](int t, char* buf) { tile_dma(Qb + (int64_t)t * 64 * p.ldq, p.ldq, buf, w2, lane); };
+  auto stage_g = [&](int t, char* buf) {
     tile_dma(Gb + (int64_t)t * 64 * p.lddo, p.lddo, buf + TILE, w2, lane);
     if (lane < 16) glds16((w2 ? Db : Lb) + t * 64 + lane * 4, buf + 2 * TILE + w2 * 256);
   };
+  auto stage = [&](int t, char* buf) { stage_q(t, buf); stage_g(t, buf); };
   if (grp < ntile) stage(grp, ring);
   bf16x8 kf[4], vf[4];
   {
@@ -504,7 +532,11 @@ __device__ __forceinline__ void attn32_dkdv_body(const sdlt_attn_params& p, char
     const char* Gs = Qs + TILE;
     const float* Ls = (const float*)(Gs + TILE);
     const float* Ds = Ls + 64;
-    if (t + KS < ntile) stage(t + KS, ring + ((it + 1) & 1) * (2 * TILE + 512));
+    char* nb = ring + ((it + 1) & 1) * (2 * TILE + 512);
+    const bool more = t + KS < ntile;
+#if SDLT_A32_DMA_SPLIT == 0
+    if (more) stage(t + KS, nb);
+#endif
     TR32();
     if (t < ntile) {
       const uint32_t qa = lds_addr(Qs), ga = lds_addr(Gs);
@@ -534,6 +566,12 @@ __device__ __forceinline__ void attn32_dkdv_body(const sdlt_attn_params& p, char
           tr_issue<3>(gt[1][1], ga, fo.t1, fo.t2);
           tr_issue<3>(qt[1][1], qa, fo.t1, fo.t2);
         }
+#if SDLT_A32_DMA_SPLIT
+        if (more) {
+          if (blk == 0) stage_q(t + KS, nb);
+          else stage_g(t + KS, nb);
+        }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         TR32();
         // s[r] = S[query blk*32 + 16*(r>>3) + 8*hl + (r&7)][key]

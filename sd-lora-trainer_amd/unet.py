@@ -657,6 +657,11 @@ class GroupNorm(_Module):
                                          gamma=self.gamma, beta=self.beta, eps=self.eps, silu=self.silu, dres=dres, stats_zeroed=self.rt.gn_prezero)
 
 
+# SDLT_LN_NOOP (bit 0: forward, bit 1: backward): a TIMING-ONLY switch that skips the UNet's LayerNorm launches - the upper bound of what folding
+# them into the neighbouring GEMMs could gain, measured before building the fold.  The results are garbage.
+_LN_NOOP = int(os.environ.get("SDLT_LN_NOOP", "0"))
+
+
 class LayerNorm(_Module):
     def __init__(self, rt, name, sd, eps=1e-5):
         super().__init__(rt, name)
@@ -668,6 +673,9 @@ class LayerNorm(_Module):
     def forward(self, x, out=None):
         y = out if out is not None else self.buf("y", *x.shape)
         self._x = x
+        if _LN_NOOP & 1:        # TIMING EXPERIMENT ONLY (SDLT_LN_NOOP): the launch is skipped, y keeps stale data - never set in a real run
+            self.buf("stats", x.shape[0] * 2, dtype=F32)
+            return y
         return self.rt.ops.layernorm_fwd(x, y, self.buf("stats", x.shape[0] * 2, dtype=F32), gamma=self.gamma, beta=self.beta, eps=self.eps)
 
     def backward(self, dy, dres=None, out=None):
@@ -675,6 +683,8 @@ class LayerNorm(_Module):
         if self.trainer is not None:
             self.trainer.affine(groupnorm=False, x1=self._x, x2=None, dy=dy, stats=self._b["stats"], gamma=self.gamma, beta=self.beta,
                                 gent=self.gent, bent=self.bent, B=1, HW=self._x.shape[0])
+        if _LN_NOOP & 2:
+            return dx
         return self.rt.ops.layernorm_bwd(self._x, dy, dx, self._b["stats"], gamma=self.gamma, dres=dres)
 
 
