@@ -27,7 +27,8 @@ pytestmark = pytest.mark.gpu
 # measured (profiles/r04_parity_report_e2e.json): tinyxl latents cos 0.99985 / rel 1.7 %, image PSNR 45.0 dB, mean |diff| 1.0 level, max 8 levels;
 # real SDXL: per-step losses within 0.2 %, latents cos 0.99990 / rel 1.4 %, PSNR 45.5 dB, mean 0.94, max 8 levels (every pixel within 8 of 255)
 TOL = {"tinyxl": dict(loss=1e-2, lat_cos=0.9995, lat_rel=0.04, psnr=40.0, mean_abs=2.0, max_abs=24.0),
-       "sdxl": dict(loss=1e-2, lat_cos=0.9995, lat_rel=0.04, psnr=40.0, mean_abs=2.0, max_abs=24.0)}
+       "sdxl": dict(loss=1e-2, lat_cos=0.9995, lat_rel=0.04, psnr=40.0, mean_abs=2.0, max_abs=24.0),
+       "sd15": dict(loss=1e-2, lat_cos=0.9995, lat_rel=0.04, psnr=40.0, mean_abs=2.0, max_abs=24.0)}
 REPORT = {}
 
 
@@ -161,3 +162,11 @@ def test_train_render_decode_sdxl_real_topology():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     run_e2e("sdxl", ["clip_l", "clip_g"], "sd", 32, 16)
+
+
+def test_train_render_decode_sd15_real_topology():
+    """the REAL SD1.5 UNet / CLIP-L / AutoencoderKL topologies (cfg2's model; head widths 40 / 80 / 160, one text tower, `first_eos` pooling, no
+    add-embedding) at a 32 x 32 latent, batch 2 in training"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    run_e2e("sd15", ["clip_l"], "sd", 32, 16, B=2)

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--rank", type=int, default=16)
     ap.add_argument("--no-ti", action="store_true")
     ap.add_argument("--top", type=int, default=60)
+    ap.add_argument("--pmc-order", default=None, help="PMC mode (tools/gemm_fetch_ratio.sh): instead of timing, launch every signature's calls eagerly once more, "
+                    "a marker kernel (torch.cuda._sleep) in front of each signature, and write the signature order + algorithmic operand bytes to this JSON file")
     args = ap.parse_args()
     device = torch.device("cuda", 0)
     cfg = topology.CONFIGS[args.config]
@@ -99,6 +101,26 @@ def main():
     for c in calls:
         s, fl = sig(*c)
         groups.setdefault(s, [[], fl])[0].append(c)
+    if args.pmc_order:
+        import json
+        order = []
+        for s, (cs, fl) in groups.items():
+            torch.cuda._sleep(1000)                  # marker dispatch: the counter rows between two markers belong to one signature
+            fetch_b = write_b = 0.0
+            for (X, W, out, kw) in cs:
+                real(X, W, out, **kw)
+                nb = kw["batch"].n if kw.get("batch") is not None else 1
+                conv = kw.get("conv")
+                x_el = X.numel() if conv is not None else X.shape[0] * X.shape[1]       # (a 3x3 conv reads its input once, not the 9 taps)
+                fetch_b += 2.0 * nb * (x_el + W.shape[0] * W.shape[1] + (kw["X2"].numel() if kw.get("X2") is not None else 0)
+                                       + (s[0] * s[1] if kw.get("residual") is not None else 0))
+                write_b += nb * s[0] * s[1] * (4.0 if (out is not None and out.dtype == torch.float32) else 2.0)
+            order.append(dict(sig=f"M{s[0]} N{s[1]} K{s[2]} {s[3]}".strip(), calls=len(cs), algorithmic_fetch_bytes=fetch_b / len(cs), algorithmic_write_bytes=write_b / len(cs),
+                              flop=fl))
+        torch.cuda._sleep(1000)
+        torch.cuda.synchronize()
+        json.dump(order, open(args.pmc_order, "w"), indent=1)
+        return
     rows = []
     for s, (cs, fl) in groups.items():
         reps = max(1, 12 // len(cs))
