@@ -112,6 +112,24 @@ typedef struct sdlt_gemm_params {
      multiplied per output column before bias / row bias / residual:  C = alpha * col_scale[n] * (X W^T + s X A^T B^T) + bias ...
      (col_scale = magnitude / || W + s B A ||_row, kept up to date by sdlt_dora_refresh).  LoRA launches (lora_R > 0) only. */
   const float* col_scale;
+  /* LayerNorm folded into the product (ln_c1 != NULL): the LayerNorm in front of attn1's to_q|to_k|to_v, attn2.to_q and ff.net.0.proj of a
+     BasicTransformerBlock (norm1 / norm2 / norm3, reached from main.py:329-336) never runs as a launch of its own.  X holds the RAW rows,
+     W = W o gamma (bf16), bias = c2 = W beta + bias, ln_c1 fp32 [N] = rowsum(W o gamma) taken from the rounded operand, and
+       C = rstd[m] (X W^T - mean[m] c1[n]) + c2[n]  (+ adapter, row bias, residual; alpha must be 1);
+     (mean, rstd) of every row come out of the same K walk (two more MFMAs per X fragment: ones . x -> row sums, x . x^T -> its diagonal =
+     row sums of squares) and are written to ln_stats fp32 [M, 2] (or NULL) in sdlt_layernorm_fwd's layout, for sdlt_layernorm_bwd[_y].
+     With an adapter (lora_R == 16 only): Adown = A o gamma and T = s (rstd (X Adown^T - mean cA) + abeta); ln_adapter fp32 [G][32] =
+     cA[16] | abeta[16] per adapter group (sdlt_ln_fold_adapters keeps Adown and the constants up to date).  Mode 0, no second K segment,
+     no split-K, no batch, epi_op 0 or 1. */
+  const float* ln_c1;
+  float* ln_stats;
+  const float* ln_adapter;
+  float ln_eps;
+  /* ln_parts (optional, with ln_nparts even, 2..16): fp32 [M, ln_nparts, 2] = (sum x, sum x^2) of every row per column tile of the launch that
+     PRODUCED X (sdlt_wsk_gemm_parts) - the statistics are then the sum of a row's partials and the K walk carries no extra work.  Used where a
+     kernel variant for it exists (the shapes of the 1280-wide blocks); otherwise ignored and the statistics are computed from the K walk. */
+  int32_t ln_nparts;
+  const void* ln_parts;
 } sdlt_gemm_params;
 int sdlt_gemm_bf16(const sdlt_gemm_params* p, void* stream);
 
@@ -240,6 +258,23 @@ int sdlt_layernorm_fwd(const void* x, int64_t ldx, int32_t M, int32_t C, const f
 int sdlt_layernorm_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy, int32_t M, int32_t C,
                        const float* gamma, const float* stats, const void* dres, int64_t lddres, void* dx,
                        int64_t lddx, void* stream);
+
+/* sdlt_layernorm_bwd that also writes the normalised rows y = xhat gamma + beta (bf16 [M, C]): the backward of a LayerNorm whose forward was
+ * folded into its consumer GEMM (sdlt_gemm_params.ln_c1 / sdlt_wsk_gemm_ln) - the adapter-gradient launch (sdlt_lora_grad) reads y as its P rows. */
+int sdlt_layernorm_bwd_y(const void* x, int64_t ldx, const void* dy, int64_t lddy, int32_t M, int32_t C, const float* gamma, const float* beta,
+                         const float* stats, const void* dres, int64_t lddres, void* dx, int64_t lddx, void* y, int64_t ldy, void* stream);
+
+/* Adapter operands behind a folded LayerNorm, refreshed after every optimizer step (one launch for all adapters; one wave per rank row):
+ *   Ag [16, K] bf16 = A32 o gamma (rows >= rank zero), consts[r] = sum_k float(Ag[r,k]), consts[16 + r] = sum_k A32[r,k] beta[k].
+ * K % 4 == 0, 16-byte aligned rows. */
+typedef struct sdlt_ln_fold_desc {
+  const float* A32; int64_t lda;     /* fp32 master [rank, K] */
+  const float* gamma; const float* beta;
+  void* Ag; int64_t ldag;
+  float* consts;                     /* fp32 [32] */
+  int32_t rank, K;
+} sdlt_ln_fold_desc;
+int sdlt_ln_fold_adapters(const sdlt_ln_fold_desc* descs, int32_t n, void* stream);
 
 /* sdlt_layernorm_bwd with dy given as nslab fp32 slabs [nslab][M][lddy32] that are added in slab order (the partial outputs of a K-split
  * sdlt_strip_gemm: the split's reduction rides in this kernel's prologue). */
@@ -482,6 +517,21 @@ int sdlt_layernorm_bwd_slabs_pair(const sdlt_ln_slabs_params* a, const sdlt_ln_s
 int sdlt_wsk_gemm(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t M, int32_t N, int32_t K, const float* bias,
                   const void* R, int64_t ldr, void* Y, int64_t ldy, const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup,
                   float lora_scale, void* T_out, int64_t ld_t, int32_t lora_group_k, void* stream);
+
+/* sdlt_wsk_gemm with the LayerNorm in front of the projection folded in (sdlt_gemm_params.ln_c1's contract; attn2.to_q of the 1280-wide blocks):
+ * X raw rows, W = W o gamma, c2 = W beta + bias, Y = rstd (X W^T - mean c1) + c2 (+ adapter with Adown = A o gamma, ln_adapter = cA | abeta, + R);
+ * ln_stats [M, 2] (or NULL) receives (mean, rstd). */
+int sdlt_wsk_gemm_ln(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t M, int32_t N, int32_t K, const float* c2,
+                     const void* R, int64_t ldr, void* Y, int64_t ldy, const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup,
+                     float lora_scale, void* T_out, int64_t ld_t, const float* ln_c1, float* ln_stats, float ln_eps,
+                     const float* ln_adapter, void* stream);
+
+/* sdlt_wsk_gemm that also leaves, for the LayerNorm that reads its output next, ln_parts fp32 [M, N / 80, 2] = (sum y, sum y^2) of every ROUNDED
+ * output row over each 80-column tile (to_out.0 + residual -> norm2 / norm3, ff.net.2 + residual -> the next block's norm1): the consumer
+ * (sdlt_gemm_params.ln_parts) adds N / 80 partials per row instead of reducing the row in its K walk. */
+int sdlt_wsk_gemm_parts(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t M, int32_t N, int32_t K, const float* bias,
+                        const void* R, int64_t ldr, void* Y, int64_t ldy, const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup,
+                        float lora_scale, void* T_out, int64_t ld_t, int32_t lora_group_k, void* ln_parts, void* stream);
 
 /* Token-attention (DAAM) loss and its gradient w.r.t. the hooked cross-attention score maps: trainer/ti_cross_attn_loss.py:239-268
  * (process_and_stack_attention_scores) + trainer/loss.py:10-80 (compute_token_attention_loss), main.py:342-345.  The loss depends on the

@@ -39,7 +39,12 @@ class GemmParams(C.Structure):
         ("batch", vp), ("n_batch", i32), ("throughput_hint", i32),
         ("epi_op", i32), ("epi_act", i32), ("epi_out", vp), ("ld_epi_out", i64), ("epi_in", vp), ("ld_epi_in", i64),
         ("col_scale", vp),
+        ("ln_c1", vp), ("ln_stats", vp), ("ln_adapter", vp), ("ln_eps", f32), ("ln_nparts", i32), ("ln_parts", vp),
     ]
+
+
+class LnFoldDesc(C.Structure):
+    _fields_ = [("A32", vp), ("lda", i64), ("gamma", vp), ("beta", vp), ("Ag", vp), ("ldag", i64), ("consts", vp), ("rank", i32), ("K", i32)]
 
 
 class GemmBatchItem(C.Structure):
@@ -150,6 +155,8 @@ SYMBOLS = {
     "sdlt_groupnorm_bwd": (i32, [C.POINTER(GroupNormParams), vp]),
     "sdlt_layernorm_fwd": (i32, [vp, i64, i32, i32, vp, vp, f32, vp, i64, vp, vp]),
     "sdlt_layernorm_bwd": (i32, [vp, i64, vp, i64, i32, i32, vp, vp, vp, i64, vp, i64, vp]),
+    "sdlt_layernorm_bwd_y": (i32, [vp, i64, vp, i64, i32, i32, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp]),
+    "sdlt_ln_fold_adapters": (i32, [vp, i32, vp]),
     "sdlt_layernorm_bwd_slabs": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp, vp, i64, vp, i64, vp]),
     "sdlt_geglu_fwd": (i32, [vp, i64, i32, i32, vp, i64, vp]),
     "sdlt_geglu_bwd": (i32, [vp, i64, vp, i64, i32, i32, vp, i64, vp]),
@@ -178,6 +185,8 @@ SYMBOLS = {
     "sdlt_attn_bwd_pair": (i32, [C.POINTER(AttnParams), C.POINTER(AttnParams), vp]),
     "sdlt_layernorm_bwd_slabs_pair": (i32, [C.POINTER(LnSlabsParams), C.POINTER(LnSlabsParams), vp]),
     "sdlt_wsk_gemm": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp, i64, vp, i64, vp, i64, vp, i64, f32, vp, i64, i32, vp]),
+    "sdlt_wsk_gemm_parts": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp, i64, vp, i64, vp, i64, vp, i64, f32, vp, i64, i32, vp, vp]),
+    "sdlt_wsk_gemm_ln": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp, i64, vp, i64, vp, i64, vp, i64, f32, vp, i64, vp, vp, f32, vp, vp]),
     "sdlt_token_attention_ws_floats": (i64, [C.POINTER(TaParams)]),
     "sdlt_token_attention_loss": (i32, [C.POINTER(TaParams), vp]),
     "sdlt_sum2x2": (i32, [vp, i32, i32, i32, i32, vp, vp]),
@@ -223,7 +232,7 @@ def struct_sizes():
     ops.py packs with `struct` (8 / 3 pointers) are listed by their packed size."""
     mirrored = (GemmParams, LoraGradDesc, AttnParams, GroupNormParams, ShadowDesc, GemmBatchItem, DoraDesc, DoraWtDesc, DoraGradDesc, SplitsumDesc, StripParams,
                 TaParams, LnSlabsParams, TaGroup)
-    return [(c.__name__, C.sizeof(c)) for c in mirrored] + [("sdlt_affine_grad_item", 8 * 8), ("sdlt_wgrad_tr_item", 3 * 8)]
+    return [(c.__name__, C.sizeof(c)) for c in mirrored] + [("sdlt_affine_grad_item", 8 * 8), ("sdlt_wgrad_tr_item", 3 * 8), ("LnFoldDesc", C.sizeof(LnFoldDesc))]
 
 
 def check(rc, what):

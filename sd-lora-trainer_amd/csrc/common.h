@@ -55,6 +55,24 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return phi + x * 0.39894228040143268f * e;
 }
 
+// Row statistics of a folded LayerNorm from an MFMA operand fragment (8 bf16 of one row per lane): s1 += sum x, s2 += sum x^2 on the VALU's packed
+// bf16 dot product (v_dot2c_f32_bf16: exact products, fp32 accumulation) - eight instructions that issue beside the MFMAs instead of two more MFMAs
+__device__ __forceinline__ void ln_frag_stats(const bf16x8 x, float& s1, float& s2) {
+  const bf16x2_hw one = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bf16x2_hw v = {x[2 * i], x[2 * i + 1]};
+    s1 = __builtin_amdgcn_fdot2_f32_bf16(v, one, s1, false);
+    s2 = __builtin_amdgcn_fdot2_f32_bf16(v, v, s2, false);
+  }
+}
+// ... and their sum over the four 8-element chunks of a 32-wide K fragment row: lanes frow + 16 fk, fk = 0..3 (every lane gets the total)
+__device__ __forceinline__ float ln_sum_fk(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

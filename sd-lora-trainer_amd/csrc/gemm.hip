@@ -50,8 +50,12 @@ __device__ long long g_gemm_tr[16];
 #define GTR(i_) do {} while (0)
 #endif
 
-template <int MI, int NI, int WN, int MODE, int R16, int NSTAGE, int KG = 0, int BT = 0, int WM = 2, int EPI = 0>
+// LN: the LayerNorm in front of the product folded in (sdlt_gemm_params.ln_c1): raw rows in, W = W o gamma, row statistics from the X fragments of
+// the same K walk (ln_frag_stats: packed bf16 dot products on the VALU, beside the MFMAs), C = rstd (acc - mean c1) + c2 applied to the
+// accumulators before the LoRA-up.
+template <int MI, int NI, int WN, int MODE, int R16, int NSTAGE, int KG = 0, int BT = 0, int WM = 2, int EPI = 0, int LN = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_params p) {
+  static_assert(!LN || (MODE == 0 && KG == 0 && BT == 0 && R16 <= 1), "folded LayerNorm: plain products, rank pad 16 at most");
   GTR(0);
   // batched launch: blockIdx.y picks the problem; its operand pointers replace the launch-wide ones (wave-uniform scalar loads)
   // (BT is a template switch so that ordinary launches do not pay the extra kernarg loads and selects in their prologue)
@@ -78,6 +82,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
   static_assert(KG == 0 || R16 >= 1, "K-grouped adapters need an adapter");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* tsh = smem + (S == 1 ? 2 : S) * STAGE;
+  float* lnsh = (float*)(tsh + (R16 ? BM * TROW * 2 : 0));     // LN: (mean, rstd) of the tile's rows
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it in an SGPR
   const int wm = wave & (WM - 1), wn = wave / WM;
@@ -327,6 +332,37 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
       }
     }
   }
+  f32x4 c1f[LN ? NI : 1], lnca = (f32x4){0.f, 0.f, 0.f, 0.f}, lnab = lnca;
+  if constexpr (LN) {
+#pragma unroll
+    for (int a = 0; a < NI; ++a) {
+      const int n = n0 + wn * NI * 16 + a * 16 + fk * 4;
+      c1f[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (n + 3 < p.N) c1f[a] = *(const f32x4*)(p.ln_c1 + n);
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.N) c1f[a][r] = p.ln_c1[n + r];
+      }
+    }
+    if constexpr (R16 != 0) {      // adapter constants of this lane's four rank rows (rank = fk * 4 + i) of this tile's adapter group
+      lnca = *(const f32x4*)(p.ln_adapter + lgrp * 32 + fk * 4);
+      lnab = *(const f32x4*)(p.ln_adapter + lgrp * 32 + 16 + fk * 4);
+    }
+  }
+  // LN == 2: the producer of the rows left (sum x, sum x^2) per row and column tile (sdlt_wsk_gemm_parts): thread t < BM fetches row t's partials
+  // here (old loads: the counted waits of the ring only ever wait longer for them) and adds them after the K loop
+  f32x4 lnp[LN == 2 ? 8 : 1];
+  if constexpr (LN == 2) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      lnp[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (tid < BM && 2 * i < p.ln_nparts) {
+        const int m = m0 + tid < p.M ? m0 + tid : p.M - 1;
+        lnp[i] = *(const f32x4*)((const float*)p.ln_parts + ((size_t)m * p.ln_nparts + 2 * i) * 2);
+      }
+    }
+  }
   // staged (bf16, full-row-segment) epilogue: geometry and the residual tile in the store loop's own layout
   constexpr int CST = BN + 4;                                    // fp32 elements per staged row (+4: bank spread)
   constexpr int REGION = (S == 1 ? 2 : S) * STAGE;
@@ -367,6 +403,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
   for (int a = 0; a < (R16 ? R16 : 1); ++a)
 #pragma unroll
     for (int b = 0; b < TMI; ++b) tacc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // LN: sum x / sum x^2 of this lane's 8-column chunks.  With an adapter the wave that owns a row block's LoRA-down fragments (xt2) owns its
+  // statistics too and shares them through LDS; without one every wave keeps the statistics of its own MI row blocks (no LDS, no barrier)
+  constexpr int LNB = LN ? (R16 ? TMI : MI) : 1;
+  float ls1[LNB], ls2[LNB];
+#pragma unroll
+  for (int b = 0; b < LNB; ++b) ls1[b] = ls2[b] = 0.f;
 
   // byte offset of this lane's fragment chunk inside a 16-row block, for kk = 0/1
   const int foff0 = frow * ROW_BYTES + (((0 * 4 + fk) ^ (frow & 7)) << 4);
@@ -393,6 +435,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
       if (R16) {
 #pragma unroll
         for (int j = 0; j < R16; ++j) af2[kk][j] = *(const bf16x8*)(as + j * 16 * ROW_BYTES + fo);
+      }
+      if (R16) {
 #pragma unroll
         for (int b = 0; b < TMI; ++b) xt2[kk][b] = *(const bf16x8*)(xs + (tb + b) * 16 * ROW_BYTES + fo);
       }
@@ -413,6 +457,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
               tacc[j][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af2[kk][j], xt2[kk][b], tacc[j][b], 0, 0, 0);
         }
       }
+#ifndef SDLT_LAB_LN_NOSTATS
+      if constexpr (LN == 1 && R16 != 0) {
+        if (t_active) {
+#pragma unroll
+          for (int b = 0; b < TMI; ++b) ln_frag_stats(xt2[kk][b], ls1[b], ls2[b]);
+        }
+      }
+      if constexpr (LN == 1 && R16 == 0) {
+#pragma unroll
+        for (int b = 0; b < MI; ++b) ln_frag_stats(xf2[kk][b], ls1[b], ls2[b]);
+      }
+#endif
     }
   };
 
@@ -506,6 +562,53 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
   }
 
   GTR(8);
+  // ---------------- folded LayerNorm: (mean, rstd) of the row blocks this wave owns ----------------
+  float ln_mean[LNB], ln_rstd[LNB];
+  if constexpr (LN == 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid < BM) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { s1 += lnp[i][0]; s2 += lnp[i][1]; s1 += lnp[i][2]; s2 += lnp[i][3]; }      // (absent partials are zero; ln_nparts even)
+      const float inv = 1.f / (float)p.K;
+      const float mean = s1 * inv, var = s2 * inv - mean * mean;
+      const float rstd = rsqrtf((var > 0.f ? var : 0.f) + p.ln_eps);
+      *(float2*)(lnsh + 2 * tid) = make_float2(mean, rstd);
+      if (p.ln_stats && bn == 0 && m0 + tid < p.M) *(float2*)(p.ln_stats + (size_t)(m0 + tid) * 2) = make_float2(mean, rstd);
+    }
+    __syncthreads();
+    if constexpr (R16 != 0) {
+      if (t_active) {
+#pragma unroll
+        for (int b = 0; b < TMI; ++b) {
+          const float2 st = *(const float2*)(lnsh + 2 * (wm * MI * 16 + (wn * TMI + b) * 16 + frow));
+          ln_mean[b] = st.x; ln_rstd[b] = st.y;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < MI; ++b) {
+        const float2 st = *(const float2*)(lnsh + 2 * (wm * MI * 16 + b * 16 + frow));
+        ln_mean[b] = st.x; ln_rstd[b] = st.y;
+      }
+    }
+  }
+  if constexpr (LN == 1) {
+    if (R16 == 0 || t_active) {
+#pragma unroll
+      for (int b = 0; b < LNB; ++b) {
+        const float inv = 1.f / (float)p.K;
+        const float mean = ln_sum_fk(ls1[b]) * inv, var = ln_sum_fk(ls2[b]) * inv - mean * mean;
+        const float rstd = rsqrtf((var > 0.f ? var : 0.f) + p.ln_eps);
+        ln_mean[b] = mean; ln_rstd[b] = rstd;
+        if (fk == 0 && (R16 != 0 || wn == 0)) {
+          const int ml = wm * MI * 16 + ((R16 ? wn * TMI : 0) + b) * 16 + frow;
+          if constexpr (R16 != 0) *(float2*)(lnsh + 2 * ml) = make_float2(mean, rstd);
+          if (p.ln_stats && bn == 0 && m0 + ml < p.M) *(float2*)(p.ln_stats + (size_t)(m0 + ml) * 2) = make_float2(mean, rstd);
+        }
+      }
+    }
+  }
   // ---------------- split-K: publish the partial tile, last arriver reduces (agent-scope release/acquire) ----------------
   if (splitk > 1) {
     constexpr int NACC = NI * MI, NT = R16 ? R16 * TMI : 0;
@@ -592,6 +695,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
       for (int b = 0; b < TMI; ++b) {
         if (!t_active) continue;
         int ml = wm * MI * 16 + (wn * TMI + b) * 16 + frow;
+        if constexpr (LN != 0) {      // T = rstd (x (A o gamma)^T - mean cA) + A beta
+#pragma unroll
+          for (int i = 0; i < 4; ++i) tacc[j][b][i] = ln_rstd[b] * (tacc[j][b][i] - ln_mean[b] * lnca[i]) + lnab[i];
+        }
         uint2 v;
         v.x = pack2bf(tacc[j][b][0] * p.lora_scale, tacc[j][b][1] * p.lora_scale);
         v.y = pack2bf(tacc[j][b][2] * p.lora_scale, tacc[j][b][3] * p.lora_scale);
@@ -600,6 +707,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
     }
     const int nup = KG ? div_small_u(p.K, p.lora_group_k) * R16 : R16;   // 16-column blocks of T (K-grouped: R16 per adapter)
     __syncthreads();
+    if constexpr (LN != 0) {
+#pragma unroll
+      for (int b = 0; b < MI; ++b) {
+        const float2 st = *(const float2*)(lnsh + 2 * (wm * MI * 16 + b * 16 + frow));
+#pragma unroll
+        for (int a = 0; a < NI; ++a) acc[a][b] = (acc[a][b] - c1f[a] * st.x) * st.y;
+      }
+    }
     if (pTout != nullptr && t_writer) {
       // [BM rows][R] bf16 -> global, 8 B per lane
       const int CH = nup * 4;  // 8-byte chunks per row
@@ -627,6 +742,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
     }
   }
 
+  if constexpr (LN != 0 && R16 == 0) {
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+#pragma unroll
+      for (int a = 0; a < NI; ++a) acc[a][b] = (acc[a][b] - c1f[a] * ln_mean[b]) * ln_rstd[b];
+    }
+  }
   GTR(10);
   // ---------------- epilogue ----------------
 #ifdef SDLT_LAB_NO_EPILOGUE
@@ -812,12 +934,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
   GTR(11);
 }
 
-template <int MI, int NI, int WN, int MODE, int R16, int NSREQ, int KG = 0, int BT = 0, int WM = 2, int EPI = 0>
+template <int MI, int NI, int WN, int MODE, int R16, int NSREQ, int KG = 0, int BT = 0, int WM = 2, int EPI = 0, int LN = 0>
 int launch(const sdlt_gemm_params& p, hipStream_t stream) {
   constexpr int NTHR = 64 * WM * WN;
   constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
   constexpr int STAGE = (BM + BN + R16 * 16) * ROW_BYTES;
-  constexpr int TSH = R16 ? BM * ((KG ? KG * R16 : R16) * 16 + 4) * 2 : 0;
+  constexpr int TSH = (R16 ? BM * ((KG ? KG * R16 : R16) * 16 + 4) * 2 : 0) + (LN ? BM * 8 : 0);
   // LDS ring depth: NSREQ == 2 keeps the footprint small (several workgroups per CU overlap each other);
   // otherwise as deep as 160 KB allows, up to 4.
   constexpr int NS = NSREQ <= 2 ? NSREQ : ((4 * STAGE + TSH <= 160 * 1024) ? 4 : ((3 * STAGE + TSH <= 160 * 1024) ? 3 : 2));
@@ -826,7 +948,7 @@ int launch(const sdlt_gemm_params& p, hipStream_t stream) {
     SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: tile %dx%d with LoRA rank pad %d does not fit the 160 KB LDS", BM, BN, R16 * 16);
   } else {
   const int smem = NBUF * STAGE + TSH;
-  if (sdlt_raise_smem((const void*)gemm_kernel<MI, NI, WN, MODE, R16, NS, KG, BT, WM, EPI>, smem))
+  if (sdlt_raise_smem((const void*)gemm_kernel<MI, NI, WN, MODE, R16, NS, KG, BT, WM, EPI, LN>, smem))
     SDLT_FAIL(SDLT_ERR_LAUNCH, "sdlt_gemm_bf16: cannot raise the dynamic LDS limit to %d bytes", smem);
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   const int splitk = p.splitk > 1 ? p.splitk : 1;
@@ -836,7 +958,7 @@ int launch(const sdlt_gemm_params& p, hipStream_t stream) {
     if (!p.ws_slab || !p.ws_cnt || (size_t)nbm * nbn * splitk * slab_bytes > (size_t)p.ws_slab_bytes || nbm * nbn > p.ws_cnt_len)
       SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: split-K workspace too small (%d tiles x %d splits x %zu B)", nbm * nbn, splitk, slab_bytes);
   }
-  hipLaunchKernelGGL((gemm_kernel<MI, NI, WN, MODE, R16, NS, KG, BT, WM, EPI>), dim3(nbm * nbn * splitk, BT ? p.n_batch : 1), dim3(NTHR), smem, stream, p);
+  hipLaunchKernelGGL((gemm_kernel<MI, NI, WN, MODE, R16, NS, KG, BT, WM, EPI, LN>), dim3(nbm * nbn * splitk, BT ? p.n_batch : 1), dim3(NTHR), smem, stream, p);
   }
   return SDLT_OK;
 }
@@ -865,6 +987,7 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
     p.splitk = (pin.splitk == G || (pin.splitk == 0 && G > 1 && t128 * G <= 320 && p.ws_slab && p.ws_cnt)) ? G : 1;
   }
   if (p.batch) p.splitk = 1;            // batched launch: the problems fill the chip, the split-K scratch is per launch
+  if (p.ln_c1) p.splitk = 1;            // folded LayerNorm: a row's statistics come out of one K walk
   const int ktot = p.K + p.K2;
   if (p.tile == 0) {
     // Shape heuristics from the tools/gemm_probe.py sweep on MI355X ("GEMM tile selection"):
@@ -978,6 +1101,49 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
   }
   // (stages == 1, the register-staged loader, is kept in the kernel source but not instantiated: hipcc places its
   //  staging registers in scratch - measured 3-6x slower than the LDS-DMA ring on every SDXL shape.)
+  if (p.ln_c1) {   // folded LayerNorm: rank pad 16 on tiles 1, 2, 3, 8 (either ring depth), ff.net.0.proj + GEGLU on tiles 1, 2, 3, 7, 8 (deep ring)
+    // ln_parts (the producer left row partials: no statistics in the K walk) exists for the shapes of the 1280-wide blocks; anything else
+    // computes the statistics itself
+    const bool parts = p.ln_parts && p.ln_nparts >= 2 && p.ln_nparts <= 16 && !(p.ln_nparts & 1) && !(((uintptr_t)p.ln_parts) & 15);
+    if constexpr (MODE == 0 && R16 == 1) {
+      if (p.tile != 1 && p.tile != 2 && p.tile != 3 && p.tile != 8) p.tile = (p.lora_group_n > 0 && (p.lora_group_n % 128)) ? 3 : 1;
+      if (parts && p.stages != 2) {
+        switch (p.tile) {
+          case 1: return launch<4, 2, 4, 0, 1, 4, 0, 0, 2, 0, 2>(p, s);
+          case 2: return launch<2, 2, 4, 0, 1, 4, 0, 0, 2, 0, 2>(p, s);
+        }
+      }
+      if (p.stages == 2) {
+        switch (p.tile) {
+          case 1: return launch<4, 2, 4, 0, 1, 2, 0, 0, 2, 0, 1>(p, s);
+          case 2: return launch<2, 2, 4, 0, 1, 2, 0, 0, 2, 0, 1>(p, s);
+          case 3: return launch<2, 2, 2, 0, 1, 2, 0, 0, 2, 0, 1>(p, s);
+          case 8: return launch<2, 5, 2, 0, 1, 2, 0, 0, 4, 0, 1>(p, s);
+        }
+      } else {
+        switch (p.tile) {
+          case 1: return launch<4, 2, 4, 0, 1, 4, 0, 0, 2, 0, 1>(p, s);
+          case 2: return launch<2, 2, 4, 0, 1, 4, 0, 0, 2, 0, 1>(p, s);
+          case 3: return launch<2, 2, 2, 0, 1, 4, 0, 0, 2, 0, 1>(p, s);
+          case 8: return launch<2, 5, 2, 0, 1, 4, 0, 0, 4, 0, 1>(p, s);
+        }
+      }
+    }
+    if constexpr (MODE == 0 && R16 == 0) {
+      if (p.epi_op == 1) {
+        if (p.tile == 4 || p.tile == 5 || p.tile == 6) p.tile = 1;
+        if (parts && p.tile == 7) return launch<4, 5, 2, 0, 0, 4, 0, 0, 4, 1, 2>(p, s);
+        switch (p.tile) {
+          case 1: return launch<4, 2, 4, 0, 0, 4, 0, 0, 2, 1, 1>(p, s);
+          case 2: return launch<2, 2, 4, 0, 0, 4, 0, 0, 2, 1, 1>(p, s);
+          case 3: return launch<2, 2, 2, 0, 0, 4, 0, 0, 2, 1, 1>(p, s);
+          case 7: return launch<4, 5, 2, 0, 0, 4, 0, 0, 4, 1, 1>(p, s);
+          case 8: return launch<2, 5, 2, 0, 0, 4, 0, 0, 4, 1, 1>(p, s);
+        }
+      }
+    }
+    SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: folded LayerNorm exists for rank-16 adapter products and for ff.net.0.proj + GEGLU (lora_R %d, epi_op %d, tile %d)", p.lora_R, p.epi_op, p.tile);
+  }
   if (p.lora_group_k > 0 && pin.tile == 0) {
     // only the deep-ring variants of tiles 1..3 exist for K-grouped adapters; with the long K = G*C loop the 128x128 tile
     // wins as soon as it yields >= 64 workgroups (4096x640x1920: 31 us vs 61 us for 64x64)
@@ -1085,6 +1251,13 @@ extern "C" int sdlt_gemm_bf16(const sdlt_gemm_params* pp, void* stream) {
       SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_gemm_bf16: fused GEGLU forward: C / R rows must be 16-byte aligned");
     if (p.epi_op == 2 && (!p.epi_in || (p.ld_epi_in & 7) || ((uintptr_t)p.epi_in & 15) || p.R))
       SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_gemm_bf16: fused GEGLU backward: F1 rows must be 16-byte aligned, no residual");
+  }
+  if (p.ln_c1) {
+    if (p.mode != 0 || p.K2 || p.batch || p.alpha != 1.f || p.col_scale || p.lora_group_k > 0 || p.out_fp32 || (p.lora_R && p.lora_R != 16) ||
+        (p.lora_R && !p.ln_adapter) || (p.epi_op != 0 && p.epi_op != 1) || (p.splitk > 1))
+      SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: folded LayerNorm needs mode 0, one K segment, alpha 1, bf16 out, lora_R 0 / 16 (+ ln_adapter), epi_op 0 / 1, no batch / DoRA / split-K");
+    if ((((uintptr_t)p.ln_c1) & 15) || (((uintptr_t)p.ln_adapter) & 15) || (((uintptr_t)p.ln_stats) & 7))
+      SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_gemm_bf16: ln_c1 / ln_adapter 16-byte, ln_stats 8-byte aligned");
   }
   if (p.accumulate && !p.out_fp32) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_gemm_bf16: accumulate needs an fp32 output (use R for bf16)");
   int r16 = 0;

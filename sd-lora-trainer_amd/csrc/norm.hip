@@ -349,10 +349,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 }
 
 // SLABS: dy arrives as `nslab` fp32 slabs [nslab][M][lddy] (partial outputs of a K-split sdlt_strip_gemm), added here in slab order
-template <bool SLABS>
+// YOUT: the normalised rows y = xhat gamma + beta are written as well (bf16) - for a LayerNorm whose forward was folded into its consumer GEMM
+// (sdlt_gemm_params.ln_c1, sdlt_wsk_gemm_ln) no normalised copy exists, and the adapter-gradient launch wants one as its P operand
+template <bool SLABS, bool YOUT = false>
 __device__ __forceinline__ void ln_bwd_body(const bf16_t* __restrict__ x, int64_t ldx, const void* __restrict__ dy_, int64_t lddy, int nslab, int M,
                                             int C, const float* __restrict__ gamma, const float* __restrict__ stats,
-                                            const bf16_t* dres, int64_t lddres, bf16_t* dx, int64_t lddx, const int bx) {
+                                            const bf16_t* dres, int64_t lddres, bf16_t* dx, int64_t lddx, const int bx,
+                                            const float* __restrict__ beta = nullptr, bf16_t* __restrict__ yout = nullptr, int64_t ldy = 0) {
   const int lane = threadIdx.x & 63;
   const int row = bx * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -361,13 +364,14 @@ __device__ __forceinline__ void ln_bwd_body(const bf16_t* __restrict__ x, int64_
   const float* dy32 = (const float*)dy_;
   uint4 xr[LN_MAXCH], dr[LN_MAXCH], rr[LN_MAXCH];
   f32x4 d32[LN_MAXCH][2];         // (dres may alias dx: read here, before any store of this row - each wave owns its row)
-  f32x4 g4[LN_MAXCH][2];
+  f32x4 g4[LN_MAXCH][2], b4[YOUT ? LN_MAXCH : 1][2];
 #pragma unroll
   for (int i = 0; i < LN_MAXCH; ++i) {
     int ch = lane + i * 64;
     rr[i] = make_uint4(0, 0, 0, 0);
     if (ch < nch) {
       xr[i] = *(const uint4*)(x + (int64_t)row * ldx + ch * 8);
+      if constexpr (YOUT) { b4[i][0] = *(const f32x4*)(beta + ch * 8); b4[i][1] = *(const f32x4*)(beta + ch * 8 + 4); }
       if constexpr (SLABS) {
         dr[i] = make_uint4(0, 0, 0, 0);
         d32[i][0] = *(const f32x4*)(dy32 + (int64_t)row * lddy + ch * 8);
@@ -414,8 +418,41 @@ __device__ __forceinline__ void ln_bwd_body(const bf16_t* __restrict__ x, int64_
       for (int j = 0; j < 8; ++j)
         o[j] = bf2f((j & 1) ? (rw[j >> 1] >> 16) : (rw[j >> 1] & 0xffff)) + rstd * (dxh[i][j] - s1 - xh[i][j] * s2);
       store8(dx + (int64_t)row * lddx + ch * 8, o);
+      if constexpr (YOUT) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = xh[i][j] * g4[i][j >> 2][j & 3] + b4[i][j >> 2][j & 3];
+        store8(yout + (int64_t)row * ldy + ch * 8, o);
+      }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_y_kernel(const bf16_t* __restrict__ x, int64_t ldx, const void* __restrict__ dy_, int64_t lddy, int M,
+                                                        int C, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ stats,
+                                                        const bf16_t* dres, int64_t lddres, bf16_t* dx, int64_t lddx, bf16_t* __restrict__ yout, int64_t ldy) {
+  ln_bwd_body<false, true>(x, ldx, dy_, lddy, 1, M, C, gamma, stats, dres, lddres, dx, lddx, blockIdx.x, beta, yout, ldy);
+}
+
+// Operands of a rank-16 adapter behind a folded LayerNorm (sdlt_ln_fold_adapters): one wave per (adapter, rank row)
+__global__ __launch_bounds__(64) void ln_fold_adapter_kernel(const sdlt_ln_fold_desc* __restrict__ descs) {
+  const sdlt_ln_fold_desc d = descs[blockIdx.x];
+  const int r = blockIdx.y, lane = threadIdx.x;
+  bf16_t* dst = (bf16_t*)d.Ag + (int64_t)r * d.ldag;
+  float s1 = 0.f, s2 = 0.f;
+  if (r < d.rank) {
+    const float* a = d.A32 + (int64_t)r * d.lda;
+    for (int k = lane * 4; k < d.K; k += 256) {
+      const f32x4 av = *(const f32x4*)(a + k), gv = *(const f32x4*)(d.gamma + k), bv = *(const f32x4*)(d.beta + k);
+      const uint32_t lo = pack2bf(av[0] * gv[0], av[1] * gv[1]), hi = pack2bf(av[2] * gv[2], av[3] * gv[3]);
+      *(uint2*)(dst + k) = make_uint2(lo, hi);
+      s1 += bf2f(lo & 0xffff) + bf2f(lo >> 16) + bf2f(hi & 0xffff) + bf2f(hi >> 16);      // cA from the ROUNDED operand: the mean term cancels what the product adds
+      s2 += av[0] * bv[0] + av[1] * bv[1] + av[2] * bv[2] + av[3] * bv[3];
+    }
+  } else {
+    for (int k = lane * 4; k < d.K; k += 256) *(uint2*)(dst + k) = make_uint2(0u, 0u);
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (lane == 0) { d.consts[r] = s1; d.consts[16 + r] = s2; }
 }
 
 template <bool SLABS>
@@ -517,6 +554,24 @@ extern "C" int sdlt_layernorm_bwd(const void* x, int64_t ldx, const void* dy, in
   if (M <= 0 || C <= 0 || (C % 8) || C > LN_MAXCH * 512) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_layernorm_bwd: M=%d C=%d", M, C);
   if ((ldx % 8) || (lddy % 8) || (lddx % 8) || (dres && (lddres % 8))) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_layernorm_bwd: ld %% 8");
   hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, dy, lddy, 1, M, C, gamma, stats, (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+
+extern "C" int sdlt_layernorm_bwd_y(const void* x, int64_t ldx, const void* dy, int64_t lddy, int32_t M, int32_t C, const float* gamma, const float* beta,
+                                    const float* stats, const void* dres, int64_t lddres, void* dx, int64_t lddx, void* y, int64_t ldy, void* stream) {
+  if (M <= 0 || C <= 0 || (C % 8) || C > LN_MAXCH * 512) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_layernorm_bwd_y: M=%d C=%d", M, C);
+  if (!beta || !y || (ldx % 8) || (lddy % 8) || (lddx % 8) || (ldy % 8) || (dres && (lddres % 8))) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_layernorm_bwd_y: beta / y required, ld %% 8");
+  hipLaunchKernelGGL(ln_bwd_y_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, dy, lddy, M, C, gamma, beta, stats,
+                     (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx, (bf16_t*)y, ldy);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+
+extern "C" int sdlt_ln_fold_adapters(const sdlt_ln_fold_desc* descs, int32_t n, void* stream) {
+  if (n <= 0) return SDLT_OK;
+  if (!descs) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_ln_fold_adapters: descs == NULL");
+  hipLaunchKernelGGL(ln_fold_adapter_kernel, dim3(n, 16), dim3(64), 0, (hipStream_t)stream, descs);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }

@@ -38,6 +38,17 @@ struct wsk_params {
   // its own rank-16 adapter: T_g = X[:, group g] . Adown[:, group g]^T, Y += sum_g bf16(s T_g) . Bup[:, 16 g .. 16 g + 15]^T; T_out [M, 16 G]
   int group_k;
   int stagger;
+  // LayerNorm folded into the product (LN kernels): X holds the RAW rows, W = W o gamma (bf16), `bias` = c2 = W beta + bias and
+  //   Y = rstd (X W^T - mean c1[n]) + c2[n] (+ adapter, + residual);  (mean, rstd) of a row come out of the same K walk (ln_frag_stats on the X fragments: packed bf16 dot
+  //   products on the VALU beside the MFMAs) and are written to ln_stats [M, 2] by column tile 0.
+  //   With an adapter: Adown = A o gamma and T = s (rstd (X Adown^T - mean cA) + abeta), ln_adapter = cA[16] | abeta[16].
+  const float* ln_c1;
+  float* ln_stats;
+  const float* ln_adapter;
+  float ln_eps;
+  // row partials for the NEXT LayerNorm (any kernel): ln_parts [M, N / 80] float2 = (sum y, sum y^2) of the ROUNDED output row over this tile's 80
+  // columns - the consumer GEMM of a folded LayerNorm (sdlt_gemm_params.ln_parts) adds the N / 80 partials of a row instead of walking it
+  float2* ln_parts;
 };
 
 // -DSDLT_WSK_TRACE (tools/wsk_trace.py): thread 0 of workgroup 0 stamps clock64() at the phase boundaries; sdlt_wsk_trace_read copies them out
@@ -50,9 +61,10 @@ __device__ long long g_wsk_tr[16];
 
 // MBK x 16 rows, JN x 16 columns per workgroup; R ring slots per wave
 // KG: 0 no adapter, 1 one rank-16 adapter, 2..3 that many K groups with an adapter each
-template <int MBK, int JN, int R, int KG = 0>
+template <int MBK, int JN, int R, int KG = 0, bool LN = false>
 __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   constexpr bool LORA = KG > 0;
+  static_assert(!LN || KG <= 1, "the folded LayerNorm belongs to forward products (no K-grouped adapters)");
   constexpr int XR = 16 * MBK, WR = 16 * JN, SROWS = XR + WR + (LORA ? 16 : 0), SLOT = SROWS * ROWB, PIECES = SROWS / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   WTR(0);
@@ -119,22 +131,29 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
 #pragma unroll
     for (int j = 0; j < JN; ++j) acc[j][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  float ls1[LN ? MBK : 1], ls2[LN ? MBK : 1];      // LN: sum x / sum x^2 of row (mb, r) over this lane's 8-column chunks of this wave's K share
+#pragma unroll
+  for (int mb = 0; mb < (LN ? MBK : 1); ++mb) ls1[mb] = ls2[mb] = 0.f;
   constexpr int UNITS_ = MBK * JN, UPW_ = (UNITS_ + NW - 1) / NW;
   // residual and bias of the units this wave finishes, requested before anything else (loads at their point of use sit exposed behind the
   // last barrier: +1.1 us per launch; being the OLDEST loads in flight they only make the counted waits below wait for them too)
   uint2 rpre[UPW_];
-  f32x4 bpre[UPW_];
+  f32x4 bpre[UPW_], c1pre[LN ? UPW_ : 1];
 #pragma unroll
   for (int q = 0; q < UPW_; ++q) {
     const int u = wave + q * NW;
     rpre[q] = make_uint2(0u, 0u);
     bpre[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (LN) c1pre[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (u < UNITS_) {
       const int mb = u / JN, j = u - mb * JN, n = n0 + 16 * j + 4 * g, m = m0 + mb * 16 + r;
       if (p.R) rpre[q] = *(const uint2*)(p.R + (int64_t)m * p.ldr + n);
       if (p.bias) bpre[q] = *(const f32x4*)(p.bias + n);
+      if constexpr (LN) c1pre[q] = *(const f32x4*)(p.ln_c1 + n);
     }
   }
+  f32x4 lnca = (f32x4){0.f, 0.f, 0.f, 0.f}, lnab = lnca;      // adapter constants of this lane's four rank rows 4g .. 4g+3
+  if constexpr (LN && LORA) { lnca = *(const f32x4*)(p.ln_adapter + 4 * g); lnab = *(const f32x4*)(p.ln_adapter + 16 + 4 * g); }
   static_assert(R == 2 || KG <= 1, "the K-grouped bookkeeping below tracks a 2-slot ring");
 
   int kq[R];               // (a small FIFO in registers: slot s holds the step whose first column is kq[s]; R is 2)
@@ -191,6 +210,12 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
             for (int mb = 0; mb < MBK; ++mb) tacc[tg][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk], xf[kk][mb], tacc[tg][mb], 0, 0, 0);
         }
     }
+    if constexpr (LN) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int mb = 0; mb < MBK; ++mb) ln_frag_stats(xf[kk][mb], ls1[mb], ls2[mb]);
+    }
     if (!refill_first && i + R < nsteps) {
       const int kn = issue(i + R, slot);
       if (slot == 0) kq[0] = kn; else kq[R - 1] = kn;
@@ -199,7 +224,8 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   }
 
   // ---- the 4 partial tiles meet in LDS; unit u = (row block, column block), wave w finishes units w, w + 4, ...
-  constexpr int UNITS = MBK * JN, TUN = LORA ? TG * MBK : 0, UALL = UNITS + TUN, UPW = (UNITS + NW - 1) / NW;
+  constexpr int UNITS = MBK * JN, TUN = LORA ? TG * MBK : 0, SMU = UNITS + TUN, UALL = UNITS + TUN + (LN ? 1 : 0),
+                UPW = (UNITS + NW - 1) / NW;
   WTR(8);
   __syncthreads();
   WTR(9);
@@ -215,6 +241,26 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
 #pragma unroll
       for (int mb = 0; mb < MBK; ++mb) red[(wave * UALL + UNITS + tg * MBK + mb) * 64 + lane] = tacc[tg][mb];
   }
+  if constexpr (LN) {
+#pragma unroll
+    for (int mb = 0; mb < MBK; ++mb) {
+      const float a = ln_sum_fk(ls1[mb]), b = ln_sum_fk(ls2[mb]);       // over the lane's three partners of the same row
+      if (g == 0) ((float2*)(red + (wave * UALL + SMU) * 64))[mb * 16 + r] = make_float2(a, b);   // one unit: [MBK * 16 rows] (sum x, sum x^2)
+    }
+  }
+  // LN: (mean, rstd) of row (mb, rr) from the four waves' partial sums, added in wave order
+  auto row_stats = [&](int mb, int rr, float& mean, float& rstd) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float2 ps = ((const float2*)(red + (w * UALL + SMU) * 64))[mb * 16 + rr];
+      s1 += ps.x; s2 += ps.y;
+    }
+    const float inv = 1.f / (float)p.K;
+    mean = s1 * inv;
+    const float var = s2 * inv - mean * mean;
+    rstd = rsqrtf((var > 0.f ? var : 0.f) + p.ln_eps);
+  };
   // adapter operands of this wave's units, requested before the barrier
   const int ngrp = KG > 1 ? p.K / p.group_k : 1;            // groups in use (<= TG; the unused accumulators stay zero)
   uint2 bupf[UPW][TG];
@@ -230,6 +276,13 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
     }
   }
   __syncthreads();
+  if constexpr (LN) {
+    if (p.ln_stats && tn == 0 && threadIdx.x < XR) {
+      float mean, rstd;
+      row_stats(threadIdx.x >> 4, threadIdx.x & 15, mean, rstd);
+      *(float2*)(p.ln_stats + (int64_t)(m0 + threadIdx.x) * 2) = make_float2(mean, rstd);
+    }
+  }
   if constexpr (LORA) {
     // T_g = s * X_g Adown_g^T of every (group, row block): summed over the waves, rounded to bf16 - the accumulator layout D[r][m] (lane: m,
     // rows 4g..4g+3) IS the B-operand layout of the 16x16x16 MFMA, so the LoRA-up below needs no data movement beyond this LDS word pair
@@ -238,6 +291,12 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
       f32x4 t = red[(UNITS + tu) * 64 + lane];
 #pragma unroll
       for (int w = 1; w < NW; ++w) t += red[(w * UALL + UNITS + tu) * 64 + lane];
+      if constexpr (LN) {
+        float mean, rstd;
+        row_stats(mb, r, mean, rstd);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = rstd * (t[i] - mean * lnca[i]) + lnab[i];
+      }
       const uint2 tb = make_uint2(pack2bf(t[0] * p.lora_scale, t[1] * p.lora_scale), pack2bf(t[2] * p.lora_scale, t[3] * p.lora_scale));
       tsh[tu * 64 + lane] = tb;
       if (p.T_out && tn == 0) *(uint2*)(p.T_out + (int64_t)(m0 + mb * 16 + r) * p.ld_t + 16 * tg + 4 * g) = tb;
@@ -245,6 +304,7 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
     __syncthreads();
   }
   WTR(10);
+  float2* psh = (float2*)(smem + (size_t)NW * UALL * 1024 + (size_t)TG * MBK * 64 * 8);     // [XR rows][JN units][4 lane groups] behind the reduction scratch
 #pragma unroll
   for (int q = 0; q < UPW; ++q) {
     const int u = wave + q * NW;
@@ -253,6 +313,11 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
     f32x4 v = red[u * 64 + lane];
 #pragma unroll
     for (int w = 1; w < NW; ++w) v += red[(w * UALL + u) * 64 + lane];
+    if constexpr (LN) {
+      float mean, rstd;
+      row_stats(mb, r, mean, rstd);
+      v = (v - c1pre[q] * mean) * rstd;
+    }
     if constexpr (LORA) {
 #pragma unroll
       for (int tg = 0; tg < TG; ++tg) {
@@ -266,21 +331,36 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
       const uint2 rv = rpre[q];
       v[0] += bf2f(rv.x & 0xffff); v[1] += bf2f(rv.x >> 16); v[2] += bf2f(rv.y & 0xffff); v[3] += bf2f(rv.y >> 16);
     }
-    *(uint2*)(p.Y + (int64_t)m * p.ldy + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+    const uint2 ov = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+    *(uint2*)(p.Y + (int64_t)m * p.ldy + n) = ov;
+    if (p.ln_parts) {     // (wave-uniform) this unit's 16 columns of row (mb, r): the four lanes r + 16 g hold four each
+      const float y0 = bf2f(ov.x & 0xffff), y1 = bf2f(ov.x >> 16), y2 = bf2f(ov.y & 0xffff), y3 = bf2f(ov.y >> 16);
+      psh[((mb * 16 + r) * JN + j) * 4 + g] = make_float2(y0 + y1 + y2 + y3, y0 * y0 + y1 * y1 + y2 * y2 + y3 * y3);     // (no cross-lane step: the row's 4 JN slots are added below)
+    }
+  }
+  if (p.ln_parts) {
+    __syncthreads();
+    if (threadIdx.x < XR) {
+      float2 t = psh[threadIdx.x * JN * 4];
+#pragma unroll
+      for (int j = 1; j < JN * 4; ++j) { const float2 u = psh[threadIdx.x * JN * 4 + j]; t.x += u.x; t.y += u.y; }
+      p.ln_parts[(int64_t)(m0 + threadIdx.x) * ntn + tn] = t;
+    }
   }
   WTR(11);
 }
 
-template <int MBK, int JN, int R, int KG>
+template <int MBK, int JN, int R, int KG, bool LN = false>
 int launch_wsk(const wsk_params& p, hipStream_t s) {
   constexpr bool LORA = KG > 0;
   constexpr int SLOT = (16 * MBK + 16 * JN + (LORA ? 16 : 0)) * ROWB;
-  constexpr int RED = NW * (MBK * JN + KG * MBK) * 1024 + KG * MBK * 64 * 8;
-  constexpr int smem = NW * R * SLOT > RED ? NW * R * SLOT : RED;
+  constexpr int RED = NW * (MBK * JN + KG * MBK + (LN ? 1 : 0)) * 1024 + KG * MBK * 64 * 8;
+  constexpr int REDP = RED + (LORA ? 0 : MBK * 64 * 8) + 16 * MBK * JN * 4 * 8;      // + the row-partial slots (ln_parts); tsh's offset is TG * MBK * 512 also without an adapter
+  constexpr int smem = NW * R * SLOT > REDP ? NW * R * SLOT : REDP;
   static_assert(smem <= 160 * 1024, "LDS budget");
-  if (sdlt_raise_smem((const void*)wsk_kernel<MBK, JN, R, KG>, smem)) SDLT_FAIL(SDLT_ERR_LAUNCH, "sdlt_wsk_gemm: cannot raise the dynamic LDS limit to %d bytes", smem);
+  if (sdlt_raise_smem((const void*)wsk_kernel<MBK, JN, R, KG, LN>, smem)) SDLT_FAIL(SDLT_ERR_LAUNCH, "sdlt_wsk_gemm: cannot raise the dynamic LDS limit to %d bytes", smem);
   const int tiles = (p.M / (16 * MBK)) * (p.N / (16 * JN));
-  hipLaunchKernelGGL((wsk_kernel<MBK, JN, R, KG>), dim3(tiles), dim3(64 * NW), smem, s, p);
+  hipLaunchKernelGGL((wsk_kernel<MBK, JN, R, KG, LN>), dim3(tiles), dim3(64 * NW), smem, s, p);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }
@@ -291,9 +371,10 @@ int launch_wsk(const wsk_params& p, hipStream_t s) {
 extern "C" int sdlt_wsk_trace_read(long long* out16) { return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_wsk_tr), sizeof(long long) * 16); }
 #endif
 
-extern "C" int sdlt_wsk_gemm(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t M, int32_t N, int32_t K, const float* bias,
-                             const void* R, int64_t ldr, void* Y, int64_t ldy, const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup,
-                             float lora_scale, void* T_out, int64_t ld_t, int32_t lora_group_k, void* stream) {
+static int wsk_gemm_impl(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t M, int32_t N, int32_t K, const float* bias,
+                         const void* R, int64_t ldr, void* Y, int64_t ldy, const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup,
+                         float lora_scale, void* T_out, int64_t ld_t, int32_t lora_group_k, const float* ln_c1, float* ln_stats, float ln_eps,
+                         const float* ln_adapter, void* ln_parts, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (M % 64) || (N % 80) || ((N / 80) % 8) || (K % 256))
     SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wsk_gemm: M=%d N=%d K=%d (M %% 64, N %% 640, K %% 256 == 0)", M, N, K);
   if (!X || !W || !Y || (ldx % 8) || (ldw % 8) || (ldy % 4) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15) || ((uintptr_t)Y & 7) || (R && ((ldr % 4) || ((uintptr_t)R & 7))) ||
@@ -301,13 +382,41 @@ extern "C" int sdlt_wsk_gemm(const void* X, int64_t ldx, const void* W, int64_t 
     SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_gemm: operand alignment");
   if (Adown && (!Bup || (ld_adown % 8) || ((uintptr_t)Adown & 15) || (ld_bup % 4) || ((uintptr_t)Bup & 7) || (T_out && ((ld_t % 4) || ((uintptr_t)T_out & 7)))))
     SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_gemm: adapter operands (Adown [16, K] 16-byte rows, Bup [N, 16] / T_out [M, 16] 8-byte rows)");
+  if (ln_c1 && (((uintptr_t)ln_c1 & 15) || ((uintptr_t)ln_stats & 7) || lora_group_k > 0 || (Adown && (!ln_adapter || ((uintptr_t)ln_adapter & 15)))))
+    SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_gemm_ln: c1 [N] / ln_adapter [32] 16-byte aligned, stats [M, 2] 8-byte aligned, no K-grouped adapters");
   static const int stagger_env = getenv("SDLT_WSK_STAGGER") ? atoi(getenv("SDLT_WSK_STAGGER")) : 1;   // (read once: A/B switch)
   wsk_params p{(const bf16_t*)X, ldx, (const bf16_t*)W, ldw, bias, (const bf16_t*)R, ldr, (bf16_t*)Y, ldy, M, N, K, 1,
-               (const bf16_t*)Adown, ld_adown, (const bf16_t*)Bup, ld_bup, (bf16_t*)T_out, ld_t, lora_scale, lora_group_k, stagger_env};
+               (const bf16_t*)Adown, ld_adown, (const bf16_t*)Bup, ld_bup, (bf16_t*)T_out, ld_t, lora_scale, lora_group_k, stagger_env,
+               ln_c1, ln_stats, ln_adapter, ln_eps, (float2*)ln_parts};
+  if (((uintptr_t)ln_parts) & 7) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_gemm: ln_parts must be 8-byte aligned");
   hipStream_t s = (hipStream_t)stream;
+  if (ln_c1) return Adown ? launch_wsk<4, 5, 2, 1, true>(p, s) : launch_wsk<4, 5, 2, 0, true>(p, s);
   if (!Adown) return launch_wsk<4, 5, 2, 0>(p, s);
   if (lora_group_k <= 0) return launch_wsk<4, 5, 2, 1>(p, s);
   const int G = K / lora_group_k;
   if ((lora_group_k % 64) || G * lora_group_k != K || G < 2 || G > 3) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_wsk_gemm: lora_group_k=%d with K=%d (2 or 3 groups of a multiple of 64 columns)", lora_group_k, K);
   return launch_wsk<4, 5, 2, 3>(p, s);
+}
+
+extern "C" int sdlt_wsk_gemm(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t M, int32_t N, int32_t K, const float* bias,
+                             const void* R, int64_t ldr, void* Y, int64_t ldy, const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup,
+                             float lora_scale, void* T_out, int64_t ld_t, int32_t lora_group_k, void* stream) {
+  return wsk_gemm_impl(X, ldx, W, ldw, M, N, K, bias, R, ldr, Y, ldy, Adown, ld_adown, Bup, ld_bup, lora_scale, T_out, ld_t, lora_group_k,
+                       nullptr, nullptr, 0.f, nullptr, nullptr, stream);
+}
+
+extern "C" int sdlt_wsk_gemm_parts(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t M, int32_t N, int32_t K, const float* bias,
+                                   const void* R, int64_t ldr, void* Y, int64_t ldy, const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup,
+                                   float lora_scale, void* T_out, int64_t ld_t, int32_t lora_group_k, void* ln_parts, void* stream) {
+  return wsk_gemm_impl(X, ldx, W, ldw, M, N, K, bias, R, ldr, Y, ldy, Adown, ld_adown, Bup, ld_bup, lora_scale, T_out, ld_t, lora_group_k,
+                       nullptr, nullptr, 0.f, nullptr, ln_parts, stream);
+}
+
+extern "C" int sdlt_wsk_gemm_ln(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t M, int32_t N, int32_t K, const float* c2,
+                                const void* R, int64_t ldr, void* Y, int64_t ldy, const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup,
+                                float lora_scale, void* T_out, int64_t ld_t, const float* ln_c1, float* ln_stats, float ln_eps,
+                                const float* ln_adapter, void* stream) {
+  if (!ln_c1) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wsk_gemm_ln: c1 is required");
+  return wsk_gemm_impl(X, ldx, W, ldw, M, N, K, c2, R, ldr, Y, ldy, Adown, ld_adown, Bup, ld_bup, lora_scale, T_out, ld_t, 0,
+                       ln_c1, ln_stats, ln_eps, ln_adapter, nullptr, stream);
 }

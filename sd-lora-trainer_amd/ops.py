@@ -136,9 +136,16 @@ def wsk_shape(M, N, K, lora=False):
     return 2560 <= K <= WSK_KMAX
 
 
+def gemm_emits_parts(M, N, K, lora_rank_pad=0):
+    """Number of row partials per row (0: none) a plain / rank-16-adapter product [M, K] x [N, K]^T (+ bias, residual) runs on the wave-split-K kernel and can therefore leave row
+    partials for the next LayerNorm (gemm(..., ln_parts_out=)): the to_out.0 and ff.net.2 products of the 1280-wide blocks at batch 1."""
+    ok = WSK and not THROUGHPUT_HINT and lora_rank_pad in (0, 16) and wsk_shape(M, N, K, lora_rank_pad > 0) and (N // 80) % 2 == 0 and N // 80 <= 16
+    return N // 80 if ok else 0
+
+
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
          residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0, batch=None,
-         geglu_out=None, geglu_bwd=None, act_out=None, dact_in=None, col_scale=None):
+         geglu_out=None, geglu_bwd=None, act_out=None, dact_in=None, col_scale=None, ln=None, ln_parts_out=None):
     """out[M,N] = alpha*col_scale[n]*(X.W^T [+ X2.W2^T] [+ s*(X.Adown^T).Bup^T]) + bias + rowbias[m//rows_per_batch] + residual.
     col_scale fp32 [N]: DoRA's magnitude / norm factor (adapter launches only; DoraPlan keeps it up to date).
     act_out = (kind, A [M,N]): also writes A = act(out), kind "gelu" | "quick_gelu" (the CLIP MLP's fc1).
@@ -151,12 +158,17 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
     Adown [G*Rp, K] (group-major), Bup [N, Rp], T_out [M, G*Rp].
     lora_group_k > 0: X is a stack of G = K / lora_group_k gradients (the dX of such a stack): Adown [Rp, K], Bup [N, G*Rp],
     T_out [M, G*Rp].
+    ln = (c1 fp32 [N], stats fp32 [M, 2] or None, eps, adapter constants fp32 [G*32] or None): the LayerNorm in front of this product is
+    folded in (fold_layernorm: X = the raw rows, W = W o gamma, bias = c2; with an adapter Adown = A o gamma, LnFoldPlan) - sdlt_gemm_params.ln_c1.
+    ... optionally followed by (parts fp32 [M, P, 2], P): the row partials the PRODUCER of X left (ln_parts_out of that call).
+    ln_parts_out fp32 [M, N / 80, 2]: also leave the row partials (sum, sum of squares of the rounded output row per 80-column tile) for the
+    LayerNorm that reads `out` next - only where this call runs on the wave-split-K kernel (gemm_emits_parts says so; asserted).
     batch: a GemmBatch - the launch runs len(batch) problems of identical shape / leading dimensions; the tensor arguments
     describe problem 0 (shapes, strides, options), every problem's operand pointers come from the batch."""
     lib = _lib.load()
     if (WSK and conv is None and X2 is None and rowbias is None and alpha == 1.0 and Ct is None and batch is None and geglu_out is None
             and geglu_bwd is None and act_out is None and dact_in is None and col_scale is None and not accumulate and tile == 0 and splitk == 0
-            and not lora_group_n and out is not None and out.dtype == BF16 and not THROUGHPUT_HINT
+            and not lora_group_n and out is not None and out.dtype == BF16 and not THROUGHPUT_HINT and (ln is None or not lora_group_k)
             and (lora is None or (lora[0].shape[0] == 16 and ((not lora_group_k and lora[1].shape[1] == 16) or
                                                                 (lora_group_k and lora_group_k % 64 == 0 and W.shape[1] // lora_group_k in (2, 3)))))
             and wsk_shape(X.shape[0], W.shape[0], W.shape[1], lora is not None)):
@@ -178,10 +190,26 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
             if T_ is not None:
                 _chk2(T_)
                 assert tuple(T_.shape) == (M_, 16 * G_)
+        if ln is not None:
+            c1, stats_, eps_, lnad = ln[:4]
+            _chk2(c1, F32)
+            assert c1.numel() == N_ and (stats_ is None or (stats_.dtype == F32 and stats_.numel() >= 2 * M_)) and (lora is None or lnad is not None)
+            _lib.check(lib.sdlt_wsk_gemm_ln(_p(X), _ld(X), _p(W), _ld(W), M_, N_, K_, _p(bias), _p(residual), _ld(residual) if residual is not None else 0,
+                                            _p(out), _ld(out), _p(A_), _ld(A_) if A_ is not None else 0, _p(B_), _ld(B_) if B_ is not None else 0, float(scale_),
+                                            _p(T_), _ld(T_) if T_ is not None else 0, _p(c1), _p(stats_), float(eps_), _p(lnad), _stream()), "sdlt_wsk_gemm_ln")
+            return out
+        if ln_parts_out is not None:
+            assert ln_parts_out.dtype == F32 and ln_parts_out.is_contiguous() and ln_parts_out.numel() >= M_ * (N_ // 80) * 2
+            _lib.check(lib.sdlt_wsk_gemm_parts(_p(X), _ld(X), _p(W), _ld(W), M_, N_, K_, _p(bias), _p(residual), _ld(residual) if residual is not None else 0,
+                                               _p(out), _ld(out), _p(A_), _ld(A_) if A_ is not None else 0, _p(B_), _ld(B_) if B_ is not None else 0, float(scale_),
+                                               _p(T_), _ld(T_) if T_ is not None else 0, int(lora_group_k) if lora is not None else 0, _p(ln_parts_out), _stream()),
+                       "sdlt_wsk_gemm_parts")
+            return out
         _lib.check(lib.sdlt_wsk_gemm(_p(X), _ld(X), _p(W), _ld(W), M_, N_, K_, _p(bias), _p(residual), _ld(residual) if residual is not None else 0,
                                      _p(out), _ld(out), _p(A_), _ld(A_) if A_ is not None else 0, _p(B_), _ld(B_) if B_ is not None else 0, float(scale_),
                                      _p(T_), _ld(T_) if T_ is not None else 0, int(lora_group_k) if lora is not None else 0, _stream()), "sdlt_wsk_gemm")
         return out
+    assert ln_parts_out is None, "ln_parts_out: this product does not run on the wave-split-K kernel (ops.gemm_emits_parts)"
     p = _lib.GemmParams()
     _chk2(X), _chk2(W)
     p.X, p.ldx, p.W, p.ldw = _p(X), _ld(X), _p(W), _ld(W)
@@ -268,6 +296,15 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
         assert Ct.shape[0] == N and Ct.shape[1] >= M
         p.Ct, p.ldct = _p(Ct), _ld(Ct)
     p.tile, p.splitk, p.stages, p.accumulate = tile, splitk, stages, int(accumulate)
+    if ln is not None:
+        c1, stats_, eps_, lnad = ln[:4]
+        _chk2(c1, F32)
+        assert c1.numel() == N and (stats_ is None or (stats_.dtype == F32 and stats_.numel() >= 2 * M)) and (lora is None or lnad is not None)
+        p.ln_c1, p.ln_stats, p.ln_eps, p.ln_adapter = _p(c1), _p(stats_), float(eps_), _p(lnad)
+        if len(ln) > 4 and ln[4] is not None:
+            parts, npart = ln[4], int(ln[5])
+            assert parts.dtype == F32 and parts.is_contiguous() and parts.numel() >= M * npart * 2
+            p.ln_parts, p.ln_nparts = _p(parts), npart
     if batch is not None:
         p.batch, p.n_batch = _p(batch.dev), batch.n
     slab, cnt = splitk_workspace(X.device)
@@ -838,10 +875,17 @@ def layernorm_fwd(x, y, stats, *, gamma, beta, eps=1e-5):
     return y
 
 
-def layernorm_bwd(x, dy, dx, stats, *, gamma, dres=None, dy_slabs=None):
-    """dy_slabs fp32 [S, M, C] (instead of dy): the partial outputs of a K-split strip_gemm, added in slab order in the kernel's prologue."""
+def layernorm_bwd(x, dy, dx, stats, *, gamma, dres=None, dy_slabs=None, beta=None, y_out=None):
+    """dy_slabs fp32 [S, M, C] (instead of dy): the partial outputs of a K-split strip_gemm, added in slab order in the kernel's prologue.
+    y_out (with beta): also writes the normalised rows - the backward of a LayerNorm whose forward was folded into its consumer GEMM."""
     lib = _lib.load()
     M, Cc = x.shape
+    if y_out is not None:
+        assert dy_slabs is None and beta is not None
+        _chk2(x), _chk2(dy), _chk2(dx), _chk2(stats, F32), _chk2(gamma, F32), _chk2(beta, F32), _chk2(y_out)
+        _lib.check(lib.sdlt_layernorm_bwd_y(_p(x), _ld(x), _p(dy), _ld(dy), M, Cc, _p(gamma), _p(beta), _p(stats), _p(dres),
+                                            _ld(dres) if dres is not None else 0, _p(dx), _ld(dx), _p(y_out), _ld(y_out), _stream()), "sdlt_layernorm_bwd_y")
+        return dx
     if dy_slabs is not None:
         assert dy is None and dy_slabs.dtype == F32 and dy_slabs.is_contiguous() and tuple(dy_slabs.shape[1:]) == (M, Cc)
         _chk2(x), _chk2(dx), _chk2(stats, F32), _chk2(gamma, F32)
@@ -971,6 +1015,26 @@ class ShadowPlan:
         _chk2(arena, F32)
         _lib.check(lib.sdlt_lora_shadow_refresh(_p(self.descs_dev), _p(self.block_desc_dev), _p(self.block_first_dev), self.n_blocks,
                                                 _p(arena), _stream()), "sdlt_lora_shadow_refresh")
+
+
+class LnFoldPlan:
+    """Descriptor table of sdlt_ln_fold_adapters: for every rank-16 adapter behind a folded LayerNorm, Ag = bf16(A o gamma) and the constants
+    cA | abeta the consumer GEMM needs; one launch after every optimizer step (LoraArena.refresh_shadows)."""
+
+    def __init__(self, items, device):
+        # items: dict(A32 fp32 [rank, K] view, gamma, beta fp32 [K], Ag bf16 [16, K] view, consts fp32 [32] view)
+        descs = (_lib.LnFoldDesc * len(items))()
+        self.keep = items
+        for d, it in zip(descs, items):
+            A, Ag = it["A32"], it["Ag"]
+            assert A.dtype == F32 and A.stride(1) == 1 and Ag.dtype == BF16 and Ag.stride(1) == 1 and Ag.shape[0] == 16 and A.shape[1] % 4 == 0
+            d.A32, d.lda, d.gamma, d.beta, d.Ag, d.ldag = A.data_ptr(), A.stride(0), it["gamma"].data_ptr(), it["beta"].data_ptr(), Ag.data_ptr(), Ag.stride(0)
+            d.consts, d.rank, d.K = it["consts"].data_ptr(), A.shape[0], A.shape[1]
+        self.n = len(items)
+        self.dev = _to_dev(descs, device)
+
+    def run(self):
+        _lib.check(_lib.load().sdlt_ln_fold_adapters(_p(self.dev), self.n, _stream()), "sdlt_ln_fold_adapters")
 
 
 def _block_table(counts, device):

@@ -153,6 +153,7 @@ class LoraArena:
         self.n = 0
         self._shadow_entries = []
         self.params = self.grads = self.m = self.v = None
+        self.ln_items, self._ln_plan = [], None      # adapters behind a folded LayerNorm (Linear.fold_ln): Ag = A o gamma + constants, refreshed with the shadows
 
     def add(self, name, N, K, conv_cin=None, W=None):
         """W: the layer's bf16 forward operand [N, K] (DoRA: its rows enter the norm)."""
@@ -206,6 +207,11 @@ class LoraArena:
                 e["M"] = self.params[e["offM"]: e["offM"] + N]
                 e["gM"] = self.grads[e["offM"]: e["offM"] + N]
         self._shadow_plan = rt.ops.ShadowPlan(sh, rt.device)
+        if self.ln_items:
+            for it in self.ln_items:
+                it["A32"] = it["entry"]["A"]
+            self._ln_plan = rt.ops.LnFoldPlan(self.ln_items, rt.device)
+            self._ln_plan.run()
         if self.dora:
             self._build_dora_plan()
             self.dora_plan.refresh(init=True)        # peft dora_init: magnitude = ||W + s B A||_row of the freshly injected adapter (B = 0)
@@ -238,6 +244,8 @@ class LoraArena:
 
     def refresh_shadows(self):
         self._shadow_plan.run(self.params)
+        if self._ln_plan is not None:
+            self._ln_plan.run()
         if self.dora:
             self.dora_plan.refresh()
 
@@ -316,19 +324,41 @@ class Linear(_Module):
         if self.bent is not None:
             self.bias = tr.view(self.bent)
 
+    ln = None
+
+    def fold_ln(self, norm, w32):
+        """The LayerNorm `norm` in front of this projection runs inside its GEMM from now on (sdlt_gemm_params.ln_c1 / sdlt_wsk_gemm_ln): the forward
+        operand becomes W o gamma, the bias c2 = W beta + b; an adapter's LoRA-down rows become A o gamma (refreshed with the shadows).  The
+        backward is untouched: it works on W^T / A^T and hands dL/dy to norm.backward as before.  w32: this layer's fp32 weight [N, K] in the
+        row order of self.W."""
+        rt = self.rt
+        assert self.trainer is None and not self.dora and (self.lora is None or self.arena.Rp == 16)
+        self.W, self.ln_c1, self.bias = rt.ops.fold_layernorm(w32.to(rt.device), self.bias, norm.gamma, norm.beta, dtype=rt.act)
+        if self.lora is not None:
+            self.lora["W"] = self.W
+            self.ln_Ag, self.ln_consts = rt.zeros(self.arena.Rp, self.K), rt.zeros(32, dtype=F32)
+            self.arena.ln_items.append(dict(entry=self.lora, gamma=norm.gamma, beta=norm.beta, Ag=self.ln_Ag, consts=self.ln_consts))
+            norm.emit_y = True
+        self.ln = norm
+        norm.folded = True
+
     def weight_grad(self, dy, xs=None):
         self.trainer.linear(self.went, self.bent, xs if xs is not None else [self._x], dy)
 
-    def forward(self, x, *, residual=None, Ct=None, key="y", out=None, train=True, geglu_out=None, act_out=None):
+    def forward(self, x, *, residual=None, Ct=None, key="y", out=None, train=True, geglu_out=None, act_out=None, parts_for=None):
+        """parts_for: the (folded) LayerNorm that reads this layer's output next - where the product runs on the wave-split-K kernel it also leaves
+        that LayerNorm's row partials (ops.gemm ln_parts_out), so the consumer GEMM has no statistics to compute."""
         M = x.shape[0]
         y = out if out is not None else self.buf(key, M, self.N)
-        lora = None
+        lora, ln = None, None
         if self.lora is not None:
             T = self.buf("T", M, self.arena.Rp) if train else None
-            lora = (self.lora["A_s"], self.lora["B_s"], self.arena.scale, T)
-            self._x = x
+            lora = (self.lora["A_s"] if self.ln is None else self.ln_Ag, self.lora["B_s"], self.arena.scale, T)
+            self._x = x if self.ln is None else self.ln.ybuf()     # (folded LayerNorm: the normalised rows are written by its backward)
         if self.trainer is not None:
             self._x = x
+        if self.ln is not None:
+            ln = (self.ln_c1, self.ln.stats_buf(), self.ln.eps, self.ln_consts if self.lora is not None else None) + (self.ln._parts or (None, 0))
         if self.dora:
             # y = scale * (x W^T + s x A^T B^T) + bias; the residual is added by a second launch because the magnitude gradient
             # needs the layer's own output (DoraPlan.mag_grad)
@@ -337,12 +367,20 @@ class Linear(_Module):
             self.rt.ops.gemm(x, self.W, y0, lora=lora, bias=self.bias, Ct=Ct, col_scale=self.lora["scale"])
             self._y0 = y0
             return y if residual is None else self.rt.ops.add2d(y0, residual, y)
+        kw = {} if ln is None else {"ln": ln}
+        if parts_for is not None:
+            parts_for._parts = None
+            if (parts_for.folded and PARTS and hasattr(self.rt.ops, "gemm_emits_parts") and self.ln is None and Ct is None and geglu_out is None and act_out is None):
+                P = self.rt.ops.gemm_emits_parts(M, self.N, self.K, self.arena.Rp if self.lora is not None else 0)
+                if P:
+                    parts_for._parts = (parts_for.buf("parts", M * P * 2, dtype=F32), P)
+                    kw["ln_parts_out"] = parts_for._parts[0]
         if geglu_out is not None:
-            self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, residual=residual, Ct=Ct, geglu_out=geglu_out)
+            self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, residual=residual, Ct=Ct, geglu_out=geglu_out, **kw)
         elif act_out is not None:
-            self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, residual=residual, Ct=Ct, act_out=act_out)
+            self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, residual=residual, Ct=Ct, act_out=act_out, **kw)
         else:
-            self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, residual=residual, Ct=Ct)
+            self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, residual=residual, Ct=Ct, **kw)
         return y
 
     def backward(self, dy, *, dres=None, Ct=None, key="dx", out=None, dact_in=None):
@@ -430,6 +468,31 @@ class StackedLinear(_Module):
                         m.Wt = None
                     self.arena.dora_wts.append(dict(src=self.Wt, dst=self.Wt_d, entries=[m.lora for m in members]))
 
+    ln = None
+
+    def fold_ln(self, norm, w32s):
+        """Linear.fold_ln for the stack (w32s: the members' fp32 weights): one folded operand, one adapter-constant block per member."""
+        rt = self.rt
+        assert self.trainer is None and not self.dora and (not self.has_lora or self.arena.Rp == 16)
+        N = self.N
+        if getattr(self, "Wt", None) is None:      # the dX operand is built lazily from W: take it from the UNFOLDED weights now
+            self.Wt = self.W.t().contiguous()
+            for m in self.members:
+                m.Wt = None
+        self.W, self.ln_c1, self.bias = rt.ops.fold_layernorm(torch.cat([w.to(rt.device) for w in w32s], 0), self.bias, norm.gamma, norm.beta, dtype=rt.act)
+        for g, m in enumerate(self.members):
+            m.W = self.W[g * N:(g + 1) * N]
+            if m.lora is not None:
+                m.lora["W"] = m.W
+        if self.has_lora:
+            Rp = self.arena.Rp
+            self.ln_Ag, self.ln_consts = rt.zeros(self.G * Rp, self.K), rt.zeros(self.G * 32, dtype=F32)
+            for g, m in enumerate(self.members):
+                self.arena.ln_items.append(dict(entry=m.lora, gamma=norm.gamma, beta=norm.beta, Ag=self.ln_Ag[g * Rp:(g + 1) * Rp], consts=self.ln_consts[g * 32:(g + 1) * 32]))
+            norm.emit_y = True
+        self.ln = norm
+        norm.folded = True
+
     def prepare(self, x):
         """Allocates the stacked output / T buffers for input x and points the members at their slices (no launch)."""
         M, N, G = x.shape[0], self.N, self.G
@@ -439,8 +502,9 @@ class StackedLinear(_Module):
             Rp = self.arena.Rp
             T = self.buf("T", M, G * Rp)
         outs = []
+        xin = x if self.ln is None or not self.has_lora else self.ln.ybuf()      # (folded LayerNorm: the adapter gradients read the rows its backward writes)
         for g, m in enumerate(self.members):
-            m._x = x
+            m._x = xin
             m._b["y"] = m._y0 = y[:, g * N:(g + 1) * N]
             if self.has_lora:
                 m._b["T"] = T[:, g * Rp:(g + 1) * Rp]
@@ -450,9 +514,11 @@ class StackedLinear(_Module):
     def forward(self, x, Ct=None):
         """Returns the member outputs as column slices of one [M, G*N] buffer."""
         y, T, outs = self.prepare(x)
-        lora = (self.A_cat, self.B_cat, self.arena.scale, T) if self.has_lora else None
-        self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, Ct=Ct, lora_group_n=self.N if self.has_lora else 0,
-                         **({"col_scale": self.col_scale()} if self.dora else {}))
+        lora = (self.A_cat if self.ln is None else self.ln_Ag, self.B_cat, self.arena.scale, T) if self.has_lora else None
+        kw = {"col_scale": self.col_scale()} if self.dora else {}
+        if self.ln is not None:
+            kw["ln"] = (self.ln_c1, self.ln.stats_buf(), self.ln.eps, self.ln_consts if self.has_lora else None) + (self.ln._parts or (None, 0))
+        self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, Ct=Ct, lora_group_n=self.N if self.has_lora else 0, **kw)
         return outs
 
     def col_scale(self):
@@ -662,6 +728,13 @@ class GroupNorm(_Module):
 _LN_NOOP = int(os.environ.get("SDLT_LN_NOOP", "0"))
 
 
+LN_FOLD = int(os.environ.get("SDLT_LN_FOLD", "7"))      # bit 0: norm1 -> to_q|to_k|to_v, bit 1: norm2 -> attn2.to_q, bit 2: norm3 -> ff.net.0.proj (A/B switch)
+
+
+LN_FOLD_WIDTH = int(os.environ.get("SDLT_LN_FOLD_WIDTH", "1280"))   # fold in blocks whose width is a multiple of this (1280: where the producers leave row partials at batch 1)
+PARTS = os.environ.get("SDLT_LN_PARTS", "1") != "0"    # row partials from the producing GEMM (A/B switch; 0: every folded consumer computes its statistics)
+
+
 class LayerNorm(_Module):
     def __init__(self, rt, name, sd, eps=1e-5):
         super().__init__(rt, name)
@@ -670,9 +743,22 @@ class LayerNorm(_Module):
         self.eps = eps
         _register_affine(self, rt, name, sd)
 
+    folded = False      # the forward runs inside the consumer GEMM (Linear.fold_ln / StackedLinear.fold_ln)
+    _parts = None       # (fp32 [M, P, 2], P): row partials the producer of this pass's input left (Linear.forward parts_for=), or None
+    emit_y = False      # ... and the consumer has an adapter: the backward also writes the normalised rows for the adapter-gradient launch
+
+    def stats_buf(self):
+        return self.buf("stats", self._x.shape[0] * 2, dtype=F32)
+
+    def ybuf(self):
+        return self.buf("yln", *self._x.shape)
+
     def forward(self, x, out=None):
-        y = out if out is not None else self.buf("y", *x.shape)
         self._x = x
+        if self.folded:           # no launch: the consumer reads the raw rows and writes (mean, rstd) into stats_buf()
+            assert out is None
+            return x
+        y = out if out is not None else self.buf("y", *x.shape)
         if _LN_NOOP & 1:        # TIMING EXPERIMENT ONLY (SDLT_LN_NOOP): the launch is skipped, y keeps stale data - never set in a real run
             self.buf("stats", x.shape[0] * 2, dtype=F32)
             return y
@@ -685,6 +771,8 @@ class LayerNorm(_Module):
                                 gent=self.gent, bent=self.bent, B=1, HW=self._x.shape[0])
         if _LN_NOOP & 2:
             return dx
+        if self.folded and self.emit_y:
+            return self.rt.ops.layernorm_bwd(self._x, dy, dx, self._b["stats"], gamma=self.gamma, dres=dres, beta=self.beta, y_out=self.ybuf())
         return self.rt.ops.layernorm_bwd(self._x, dy, dx, self._b["stats"], gamma=self.gamma, dres=dres)
 
 
@@ -710,7 +798,7 @@ class Attention(_Module):
         self.d = self.C // heads
         self.scale = 1.0 / math.sqrt(self.d)
 
-    def forward(self, x, ctx, B, N, residual):
+    def forward(self, x, ctx, B, N, residual, parts_for=None):
         """x [B*N, C]; ctx [B*CTX_PAD, D] for cross attention.  Returns residual + to_out(attn)."""
         rt, C = self.rt, self.C
         kv = ctx if self.cross else x
@@ -754,7 +842,7 @@ class Attention(_Module):
                 for b in range(B):
                     rt.ops.gemm(q[b * N:(b + 1) * N], k[b * Nkp:(b + 1) * Nkp], S[b * N:(b + 1) * N], alpha=self.scale)
                 rt.daam.append((self.name, S.view(B, N, CTX_PAD)))
-        return self.to_out.forward(O, residual=residual)
+        return self.to_out.forward(O, residual=residual, parts_for=parts_for)
 
     def backward(self, dout, dctx=None):
         """dout = grad of (residual + to_out(attn)); returns d(attention input) WITHOUT the residual path."""
@@ -844,22 +932,39 @@ class TransformerBlock(_Module):
         # transformer widths >= the value (a huge value = the element-wise kernels).
         self.fused_geglu = (self.ff1.trainer is None and H % 16 == 0 and hasattr(rt.ops, "geglu_perm")
                             and self.ff2.N >= int(os.environ.get("SDLT_GEGLU_MIN_C", "0")))
+        perm = None
         if self.fused_geglu:
             perm = rt.ops.geglu_perm(H, self.ff1.W.device)
             self.ff1.W = self.ff1.W[perm].contiguous()
             self.ff1.Wt = self.ff1.W.t().contiguous()
             self.ff1.bias = self.ff1.bias[perm].contiguous()
+        # LayerNorm forward folded into the GEMM behind it (sdlt_gemm_params.ln_c1): norm1 -> to_q|to_k|to_v, norm2 -> attn2.to_q,
+        # norm3 -> ff.net.0.proj (with the fused GEGLU epilogue only).  Not with the full fine-tune (gamma / beta / W are trained), DoRA (the
+        # column factor needs the unfolded rows) or rank pads above 16.  SDLT_LN_FOLD=0: the LayerNorm launches (bit mask per norm).
+        lin = (self.attn1.to_q, self.attn2.to_q, self.ff1)
+        if (LN_FOLD and hasattr(rt.ops, "LnFoldPlan") and all(l.trainer is None and not l.dora for l in lin) and self.norm1.trainer is None
+                and (arena is None or arena.Rp == 16) and self.attn1.C % LN_FOLD_WIDTH == 0):
+            w = lambda n: sd[n + ".weight"].float()
+            a1 = self.attn1
+            if LN_FOLD & 1:
+                a1.stack.fold_ln(self.norm1, [w(m.name) for m in a1.stack.members])
+            if LN_FOLD & 2:
+                self.attn2.to_q.fold_ln(self.norm2, w(self.attn2.to_q.name))
+            if self.fused_geglu and (LN_FOLD & 4):
+                w3 = w(self.ff1.name).to(rt.device)
+                self.ff1.fold_ln(self.norm3, w3[perm])
 
-    def forward(self, x, ctx, B, N):
-        x1 = self.attn1.forward(self.norm1.forward(x), None, B, N, residual=x)
-        x2 = self.attn2.forward(self.norm2.forward(x1), ctx, B, N, residual=x1)
+    def forward(self, x, ctx, B, N, next_norm=None):
+        """next_norm: the LayerNorm that reads this block's output (the next block's norm1) - see Linear.forward parts_for."""
+        x1 = self.attn1.forward(self.norm1.forward(x), None, B, N, residual=x, parts_for=self.norm2)
+        x2 = self.attn2.forward(self.norm2.forward(x1), ctx, B, N, residual=x1, parts_for=self.norm3)
         if self.fused_geglu:
             g = self.buf("g", x.shape[0], self.ff2.K)
             self.ff1.forward(self.norm3.forward(x2), geglu_out=g)
         else:
             f1 = self.ff1.forward(self.norm3.forward(x2))
             g = self.rt.ops.geglu_fwd(f1, self.buf("g", x.shape[0], f1.shape[1] // 2))
-        return self.ff2.forward(g, residual=x2)
+        return self.ff2.forward(g, residual=x2, parts_for=next_norm)
 
     def backward(self, dx3, dctx):
         rt = self.rt
@@ -884,8 +989,9 @@ class Transformer2D(_Module):
 
     def forward(self, x, ctx, B, HW):
         h = self.proj_in.forward(self.norm.forward(x, None, B, HW))
-        for blk in self.blocks:
-            h = blk.forward(h, ctx, B, HW)
+        self.blocks[0].norm1._parts = None            # (proj_in leaves no row partials)
+        for i, blk in enumerate(self.blocks):
+            h = blk.forward(h, ctx, B, HW, next_norm=self.blocks[i + 1].norm1 if i + 1 < len(self.blocks) else None)
         return self.proj_out.forward(h, residual=x)
 
     def backward(self, dout, dctx):

@@ -48,7 +48,19 @@ def set_throughput_hint(flag):
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
          residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0, batch=None,
-         geglu_out=None, geglu_bwd=None, act_out=None, dact_in=None, col_scale=None):
+         geglu_out=None, geglu_bwd=None, act_out=None, dact_in=None, col_scale=None, ln=None, ln_parts_out=None):
+    if ln is not None:      # folded LayerNorm (sdlt_gemm_params.ln_c1): raw rows in, W = W o gamma, bias = c2
+        c1, stats_, eps_, lnad = ln[:4]
+        assert conv is None and X2 is None and alpha == 1.0 and col_scale is None and not lora_group_k and batch is None
+        xf = X.float()
+        mean = xf.mean(1, keepdim=True)
+        rstd = torch.rsqrt(xf.var(1, unbiased=False, keepdim=True) + eps_)
+        if len(ln) > 4 and ln[4] is not None:      # statistics from the producer's row partials [M, P, 2]
+            pp = ln[4].view(-1)[: X.shape[0] * ln[5] * 2].view(X.shape[0], ln[5], 2).float().sum(1)
+            mean = pp[:, :1] / X.shape[1]
+            rstd = torch.rsqrt((pp[:, 1:] / X.shape[1] - mean * mean).clamp_min(0) + eps_)
+        if stats_ is not None:
+            stats_.view(-1)[: 2 * X.shape[0]].copy_(torch.cat([mean, rstd], 1).reshape(-1))
     if geglu_bwd is not None:     # dX of ff.net.2 fused with GEGLU's backward; F1 / dF1 in the interleaved-16 layout
         f1, df1 = geglu_bwd
         H = W.shape[0]
@@ -70,6 +82,8 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
                  col_scale=it.get("col_scale") if it.get("col_scale") is not None else col_scale)
         return out
     acc = X.float() @ W.float().t() if conv is None else _conv_apply(X, W, conv)
+    if ln is not None:
+        acc = rstd * (acc - mean * c1.float()[None, :])
     if X2 is not None:
         acc = acc + X2.float() @ W2.float().t()
     if lora is not None:
@@ -80,6 +94,9 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
                            for gi in range(Gk)], 1)
         else:
             T = X.float() @ Adown.float().t() if conv is None else _conv_apply(X, Adown, conv)
+        if ln is not None:      # T = rstd (x (A o gamma)^T - mean cA) + A beta, constants [G][cA(16) | abeta(16)]
+            cc = lnad.float().view(-1, 2, 16)
+            T = rstd * (T - mean * cc[:, 0].reshape(1, -1)) + cc[:, 1].reshape(1, -1)
         Tb = (T * scale).to(out.dtype if out.dtype != F32 else X.dtype)
         if T_out is not None:
             T_out.copy_(Tb)
@@ -110,6 +127,9 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
         (dx,) = torch.autograd.grad(y, x, acc)
         acc = dx
     out.copy_(acc.to(out.dtype))
+    if ln_parts_out is not None:      # (sum, sum of squares) of the rounded output row per 80-column tile
+        o = out.float().view(out.shape[0], -1, _part_width(out.shape[1]))
+        ln_parts_out.view(-1)[: o.shape[0] * o.shape[1] * 2].copy_(torch.stack([o.sum(2), (o * o).sum(2)], 2).reshape(-1))
     if act_out is not None:
         kind, a_ = act_out
         a_.copy_((F.gelu(acc) if kind == "gelu" else acc * torch.sigmoid(1.702 * acc)).to(a_.dtype))
@@ -174,6 +194,16 @@ def strip_gemm(X, W, out, *, B, T, Tp, bias=None, residual=None, act_out=None, d
         kind, a = act_out
         a[rows] = (F.gelu(acc) if kind == "gelu" else acc * torch.sigmoid(1.702 * acc)).to(a.dtype)
     return out
+
+
+def _part_width(N):
+    return 80 if (N % 160 == 0 and N // 80 <= 16) else N // 2
+
+
+def gemm_emits_parts(M, N, K, lora_rank_pad=0):
+    """(the emulation leaves partials for every even width - two per row where the 80-column tiling does not apply - so that the CPU tests
+    exercise the producer / consumer plumbing on the tiny topologies too)"""
+    return N // _part_width(N) if N % 2 == 0 else 0
 
 
 def fold_layernorm(W, bias, gamma, beta, dtype=None):
@@ -433,9 +463,11 @@ def layernorm_fwd(x, y, stats, *, gamma, beta, eps=1e-5):
     return y
 
 
-def layernorm_bwd(x, dy, dx, stats, *, gamma, dres=None, dy_slabs=None):
+def layernorm_bwd(x, dy, dx, stats, *, gamma, dres=None, dy_slabs=None, beta=None, y_out=None):
     if dy_slabs is not None:
         dy = dy_slabs.float().sum(0)
+    if y_out is not None:     # sdlt_layernorm_bwd_y: the normalised rows as a second output
+        y_out.copy_(F.layer_norm(x.float(), (x.shape[1],), gamma.float(), beta.float(), 1e-5).to(y_out.dtype))
     xx = x.detach().float().clone().requires_grad_(True)
     z = F.layer_norm(xx, (x.shape[1],), gamma.float(), None, 1e-5)
     (g,) = torch.autograd.grad(z, xx, dy.float())
@@ -569,6 +601,23 @@ def prodigy_step(p, g, p0, m, v, s, hyper, state, acc, l1_sum=None):
         state[PRODIGY_STATE.index(k_)] = val
     decay = 1.0 - h["weight_decay"] * dlr if h["decouple"] else 1.0
     p.mul_(decay).addcdiv_(m, v.sqrt() + f32(d * h["eps"]), value=-dlr)
+
+
+class LnFoldPlan:
+    """sdlt_ln_fold_adapters: Ag = A o gamma (rounded), cA = rowsum(Ag), abeta = A beta."""
+
+    def __init__(self, items, device):
+        self.items = items
+
+    def run(self):
+        for it in self.items:
+            A, Ag, c = it["A32"].float(), it["Ag"], it["consts"]
+            r = A.shape[0]
+            Ag.zero_()
+            Ag[:r].copy_((A * it["gamma"].float()[None, :]).to(Ag.dtype))
+            c.zero_()
+            c[:r].copy_(Ag[:r].float().sum(1))
+            c[16:16 + r].copy_(A @ it["beta"].float())
 
 
 class ShadowPlan:

@@ -40,6 +40,223 @@ def dev(*ts):
     return [t.cuda() if t is not None else None for t in ts]
 
 
+# --------------------------------------------------------------------------------------------- folded LayerNorm
+def _ln_case(M, N, K, G, rank, g, mean=0.7, std=1.5):
+    """Operands of a LayerNorm folded into the projection behind it, the way unet.Linear.fold_ln / StackedLinear.fold_ln build them:
+    raw rows x (non-zero mean), W o gamma, c1, c2, per-adapter A o gamma + constants; plus the UNFOLDED reference y = LN(x), W, A."""
+    x = (torch.randn(M, K, generator=g) * std + mean + torch.randn(M, 1, generator=g)).to(BF)
+    gamma, beta = 1.0 + 0.2 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    W32 = torch.randn(N, K, generator=g) * K ** -0.5
+    bias = torch.randn(N, generator=g) * 0.1
+    Wg, c1, c2 = E.fold_layernorm(W32, bias, gamma, beta, dtype=BF)
+    A32 = [torch.randn(rank, K, generator=g) * K ** -0.5 for _ in range(G)] if rank else []
+    Bup = rnd(N, 16, g=g, scale=0.3) if rank else None
+    if rank:
+        Bup[:, rank:] = 0
+    Ag, consts = torch.zeros(G * 16, K, dtype=BF), torch.zeros(G * 32)
+    items = [dict(A32=A32[i], gamma=gamma, beta=beta, Ag=Ag[i * 16:(i + 1) * 16], consts=consts[i * 32:(i + 1) * 32]) for i in range(G if rank else 0)]
+    E.LnFoldPlan(items, "cpu").run()
+    return dict(x=x, gamma=gamma, beta=beta, W32=W32, bias=bias, Wg=Wg, c1=c1, c2=c2, A32=A32, Bup=Bup, Ag=Ag, consts=consts)
+
+
+def _ln_reference(c, M, N, G, rank, scale, residual=None, geglu=False):
+    """The unfolded computation in fp32 on the same bf16 inputs: y = bf16(LN(x)); out = y W^T + b + s bf16(y A^T) B^T (+ residual)."""
+    K = c["x"].shape[1]
+    y = torch.nn.functional.layer_norm(c["x"].float(), (K,), c["gamma"], c["beta"], 1e-5)
+    xf = c["x"].float()
+    stats = torch.stack([xf.mean(1), torch.rsqrt(xf.var(1, unbiased=False) + 1e-5)], 1)
+    out = y @ c["W32"].t() + c["bias"]
+    T = None
+    if rank:
+        gn = N // G
+        T = torch.cat([y @ torch.nn.functional.pad(a, (0, 0, 0, 16 - rank)).t() for a in c["A32"]], 1) * scale
+        for i in range(G):
+            out[:, i * gn:(i + 1) * gn] += T[:, i * 16:(i + 1) * 16].to(BF).float() @ c["Bup"][i * gn:(i + 1) * gn].float().t()
+    if residual is not None:
+        out = out + residual.float()
+    return out, T, stats, y
+
+
+@pytest.mark.parametrize("M,N,K,G,rank,tile,stages,mode", [
+    (1024, 3840, 1280, 3, 16, 0, 0, "plain"),      # attn1 q|k|v of the 1280-wide blocks (128 x 128 tiles, deep ring)
+    (4096, 1920, 640, 3, 16, 0, 0, "plain"),       # ... of the 640-wide blocks (shallow ring)
+    (4096, 640, 640, 1, 8, 0, 0, "res"),           # attn2.to_q, 640 wide
+    (1000, 960, 320, 3, 4, 0, 0, "plain"),         # SD1.5 320-wide stack: 64 x 64 tiles (group width 320), ragged M
+    (2048, 320, 320, 1, 16, 8, 0, "ct"),           # 128 x 160 tile with an adapter + transposed copy
+    (256, 1280, 1280, 1, 16, 2, 4, "plain"),       # 64 x 128 tile
+    (1024, 10240, 1280, 0, 0, 0, 0, "geglu"),      # ff.net.0.proj + GEGLU, 256 x 160 tiles
+    (4096, 5120, 640, 0, 0, 0, 0, "geglu"),
+    (300, 640, 320, 0, 0, 3, 0, "geglu"),          # ragged M, 64 x 64 tile
+    (256, 2560, 320, 0, 0, 8, 0, "geglu"),
+])
+def test_gemm_folded_layernorm(ops, M, N, K, G, rank, tile, stages, mode):
+    """sdlt_gemm_params.ln_c1: LayerNorm folded into the tiled product - against the UNFOLDED fp32 computation on the same inputs
+    (LN -> projection -> adapter), row statistics against torch, T_out against the unfolded adapter product."""
+    g = torch.Generator().manual_seed(M + N + K)
+    scale = 0.75
+    c = _ln_case(M, N, K, max(G, 1), rank, g)
+    res = rnd(M, N, g=g) if mode == "res" else None
+    ref, Tref, stats_ref, _ = _ln_reference(c, M, N, max(G, 1), rank, scale, residual=res)
+    xd, Wg, c1, c2, Ag, consts, Bup, resd = dev(c["x"], c["Wg"], c["c1"], c["c2"], c["Ag"], c["consts"], c["Bup"], res)
+    out = torch.empty(M, N, dtype=BF, device="cuda")
+    stats = torch.zeros(M, 2, device="cuda")
+    T = torch.zeros(M, 16 * max(G, 1), dtype=BF, device="cuda") if rank else None
+    kw = dict(bias=c2, ln=(c1, stats, 1e-5, consts if rank else None), tile=tile, stages=stages)
+    if rank:
+        kw.update(lora=(Ag, Bup, scale, T), lora_group_n=N // G if G > 1 else 0)
+    Ct = gout = None
+    if mode == "geglu":
+        perm = E.geglu_perm(N // 2).cuda()
+        Wg, c1, c2 = Wg[perm].contiguous(), c1[perm].contiguous(), c2[perm].contiguous()
+        gout = torch.empty(M, N // 2, dtype=BF, device="cuda")
+        kw.update(bias=c2, ln=(c1, stats, 1e-5, None), geglu_out=gout)
+    if mode == "ct":
+        Ct = torch.zeros(N, M, dtype=BF, device="cuda")
+        kw["Ct"] = Ct
+    if res is not None:
+        kw["residual"] = resd
+    ops.gemm(xd, Wg, out, **kw)
+    torch.cuda.synchronize()
+    close(stats[:, 0], stats_ref[:, 0], tol=2e-3, what="mean")
+    close(stats[:, 1], stats_ref[:, 1], tol=2e-3, what="rstd")
+    if mode == "geglu":
+        refp = ref[:, perm.cpu()]
+        close(out, refp, what="F1")
+        h, gt = ref.chunk(2, dim=1)
+        close(gout, h * torch.nn.functional.gelu(gt), tol=2e-2, what="geglu")
+    else:
+        close(out, ref, what="out")
+    if rank:
+        close(T, Tref, what="T_out")
+    if Ct is not None:
+        close(Ct.t(), ref, what="Ct")
+
+
+@pytest.mark.parametrize("M,N,K,rank,res", [(1024, 1280, 1280, 16, False), (1024, 1280, 1280, 4, True), (512, 1280, 2560, 16, True), (1024, 1280, 1280, 0, True)])
+def test_wsk_gemm_folded_layernorm(ops, M, N, K, rank, res):
+    """sdlt_wsk_gemm_ln (attn2.to_q of the 1280-wide blocks) against the unfolded fp32 computation; the kernel must be the one that ran."""
+    assert ops.wsk_shape(M, N, K, rank > 0) or rank == 0
+    g = torch.Generator().manual_seed(M + K + rank)
+    scale = 1.0
+    c = _ln_case(M, N, K, 1, rank, g, mean=-1.2, std=2.0)
+    r = rnd(M, N, g=g) if res else None
+    ref, Tref, stats_ref, _ = _ln_reference(c, M, N, 1, rank, scale, residual=r)
+    xd, Wg, c1, c2, Ag, consts, Bup, rd = dev(c["x"], c["Wg"], c["c1"], c["c2"], c["Ag"], c["consts"], c["Bup"], r)
+    out = torch.empty(M, N, dtype=BF, device="cuda")
+    stats = torch.zeros(M, 2, device="cuda")
+    T = torch.zeros(M, 16, dtype=BF, device="cuda") if rank else None
+    lib = ops._lib.load()
+    ops._lib.check(lib.sdlt_wsk_gemm_ln(xd.data_ptr(), K, Wg.data_ptr(), K, M, N, K, c2.data_ptr(), rd.data_ptr() if res else None, N if res else 0, out.data_ptr(), N,
+                                        Ag.data_ptr() if rank else None, K if rank else 0, Bup.data_ptr() if rank else None, 16 if rank else 0, scale,
+                                        T.data_ptr() if rank else None, 16 if rank else 0, c1.data_ptr(), stats.data_ptr(), 1e-5, consts.data_ptr() if rank else None,
+                                        torch.cuda.current_stream().cuda_stream), "sdlt_wsk_gemm_ln")
+    torch.cuda.synchronize()
+    close(stats[:, 0], stats_ref[:, 0], tol=2e-3, what="mean")
+    close(stats[:, 1], stats_ref[:, 1], tol=2e-3, what="rstd")
+    close(out, ref, what="out")
+    if rank:
+        close(T, Tref, what="T_out")
+        # ops.gemm routes the same call to the same kernel: identical bits
+        out2, T2 = torch.empty_like(out), torch.zeros_like(T)
+        ops.gemm(xd, Wg, out2, bias=c2, residual=rd, lora=(Ag, Bup, scale, T2), ln=(c1, stats, 1e-5, consts))
+        torch.cuda.synchronize()
+        assert torch.equal(out2, out) and torch.equal(T2, T)
+
+
+@pytest.mark.parametrize("M,N,K,G,rank,mode", [(1024, 3840, 1280, 3, 16, "plain"), (1024, 1280, 1280, 1, 16, "ct"), (1024, 10240, 1280, 0, 0, "geglu"),
+                                                 (1000, 640, 640, 1, 8, "plain")])
+def test_gemm_folded_layernorm_from_row_partials(ops, M, N, K, G, rank, mode):
+    """sdlt_gemm_params.ln_parts: the statistics are the sum of the row partials the producing launch left (here: computed from x the way
+    sdlt_wsk_gemm_parts does); same contract as the K-walk statistics, checked against the unfolded computation.  (The last case has no kernel
+    variant for partials: they are ignored and the K walk computes the statistics - same result.)"""
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    scale = 1.0
+    c = _ln_case(M, N, K, max(G, 1), rank, g)
+    ref, Tref, stats_ref, _ = _ln_reference(c, M, N, max(G, 1), rank, scale)
+    P = K // 80
+    xt = c["x"].float().view(M, P, 80)
+    parts = torch.stack([xt.sum(2), (xt * xt).sum(2)], 2).contiguous()
+    xd, Wg, c1, c2, Ag, consts, Bup, partsd = dev(c["x"], c["Wg"], c["c1"], c["c2"], c["Ag"], c["consts"], c["Bup"], parts)
+    out = torch.empty(M, N, dtype=BF, device="cuda")
+    stats = torch.zeros(M, 2, device="cuda")
+    T = torch.zeros(M, 16 * max(G, 1), dtype=BF, device="cuda") if rank else None
+    kw = dict(bias=c2, ln=(c1, stats, 1e-5, consts if rank else None, partsd, P))
+    if rank:
+        kw.update(lora=(Ag, Bup, scale, T), lora_group_n=N // G if G > 1 else 0)
+    gout = Ct = None
+    if mode == "geglu":
+        perm = E.geglu_perm(N // 2).cuda()
+        Wg, c1, c2 = Wg[perm].contiguous(), c1[perm].contiguous(), c2[perm].contiguous()
+        gout = torch.empty(M, N // 2, dtype=BF, device="cuda")
+        kw.update(bias=c2, ln=(c1, stats, 1e-5, None, partsd, P), geglu_out=gout)
+    if mode == "ct":
+        Ct = torch.zeros(N, M, dtype=BF, device="cuda")
+        kw["Ct"] = Ct
+    ops.gemm(xd, Wg, out, **kw)
+    torch.cuda.synchronize()
+    close(stats[:, 0], stats_ref[:, 0], tol=2e-3, what="mean")
+    close(stats[:, 1], stats_ref[:, 1], tol=2e-3, what="rstd")
+    if mode == "geglu":
+        close(out, ref[:, perm.cpu()], what="F1")
+        h, gt = ref.chunk(2, dim=1)
+        close(gout, h * torch.nn.functional.gelu(gt), tol=2e-2, what="geglu")
+    else:
+        close(out, ref, what="out")
+    if rank:
+        close(T, Tref, what="T_out")
+    if Ct is not None:
+        close(Ct.t(), ref, what="Ct")
+
+
+@pytest.mark.parametrize("M,N,K,rank,res", [(1024, 1280, 1280, 16, True), (1024, 1280, 5120, 0, True), (512, 1280, 2560, 8, False)])
+def test_wsk_gemm_row_partials(ops, M, N, K, rank, res):
+    """sdlt_wsk_gemm_parts: the output is bit-identical to sdlt_wsk_gemm and the partials are (sum, sum of squares) of the ROUNDED output rows per
+    80-column tile; ops.gemm_emits_parts names exactly these shapes."""
+    assert ops.gemm_emits_parts(M, N, K, 16 if rank else 0) == N // 80
+    g = torch.Generator().manual_seed(M + K + rank + 7)
+    x, w, b = rnd(M, K, g=g), rnd(N, K, g=g, scale=K ** -0.5), torch.randn(N, generator=g)
+    r = rnd(M, N, g=g) if res else None
+    A, Bu = (rnd(16, K, g=g, scale=K ** -0.5), rnd(N, 16, g=g, scale=0.3)) if rank else (None, None)
+    if rank:
+        A[rank:] = 0
+    xd, wd, bd, rd, Ad, Bd = dev(x, w, b, r, A, Bu)
+    o0, o1 = torch.empty(M, N, dtype=BF, device="cuda"), torch.empty(M, N, dtype=BF, device="cuda")
+    parts = torch.zeros(M, N // 80, 2, device="cuda")
+    lora = (Ad, Bd, 1.0, None) if rank else None
+    ops.gemm(xd, wd, o0, bias=bd, residual=rd, lora=lora)
+    ops.gemm(xd, wd, o1, bias=bd, residual=rd, lora=lora, ln_parts_out=parts)
+    torch.cuda.synchronize()
+    assert torch.equal(o0, o1)
+    ot = o1.float().view(M, N // 80, 80)
+    close(parts[:, :, 0], ot.sum(2), tol=1e-4, what="row sums")
+    close(parts[:, :, 1], (ot * ot).sum(2), tol=1e-4, what="row sums of squares")
+
+
+@pytest.mark.parametrize("M,C,rank", [(1024, 1280, 16), (4096, 640, 4), (130, 320, 8)])
+def test_layernorm_bwd_y_and_fold_plan(ops, M, C, rank):
+    """sdlt_layernorm_bwd_y: dx identical to sdlt_layernorm_bwd, y = the forward kernel's rows; sdlt_ln_fold_adapters against its restatement."""
+    g = torch.Generator().manual_seed(M + C)
+    x, dy, dres = rnd(M, C, g=g, scale=2.0), rnd(M, C, g=g), rnd(M, C, g=g)
+    gamma, beta = 1.0 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    xd, dyd, dresd, gd, bd = dev(x, dy, dres, gamma, beta)
+    y0, stats = torch.empty(M, C, dtype=BF, device="cuda"), torch.empty(M, 2, device="cuda")
+    ops.layernorm_fwd(xd, y0, stats, gamma=gd, beta=bd)
+    dx0, dx1, y1 = (torch.empty(M, C, dtype=BF, device="cuda") for _ in range(3))
+    ops.layernorm_bwd(xd, dyd, dx0, stats, gamma=gd, dres=dresd)
+    ops.layernorm_bwd(xd, dyd, dx1, stats, gamma=gd, dres=dresd, beta=bd, y_out=y1)
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, dx1) and torch.equal(y0, y1)
+    A32 = torch.randn(3, rank, C, generator=g) * C ** -0.5
+    Ag_ref, c_ref = torch.zeros(3, 16, C, dtype=BF), torch.zeros(3, 32)
+    E.LnFoldPlan([dict(A32=A32[i], gamma=gamma, beta=beta, Ag=Ag_ref[i], consts=c_ref[i]) for i in range(3)], "cpu").run()
+    A32d = A32.cuda()
+    Ag, cc = torch.full((3, 16, C), 7.0, dtype=BF, device="cuda"), torch.full((3, 32), 7.0, device="cuda")
+    ops.LnFoldPlan([dict(A32=A32d[i], gamma=gd, beta=bd, Ag=Ag[i], consts=cc[i]) for i in range(3)], "cuda").run()
+    torch.cuda.synchronize()
+    assert torch.equal(Ag.cpu(), Ag_ref)
+    close(cc, c_ref, tol=1e-4, what="constants")
+
+
 # --------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,H,K,tile,splitk", [(300, 320, 128, 0, 0), (1024, 640, 320, 7, 0), (1024, 640, 320, 8, 0), (256, 64, 512, 3, 2),
                                                  (1000, 1280, 320, 1, 0), (128, 160, 1024, 2, 4)])
