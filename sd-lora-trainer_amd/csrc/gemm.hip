@@ -109,7 +109,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
     int live = splitk == 1 ? 32 : div_small_u(32, splitk);                          // tiles of the ~32 workgroups an XCD runs concurrently
     live = live < 1 ? 1 : live;
     live = per_xcd < live ? per_xcd : live;
-    int GROUP_M = (int)(sqrtf((float)live * BN / BM) + 0.5f);
+    // (implicit-GEMM convolution: the nine taps of a row tile re-read the same activation rows, so an X panel costs the L2 a ninth of what its K
+    //  length says while a W panel costs all of it - the super-tile that minimises fetched bytes is nine times taller)
+#ifndef SDLT_CONV_GROUP_FACTOR
+#define SDLT_CONV_GROUP_FACTOR 9
+#endif
+    int GROUP_M = (int)(sqrtf((float)live * BN / BM * (MODE == 1 ? SDLT_CONV_GROUP_FACTOR : 1)) + 0.5f);
     GROUP_M = GROUP_M < 1 ? 1 : (GROUP_M > nbm ? nbm : GROUP_M);
     const int per_group = GROUP_M * nbn;
     const int grp = div_small_u(tile_id, per_group), first_m = grp * GROUP_M;
