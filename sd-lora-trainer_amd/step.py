@@ -20,6 +20,9 @@ assert TP == CTX_PAD
 TEXT_PAIR = os.environ.get("SDLT_TEXT_PAIR", "1") != "0"
 
 
+TAIL_OVERLAP = os.environ.get("SDLT_TAIL_OVERLAP", "0") != "0"      # measured: 44.15 vs 42.66 ms - the two extra graph launches and the event join cost 1.5 ms, off by default
+
+
 class TextStack:
     """The text encoders wired as diffusers' `encode_prompt` wires them (trainer/inference.py:131-177):
     SD1.5: prompt_embeds = CLIP-L last_hidden_state (after final LN).
@@ -615,6 +618,24 @@ class TrainStep:
             return [self.body]
         return [self._phase_text_fwd, self._phase_unet, lambda: (self._phase_text_bwd(), self.optimizer_step())]
 
+    # Tail overlap (SDLT_TAIL_OVERLAP=1; built, measured in round 4 and left OFF - see the constant): for LoRA + TI jobs on one GPU, once the UNet backward has produced dL/d(conditioning), the
+    # text-encoder backward (2.2 ms of 77-row launches that fill a third of the chip) and the UNet's own tail - the grouped adapter-gradient
+    # launch, AdamW on the adapter arena, the operand refresh (1.0 ms, HBM-bound) - are independent.  Forked branches inside ONE hipGraph are
+    # replayed one after the other by this runtime (see above), but two graphs launched on two streams do overlap (that is how two jobs
+    # share a GPU): the step is replayed as graph A (text forward, UNet forward + backward) on the step's stream, then graph B
+    # (the UNet tail) on a side stream beside graph C (text backward, token-row optimizer) on the step's stream, joined by events.
+    def _phase_unet_tail(self):
+        self.unet.lora_grads()
+        self._unet_optimizer()
+
+    def _phase_text_tail(self):
+        self._phase_text_bwd()
+        self._other_optimizers()
+
+    def _overlap_ok(self):
+        return (TAIL_OVERLAP and self.world == 1 and self._acc is None and self.text is not None and not self.text.concurrent and not self.full_ft
+                and self.rt.device.type == "cuda" and not getattr(self, "zero1", False))
+
     def _phase_unet_cached(self):
         """UNet phase on a conditioning the caller placed in self.ctx / self.pooled (frozen token rows: no text-encoder forward)."""
         self._pooled_live = self.pooled
@@ -755,6 +776,25 @@ class TrainStep:
 
         self.graphs, self.graphs_frozen, pool = cap_set(None)
         self.graph = self.graphs[0]
+        self.graphs_overlap = None
+        if self._overlap_ok():
+            # graph A / C on this capture's stream and pool; graph B on the side stream with a pool of its own (it runs beside C)
+            self.unet.defer_lora_grads = True
+            try:
+                gA = cap([self._phase_text_fwd, self._phase_unet], pool)
+                pool = gA.pool()
+                self._side = torch.cuda.Stream()
+                self._side.wait_stream(torch.cuda.current_stream())
+                gB = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gB, stream=self._side):
+                    self._phase_unet_tail()
+                torch.cuda.current_stream().wait_stream(self._side)
+                gC = cap([self._phase_text_tail], pool)
+                pool = gC.pool()
+                self.graphs_overlap = (gA, gB, gC)
+                self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
+            finally:
+                self.unet.defer_lora_grads = False
         if self._acc is not None:
             self.graphs_frozen = None
             self.graphs_micro = [cap([self.body_micro], pool)]
@@ -806,6 +846,17 @@ class TrainStep:
             self.graphs[0].replay()
             self.sync_gradients()
             self.graphs[1].replay()
+        elif self.graph is not None and not frozen and getattr(self, "graphs_overlap", None) is not None:
+            gA, gB, gC = self.graphs_overlap
+            cur = torch.cuda.current_stream()
+            gA.replay()
+            self._ev_fork.record(cur)
+            self._side.wait_event(self._ev_fork)
+            with torch.cuda.stream(self._side):
+                gB.replay()
+                self._ev_join.record(self._side)
+            gC.replay()
+            cur.wait_event(self._ev_join)
         elif self.graph is not None:
             cached = frozen and self._cond_cached and self.graphs_frozen_cached is not None
             assert not self._cond_cached or frozen, "a cached conditioning is only valid while the token rows are frozen (ti lr == 0, no text-encoder LoRA)"

@@ -1396,12 +1396,16 @@ def _count_paired(ops, gens, prefer):
                                         (dict(SDLT_ATTN_XCD="0", SDLT_ATTN_KS="1", SDLT_ATTN_R32="0"), "test_attention_fwd_bwd"),
                                         (dict(SDLT_ATTN32_KS_FWD="4", SDLT_ATTN32_KS_BWD="4"), "test_attention_fwd_bwd"),
                                         (dict(SDLT_ATTN32_KS_FWD="1", SDLT_ATTN32_KS_BWD="1"), "test_attention_fwd_bwd"),
-                                        (dict(SDLT_WSK_STAGGER="0", SDLT_STRIP_WIDE_MIN="4096"), "test_wsk or test_strip")],
-                         ids=["single-role", "single-role-128-keys", "plain-order-unsplit-16-rows", "attn32-four-groups", "attn32-one-group", "unstaggered-narrow-strips"])
+                                        (dict(SDLT_WSK_STAGGER="0", SDLT_STRIP_WIDE_MIN="4096"), "test_wsk or test_strip"),
+                                        (dict(SDLT_LN_FOLD="7", SDLT_LN_FOLD_WIDTH="64", SDLT_LN_PARTS="0"), "file:test_ti_step_gpu.py:trajectory or step"),
+                                        (dict(SDLT_LN_FOLD="0"), "file:test_ti_step_gpu.py:trajectory or step"),
+                                        (dict(SDLT_TAIL_OVERLAP="1"), "file:test_ti_step_gpu.py:trajectory or step")],
+                         ids=["single-role", "single-role-128-keys", "plain-order-unsplit-16-rows", "attn32-four-groups", "attn32-one-group", "unstaggered-narrow-strips",
+                              "layernorm-fold-every-width-k-walk-statistics", "layernorm-launches", "tail-overlap-two-streams"])
 def test_fallback_kernel_paths_in_a_subprocess(env, select):
     """The A/B switches are read once per process, so the non-default kernels behind them (single-role / 128-key cross-attention backward,
-    plain workgroup order, unsplit attention forward, unstaggered wave-split-K refills, 16-column strips) run in a child pytest: the same
-    checks must pass on them too."""
+    plain workgroup order, unsplit attention forward, unstaggered wave-split-K refills, 16-column strips; step level: the LayerNorm fold at every
+    width with K-walk statistics / the LayerNorm launches / the two-stream tail) run in a child pytest: the same checks must pass on them too."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import subprocess
@@ -1409,7 +1413,10 @@ def test_fallback_kernel_paths_in_a_subprocess(env, select):
     e = dict(os.environ)
     e.update(env)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+    target = "test_kernels_gpu.py"
+    if select.startswith("file:"):          # "file:<test file>:<-k expression>": a step-level switch checked by that file's tests
+        _, target, select = select.split(":", 2)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", target), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
                         "-k", f"({select}) and not subprocess"],       # (never this test itself: a child that selects it spawns children for ever)
                        env=e, cwd=root, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
