@@ -34,3 +34,5 @@ for v in "--no-ti" "--ti-frozen" "--config sd15" "--full-ft" "--rank 64" "--jobs
   timeout 600 python bench.py $v $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', round(d['ms_per_step'],2), round(d['value'],2), round(d['roofline']['frac'],4))" >> $O/r04_bench_variants.txt
 done
 timeout 900 python bench.py --profile-json $O/r04_sdxl1024_ti_step_profile.json > $O/r04_bench_line.json 2> $O/bench_default.err
+# RCCL sanity on the one GPU of the box: the driver's launch line with one rank (process group "nccl" = RCCL, barrier + MAX reduction of the timing)
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 $B > $O/r04_bench_line_torchrun_1rank.json 2> $O/torchrun.err
