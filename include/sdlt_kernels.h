@@ -125,8 +125,9 @@ typedef struct sdlt_gemm_params {
   float* ln_stats;
   const float* ln_adapter;
   float ln_eps;
-  /* ln_parts (optional, with ln_nparts even, 2..16): fp32 [M, ln_nparts, 2] = (sum x, sum x^2) of every row per column tile of the launch that
-     PRODUCED X (sdlt_wsk_gemm_parts) - the statistics are then the sum of a row's partials and the K walk carries no extra work.  Used where a
+  /* ln_parts (optional, with ln_nparts even, 2..16): fp32 [M, ln_nparts, 2] = (sum x, sum (x - tile mean)^2) of every row per column tile
+     (K / ln_nparts columns each) of the launch that PRODUCED X (sdlt_wsk_gemm_parts) - the statistics are then merged from a row's partials
+     (M2 = sum_t M2_t + n_t (mean_t - mean)^2: as stable as a two-pass variance) and the K walk carries no extra work.  Used where a
      kernel variant for it exists (the shapes of the 1280-wide blocks); otherwise ignored and the statistics are computed from the K walk. */
   int32_t ln_nparts;
   const void* ln_parts;
@@ -526,7 +527,7 @@ int sdlt_wsk_gemm_ln(const void* X, int64_t ldx, const void* W, int64_t ldw, int
                      float lora_scale, void* T_out, int64_t ld_t, const float* ln_c1, float* ln_stats, float ln_eps,
                      const float* ln_adapter, void* stream);
 
-/* sdlt_wsk_gemm that also leaves, for the LayerNorm that reads its output next, ln_parts fp32 [M, N / 80, 2] = (sum y, sum y^2) of every ROUNDED
+/* sdlt_wsk_gemm that also leaves, for the LayerNorm that reads its output next, ln_parts fp32 [M, N / 80, 2] = (sum y, sum (y - tile mean)^2) of every ROUNDED
  * output row over each 80-column tile (to_out.0 + residual -> norm2 / norm3, ff.net.2 + residual -> the next block's norm1): the consumer
  * (sdlt_gemm_params.ln_parts) adds N / 80 partials per row instead of reducing the row in its K walk. */
 int sdlt_wsk_gemm_parts(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t M, int32_t N, int32_t K, const float* bias,

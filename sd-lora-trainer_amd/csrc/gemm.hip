@@ -572,12 +572,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
   if constexpr (LN == 2) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid < BM) {
-      float s1 = 0.f, s2 = 0.f;
+      // partial t = (sum, centred sum of squares) of K / ln_nparts columns: total M2 = sum_t M2_t + n_t (mean_t - mean)^2 (no large cancellation)
+      float s1 = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { s1 += lnp[i][0]; s2 += lnp[i][1]; s1 += lnp[i][2]; s2 += lnp[i][3]; }      // (absent partials are zero; ln_nparts even)
-      const float inv = 1.f / (float)p.K;
-      const float mean = s1 * inv, var = s2 * inv - mean * mean;
-      const float rstd = rsqrtf((var > 0.f ? var : 0.f) + p.ln_eps);
+      for (int i = 0; i < 8; ++i) s1 += lnp[i][0] + lnp[i][2];          // (absent partials are zero; ln_nparts even)
+      const float inv = 1.f / (float)p.K, nt = (float)p.K / (float)p.ln_nparts, invt = 1.f / nt;
+      const float mean = s1 * inv;
+      float m2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (2 * i < p.ln_nparts) {
+          const float d0 = lnp[i][0] * invt - mean, d1 = lnp[i][2] * invt - mean;
+          m2 += lnp[i][1] + lnp[i][3] + nt * (d0 * d0 + d1 * d1);
+        }
+      }
+      const float rstd = rsqrtf(m2 * inv + p.ln_eps);
       *(float2*)(lnsh + 2 * tid) = make_float2(mean, rstd);
       if (p.ln_stats && bn == 0 && m0 + tid < p.M) *(float2*)(p.ln_stats + (size_t)(m0 + tid) * 2) = make_float2(mean, rstd);
     }

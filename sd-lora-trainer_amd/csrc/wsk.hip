@@ -46,7 +46,7 @@ struct wsk_params {
   float* ln_stats;
   const float* ln_adapter;
   float ln_eps;
-  // row partials for the NEXT LayerNorm (any kernel): ln_parts [M, N / 80] float2 = (sum y, sum y^2) of the ROUNDED output row over this tile's 80
+  // row partials for the NEXT LayerNorm (any kernel): ln_parts [M, N / 80] float2 = (sum y, sum (y - tile mean)^2) of the ROUNDED output row over this tile's 80
   // columns - the consumer GEMM of a folded LayerNorm (sdlt_gemm_params.ln_parts) adds the N / 80 partials of a row instead of walking it
   float2* ln_parts;
 };
@@ -335,15 +335,22 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
     *(uint2*)(p.Y + (int64_t)m * p.ldy + n) = ov;
     if (p.ln_parts) {     // (wave-uniform) this unit's 16 columns of row (mb, r): the four lanes r + 16 g hold four each
       const float y0 = bf2f(ov.x & 0xffff), y1 = bf2f(ov.x >> 16), y2 = bf2f(ov.y & 0xffff), y3 = bf2f(ov.y >> 16);
-      psh[((mb * 16 + r) * JN + j) * 4 + g] = make_float2(y0 + y1 + y2 + y3, y0 * y0 + y1 * y1 + y2 * y2 + y3 * y3);     // (no cross-lane step: the row's 4 JN slots are added below)
+      // (sum, CENTRED sum of squares) of this lane's four columns: the slots of a row are merged below around the tile's row mean (the update of Chan et al.), so
+      // the variance never comes out of a difference of two large numbers (rows whose mean dwarfs their spread)
+      const float s4 = y0 + y1 + y2 + y3, m4 = 0.25f * s4;
+      psh[((mb * 16 + r) * JN + j) * 4 + g] = make_float2(s4, (y0 - m4) * (y0 - m4) + (y1 - m4) * (y1 - m4) + (y2 - m4) * (y2 - m4) + (y3 - m4) * (y3 - m4));
     }
   }
   if (p.ln_parts) {
     __syncthreads();
     if (threadIdx.x < XR) {
-      float2 t = psh[threadIdx.x * JN * 4];
+      float2 u[JN * 4];
+      float2 t = make_float2(0.f, 0.f);
 #pragma unroll
-      for (int j = 1; j < JN * 4; ++j) { const float2 u = psh[threadIdx.x * JN * 4 + j]; t.x += u.x; t.y += u.y; }
+      for (int j = 0; j < JN * 4; ++j) { u[j] = psh[threadIdx.x * JN * 4 + j]; t.x += u[j].x; }
+      const float mt = t.x * (1.f / (16 * JN));            // the tile's row mean; M2 = sum_slots M2_s + 4 (mean_s - mean)^2
+#pragma unroll
+      for (int j = 0; j < JN * 4; ++j) { const float d = u[j].x * 0.25f - mt; t.y += u[j].y + 4.f * d * d; }
       p.ln_parts[(int64_t)(m0 + threadIdx.x) * ntn + tn] = t;
     }
   }

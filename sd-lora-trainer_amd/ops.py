@@ -161,7 +161,7 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
     ln = (c1 fp32 [N], stats fp32 [M, 2] or None, eps, adapter constants fp32 [G*32] or None): the LayerNorm in front of this product is
     folded in (fold_layernorm: X = the raw rows, W = W o gamma, bias = c2; with an adapter Adown = A o gamma, LnFoldPlan) - sdlt_gemm_params.ln_c1.
     ... optionally followed by (parts fp32 [M, P, 2], P): the row partials the PRODUCER of X left (ln_parts_out of that call).
-    ln_parts_out fp32 [M, N / 80, 2]: also leave the row partials (sum, sum of squares of the rounded output row per 80-column tile) for the
+    ln_parts_out fp32 [M, N / 80, 2]: also leave the row partials (sum, centred sum of squares of the rounded output row per 80-column tile) for the
     LayerNorm that reads `out` next - only where this call runs on the wave-split-K kernel (gemm_emits_parts says so; asserted).
     batch: a GemmBatch - the launch runs len(batch) problems of identical shape / leading dimensions; the tensor arguments
     describe problem 0 (shapes, strides, options), every problem's operand pointers come from the batch."""

@@ -56,9 +56,11 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
         mean = xf.mean(1, keepdim=True)
         rstd = torch.rsqrt(xf.var(1, unbiased=False, keepdim=True) + eps_)
         if len(ln) > 4 and ln[4] is not None:      # statistics from the producer's row partials [M, P, 2]
-            pp = ln[4].view(-1)[: X.shape[0] * ln[5] * 2].view(X.shape[0], ln[5], 2).float().sum(1)
-            mean = pp[:, :1] / X.shape[1]
-            rstd = torch.rsqrt((pp[:, 1:] / X.shape[1] - mean * mean).clamp_min(0) + eps_)
+            pp = ln[4].view(-1)[: X.shape[0] * ln[5] * 2].view(X.shape[0], ln[5], 2).float()      # (sum, centred sum of squares) per tile
+            nt = X.shape[1] / ln[5]
+            mean = pp[:, :, 0].sum(1, keepdim=True) / X.shape[1]
+            m2 = pp[:, :, 1].sum(1, keepdim=True) + (nt * (pp[:, :, 0] / nt - mean) ** 2).sum(1, keepdim=True)
+            rstd = torch.rsqrt(m2 / X.shape[1] + eps_)
         if stats_ is not None:
             stats_.view(-1)[: 2 * X.shape[0]].copy_(torch.cat([mean, rstd], 1).reshape(-1))
     if geglu_bwd is not None:     # dX of ff.net.2 fused with GEGLU's backward; F1 / dF1 in the interleaved-16 layout
@@ -127,9 +129,9 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
         (dx,) = torch.autograd.grad(y, x, acc)
         acc = dx
     out.copy_(acc.to(out.dtype))
-    if ln_parts_out is not None:      # (sum, sum of squares) of the rounded output row per 80-column tile
+    if ln_parts_out is not None:      # (sum, centred sum of squares) of the rounded output row per 80-column tile
         o = out.float().view(out.shape[0], -1, _part_width(out.shape[1]))
-        ln_parts_out.view(-1)[: o.shape[0] * o.shape[1] * 2].copy_(torch.stack([o.sum(2), (o * o).sum(2)], 2).reshape(-1))
+        ln_parts_out.view(-1)[: o.shape[0] * o.shape[1] * 2].copy_(torch.stack([o.sum(2), ((o - o.mean(2, keepdim=True)) ** 2).sum(2)], 2).reshape(-1))
     if act_out is not None:
         kind, a_ = act_out
         a_.copy_((F.gelu(acc) if kind == "gelu" else acc * torch.sigmoid(1.702 * acc)).to(a_.dtype))

@@ -171,11 +171,11 @@ def test_gemm_folded_layernorm_from_row_partials(ops, M, N, K, G, rank, mode):
     variant for partials: they are ignored and the K walk computes the statistics - same result.)"""
     g = torch.Generator().manual_seed(M + N + K + 1)
     scale = 1.0
-    c = _ln_case(M, N, K, max(G, 1), rank, g)
+    c = _ln_case(M, N, K, max(G, 1), rank, g, mean=40.0 if mode == "plain" else 0.7)     # (rows whose mean dwarfs their spread: the merged partials stay exact)
     ref, Tref, stats_ref, _ = _ln_reference(c, M, N, max(G, 1), rank, scale)
     P = K // 80
     xt = c["x"].float().view(M, P, 80)
-    parts = torch.stack([xt.sum(2), (xt * xt).sum(2)], 2).contiguous()
+    parts = torch.stack([xt.sum(2), ((xt - xt.mean(2, keepdim=True)) ** 2).sum(2)], 2).contiguous()
     xd, Wg, c1, c2, Ag, consts, Bup, partsd = dev(c["x"], c["Wg"], c["c1"], c["c2"], c["Ag"], c["consts"], c["Bup"], parts)
     out = torch.empty(M, N, dtype=BF, device="cuda")
     stats = torch.zeros(M, 2, device="cuda")
@@ -210,7 +210,7 @@ def test_gemm_folded_layernorm_from_row_partials(ops, M, N, K, G, rank, mode):
 
 @pytest.mark.parametrize("M,N,K,rank,res", [(1024, 1280, 1280, 16, True), (1024, 1280, 5120, 0, True), (512, 1280, 2560, 8, False)])
 def test_wsk_gemm_row_partials(ops, M, N, K, rank, res):
-    """sdlt_wsk_gemm_parts: the output is bit-identical to sdlt_wsk_gemm and the partials are (sum, sum of squares) of the ROUNDED output rows per
+    """sdlt_wsk_gemm_parts: the output is bit-identical to sdlt_wsk_gemm and the partials are (sum, centred sum of squares) of the ROUNDED output rows per
     80-column tile; ops.gemm_emits_parts names exactly these shapes."""
     assert ops.gemm_emits_parts(M, N, K, 16 if rank else 0) == N // 80
     g = torch.Generator().manual_seed(M + K + rank + 7)
@@ -229,7 +229,7 @@ def test_wsk_gemm_row_partials(ops, M, N, K, rank, res):
     assert torch.equal(o0, o1)
     ot = o1.float().view(M, N // 80, 80)
     close(parts[:, :, 0], ot.sum(2), tol=1e-4, what="row sums")
-    close(parts[:, :, 1], (ot * ot).sum(2), tol=1e-4, what="row sums of squares")
+    close(parts[:, :, 1], ((ot - ot.mean(2, keepdim=True)) ** 2).sum(2), tol=1e-4, what="centred row sums of squares")
 
 
 @pytest.mark.parametrize("M,C,rank", [(1024, 1280, 16), (4096, 640, 4), (130, 320, 8)])
