@@ -201,6 +201,67 @@ def cpu_baseline(version, rank, full_hw, budget_s=150.0, with_text=True):
     return dict(times=times, hw=h, flops=flops(h), cores=cores, what=what)
 
 
+def library_gpu_baseline(version, rank, hw, steps=5):
+    """The SAME step as cpu_baseline (oracle.step_ref.RefTrainer.step, the torch restatement of main.py:263-382), executed on cuda:0 by PyTorch-ROCm's
+    own kernels the way the reference runs it: frozen UNet / text-encoder weights in bf16 (config.py:99 weight_type), trainable LoRA tensors and
+    token tables in fp32, torch.autocast(bfloat16), F.scaled_dot_product_attention for every attention without the DAAM hook (diffusers
+    AttnProcessor2_0), torch.optim.AdamW.  A reported baseline like cpu_baseline - what the library path reaches on this GPU for the step the HIP
+    path replaces (diffusers / peft are thin module wrappers over these calls; they are not installed here).  Returns a dict for the JSON line."""
+    from oracle import step_ref as R
+    from oracle import unet_ref as U
+    from sd_lora_trainer_amd import topology
+    dev = torch.device("cuda", 0)
+    cfg = U.CONFIGS[version]
+    torch.manual_seed(0)
+    sd = {}
+    for n, shp in U.param_shapes(cfg).items():
+        t = torch.randn(shp, device=dev)
+        t = t / math.sqrt(math.prod(shp[1:])) if len(shp) >= 2 else t * 0.02
+        if (".norm" in n or n.startswith("conv_norm_out")) and len(shp) == 1 and n.endswith(".weight"):
+            t = 1.0 + t
+        sd[n] = t.to(torch.bfloat16)
+    lora = {k: tuple(t.to(dev) for t in v) for k, v in U.init_lora(cfg, rank, seed=1, b_std=0.01).items()}
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
+    n_tok, text_models, vocab = 3, [], None
+    for kd in (["clip_l", "clip_g"] if cfg["addition"] else ["clip_l"]):
+        c = topology.CLIP_CONFIGS[kd]
+        vocab = c["vocab"] + n_tok
+        hc = CLIPTextConfig(vocab_size=vocab, hidden_size=c["width"], intermediate_size=c["mlp"], num_hidden_layers=c["layers"], num_attention_heads=c["heads"],
+                            max_position_embeddings=77, hidden_act=c["act"], projection_dim=c["proj"] or 768, eos_token_id=2, bos_token_id=0, pad_token_id=1)
+        m = (CLIPTextModelWithProjection if c["proj"] else CLIPTextModel)(hc).eval().to(dev).to(torch.bfloat16)
+        m.get_input_embeddings().weight.data = m.get_input_embeddings().weight.data.float()       # the trained tables stay fp32 (main.py:106-113 upcasts what it trains)
+        text_models.append(m)
+    tr = R.RefTrainer(cfg, sd, lora, text_models=text_models, n_tokens=n_tok, train_ids=[vocab - 3, vocab - 2, vocab - 1], snr_gamma=5.0, l1_penalty=0.03, weight_decay=0.004)
+    U.USE_SDPA = True
+    g = torch.Generator().manual_seed(1)
+    latent = (torch.randn(1, 4, hw, hw, generator=g) * cfg["scaling_factor"]).to(dev)
+    noise = torch.randn(1, 4, hw, hw, generator=g).to(dev)
+    mask = (torch.rand(1, 1, hw, hw, generator=g).repeat(1, 4, 1, 1) * 0.95 + 0.05).to(dev)
+    t = torch.tensor([500], device=dev)
+    tid = torch.tensor([[1024., 1024, 0, 0, 8. * hw, 8. * hw]], device=dev) if cfg["addition"] else None
+    words = torch.randint(1000, 40000, (8,), generator=g).tolist()
+    l = [49406] + words[:4] + [vocab - 3, vocab - 2, vocab - 1] + words[4:] + [49407]
+    ids = torch.full((1, 77), 49407, dtype=torch.int64)
+    ids[0, :len(l)] = torch.tensor(l)
+    ids = ids.to(dev)
+
+    def one():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return tr.step(latent, noise, t, mask, lr=1e-4, ids=ids, caption_token_lists=[l], time_ids=tid, lr_ti=1e-3)
+    for _ in range(2):
+        out = one()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(steps):
+        out = one()
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / steps
+    return {"value": 1.0 / dt, "unit": "images/s", "ms_per_step": dt * 1e3, "steps": steps, "loss": out["tot_loss"],
+            "sample": f"the torch restatement of the reference step (oracle.step_ref.RefTrainer.step: text encoders, UNet + LoRA forward / backward with autograd, both losses, L1, "
+                      f"both torch.optim.AdamW) on cuda:0 at {hw * 8}x{hw * 8} B=1: bf16 frozen weights, fp32 trained tensors, torch.autocast(bfloat16), scaled_dot_product_attention "
+                      f"for the attentions without the DAAM hook - PyTorch-ROCm's library kernels on the same GPU, eager, after 2 warm-up steps"}
+
+
 def train_loop_measure(args):
     """The workload driven by the train() generator (sd_lora_trainer_amd.train, the main.py:34-551 mirror): per step LR schedules,
     posterior sampling, noise / timestep draws, caption dropout, host->device copies of the batch (set_batch), then the graph replay;
@@ -295,6 +356,8 @@ def main():
     ap.add_argument("--no-train-loop", action="store_true", help="skip the extra measurement of the train() generator's own step loop")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)      # child modes of the guarded extras
     ap.add_argument("--train-loop-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--library-gpu-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-library-gpu", action="store_true", help="skip the extra measurement of the torch restatement of the step on the GPU (library kernels)")
     ap.add_argument("--full-ft", action="store_true", help="full-UNet fine-tune (BASELINE configs[4], train_configs/full_finetuning_example.json: "
                     "SDXL 512 px, batch 4 per GPU, AdamW over every UNet parameter); data parallel when --gpus > 1: per-bucket reduce-scatter, sharded AdamW, all-gather (SDLT_DDP_ZERO1=0: all-reduce)")
     ap.add_argument("--ddp-wire", default=None, choices=["fp32", "bf16"], help="--full-ft --gpus N: dtype of the matrix gradients on the xGMI wire "
@@ -316,6 +379,11 @@ def main():
         version = args.config
         res = args.res or (1024 if "xl" in version else 512)
         print(json.dumps(cpu_baseline(version, args.rank, res // 8, with_text=not args.no_ti)), flush=True)
+        return
+    if args.library_gpu_only:
+        version = args.config
+        res = args.res or (1024 if "xl" in version else 512)
+        print(json.dumps(library_gpu_baseline(version, args.rank, res // 8)), flush=True)
         return
     if args.train_loop_only:
         print(json.dumps(train_loop_measure(args)), flush=True)
@@ -543,6 +611,15 @@ def main():
             if not child:
                 out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": usable_cores(), "kind": "port", "step_seconds": [],
                                        "sample": "the CPU oracle did not complete a step within the 420 s guard of the default run"}
+        if world == 1 and J == 1 and not full_ft and not args.no_cpu_baseline and not args.no_library_gpu and text is not None and not args.no_ti and not args.dora and version in ("sdxl", "sd15") and not args.batch:
+            # Extra object beside cpu_baseline (never `value`): the same torch restatement of the step on THIS GPU through PyTorch-ROCm's library kernels
+            # (library_gpu_baseline), in a child process with a wall-clock limit; the parent's model stays resident, the child needs ~25 GB more
+            if B == 1:
+                child = run_guarded(["--library-gpu-only", "--config", version, "--res", str(res), "--rank", str(args.rank)], 300)
+                if child:
+                    out["library_gpu_baseline"] = child[-1]
+                    out["library_gpu_baseline"]["speedup_of_value"] = out["value"] / child[-1]["value"]
+                print("[bench] library GPU baseline done", file=sys.stderr, flush=True)
         if world == 1 and J == 1 and not full_ft and not args.no_graph and not args.no_train_loop and text is not None:
             # Extra measurement (never `value`), in a child process with a wall-clock limit (see train_loop_measure)
             child = run_guarded(["--train-loop-only", "--config", version, "--res", str(res), "--rank", str(args.rank), "--steps", str(args.steps)]

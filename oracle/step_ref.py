@@ -40,7 +40,7 @@ class RefTrainer:
         self.text = text_models
         self.n_tokens, self.train_ids = n_tokens, train_ids
         self.snr_gamma, self.l1, self.ta_w, self.std_w, self.lora_scale = snr_gamma, l1_penalty, token_attention_loss_w, ti_std_loss_w, lora_scale
-        self.acp = L.ddpm_alphas_cumprod()
+        self.acp = L.ddpm_alphas_cumprod().to(next(iter(sd.values())).device)
         # optimizer.py:17-18: AdamW(params, lr=1e-4 (overwritten every step), weight_decay=lora_weight_decay)
         self.opt_unet = torch.optim.AdamW(self.lora_params, lr=1e-4, weight_decay=weight_decay)
         self.opt_ti = None

@@ -260,7 +260,7 @@ def init_dora_magnitudes(cfg, sd, lora, lora_scale=1.0, jitter=0.0, seed=0):
 def timestep_embedding(t, dim):
     """diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0)."""
     half = dim // 2
-    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half
     emb = t.float()[:, None] * torch.exp(exponent)[None, :]
     return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
 
@@ -336,6 +336,9 @@ def _resnet(c, n, x, temb):
     return c.q(x + h)
 
 
+USE_SDPA = False
+
+
 def _attention(c, n, x, ctx, heads, hooked):
     B, N, C = x.shape
     kv = x if ctx is None else ctx
@@ -346,6 +349,11 @@ def _attention(c, n, x, ctx, heads, hooked):
     qh = q.view(B, N, heads, d).transpose(1, 2)
     kh = k.view(B, -1, heads, d).transpose(1, 2)
     vh = v.view(B, -1, heads, d).transpose(1, 2)
+    if USE_SDPA and not (ctx is not None and hooked):
+        # what the reference runs for every attention without the DAAM hook (diffusers AttnProcessor2_0): the library's fused kernel.  Same
+        # function as the explicit form below; only the library-path timing of bench.py switches it on.
+        o = F.scaled_dot_product_attention(qh, kh, vh)
+        return c.linear(n + ".to_out.0", o.transpose(1, 2).reshape(B, N, C))
     s = qh @ kh.transpose(-1, -2) / math.sqrt(d)
     if ctx is not None and hooked:
         # ti_cross_attn_loss.py:201-212: raw QK^T/sqrt(d) summed over heads, kept in graph
