@@ -943,7 +943,7 @@ class TransformerBlock(_Module):
         # column factor needs the unfolded rows) or rank pads above 16.  SDLT_LN_FOLD=0: the LayerNorm launches (bit mask per norm).
         lin = (self.attn1.to_q, self.attn2.to_q, self.ff1)
         if (LN_FOLD and hasattr(rt.ops, "LnFoldPlan") and all(l.trainer is None and not l.dora for l in lin) and self.norm1.trainer is None
-                and (arena is None or arena.Rp == 16) and self.attn1.C % LN_FOLD_WIDTH == 0):
+                and arena is not None and arena.Rp == 16 and self.attn1.C % LN_FOLD_WIDTH == 0):      # (the folded kernel variants exist for rank-16 adapter products and for ff.net.0.proj + GEGLU)
             w = lambda n: sd[n + ".weight"].float()
             a1 = self.attn1
             if LN_FOLD & 1:
