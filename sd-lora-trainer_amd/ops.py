@@ -112,7 +112,9 @@ def set_throughput_hint(flag):
     """Several independent jobs are stepped concurrently on this device (train.train_concurrent, bench.py --jobs-per-gpu): every
     GEMM enqueued (i.e. captured) from now on carries sdlt_gemm_params.throughput_hint."""
     global THROUGHPUT_HINT
-    THROUGHPUT_HINT = bool(flag)
+    # Round 4: with the wave-split-K kernel and the folded LayerNorm in the one-job plan the hint LOSES (two SDXL jobs: 72.3 ms per pair of steps with it,
+    # 68.5 without, same session) - concurrent jobs keep the one-job kernel choices unless SDLT_THROUGHPUT_HINT=1 asks for the round-2 rules.
+    THROUGHPUT_HINT = bool(flag) and os.environ.get("SDLT_THROUGHPUT_HINT", "0") == "1"
 
 
 WSK = os.environ.get("SDLT_WSK", "1") != "0"

@@ -928,7 +928,7 @@ def test_gemm_throughput_hint(ops):
     """sdlt_gemm_params.throughput_hint (several jobs share the device): the heuristics pick 256x128 tiles for the >= 320-tile
     classes and the mid-size convs - same results."""
     g = torch.Generator().manual_seed(21)
-    ops.set_throughput_hint(True)
+    ops.THROUGHPUT_HINT = True            # (set_throughput_hint only arms it with SDLT_THROUGHPUT_HINT=1 since round 4: measured slower; the kernels' rule is still checked)
     try:
         for (M, N, K, lora) in [(4096, 1920, 640, False), (4096, 1280, 640, True), (1024, 10240, 1280, False)]:
             X = torch.randn(M, K, generator=g).to(BF)
