@@ -326,13 +326,17 @@ class Linear(_Module):
 
     ln = None
 
-    def fold_ln(self, norm, w32):
+    def fold_ln(self, norm, w32, keep_plain=False):
         """The LayerNorm `norm` in front of this projection runs inside its GEMM from now on (sdlt_gemm_params.ln_c1 / sdlt_wsk_gemm_ln): the forward
         operand becomes W o gamma, the bias c2 = W beta + b; an adapter's LoRA-down rows become A o gamma (refreshed with the shadows).  The
         backward is untouched: it works on W^T / A^T and hands dL/dy to norm.backward as before.  w32: this layer's fp32 weight [N, K] in the
-        row order of self.W."""
+        row order of self.W.  keep_plain: the unfolded operand stays too (forward(..., unfolded=True) on the output of the LayerNorm launch) - for the
+        consumer whose fold only pays when the producer left row partials (ff.net.0.proj, 26 MB per block of 288 GB)."""
         rt = self.rt
         assert self.trainer is None and not self.dora and (self.lora is None or self.arena.Rp == 16)
+        if keep_plain:
+            assert self.lora is None
+            self.W_plain, self.bias_plain = self.W, self.bias
         self.W, self.ln_c1, self.bias = rt.ops.fold_layernorm(w32.to(rt.device), self.bias, norm.gamma, norm.beta, dtype=rt.act)
         if self.lora is not None:
             self.lora["W"] = self.W
@@ -345,7 +349,7 @@ class Linear(_Module):
     def weight_grad(self, dy, xs=None):
         self.trainer.linear(self.went, self.bent, xs if xs is not None else [self._x], dy)
 
-    def forward(self, x, *, residual=None, Ct=None, key="y", out=None, train=True, geglu_out=None, act_out=None, parts_for=None):
+    def forward(self, x, *, residual=None, Ct=None, key="y", out=None, train=True, geglu_out=None, act_out=None, parts_for=None, unfolded=False):
         """parts_for: the (folded) LayerNorm that reads this layer's output next - where the product runs on the wave-split-K kernel it also leaves
         that LayerNorm's row partials (ops.gemm ln_parts_out), so the consumer GEMM has no statistics to compute."""
         M = x.shape[0]
@@ -357,7 +361,10 @@ class Linear(_Module):
             self._x = x if self.ln is None else self.ln.ybuf()     # (folded LayerNorm: the normalised rows are written by its backward)
         if self.trainer is not None:
             self._x = x
-        if self.ln is not None:
+        W, bias = self.W, self.bias
+        if unfolded and self.ln is not None:       # x is the OUTPUT of the LayerNorm launch (fold_ln keep_plain)
+            W, bias = self.W_plain, self.bias_plain
+        elif self.ln is not None:
             ln = (self.ln_c1, self.ln.stats_buf(), self.ln.eps, self.ln_consts if self.lora is not None else None) + (self.ln._parts or (None, 0))
         if self.dora:
             # y = scale * (x W^T + s x A^T B^T) + bias; the residual is added by a second launch because the magnitude gradient
@@ -376,11 +383,11 @@ class Linear(_Module):
                     parts_for._parts = (parts_for.buf("parts", M * P * 2, dtype=F32), P)
                     kw["ln_parts_out"] = parts_for._parts[0]
         if geglu_out is not None:
-            self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, residual=residual, Ct=Ct, geglu_out=geglu_out, **kw)
+            self.rt.ops.gemm(x, W, y, lora=lora, bias=bias, residual=residual, Ct=Ct, geglu_out=geglu_out, **kw)
         elif act_out is not None:
-            self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, residual=residual, Ct=Ct, act_out=act_out, **kw)
+            self.rt.ops.gemm(x, W, y, lora=lora, bias=bias, residual=residual, Ct=Ct, act_out=act_out, **kw)
         else:
-            self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, residual=residual, Ct=Ct, **kw)
+            self.rt.ops.gemm(x, W, y, lora=lora, bias=bias, residual=residual, Ct=Ct, **kw)
         return y
 
     def backward(self, dy, *, dres=None, Ct=None, key="dx", out=None, dact_in=None):
@@ -753,9 +760,9 @@ class LayerNorm(_Module):
     def ybuf(self):
         return self.buf("yln", *self._x.shape)
 
-    def forward(self, x, out=None):
+    def forward(self, x, out=None, unfolded=False):
         self._x = x
-        if self.folded:           # no launch: the consumer reads the raw rows and writes (mean, rstd) into stats_buf()
+        if self.folded and not unfolded:           # no launch: the consumer reads the raw rows and writes (mean, rstd) into stats_buf()
             assert out is None
             return x
         y = out if out is not None else self.buf("y", *x.shape)
@@ -952,7 +959,7 @@ class TransformerBlock(_Module):
                 self.attn2.to_q.fold_ln(self.norm2, w(self.attn2.to_q.name))
             if self.fused_geglu and (LN_FOLD & 4):
                 w3 = w(self.ff1.name).to(rt.device)
-                self.ff1.fold_ln(self.norm3, w3[perm])
+                self.ff1.fold_ln(self.norm3, w3[perm], keep_plain=True)
 
     def forward(self, x, ctx, B, N, next_norm=None):
         """next_norm: the LayerNorm that reads this block's output (the next block's norm1) - see Linear.forward parts_for."""
@@ -960,7 +967,10 @@ class TransformerBlock(_Module):
         x2 = self.attn2.forward(self.norm2.forward(x1), ctx, B, N, residual=x1, parts_for=self.norm3)
         if self.fused_geglu:
             g = self.buf("g", x.shape[0], self.ff2.K)
-            self.ff1.forward(self.norm3.forward(x2), geglu_out=g)
+            # norm3's fold pays only with the producer's row partials (K-walk statistics cost ff.net.0.proj more than the LayerNorm launch: DESIGN 4.12):
+            # without them - other batch sizes / resolutions than 1024 rows, concurrent-job hint - this pass runs the launch and the unfolded operand
+            plain = self.ff1.ln is not None and self.norm3._parts is None
+            self.ff1.forward(self.norm3.forward(x2, unfolded=plain), geglu_out=g, unfolded=plain)
         else:
             f1 = self.ff1.forward(self.norm3.forward(x2))
             g = self.rt.ops.geglu_fwd(f1, self.buf("g", x.shape[0], f1.shape[1] // 2))

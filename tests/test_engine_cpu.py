@@ -37,8 +37,16 @@ def _oracle_step(cfg, sd, lora, rank, latent, noise, t, mask, ctx, add, gamma, l
     return pred.detach(), loss.detach(), {k: (grads[2 * i], grads[2 * i + 1]) for i, k in enumerate(lora)}, grads[-1]
 
 
+@pytest.mark.parametrize("fold", ["default", "fold-with-partials", "fold-k-walk-statistics", "fold-attention-only"])
 @pytest.mark.parametrize("version,B,gamma", [("tiny15", 2, 5.0), ("tinyxl", 1, 0.0)])
-def test_engine_matches_oracle_autograd(version, B, gamma):
+def test_engine_matches_oracle_autograd(version, B, gamma, fold, monkeypatch):
+    # the LayerNorm fold (unet.Linear.fold_ln) is on for 1280-wide blocks by default - never on the toy topologies; the other cases
+    # switch it on at every width so that the host plumbing (folded operands, adapter constants, producer row partials / K-walk statistics /
+    # the per-pass fallback of norm3 to the LayerNorm launch, the normalised rows written by the LayerNorm backward) is checked against autograd too
+    if fold != "default":
+        monkeypatch.setattr(unet_mod, "LN_FOLD_WIDTH", 32)
+        monkeypatch.setattr(unet_mod, "PARTS", fold == "fold-with-partials")
+        monkeypatch.setattr(unet_mod, "LN_FOLD", 3 if fold == "fold-attention-only" else 7)
     torch.manual_seed(0)
     cfg = U.CONFIGS[version]
     rank, h = 4, 16
@@ -61,6 +69,8 @@ def test_engine_matches_oracle_autograd(version, B, gamma):
     rt.keep_daam_maps = True
     unet = unet_mod.UNet(rt, topology.CONFIGS[version], sd, lora_rank=rank)
     unet.arena.load(lora)
+    n_folded = len(unet.arena.ln_items)
+    assert (n_folded == 0) == (fold == "default"), n_folded      # (four adapters per block: q, k, v of attn1 and attn2.to_q)
     ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=gamma, l1_penalty=0.0, weight_decay=0.0)
     ts.set_batch(latent, noise, t, mask, ctx, pooled, tid)
     pred = ts.forward_backward()
