@@ -197,18 +197,35 @@ __global__ void mse_grad_kernel(const float* pred, int64_t ldp, const float* noi
 // L1 penalty main.py:353-356 (grad of l1w * sum|p| / N is l1w*sign(p)/N, folded in here).
 // hyper (device, fp32): [0] lr  [1] beta1  [2] beta2  [3] eps  [4] weight_decay  [5] 1-beta1^t  [6] 1-beta2^t
 //                       [7] l1 coefficient (= l1_penalty * loss_scale / N_total)  [8] grad scale
-__global__ void adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float* l1_partial) {
+__global__ void adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float* l1_partial, int vec) {
   const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2 = hyper[6],
               l1c = hyper[7], gs = hyper[8];
   const float rs2 = rsqrtf(bc2), step = lr / bc1;
   float l1 = 0.f;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float pi = p[i];
+  auto upd = [&](float& pi, const float g_, float& mi, float& vi) {      // torch.optim.AdamW (decoupled decay) + the L1 subgradient of main.py:353-356
     l1 += fabsf(pi);
-    float gi = g[i] * gs + l1c * (pi > 0.f ? 1.f : (pi < 0.f ? -1.f : 0.f));
-    float mi = b1 * m[i] + (1.f - b1) * gi;
-    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float gi = g_ * gs + l1c * (pi > 0.f ? 1.f : (pi < 0.f ? -1.f : 0.f));
+    mi = b1 * mi + (1.f - b1) * gi;
+    vi = b2 * vi + (1.f - b2) * gi * gi;
     pi = pi * (1.f - lr * wd) - step * mi / (sqrtf(vi) * rs2 + eps);
+  };
+  // 16 bytes per lane and stream (seven streams: the kernel is pure HBM traffic); the arenas are 16-byte aligned (checked by the launcher), the
+  // last n % 4 elements go one by one
+  const int64_t n4 = vec ? n >> 2 : 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 pv = ((const f32x4*)p)[i], mv = ((const f32x4*)m)[i], vv = ((const f32x4*)v)[i];
+    const f32x4 gv = ((const f32x4*)g)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float pi = pv[k], mi = mv[k], vi = vv[k];
+      upd(pi, gv[k], mi, vi);
+      pv[k] = pi; mv[k] = mi; vv[k] = vi;
+    }
+    ((f32x4*)p)[i] = pv; ((f32x4*)m)[i] = mv; ((f32x4*)v)[i] = vv;
+  }
+  for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    upd(pi, g[i], mi, vi);
     p[i] = pi; m[i] = mi; v[i] = vi;
   }
   if (l1_partial) {
@@ -417,7 +434,8 @@ extern "C" int sdlt_adamw_fused(float* p, const float* g, float* m, float* v, in
   if (n <= 0) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_adamw_fused: n=%lld", (long long)n);
   hipStream_t s = (hipStream_t)stream;
   if (l1_sum) sdlt_zero_async(l1_sum, sizeof(float), s);
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, g, m, v, n, hyper, l1_sum);
+  const int vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) ? 1 : 0;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(vec ? (n + 3) / 4 : n)), dim3(256), 0, s, p, g, m, v, n, hyper, l1_sum, vec);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }
