@@ -462,8 +462,9 @@ def main():
             vocab = text.encoders[0].V
             tok = [vocab - 3, vocab - 2, vocab - 1]
             lists, ids = [], torch.full((B, 77), 49407 if vocab > 49407 else vocab - 4, dtype=torch.int64)
+            gw = torch.Generator().manual_seed(7000 + seed)      # (host generator, seeded like every other draw: `final_loss` is a function of the code, not of the run)
             for b in range(B):   # "a photo of <s0><s1><s2> ..." style caption: BOS, 8 words, the 3 TI tokens, EOS, padding
-                words = torch.randint(1000 if vocab > 2000 else 10, min(40000, vocab - 10), (8,)).tolist()
+                words = torch.randint(1000 if vocab > 2000 else 10, min(40000, vocab - 10), (8,), generator=gw).tolist()
                 l = [49406 if vocab > 49407 else vocab - 5] + words[:4] + tok + words[4:] + [49407 if vocab > 49407 else vocab - 4]
                 ids[b, :len(l)] = torch.tensor(l)
                 lists.append(l)

@@ -20,7 +20,6 @@ assert TP == CTX_PAD
 TEXT_PAIR = os.environ.get("SDLT_TEXT_PAIR", "1") != "0"
 
 
-TAIL_OVERLAP = os.environ.get("SDLT_TAIL_OVERLAP", "0") != "0"      # measured: 44.15 vs 42.66 ms - the two extra graph launches and the event join cost 1.5 ms, off by default
 
 
 class TextStack:
@@ -618,24 +617,6 @@ class TrainStep:
             return [self.body]
         return [self._phase_text_fwd, self._phase_unet, lambda: (self._phase_text_bwd(), self.optimizer_step())]
 
-    # Tail overlap (SDLT_TAIL_OVERLAP=1; built, measured in round 4 and left OFF - see the constant): for LoRA + TI jobs on one GPU, once the UNet backward has produced dL/d(conditioning), the
-    # text-encoder backward (2.2 ms of 77-row launches that fill a third of the chip) and the UNet's own tail - the grouped adapter-gradient
-    # launch, AdamW on the adapter arena, the operand refresh (1.0 ms, HBM-bound) - are independent.  Forked branches inside ONE hipGraph are
-    # replayed one after the other by this runtime (see above), but two graphs launched on two streams do overlap (that is how two jobs
-    # share a GPU): the step is replayed as graph A (text forward, UNet forward + backward) on the step's stream, then graph B
-    # (the UNet tail) on a side stream beside graph C (text backward, token-row optimizer) on the step's stream, joined by events.
-    def _phase_unet_tail(self):
-        self.unet.lora_grads()
-        self._unet_optimizer()
-
-    def _phase_text_tail(self):
-        self._phase_text_bwd()
-        self._other_optimizers()
-
-    def _overlap_ok(self):
-        return (TAIL_OVERLAP and self.world == 1 and self._acc is None and self.text is not None and not self.text.concurrent and not self.full_ft
-                and self.rt.device.type == "cuda" and not getattr(self, "zero1", False))
-
     def _phase_unet_cached(self):
         """UNet phase on a conditioning the caller placed in self.ctx / self.pooled (frozen token rows: no text-encoder forward)."""
         self._pooled_live = self.pooled
@@ -701,14 +682,34 @@ class TrainStep:
 
     def grad_norm(self):
         """Global L2 norm of the LoRA gradients, the reference's debug read-out (loss.py:108-125, main.py:373-379)."""
-        return float(self.group.grads.norm())
+        return self._unet_grad_norm()
+
+    def _unet_grad_norm(self):
+        """L2 norm of the UNet gradient the optimizer consumes.  Data parallel: the gradient of the global batch is the rank sum / world.  After
+        the all-reduce every rank holds the sum; after ZeRO-1's in-place reduce-scatter only this rank's slice of each bucket does (the rest of
+        the bucket is scratch), so the squared norm is taken over the owned slices + the replicated vector region once (rank 0) and the
+        scalar is summed over the ranks."""
+        a = self.group
+        if self.world == 1:
+            return float(a.grads.norm())
+        if getattr(self, "zero1", False):
+            import torch.distributed as dist
+            sq = torch.zeros(1, dtype=torch.float64, device=a.grads.device)
+            for b in range(len(a.buckets)):
+                s0, s1 = a.shard_range(b)
+                sq += a.grads[s0:s1].double().pow(2).sum()
+            if a.n > a.n_mat and a.z_rank == 0:
+                sq += a.grads[a.n_mat:].double().pow(2).sum()
+            dist.all_reduce(sq, group=self.pg)
+            return math.sqrt(float(sq)) / self.world
+        return float(a.grads.norm()) / self.world
 
     def grad_norms(self):
         """The whole debug read-out of main.py:373-379: {'unet': ..., 'text_encoder_0': ..., 'text_encoder_1': ...} - `compute_grad_norm` over
         every parameter that has a gradient.  For a text encoder that is its token table AFTER the rows of the frozen vocabulary were zeroed
         (main.py:368-371: only the trained rows count - this engine never forms the other rows' gradients) plus, with
         text_encoder_lora_optimizer, that encoder's adapters.  One device sync per entry; not part of the step's graph."""
-        out = {"unet": float(self.group.grads.norm())}
+        out = {"unet": self._unet_grad_norm()}
         if self.ti is not None:
             sq = [float(r.float().pow(2).sum()) for r in self.ti.grad_rows]
             if self.te_arena is not None:
@@ -765,7 +766,9 @@ class TrainStep:
                 graphs.append(cap(fns, pool))
                 pool = graphs[-1].pool()
             frozen = None
-            if self.text is not None and self.te_arena is None:     # variant for ti lr == 0: same first phases, LoRA-only last phase
+            # variant for ti lr == 0: same first phases, LoRA-only last phase.  Not under data parallelism: _run never takes the frozen branch there
+            # (the exchange step lives in the per-bucket graphs), and with ZeRO-1 the full-arena AdamW those graphs would record has no moments
+            if self.text is not None and self.te_arena is None and self.world == 1:
                 if split:
                     frozen = graphs[:2] + [cap([self._phase_opt_frozen_ti], pool)]
                 else:
@@ -776,25 +779,6 @@ class TrainStep:
 
         self.graphs, self.graphs_frozen, pool = cap_set(None)
         self.graph = self.graphs[0]
-        self.graphs_overlap = None
-        if self._overlap_ok():
-            # graph A / C on this capture's stream and pool; graph B on the side stream with a pool of its own (it runs beside C)
-            self.unet.defer_lora_grads = True
-            try:
-                gA = cap([self._phase_text_fwd, self._phase_unet], pool)
-                pool = gA.pool()
-                self._side = torch.cuda.Stream()
-                self._side.wait_stream(torch.cuda.current_stream())
-                gB = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gB, stream=self._side):
-                    self._phase_unet_tail()
-                torch.cuda.current_stream().wait_stream(self._side)
-                gC = cap([self._phase_text_tail], pool)
-                pool = gC.pool()
-                self.graphs_overlap = (gA, gB, gC)
-                self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
-            finally:
-                self.unet.defer_lora_grads = False
         if self._acc is not None:
             self.graphs_frozen = None
             self.graphs_micro = [cap([self.body_micro], pool)]
@@ -846,17 +830,6 @@ class TrainStep:
             self.graphs[0].replay()
             self.sync_gradients()
             self.graphs[1].replay()
-        elif self.graph is not None and not frozen and getattr(self, "graphs_overlap", None) is not None:
-            gA, gB, gC = self.graphs_overlap
-            cur = torch.cuda.current_stream()
-            gA.replay()
-            self._ev_fork.record(cur)
-            self._side.wait_event(self._ev_fork)
-            with torch.cuda.stream(self._side):
-                gB.replay()
-                self._ev_join.record(self._side)
-            gC.replay()
-            cur.wait_event(self._ev_join)
         elif self.graph is not None:
             cached = frozen and self._cond_cached and self.graphs_frozen_cached is not None
             assert not self._cond_cached or frozen, "a cached conditioning is only valid while the token rows are frozen (ti lr == 0, no text-encoder LoRA)"

@@ -1340,10 +1340,7 @@ class UNet(_Module):
         if tr is not None and not tr.defer_flush:
             tr.flush()             # every weight gradient of this pass, batched by layer shape (data parallel: the step flushes bucket by bucket)
         self._cross_kv_backward(dctx)
-        if not self.defer_lora_grads:
-            self.lora_grads()
-
-    defer_lora_grads = False     # the step runs lora_grads() itself (TrainStep: beside the text-encoder backward, on a second stream)
+        self.lora_grads()
 
     def lora_grads(self):
         """The grouped adapter-gradient launch of this pass (+ DoRA's magnitude gradients): every dY / T / U / input buffer is complete once the

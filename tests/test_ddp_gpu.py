@@ -75,3 +75,77 @@ def test_bucketed_ddp_two_ranks_on_one_gpu(zero1):
         assert all(x == x for x in losses)
     mean = [0.5 * (a + b) for a, b in zip(res[0][2], res[1][2])]
     assert mean[-1] < mean[0], mean
+
+
+def _worker_ti(rank, world, port, out, zero1=True):
+    """Full fine-tune + textual inversion under data parallelism, CAPTURED (the default workload of full_finetuning_example.json: ti_lr > 0).
+    Round 4 crashed here inside torch.cuda.graph: the frozen-TI graph variants were captured also for world > 1 and recorded the full-arena
+    AdamW, whose moments ZeRO-1 has released."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import sd_lora_trainer_amd.clip as clip_mod
+    from oracle import unet_ref as U
+    from sd_lora_trainer_amd import fullft, topology
+    from sd_lora_trainer_amd import step as step_mod
+    from sd_lora_trainer_amd import unet as unet_mod
+    from tests.test_ti_step_cpu import EOS, NTOK, _captions, _hf
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    cfg, h = U.CONFIGS["tinyxl"], 32
+    sd = U.init_unet_state(cfg, seed=0)
+    hf = [_hf("quick_gelu", False, 64, 1, 11), _hf("gelu", True, 64, 1, 12, proj=cfg["proj_class_in"] - 6 * cfg["addition_time_embed_dim"])]
+    g = torch.Generator().manual_seed(3)
+    latent = torch.randn(2, 4, h, h, generator=g) * cfg["scaling_factor"]
+    noise = torch.randn(2, 4, h, h, generator=g)
+    mask = torch.ones(2, 4, h, h)
+    t = torch.tensor([10, 900])
+    tid = torch.tensor([[1024., 1024, 0, 0, 8. * h, 8. * h]] * 2)
+    lists, ids = _captions(2)
+    rt = unet_mod.Runtime("cuda:0", 1)
+    tr = fullft.WeightTrainer(rt)
+    tr.bucket_floats = 150_000
+    unet = unet_mod.UNet(rt, topology.CONFIGS["tinyxl"], sd, trainer=tr)
+    sds = [{k: v.detach() for k, v in m.state_dict().items()} for m in hf]
+    encs = [clip_mod.ClipTextEncoder(rt, "te1", sds[0], heads=1, act="quick_gelu", mode="penultimate", with_projection=False, n_train=NTOK),
+            clip_mod.ClipTextEncoder(rt, "te2", sds[1], heads=1, act="gelu", mode="penultimate", with_projection=True, n_train=NTOK)]
+    text = step_mod.TextStack(rt, encs, pool_mode="first_eos", eos_token_id=EOS)
+    ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, text=text, n_tokens=NTOK, token_attention_loss_w=2e-2, ti_std_loss_w=0.01,
+                            process_group=True, ddp_zero1=zero1)
+    assert ts.zero1 == zero1 and ts.bucketed
+    s = slice(rank, rank + 1)
+    ts.set_batch(latent[s].cuda(), noise[s].cuda(), t[s].cuda(), mask[s].cuda(), time_ids=tid[s].cuda(), ids=[ids[s]] * 2, caption_token_lists=lists[rank:rank + 1])
+    ts.capture(warmup=1)
+    assert ts.graphs_frozen is None          # no frozen-TI variants under data parallelism (_run never takes them there)
+    rows0 = ts.ti.params.clone()
+    losses = []
+    for i in range(4):
+        ts.run(2e-4, lr_ti=1e-3)
+        losses.append(float(ts.loss))
+    ts.run(2e-4, lr_ti=0.0)                  # frozen token rows under DDP: the full graphs with lr 0 (no fast path), the exchange still runs
+    gn = ts.grad_norms()
+    torch.cuda.synchronize()
+    out.put((rank, tr.params.cpu().numpy().copy(), losses, ts.ti.params.cpu().numpy().copy(), bool((ts.ti.params != rows0).any()), gn))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("zero1", [True, False])
+def test_ddp_full_finetune_with_textual_inversion_captured(zero1):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    ctx_mp = mp.get_context("spawn")
+    q = ctx_mp.Queue()
+    port = _free_port()
+    procs = [ctx_mp.Process(target=_worker_ti, args=(r, 2, port, q, zero1)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert torch.equal(torch.from_numpy(res[0][1]), torch.from_numpy(res[1][1])), "UNet replicas diverged"
+    assert torch.equal(torch.from_numpy(res[0][3]), torch.from_numpy(res[1][3])), "token rows diverged"
+    assert res[0][4] and res[1][4], "token rows did not train"
+    for _, _, losses, _, _, gn in res:
+        assert all(x == x for x in losses) and gn["unet"] > 0 and gn["unet"] == gn["unet"]
+    assert abs(res[0][5]["unet"] - res[1][5]["unet"]) <= 1e-5 * res[0][5]["unet"]        # the read-out is rank-independent

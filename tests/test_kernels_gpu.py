@@ -566,6 +566,7 @@ ATTN_CASES = [
     dict(B=1, H=2, Nq=192, Nk=64, Nkp=64, d=64, causal=False, qsplit=1),
     dict(B=2, H=1, Nq=576, Nk=576, Nkp=576, d=64, causal=False, qsplit=1),
     dict(B=1, H=20, Nq=1024, Nk=1024, Nkp=1024, d=64, causal=False, qsplit=1),
+    dict(B=1, H=10, Nq=4096, Nk=4096, Nkp=4096, d=64, causal=False, qsplit=1),      # the 64 x 64 level of SDXL at 1024 px (attn32: 4096 tokens x 10 heads)
 ]
 
 
@@ -1398,14 +1399,13 @@ def _count_paired(ops, gens, prefer):
                                         (dict(SDLT_ATTN32_KS_FWD="1", SDLT_ATTN32_KS_BWD="1"), "test_attention_fwd_bwd"),
                                         (dict(SDLT_WSK_STAGGER="0", SDLT_STRIP_WIDE_MIN="4096"), "test_wsk or test_strip"),
                                         (dict(SDLT_LN_FOLD="7", SDLT_LN_FOLD_WIDTH="64", SDLT_LN_PARTS="0"), "file:test_ti_step_gpu.py:trajectory or step"),
-                                        (dict(SDLT_LN_FOLD="0"), "file:test_ti_step_gpu.py:trajectory or step"),
-                                        (dict(SDLT_TAIL_OVERLAP="1"), "file:test_ti_step_gpu.py:trajectory or step")],
+                                        (dict(SDLT_LN_FOLD="0"), "file:test_ti_step_gpu.py:trajectory or step")],
                          ids=["single-role", "single-role-128-keys", "plain-order-unsplit-16-rows", "attn32-four-groups", "attn32-one-group", "unstaggered-narrow-strips",
-                              "layernorm-fold-every-width-k-walk-statistics", "layernorm-launches", "tail-overlap-two-streams"])
+                              "layernorm-fold-every-width-k-walk-statistics", "layernorm-launches"])
 def test_fallback_kernel_paths_in_a_subprocess(env, select):
     """The A/B switches are read once per process, so the non-default kernels behind them (single-role / 128-key cross-attention backward,
     plain workgroup order, unsplit attention forward, unstaggered wave-split-K refills, 16-column strips; step level: the LayerNorm fold at every
-    width with K-walk statistics / the LayerNorm launches / the two-stream tail) run in a child pytest: the same checks must pass on them too."""
+    width with K-walk statistics / the LayerNorm launches) run in a child pytest: the same checks must pass on them too."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import subprocess

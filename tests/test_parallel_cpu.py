@@ -97,8 +97,9 @@ def _ddp_worker(rank, world, port, out, wire="fp32", zero1=True, optimizer="adam
         ts.set_batch(latent[s], noise[s], t[s], mask[s], ctx[s])
         ts.run(1e-3)
     own = [tr.shard_range(b) for b in range(len(tr.buckets))] if zero1 else None
+    gn = ts.grad_norm()                 # (a collective under ZeRO-1: every rank calls it)
     extra = dict(state=ts.prodigy.state.numpy().copy(), s=ts.prodigy.s.numpy().copy()) if ts.prodigy is not None else None
-    out.put((rank, tr.params.numpy().copy(), float(ts.loss), tr.grads.numpy().copy(), own, tr.n_mat, extra))      # numpy: pickled through the pipe (a shared-memory tensor dies with the worker)
+    out.put((rank, tr.params.numpy().copy(), float(ts.loss), tr.grads.numpy().copy(), own, tr.n_mat, extra, gn))      # numpy: pickled through the pipe (a shared-memory tensor dies with the worker)
     torch.distributed.destroy_process_group()
 
 
@@ -199,6 +200,12 @@ def test_fullft_data_parallel_two_ranks_gloo(wire, zero1):
                 g_ddp[s0:s1] = torch.from_numpy(res[r][3])[s0:s1]
         assert sum(s1 - s0 for r in range(2) for s0, s1 in res[r][4]) == res[0][5]          # the slices of the two ranks tile the matrix region
     g_ddp = g_ddp / 2
+    # the debug read-out (main.py:373-379) is the norm of the global batch's gradient on every rank, sharded exchange or not
+    assert res[0][7] == res[1][7] or not zero1
+    for r in range(2):
+        ref_norm = float(g_ddp.double().norm())
+        # all-reduce path: torch's fp32 norm of the whole arena (its own summation order); sharded path: fp64 partial sums
+        assert abs(res[r][7] - ref_norm) <= (1e-6 if zero1 else 2e-3) * ref_norm, (res[r][7], ref_norm)
     if wire == "bf16":      # two bf16 roundings (the pack, the sum over the ranks) of each rank's share: 2^-8 of the addends
         assert float((g_ddp - g_one).norm() / g_one.norm()) <= 6e-3
         assert float((g_ddp - g_one).abs().max()) <= 1e-2 * float(g_one.abs().max())
