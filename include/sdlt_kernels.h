@@ -519,6 +519,14 @@ int sdlt_wsk_gemm(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_
                   const void* R, int64_t ldr, void* Y, int64_t ldy, const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup,
                   float lora_scale, void* T_out, int64_t ld_t, int32_t lora_group_k, void* stream);
 
+/* FROZEN weights (the UNet under LoRA / textual inversion, main.py:329-336 with trainer/optimizer.py:84-95: only adapters train) can be handed to the three
+ * sdlt_wsk_gemm* entry points in fragment-major order: Wp = [N / 80][K / 64][2][5][64 lanes][8 bf16], lane (r = lane % 16, g = lane / 16) of fragment
+ * (kk, j) of block (tn, ks) holding W[80 tn + 16 j + r][64 ks + 32 kk + 8 g .. + 7] - the MFMA operand as it sits in registers.  Pass the packed
+ * copy as W with ldw = 0: a wave's K step is then ten contiguous 1 KB loads straight into a register ring, the LDS rings carry the activation (and
+ * LoRA-down) rows only, and the K walk no longer runs at the rate four waves can issue LDS-DMA pieces at.  Same arithmetic, same
+ * summation order: results are bit-identical to the row-major call.  sdlt_wsk_pack_weight writes the copy (N % 80 == 0, K % 64 == 0, N K bf16). */
+int sdlt_wsk_pack_weight(const void* W, int64_t ldw, int32_t N, int32_t K, void* Wp, void* stream);
+
 /* sdlt_wsk_gemm with the LayerNorm in front of the projection folded in (sdlt_gemm_params.ln_c1's contract; attn2.to_q of the 1280-wide blocks):
  * X raw rows, W = W o gamma, c2 = W beta + bias, Y = rstd (X W^T - mean c1) + c2 (+ adapter with Adown = A o gamma, ln_adapter = cA | abeta, + R);
  * ln_stats [M, 2] (or NULL) receives (mean, rstd). */

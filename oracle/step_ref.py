@@ -137,3 +137,8 @@ class RefTrainer:
 
     def lora_flat(self):
         return torch.cat([p.detach().reshape(-1) for p in self.lora_params])
+
+    def adam_moments(self):
+        """(exp_avg, exp_avg_sq, step count) of the adapter optimizer (torch.optim.AdamW's state, optimizer.py:17-18), flat in lora_flat()'s order."""
+        st = [self.opt_unet.state[p] for p in self.lora_params]
+        return (torch.cat([s_["exp_avg"].reshape(-1) for s_ in st]), torch.cat([s_["exp_avg_sq"].reshape(-1) for s_ in st]), int(st[0]["step"]))

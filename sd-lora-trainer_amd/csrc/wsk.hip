@@ -49,6 +49,10 @@ struct wsk_params {
   // row partials for the NEXT LayerNorm (any kernel): ln_parts [M, N / 80] float2 = (sum y, sum (y - tile mean)^2) of the ROUNDED output row over this tile's 80
   // columns - the consumer GEMM of a folded LayerNorm (sdlt_gemm_params.ln_parts) adds the N / 80 partials of a row instead of walking it
   float2* ln_parts;
+  // W in fragment-major order (kernels with WP; sdlt_wsk_pack_weight's output, frozen weights only): [N / 80][K / 64][2][5][64 lanes][8 bf16] - lane (r, g)
+  // of fragment (kk, j) holds W[n0 + 16 j + r][k0 + 32 kk + 8 g .. + 7], i.e. the MFMA A operand as it sits in registers.  A wave's K step is
+  // ten contiguous 1 KB wave loads (16 B per lane, whole 128-byte lines) that never touch LDS.
+  const bf16_t* Wp;
 };
 
 // -DSDLT_WSK_TRACE (tools/wsk_trace.py): thread 0 of workgroup 0 stamps clock64() at the phase boundaries; sdlt_wsk_trace_read copies them out
@@ -61,17 +65,22 @@ __device__ long long g_wsk_tr[16];
 
 // MBK x 16 rows, JN x 16 columns per workgroup; R ring slots per wave
 // KG: 0 no adapter, 1 one rank-16 adapter, 2..3 that many K groups with an adapter each
-template <int MBK, int JN, int R, int KG = 0, bool LN = false>
+// WP: the weight operand comes from the fragment-major copy straight into a register ring of R stages (wsk_params::Wp); the LDS rings hold the
+//     activation (and LoRA-down) rows only.  In wsk_kernel no wave shares an operand with another wave, so LDS is only a layout converter for W -
+//     and the K walk is bound by the rate four waves can issue LDS-DMA pieces at: taking the frozen operand's 56 % of the bytes out of
+//     that path, and its layout conversion to pack time, is what this variant is for.
+template <int MBK, int JN, int R, int KG = 0, bool LN = false, bool WP = false>
 __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   constexpr bool LORA = KG > 0;
   static_assert(!LN || KG <= 1, "the folded LayerNorm belongs to forward products (no K-grouped adapters)");
-  constexpr int XR = 16 * MBK, WR = 16 * JN, SROWS = XR + WR + (LORA ? 16 : 0), SLOT = SROWS * ROWB, PIECES = SROWS / 8;
+  constexpr int XR = 16 * MBK, WR = 16 * JN, AOFF = XR + (WP ? 0 : WR), SROWS = AOFF + (LORA ? 16 : 0), SLOT = SROWS * ROWB,
+                PIECES = SROWS / 8 + (WP ? 2 * JN : 0);      // vector-memory operations of one K step of one wave (what the counted waits count)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   WTR(0);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int ntn = p.N / WR, ntm = p.M / XR;
-  int tm, tn;
+  int tm, tn, phase, nphase;     // phase / nphase: this workgroup's place among the workgroups of its XCD (row-major over the XCD's block of tiles)
   {
     // XCD-aware: the workgroups of one XCD (blockIdx % 8) take neighbouring column tiles over all row tiles, so every weight panel is
     // fetched into one L2 only and the activation rows are what the L2s share
@@ -83,10 +92,14 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
       const int dq = div_small_u(idx, pc);
       tm = (xcd >> 2) * pr + dq;
       tn = (xcd & 3) * pc + idx - dq * pc;
+      phase = 2 * idx + (xcd >> 2);                      // (the two XCDs that read the same weight panels are half a place apart)
+      nphase = 2 * pr * pc;
     } else {
       const int per = ntn >> 3;                          // column tiles per XCD (ntn % 8 == 0)
       tm = div_small_u(idx, per);
       tn = xcd * per + idx - tm * per;
+      phase = idx;
+      nphase = ntm * per;
     }
   }
   if (tm >= ntm || tn >= ntn) return;
@@ -94,17 +107,27 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   const int nsteps = p.K >> 8;
 
   const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
-  const bf16_t* xsrc = p.X + (int64_t)(m0 + srow) * p.ldx + schunk * 8;
-  const bf16_t* wsrc = p.W + (int64_t)(n0 + srow) * p.ldw + schunk * 8;
+#ifdef SDLT_WSK_LAB      // bound experiments (tools/wsk_lab.sh; results are garbage): bit 1 of `stagger` = every workgroup reads row tile 0 of X, bit 2 = column tile 0 of W
+  const int m0x = (p.stagger & 2) ? 0 : m0, tnw = (p.stagger & 4) ? 0 : tn;     // (operands then stay L2-resident: no fabric traffic for them), bit 3 = no MFMAs
+#else
+  const int m0x = m0, tnw = tn;
+#endif
+  const bf16_t* xsrc = p.X + (int64_t)(m0x + srow) * p.ldx + schunk * 8;
+  const bf16_t* wsrc = p.W + (int64_t)(tnw * WR + srow) * p.ldw + schunk * 8;
   const bf16_t* asrc = LORA ? p.Adown + (int64_t)srow * p.ld_adown + schunk * 8 : nullptr;
   const int64_t x8 = 8 * p.ldx, w8 = 8 * p.ldw, a8 = 8 * p.ld_adown;
   char* ring = smem + wave * (R * SLOT);
   // column tile tn starts its K walk `rot` steps in (the 16 tiles of a row block do not ask the L2 for the same X lines at the same time).  The
   // fp32 K sums are therefore ordered per tile: Y is a fixed function of the operands per tile (bitwise reproducible), but the adapter's
   // T = s X Adown^T, which every tile recomputes for itself, can differ between tiles in the last bit of its fp32 sum, i.e. rarely by one bf16 ulp
-  // after rounding; T_out (the copy the adapter-gradient launch reads) is tile 0's (rot = 0, the plain K order).  That is inside the
+  // after rounding; T_out (the copy the adapter-gradient launch reads) is column tile 0's.  That is inside the
   // rounding of T itself (2^-9 relative) - the parity tests compare Y and the adapter gradients with that tolerance.
-  const int rot = tn - div_small_u(tn, nsteps) * nsteps;
+  // Round 5: the rotation follows the workgroup's place in its XCD instead of tn alone.  With rot = tn % nsteps the 8 workgroups of an XCD that walk the SAME
+  // weight panel (same tn, different tm) were in lockstep: every K step of theirs was a first touch - an HBM / fabric round trip the 2-step prefetch cannot
+  // cover (lab build with the weight panel L2-resident: K = 10240 42.7 -> 36.3 us, tools/wsk_lab.sh).  Spread over the walk, a workgroup is the first to
+  // touch only its own 1 / 8 of the panel and finds the rest in L2, fetched by the neighbour that is ahead of it; same for the 4 that share an X panel.
+  const int rot2 = div_small_u(phase * nsteps, nphase);
+  const int rot = (p.stagger & 16) ? (rot2 >= nsteps ? nsteps - 1 : rot2) : tn - div_small_u(tn, nsteps) * nsteps;
   auto issue = [&](int i, int slot) -> int {
     int ii = i + rot;
     ii = ii >= nsteps ? ii - nsteps : ii;
@@ -112,13 +135,44 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
     char* dst = ring + slot * SLOT;
 #pragma unroll
     for (int q = 0; q < XR / 8; ++q) glds16(xsrc + q * x8 + k0, dst + q * 1024);
+    if constexpr (!WP) {
 #pragma unroll
-    for (int q = 0; q < WR / 8; ++q) glds16(wsrc + q * w8 + k0, dst + XR * ROWB + q * 1024);
+      for (int q = 0; q < WR / 8; ++q) glds16(wsrc + q * w8 + k0, dst + XR * ROWB + q * 1024);
+    }
     if constexpr (LORA) {
 #pragma unroll
-      for (int q = 0; q < 2; ++q) glds16(asrc + q * a8 + k0, dst + (XR + WR) * ROWB + q * 1024);
+      for (int q = 0; q < 2; ++q) glds16(asrc + q * a8 + k0, dst + AOFF * ROWB + q * 1024);
     }
     return k0;
+  };
+  // WP: the 2 x JN weight fragments of K step i of this wave -> registers.  Hand-issued loads (saddr form: wave-uniform base, 32-bit lane offset): the
+  // compiler's own wait-count pass cannot see that a refill and the step that consumes it are R steps apart (it merges the paths with and without a
+  // refill and falls back to vmcnt(0) in front of the MFMAs - seen in the ISA), so these loads are invisible to it and the counted waits of the K walk
+  // below cover them: queue order per step = activation pieces, then the weight loads, so "step i's weight loads have landed" implies its pieces have.
+  // (The fragments are only read by the MFMAs behind that step's wait; nothing else may touch wr[][][] in between - checked in the ISA: no copies.)
+  const uint32_t wvo = (uint32_t)lane * 16u;
+  const char* wpbase = WP ? (const char*)p.Wp + ((int64_t)tnw * (p.K >> 6)) * (2 * JN * 1024) : nullptr;
+  auto issue_w = [&](int i, bf16x8 (&dst)[2][JN]) {
+    int ii = i + rot;
+    ii = ii >= nsteps ? ii - nsteps : ii;
+    const char* src = wpbase + (int64_t)(wave + NW * ii) * (2 * JN * 1024);
+    const uint64_t sb = (uint64_t)src;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sb), hi = __builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32));
+    const uint64_t sbase = ((uint64_t)hi << 32) | lo;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < JN; ++j) {
+        constexpr int dummy = 0; (void)dummy;
+        const int f = kk * JN + j;              // fragment f at byte f * 1024: immediate offsets reach 4095, so every fourth fragment moves the base
+        const uint64_t b4 = sbase + (uint64_t)(f >> 2) * 4096u;
+        switch (f & 3) {
+          case 0: asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst[kk][j]) : "v"(wvo), "s"(b4) : "memory"); break;
+          case 1: asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=&v"(dst[kk][j]) : "v"(wvo), "s"(b4) : "memory"); break;
+          case 2: asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=&v"(dst[kk][j]) : "v"(wvo), "s"(b4) : "memory"); break;
+          default: asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=&v"(dst[kk][j]) : "v"(wvo), "s"(b4) : "memory"); break;
+        }
+      }
   };
   const int foff0 = r * ROWB + (((0 * 4 + g) ^ (r & 7)) << 4), foff1 = r * ROWB + (((1 * 4 + g) ^ (r & 7)) << 4);
 
@@ -137,25 +191,133 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   constexpr int UNITS_ = MBK * JN, UPW_ = (UNITS_ + NW - 1) / NW;
   // residual and bias of the units this wave finishes, requested before anything else (loads at their point of use sit exposed behind the
   // last barrier: +1.1 us per launch; being the OLDEST loads in flight they only make the counted waits below wait for them too)
+  // (unconditional loads through selected pointers: with `if (p.R)` / `if (p.bias)` around them hipcc merged each loaded vector with its zero default
+  // through register copies and put an s_waitcnt vmcnt(0) behind EVERY unit's pair - five serial global round trips, ~2 us, in front of the ring
+  // prefill of every launch (found in the ISA in round 5; the clock stamps of DESIGN 4.7 showed them as "prefill issued 2.7 us after the start").  A
+  // missing residual / bias reads in-bounds rows of Y / X instead and the epilogue skips the addition.)
+  static_assert(UNITS_ % NW == 0, "every wave finishes the same number of units");
+  const bf16_t* rsrc = p.R ? p.R : p.Y;
+  const int64_t rld = p.R ? p.ldr : p.ldy;
+  const float* bsrc = p.bias ? p.bias : (const float*)p.X;       // (N floats <= 64 rows of X: K >= 1024 columns)
   uint2 rpre[UPW_];
   f32x4 bpre[UPW_], c1pre[LN ? UPW_ : 1];
 #pragma unroll
   for (int q = 0; q < UPW_; ++q) {
     const int u = wave + q * NW;
-    rpre[q] = make_uint2(0u, 0u);
-    bpre[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if constexpr (LN) c1pre[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (u < UNITS_) {
-      const int mb = u / JN, j = u - mb * JN, n = n0 + 16 * j + 4 * g, m = m0 + mb * 16 + r;
-      if (p.R) rpre[q] = *(const uint2*)(p.R + (int64_t)m * p.ldr + n);
-      if (p.bias) bpre[q] = *(const f32x4*)(p.bias + n);
-      if constexpr (LN) c1pre[q] = *(const f32x4*)(p.ln_c1 + n);
-    }
+    const int mb = u / JN, j = u - mb * JN, n = n0 + 16 * j + 4 * g, m = m0 + mb * 16 + r;
+    rpre[q] = *(const uint2*)(rsrc + (int64_t)m * rld + n);
+    bpre[q] = *(const f32x4*)(bsrc + n);
+    if constexpr (LN) c1pre[q] = *(const f32x4*)(p.ln_c1 + n);
   }
   f32x4 lnca = (f32x4){0.f, 0.f, 0.f, 0.f}, lnab = lnca;      // adapter constants of this lane's four rank rows 4g .. 4g+3
   if constexpr (LN && LORA) { lnca = *(const f32x4*)(p.ln_adapter + 4 * g); lnab = *(const f32x4*)(p.ln_adapter + 16 + 4 * g); }
-  static_assert(R == 2 || KG <= 1, "the K-grouped bookkeeping below tracks a 2-slot ring");
+  static_assert(WP || R == 2 || KG <= 1, "the K-grouped bookkeeping below tracks a 2-slot ring");
 
+  if constexpr (WP) {
+    // ---- K walk, weight fragments in registers: R stages in flight per wave; queue order per step: X (+ LoRA-down) pieces, then the weight loads
+    bf16x8 wr[R][2][JN];
+    int kq[R];
+#pragma unroll
+    for (int s = 0; s < R; ++s) kq[s] = 0;
+    // The steps BEHIND the ring's reach (R .. R + TOUCH - 1) are touched now, one lane per 128-byte line: their HBM / fabric round trips start with the
+    // launch instead of one ring turn at a time (a K = 1280 product is 5 steps per wave: all of its operands are on their way at t = 0).  Issued before
+    // the prefill, so they are the OLDEST loads in flight and every counted wait below already covers them (the prefill's own first-touch latency is the
+    // same, so nothing waits longer for them); the dummy registers stay reserved until behind the K walk.
+    constexpr int TOUCH = 4;
+    uint32_t tdum[TOUCH][3];
+#pragma unroll
+    for (int t = 0; t < TOUCH; ++t) tdum[t][0] = tdum[t][1] = tdum[t][2] = 0u;
+    if (p.stagger & 32) {
+#pragma unroll
+      for (int t = 0; t < TOUCH; ++t) {
+        const int i = R + t;
+        if (i < nsteps) {
+          int ii = i + rot;
+          ii = ii >= nsteps ? ii - nsteps : ii;
+          const int ks = wave + NW * ii;
+          const char* wl = wpbase + (int64_t)ks * (2 * JN * 1024);
+          const char* w0 = wl + lane * 128, *w1 = wl + (64 + (lane & 15)) * 128;
+          const char* x0 = (const char*)(p.X + (int64_t)(m0x + lane) * p.ldx + ks * 64);
+          asm volatile("global_load_dword %0, %1, off" : "=&v"(tdum[t][0]) : "v"(w0) : "memory");
+          asm volatile("global_load_dword %0, %1, off" : "=&v"(tdum[t][1]) : "v"(w1) : "memory");
+          asm volatile("global_load_dword %0, %1, off" : "=&v"(tdum[t][2]) : "v"(x0) : "memory");
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < R; ++s)
+      if (s < nsteps) { kq[s] = issue(s, s); issue_w(s, wr[s]); }
+    WTR(1);
+    const bool refill_first = !(p.stagger & 1) || (wave & 1) == 0;
+    for (int i0 = 0; i0 < nsteps; i0 += R) {
+#pragma unroll
+      for (int s = 0; s < R; ++s) {
+        const int i = i0 + s;
+        if (i < nsteps) {            // (wave-uniform)
+          const int kcur = kq[s];
+          const int after = nsteps - 1 - i;
+          if (after >= R - 1) wait_vmcnt<PIECES * (R - 1)>();
+          else if (R > 2 && after == R - 2) wait_vmcnt<PIECES * (R > 2 ? R - 2 : 0)>();
+          else if (R > 3 && after == R - 3) wait_vmcnt<PIECES * (R > 3 ? R - 3 : 0)>();
+          else wait_vmcnt<0>();
+          if (i < 6) WTR(2 + i);
+          const char* base = ring + s * SLOT;
+          bf16x8 xf[2][MBK], af[2];
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const int fo = kk ? foff1 : foff0;
+#pragma unroll
+            for (int mb = 0; mb < MBK; ++mb) xf[kk][mb] = *(const bf16x8*)(base + mb * 16 * ROWB + fo);
+            if constexpr (LORA) af[kk] = *(const bf16x8*)(base + AOFF * ROWB + fo);
+          }
+          if (refill_first && i + R < nsteps) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            kq[s] = issue(i + R, s);
+          }
+#ifdef SDLT_WSK_LAB
+          if (p.stagger & 8) {       // no MFMAs: the fragments are still consumed (one VALU op each)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+              for (int j = 0; j < JN; ++j) acc[j][0][0] += (float)wr[s][kk][j][0];
+#pragma unroll
+              for (int mb = 0; mb < MBK; ++mb) acc[0][mb][1] += (float)xf[kk][mb][0];
+            }
+          } else
+#endif
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < JN; ++j)
+#pragma unroll
+              for (int mb = 0; mb < MBK; ++mb) acc[j][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[s][kk][j], xf[kk][mb], acc[j][mb], 0, 0, 0);
+          if constexpr (LORA) {
+            const int tgrp = KG > 1 ? kcur / p.group_k : 0;
+#pragma unroll
+            for (int tg = 0; tg < TG; ++tg)
+              if (tg == tgrp) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                  for (int mb = 0; mb < MBK; ++mb) tacc[tg][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk], xf[kk][mb], tacc[tg][mb], 0, 0, 0);
+              }
+          }
+          if constexpr (LN) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+              for (int mb = 0; mb < MBK; ++mb) ln_frag_stats(xf[kk][mb], ls1[mb], ls2[mb]);
+          }
+          if (i + R < nsteps) {
+            if (!refill_first) kq[s] = issue(i + R, s);
+            issue_w(i + R, wr[s]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TOUCH; ++t) asm volatile("" ::"v"(tdum[t][0]), "v"(tdum[t][1]), "v"(tdum[t][2]));
+  } else {
   int kq[R];               // (a small FIFO in registers: slot s holds the step whose first column is kq[s]; R is 2)
 #pragma unroll
   for (int s = 0; s < R; ++s) kq[s] = 0;
@@ -187,7 +349,7 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
     // The CU's texture path takes 1 KB of DMA per 16 cycles, shared by the 4 waves: when all of them refill at once each sits ~1100 cycles in
     // DMA issue and then all run their 680 cycles of MFMAs with the path idle (PMC: 49 % of the wave cycles are issue stalls).  Odd waves
     // therefore refill AFTER their MFMAs: the two halves of the workgroup alternate between the two resources.
-    const bool refill_first = !p.stagger || (wave & 1) == 0;
+    const bool refill_first = !(p.stagger & 1) || (wave & 1) == 0;
     if (refill_first && i + R < nsteps) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slot is refilled: its fragments must be in registers first
       const int kn = issue(i + R, slot);
@@ -222,6 +384,8 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
     }
     slot = slot + 1 == R ? 0 : slot + 1;
   }
+
+  }   // !WP
 
   // ---- the 4 partial tiles meet in LDS; unit u = (row block, column block), wave w finishes units w, w + 4, ...
   constexpr int UNITS = MBK * JN, TUN = LORA ? TG * MBK : 0, SMU = UNITS + TUN, UALL = UNITS + TUN + (LN ? 1 : 0),
@@ -326,8 +490,8 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
         v = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, bupf[q][tg]), __builtin_bit_cast(s16x4, tb), v, 0, 0, 0);
       }
     }
-    v += bpre[q];
-    {
+    if (p.bias) v += bpre[q];
+    if (p.R) {
       const uint2 rv = rpre[q];
       v[0] += bf2f(rv.x & 0xffff); v[1] += bf2f(rv.x >> 16); v[2] += bf2f(rv.y & 0xffff); v[3] += bf2f(rv.y >> 16);
     }
@@ -357,22 +521,47 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   WTR(11);
 }
 
-template <int MBK, int JN, int R, int KG, bool LN = false>
+template <int MBK, int JN, int R, int KG, bool LN = false, bool WP = false>
 int launch_wsk(const wsk_params& p, hipStream_t s) {
   constexpr bool LORA = KG > 0;
-  constexpr int SLOT = (16 * MBK + 16 * JN + (LORA ? 16 : 0)) * ROWB;
+  constexpr int SLOT = (16 * MBK + (WP ? 0 : 16 * JN) + (LORA ? 16 : 0)) * ROWB;
   constexpr int RED = NW * (MBK * JN + KG * MBK + (LN ? 1 : 0)) * 1024 + KG * MBK * 64 * 8;
   constexpr int REDP = RED + (LORA ? 0 : MBK * 64 * 8) + 16 * MBK * JN * 4 * 8;      // + the row-partial slots (ln_parts); tsh's offset is TG * MBK * 512 also without an adapter
   constexpr int smem = NW * R * SLOT > REDP ? NW * R * SLOT : REDP;
   static_assert(smem <= 160 * 1024, "LDS budget");
-  if (sdlt_raise_smem((const void*)wsk_kernel<MBK, JN, R, KG, LN>, smem)) SDLT_FAIL(SDLT_ERR_LAUNCH, "sdlt_wsk_gemm: cannot raise the dynamic LDS limit to %d bytes", smem);
+  if (sdlt_raise_smem((const void*)wsk_kernel<MBK, JN, R, KG, LN, WP>, smem)) SDLT_FAIL(SDLT_ERR_LAUNCH, "sdlt_wsk_gemm: cannot raise the dynamic LDS limit to %d bytes", smem);
   const int tiles = (p.M / (16 * MBK)) * (p.N / (16 * JN));
-  hipLaunchKernelGGL((wsk_kernel<MBK, JN, R, KG, LN>), dim3(tiles), dim3(64 * NW), smem, s, p);
+  hipLaunchKernelGGL((wsk_kernel<MBK, JN, R, KG, LN, WP>), dim3(tiles), dim3(64 * NW), smem, s, p);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }
 
+// W [N, K] (row-major, leading dimension ldw) -> the fragment-major copy of wsk_params::Wp; one 16-byte chunk per thread
+__global__ void wsk_pack_kernel(const bf16_t* __restrict__ W, int64_t ldw, int N, int K, bf16_t* __restrict__ Wp) {
+  const int64_t nchunk = (int64_t)N * K / 8;
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nchunk; c += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(c & 63);
+    int64_t f = c >> 6;                       // fragment index: ((tn * (K / 64) + ks) * 2 + kk) * 5 + j
+    const int j = (int)(f % 5); f /= 5;
+    const int kk = (int)(f & 1); f >>= 1;
+    const int nks = K >> 6;
+    const int ks = (int)(f % nks), tn = (int)(f / nks);
+    const int r = lane & 15, g = lane >> 4;
+    *(uint4*)(Wp + c * 8) = *(const uint4*)(W + (int64_t)(tn * 80 + j * 16 + r) * ldw + ks * 64 + kk * 32 + g * 8);
+  }
+}
+
 }  // namespace
+
+extern "C" int sdlt_wsk_pack_weight(const void* W, int64_t ldw, int32_t N, int32_t K, void* Wp, void* stream) {
+  if (N <= 0 || K <= 0 || (N % 80) || (K % 64)) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wsk_pack_weight: N=%d K=%d (N %% 80, K %% 64 == 0)", N, K);
+  if (!W || !Wp || (ldw % 8) || ((uintptr_t)W & 15) || ((uintptr_t)Wp & 15)) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_pack_weight: 16-byte aligned operands, ldw %% 8 == 0");
+  const int64_t nchunk = (int64_t)N * K / 8;
+  const int blocks = (int)((nchunk + 255) / 256 > 4096 ? 4096 : (nchunk + 255) / 256);
+  hipLaunchKernelGGL(wsk_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)W, ldw, N, K, (bf16_t*)Wp);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
 
 #ifdef SDLT_WSK_TRACE
 extern "C" int sdlt_wsk_trace_read(long long* out16) { return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_wsk_tr), sizeof(long long) * 16); }
@@ -384,6 +573,7 @@ static int wsk_gemm_impl(const void* X, int64_t ldx, const void* W, int64_t ldw,
                          const float* ln_adapter, void* ln_parts, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (M % 64) || (N % 80) || ((N / 80) % 8) || (K % 256))
     SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wsk_gemm: M=%d N=%d K=%d (M %% 64, N %% 640, K %% 256 == 0)", M, N, K);
+  const bool packed = ldw == 0;          // W is sdlt_wsk_pack_weight's output
   if (!X || !W || !Y || (ldx % 8) || (ldw % 8) || (ldy % 4) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15) || ((uintptr_t)Y & 7) || (R && ((ldr % 4) || ((uintptr_t)R & 7))) ||
       (bias && ((uintptr_t)bias & 15)))
     SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_gemm: operand alignment");
@@ -394,9 +584,19 @@ static int wsk_gemm_impl(const void* X, int64_t ldx, const void* W, int64_t ldw,
   static const int stagger_env = getenv("SDLT_WSK_STAGGER") ? atoi(getenv("SDLT_WSK_STAGGER")) : 1;   // (read once: A/B switch)
   wsk_params p{(const bf16_t*)X, ldx, (const bf16_t*)W, ldw, bias, (const bf16_t*)R, ldr, (bf16_t*)Y, ldy, M, N, K, 1,
                (const bf16_t*)Adown, ld_adown, (const bf16_t*)Bup, ld_bup, (bf16_t*)T_out, ld_t, lora_scale, lora_group_k, stagger_env,
-               ln_c1, ln_stats, ln_adapter, ln_eps, (float2*)ln_parts};
+               ln_c1, ln_stats, ln_adapter, ln_eps, (float2*)ln_parts, packed ? (const bf16_t*)W : nullptr};
   if (((uintptr_t)ln_parts) & 7) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_gemm: ln_parts must be 8-byte aligned");
   hipStream_t s = (hipStream_t)stream;
+  if (packed) {          // register ring of 3 stages (probed 2 / 3 / 4 in round 5: 3 wins on every shape; 4 runs out of registers with an adapter)
+#define WSK_WP(KG_, LN_) launch_wsk<4, 5, 3, KG_, LN_, true>(p, s)
+    if (ln_c1) return Adown ? WSK_WP(1, true) : WSK_WP(0, true);
+    if (!Adown) return WSK_WP(0, false);
+    if (lora_group_k <= 0) return WSK_WP(1, false);
+    const int G = K / lora_group_k;
+    if ((lora_group_k % 64) || G * lora_group_k != K || G < 2 || G > 3) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_wsk_gemm: lora_group_k=%d with K=%d (2 or 3 groups of a multiple of 64 columns)", lora_group_k, K);
+    return WSK_WP(3, false);
+#undef WSK_WP
+  }
   if (ln_c1) return Adown ? launch_wsk<4, 5, 2, 1, true>(p, s) : launch_wsk<4, 5, 2, 0, true>(p, s);
   if (!Adown) return launch_wsk<4, 5, 2, 0>(p, s);
   if (lora_group_k <= 0) return launch_wsk<4, 5, 2, 1>(p, s);

@@ -6,6 +6,7 @@ arbitrary row stride (views of wider buffers are fine); "NHWC" means rows = B*H*
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -138,6 +139,47 @@ def wsk_shape(M, N, K, lora=False):
     return 2560 <= K <= WSK_KMAX
 
 
+WSK_PACK = os.environ.get("SDLT_WSK_PACK", "1") != "0"
+_WSK_FROZEN = {}         # data_ptr of a weight declared frozen -> weakref of the tensor
+_WSK_PACKED = {}         # data_ptr -> (fragment-major copy (sdlt_wsk_pack_weight's layout), N, K, ld, weakref of the tensor)
+
+
+def wsk_mark_frozen(W):
+    """Declare a bf16 weight [N, K] FROZEN: nothing rewrites it for as long as the tensor lives (the UNet under LoRA / textual inversion; NOT the full
+    fine-tune's refreshed operands, NOT DoRA's per-step W^T).  The first gemm(X, W, ...) that runs on the wave-split-K kernel then makes the
+    fragment-major copy of include/sdlt_kernels.h (sdlt_wsk_pack_weight) once and every such call reads the weight through it."""
+    if WSK and WSK_PACK and W is not None and W.dim() == 2 and W.dtype == BF16 and W.is_cuda and W.stride(1) == 1:
+        key = W.data_ptr()
+        e = _WSK_PACKED.get(key)
+        if e is not None and e[4]() is not W:          # a copy made for an earlier tensor at this address
+            del _WSK_PACKED[key]
+        _WSK_FROZEN[key] = weakref.ref(W)
+
+
+def _wsk_operand(W):
+    """(pointer, ld) of W for sdlt_wsk_gemm*: the packed copy with ld 0 for a weight declared frozen."""
+    key = W.data_ptr()
+    e = _WSK_PACKED.get(key)
+    if e is not None:
+        if e[4]() is None:          # the registered tensor is gone (its address may have been reused): drop the copy
+            del _WSK_PACKED[key]
+        elif e[1] == W.shape[0] and e[2] == W.shape[1] and e[3] == _ld(W):
+            return _p(e[0]), 0
+    f = _WSK_FROZEN.get(key)
+    if f is not None and f() is None:
+        del _WSK_FROZEN[key]
+        f = None
+    if f is not None and tuple(f().shape) == tuple(W.shape) and f().stride(0) == W.stride(0) and key not in _WSK_PACKED:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("wave-split-K GEMM: the packed copy of a frozen weight is made on its first eager use - run the body once before capturing it")
+        N, K = W.shape
+        Wp = torch.empty(N * K, device=W.device, dtype=BF16)
+        _lib.check(_lib.load().sdlt_wsk_pack_weight(_p(W), _ld(W), N, K, _p(Wp), _stream()), "sdlt_wsk_pack_weight")
+        _WSK_PACKED[key] = (Wp, N, K, _ld(W), f)
+        return _p(Wp), 0
+    return _p(W), _ld(W)
+
+
 def gemm_emits_parts(M, N, K, lora_rank_pad=0):
     """Number of row partials per row (0: none) a plain / rank-16-adapter product [M, K] x [N, K]^T (+ bias, residual) runs on the wave-split-K kernel and can therefore leave row
     partials for the next LayerNorm (gemm(..., ln_parts_out=)): the to_out.0 and ff.net.2 products of the 1280-wide blocks at batch 1."""
@@ -192,22 +234,23 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
             if T_ is not None:
                 _chk2(T_)
                 assert tuple(T_.shape) == (M_, 16 * G_)
+        Wptr, Wld = _wsk_operand(W)
         if ln is not None:
             c1, stats_, eps_, lnad = ln[:4]
             _chk2(c1, F32)
             assert c1.numel() == N_ and (stats_ is None or (stats_.dtype == F32 and stats_.numel() >= 2 * M_)) and (lora is None or lnad is not None)
-            _lib.check(lib.sdlt_wsk_gemm_ln(_p(X), _ld(X), _p(W), _ld(W), M_, N_, K_, _p(bias), _p(residual), _ld(residual) if residual is not None else 0,
+            _lib.check(lib.sdlt_wsk_gemm_ln(_p(X), _ld(X), Wptr, Wld, M_, N_, K_, _p(bias), _p(residual), _ld(residual) if residual is not None else 0,
                                             _p(out), _ld(out), _p(A_), _ld(A_) if A_ is not None else 0, _p(B_), _ld(B_) if B_ is not None else 0, float(scale_),
                                             _p(T_), _ld(T_) if T_ is not None else 0, _p(c1), _p(stats_), float(eps_), _p(lnad), _stream()), "sdlt_wsk_gemm_ln")
             return out
         if ln_parts_out is not None:
             assert ln_parts_out.dtype == F32 and ln_parts_out.is_contiguous() and ln_parts_out.numel() >= M_ * (N_ // 80) * 2
-            _lib.check(lib.sdlt_wsk_gemm_parts(_p(X), _ld(X), _p(W), _ld(W), M_, N_, K_, _p(bias), _p(residual), _ld(residual) if residual is not None else 0,
+            _lib.check(lib.sdlt_wsk_gemm_parts(_p(X), _ld(X), Wptr, Wld, M_, N_, K_, _p(bias), _p(residual), _ld(residual) if residual is not None else 0,
                                                _p(out), _ld(out), _p(A_), _ld(A_) if A_ is not None else 0, _p(B_), _ld(B_) if B_ is not None else 0, float(scale_),
                                                _p(T_), _ld(T_) if T_ is not None else 0, int(lora_group_k) if lora is not None else 0, _p(ln_parts_out), _stream()),
                        "sdlt_wsk_gemm_parts")
             return out
-        _lib.check(lib.sdlt_wsk_gemm(_p(X), _ld(X), _p(W), _ld(W), M_, N_, K_, _p(bias), _p(residual), _ld(residual) if residual is not None else 0,
+        _lib.check(lib.sdlt_wsk_gemm(_p(X), _ld(X), Wptr, Wld, M_, N_, K_, _p(bias), _p(residual), _ld(residual) if residual is not None else 0,
                                      _p(out), _ld(out), _p(A_), _ld(A_) if A_ is not None else 0, _p(B_), _ld(B_) if B_ is not None else 0, float(scale_),
                                      _p(T_), _ld(T_) if T_ is not None else 0, int(lora_group_k) if lora is not None else 0, _stream()), "sdlt_wsk_gemm")
         return out

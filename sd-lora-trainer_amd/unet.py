@@ -274,8 +274,13 @@ class LoraArena:
 
     def export(self, which="params"):
         out = {}
+        r_ = self.rank
         for e in self.entries:
-            A, B = (e["A"], e["B"]) if which == "params" else (e["gA"], e["gB"])
+            if which in ("m", "v"):          # AdamW moments, in the layout of the parameters they belong to
+                flat = self.m if which == "m" else self.v
+                A, B = flat[e["offA"]: e["offA"] + r_ * e["K"]].view(r_, e["K"]), flat[e["offB"]: e["offB"] + e["N"] * r_].view(e["N"], r_)
+            else:
+                A, B = (e["A"], e["B"]) if which == "params" else (e["gA"], e["gB"])
             A, B = A.detach().float().cpu(), B.detach().float().cpu()
             if e["conv_cin"] is not None:
                 r = A.shape[0]
@@ -283,12 +288,21 @@ class LoraArena:
                 B = B.reshape(B.shape[0], r, 1, 1)
             out[e["name"]] = (A, B)
             if self.dora:                   # peft lora_magnitude_vector: [N] (Linear), [1, N, 1, 1] (Conv2d)
-                m = (e["M"] if which == "params" else e["gM"]).detach().float().cpu().clone()
+                m = ((self.m if which == "m" else self.v)[e["offM"]: e["offM"] + e["N"]] if which in ("m", "v") else (e["M"] if which == "params" else e["gM"])).detach().float().cpu().clone()
                 out[e["name"]] = (A, B, m.reshape(1, -1, 1, 1) if e["conv_cin"] is not None else m)
         return out
 
 
 # ---------------------------------------------------------------------------------------- leaf layers
+
+def _mark_frozen(rt, *ws):
+    """Frozen GEMM operands (no trainer; nothing rewrites them): the wave-split-K kernel may read them through a fragment-major copy (ops.wsk_mark_frozen)."""
+    mark = getattr(rt.ops, "wsk_mark_frozen", None)
+    if mark is not None and rt.trainer is None:
+        for w in ws:
+            if w is not None:
+                mark(w)
+
 
 class Linear(_Module):
     """y = x W^T + b (+ LoRA) (+ residual);  dx = dy W (+ LoRA) (+ dres)."""
@@ -317,6 +331,7 @@ class Linear(_Module):
             self.went = tr.add(name + ".weight", w.float(), "conv1x1" if sd[name + ".weight"].dim() == 4 else "matrix")
             self.bent = tr.add(name + ".bias", b.float(), "vector") if b is not None else None
             tr.on_finalize(self._bind_trainer)
+        _mark_frozen(rt, self.W, self.Wt)      # (DoRA's dX operand is Wt_d, rewritten every step: never marked)
 
     def _bind_trainer(self):
         tr = self.trainer
@@ -338,6 +353,7 @@ class Linear(_Module):
             assert self.lora is None
             self.W_plain, self.bias_plain = self.W, self.bias
         self.W, self.ln_c1, self.bias = rt.ops.fold_layernorm(w32.to(rt.device), self.bias, norm.gamma, norm.beta, dtype=rt.act)
+        _mark_frozen(rt, self.W)
         if self.lora is not None:
             self.lora["W"] = self.W
             self.ln_Ag, self.ln_consts = rt.zeros(self.arena.Rp, self.K), rt.zeros(32, dtype=F32)
@@ -429,6 +445,7 @@ class StackedLinear(_Module):
         assert all(m.N == N and m.K == K for m in members), "stacked projections must share their shape"
         self.N, self.K, self.G = N, K, len(members)
         self.W = torch.cat([m.W for m in members], 0).contiguous()
+        _mark_frozen(rt, self.W)
         for g, m in enumerate(members):
             m.W = self.W[g * N:(g + 1) * N]
             if m.lora is not None:
@@ -484,9 +501,11 @@ class StackedLinear(_Module):
         N = self.N
         if getattr(self, "Wt", None) is None:      # the dX operand is built lazily from W: take it from the UNFOLDED weights now
             self.Wt = self.W.t().contiguous()
+            _mark_frozen(self.rt, self.Wt)
             for m in self.members:
                 m.Wt = None
         self.W, self.ln_c1, self.bias = rt.ops.fold_layernorm(torch.cat([w.to(rt.device) for w in w32s], 0), self.bias, norm.gamma, norm.beta, dtype=rt.act)
+        _mark_frozen(rt, self.W)
         for g, m in enumerate(self.members):
             m.W = self.W[g * N:(g + 1) * N]
             if m.lora is not None:
@@ -541,6 +560,7 @@ class StackedLinear(_Module):
         M, N, G = dy_cat.shape[0], self.N, self.G
         if getattr(self, "Wt", None) is None:
             self.Wt = self.W.t().contiguous()
+            _mark_frozen(self.rt, self.Wt)
             for m in self.members:
                 m.Wt = None          # the per-member transposes are dead once the stacked one exists
         dx = out if out is not None else self.buf("dx", M, self.K)
@@ -559,6 +579,7 @@ class StackedLinear(_Module):
         M, N, G = dy_cat.shape[0], self.N, self.G
         if getattr(self, "Wt", None) is None:
             self.Wt = self.W.t().contiguous()
+            _mark_frozen(self.rt, self.Wt)
             for m in self.members:
                 m.Wt = None
         Rp = self.arena.Rp
@@ -944,6 +965,7 @@ class TransformerBlock(_Module):
             perm = rt.ops.geglu_perm(H, self.ff1.W.device)
             self.ff1.W = self.ff1.W[perm].contiguous()
             self.ff1.Wt = self.ff1.W.t().contiguous()
+            _mark_frozen(rt, self.ff1.W, self.ff1.Wt)
             self.ff1.bias = self.ff1.bias[perm].contiguous()
         # LayerNorm forward folded into the GEMM behind it (sdlt_gemm_params.ln_c1): norm1 -> to_q|to_k|to_v, norm2 -> attn2.to_q,
         # norm3 -> ff.net.0.proj (with the fused GEGLU epilogue only).  Not with the full fine-tune (gamma / beta / W are trained), DoRA (the

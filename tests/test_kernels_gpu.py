@@ -1276,6 +1276,60 @@ def test_wsk_gemm_k_grouped_lora(ops, M, N, gk, G, res):
         assert torch.equal(y3, y) and torch.equal(T3, T)
 
 
+@pytest.mark.parametrize("M,N,K,mode", [(1024, 1280, 1280, "plain"), (1024, 1280, 5120, "plain"), (1024, 1280, 10240, "plain"), (64, 1280, 256, "plain"), (128, 640, 512, "plain"),
+                                        (128, 640, 768, "lora"), (256, 640, 1024, "plain"), (2048, 640, 4096, "plain"), (1024, 1280, 1280, "lora"), (512, 1280, 2560, "lora"),
+                                        (1024, 1280, 3840, "kgroup"), (256, 640, 768, "kgroup"), (1024, 1280, 1280, "ln"), (1024, 1280, 1280, "ln_lora"), (1024, 1280, 5120, "parts"),
+                                        (1024, 1280, 1280, "parts_lora")])
+def test_wsk_gemm_packed_weight_is_bit_identical(ops, M, N, K, mode):
+    """Frozen weights in fragment-major order (sdlt_wsk_pack_weight; W passed with ldw = 0): the weight fragments go from global memory straight into a
+    register ring instead of through LDS.  Same arithmetic in the same order - every entry point, adapter form and side output must give the SAME BITS as
+    the row-major call (which the tests above pin against fp32 math); step counts per wave of 1, 2, 3, 4, 5, 10, 15, 16, 20, 40 exercise the prologue /
+    steady state / drain of the 3-deep ring, and ops.gemm must take the packed route for a weight declared frozen."""
+    g = torch.Generator().manual_seed(M + N + K + len(mode))
+    lora, kgroup, ln, parts = "lora" in mode or mode == "kgroup", mode == "kgroup", mode.startswith("ln"), mode.startswith("parts")
+    G = 3 if kgroup else 1
+    x = (rnd(M, K, g=g).float() * (2.0 if ln else 1.0) + (0.7 if ln else 0.0)).to(BF).cuda()
+    w = rnd(N, K, g=g, scale=K ** -0.5).cuda()
+    b, r = torch.randn(N, generator=g).cuda(), rnd(M, N, g=g).cuda()
+    A, Bu = rnd(16, K, g=g, scale=1.0 / 16).cuda(), rnd(N, 16 * G, g=g, scale=0.05).cuda()
+    c1, consts = torch.randn(N, generator=g).cuda(), torch.randn(32, generator=g).cuda()
+    lib = ops._lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    wp = torch.empty(N * K, dtype=BF, device="cuda")
+    ops._lib.check(lib.sdlt_wsk_pack_weight(w.data_ptr(), K, N, K, wp.data_ptr(), st), "sdlt_wsk_pack_weight")
+    # the layout of include/sdlt_kernels.h, element by element
+    ref_pack = w.view(N // 80, 5, 16, K // 64, 2, 4, 8).permute(0, 3, 4, 1, 5, 2, 6).contiguous().view(-1)
+    assert torch.equal(wp, ref_pack)
+
+    def run(wptr, ldw):
+        y = torch.full((M, N), 7.0, dtype=BF, device="cuda")
+        T = torch.full((M, 16 * G), 7.0, dtype=BF, device="cuda")
+        stats = torch.zeros(M, 2, device="cuda")
+        pr = torch.zeros(M, N // 80, 2, device="cuda")
+        la = (A.data_ptr(), K, Bu.data_ptr(), 16 * G, 0.75, T.data_ptr(), 16 * G) if lora else (None, 0, None, 0, 0.0, None, 0)
+        if ln:
+            rc = lib.sdlt_wsk_gemm_ln(x.data_ptr(), K, wptr, ldw, M, N, K, b.data_ptr(), r.data_ptr(), N, y.data_ptr(), N, *la, c1.data_ptr(), stats.data_ptr(), 1e-5,
+                                      consts.data_ptr() if lora else None, st)
+        elif parts:
+            rc = lib.sdlt_wsk_gemm_parts(x.data_ptr(), K, wptr, ldw, M, N, K, b.data_ptr(), r.data_ptr(), N, y.data_ptr(), N, *la, 0, pr.data_ptr(), st)
+        else:
+            rc = lib.sdlt_wsk_gemm(x.data_ptr(), K, wptr, ldw, M, N, K, b.data_ptr(), r.data_ptr(), N, y.data_ptr(), N, *la, K // G if kgroup else 0, st)
+        assert rc == 0, lib.sdlt_last_error()
+        torch.cuda.synchronize()
+        return y, T, stats, pr
+    base, packed = run(w.data_ptr(), K), run(wp.data_ptr(), 0)
+    assert float((base[0].float() - 7.0).abs().max()) > 1.0          # (the kernel wrote the output)
+    for a_, b_, what in zip(base, packed, ("Y", "T_out", "ln_stats", "ln_parts")):
+        assert torch.equal(a_, b_), f"packed weight: {what} differs, max abs diff {float((a_.float() - b_.float()).abs().max())}"
+    assert torch.equal(run(wp.data_ptr(), 0)[0], packed[0])          # reproducible
+    if mode in ("plain", "lora", "kgroup") and ops.wsk_shape(M, N, K, lora):      # ops.gemm: the packed route for a weight declared frozen, lazily on first use
+        ops.wsk_mark_frozen(w)
+        y2, T2 = torch.empty(M, N, dtype=BF, device="cuda"), torch.empty(M, 16 * G, dtype=BF, device="cuda")
+        ops.gemm(x, w, y2, bias=b, residual=r, **(dict(lora=(A, Bu, 0.75, T2), lora_group_k=K // G if kgroup else 0) if lora else {}))
+        assert w.data_ptr() in ops._WSK_PACKED and torch.equal(ops._WSK_PACKED[w.data_ptr()][0], wp)
+        assert torch.equal(y2, base[0]) and (not lora or torch.equal(T2, base[1]))
+
+
 @pytest.mark.parametrize("B,sizes,ratio,has", [(1, [(64, 64, 10), (32, 32, 50)], 1.0, [1]), (2, [(64, 64, 3), (32, 32, 6), (16, 16, 6)], 1.0, [1, 0]),
                                                (2, [(32, 32, 4)], 1.0, [1, 1]), (1, [(32, 64, 2), (16, 32, 5)], 2.0, [1]), (2, [(32, 32, 2), (16, 16, 2)], 1.0, [0, 0])])
 def test_token_attention_loss_fused(ops, B, sizes, ratio, has):

@@ -322,15 +322,33 @@ def run_step_and_trajectory(version, B, h, sd, kinds, *, device, ops=None, act_d
     # final state: the LoRA displacement and the token rows agree with the oracle's
     start = torch.cat([t.reshape(-1).float() for k in names for t in lora[k]])
     got = unet.arena.export("params")
-    cos, rel = _cos_rel(torch.cat([t.reshape(-1) for k in names for t in got[k]]) - start, ref.lora_flat() - start)
+    disp, disp_ref = torch.cat([t.reshape(-1) for k in names for t in got[k]]) - start, ref.lora_flat() - start
+    cos, rel = _cos_rel(disp, disp_ref)
+    # What the raw displacement cosine mixes: AdamW moves a coordinate by ~lr * m_hat / sqrt(v_hat) per step, which is +-lr for ANY gradient of
+    # consistent sign however small, and sign noise for a coordinate whose gradient is numerically nothing.  So (1) the moments themselves - m is linear and v quadratic in the
+    # gradients of the six steps, no division: they must agree like the gradients do - and (2) the displacement on the coordinates whose oracle update is decided,
+    # |m_hat| / sqrt(v_hat) >= 0.5 (the last step moved them by at least lr / 2 in a definite direction), with the share of such coordinates in the report.
+    m_ref, v_ref, k_adam = ref.adam_moments()
+    gm, gv = unet.arena.export("m"), unet.arena.export("v")
+    m_got, v_got = (torch.cat([t.reshape(-1) for k in names for t in d_[k]]) for d_ in (gm, gv))
+    assert k_adam == n_steps
+    m_cos, m_rel = _cos_rel(m_got, m_ref)
+    v_cos, v_rel = _cos_rel(v_got, v_ref)
+    ratio = (m_ref / (1 - 0.9 ** k_adam)).abs() / ((v_ref / (1 - 0.999 ** k_adam)).sqrt() + 1e-8)
+    decided = ratio >= 0.5
+    d_cos, d_rel = _cos_rel(disp[decided], disp_ref[decided])
+    u_cos, _ = _cos_rel(disp[~decided], disp_ref[~decided])
+    moments = dict(m_cos=m_cos, m_rel=m_rel, v_cos=v_cos, v_rel=v_rel, decided_fraction=float(decided.float().mean()), decided_cos=d_cos, decided_rel=d_rel, undecided_cos=u_cos)
     if case is not None and case in REPORT:
-        REPORT[case]["displacement_after_steps"] = dict(steps=n_steps, cos=cos, rel=rel)
+        REPORT[case]["displacement_after_steps"] = dict(steps=n_steps, cos=cos, rel=rel, **moments)
         out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
         if os.path.isdir(out_dir):
             import json
             with open(os.path.join(out_dir, "parity_report.json"), "w") as fh:
                 json.dump(REPORT, fh, indent=1)
     assert cos >= tol["disp_cos"], f"LoRA displacement after {n_steps} AdamW steps: cos {cos} rel {rel}"
+    assert m_cos >= tol.get("m_cos", 0.999) and v_cos >= tol.get("v_cos", 0.999), f"AdamW moments after {n_steps} steps: {moments}"
+    assert d_cos >= tol.get("decided_cos", 0.995) and moments["decided_fraction"] >= 0.2, f"LoRA displacement on the decided coordinates after {n_steps} steps: {moments}"
     for rows, table in zip(ts.ti.rows, ref.tables):
         cos, rel = _cos_rel(rows, table.detach()[-NTOK:])
         assert cos >= 0.999 and rel <= tol["rows_final"], f"token rows after {n_steps} steps: cos {cos} rel {rel}"
