@@ -66,7 +66,7 @@ typedef struct sdlt_gemm_params {
   int32_t lora_R;
   float lora_scale;
   float alpha;
-  const float* bias;
+  const float* bias;                 /* fp32 [N] or NULL; N % 4 == 0 with a bias, a folded LayerNorm or a batch (four columns per lane are fetched at once) */
   const void* rowbias; int64_t ld_rowbias; int32_t rows_per_batch;
   const void* R; int64_t ldr;
   void* C; int64_t ldc;

@@ -319,22 +319,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
       for (int a = 0; a < NI; ++a) {
         const int n = n0 + wn * NI * 16 + a * 16 + frow;
         const int nc = n < p.N ? n : p.N - 1;
-        bupf[j][a] = (s16x4){0, 0, 0, 0};
-        if (j < nup_) bupf[j][a] = *(const s16x4*)((const bf16_t*)pBup + (size_t)nc * p.ld_bup + j * 16 + fk * 4);
+        // (UNCONDITIONAL loads from clamped addresses, here and below - round 5: a load under a condition, merged with a zero default, made hipcc copy the
+        // loaded registers at the join and put an s_waitcnt vmcnt(0) behind it: three to five serial global round trips - the first DMA stage included - in the
+        // prologue of every launch, seen in the ISA.  What an absent operand would have been is decided where it is USED.)
+        bupf[j][a] = *(const s16x4*)((const bf16_t*)pBup + (size_t)nc * p.ld_bup + (j < nup_ ? j : 0) * 16 + fk * 4);
       }
   }
+  // bias / c1: four columns per lane; N % 4 == 0 whenever either is given (host-checked), columns beyond N read chunk 0 and are never stored
   f32x4 biasf[NI];
+  {
+    const float* bsrc = pBias ? pBias : (const float*)pW;         // (no bias: any readable N floats; the epilogue skips the addition)
 #pragma unroll
-  for (int a = 0; a < NI; ++a) {
-    const int n = n0 + wn * NI * 16 + a * 16 + fk * 4;
-    biasf[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (pBias) {
-      if (n + 3 < p.N) biasf[a] = *(const f32x4*)(pBias + n);
-      else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < p.N) biasf[a][r] = pBias[n + r];
-      }
+    for (int a = 0; a < NI; ++a) {
+      const int n = n0 + wn * NI * 16 + a * 16 + fk * 4;
+      biasf[a] = *(const f32x4*)(bsrc + (n < p.N ? n : 0));
     }
   }
   f32x4 c1f[LN ? NI : 1], lnca = (f32x4){0.f, 0.f, 0.f, 0.f}, lnab = lnca;
@@ -342,13 +340,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
 #pragma unroll
     for (int a = 0; a < NI; ++a) {
       const int n = n0 + wn * NI * 16 + a * 16 + fk * 4;
-      c1f[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (n + 3 < p.N) c1f[a] = *(const f32x4*)(p.ln_c1 + n);
-      else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < p.N) c1f[a][r] = p.ln_c1[n + r];
-      }
+      c1f[a] = *(const f32x4*)(p.ln_c1 + (n < p.N ? n : 0));
     }
     if constexpr (R16 != 0) {      // adapter constants of this lane's four rank rows (rank = fk * 4 + i) of this tile's adapter group
       lnca = *(const f32x4*)(p.ln_adapter + lgrp * 32 + fk * 4);
@@ -361,11 +353,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
   if constexpr (LN == 2) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      lnp[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (tid < BM && 2 * i < p.ln_nparts) {
-        const int m = m0 + tid < p.M ? m0 + tid : p.M - 1;
-        lnp[i] = *(const f32x4*)((const float*)p.ln_parts + ((size_t)m * p.ln_nparts + 2 * i) * 2);
-      }
+      const int tr = tid < BM ? tid : 0;
+      const int m = m0 + tr < p.M ? m0 + tr : p.M - 1;
+      lnp[i] = *(const f32x4*)((const float*)p.ln_parts + ((size_t)m * p.ln_nparts + (2 * i < p.ln_nparts ? 2 * i : 0)) * 2);    // (absent pairs: pair 0 again, skipped below)
     }
   }
   // staged (bf16, full-row-segment) epilogue: geometry and the residual tile in the store loop's own layout
@@ -389,8 +379,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
     for (int t = 0; t < RIT; ++t) {
       const int it = tid + (t % QPP) * NTHR, row = it / NCH, ch = it - row * NCH;
       const int m = m0 + (t / QPP) * CROWS + row, n = n0 + ch * 8;
-      rpre[t] = (uint4){0u, 0u, 0u, 0u};
-      if (m < p.M && n < p.N) rpre[t] = *(const uint4*)((const bf16_t*)p.R + (size_t)m * p.ldr + n);
+      rpre[t] = *(const uint4*)((const bf16_t*)p.R + (size_t)(m < p.M ? m : p.M - 1) * p.ldr + (n < p.N ? n : 0));      // (rows / chunks outside the matrix are never stored)
     }
   }
 
@@ -575,7 +564,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
       // partial t = (sum, centred sum of squares) of K / ln_nparts columns: total M2 = sum_t M2_t + n_t (mean_t - mean)^2 (no large cancellation)
       float s1 = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) s1 += lnp[i][0] + lnp[i][2];          // (absent partials are zero; ln_nparts even)
+      for (int i = 0; i < 8; ++i)
+        if (2 * i < p.ln_nparts) s1 += lnp[i][0] + lnp[i][2];            // (ln_nparts even)
       const float inv = 1.f / (float)p.K, nt = (float)p.K / (float)p.ln_nparts, invt = 1.f / nt;
       const float mean = s1 * inv;
       float m2 = 0.f;
@@ -795,7 +785,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
           if constexpr (R16 != 0) {
             if (pCs && n < p.N) v *= *(const f32x4*)(pCs + n);    // (staged: N % 8 == 0)
           }
-          v += biasf[a];
+          if (pBias) v += biasf[a];
           if (n < p.N) {
             if (p.rowbias) {
               uint2 rb = *(const uint2*)((const bf16_t*)p.rowbias + (size_t)brow * p.ld_rowbias + n);
@@ -907,7 +897,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
       }
       if (vec_ok && n + 3 < p.N) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += biasf[a][r];
+        for (int r = 0; r < 4; ++r) v[r] += pBias ? biasf[a][r] : 0.f;
         if (p.rowbias) {
           uint2 rb = *(const uint2*)((const bf16_t*)p.rowbias + (size_t)brow * p.ld_rowbias + n);
           v[0] += bf2f(rb.x & 0xffff); v[1] += bf2f(rb.x >> 16); v[2] += bf2f(rb.y & 0xffff); v[3] += bf2f(rb.y >> 16);
@@ -935,7 +925,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (n + r >= p.N) break;
-          float x = v[r] + biasf[a][r];
+          float x = v[r] + (pBias ? biasf[a][r] : 0.f);
           if (p.rowbias) x += bf2f(((const bf16_t*)p.rowbias)[(size_t)brow * p.ld_rowbias + n + r]);
           if (p.R) x += bf2f(((const bf16_t*)p.R)[(size_t)m * p.ldr + n + r]);
           if (pCt) ((bf16_t*)pCt)[(size_t)(n + r) * p.ldct + m] = f2bf(x);
@@ -1243,6 +1233,7 @@ extern "C" int sdlt_gemm_bf16(const sdlt_gemm_params* pp, void* stream) {
     SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_gemm_bf16: operand rows must be 16-byte aligned (ld %% 8)");
   if (((uintptr_t)p.X | (uintptr_t)p.W | (uintptr_t)p.X2 | (uintptr_t)p.W2 | (uintptr_t)p.Adown) & 15)
     SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_gemm_bf16: operand base pointers must be 16-byte aligned");
+  if ((p.bias || p.ln_c1 || p.batch) && (p.N & 3)) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: N=%d with a bias / folded LayerNorm / batch must be a multiple of 4 (the kernels fetch four columns per lane)", p.N);
   if (p.mode == 1) {
     if (!p.zero) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: conv mode needs a zero page");
     if (p.Cin % BK || p.K != 9 * p.Cin) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: conv needs Cin%%64==0 and K==9*Cin (Cin=%d K=%d)", p.Cin, p.K);

@@ -116,7 +116,11 @@ __device__ __forceinline__ void gn_combine_partials(int C, const float* __restri
     float t = parts[tid];
     for (int k = 1; k < nparts; ++k) t += parts[k * p2 + tid];
     fin[slot] = t;
-    if (out && blockIdx.y == 0) out[b * 64 + slot] = t;
+    // ONE writer per slot: a group that straddles two 64-channel blocks is summed by both, but with different (slot, part) splits of the 256 threads when the
+    // blocks touch different numbers of groups (C = 1280: 40 channels per group, 2 or 3 groups per block) - the two sums can differ in the last bit, and which one
+    // landed in `out` was a race (found in round 5: the forward statistics the backward pass reads differed by an ulp between two passes from the same state,
+    // tools/determinism_probe.py - the only nondeterminism of the LoRA / TI step).  The first block of the group stores.
+    if (out && blockIdx.y == 0 && (int)blockIdx.x == ((slot >> 1) * cpg) / 64) out[b * 64 + slot] = t;
   }
   __syncthreads();
 }

@@ -77,10 +77,15 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
                 PIECES = SROWS / 8 + (WP ? 2 * JN : 0);      // vector-memory operations of one K step of one wave (what the counted waits count)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   WTR(0);
+  // every kernel argument is fetched by the FIRST scalar-load batch (hipcc otherwise fetches a field where it is first used: three more scalar round trips,
+  // each behind an s_waitcnt lgkmcnt(0), in the prologue and in front of the epilogue)
+  asm volatile("" ::"s"(p.X), "s"(p.ldx), "s"(p.W), "s"(p.ldw), "s"(p.bias), "s"(p.R), "s"(p.ldr), "s"(p.Y), "s"(p.ldy), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.map2d));
+  asm volatile("" ::"s"(p.Adown), "s"(p.ld_adown), "s"(p.Bup), "s"(p.ld_bup), "s"(p.T_out), "s"(p.ld_t), "s"(p.lora_scale), "s"(p.group_k), "s"(p.stagger));
+  asm volatile("" ::"s"(p.ln_c1), "s"(p.ln_stats), "s"(p.ln_adapter), "s"(p.ln_eps), "s"(p.ln_parts), "s"(p.Wp));
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int ntn = p.N / WR, ntm = p.M / XR;
-  int tm, tn, phase, nphase;     // phase / nphase: this workgroup's place among the workgroups of its XCD (row-major over the XCD's block of tiles)
+  int tm, tn;
   {
     // XCD-aware: the workgroups of one XCD (blockIdx % 8) take neighbouring column tiles over all row tiles, so every weight panel is
     // fetched into one L2 only and the activation rows are what the L2s share
@@ -92,17 +97,14 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
       const int dq = div_small_u(idx, pc);
       tm = (xcd >> 2) * pr + dq;
       tn = (xcd & 3) * pc + idx - dq * pc;
-      phase = 2 * idx + (xcd >> 2);                      // (the two XCDs that read the same weight panels are half a place apart)
-      nphase = 2 * pr * pc;
     } else {
       const int per = ntn >> 3;                          // column tiles per XCD (ntn % 8 == 0)
       tm = div_small_u(idx, per);
       tn = xcd * per + idx - tm * per;
-      phase = idx;
-      nphase = ntm * per;
     }
   }
   if (tm >= ntm || tn >= ntn) return;
+  WTR(13);
   const int m0 = tm * XR, n0 = tn * WR;
   const int nsteps = p.K >> 8;
 
@@ -122,12 +124,10 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   // T = s X Adown^T, which every tile recomputes for itself, can differ between tiles in the last bit of its fp32 sum, i.e. rarely by one bf16 ulp
   // after rounding; T_out (the copy the adapter-gradient launch reads) is column tile 0's.  That is inside the
   // rounding of T itself (2^-9 relative) - the parity tests compare Y and the adapter gradients with that tolerance.
-  // Round 5: the rotation follows the workgroup's place in its XCD instead of tn alone.  With rot = tn % nsteps the 8 workgroups of an XCD that walk the SAME
-  // weight panel (same tn, different tm) were in lockstep: every K step of theirs was a first touch - an HBM / fabric round trip the 2-step prefetch cannot
-  // cover (lab build with the weight panel L2-resident: K = 10240 42.7 -> 36.3 us, tools/wsk_lab.sh).  Spread over the walk, a workgroup is the first to
-  // touch only its own 1 / 8 of the panel and finds the rest in L2, fetched by the neighbour that is ahead of it; same for the 4 that share an X panel.
-  const int rot2 = div_small_u(phase * nsteps, nphase);
-  const int rot = (p.stagger & 16) ? (rot2 >= nsteps ? nsteps - 1 : rot2) : tn - div_small_u(tn, nsteps) * nsteps;
+  // (Round 5, measured and dropped: a rotation that also spreads the 8 workgroups of an XCD that walk the SAME weight panel over the K range - so that each is the
+  // first to touch only 1 / 8 of it - makes the XCD's working set the whole of X / 2 + W / 4 at once instead of a window that slides along K: K = 10240 went from
+  // 44 to 74 us.  The lockstep of the workgroups is what lets a 4 MB L2 serve a 17 MB operand set.)
+  const int rot = tn - div_small_u(tn, nsteps) * nsteps;
   auto issue = [&](int i, int slot) -> int {
     int ii = i + rot;
     ii = ii >= nsteps ? ii - nsteps : ii;
@@ -188,64 +188,50 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   float ls1[LN ? MBK : 1], ls2[LN ? MBK : 1];      // LN: sum x / sum x^2 of row (mb, r) over this lane's 8-column chunks of this wave's K share
 #pragma unroll
   for (int mb = 0; mb < (LN ? MBK : 1); ++mb) ls1[mb] = ls2[mb] = 0.f;
-  constexpr int UNITS_ = MBK * JN, UPW_ = (UNITS_ + NW - 1) / NW;
-  // residual and bias of the units this wave finishes, requested before anything else (loads at their point of use sit exposed behind the
-  // last barrier: +1.1 us per launch; being the OLDEST loads in flight they only make the counted waits below wait for them too)
-  // (unconditional loads through selected pointers: with `if (p.R)` / `if (p.bias)` around them hipcc merged each loaded vector with its zero default
-  // through register copies and put an s_waitcnt vmcnt(0) behind EVERY unit's pair - five serial global round trips, ~2 us, in front of the ring
-  // prefill of every launch (found in the ISA in round 5; the clock stamps of DESIGN 4.7 showed them as "prefill issued 2.7 us after the start").  A
-  // missing residual / bias reads in-bounds rows of Y / X instead and the epilogue skips the addition.)
-  static_assert(UNITS_ % NW == 0, "every wave finishes the same number of units");
-  const bf16_t* rsrc = p.R ? p.R : p.Y;
-  const int64_t rld = p.R ? p.ldr : p.ldy;
-  const float* bsrc = p.bias ? p.bias : (const float*)p.X;       // (N floats <= 64 rows of X: K >= 1024 columns)
-  uint2 rpre[UPW_];
-  f32x4 bpre[UPW_], c1pre[LN ? UPW_ : 1];
+  // ---- the first K step's loads go out before anything else is computed (round 5; clock stamps: the prefill used to be issued 2.7 - 3.4 us into a launch that lasts 8)
+  static_assert(MBK == NW, "the epilogue gives row block w of the tile to wave w");
+  [[maybe_unused]] bf16x8 wr[WP ? R : 1][2][JN];      // WP: register ring of the weight fragments
+  int kq[R];               // slot s holds the step whose first column is kq[s]
 #pragma unroll
-  for (int q = 0; q < UPW_; ++q) {
-    const int u = wave + q * NW;
-    const int mb = u / JN, j = u - mb * JN, n = n0 + 16 * j + 4 * g, m = m0 + mb * 16 + r;
-    rpre[q] = *(const uint2*)(rsrc + (int64_t)m * rld + n);
-    bpre[q] = *(const f32x4*)(bsrc + n);
-    if constexpr (LN) c1pre[q] = *(const f32x4*)(p.ln_c1 + n);
+  for (int s = 0; s < R; ++s) kq[s] = 0;
+  kq[0] = issue(0, 0);
+  if constexpr (WP) issue_w(0, wr[0]);
+  // ---- epilogue operands of the units this wave finishes - row block `wave` of the tile, all JN column blocks (unit q = column block q) -, requested now: loads at their point
+  // of use sat exposed behind the last barrier (+1.1 us per launch with a residual; the LoRA-up fragments even behind an s_waitcnt vmcnt(0) of their own).  Queue order:
+  // step 0, these, steps 1 .. R - 1 - so the counted waits of the K walk cover them from step 0 on and never wait FOR them alone.
+  // Unconditional loads through selected pointers: with `if (p.R)` / `if (p.bias)` around them hipcc merged each loaded vector with its zero default through register copies and
+  // put an s_waitcnt vmcnt(0) behind EVERY unit's pair - five serial round trips in front of the ring prefill (found in the ISA in round 5).  A missing residual / bias reads
+  // in-bounds rows of Y / X instead and the epilogue skips the addition; adapter groups beyond the ones in use read group 0's columns and are skipped.
+  const bf16_t* rsrc = (p.R ? p.R : p.Y) + (int64_t)(m0 + wave * 16 + r) * (p.R ? p.ldr : p.ldy) + n0 + 4 * g;
+  const float* bsrc = (p.bias ? p.bias : (const float*)p.X) + n0 + 4 * g;       // (N floats <= 64 rows of X: K >= 256 columns)
+  uint2 rpre[JN];
+  f32x4 bpre[JN], c1pre[LN ? JN : 1];
+  uint2 bupf[JN][KG > 0 ? KG : 1];
+#pragma unroll
+  for (int q = 0; q < JN; ++q) {
+    rpre[q] = *(const uint2*)(rsrc + 16 * q);
+    bpre[q] = *(const f32x4*)(bsrc + 16 * q);
+    if constexpr (LN) c1pre[q] = *(const f32x4*)(p.ln_c1 + n0 + 16 * q + 4 * g);
   }
+  if constexpr (LORA) {
+    const int ngrp0 = KG > 1 ? p.K / p.group_k : 1;
+    const bf16_t* bu = p.Bup + (int64_t)(n0 + r) * p.ld_bup + 4 * g;
+#pragma unroll
+    for (int q = 0; q < JN; ++q)
+#pragma unroll
+      for (int tg = 0; tg < KG; ++tg) bupf[q][tg] = *(const uint2*)(bu + (int64_t)(16 * q) * p.ld_bup + (tg < ngrp0 ? 16 * tg : 0));
+  }
+  WTR(14);
   f32x4 lnca = (f32x4){0.f, 0.f, 0.f, 0.f}, lnab = lnca;      // adapter constants of this lane's four rank rows 4g .. 4g+3
   if constexpr (LN && LORA) { lnca = *(const f32x4*)(p.ln_adapter + 4 * g); lnab = *(const f32x4*)(p.ln_adapter + 16 + 4 * g); }
   static_assert(WP || R == 2 || KG <= 1, "the K-grouped bookkeeping below tracks a 2-slot ring");
 
   if constexpr (WP) {
     // ---- K walk, weight fragments in registers: R stages in flight per wave; queue order per step: X (+ LoRA-down) pieces, then the weight loads
-    bf16x8 wr[R][2][JN];
-    int kq[R];
+    // (Round 5, measured and dropped: touching the steps behind the ring's reach at the top of the kernel, one lane per 128-byte line, so that their HBM round
+    // trips start with the launch - 5-11 % SLOWER on every shape: the extra requests queue in front of the prefill's own first-touch loads.)
 #pragma unroll
-    for (int s = 0; s < R; ++s) kq[s] = 0;
-    // The steps BEHIND the ring's reach (R .. R + TOUCH - 1) are touched now, one lane per 128-byte line: their HBM / fabric round trips start with the
-    // launch instead of one ring turn at a time (a K = 1280 product is 5 steps per wave: all of its operands are on their way at t = 0).  Issued before
-    // the prefill, so they are the OLDEST loads in flight and every counted wait below already covers them (the prefill's own first-touch latency is the
-    // same, so nothing waits longer for them); the dummy registers stay reserved until behind the K walk.
-    constexpr int TOUCH = 4;
-    uint32_t tdum[TOUCH][3];
-#pragma unroll
-    for (int t = 0; t < TOUCH; ++t) tdum[t][0] = tdum[t][1] = tdum[t][2] = 0u;
-    if (p.stagger & 32) {
-#pragma unroll
-      for (int t = 0; t < TOUCH; ++t) {
-        const int i = R + t;
-        if (i < nsteps) {
-          int ii = i + rot;
-          ii = ii >= nsteps ? ii - nsteps : ii;
-          const int ks = wave + NW * ii;
-          const char* wl = wpbase + (int64_t)ks * (2 * JN * 1024);
-          const char* w0 = wl + lane * 128, *w1 = wl + (64 + (lane & 15)) * 128;
-          const char* x0 = (const char*)(p.X + (int64_t)(m0x + lane) * p.ldx + ks * 64);
-          asm volatile("global_load_dword %0, %1, off" : "=&v"(tdum[t][0]) : "v"(w0) : "memory");
-          asm volatile("global_load_dword %0, %1, off" : "=&v"(tdum[t][1]) : "v"(w1) : "memory");
-          asm volatile("global_load_dword %0, %1, off" : "=&v"(tdum[t][2]) : "v"(x0) : "memory");
-        }
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < R; ++s)
+    for (int s = 1; s < R; ++s)
       if (s < nsteps) { kq[s] = issue(s, s); issue_w(s, wr[s]); }
     WTR(1);
     const bool refill_first = !(p.stagger & 1) || (wave & 1) == 0;
@@ -315,14 +301,9 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
         }
       }
     }
-#pragma unroll
-    for (int t = 0; t < TOUCH; ++t) asm volatile("" ::"v"(tdum[t][0]), "v"(tdum[t][1]), "v"(tdum[t][2]));
   } else {
-  int kq[R];               // (a small FIFO in registers: slot s holds the step whose first column is kq[s]; R is 2)
 #pragma unroll
-  for (int s = 0; s < R; ++s) kq[s] = 0;
-#pragma unroll
-  for (int s = 0; s < R; ++s)
+  for (int s = 1; s < R; ++s)
     if (s < nsteps) kq[s] = issue(s, s);
   int slot = 0;
   WTR(1);
@@ -387,14 +368,14 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
 
   }   // !WP
 
-  // ---- the 4 partial tiles meet in LDS; unit u = (row block, column block), wave w finishes units w, w + 4, ...
-  constexpr int UNITS = MBK * JN, TUN = LORA ? TG * MBK : 0, SMU = UNITS + TUN, UALL = UNITS + TUN + (LN ? 1 : 0),
-                UPW = (UNITS + NW - 1) / NW;
+  // ---- the 4 partial tiles meet in LDS; unit (row block mb, column block j); wave w finishes row block w (all JN column blocks): its adapter tile T_w never
+  // leaves the wave's registers and the row partials of ln_parts are finished inside the wave - two barriers and two LDS round trips less than the
+  // round-3 assignment (units w, w + 4, ... per wave)
+  constexpr int UNITS = MBK * JN, TUN = LORA ? TG * MBK : 0, SMU = UNITS + TUN, UALL = UNITS + TUN + (LN ? 1 : 0);
   WTR(8);
   __syncthreads();
   WTR(9);
   f32x4* red = (f32x4*)smem;                                  // [NW][UALL][64 lanes]
-  uint2* tsh = (uint2*)(smem + (size_t)NW * UALL * 1024);     // [TG][MBK][64 lanes]: bf16(s T_g) in the 16x16x16 B-operand layout
 #pragma unroll
   for (int j = 0; j < JN; ++j)
 #pragma unroll
@@ -412,82 +393,59 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
       if (g == 0) ((float2*)(red + (wave * UALL + SMU) * 64))[mb * 16 + r] = make_float2(a, b);   // one unit: [MBK * 16 rows] (sum x, sum x^2)
     }
   }
-  // LN: (mean, rstd) of row (mb, rr) from the four waves' partial sums, added in wave order
-  auto row_stats = [&](int mb, int rr, float& mean, float& rstd) {
+  const int ngrp = KG > 1 ? p.K / p.group_k : 1;            // groups in use (<= TG; the unused accumulators stay zero)
+  __syncthreads();
+  WTR(12);
+  const int mb = wave;                                       // this wave's row block; lane (r, g): row m, columns 16 j + 4 g .. + 3 of unit j
+  const int m = m0 + mb * 16 + r;
+  // LN: (mean, rstd) of row (mb, r) from the four waves' partial sums, added in wave order
+  float mean = 0.f, rstd = 1.f;
+  if constexpr (LN) {
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-      const float2 ps = ((const float2*)(red + (w * UALL + SMU) * 64))[mb * 16 + rr];
+      const float2 ps = ((const float2*)(red + (w * UALL + SMU) * 64))[mb * 16 + r];
       s1 += ps.x; s2 += ps.y;
     }
     const float inv = 1.f / (float)p.K;
     mean = s1 * inv;
     const float var = s2 * inv - mean * mean;
     rstd = rsqrtf((var > 0.f ? var : 0.f) + p.ln_eps);
-  };
-  // adapter operands of this wave's units, requested before the barrier
-  const int ngrp = KG > 1 ? p.K / p.group_k : 1;            // groups in use (<= TG; the unused accumulators stay zero)
-  uint2 bupf[UPW][TG];
+    if (p.ln_stats && tn == 0 && g == 0) *(float2*)(p.ln_stats + (int64_t)m * 2) = make_float2(mean, rstd);
+  }
+  // T_g = s * X_g Adown_g^T of this row block, summed over the waves and rounded to bf16: the accumulator layout D[rank][m] (lane: row m, ranks 4g..4g+3) IS the
+  // B-operand layout of the 16x16x16 MFMA, so the LoRA-up below takes it as it is
+  [[maybe_unused]] uint2 tb[TG];
   if constexpr (LORA) {
 #pragma unroll
-    for (int q = 0; q < UPW; ++q) {
-      const int u = wave + q * NW;
+    for (int tg = 0; tg < TG; ++tg) {
+      tb[tg] = make_uint2(0u, 0u);
+      if (tg < ngrp) {
+        f32x4 t = red[(UNITS + tg * MBK + mb) * 64 + lane];
 #pragma unroll
-      for (int tg = 0; tg < TG; ++tg) {
-        bupf[q][tg] = make_uint2(0u, 0u);
-        if (u < UNITS && tg < ngrp) bupf[q][tg] = *(const uint2*)(p.Bup + (int64_t)(n0 + 16 * (u % JN) + r) * p.ld_bup + 16 * tg + 4 * g);
+        for (int w = 1; w < NW; ++w) t += red[(w * UALL + UNITS + tg * MBK + mb) * 64 + lane];
+        if constexpr (LN) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) t[i] = rstd * (t[i] - mean * lnca[i]) + lnab[i];
+        }
+        tb[tg] = make_uint2(pack2bf(t[0] * p.lora_scale, t[1] * p.lora_scale), pack2bf(t[2] * p.lora_scale, t[3] * p.lora_scale));
+        if (p.T_out && tn == 0) *(uint2*)(p.T_out + (int64_t)m * p.ld_t + 16 * tg + 4 * g) = tb[tg];
       }
     }
-  }
-  __syncthreads();
-  if constexpr (LN) {
-    if (p.ln_stats && tn == 0 && threadIdx.x < XR) {
-      float mean, rstd;
-      row_stats(threadIdx.x >> 4, threadIdx.x & 15, mean, rstd);
-      *(float2*)(p.ln_stats + (int64_t)(m0 + threadIdx.x) * 2) = make_float2(mean, rstd);
-    }
-  }
-  if constexpr (LORA) {
-    // T_g = s * X_g Adown_g^T of every (group, row block): summed over the waves, rounded to bf16 - the accumulator layout D[r][m] (lane: m,
-    // rows 4g..4g+3) IS the B-operand layout of the 16x16x16 MFMA, so the LoRA-up below needs no data movement beyond this LDS word pair
-    for (int tu = wave; tu < ngrp * MBK; tu += NW) {
-      const int tg = tu / MBK, mb = tu - tg * MBK;
-      f32x4 t = red[(UNITS + tu) * 64 + lane];
-#pragma unroll
-      for (int w = 1; w < NW; ++w) t += red[(w * UALL + UNITS + tu) * 64 + lane];
-      if constexpr (LN) {
-        float mean, rstd;
-        row_stats(mb, r, mean, rstd);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) t[i] = rstd * (t[i] - mean * lnca[i]) + lnab[i];
-      }
-      const uint2 tb = make_uint2(pack2bf(t[0] * p.lora_scale, t[1] * p.lora_scale), pack2bf(t[2] * p.lora_scale, t[3] * p.lora_scale));
-      tsh[tu * 64 + lane] = tb;
-      if (p.T_out && tn == 0) *(uint2*)(p.T_out + (int64_t)(m0 + mb * 16 + r) * p.ld_t + 16 * tg + 4 * g) = tb;
-    }
-    __syncthreads();
   }
   WTR(10);
-  float2* psh = (float2*)(smem + (size_t)NW * UALL * 1024 + (size_t)TG * MBK * 64 * 8);     // [XR rows][JN units][4 lane groups] behind the reduction scratch
+  float ps4[JN], pm2[JN];     // ln_parts: (sum, centred sum of squares) of this lane's four columns of every unit
 #pragma unroll
-  for (int q = 0; q < UPW; ++q) {
-    const int u = wave + q * NW;
-    if (u >= UNITS) break;
-    const int mb = u / JN, j = u - mb * JN, n = n0 + 16 * j + 4 * g, m = m0 + mb * 16 + r;
-    f32x4 v = red[u * 64 + lane];
+  for (int q = 0; q < JN; ++q) {
+    f32x4 v = red[(mb * JN + q) * 64 + lane];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) v += red[(w * UALL + u) * 64 + lane];
-    if constexpr (LN) {
-      float mean, rstd;
-      row_stats(mb, r, mean, rstd);
-      v = (v - c1pre[q] * mean) * rstd;
-    }
+    for (int w = 1; w < NW; ++w) v += red[(w * UALL + mb * JN + q) * 64 + lane];
+    if constexpr (LN) v = (v - c1pre[q] * mean) * rstd;
     if constexpr (LORA) {
 #pragma unroll
       for (int tg = 0; tg < TG; ++tg) {
         if (tg >= ngrp) break;
-        const uint2 tb = tsh[(tg * MBK + mb) * 64 + lane];
-        v = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, bupf[q][tg]), __builtin_bit_cast(s16x4, tb), v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, bupf[q][tg]), __builtin_bit_cast(s16x4, tb[tg]), v, 0, 0, 0);
       }
     }
     if (p.bias) v += bpre[q];
@@ -496,27 +454,25 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
       v[0] += bf2f(rv.x & 0xffff); v[1] += bf2f(rv.x >> 16); v[2] += bf2f(rv.y & 0xffff); v[3] += bf2f(rv.y >> 16);
     }
     const uint2 ov = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-    *(uint2*)(p.Y + (int64_t)m * p.ldy + n) = ov;
-    if (p.ln_parts) {     // (wave-uniform) this unit's 16 columns of row (mb, r): the four lanes r + 16 g hold four each
-      const float y0 = bf2f(ov.x & 0xffff), y1 = bf2f(ov.x >> 16), y2 = bf2f(ov.y & 0xffff), y3 = bf2f(ov.y >> 16);
-      // (sum, CENTRED sum of squares) of this lane's four columns: the slots of a row are merged below around the tile's row mean (the update of Chan et al.), so
-      // the variance never comes out of a difference of two large numbers (rows whose mean dwarfs their spread)
-      const float s4 = y0 + y1 + y2 + y3, m4 = 0.25f * s4;
-      psh[((mb * 16 + r) * JN + j) * 4 + g] = make_float2(s4, (y0 - m4) * (y0 - m4) + (y1 - m4) * (y1 - m4) + (y2 - m4) * (y2 - m4) + (y3 - m4) * (y3 - m4));
-    }
+    *(uint2*)(p.Y + (int64_t)m * p.ldy + n0 + 16 * q + 4 * g) = ov;
+    // (sum, CENTRED sum of squares) of the four ROUNDED columns: the slots of a row are merged below around the tile's row mean (the update of Chan et al.), so
+    // the variance never comes out of a difference of two large numbers (rows whose mean dwarfs their spread)
+    const float y0 = bf2f(ov.x & 0xffff), y1 = bf2f(ov.x >> 16), y2 = bf2f(ov.y & 0xffff), y3 = bf2f(ov.y >> 16);
+    const float s4 = y0 + y1 + y2 + y3, m4 = 0.25f * s4;
+    ps4[q] = s4;
+    pm2[q] = (y0 - m4) * (y0 - m4) + (y1 - m4) * (y1 - m4) + (y2 - m4) * (y2 - m4) + (y3 - m4) * (y3 - m4);
   }
-  if (p.ln_parts) {
-    __syncthreads();
-    if (threadIdx.x < XR) {
-      float2 u[JN * 4];
-      float2 t = make_float2(0.f, 0.f);
+  if (p.ln_parts) {      // (wave-uniform) the row's 4 JN slots sit in the lanes r + 16 g of this wave: M2 = sum_slots M2_s + 4 (mean_s - mean)^2 around the tile's row mean
+    float sx = 0.f;
 #pragma unroll
-      for (int j = 0; j < JN * 4; ++j) { u[j] = psh[threadIdx.x * JN * 4 + j]; t.x += u[j].x; }
-      const float mt = t.x * (1.f / (16 * JN));            // the tile's row mean; M2 = sum_slots M2_s + 4 (mean_s - mean)^2
+    for (int q = 0; q < JN; ++q) sx += ps4[q];
+    sx = ln_sum_fk(sx);
+    const float mt = sx * (1.f / (16 * JN));
+    float m2 = 0.f;
 #pragma unroll
-      for (int j = 0; j < JN * 4; ++j) { const float d = u[j].x * 0.25f - mt; t.y += u[j].y + 4.f * d * d; }
-      p.ln_parts[(int64_t)(m0 + threadIdx.x) * ntn + tn] = t;
-    }
+    for (int q = 0; q < JN; ++q) { const float d = ps4[q] * 0.25f - mt; m2 += pm2[q] + 4.f * d * d; }
+    m2 = ln_sum_fk(m2);
+    if (g == 0) p.ln_parts[(int64_t)m * ntn + tn] = make_float2(sx, m2);
   }
   WTR(11);
 }
@@ -525,9 +481,8 @@ template <int MBK, int JN, int R, int KG, bool LN = false, bool WP = false>
 int launch_wsk(const wsk_params& p, hipStream_t s) {
   constexpr bool LORA = KG > 0;
   constexpr int SLOT = (16 * MBK + (WP ? 0 : 16 * JN) + (LORA ? 16 : 0)) * ROWB;
-  constexpr int RED = NW * (MBK * JN + KG * MBK + (LN ? 1 : 0)) * 1024 + KG * MBK * 64 * 8;
-  constexpr int REDP = RED + (LORA ? 0 : MBK * 64 * 8) + 16 * MBK * JN * 4 * 8;      // + the row-partial slots (ln_parts); tsh's offset is TG * MBK * 512 also without an adapter
-  constexpr int smem = NW * R * SLOT > REDP ? NW * R * SLOT : REDP;
+  constexpr int RED = NW * (MBK * JN + KG * MBK + (LN ? 1 : 0)) * 1024;           // the four partial tiles (+ adapter tiles, + row sums) of the reduction
+  constexpr int smem = NW * R * SLOT > RED ? NW * R * SLOT : RED;
   static_assert(smem <= 160 * 1024, "LDS budget");
   if (sdlt_raise_smem((const void*)wsk_kernel<MBK, JN, R, KG, LN, WP>, smem)) SDLT_FAIL(SDLT_ERR_LAUNCH, "sdlt_wsk_gemm: cannot raise the dynamic LDS limit to %d bytes", smem);
   const int tiles = (p.M / (16 * MBK)) * (p.N / (16 * JN));

@@ -11,6 +11,17 @@ from oracle import unet_ref as U
 from tests import test_real_topology_gpu as T
 from sd_lora_trainer_amd import unet as unet_mod
 
+ORDER = []          # (module, key) in the order the persistent buffers come into existence = execution order of the first pass
+_buf = unet_mod._Module.buf
+
+
+def _buf_logged(self, key, *shape, **kw):
+    if key not in self._b:
+        ORDER.append((self, key))
+    return _buf(self, key, *shape, **kw)
+
+
+unet_mod._Module.buf = _buf_logged
 version = sys.argv[1] if len(sys.argv) > 1 else "sdxl"
 h = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
@@ -42,14 +53,11 @@ def modules(root, seen, out, prefix):
 
 
 def snapshot():
-    mods = []
-    modules(ts, set(), mods, "step")
-    modules(unet, set([id(ts)]), mods, "unet")
     snap = {}
-    for name, m in mods:
-        for k, t in m._b.items():
-            if isinstance(t, torch.Tensor):
-                snap[f"{name}:{k}"] = t.clone()
+    for i, (m, k) in enumerate(ORDER):
+        t = m._b.get(k)
+        if isinstance(t, torch.Tensor):
+            snap[f"{i:05d} {m.name}:{k}"] = t.clone()
     snap["arena.grads"] = unet.arena.grads.clone()
     for i, r in enumerate(ts.ti.grad_rows):
         snap[f"ti.grad_rows[{i}]"] = r.clone()
@@ -67,7 +75,13 @@ torch.cuda.synchronize()
 bsn = snapshot()
 diff = [(k, float((a[k].float() - bsn[k].float()).abs().max()), float(a[k].float().abs().max())) for k in a if k in bsn and a[k].shape == bsn[k].shape and not torch.equal(a[k], bsn[k])]
 print(f"{len(a)} buffers compared, {len(diff)} differ between two eager passes from the same state")
-for k, d, m in diff[:60]:
+first = min(int(k.split()[0]) for k, _, _ in diff if k[0].isdigit()) if diff else -1
+print("first differing buffer in execution order:", first)
+for k in sorted(a):
+    if k[0].isdigit() and first - 25 <= int(k.split()[0]) <= first + 40:
+        same = k in bsn and a[k].shape == bsn[k].shape and torch.equal(a[k], bsn[k])
+        print(f"  {k:90s} {'same' if same else 'DIFFERS'}  {tuple(a[k].shape)} {a[k].dtype}")
+for k, d, m in diff[:400]:
     print(f"  {k:90s} max abs diff {d:.3e} (max abs {m:.3e})")
 # NaN-aware recount: torch.equal is False for NaN == NaN; list the buffers whose only 'difference' is NaN / uninitialised padding
 nan_only = [k for k, d, m in diff if d != d]
