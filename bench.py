@@ -360,6 +360,8 @@ def main():
     ap.add_argument("--no-library-gpu", action="store_true", help="skip the extra measurement of the torch restatement of the step on the GPU (library kernels)")
     ap.add_argument("--full-ft", action="store_true", help="full-UNet fine-tune (BASELINE configs[4], train_configs/full_finetuning_example.json: "
                     "SDXL 512 px, batch 4 per GPU, AdamW over every UNet parameter); data parallel when --gpus > 1: per-bucket reduce-scatter, sharded AdamW, all-gather (SDLT_DDP_ZERO1=0: all-reduce)")
+    ap.add_argument("--dry-collectives", action="store_true", help="--full-ft on ONE GPU: run the data-parallel exchange step (per-bucket graphs, in-place reduce-scatter / all-gather, "
+                    "async works) on a 1-rank RCCL group - the exact call sequence of --gpus N - and report every collective's bytes and the ring wire time it implies for 2 / 4 / 8 GPUs")
     ap.add_argument("--ddp-wire", default=None, choices=["fp32", "bf16"], help="--full-ft --gpus N: dtype of the matrix gradients on the xGMI wire "
                     "(TrainStep(ddp_wire_dtype=); default fp32 = exact)")
     ap.add_argument("--profile-json", default=None, help="step profile of THIS command (tools/step_profile.py over the rocprofv3 kernel trace + FETCH_SIZE / "
@@ -393,6 +395,11 @@ def main():
     rank, world, local_rank = parallel.init_distributed("nccl")
     torch.cuda.set_device(local_rank if world > 1 else 0)
     device = torch.device("cuda", local_rank if world > 1 else 0)
+    dry = bool(args.dry_collectives) and args.full_ft and world == 1
+    if dry and not torch.distributed.is_initialized():          # a 1-rank RCCL communicator: the collectives are real library calls on this GPU
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=device)
 
     import sd_lora_trainer_amd.step as S
     import sd_lora_trainer_amd.unet as M
@@ -445,7 +452,8 @@ def main():
                 del csd
             text = S.TextStack(rt, encs, pool_mode="argmax")
         ts = S.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, l1_penalty=0.0 if args.dora else 0.03, weight_decay=0.0 if args.dora else 0.004, text=text, n_tokens=n_tok,
-                         process_group=True if (full_ft and world > 1) else None, ddp_wire_dtype=args.ddp_wire if (full_ft and world > 1) else None)
+                         process_group=True if (full_ft and (world > 1 or dry)) else None, ddp_wire_dtype=args.ddp_wire if (full_ft and (world > 1 or dry)) else None,
+                         ddp_force=dry)
         rn = lambda *s: torch.randn(*s, generator=g, device=device)  # noqa: E731
         latent = rn(B, 4, h, h) * cfg["scaling_factor"]
         noise = rn(B, 4, h, h)
@@ -594,6 +602,29 @@ def main():
                                  "hbm_kernels: the HBM-bound kernel families - algorithmic bytes (topology.hbm_bytes) / their time in the profiled step, against 8 TB/s; "
                                  "families: the MFMA-bound kernel families of the same profiled step - algorithmic TFLOP (2 x fwd census) / their kernel time, against 2.5 PFLOP/s"},
         }
+        if dry:
+            # one more step with the collectives recorded: what crosses the wire per step and what a ring over xGMI needs for it.  Ring reduce-scatter / all-gather move
+            # (N - 1) / N of the buffer through each GPU's slowest link, an all-reduce twice that; one xGMI link of an MI355X carries ~153 GB/s per direction (the prompt's
+            # figure; 7 links per GPU, but a ring uses one neighbour link each way).  Lower bound of the exposed time: the collectives overlap the weight-gradient GEMMs.
+            ts.coll_log = []
+            ts.run(lr_at(total, total), 0.0)
+            torch.cuda.synchronize()
+            log, ts.coll_log = ts.coll_log, None
+            link = 153e9
+            by_op = {}
+            for op, _, n_in, _, n_out, dt, _ in log:
+                e = by_op.setdefault(op, {"calls": 0, "bytes": 0})
+                e["calls"] += 1
+                e["bytes"] += max(n_in, n_out) * (2 if dt == "bfloat16" else 4)
+            wire = {}
+            for n in (2, 4, 8):
+                tsec = sum(e["bytes"] * (n - 1) / n * (2 if op.startswith("all_reduce") else 1) / link for op, e in by_op.items())
+                wire[str(n)] = {"ring_ms": tsec * 1e3}
+            out["collectives"] = {"sequence": [f"{op} x{e['calls']}: {e['bytes'] / 1e9:.3f} GB" for op, e in by_op.items()], "calls_per_step": len(log),
+                                  "all_views_16B_aligned": all(e[6] for e in log), "ring_wire_time_per_step_ms_by_gpus": wire,
+                                  "note": "1-rank RCCL group (--dry-collectives): the call sequence, buffers and graph phases of --gpus N, executed; ring time = bytes x (N-1)/N "
+                                          "(x2 for all-reduce) / 153 GB/s per xGMI link - a lower bound that the overlap with the weight-gradient GEMMs hides or not"}
+            out["config"]["parallelism"] = (f"dry run of dp-N on one GPU: {len(log)} collectives per step on a 1-rank RCCL communicator (" + "; ".join(out["collectives"]["sequence"]) + ")")
         print(f"[bench] timed region done: {t_step * 1e3:.2f} ms/step; extras follow", file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline and not full_ft:
             # measured in a CHILD process with a wall-clock limit: nothing on the host side may keep the JSON line from being printed

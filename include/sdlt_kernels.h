@@ -66,7 +66,7 @@ typedef struct sdlt_gemm_params {
   int32_t lora_R;
   float lora_scale;
   float alpha;
-  const float* bias;                 /* fp32 [N] or NULL; N % 4 == 0 with a bias, a folded LayerNorm or a batch (four columns per lane are fetched at once) */
+  const float* bias;                 /* fp32 [N] or NULL */
   const void* rowbias; int64_t ld_rowbias; int32_t rows_per_batch;
   const void* R; int64_t ldr;
   void* C; int64_t ldc;
@@ -526,6 +526,19 @@ int sdlt_wsk_gemm(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_
  * LoRA-down) rows only, and the K walk no longer runs at the rate four waves can issue LDS-DMA pieces at.  Same arithmetic, same
  * summation order: results are bit-identical to the row-major call.  sdlt_wsk_pack_weight writes the copy (N % 80 == 0, K % 64 == 0, N K bf16). */
 int sdlt_wsk_pack_weight(const void* W, int64_t ldw, int32_t N, int32_t K, void* Wp, void* stream);
+
+/* 3 x 3 convolution (stride 1, padding 1) of the 32 x 32 level of the UNet on the wave-split-K kernel - the ResnetBlock2D conv1 / conv2 of the 1280-wide
+ * stages reached from main.py:329-336 and their input gradients - as an implicit GEMM:  Y[B H W, N] = im2col(X) . W^T + bias[n] + rowbias[b, n] + R[m, n],
+ * X the NHWC activation [B H W, Cin] (bf16, row stride ldx), W [N, 9 Cin] with k = tap Cin + ci, tap = 3 dy + dx (row-major, or sdlt_wsk_pack_weight's copy
+ * with ldw = 0 for frozen weights), flip = 1: taps mirrored (the input gradient: W = the [Cin, 9 Cout] backward operand).  B H W % 64 == 0, N % 640 == 0,
+ * Cin % 64 == 0; zero: a zero page of >= 128 bytes (the halo).  rowbias bf16 [B, N] or NULL: the per-image bias (time-embedding projection).  Adown [16, 9 Cin] /
+ * Bup [N, 16] / T_out [M, 16]: the rank-16 adapter of sdlt_wsk_gemm (peft LoRA on conv2: a 3 x 3 LoRA-down convolution and a 1 x 1 up-projection,
+ * trainer/optimizer.py:84-95).  One workgroup owns a whole 64 x 80 output tile and its four waves split K: no split-K partials travel through HBM (the tiled
+ * kernel wrote 23.6 MB of fp32 slabs for a 2.6 MB output here), and the nine taps of a pixel block re-read the same rows from L2. */
+int sdlt_wsk_conv(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t B, int32_t H, int32_t Wd, int32_t Cin, int32_t N, int32_t flip,
+                  const float* bias, const void* rowbias, int64_t ld_rowbias, const void* R, int64_t ldr, void* Y, int64_t ldy,
+                  const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup, float lora_scale, void* T_out, int64_t ld_t,
+                  const void* zero, void* stream);
 
 /* sdlt_wsk_gemm with the LayerNorm in front of the projection folded in (sdlt_gemm_params.ln_c1's contract; attn2.to_q of the 1280-wide blocks):
  * X raw rows, W = W o gamma, c2 = W beta + bias, Y = rstd (X W^T - mean c1) + c2 (+ adapter with Adown = A o gamma, ln_adapter = cA | abeta, + R);

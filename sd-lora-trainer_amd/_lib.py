@@ -186,6 +186,7 @@ SYMBOLS = {
     "sdlt_layernorm_bwd_slabs_pair": (i32, [C.POINTER(LnSlabsParams), C.POINTER(LnSlabsParams), vp]),
     "sdlt_wsk_gemm": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp, i64, vp, i64, vp, i64, vp, i64, f32, vp, i64, i32, vp]),
     "sdlt_wsk_pack_weight": (i32, [vp, i64, i32, i32, vp, vp]),
+    "sdlt_wsk_conv": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, vp, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, f32, vp, i64, vp, vp]),
     "sdlt_wsk_gemm_parts": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp, i64, vp, i64, vp, i64, vp, i64, f32, vp, i64, i32, vp, vp]),
     "sdlt_wsk_gemm_ln": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp, i64, vp, i64, vp, i64, vp, i64, f32, vp, i64, vp, vp, f32, vp, vp]),
     "sdlt_token_attention_ws_floats": (i64, [C.POINTER(TaParams)]),

@@ -325,18 +325,28 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
         bupf[j][a] = *(const s16x4*)((const bf16_t*)pBup + (size_t)nc * p.ld_bup + (j < nup_ ? j : 0) * 16 + fk * 4);
       }
   }
-  // bias / c1: four columns per lane; N % 4 == 0 whenever either is given (host-checked), columns beyond N read chunk 0 and are never stored
+  // bias / c1: four columns per lane.  N % 4 == 0 (every layer of the UNet and the text encoders): one 16-byte load per block, columns beyond N read chunk 0 and
+  // are never stored; any other N (wave-uniform branch): four clamped scalar loads
   f32x4 biasf[NI];
   {
     const float* bsrc = pBias ? pBias : (const float*)pW;         // (no bias: any readable N floats; the epilogue skips the addition)
+    if ((p.N & 3) == 0) {
 #pragma unroll
-    for (int a = 0; a < NI; ++a) {
-      const int n = n0 + wn * NI * 16 + a * 16 + fk * 4;
-      biasf[a] = *(const f32x4*)(bsrc + (n < p.N ? n : 0));
+      for (int a = 0; a < NI; ++a) {
+        const int n = n0 + wn * NI * 16 + a * 16 + fk * 4;
+        biasf[a] = *(const f32x4*)(bsrc + (n < p.N ? n : 0));
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < NI; ++a) {
+        const int n = n0 + wn * NI * 16 + a * 16 + fk * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) biasf[a][r] = bsrc[n + r < p.N ? n + r : p.N - 1];
+      }
     }
   }
   f32x4 c1f[LN ? NI : 1], lnca = (f32x4){0.f, 0.f, 0.f, 0.f}, lnab = lnca;
-  if constexpr (LN) {
+  if constexpr (LN) {          // (host-checked: N % 4 == 0 with a folded LayerNorm)
 #pragma unroll
     for (int a = 0; a < NI; ++a) {
       const int n = n0 + wn * NI * 16 + a * 16 + fk * 4;
@@ -1233,7 +1243,7 @@ extern "C" int sdlt_gemm_bf16(const sdlt_gemm_params* pp, void* stream) {
     SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_gemm_bf16: operand rows must be 16-byte aligned (ld %% 8)");
   if (((uintptr_t)p.X | (uintptr_t)p.W | (uintptr_t)p.X2 | (uintptr_t)p.W2 | (uintptr_t)p.Adown) & 15)
     SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_gemm_bf16: operand base pointers must be 16-byte aligned");
-  if ((p.bias || p.ln_c1 || p.batch) && (p.N & 3)) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: N=%d with a bias / folded LayerNorm / batch must be a multiple of 4 (the kernels fetch four columns per lane)", p.N);
+  if (p.ln_c1 && (p.N & 3)) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: N=%d with a folded LayerNorm must be a multiple of 4", p.N);
   if (p.mode == 1) {
     if (!p.zero) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: conv mode needs a zero page");
     if (p.Cin % BK || p.K != 9 * p.Cin) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_gemm_bf16: conv needs Cin%%64==0 and K==9*Cin (Cin=%d K=%d)", p.Cin, p.K);

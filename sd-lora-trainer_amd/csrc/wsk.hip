@@ -53,6 +53,12 @@ struct wsk_params {
   // of fragment (kk, j) holds W[n0 + 16 j + r][k0 + 32 kk + 8 g .. + 7], i.e. the MFMA A operand as it sits in registers.  A wave's K step is
   // ten contiguous 1 KB wave loads (16 B per lane, whole 128-byte lines) that never touch LDS.
   const bf16_t* Wp;
+  // implicit 3 x 3 convolution (CONV kernels; stride 1, padding 1): X is the NHWC activation [B Hc Wc, Cin], K = 9 Cin with k = tap Cin + ci (tap = 3 dy + dx), row m of the
+  // product reads pixel (y + dy - 1, x + dx - 1) of its image (flip: (y + 1 - dy, x + 1 - dx), the input gradient's flipped taps) or the zero page outside it;
+  // rowbias bf16 [B, N] (or NULL) is added per image (the resnets' time-embedding projection), rows_per_batch = Hc Wc
+  int Hc, Wc, Cin, flip;
+  const bf16_t* zero;
+  const bf16_t* rowbias; int64_t ld_rowbias;
 };
 
 // -DSDLT_WSK_TRACE (tools/wsk_trace.py): thread 0 of workgroup 0 stamps clock64() at the phase boundaries; sdlt_wsk_trace_read copies them out
@@ -69,10 +75,13 @@ __device__ long long g_wsk_tr[16];
 //     activation (and LoRA-down) rows only.  In wsk_kernel no wave shares an operand with another wave, so LDS is only a layout converter for W -
 //     and the K walk is bound by the rate four waves can issue LDS-DMA pieces at: taking the frozen operand's 56 % of the bytes out of
 //     that path, and its layout conversion to pack time, is what this variant is for.
-template <int MBK, int JN, int R, int KG = 0, bool LN = false, bool WP = false>
+// CONV: implicit-GEMM 3 x 3 convolution (wsk_params::Hc ...): the activation pieces are gathered per tap (per-lane addresses, zero page for the halo), everything else is
+//     the same walk.  Replaces the tiled kernel's split-K (fp32 slabs through HBM: 23.6 MB written for a 2.6 MB output) for the 32 x 32 level of the UNet.
+template <int MBK, int JN, int R, int KG = 0, bool LN = false, bool WP = false, bool CONV = false>
 __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   constexpr bool LORA = KG > 0;
   static_assert(!LN || KG <= 1, "the folded LayerNorm belongs to forward products (no K-grouped adapters)");
+  static_assert(!CONV || (!LN && KG <= 1), "convolutions: plain or with one rank-16 adapter");
   constexpr int XR = 16 * MBK, WR = 16 * JN, AOFF = XR + (WP ? 0 : WR), SROWS = AOFF + (LORA ? 16 : 0), SLOT = SROWS * ROWB,
                 PIECES = SROWS / 8 + (WP ? 2 * JN : 0);      // vector-memory operations of one K step of one wave (what the counted waits count)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -82,6 +91,7 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   asm volatile("" ::"s"(p.X), "s"(p.ldx), "s"(p.W), "s"(p.ldw), "s"(p.bias), "s"(p.R), "s"(p.ldr), "s"(p.Y), "s"(p.ldy), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.map2d));
   asm volatile("" ::"s"(p.Adown), "s"(p.ld_adown), "s"(p.Bup), "s"(p.ld_bup), "s"(p.T_out), "s"(p.ld_t), "s"(p.lora_scale), "s"(p.group_k), "s"(p.stagger));
   asm volatile("" ::"s"(p.ln_c1), "s"(p.ln_stats), "s"(p.ln_adapter), "s"(p.ln_eps), "s"(p.ln_parts), "s"(p.Wp));
+  if constexpr (CONV) asm volatile("" ::"s"(p.Hc), "s"(p.Wc), "s"(p.Cin), "s"(p.flip), "s"(p.zero), "s"(p.rowbias), "s"(p.ld_rowbias));
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int ntn = p.N / WR, ntm = p.M / XR;
@@ -106,7 +116,8 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   if (tm >= ntm || tn >= ntn) return;
   WTR(13);
   const int m0 = tm * XR, n0 = tn * WR;
-  const int nsteps = p.K >> 8;
+  // wave w walks the 64-column steps w, w + 4, ... of K: K / 256 each, or one more for the first waves when K / 64 is not a multiple of 4 (convolutions: Cin = 1920)
+  const int nsteps = ((p.K >> 6) - wave + NW - 1) >> 2;
 
   const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
 #ifdef SDLT_WSK_LAB      // bound experiments (tools/wsk_lab.sh; results are garbage): bit 1 of `stagger` = every workgroup reads row tile 0 of X, bit 2 = column tile 0 of W
@@ -117,6 +128,20 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   const bf16_t* xsrc = p.X + (int64_t)(m0x + srow) * p.ldx + schunk * 8;
   const bf16_t* wsrc = p.W + (int64_t)(tnw * WR + srow) * p.ldw + schunk * 8;
   const bf16_t* asrc = LORA ? p.Adown + (int64_t)srow * p.ld_adown + schunk * 8 : nullptr;
+  // CONV: the pixel of each of this lane's XR / 8 piece rows - linear index (= row of X) and (y, x) inside its image
+  [[maybe_unused]] int pm[XR / 8], pyx[XR / 8];
+  [[maybe_unused]] const bf16_t* zsrc = nullptr;
+  if constexpr (CONV) {
+    const int hw = p.Hc * p.Wc;
+#pragma unroll
+    for (int q = 0; q < XR / 8; ++q) {
+      const int m = m0x + q * 8 + srow;
+      const int rem = m - div_small(m, hw) * hw, y = div_small(rem, p.Wc);
+      pm[q] = m;
+      pyx[q] = (y << 16) | (rem - y * p.Wc);
+    }
+    zsrc = p.zero + schunk * 8;
+  }
   const int64_t x8 = 8 * p.ldx, w8 = 8 * p.ldw, a8 = 8 * p.ld_adown;
   char* ring = smem + wave * (R * SLOT);
   // column tile tn starts its K walk `rot` steps in (the 16 tiles of a row block do not ask the L2 for the same X lines at the same time).  The
@@ -127,14 +152,29 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   // (Round 5, measured and dropped: a rotation that also spreads the 8 workgroups of an XCD that walk the SAME weight panel over the K range - so that each is the
   // first to touch only 1 / 8 of it - makes the XCD's working set the whole of X / 2 + W / 4 at once instead of a window that slides along K: K = 10240 went from
   // 44 to 74 us.  The lockstep of the workgroups is what lets a 4 MB L2 serve a 17 MB operand set.)
-  const int rot = tn - div_small_u(tn, nsteps) * nsteps;
+  const int rotn = p.K >> 8;              // (the shortest walk among the waves)
+  const int rot = tn - div_small_u(tn, rotn) * rotn;
   auto issue = [&](int i, int slot) -> int {
     int ii = i + rot;
     ii = ii >= nsteps ? ii - nsteps : ii;
     const int k0 = (wave + NW * ii) * 64;
     char* dst = ring + slot * SLOT;
+    if constexpr (CONV) {
+      const int tap = div_small_u(k0, p.Cin), ci0 = k0 - tap * p.Cin;        // (wave-uniform; a 64-column step lies inside one tap: Cin % 64 == 0)
+      const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;                       // tap / 3 for tap < 9
+      const int oy = p.flip ? 1 - dy : dy - 1, ox = p.flip ? 1 - dx : dx - 1;
+      const int shift = oy * p.Wc + ox;
 #pragma unroll
-    for (int q = 0; q < XR / 8; ++q) glds16(xsrc + q * x8 + k0, dst + q * 1024);
+      for (int q = 0; q < XR / 8; ++q) {
+        const int yy = (pyx[q] >> 16) + oy, xx = (pyx[q] & 0xffff) + ox;
+        const bool ok = (unsigned)yy < (unsigned)p.Hc && (unsigned)xx < (unsigned)p.Wc;
+        const bf16_t* src = ok ? p.X + (int64_t)(pm[q] + shift) * p.ldx + ci0 + schunk * 8 : zsrc;
+        glds16(src, dst + q * 1024);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < XR / 8; ++q) glds16(xsrc + q * x8 + k0, dst + q * 1024);
+    }
     if constexpr (!WP) {
 #pragma unroll
       for (int q = 0; q < WR / 8; ++q) glds16(wsrc + q * w8 + k0, dst + XR * ROWB + q * 1024);
@@ -212,6 +252,13 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
     rpre[q] = *(const uint2*)(rsrc + 16 * q);
     bpre[q] = *(const f32x4*)(bsrc + 16 * q);
     if constexpr (LN) c1pre[q] = *(const f32x4*)(p.ln_c1 + n0 + 16 * q + 4 * g);
+  }
+  [[maybe_unused]] uint2 rbpre[JN];
+  if constexpr (CONV) {      // the image's row of the per-image bias (none: the residual's address again, skipped by the epilogue)
+    const int mrow = m0 + wave * 16 + r;
+    const bf16_t* rb = p.rowbias ? p.rowbias + (int64_t)div_small(mrow, p.Hc * p.Wc) * p.ld_rowbias + n0 + 4 * g : rsrc;
+#pragma unroll
+    for (int q = 0; q < JN; ++q) rbpre[q] = *(const uint2*)(rb + 16 * q);
   }
   if constexpr (LORA) {
     const int ngrp0 = KG > 1 ? p.K / p.group_k : 1;
@@ -449,6 +496,12 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
       }
     }
     if (p.bias) v += bpre[q];
+    if constexpr (CONV) {
+      if (p.rowbias) {
+        const uint2 rv = rbpre[q];
+        v[0] += bf2f(rv.x & 0xffff); v[1] += bf2f(rv.x >> 16); v[2] += bf2f(rv.y & 0xffff); v[3] += bf2f(rv.y >> 16);
+      }
+    }
     if (p.R) {
       const uint2 rv = rpre[q];
       v[0] += bf2f(rv.x & 0xffff); v[1] += bf2f(rv.x >> 16); v[2] += bf2f(rv.y & 0xffff); v[3] += bf2f(rv.y >> 16);
@@ -477,16 +530,16 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   WTR(11);
 }
 
-template <int MBK, int JN, int R, int KG, bool LN = false, bool WP = false>
+template <int MBK, int JN, int R, int KG, bool LN = false, bool WP = false, bool CONV = false>
 int launch_wsk(const wsk_params& p, hipStream_t s) {
   constexpr bool LORA = KG > 0;
   constexpr int SLOT = (16 * MBK + (WP ? 0 : 16 * JN) + (LORA ? 16 : 0)) * ROWB;
   constexpr int RED = NW * (MBK * JN + KG * MBK + (LN ? 1 : 0)) * 1024;           // the four partial tiles (+ adapter tiles, + row sums) of the reduction
   constexpr int smem = NW * R * SLOT > RED ? NW * R * SLOT : RED;
   static_assert(smem <= 160 * 1024, "LDS budget");
-  if (sdlt_raise_smem((const void*)wsk_kernel<MBK, JN, R, KG, LN, WP>, smem)) SDLT_FAIL(SDLT_ERR_LAUNCH, "sdlt_wsk_gemm: cannot raise the dynamic LDS limit to %d bytes", smem);
+  if (sdlt_raise_smem((const void*)wsk_kernel<MBK, JN, R, KG, LN, WP, CONV>, smem)) SDLT_FAIL(SDLT_ERR_LAUNCH, "sdlt_wsk_gemm: cannot raise the dynamic LDS limit to %d bytes", smem);
   const int tiles = (p.M / (16 * MBK)) * (p.N / (16 * JN));
-  hipLaunchKernelGGL((wsk_kernel<MBK, JN, R, KG, LN, WP>), dim3(tiles), dim3(64 * NW), smem, s, p);
+  hipLaunchKernelGGL((wsk_kernel<MBK, JN, R, KG, LN, WP, CONV>), dim3(tiles), dim3(64 * NW), smem, s, p);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }
@@ -539,7 +592,7 @@ static int wsk_gemm_impl(const void* X, int64_t ldx, const void* W, int64_t ldw,
   static const int stagger_env = getenv("SDLT_WSK_STAGGER") ? atoi(getenv("SDLT_WSK_STAGGER")) : 1;   // (read once: A/B switch)
   wsk_params p{(const bf16_t*)X, ldx, (const bf16_t*)W, ldw, bias, (const bf16_t*)R, ldr, (bf16_t*)Y, ldy, M, N, K, 1,
                (const bf16_t*)Adown, ld_adown, (const bf16_t*)Bup, ld_bup, (bf16_t*)T_out, ld_t, lora_scale, lora_group_k, stagger_env,
-               ln_c1, ln_stats, ln_adapter, ln_eps, (float2*)ln_parts, packed ? (const bf16_t*)W : nullptr};
+               ln_c1, ln_stats, ln_adapter, ln_eps, (float2*)ln_parts, packed ? (const bf16_t*)W : nullptr, 0, 0, 0, 0, nullptr, nullptr, 0};
   if (((uintptr_t)ln_parts) & 7) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_gemm: ln_parts must be 8-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   if (packed) {          // register ring of 3 stages (probed 2 / 3 / 4 in round 5: 3 wins on every shape; 4 runs out of registers with an adapter)
@@ -581,4 +634,27 @@ extern "C" int sdlt_wsk_gemm_ln(const void* X, int64_t ldx, const void* W, int64
   if (!ln_c1) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wsk_gemm_ln: c1 is required");
   return wsk_gemm_impl(X, ldx, W, ldw, M, N, K, c2, R, ldr, Y, ldy, Adown, ld_adown, Bup, ld_bup, lora_scale, T_out, ld_t, 0,
                        ln_c1, ln_stats, ln_eps, ln_adapter, nullptr, stream);
+}
+
+extern "C" int sdlt_wsk_conv(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t B, int32_t H, int32_t Wd, int32_t Cin, int32_t N, int32_t flip,
+                             const float* bias, const void* rowbias, int64_t ld_rowbias, const void* R, int64_t ldr, void* Y, int64_t ldy,
+                             const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup, float lora_scale, void* T_out, int64_t ld_t,
+                             const void* zero, void* stream) {
+  const int64_t M64 = (int64_t)B * H * Wd;
+  const int32_t M = (int32_t)M64, K = 9 * Cin;
+  if (B <= 0 || H <= 0 || Wd <= 0 || Cin <= 0 || N <= 0 || M64 >= (1ll << 22) || (M % 64) || (N % 80) || ((N / 80) % 8) || (Cin % 64) || K >= (1 << 22) || H >= 32768 || Wd >= 32768)
+    SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wsk_conv: B=%d H=%d W=%d Cin=%d N=%d (B H W %% 64, N %% 640, Cin %% 64 == 0)", B, H, Wd, Cin, N);
+  const bool packed = ldw == 0;
+  if (!X || !W || !Y || !zero || (ldx % 8) || (ldw % 8) || (ldy % 4) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15) || ((uintptr_t)Y & 7) || ((uintptr_t)zero & 15) ||
+      (R && ((ldr % 4) || ((uintptr_t)R & 7))) || (bias && ((uintptr_t)bias & 15)) || (rowbias && ((ld_rowbias % 4) || ((uintptr_t)rowbias & 7))))
+    SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_conv: operand alignment (zero: a >= 128-byte zero page)");
+  if (Adown && (!Bup || (ld_adown % 8) || ((uintptr_t)Adown & 15) || (ld_bup % 4) || ((uintptr_t)Bup & 7) || (T_out && ((ld_t % 4) || ((uintptr_t)T_out & 7)))))
+    SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_conv: adapter operands (Adown [16, 9 Cin] 16-byte rows, Bup [N, 16] / T_out [M, 16] 8-byte rows)");
+  static const int stagger_env = getenv("SDLT_WSK_STAGGER") ? atoi(getenv("SDLT_WSK_STAGGER")) : 1;
+  wsk_params p{(const bf16_t*)X, ldx, (const bf16_t*)W, ldw, bias, (const bf16_t*)R, ldr, (bf16_t*)Y, ldy, M, N, K, 1,
+               (const bf16_t*)Adown, ld_adown, (const bf16_t*)Bup, ld_bup, (bf16_t*)T_out, ld_t, lora_scale, 0, stagger_env,
+               nullptr, nullptr, nullptr, 0.f, nullptr, packed ? (const bf16_t*)W : nullptr, H, Wd, Cin, flip ? 1 : 0, (const bf16_t*)zero, (const bf16_t*)rowbias, ld_rowbias};
+  hipStream_t s = (hipStream_t)stream;
+  if (packed) return Adown ? launch_wsk<4, 5, 3, 1, false, true, true>(p, s) : launch_wsk<4, 5, 3, 0, false, true, true>(p, s);
+  return Adown ? launch_wsk<4, 5, 2, 1, false, false, true>(p, s) : launch_wsk<4, 5, 2, 0, false, false, true>(p, s);
 }

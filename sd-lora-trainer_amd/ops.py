@@ -180,6 +180,20 @@ def _wsk_operand(W):
     return _p(W), _ld(W)
 
 
+WSK_CONV = os.environ.get("SDLT_WSK_CONV", "1") != "0"
+
+
+def wsk_conv_shape(conv, N, lora_rank_pad=0):
+    """3 x 3 convolutions the wave-split-K kernel takes over from the tiled one (sdlt_wsk_conv): stride 1 at the resolution where 64 x 80 output tiles fill the
+    256 CUs at most once - the 32 x 32 level of SDXL at 1024 px (ResnetBlock2D conv1 / conv2 of the 1280-wide stages, forward and input gradient)."""
+    if not (WSK and WSK_CONV) or conv.stride != 1 or conv.ups != 1 or conv.tr or conv.Hin != conv.Hout or conv.Win != conv.Wout:
+        return False
+    M = conv.B * conv.Hout * conv.Wout
+    if M % 64 or N % 640 or conv.Cin % 64 or lora_rank_pad not in (0, 16):
+        return False
+    return 128 <= (M // 64) * (N // 80) <= 256
+
+
 def gemm_emits_parts(M, N, K, lora_rank_pad=0):
     """Number of row partials per row (0: none) a plain / rank-16-adapter product [M, K] x [N, K]^T (+ bias, residual) runs on the wave-split-K kernel and can therefore leave row
     partials for the next LayerNorm (gemm(..., ln_parts_out=)): the to_out.0 and ff.net.2 products of the 1280-wide blocks at batch 1."""
@@ -255,6 +269,34 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
                                      _p(T_), _ld(T_) if T_ is not None else 0, int(lora_group_k) if lora is not None else 0, _stream()), "sdlt_wsk_gemm")
         return out
     assert ln_parts_out is None, "ln_parts_out: this product does not run on the wave-split-K kernel (ops.gemm_emits_parts)"
+    if (conv is not None and X2 is None and alpha == 1.0 and Ct is None and batch is None and geglu_out is None and geglu_bwd is None and act_out is None
+            and dact_in is None and col_scale is None and not accumulate and tile == 0 and splitk == 0 and not lora_group_n and not lora_group_k and ln is None
+            and out is not None and out.dtype == BF16 and not THROUGHPUT_HINT and (lora is None or (lora[0].shape[0] == 16 and lora[1].shape[1] == 16))
+            and wsk_conv_shape(conv, W.shape[0], 16 if lora is not None else 0)):
+        # 3 x 3 convolution of the 32 x 32 level: one 64 x 80 tile per CU, K = 9 Cin split over the waves, no split-K partials through HBM (sdlt_wsk_conv)
+        _chk2(X), _chk2(W), _chk2(out)
+        M_, N_ = conv.B * conv.Hout * conv.Wout, W.shape[0]
+        assert W.shape[1] == 9 * conv.Cin and X.shape[1] == conv.Cin and X.shape[0] == M_ and tuple(out.shape) == (M_, N_)
+        A_ = B_ = T_ = None
+        scale_ = 0.0
+        if lora is not None:
+            A_, B_, scale_, T_ = lora
+            _chk2(A_), _chk2(B_)
+            assert tuple(A_.shape) == (16, 9 * conv.Cin) and tuple(B_.shape) == (N_, 16) and (T_ is None or tuple(T_.shape) == (M_, 16))
+        if bias is not None:
+            _chk2(bias, F32)
+        if rowbias is not None:
+            _chk2(rowbias)
+            assert rowbias.shape[1] == N_ and rows_per_batch == conv.Hout * conv.Wout and rowbias.shape[0] >= conv.B
+        if residual is not None:
+            _chk2(residual)
+            assert tuple(residual.shape) == (M_, N_)
+        Wptr, Wld = _wsk_operand(W)
+        _lib.check(lib.sdlt_wsk_conv(_p(X), _ld(X), Wptr, Wld, conv.B, conv.Hout, conv.Wout, conv.Cin, N_, int(conv.flip), _p(bias), _p(rowbias),
+                                     _ld(rowbias) if rowbias is not None else 0, _p(residual), _ld(residual) if residual is not None else 0, _p(out), _ld(out),
+                                     _p(A_), _ld(A_) if A_ is not None else 0, _p(B_), _ld(B_) if B_ is not None else 0, float(scale_), _p(T_),
+                                     _ld(T_) if T_ is not None else 0, _p(zero_page(X.device)), _stream()), "sdlt_wsk_conv")
+        return out
     p = _lib.GemmParams()
     _chk2(X), _chk2(W)
     p.X, p.ldx, p.W, p.ldw = _p(X), _ld(X), _p(W), _ld(W)

@@ -192,7 +192,7 @@ class TrainStep:
                  weight_decay=0.004, grad_accum=1, betas=(0.9, 0.999), eps=1e-8, text: TextStack = None, n_tokens=3,
                  token_attention_loss_w=3e-7, ti_weight_decay=0.0, ti_std_loss_w=0.01, optimizer="adamw", ti_optimizer="adamw",
                  prodigy_d_coef=1.0, prodigy_growth_rate=1.05, text_lora_weight_decay=1e-5, process_group=None,
-                 cond_reg_w=0.0, tok_cov_reg_w=0.0, cond_target_norm=None, tok_cond_reg_w=0.0, reg_caption_ids=None, ddp_wire_dtype=None, ddp_zero1=None):
+                 cond_reg_w=0.0, tok_cov_reg_w=0.0, cond_target_norm=None, tok_cond_reg_w=0.0, reg_caption_ids=None, ddp_wire_dtype=None, ddp_zero1=None, ddp_force=False):
         """process_group: data-parallel full fine-tune only (`unet.trainer` set) - a torch.distributed group (or True for the
         default one) over which the gradient arena is all-reduced once per optimiser step (RCCL on the GPU)."""
         if optimizer == "AdamW8bit":
@@ -210,14 +210,21 @@ class TrainStep:
         if self.full_ft:
             l1_penalty = 0.0       # main.py:353: the L1 term only exists over unet_lora_parameters
         self.pg, self.world = None, 1
+        # self.ddp: the data-parallel code path is live.  ddp_force (or SDLT_DDP_FORCE=1): also with ONE rank - the exact call sequence of the exchange step (per-bucket
+        # graphs, in-place reduce-scatter / all-gather on slices of the arenas, asynchronous works joined around the graphs) on a 1-rank group, so that the first
+        # multi-GPU run of `bench.py --full-ft --gpus N` is a measurement, not the first execution of the path (bench.py --dry-collectives).
+        self.ddp = False
+        self.coll_log = None       # a list: every collective of a step is recorded as (op, input offset, input numel, output offset, output numel, dtype)
         if process_group is not None:
             import torch.distributed as dist
             assert self.full_ft, "LoRA / TI jobs are independent per GPU (no collective); only the full fine-tune is data parallel"
             self.pg = None if process_group is True else process_group
             self.world = dist.get_world_size(self.pg)
+            import os as _os0
+            self.ddp = self.world > 1 or bool(ddp_force) or _os0.environ.get("SDLT_DDP_FORCE", "0") == "1"
             # bucketed, overlapped gradient exchange: the weight gradients are produced bucket by bucket at the end of the
             # backward (fullft.WeightTrainer.flush(bucket=i)), each bucket's all-reduce starts as soon as its gradients exist
-            self.bucketed = self.world > 1 and grad_accum == 1
+            self.bucketed = self.ddp and grad_accum == 1
             unet.trainer.defer_flush = self.bucketed
             # ddp_wire_dtype "bf16" (or SDLT_DDP_WIRE=bf16): the matrix gradients cross xGMI as bf16 - half the wire bytes (per GPU 2 (N-1)/N x 5.1
             # instead of 10.3 GB for SDXL) for two more HBM passes per bucket (pack after its weight-gradient GEMMs, unpack after its
@@ -490,13 +497,22 @@ class TrainStep:
     def sync_gradients(self):
         """Data-parallel full fine-tune, unbucketed form (gradient accumulation): ONE all-reduce (sum) of the flat fp32 gradient
         arena per optimiser step.  RCCL over xGMI on the GPU (backend "nccl"), gloo in the CPU tests."""
-        if self.world > 1 and not getattr(self, "bucketed", False):
+        if self.ddp and not getattr(self, "bucketed", False):
             import torch.distributed as dist
+            self._log("all_reduce", self.group.grads, self.group.grads, self.group.grads)
             dist.all_reduce(self.group.grads, group=self.pg)
             if self.ti is not None:
                 dist.all_reduce(self.ti.grads, group=self.pg)
             if self.te_arena is not None:
                 dist.all_reduce(self.te_arena.grads, group=self.pg)
+
+    def _log(self, op, base, inp, out):
+        """Record a collective for the call-sequence checks (tests/test_parallel_cpu.py, bench.py --dry-collectives): element offsets of the input / output views inside
+        `base` (the arena they are slices of), their sizes and dtype."""
+        if self.coll_log is not None:
+            es = base.element_size()
+            self.coll_log.append((op, (inp.data_ptr() - base.data_ptr()) // es, inp.numel(), (out.data_ptr() - base.data_ptr()) // es, out.numel(), str(inp.dtype).replace("torch.", ""),
+                                  inp.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0))
 
     def flush_and_reduce(self, flush_fns=None):
         """Data-parallel full fine-tune, the exchange step of the path: the deferred weight-gradient plan runs bucket
@@ -508,8 +524,10 @@ class TrainStep:
         tr = self.group
         works = []
         if self.ti is not None:      # token-row gradients (a few KB): complete after the backward graph, exchanged beside the first bucket
+            self._log("all_reduce:ti", self.ti.grads, self.ti.grads, self.ti.grads)
             works.append((dist.all_reduce(self.ti.grads, group=self.pg, async_op=True), None, None))
         if self.te_arena is not None:    # text-encoder adapter gradients (a few MB), complete after the backward graph as well
+            self._log("all_reduce:te", self.te_arena.grads, self.te_arena.grads, self.te_arena.grads)
             works.append((dist.all_reduce(self.te_arena.grads, group=self.pg, async_op=True), None, None))
         wire = getattr(self, "wire", None)
         zero1 = getattr(self, "zero1", False)
@@ -521,16 +539,21 @@ class TrainStep:
                 s0, s1 = tr.shard_range(b)
                 if wire is not None:
                     wire[o0:o1].copy_(tr.grads[o0:o1])       # pack: fp32 -> bf16; only the owned slice is unpacked afterwards
+                    self._log("reduce_scatter", wire, wire[o0:o1], wire[s0:s1])
                     works.append((dist.reduce_scatter_tensor(wire[s0:s1], wire[o0:o1], group=self.pg, async_op=True), s0, s1))
                 else:
+                    self._log("reduce_scatter", tr.grads, tr.grads[o0:o1], tr.grads[s0:s1])
                     works.append((dist.reduce_scatter_tensor(tr.grads[s0:s1], tr.grads[o0:o1], group=self.pg, async_op=True), None, None))
             elif wire is not None:
                 o1w = min(o1, tr.n_mat)
                 wire[o0:o1w].copy_(tr.grads[o0:o1w])           # pack: fp32 -> bf16, queued behind the bucket's GEMMs
+                self._log("all_reduce", wire, wire[o0:o1w], wire[o0:o1w])
                 works.append((dist.all_reduce(wire[o0:o1w], group=self.pg, async_op=True), o0, o1w))
             else:
+                self._log("all_reduce", tr.grads, tr.grads[o0:o1], tr.grads[o0:o1])
                 works.append((dist.all_reduce(tr.grads[o0:o1], group=self.pg, async_op=True), None, None))
         if tr.n > tr.n_mat:
+            self._log("all_reduce:vec", tr.grads, tr.grads[tr.n_mat:], tr.grads[tr.n_mat:])
             works.append((dist.all_reduce(tr.grads[tr.n_mat:], group=self.pg, async_op=True), None, None))
         for w, o0, o1w in works:
             w.wait()
@@ -545,6 +568,7 @@ class TrainStep:
         works = []
         for b, (o0, o1) in enumerate(tr.buckets):
             s0, s1 = tr.shard_range(b)
+            self._log("all_gather", tr.params, tr.params[s0:s1], tr.params[o0:o1])
             works.append(dist.all_gather_into_tensor(tr.params[o0:o1], tr.params[s0:s1], group=self.pg, async_op=True))
         for w in works:
             w.wait()
@@ -605,11 +629,11 @@ class TrainStep:
         self.optimizer_step()
 
     def _phases(self):
-        if self.world > 1 and self.bucketed:   # forward+backward | per bucket: weight gradients, exchange (outside the graphs) | optimizer
+        if self.ddp and self.bucketed:   # forward+backward | per bucket: weight gradients, exchange (outside the graphs) | optimizer
             tr = self.group
             opt = [self._opt_shard_phase, self._opt_post_phase] if getattr(self, "zero1", False) else [self.optimizer_step]     # (the all-gather sits between the two)
             return [self.forward_backward] + [(lambda b=b: tr.flush(bucket=b)) for b in range(len(tr.buckets))] + opt
-        if self.world > 1:         # the collective stays outside the graphs: forward+backward | all-reduce | optimizer
+        if self.ddp:         # the collective stays outside the graphs: forward+backward | all-reduce | optimizer
             return [lambda: (self.forward_backward(), self._accumulate(True)), self.optimizer_step]
         if self._acc is not None:
             return [self.body]
@@ -690,7 +714,7 @@ class TrainStep:
         the bucket is scratch), so the squared norm is taken over the owned slices + the replicated vector region once (rank 0) and the
         scalar is summed over the ranks."""
         a = self.group
-        if self.world == 1:
+        if not self.ddp:
             return float(a.grads.norm())
         if getattr(self, "zero1", False):
             import torch.distributed as dist
@@ -758,7 +782,7 @@ class TrainStep:
                     fn()
             return g
         phases = self._phases()
-        split = (self.text is not None and self.text.concurrent) or self.world > 1      # one graph per phase when the encoders fork / DDP
+        split = (self.text is not None and self.text.concurrent) or self.ddp      # one graph per phase when the encoders fork / DDP
 
         def cap_set(pool):
             graphs = []
@@ -768,7 +792,7 @@ class TrainStep:
             frozen = None
             # variant for ti lr == 0: same first phases, LoRA-only last phase.  Not under data parallelism: _run never takes the frozen branch there
             # (the exchange step lives in the per-bucket graphs), and with ZeRO-1 the full-arena AdamW those graphs would record has no moments
-            if self.text is not None and self.te_arena is None and self.world == 1:
+            if self.text is not None and self.te_arena is None and not self.ddp:
                 if split:
                     frozen = graphs[:2] + [cap([self._phase_opt_frozen_ti], pool)]
                 else:
@@ -814,19 +838,19 @@ class TrainStep:
         # frozen-TI fast path (Prodigy with lr 0 is a no-op as well: sdlt_prodigy_step); never with text-encoder LoRA, whose
         # gradients need the text backward for the whole run
         # (not under data parallelism: the exchange step lives in body() / the per-bucket graphs, and the eager frozen branch below would skip it)
-        frozen = self.text is not None and lr_ti == 0.0 and self.te_arena is None and self._acc is None and self.world == 1
+        frozen = self.text is not None and lr_ti == 0.0 and self.te_arena is None and self._acc is None and not self.ddp
         self._frozen_last = frozen
-        if self.graph is not None and self.world > 1 and self.bucketed and getattr(self, "zero1", False):
+        if self.graph is not None and self.ddp and self.bucketed and getattr(self, "zero1", False):
             self.graphs[0].replay()
             self.flush_and_reduce([g.replay for g in self.graphs[1:-2]])
             self.graphs[-2].replay()
             self.gather_params()
             self.graphs[-1].replay()
-        elif self.graph is not None and self.world > 1 and self.bucketed:
+        elif self.graph is not None and self.ddp and self.bucketed:
             self.graphs[0].replay()
             self.flush_and_reduce([g.replay for g in self.graphs[1:-1]])
             self.graphs[-1].replay()
-        elif self.graph is not None and self.world > 1:
+        elif self.graph is not None and self.ddp:
             self.graphs[0].replay()
             self.sync_gradients()
             self.graphs[1].replay()

@@ -623,6 +623,7 @@ class Conv3x3(_Module):
             assert self.Cin_p == self.Cin and need_dx
             self.Wb_d = torch.empty_like(self.Wb)
             arena.dora_wts.append(dict(src=self.Wb, dst=self.Wb_d, entries=[self.lora], period=self.Cout_p, nvalid=self.Cout))
+        _mark_frozen(rt, self.Wf, self.Wb)      # (DoRA's dX operand is Wb_d, rewritten every step: never marked)
         tr = rt.trainer if (rt.trainer is not None and rt.trainer.registering) else None
         self.trainer = tr
         if tr is not None:         # master weight tap-major [Cout, (ky, kx, ci)], like the forward GEMM operand

@@ -425,6 +425,63 @@ def test_conv3x3_fused_lora_and_strided_input(ops):
     close(out, ref, what="conv lora out")
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,flip,lora,extras", [(1, 32, 32, 128, 1280, 0, False, True), (1, 32, 32, 192, 1280, 1, False, True), (4, 16, 16, 128, 1280, 0, True, True),
+                                                              (2, 16, 32, 64, 640, 1, False, False), (1, 32, 32, 320, 1280, 0, True, False), (1, 32, 32, 1280, 1280, 0, False, True)])
+def test_wsk_conv(ops, B, H, W, Cin, Cout, flip, lora, extras):
+    """sdlt_wsk_conv - the 3 x 3 convolutions of the 32 x 32 level on the wave-split-K kernel (K = 9 Cin split over the waves of ONE workgroup per output tile, no
+    split-K partials through HBM) - against the emulation of the tiled kernel's contract (bias, per-image row bias, residual, fused rank-16 adapter with T_out) and
+    against the tiled kernel itself; Cin = 192 / 320 give the waves UNEVEN step counts (K / 64 not a multiple of 4), flip = the input gradient's mirrored taps, several
+    images per batch, a non-square map; the packed (frozen) weight gives the same bits as the row-major one, and ops.gemm routes these shapes here."""
+    g = torch.Generator().manual_seed(B + H + Cin + flip)
+    M, K = B * H * W, 9 * Cin
+    X = rnd(M, Cin, g=g)
+    Wm = rnd(Cout, K, g=g, scale=1 / math.sqrt(K))
+    bias = torch.randn(Cout, generator=g) if extras else None
+    R = rnd(M, Cout, g=g) if extras else None
+    rowb = rnd(B, Cout, g=g) if extras else None
+    A = Bu = None
+    kw = {}
+    Tref = torch.empty(M, 16, dtype=BF)
+    if lora:
+        A, Bu = rnd(16, K, g=g, scale=0.05), rnd(Cout, 16, g=g, scale=0.3)
+        kw = dict(lora=(A, Bu, 0.75, Tref))
+    ref = E.gemm(X, Wm, torch.empty(M, Cout, dtype=BF), conv=E.ConvGeom(B, H, W, Cin, H, W, flip=flip), bias=bias, residual=R, rowbias=rowb, rows_per_batch=H * W, **kw)
+    Xd, Wd, bd, Rd, rbd, Ad, Bd = dev(X, Wm, bias, R, rowb, A, Bu)
+    lib = ops._lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    zero = ops.zero_page(Xd.device)
+    wp = torch.empty(Cout * K, dtype=BF, device="cuda")
+    ops._lib.check(lib.sdlt_wsk_pack_weight(Wd.data_ptr(), K, Cout, K, wp.data_ptr(), st), "sdlt_wsk_pack_weight")
+    P = lambda t: t.data_ptr() if t is not None else None      # noqa: E731
+
+    def run(wptr, ldw):
+        y, T = torch.full((M, Cout), 7.0, dtype=BF, device="cuda"), torch.full((M, 16), 7.0, dtype=BF, device="cuda")
+        rc = lib.sdlt_wsk_conv(Xd.data_ptr(), Cin, wptr, ldw, B, H, W, Cin, Cout, flip, P(bd), P(rbd), Cout if extras else 0, P(Rd), Cout if extras else 0, y.data_ptr(), Cout,
+                               P(Ad), K if lora else 0, P(Bd), 16 if lora else 0, 0.75 if lora else 0.0, T.data_ptr() if lora else None, 16 if lora else 0, zero.data_ptr(), st)
+        assert rc == 0, lib.sdlt_last_error()
+        torch.cuda.synchronize()
+        return y, T
+    y, T = run(Wd.data_ptr(), K)
+    close(y, ref, what="wsk conv")
+    if lora:
+        close(T, Tref, what="wsk conv T_out")
+    yp, Tp = run(wp.data_ptr(), 0)
+    assert torch.equal(yp, y) and torch.equal(Tp, T), "packed weight: different bits"
+    assert torch.equal(run(wp.data_ptr(), 0)[0], yp)
+    # the tiled kernel (an explicit tile keeps it there) and ops.gemm's routing
+    geom = ops.ConvGeom(B, H, W, Cin, H, W, flip=flip)
+    kwd = dict(bias=bd, residual=Rd, rowbias=rbd, rows_per_batch=H * W)
+    y2, T2 = torch.empty(M, Cout, dtype=BF, device="cuda"), torch.empty(M, 16, dtype=BF, device="cuda")
+    ops.gemm(Xd, Wd, y2, conv=geom, tile=2, **kwd, **(dict(lora=(Ad, Bd, 0.75, T2)) if lora else {}))
+    close(y, y2, tol=1e-2, what="wsk conv vs tiled kernel")
+    if ops.wsk_conv_shape(geom, Cout, 16 if lora else 0):
+        ops.wsk_mark_frozen(Wd)
+        y3, T3 = torch.empty(M, Cout, dtype=BF, device="cuda"), torch.empty(M, 16, dtype=BF, device="cuda")
+        ops.gemm(Xd, Wd, y3, conv=geom, **kwd, **(dict(lora=(Ad, Bd, 0.75, T3)) if lora else {}))
+        assert torch.equal(y3, y) and (not lora or torch.equal(T3, T)), "ops.gemm did not take the wave-split-K route for this convolution"
+        assert Wd.data_ptr() in ops._WSK_PACKED
+
+
 # --------------------------------------------------------------------------------------------- LoRA grads
 def test_lora_grad_grouped(ops):
     g = torch.Generator().manual_seed(21)

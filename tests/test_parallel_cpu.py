@@ -93,13 +93,14 @@ def _ddp_worker(rank, world, port, out, wire="fp32", zero1=True, optimizer="adam
     assert ts.bucketed and len(tr.buckets) >= 4 and tr.buckets[0][0] == 0 and tr.buckets[-1][1] == tr.n_mat
     assert all(a[1] == b[0] for a, b in zip(tr.buckets, tr.buckets[1:]))          # contiguous cover of the matrix region
     s = slice(rank, rank + 1)
-    for _ in range(2):
+    for it in range(2):
         ts.set_batch(latent[s], noise[s], t[s], mask[s], ctx[s])
+        ts.coll_log = [] if it == 1 else None       # the second step's collectives, in call order
         ts.run(1e-3)
     own = [tr.shard_range(b) for b in range(len(tr.buckets))] if zero1 else None
     gn = ts.grad_norm()                 # (a collective under ZeRO-1: every rank calls it)
     extra = dict(state=ts.prodigy.state.numpy().copy(), s=ts.prodigy.s.numpy().copy()) if ts.prodigy is not None else None
-    out.put((rank, tr.params.numpy().copy(), float(ts.loss), tr.grads.numpy().copy(), own, tr.n_mat, extra, gn))      # numpy: pickled through the pipe (a shared-memory tensor dies with the worker)
+    out.put((rank, tr.params.numpy().copy(), float(ts.loss), tr.grads.numpy().copy(), own, tr.n_mat, extra, gn, (ts.coll_log, list(tr.buckets), tr.n)))      # numpy: pickled through the pipe (a shared-memory tensor dies with the worker)
     torch.distributed.destroy_process_group()
 
 
@@ -315,3 +316,89 @@ def test_bench_gpus_flag_spawns_ranks():
                            capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
         assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def _check_collective_sequence(log, buckets, n, n_mat, rank, world, zero1, wire):
+    """The exchange step as RCCL will see it (step.TrainStep.flush_and_reduce / gather_params): per bucket, in flush order, one in-place reduce-scatter whose output is
+    THIS rank's slice of its input (output = input + rank * count: the form NCCL / RCCL runs without a staging copy) - or one all-reduce -, then the replicated
+    vector region, then (ZeRO-1) one in-place all-gather per bucket whose input is this rank's slice of the output; every view 16-byte aligned."""
+    dt = "bfloat16" if wire == "bf16" else "float32"
+    ops = [e[0] for e in log]
+    nb = len(buckets)
+    if zero1:
+        assert ops == ["reduce_scatter"] * nb + ["all_reduce:vec"] + ["all_gather"] * nb, ops
+    else:
+        assert ops == ["all_reduce"] * nb + ["all_reduce:vec"], ops
+    for b, (o0, o1) in enumerate(buckets):
+        op, i_off, i_n, o_off, o_n, dtype, aligned = log[b]
+        assert aligned and dtype == dt and i_off == o0, (log[b], buckets[b])
+        if zero1:
+            cnt = (o1 - o0) // world
+            assert i_n == o1 - o0 and cnt * world == i_n and o_n == cnt and o_off == i_off + rank * cnt, (log[b], buckets[b], rank)
+            ag = log[nb + 1 + b]
+            assert ag[0] == "all_gather" and ag[5] == "float32" and ag[6] and ag[3] == o0 and ag[4] == o1 - o0 and ag[2] == cnt and ag[1] == o0 + rank * cnt, (ag, buckets[b])
+        else:
+            assert i_n == o_n and o_off == i_off and i_n == min(o1, n_mat) - o0
+    vec = log[nb]
+    assert vec[1] == n_mat and vec[2] == n - n_mat and vec[5] == "float32"
+    assert buckets[0][0] == 0 and buckets[-1][1] == n_mat and all(a[1] == b_[0] for a, b_ in zip(buckets, buckets[1:]))
+
+
+@pytest.mark.parametrize("wire,zero1", [("fp32", True), ("bf16", True), ("fp32", False)])
+def test_ddp_collective_call_sequence_two_ranks_gloo(wire, zero1):
+    """What the first RCCL run of `bench.py --full-ft --gpus N` will execute, asserted on two gloo ranks: call order, slice arithmetic and alignment of every collective
+    of one optimizer step (make the first multi-GPU run a measurement, not a debugging session)."""
+    res = _run_ddp(wire, zero1)
+    for r in range(2):
+        log, buckets, n = res[r][8]
+        _check_collective_sequence(log, buckets, n, res[r][5], r, 2, zero1, wire)
+    assert [e[:6] for e in res[0][8][0] if not e[0].startswith("reduce_scatter") and not e[0].startswith("all_gather")] == \
+           [e[:6] for e in res[1][8][0] if not e[0].startswith("reduce_scatter") and not e[0].startswith("all_gather")]      # rank-independent collectives are issued identically
+
+
+def _forced_worker(port, out):
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    import torch.distributed as dist
+    from oracle import unet_ref as U
+    from sd_lora_trainer_amd import fullft, topology
+    from sd_lora_trainer_amd import step as step_mod
+    from sd_lora_trainer_amd import unet as unet_mod
+    from tests import emu_ops
+    from tests.test_fullft_cpu import _inputs
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    cfg, h = U.CONFIGS["tiny15"], 16
+    sd = U.init_unet_state(cfg, seed=0)
+    latent, noise, mask, t, ctx, _, _, _ = _inputs(cfg, 1, h)
+
+    def build(ddp):
+        rt = unet_mod.Runtime("cpu", 1, act_dtype=torch.float32, ops=emu_ops)
+        tr = fullft.WeightTrainer(rt)
+        tr.bucket_floats = 150_000
+        unet = unet_mod.UNet(rt, topology.CONFIGS["tiny15"], {k: v.clone() for k, v in sd.items()}, trainer=tr)      # (a CPU runtime aliases the tensors it is given)
+        ts = step_mod.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=0.0, **(dict(process_group=True, ddp_force=True) if ddp else {}))
+        return ts, tr
+    ts, tr = build(True)
+    assert ts.ddp and ts.bucketed and ts.zero1 and ts.world == 1
+    ts1, tr1 = build(False)
+    for it in range(2):
+        for x in (ts, ts1):
+            x.set_batch(latent, noise, t, mask, ctx)
+            x.coll_log = [] if (it == 1 and x is ts) else None
+            x.run(1e-3)
+    _check_collective_sequence(ts.coll_log, list(tr.buckets), tr.n, tr.n_mat, 0, 1, True, "fp32")
+    out.put((torch.equal(tr.params, tr1.params), float(ts.loss), float(ts1.loss), len(ts.coll_log)))
+    dist.destroy_process_group()
+
+
+def test_ddp_forced_on_one_rank_runs_the_exchange_step_and_changes_nothing():
+    """ddp_force (bench.py --dry-collectives): the data-parallel exchange step on a ONE-rank group - same call sequence as with N ranks (checked), and the training
+    result is bit-identical to the plain single-process step (a 1-rank reduce-scatter / all-gather is the identity; AdamW on '1 / 1 of every bucket' is AdamW)."""
+    ctx_mp = mp.get_context("spawn")
+    q = ctx_mp.Queue()
+    p = ctx_mp.Process(target=_forced_worker, args=(_free_port(), q))
+    p.start()
+    same, l_ddp, l_one, ncoll = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert same and l_ddp == l_one and ncoll >= 9, (same, l_ddp, l_one, ncoll)
