@@ -618,12 +618,14 @@ def main():
                 e["bytes"] += max(n_in, n_out) * (2 if dt == "bfloat16" else 4)
             wire = {}
             for n in (2, 4, 8):
-                tsec = sum(e["bytes"] * (n - 1) / n * (2 if op.startswith("all_reduce") else 1) / link for op, e in by_op.items())
-                wire[str(n)] = {"ring_ms": tsec * 1e3}
+                vol = sum(e["bytes"] * (n - 1) / n * (2 if op.startswith("all_reduce") else 1) for op, e in by_op.items())      # bytes every GPU sends (and receives) per step
+                # one ring = one neighbour link; the node is fully connected (a link to each of the other N - 1 GPUs), so a direct exchange spreads the same volume over N - 1 links
+                wire[str(n)] = {"sent_GB_per_gpu": vol / 1e9, "one_ring_ms": vol / link * 1e3, "all_links_direct_ms": vol / (link * (n - 1)) * 1e3}
             out["collectives"] = {"sequence": [f"{op} x{e['calls']}: {e['bytes'] / 1e9:.3f} GB" for op, e in by_op.items()], "calls_per_step": len(log),
-                                  "all_views_16B_aligned": all(e[6] for e in log), "ring_wire_time_per_step_ms_by_gpus": wire,
-                                  "note": "1-rank RCCL group (--dry-collectives): the call sequence, buffers and graph phases of --gpus N, executed; ring time = bytes x (N-1)/N "
-                                          "(x2 for all-reduce) / 153 GB/s per xGMI link - a lower bound that the overlap with the weight-gradient GEMMs hides or not"}
+                                  "all_views_16B_aligned": all(e[6] for e in log), "wire_time_per_step_by_gpus": wire,
+                                  "note": "1-rank RCCL group (--dry-collectives): the call sequence, buffers and graph phases of --gpus N, executed; wire time = bytes x (N-1)/N "
+                                          "(x2 for all-reduce) / 153 GB/s per xGMI link, over one link (a single ring) and over all N-1 links of the fully connected node - bounds "
+                                          "that the overlap with the weight-gradient GEMMs hides or not"}
             out["config"]["parallelism"] = (f"dry run of dp-N on one GPU: {len(log)} collectives per step on a 1-rank RCCL communicator (" + "; ".join(out["collectives"]["sequence"]) + ")")
         print(f"[bench] timed region done: {t_step * 1e3:.2f} ms/step; extras follow", file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline and not full_ft:

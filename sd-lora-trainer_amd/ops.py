@@ -191,7 +191,8 @@ def wsk_conv_shape(conv, N, lora_rank_pad=0):
     M = conv.B * conv.Hout * conv.Wout
     if M % 64 or N % 640 or conv.Cin % 64 or lora_rank_pad not in (0, 16):
         return False
-    return 128 <= (M // 64) * (N // 80) <= 256
+    # (probed, tools/wsk_conv_probe.py: 256 tiles - 1280 -> 1280 62 -> 52 us, 640 -> 1280 38.5 -> 28, 2560 -> 1280 93 -> 91; the 128 tiles of a 640-wide output LOSE, 42 -> 47 us)
+    return 200 <= (M // 64) * (N // 80) <= 256
 
 
 def gemm_emits_parts(M, N, K, lora_rank_pad=0):
