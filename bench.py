@@ -534,7 +534,7 @@ def main():
         achieved = J * f_step / (ev_ms * 1e-3 / args.steps)
         # HBM-side bytes per step and per-family kernel time: measured around the process (PMC counters and the kernel trace need rocprofv3), handed
         # back through --profile-json; the default workload falls back to the committed profile of this round and says which commit it is from
-        traffic = traffic_commit = hbm_kernels = families = None
+        traffic = traffic_commit = hbm_kernels = families = traffic_sources_match = None
         pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
         default_workload = (version == "sdxl" and res == 1024 and B == 1 and args.rank == 16 and text is not None and not args.ti_frozen and not full_ft
                             and not args.dora and J == 1)
@@ -545,6 +545,16 @@ def main():
             with open(ppath) as fh:
                 prof = json.load(fh)
             traffic, traffic_commit = prof.get("traffic_bytes_per_step"), prof.get("commit")
+            # does the quoted profile belong to the code that runs?  (the profile records a hash of the kernel sources + plan code it was taken on)
+            try:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("_step_profile_sha", os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "step_profile_sha.py"))
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                sources_now = mod.kernel_sources_sha()
+            except Exception:
+                sources_now = None
+            traffic_sources_match = (prof.get("kernel_sources_sha16") == sources_now) if (sources_now and prof.get("kernel_sources_sha16")) else None
             # families bound by HBM: algorithmic bytes (every operand once, topology.hbm_bytes) / their kernel time in the profiled step
             alg = topology.hbm_bytes(cfg, B, h, h, args.rank)
             hbm_kernels = {}
@@ -594,7 +604,7 @@ def main():
                                             + (f"; a step advances every job once ({J} images per GPU and step), ms_per_step is per such step" if J > 1 else "")),
                        "trained_params": arena.n, "graph": not args.no_graph, "final_loss": loss},
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_DENSE, "traffic": traffic, "traffic_commit": traffic_commit,
+                         "frac": achieved / PEAK_BF16_DENSE, "traffic": traffic, "traffic_commit": traffic_commit, "traffic_sources_match": traffic_sources_match,
                          "traffic_GB_per_s": (traffic / (ev_ms * 1e-3 / args.steps) / 1e9) if traffic else None, "hbm_kernels": hbm_kernels, "families": families,
                          "note": f"algorithmic {J} x {f_step / 1e12:.3f} TFLOP per step (2 x fwd census) / {ev_ms / args.steps:.3f} ms "
                                  "per step (HIP events on the replay stream); traffic = HBM-side bytes per step (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, "

@@ -197,6 +197,13 @@ def _per_adapter(names, lora, got, flat_ref):
             off += n
     assert off == flat_ref.numel()
     med = sorted(x[3] for x in res)[len(res) // 2]
+    # the two classes behind the adjusted figure, reported on their own: adapters with a normal-sized gradient (rms >= 0.1 median) are judged by their
+    # plain relative L2 error; the rest - self-attention q / k adapters deep in the 1280-wide stacks, whose gradient is ~1 % of the median adapter's because the softmax of a
+    # random-init model is near uniform - by their ABSOLUTE error in units of the median adapter's rms: what bf16 storage of dS leaves on them is noise of the size every
+    # adapter carries, it only looks large against a gradient that is (numerically) nothing
+    _per_adapter.classes = dict(worst_normal_rel=max((x[0] / x[3] for x in res if x[3] >= 0.1 * med), default=0.0),
+                                worst_small_abs_over_median_rms=max((x[0] / med for x in res if x[3] < 0.1 * med), default=0.0),
+                                n_small=sum(1 for x in res if x[3] < 0.1 * med), median_abs_over_median_rms=sorted(x[0] / med for x in res)[len(res) // 2])
     for x in res:
         x[0] = x[0] / math.sqrt(x[3] ** 2 + (0.1 * med) ** 2)
         x[3] = x[3] / med
@@ -215,9 +222,12 @@ def _check_first_step(tag, tol, names, lora, pred, got, rows, o, dora):
         fails.append(f"[{tag}] LoRA grads cos {cos} rel {rel}")
     per = _per_adapter(names, lora, got, o["lora_grads"])
     rep = dict(pred_err=err, lora_cos=cos, lora_rel=rel, worst_adapters=[dict(adj_rel=round(r, 4), cos=round(c, 5), name=n, rms_over_median=round(w, 4)) for r, c, n, w in per[:5]],
-               median_adapter_rel=per[len(per) // 2][0], n_adapter_tensors=len(per))
+               median_adapter_rel=per[len(per) // 2][0], n_adapter_tensors=len(per), adapter_classes=dict(_per_adapter.classes))
     if per[0][0] > tol["ada_rel"]:
         fails.append(f"[{tag}] worst adapter gradients (adjusted rel, cos, name, rms / median) {per[:5]}")
+    cl = _per_adapter.classes
+    if cl["worst_normal_rel"] > tol.get("ada_normal_rel", tol["ada_rel"]) or cl["worst_small_abs_over_median_rms"] > tol.get("ada_small_abs", 0.1 * tol["ada_rel"] * 1.5):
+        fails.append(f"[{tag}] adapter classes {cl}")
     rr = []
     for got_r, ref_r in zip(rows, o["row_grads"]):
         cos, rel = _cos_rel(got_r, ref_r)
@@ -389,6 +399,12 @@ def _case_full_size_properties(version, B, h):
     assert torch.isfinite(pred).all() and torch.isfinite(unet.arena.grads).all() and float(unet.arena.grads.abs().max()) > 0
     assert all(torch.isfinite(r).all() and float(r.abs().max()) > 0 for r in ts.ti.grad_rows)
     g_eager, rows_eager, loss_eager = unet.arena.grads.clone(), [r.clone() for r in ts.ti.grad_rows], float(ts.loss)
+    # bit-reproducible: a second pass from the same state leaves the same bits everywhere (round 5: the GroupNorm statistics of the 1280- / 2560-wide maps had two
+    # writers per slot with different summation splits - the only nondeterminism of the step, tools/determinism_probe.py; every reduction runs in a fixed order)
+    ts.forward_backward()
+    torch.cuda.synchronize()
+    assert torch.equal(unet.arena.grads, g_eager) and all(torch.equal(a, e) for a, e in zip(ts.ti.grad_rows, rows_eager)) and float(ts.loss) == loss_eager, \
+        "two eager passes from the same state differ"
     ts.capture(warmup=1)
     p0, rows0 = unet.arena.params.clone(), ts.ti.params.clone()
     assert float(unet.arena.m.abs().max()) == 0.0 and ts.opt_step == 0           # capture is not training
@@ -396,10 +412,10 @@ def _case_full_size_properties(version, B, h):
     torch.cuda.synchronize()
     assert abs(float(ts.loss) - loss_eager) <= 2e-3 * abs(loss_eager), (float(ts.loss), loss_eager)
     cos, rel = _cos_rel(unet.arena.grads, g_eager)
-    assert cos >= 0.9999 and rel <= 1e-2, f"graph replay vs eager LoRA gradients: cos {cos} rel {rel}"      # (fixed-order reductions; round 1: 5e-2)
+    assert torch.equal(unet.arena.grads, g_eager), f"graph replay vs eager LoRA gradients differ: cos {cos} rel {rel}"      # (round 1: 5e-2, rounds 2-4: 1e-2, round 5: the same bits)
     for a, e in zip(ts.ti.grad_rows, rows_eager):
         cos, rel = _cos_rel(a, e)
-        assert cos >= 0.99, f"graph replay vs eager token-row gradients: cos {cos} rel {rel}"
+        assert torch.equal(a, e), f"graph replay vs eager token-row gradients differ: cos {cos} rel {rel}"
     # optimizer state advanced: moments non-zero, parameters moved by ~lr, L1 norm read-out equals mean|p| of the arena
     assert ts.opt_step == 1 and float(unet.arena.m.abs().max()) > 0 and float(unet.arena.v.abs().max()) > 0
     d = (unet.arena.params - p0).abs()

@@ -6,6 +6,7 @@
   64 B -> doubled, WRITE_SIZE as reported (uncalibrated), unit KiB; Infinity-Cache hits are included in both.
 `bench.py --profile-json <out.json>` turns the family times into GB/s against the algorithmic bytes (topology.hbm_bytes)."""
 import collections
+import os
 import csv
 import json
 import re
@@ -70,7 +71,10 @@ for k, v in per.items():
     fam_w[f] += v["write_bytes"]
     fam_n[f] += v["count"]
 srt = lambda d: {k: v for k, v in sorted(d.items(), key=lambda kv: -kv[1])}  # noqa: E731
-out = {"commit": commit, "command": command, "kernels_per_step": len(step), "kernels_per_step_pmc_pass": n_pmc, "step_span_ms": span_ms,
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from step_profile_sha import kernel_sources_sha  # noqa: E402
+
+out = {"commit": commit, "kernel_sources_sha16": kernel_sources_sha(), "command": command, "kernels_per_step": len(step), "kernels_per_step_pmc_pass": n_pmc, "step_span_ms": span_ms,
        "step_busy_ms": sum(fam_ms.values()), "family_ms": srt(fam_ms), "family_launches": srt(fam_n),
        "fetch_bytes_by_family": srt(fam_f), "write_bytes_by_family": srt(fam_w),
        "fetch_bytes_per_step": sum(fam_f.values()), "write_bytes_per_step": sum(fam_w.values()),
