@@ -862,13 +862,21 @@ __device__ __forceinline__ void attn_bwd_cross_body(const sdlt_attn_params& p, c
         }
       }
       if (q < p.Nqp) {   // pad rows: dq == 0
+        // accumulate_dq: the buffer already holds the score side output's dQ (batched GEMM before the backward pass).  All DP / 16 old words are requested at once
+        // (unconditional per block, column clamped) - read where they are added, each was a round trip of its own behind the last MFMA (round 5, ISA scan)
+        uint2 oldq[DP / 16];
+        if (p.accumulate_dq) {
+          const bf16_t* qrow = (const bf16_t*)p.dQ + ((int64_t)b * p.Nqp + q) * p.lddq + hc;
+#pragma unroll
+          for (int df = 0; df < DP / 16; ++df) { const int col = df * 16 + g * 4; oldq[df] = *(const uint2*)(qrow + (col < d ? col : 0)); }
+        }
 #pragma unroll
         for (int df = 0; df < DP / 16; ++df) {
           int col = df * 16 + g * 4;
           if (col < d) {
             uint2* dst = (uint2*)((bf16_t*)p.dQ + ((int64_t)b * p.Nqp + q) * p.lddq + hc + col);
-            if (p.accumulate_dq) {    // the buffer already holds the score side output's dQ (batched GEMM before the backward pass)
-              const uint2 old = *dst;
+            if (p.accumulate_dq) {
+              const uint2 old = oldq[df];
               dq[df][0] += bf2f(old.x & 0xffff); dq[df][1] += bf2f(old.x >> 16);
               dq[df][2] += bf2f(old.y & 0xffff); dq[df][3] += bf2f(old.y >> 16);
             }

@@ -99,14 +99,17 @@ __device__ __forceinline__ void gn_combine_partials(int C, const float* __restri
 #pragma unroll
     for (int u = 0; u < 8; ++u) a8[u] = 0.f;
     for (int r = part; r < rows; r += nparts * 8) {
+      // (eight loads in flight: unconditional, from a clamped row, masked where they are added - under `if (rr < rows)` hipcc issued and awaited them one at a
+      // time: eight serial round trips in the prologue of every apply kernel, found in the ISA in round 5)
+      float t8[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int rr = r + nparts * u;
-        if (rr < rows) {
-          const int by = rr / nbx, bx = bxlo + (rr - by * nbx);
-          a8[u] += base[((size_t)by * cb + bx) * 64];
-        }
+        const int rr = r + nparts * u, rc = rr < rows ? rr : rows - 1;
+        const int by = rc / nbx, bx = bxlo + (rc - by * nbx);
+        t8[u] = base[((size_t)by * cb + bx) * 64];
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a8[u] += (r + nparts * u < rows) ? t8[u] : 0.f;
     }
     acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
   }
@@ -136,11 +139,21 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(CatIn in, int HW, int C, 
   float s[8], q[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
-  for (int r = blockIdx.y * 32 + wave * 8 + (lane >> 3); r < HW; r += gridDim.y * 32) {
-    float v[8];
-    load8(in.at((int64_t)b * HW + r, c0), v);
+  // (the next row is requested - unconditionally, from a clamped row - before the current one is consumed: a load under `if (r < HW)` with a default made hipcc wait for every
+  // load where it was issued, i.e. one exposed round trip per row of the loop; round 5, tools/scan_exposed_waits.py)
+  const int rstep = gridDim.y * 32;
+  int r = blockIdx.y * 32 + wave * 8 + (lane >> 3);
+  uint4 xn = *(const uint4*)in.at((int64_t)b * HW + (r < HW ? r : HW - 1), c0);
+  while (r < HW) {
+    const uint4 xc = xn;
+    r += rstep;
+    xn = *(const uint4*)in.at((int64_t)b * HW + (r < HW ? r : HW - 1), c0);
+    const uint32_t w[4] = {xc.x, xc.y, xc.z, xc.w};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
+    for (int j = 0; j < 8; ++j) {
+      const float v = bf2f((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffff));
+      s[j] += v; q[j] += v * v;
+    }
   }
   gn_block_partials(s, q, C, ws);
 }
@@ -155,14 +168,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(CatIn in, int HW, int C, 
   const int c0 = blockIdx.x * 64 + (lane & 7) * 8;
   // per-channel parameters and the first row are requested BEFORE the statistics are combined (one memory latency instead of three
   // in a row: partial rows -> gamma / beta -> x); the row loop keeps the next row's load in flight
-  float gm[8], bt[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { gm[j] = gamma[c0 + j]; bt[j] = beta[c0 + j]; }
+  const f32x4 gv0 = *(const f32x4*)(gamma + c0), gv1 = *(const f32x4*)(gamma + c0 + 4), bv0 = *(const f32x4*)(beta + c0), bv1 = *(const f32x4*)(beta + c0 + 4);
   const int rstep = gridDim.y * 32;
   int r = blockIdx.y * 32 + wave * 8 + (lane >> 3);
-  uint4 xn = make_uint4(0, 0, 0, 0);
-  if (r < HW) xn = *(const uint4*)in.at((int64_t)b * HW + r, c0);
+  uint4 xn = *(const uint4*)in.at((int64_t)b * HW + (r < HW ? r : HW - 1), c0);      // (unconditional, clamped: see gn_stats_kernel)
   gn_combine_partials(C, ws, stats, stats_out);
+  float gm[8], bt[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { gm[j] = j < 4 ? gv0[j & 3] : gv1[j & 3]; bt[j] = j < 4 ? bv0[j & 3] : bv1[j & 3]; }
   const int cpg = C / G;
   const float inv_n = 1.0f / ((float)HW * (float)cpg);
   float sc[8], sh[8];
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(CatIn in, int HW, int C, 
     const uint4 xc = xn;
     const int64_t row = (int64_t)b * HW + r;
     r += rstep;
-    if (r < HW) xn = *(const uint4*)in.at((int64_t)b * HW + r, c0);
+    xn = *(const uint4*)in.at((int64_t)b * HW + (r < HW ? r : HW - 1), c0);
     const uint32_t w[4] = {xc.x, xc.y, xc.z, xc.w};
     float v[8];
 #pragma unroll
@@ -188,6 +201,39 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(CatIn in, int HW, int C, 
       v[j] = SILU ? silu_f(z) : z;
     }
     store8(y + row * ldy + c0, v);
+  }
+}
+
+// Backward kernels: gamma / beta of a lane's 8 consecutive channels (two 16-byte loads each) and the forward statistics (sum, sum of squares) of their groups (one 8-byte load per
+// channel, mostly the same address), ALL REQUESTED TOGETHER and consumed later by gn_lane_finish - the per-channel form `mean[j] = stats[...] * inv_n` right behind each load made
+// eight serial round trips out of the prologue of every GroupNorm backward launch (round 5, tools/scan_exposed_waits.py)
+struct GnLaneRaw { f32x4 g0, g1, b0, b1; float2 st[8]; };
+__device__ __forceinline__ GnLaneRaw gn_lane_loads(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ stats, int b, int c0, int cpg) {
+  GnLaneRaw w;
+  w.g0 = *(const f32x4*)(gamma + c0); w.g1 = *(const f32x4*)(gamma + c0 + 4);
+  w.b0 = *(const f32x4*)(beta + c0); w.b1 = *(const f32x4*)(beta + c0 + 4);
+  int gj[8];
+  const int ga = c0 / cpg;
+  if (cpg >= 8) {            // 8 consecutive channels cross at most one group boundary
+    const int jb = (ga + 1) * cpg - c0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gj[j] = ga + (j >= jb ? 1 : 0);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gj[j] = (c0 + j) / cpg;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) w.st[j] = *(const float2*)(stats + (b * G + gj[j]) * 2);
+  return w;
+}
+__device__ __forceinline__ void gn_lane_finish(const GnLaneRaw& w, float inv_n, float eps, float (&mean)[8], float (&rstd)[8], float (&gm)[8], float (&bt)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mean[j] = w.st[j].x * inv_n;
+    const float var = fmaxf(w.st[j].y * inv_n - mean[j] * mean[j], 0.f);
+    rstd[j] = rsqrtf(var + eps);
+    gm[j] = j < 4 ? w.g0[j & 3] : w.g1[j & 3];
+    bt[j] = j < 4 ? w.b0[j & 3] : w.b1[j & 3];
   }
 }
 
@@ -202,26 +248,28 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(CatIn in, const bf16_
   const int cpg = C / G;
   const float inv_n = 1.0f / ((float)HW * (float)cpg);
   float mean[8], rstd[8], gm[8], bt[8], s1[8], s2[8];
+  const GnLaneRaw raw = gn_lane_loads(gamma, beta, stats, b, c0, cpg);
+  const int rstep = gridDim.y * 32;
+  int r = blockIdx.y * 32 + wave * 8 + (lane >> 3);
+  int64_t row = (int64_t)b * HW + (r < HW ? r : HW - 1);
+  uint4 xn = *(const uint4*)in.at(row, c0), dn = *(const uint4*)(dy + row * lddy + c0);       // (unconditional, clamped rows; the next row is in flight while this one is consumed)
+  gn_lane_finish(raw, inv_n, eps, mean, rstd, gm, bt);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    int g = (c0 + j) / cpg;
-    mean[j] = stats[(b * G + g) * 2] * inv_n;
-    float var = fmaxf(stats[(b * G + g) * 2 + 1] * inv_n - mean[j] * mean[j], 0.f);
-    rstd[j] = rsqrtf(var + eps);
-    gm[j] = gamma[c0 + j]; bt[j] = beta[c0 + j];
-    s1[j] = s2[j] = 0.f;
-  }
-  for (int r = blockIdx.y * 32 + wave * 8 + (lane >> 3); r < HW; r += gridDim.y * 32) {
-    float v[8], d[8];
-    int64_t row = (int64_t)b * HW + r;
-    load8(in.at(row, c0), v);
-    load8(dy + row * lddy + c0, d);
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  while (r < HW) {
+    const uint4 xc = xn, dc = dn;
+    r += rstep;
+    row = (int64_t)b * HW + (r < HW ? r : HW - 1);
+    xn = *(const uint4*)in.at(row, c0);
+    dn = *(const uint4*)(dy + row * lddy + c0);
+    const uint32_t xw[4] = {xc.x, xc.y, xc.z, xc.w}, dw[4] = {dc.x, dc.y, dc.z, dc.w};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float xh = (v[j] - mean[j]) * rstd[j];
-      float dz = d[j];
+      const float v = bf2f((j & 1) ? (xw[j >> 1] >> 16) : (xw[j >> 1] & 0xffff));
+      float dz = bf2f((j & 1) ? (dw[j >> 1] >> 16) : (dw[j >> 1] & 0xffff));
+      const float xh = (v - mean[j]) * rstd[j];
       if (SILU) dz *= dsilu_f(xh * gm[j] + bt[j]);
-      float dxh = dz * gm[j];
+      const float dxh = dz * gm[j];
       s1[j] += dxh; s2[j] += dxh * xh;
     }
   }
@@ -241,24 +289,21 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(CatIn in, const bf16_
   const float inv_n = 1.0f / ((float)HW * (float)cpg);
   // (as gn_apply_kernel: parameters, forward statistics and the first row's three tiles are in flight while the partial sums are combined)
   float mean[8], rstd[8], gm[8], bt[8], m1[8], m2[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    int g = (c0 + j) / cpg;
-    mean[j] = stats[(b * G + g) * 2] * inv_n;
-    float var = fmaxf(stats[(b * G + g) * 2 + 1] * inv_n - mean[j] * mean[j], 0.f);
-    rstd[j] = rsqrtf(var + eps);
-    gm[j] = gamma[c0 + j]; bt[j] = beta[c0 + j];
-  }
+  const GnLaneRaw raw = gn_lane_loads(gamma, beta, stats, b, c0, cpg);
   const int rstep = gridDim.y * 32;
   int r = blockIdx.y * 32 + wave * 8 + (lane >> 3);
-  uint4 xn = make_uint4(0, 0, 0, 0), dn = xn, on = xn;
-  if (r < HW) {
-    const int64_t row = (int64_t)b * HW + r;
+  // (unconditional loads from clamped rows; a missing residual gradient reads dy again and is skipped where it would be added)
+  const bf16_t* rsrc = dres ? dres : dy;
+  const int64_t ldrs = dres ? lddres : lddy;
+  uint4 xn, dn, on;
+  {
+    const int64_t row = (int64_t)b * HW + (r < HW ? r : HW - 1);
     xn = *(const uint4*)in.at(row, c0);
     dn = *(const uint4*)(dy + row * lddy + c0);
-    if (dres) on = *(const uint4*)(dres + row * lddres + c0);
+    on = *(const uint4*)(rsrc + row * ldrs + c0);
   }
   gn_combine_partials(C, ws, bstats, bstats_out);
+  gn_lane_finish(raw, inv_n, eps, mean, rstd, gm, bt);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     int g = (c0 + j) / cpg;
@@ -269,11 +314,11 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(CatIn in, const bf16_
     const uint4 xc = xn, dc = dn, oc = on;
     const int64_t row = (int64_t)b * HW + r;
     r += rstep;
-    if (r < HW) {      // (dres may alias dx: a row is read before it is written, and rows are disjoint between iterations)
-      const int64_t nrow = (int64_t)b * HW + r;
+    {      // (dres may alias dx: a row is read before it is written, and rows are disjoint between iterations - the clamped re-read behind the last row is never used)
+      const int64_t nrow = (int64_t)b * HW + (r < HW ? r : HW - 1);
       xn = *(const uint4*)in.at(nrow, c0);
       dn = *(const uint4*)(dy + nrow * lddy + c0);
-      if (dres) on = *(const uint4*)(dres + nrow * lddres + c0);
+      on = *(const uint4*)(rsrc + nrow * ldrs + c0);
     }
     const uint32_t xw[4] = {xc.x, xc.y, xc.z, xc.w}, dw[4] = {dc.x, dc.y, dc.z, dc.w}, ow[4] = {oc.x, oc.y, oc.z, oc.w};
     float o[8];
@@ -284,7 +329,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(CatIn in, const bf16_
       const float xh = (v - mean[j]) * rstd[j];
       if (SILU) dz *= dsilu_f(xh * gm[j] + bt[j]);
       const float dxh = dz * gm[j];
-      o[j] = bf2f((j & 1) ? (ow[j >> 1] >> 16) : (ow[j >> 1] & 0xffff)) + rstd[j] * (dxh - m1[j] - xh * m2[j]);
+      o[j] = (dres ? bf2f((j & 1) ? (ow[j >> 1] >> 16) : (ow[j >> 1] & 0xffff)) : 0.f) + rstd[j] * (dxh - m1[j] - xh * m2[j]);
     }
     store8(dx + row * lddx + c0, o);
   }
@@ -307,13 +352,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
   uint4 xr[LN_MAXCH];
   f32x4 g4[LN_MAXCH][2], b4[LN_MAXCH][2];
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
-    int ch = lane + i * 64;
-    if (ch < nch) {
-      xr[i] = *(const uint4*)(x + (int64_t)row * ldx + ch * 8);
-      g4[i][0] = *(const f32x4*)(gamma + ch * 8); g4[i][1] = *(const f32x4*)(gamma + ch * 8 + 4);
-      b4[i][0] = *(const f32x4*)(beta + ch * 8); b4[i][1] = *(const f32x4*)(beta + ch * 8 + 4);
-    }
+  for (int i = 0; i < LN_MAXCH; ++i) {      // (unconditional, clamped: one round trip - see ln_bwd_body)
+    const int ch = lane + i * 64, cc = ch < nch ? ch : nch - 1;
+    xr[i] = *(const uint4*)(x + (int64_t)row * ldx + cc * 8);
+    g4[i][0] = *(const f32x4*)(gamma + cc * 8); g4[i][1] = *(const f32x4*)(gamma + cc * 8 + 4);
+    b4[i][0] = *(const f32x4*)(beta + cc * 8); b4[i][1] = *(const f32x4*)(beta + cc * 8 + 4);
   }
   float v[LN_MAXCH][8];
   float s = 0.f;
@@ -369,30 +412,42 @@ __device__ __forceinline__ void ln_bwd_body(const bf16_t* __restrict__ x, int64_
   uint4 xr[LN_MAXCH], dr[LN_MAXCH], rr[LN_MAXCH];
   f32x4 d32[LN_MAXCH][2];         // (dres may alias dx: read here, before any store of this row - each wave owns its row)
   f32x4 g4[LN_MAXCH][2], b4[YOUT ? LN_MAXCH : 1][2];
+  // ONE round trip per wave: every load of the row - and the statistics - is issued unconditionally, from clamped addresses, before anything is consumed.  (Round 5, seen in
+  // the ISA: with `if (ch < nch)` / `if (dres)` around the loads and a zero default hipcc copied the loaded registers at each join and put an s_waitcnt vmcnt(0) behind every
+  // 8-column chunk - four serial round trips, the statistics a fifth - in a kernel that is nothing but one dependent chain per wave; 253 launches per SDXL step.)  Chunks
+  // beyond the row read its last chunk again and are skipped where they would be used; a missing residual gradient reads x instead.
+  const float2 mr = *(const float2*)(stats + row * 2);
+  const bf16_t* rsrc = dres ? dres + (int64_t)row * lddres : x + (int64_t)row * ldx;
 #pragma unroll
   for (int i = 0; i < LN_MAXCH; ++i) {
-    int ch = lane + i * 64;
-    rr[i] = make_uint4(0, 0, 0, 0);
-    if (ch < nch) {
-      xr[i] = *(const uint4*)(x + (int64_t)row * ldx + ch * 8);
-      if constexpr (YOUT) { b4[i][0] = *(const f32x4*)(beta + ch * 8); b4[i][1] = *(const f32x4*)(beta + ch * 8 + 4); }
-      if constexpr (SLABS) {
-        dr[i] = make_uint4(0, 0, 0, 0);
-        d32[i][0] = *(const f32x4*)(dy32 + (int64_t)row * lddy + ch * 8);
-        d32[i][1] = *(const f32x4*)(dy32 + (int64_t)row * lddy + ch * 8 + 4);
-        for (int sl = 1; sl < nslab; ++sl) {
-          const float* o = dy32 + ((int64_t)sl * M + row) * lddy + ch * 8;
-          d32[i][0] += *(const f32x4*)o;
-          d32[i][1] += *(const f32x4*)(o + 4);
-        }
-      } else {
-        dr[i] = *(const uint4*)(dy + (int64_t)row * lddy + ch * 8);
+    const int ch = lane + i * 64, cc = ch < nch ? ch : nch - 1;
+    xr[i] = *(const uint4*)(x + (int64_t)row * ldx + cc * 8);
+    if constexpr (YOUT) { b4[i][0] = *(const f32x4*)(beta + cc * 8); b4[i][1] = *(const f32x4*)(beta + cc * 8 + 4); }
+    if constexpr (SLABS) {
+      dr[i] = make_uint4(0, 0, 0, 0);
+      d32[i][0] = *(const f32x4*)(dy32 + (int64_t)row * lddy + cc * 8);
+      d32[i][1] = *(const f32x4*)(dy32 + (int64_t)row * lddy + cc * 8 + 4);
+    } else {
+      dr[i] = *(const uint4*)(dy + (int64_t)row * lddy + cc * 8);
+    }
+    g4[i][0] = *(const f32x4*)(gamma + cc * 8); g4[i][1] = *(const f32x4*)(gamma + cc * 8 + 4);
+    rr[i] = *(const uint4*)(rsrc + cc * 8);
+  }
+  if constexpr (SLABS) {          // the other slabs, in slab order (all requested before the first addition is needed)
+    for (int sl = 1; sl < nslab; ++sl) {
+      f32x4 t[LN_MAXCH][2];
+#pragma unroll
+      for (int i = 0; i < LN_MAXCH; ++i) {
+        const int ch = lane + i * 64, cc = ch < nch ? ch : nch - 1;
+        const float* o = dy32 + ((int64_t)sl * M + row) * lddy + cc * 8;
+        t[i][0] = *(const f32x4*)o;
+        t[i][1] = *(const f32x4*)(o + 4);
       }
-      g4[i][0] = *(const f32x4*)(gamma + ch * 8); g4[i][1] = *(const f32x4*)(gamma + ch * 8 + 4);
-      if (dres) rr[i] = *(const uint4*)(dres + (int64_t)row * lddres + ch * 8);
+#pragma unroll
+      for (int i = 0; i < LN_MAXCH; ++i) { d32[i][0] += t[i][0]; d32[i][1] += t[i][1]; }
     }
   }
-  const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+  const float mean = mr.x, rstd = mr.y;
   float xh[LN_MAXCH][8], dxh[LN_MAXCH][8];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -420,7 +475,7 @@ __device__ __forceinline__ void ln_bwd_body(const bf16_t* __restrict__ x, int64_
       float o[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        o[j] = bf2f((j & 1) ? (rw[j >> 1] >> 16) : (rw[j >> 1] & 0xffff)) + rstd * (dxh[i][j] - s1 - xh[i][j] * s2);
+        o[j] = (dres ? bf2f((j & 1) ? (rw[j >> 1] >> 16) : (rw[j >> 1] & 0xffff)) : 0.f) + rstd * (dxh[i][j] - s1 - xh[i][j] * s2);
       store8(dx + (int64_t)row * lddx + ch * 8, o);
       if constexpr (YOUT) {
 #pragma unroll
