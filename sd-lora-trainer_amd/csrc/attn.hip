@@ -563,11 +563,12 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const sdlt_attn_params& p, ch
       int col = df * 16 + g * 4;
       if (col < d) {
         if (p.qsplit > 1) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            atomicAdd(p.dK32 + row * p.ld32 + hc + col + r, dk[df][r] * p.scale);
-            atomicAdd(p.dV32 + row * p.ld32 + hc + col + r, dv[df][r]);
-          }
+          // partial dK / dV of this query range -> slab[split] (plain stores; attn_splitsum_kernel adds the slabs in order and converts).  Until round 5 the splits
+          // met in ONE fp32 buffer through float atomics: the only order-dependent sum left on the LoRA / TI path (SD1.5's 160-wide cross-attention heads, which the
+          // single-pass cross kernel does not take) - tools/determinism_probe.py sd15 found the step differing run to run through it.
+          const int64_t srow = ((int64_t)split * p.B + b) * p.Nkp + key;
+          *(f32x4*)(p.dK32 + srow * p.ld32 + hc + col) = (f32x4){dk[df][0] * p.scale, dk[df][1] * p.scale, dk[df][2] * p.scale, dk[df][3] * p.scale};
+          *(f32x4*)(p.dV32 + srow * p.ld32 + hc + col) = dv[df];
         } else {
           uint2 w;
           w.x = pack2bf(dk[df][0] * p.scale, dk[df][1] * p.scale); w.y = pack2bf(dk[df][2] * p.scale, dk[df][3] * p.scale);
@@ -1095,22 +1096,6 @@ __global__ void attn_splitsum_batch_kernel(const sdlt_splitsum_desc* descs, cons
   }
 }
 
-// fp32 [rows, C] (ld32) -> bf16 [rows, C] (ld) after the atomics of the query-split path
-__global__ void cvt_f32_bf16_kernel(const float* in0, const float* in1, int64_t ldi, bf16_t* out0, int64_t ldo0, bf16_t* out1, int64_t ldo1,
-                                    int rows, int C) {
-  const int nch = C >> 2;
-  const int64_t per = (int64_t)rows * nch;
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < 2 * per; t += (int64_t)gridDim.x * blockDim.x) {
-    const bool second = t >= per;
-    const int64_t u = second ? t - per : t;
-    int r = u / nch, c = (u - (int64_t)r * nch) * 4;
-    float4 v = *(const float4*)((second ? in1 : in0) + r * ldi + c);
-    uint2 w;
-    w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
-    *(uint2*)((second ? out1 + r * ldo1 : out0 + r * ldo0) + c) = w;
-  }
-}
-
 int attn_dp(int d) {
   if (d <= 0 || (d % 8)) return -1;
   if (d <= 64) return 64;
@@ -1203,16 +1188,6 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
     SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_attn_bwd: dK/dV outputs for qsplit=%d", p.qsplit);
   const int dp = attn_dp(p.d);
   const int C = p.H * p.d, krows = p.B * p.Nkp;
-  auto zero32 = [&]() {     // fp32 dK/dV scratch of the atomic paths; one launch when the two buffers are adjacent
-    const size_t n = (size_t)krows * p.ld32;
-    if (p.dV32 == p.dK32 + n) sdlt_zero_async(p.dK32, sizeof(float) * 2 * n, s);
-    else { sdlt_zero_async(p.dK32, sizeof(float) * n, s); sdlt_zero_async(p.dV32, sizeof(float) * n, s); }
-  };
-  auto cvt32 = [&]() {
-    int blocks = (int)(((int64_t)krows * C / 2 + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(cvt_f32_bf16_kernel, dim3(blocks), dim3(256), 0, s, p.dK32, p.dV32, p.ld32, (bf16_t*)p.dK, p.lddk, (bf16_t*)p.dV, p.lddv, krows, C);
-  };
   if (p.qsplit > 1 && !p.causal && p.Nk <= 128 && p.Nkp <= 128 && dp <= 96) {
     // cross-attention: prep + dQ + dK/dV in one kernel (see attn_bwd_cross_kernel); qsplit = workgroups along the queries,
     // dK32 / dV32 = [qsplit][B*Nkp][ld32] partial slabs (any contents)
@@ -1262,11 +1237,16 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
   dim3 gq((p.Nq + 63) / 64, p.H, p.B);
 #define SMEM_DQ(D_) (2 * (2 * 64 * NSTRH(D_)))
   ATTN_DISPATCH(dp, attn_bwd_dq_kernel, gq, SMEM_DQ)
-  if (p.qsplit > 1) zero32();
+  if (p.qsplit > 1 && (((uintptr_t)p.dK32 | (uintptr_t)p.dV32) & 15 || (p.ld32 & 3) || (C & 3)))
+    SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_attn_bwd: the dK / dV slabs of a query-split backward need 16-byte rows (ld32 %% 4, C %% 4)");
   dim3 gk(((p.Nk + 63) / 64) * p.qsplit, p.H, p.B);
 #define SMEM_DKV(D_) (2 * (2 * 64 * NSTRH(D_) + 512))
   ATTN_DISPATCH(dp, attn_bwd_dkdv_kernel, gk, SMEM_DKV)
-  if (p.qsplit > 1) cvt32();
+  if (p.qsplit > 1) {      // [qsplit][B * Nkp][ld32] partial slabs -> bf16 dK / dV, summed in slab order (bitwise reproducible)
+    int blocks = (int)(((int64_t)krows * C / 2 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(attn_splitsum_kernel, dim3(blocks), dim3(256), 0, s, p.dK32, p.dV32, p.qsplit, p.ld32, (bf16_t*)p.dK, p.lddk, (bf16_t*)p.dV, p.lddv, p.B, p.Nk, p.Nkp, C, 0);
+  }
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }

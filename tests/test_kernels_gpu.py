@@ -624,6 +624,8 @@ ATTN_CASES = [
     dict(B=2, H=1, Nq=576, Nk=576, Nkp=576, d=64, causal=False, qsplit=1),
     dict(B=1, H=20, Nq=1024, Nk=1024, Nkp=1024, d=64, causal=False, qsplit=1),
     dict(B=1, H=10, Nq=4096, Nk=4096, Nkp=4096, d=64, causal=False, qsplit=1),      # the 64 x 64 level of SDXL at 1024 px (attn32: 4096 tokens x 10 heads)
+    # SD1.5's 160-wide cross-attention heads with a query split: the generic dQ + dK / dV launches, partial dK / dV in per-split slabs (ordered sum; float atomics until round 5)
+    dict(B=2, H=2, Nq=320, Nk=77, Nkp=128, d=160, causal=False, qsplit=4),
 ]
 
 
