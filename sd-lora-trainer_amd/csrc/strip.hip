@@ -126,6 +126,26 @@ __device__ __forceinline__ void strip_body(const sdlt_strip_params& p, char* sme
 #pragma unroll
   for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
 
+#ifdef SDLT_STRIP_TOUCH
+  // The weight rows of the steps BEHIND the ring's reach are touched now, one lane per 128-byte line: a strip launch is a handful of workgroups that stream a weight matrix
+  // from HBM exactly once - with R - 1 steps in flight every ring turn used to pay its own first-touch round trip (K = 1280: two in a row for five steps per wave).  Issued
+  // before the prefill: oldest loads in flight, covered by every counted wait below; the dummy registers stay reserved until behind the K walk.
+  uint32_t tdum[5] = {0u, 0u, 0u, 0u, 0u};
+  {
+    const int nline = (nsteps > R ? nsteps - R : 0) * 16 * J;          // (step, weight row) pairs to touch
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int idx = lane + 64 * t;
+      if (idx < nline) {
+        const int st = idx / (16 * J), row = idx - st * (16 * J);
+        int ii = R + st + rot;
+        ii = ii >= nsteps ? ii - nsteps : ii;
+        const char* a = (const char*)((const bf16_t*)p.W + (int64_t)(n0 + row) * p.ldw + kbase + (wave + NW * ii) * 64);
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(tdum[t]) : "v"(a) : "memory");
+      }
+    }
+  }
+#endif
 #pragma unroll
   for (int s = 0; s < R; ++s)
     if (s < nsteps) issue(s, s);
@@ -164,6 +184,9 @@ __device__ __forceinline__ void strip_body(const sdlt_strip_params& p, char* sme
     slot = slot + 1 == R ? 0 : slot + 1;
   }
 
+#ifdef SDLT_STRIP_TOUCH
+  asm volatile("" ::"v"(tdum[0]), "v"(tdum[1]), "v"(tdum[2]), "v"(tdum[3]), "v"(tdum[4]));
+#endif
   // ---- the NW partial tiles (and row statistics) meet in LDS (the rings are dead: every DMA has been waited for and read)
   __syncthreads();
   f32x4* red = (f32x4*)smem;                                        // [NW][UNITS][64 lanes]

@@ -175,8 +175,10 @@ def _set(ts, b, xl, h, n_enc):
 # separates the HIP path from the fp32 reference is NOT dominated by where activations are rounded, so the bars below sit 2-3x above the
 # measurements for both (round 2: cos 0.99 / rel 8 % on the flat vector only).  LoRA displacement after 6 AdamW steps: cos 0.970 (SDXL: Adam turns the
 # noise of the near-zero gradients into +-lr moves) / 0.9995 (SD1.5); floor 0.95 (round 2: 0.9).
-TOL_BF16 = dict(pred=3e-2, loss=2e-2, ta=5e-2, reg=5e-2, cos=0.9995, rel=3e-2, rows_cos=0.999, rows_rel=5e-2, disp_cos=0.95, rows_final=2e-2, ada_rel=0.12)
-TOL_FAITHFUL = dict(pred=3e-2, loss=8e-3, cos=0.9995, rel=3e-2, rows_cos=0.999, rows_rel=5e-2, ada_rel=0.12)
+# round 5, the two adapter classes on their own (profiles/r05_parity_report.json -> adapter_classes): normal-sized adapters (rms >= 0.1 median) worst plain relative error 1.4-5.4 %
+# -> bar 10 %; the ~1 %-sized ones worst ABSOLUTE error 0.1-1.0 % of the median adapter's rms - below the median adapter's own absolute error (0.6-1.2 %) - -> bar 2 %
+TOL_BF16 = dict(pred=3e-2, loss=2e-2, ta=5e-2, reg=5e-2, cos=0.9995, rel=3e-2, rows_cos=0.999, rows_rel=5e-2, disp_cos=0.95, rows_final=2e-2, ada_rel=0.12, ada_normal_rel=0.10, ada_small_abs=0.02)
+TOL_FAITHFUL = dict(pred=3e-2, loss=8e-3, cos=0.9995, rel=3e-2, rows_cos=0.999, rows_rel=5e-2, ada_rel=0.12, ada_normal_rel=0.10, ada_small_abs=0.02)
 TOL_FP32 = dict(pred=2e-3, loss=1e-3, ta=2e-3, reg=2e-3, cos=0.9999, rel=5e-3, rows_cos=0.9999, rows_rel=1e-2, disp_cos=0.99, rows_final=1e-3, ada_rel=2e-2)
 TOL_FP32_FAITHFUL = dict(pred=3e-2, loss=2e-2, cos=0.99, rel=8e-2, rows_cos=0.985, rows_rel=0.2, ada_rel=0.45)     # (fp32 engine vs rounded oracle: the bf16 bars)
 REPORT = {}        # case -> worst adapters etc., written to gpurun_out/parity_report.json when that directory exists
