@@ -126,13 +126,15 @@ __device__ __forceinline__ void strip_body(const sdlt_strip_params& p, char* sme
 #pragma unroll
   for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
 
-#ifdef SDLT_STRIP_TOUCH
-  // The weight rows of the steps BEHIND the ring's reach are touched now, one lane per 128-byte line: a strip launch is a handful of workgroups that stream a weight matrix
-  // from HBM exactly once - with R - 1 steps in flight every ring turn used to pay its own first-touch round trip (K = 1280: two in a row for five steps per wave).  Issued
-  // before the prefill: oldest loads in flight, covered by every counted wait below; the dummy registers stay reserved until behind the K walk.
+  // Long K walks (more than two ring turns: K >= 1792 per split): the weight rows of the steps BEHIND the ring's reach are touched now, one lane per 128-byte line.  A strip
+  // launch is a handful of workgroups that stream a weight matrix from HBM exactly once; with R - 1 steps in flight every ring turn paid its own first-touch round trip.
+  // Round 5, tools/strip_probe.py (weights rotating through 600 MB): 1280 x 5120 18.0 -> 13.8 us, 1280 x 3840 14.7 -> 11.8, 768 x 3072 12.1 -> 9.9; the five-step walks
+  // (K = 1280) are neutral to 0.4 us worse and keep the plain prefill; whole step -0.25 ms.  (The same idea LOST on the wave-split-K kernel, whose 256 workgroups are
+  // bandwidth-bound - DESIGN 4.14; here 16-320 workgroups are latency-bound.)  Issued before the prefill: oldest loads in flight, covered by every counted wait below; the
+  // dummy registers stay reserved until behind the K walk.
   uint32_t tdum[5] = {0u, 0u, 0u, 0u, 0u};
-  {
-    const int nline = (nsteps > R ? nsteps - R : 0) * 16 * J;          // (step, weight row) pairs to touch
+  if (nsteps > 2 * R) {
+    const int nline = (nsteps - R) * 16 * J;          // (step, weight row) pairs to touch (at most 320: the tail of a very long walk is left to the ring)
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
       const int idx = lane + 64 * t;
@@ -145,7 +147,6 @@ __device__ __forceinline__ void strip_body(const sdlt_strip_params& p, char* sme
       }
     }
   }
-#endif
 #pragma unroll
   for (int s = 0; s < R; ++s)
     if (s < nsteps) issue(s, s);
@@ -184,9 +185,7 @@ __device__ __forceinline__ void strip_body(const sdlt_strip_params& p, char* sme
     slot = slot + 1 == R ? 0 : slot + 1;
   }
 
-#ifdef SDLT_STRIP_TOUCH
   asm volatile("" ::"v"(tdum[0]), "v"(tdum[1]), "v"(tdum[2]), "v"(tdum[3]), "v"(tdum[4]));
-#endif
   // ---- the NW partial tiles (and row statistics) meet in LDS (the rings are dead: every DMA has been waited for and read)
   __syncthreads();
   f32x4* red = (f32x4*)smem;                                        // [NW][UNITS][64 lanes]
