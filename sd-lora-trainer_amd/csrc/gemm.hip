@@ -506,23 +506,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
   } else {
   // prologue: S-1 stages in flight
   GTR(1);
-#ifdef SDLT_GEMM_TOUCH
-  // lab (round 5): the weight rows of this tile BEHIND the ring's reach are touched now, one lane per 128-byte line, consecutive lanes along a row - the first-touch HBM
-  // round trips of a cold weight panel then start with the launch instead of one ring turn at a time (the idea that wins on the text encoders' strips and lost on wsk)
-  uint32_t tdum[4] = {0u, 0u, 0u, 0u};
-  if (MODE == 0 && nk2 == 0 && kend - kbeg > 2 * S) {
-    const int nrow = p.N - n0 < BN ? p.N - n0 : BN, nst = kend - kbeg - (S - 1), total = nrow * nst;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int idx = tid + t * NTHR;
-      if (idx < total) {
-        const int row = div_small(idx, nst), st = idx - row * nst;
-        const char* a = (const char*)((const bf16_t*)pW + (size_t)(n0 + row) * p.ldw + (size_t)(kbeg + S - 1 + st) * BK);
-        asm volatile("global_load_dword %0, %1, off" : "=&v"(tdum[t]) : "v"(a) : "memory");
-      }
-    }
-  }
-#endif
+  // (Round 5, measured and dropped: touching this tile's weight rows behind the ring's reach at launch - the trick that takes a quarter off the text encoders' long strips -
+  // makes the whole step 1.0 ms SLOWER here (SD1.5 +0.35, full fine-tune +4.8): like the wave-split-K products these launches are bandwidth-bound, not latency-bound.)
 #pragma unroll
   for (int t = 1; t < S - 1; ++t)          // (stage kbeg went out in front of the epilogue prefetch)
     if (kbeg + t < kend) stage(kbeg + t, t);
@@ -580,9 +565,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const sdlt_gemm_para
     kg_flush(kt);
     rd = rd + 1 == S ? 0 : rd + 1;
   }
-#ifdef SDLT_GEMM_TOUCH
-  asm volatile("" ::"v"(tdum[0]), "v"(tdum[1]), "v"(tdum[2]), "v"(tdum[3]));
-#endif
   }
 
   GTR(8);
