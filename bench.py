@@ -360,6 +360,7 @@ def main():
     ap.add_argument("--no-library-gpu", action="store_true", help="skip the extra measurement of the torch restatement of the step on the GPU (library kernels)")
     ap.add_argument("--full-ft", action="store_true", help="full-UNet fine-tune (BASELINE configs[4], train_configs/full_finetuning_example.json: "
                     "SDXL 512 px, batch 4 per GPU, AdamW over every UNet parameter); data parallel when --gpus > 1: per-bucket reduce-scatter, sharded AdamW, all-gather (SDLT_DDP_ZERO1=0: all-reduce)")
+    ap.add_argument("--fp32-moments", action="store_true", help="--full-ft: AdamW with fp32 moments instead of the example config's AdamW8bit (A/B of the optimizer pass)")
     ap.add_argument("--dry-collectives", action="store_true", help="--full-ft on ONE GPU: run the data-parallel exchange step (per-bucket graphs, in-place reduce-scatter / all-gather, "
                     "async works) on a 1-rank RCCL group - the exact call sequence of --gpus N - and report every collective's bytes and the ring wire time it implies for 2 / 4 / 8 GPUs")
     ap.add_argument("--ddp-wire", default=None, choices=["fp32", "bf16"], help="--full-ft --gpus N: dtype of the matrix gradients on the xGMI wire "
@@ -453,7 +454,7 @@ def main():
             text = S.TextStack(rt, encs, pool_mode="argmax")
         ts = S.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, l1_penalty=0.0 if args.dora else 0.03, weight_decay=0.0 if args.dora else 0.004, text=text, n_tokens=n_tok,
                          process_group=True if (full_ft and (world > 1 or dry)) else None, ddp_wire_dtype=args.ddp_wire if (full_ft and (world > 1 or dry)) else None,
-                         ddp_force=dry)
+                         ddp_force=dry, optimizer="AdamW8bit" if (full_ft and not args.fp32_moments) else "adamw")      # full_finetuning_example.json: unet_optimizer_type AdamW8bit
         rn = lambda *s: torch.randn(*s, generator=g, device=device)  # noqa: E731
         latent = rn(B, 4, h, h) * cfg["scaling_factor"]
         noise = rn(B, 4, h, h)
@@ -590,7 +591,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": (f"{version} {res}x{res} FULL-UNet fine-tune batch {B}/GPU: UNet fwd + bwd (dX and every dW), masked/min-SNR MSE, "
-                                    f"AdamW over {arena.n / 1e6:.0f} M parameters, bf16 operand refresh" if full_ft else
+                                    f"{'AdamW8bit (block-quantised moments)' if getattr(ts, 'adam8', False) else 'AdamW (fp32 moments)'} over {arena.n / 1e6:.0f} M parameters, bf16 operand refresh" if full_ft else
                                     f"{version} {res}x{res} {'DoRA' if args.dora else 'LoRA'} rank {args.rank} batch {B}" + ("/GPU" if J == 1 else f" per job, {J} concurrent jobs/GPU")
                                     + (": UNet fwd+bwd, masked/min-SNR MSE, AdamW (adapters + magnitudes; per-step weight-norm / scaled-operand refresh)" if args.dora
                                        else ": UNet fwd+bwd, masked/min-SNR MSE, L1, AdamW"))

@@ -381,6 +381,15 @@ int sdlt_lora_shadow_refresh(const sdlt_shadow_desc* descs_dev, const int32_t* b
 int sdlt_adamw_shadow_refresh(const sdlt_shadow_desc* descs_dev, const int32_t* block_desc_dev, const int32_t* block_first_dev,
                               int32_t n_blocks, float* p, const float* g, float* m, float* v, const float* hyper, void* stream);
 
+/* bitsandbytes 0.43.1 `AdamW8bit` (trainer/optimizer.py:19-21; unet_optimizer_type of train_configs/full_finetuning_example.json), restated from its published
+ * blockwise 8-bit Adam [3P-unverified: bitsandbytes is absent from /root/reference and from this image]: the same tiles as sdlt_adamw_shadow_refresh with
+ * the moments held as one byte per element (m8, v8: indices into the signed / unsigned "dynamic" code books, addressed like the fp32 arena) times one fp32
+ * absmax per block of 2048 elements.  A block is one half of a 64 x 64 tile (rows 0-31 | rows 32-63) - absmax: fp32 [n_blocks][4] = {m lo, m hi, v lo, v hi},
+ * 16-byte aligned, zero before the first step (m8 / v8 zero too).  tables: fp32 [1024], 16-byte aligned = q1[256] | mid1[256] | q2[256] | mid2[256] with
+ * q the sorted code book and mid[k] = (q[k] + q[k + 1]) / 2, mid[255] = +inf.  hyper as sdlt_adamw_fused.  Update order as bnb: p += step, then p *= 1 - lr wd. */
+int sdlt_adamw8_shadow_refresh(const sdlt_shadow_desc* descs_dev, const int32_t* block_desc_dev, const int32_t* block_first_dev, int32_t n_blocks, float* p,
+                               const float* g, uint8_t* m8, uint8_t* v8, float* absmax, const float* tables, const float* hyper, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ DoRA
  * Weight-decomposed adapters: peft `LoraConfig(use_dora=True)` as the reference requests it (trainer/optimizer.py:86-95; L1 penalty
  * and weight decay are switched off with it, config.py:153-157).  [3P-unverified: peft 0.10.0 LoraLayer._apply_dora / Conv2d]

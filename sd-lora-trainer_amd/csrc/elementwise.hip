@@ -303,6 +303,246 @@ __global__ __launch_bounds__(256) void shadow_kernel(const sdlt_shadow_desc* des
   }
 }
 
+// ------------------------------------------------------------------ AdamW8bit: block-quantised moments, fused into the refresh tiles
+// bitsandbytes 0.43.1 `AdamW8bit` (trainer/optimizer.py:19-21; the optimizer full_finetuning_example.json names), restated from its published blockwise
+// 8-bit Adam (kOptimizerStatic8bit2StateBlockwise): both moments live as one byte per element - an index into a 256-entry code book ("dynamic" map, signed
+// for m, unsigned for v) - times one fp32 absmax per block of 2048 elements.  Per step and block: dequantise, m = b1 m + (1 - b1) g, v = b2 v + (1 - b2) g^2,
+// new absmax = max |m|, max v over the block, p += -lr sqrt(bc2) / bc1 * m / (sqrt(v) + sqrt(bc2) eps), then p *= 1 - lr wd, requantise m / absmax and
+// v / absmax to the nearest code (m keeps its sign: a code of the other sign moves one step towards it).
+// Here a block is one half of a 64 x 64 refresh tile (32 rows x 64 columns = 2048 elements of the weight's [N, K] view) instead of 2048 consecutive elements of
+// the flattened tensor: the tile is the unit this pass already owns (fp32 master in, W and W^T bf16 out), so the whole optimizer step stays ONE pass
+// - p, g 4 B + m, v 1 B in, p 4 B + m, v 1 B + two bf16 copies out = 20 B per parameter instead of 32 B with fp32 moments.
+// tables (fp32, device): q1[256] | mid1[256] | q2[256] | mid2[256], mid[k] = (q[k] + q[k + 1]) / 2, mid[255] = +inf.  absmax: [n_blocks][4] = {m rows 0-31, m rows 32-63,
+// v rows 0-31, v rows 32-63}.  The nearest code is found from the code book's structure (decade i holds 2^i (signed) / 2^(i+1) (unsigned) equally spaced values in
+// 10^(i-6) [0.1, 1]: q8_guess) and corrected by at most one step against the two neighbouring midpoints (q8_fix): two LDS reads instead of bnb's eight-step search.
+template <bool SIGNED>
+__device__ __forceinline__ int q8_guess(float x) {
+  const float a = fabsf(x);
+  const float L = __builtin_amdgcn_logf(fmaxf(a, 1e-7f)) * 0.30102999566f + 7.f;          // log10(a) + 7 in [0, 7]
+  int i = (int)L;
+  i = i > 6 ? 6 : i;
+  const int n = SIGNED ? (1 << i) : (2 << i);
+  // cell j = floor((a 10^(6-i) - 0.1) n / 0.9) = floor(a K - n / 9), K = 10^(6-i) 2^i / 0.9 = exp2(log2(1e6 / 0.9) - i log2(5))   (unsigned book: twice the cells)
+  const float K = __builtin_amdgcn_exp2f((SIGNED ? 20.083571662f : 21.083571662f) - (float)i * 2.321928095f);
+  int j = (int)(a * K - ldexpf(SIGNED ? (1.f / 9.f) : (2.f / 9.f), i));
+  j = j < 0 ? 0 : (j > n - 1 ? n - 1 : j);
+  const int pos = n - 1 + j;
+  return SIGNED ? (x >= 0.f ? 128 + pos : 126 - pos) : pos;               // 0 <= c <= 254: the nearest code or one of its neighbours
+}
+// ... corrected against the midpoints on either side of the guess (up = mid[c], dn = mid[max(c - 1, 0)]); plain integer arithmetic on the comparisons, so that the
+// compiler keeps the two LDS reads unconditional and batched instead of turning a select into a divergent branch per element
+__device__ __forceinline__ int q8_fix(int c, float x, float up, float dn) { return c + (int)(x > up) - (int)((c > 0) & (x <= dn)); }
+
+// FULL: the tile lies inside the tensor (no row / column tests, no clamped addresses)
+template <bool FULL>
+__device__ __forceinline__ void adamw8_tile(const sdlt_shadow_desc& d, int r0, int c0, float* arena, const float* g, uint8_t* m8, uint8_t* v8, float* absmax_blk,
+                                            const float* hyper, const float* tb, float (*red)[4], bf16_t (*tile)[72]) {
+  const int thr = threadIdx.x, wave = thr >> 6, lane = thr & 63;
+  const float4 am = *(const float4*)absmax_blk;
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2 = hyper[6], gs = hyper[8];
+  const float c2 = sqrtf(bc2), step_size = -lr * c2 / bc1, eps2 = c2 * eps, decay = wd > 0.f ? 1.f - lr * wd : 1.f;
+  const int c = c0 + lane;
+  // element (row r0 + 4 k + wave, column c) = tile origin (uniform: a scalar base address) + a 32-bit per-lane offset
+  const int64_t org = d.offset + (int64_t)r0 * d.src_ld + c0;
+  float* pa = arena + org;
+  const float* pg = g + org;
+  uint8_t* pm = m8 + org;
+  uint8_t* pq = v8 + org;
+  const uint32_t lo = (uint32_t)wave * (uint32_t)d.src_ld + lane, rstep = 4u * (uint32_t)d.src_ld;
+  // all 64 requests of the lane first (unconditional; ragged tiles read element 0 of the tensor instead), then the arithmetic
+  float pv[16], gv[16];
+  uint8_t cm[16], cv[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const bool ok = FULL || (r0 + k * 4 + wave < d.rows && c < d.cols);
+    const uint32_t i = ok ? lo + k * rstep : 0u;
+    pv[k] = pa[i]; gv[k] = pg[i]; cm[k] = pm[i]; cv[k] = pq[i];
+  }
+  __syncthreads();                                                  // the tables are in LDS
+  float mn[16], vn[16], mx[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int h = k >> 3;
+    const bool ok = FULL || (r0 + k * 4 + wave < d.rows && c < d.cols);
+    const float gi = gv[k] * gs;
+    float mi = b1 * (tb[cm[k]] * (h ? am.y : am.x)) + (1.f - b1) * gi;
+    float vi = b2 * (tb[512 + cv[k]] * (h ? am.w : am.z)) + (1.f - b2) * gi * gi;
+    if (!ok) mi = vi = 0.f;
+    mn[k] = mi; vn[k] = vi;
+    mx[h] = fmaxf(mx[h], fabsf(mi));
+    mx[2 + h] = fmaxf(mx[2 + h], vi);
+    // (hardware square root and reciprocal, 1 ulp each - bnb's own kernel divides with __fdividef)
+    const float val = (pv[k] + step_size * (mi * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vi) + eps2))) * decay;
+    if (ok) pa[lo + k * rstep] = val;
+    tile[k * 4 + wave][lane] = f2bf(ok ? val : 0.f);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) mx[u] = wave_max(mx[u]);
+  if (lane == 0) *(float4*)&red[wave][0] = (float4){mx[0], mx[1], mx[2], mx[3]};
+  __syncthreads();                                                  // (also: the bf16 tile is complete)
+  float inv[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    mx[u] = fmaxf(fmaxf(red[0][u], red[1][u]), fmaxf(red[2][u], red[3][u]));
+    inv[u] = mx[u] > 0.f ? __builtin_amdgcn_rcpf(mx[u]) : 0.f;
+  }
+  if (thr == 0) *(float4*)absmax_blk = (float4){mx[0], mx[1], mx[2], mx[3]};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {                                     // one block of 2048 (8 elements per lane) at a time: guesses, then ALL midpoint reads, then the codes
+    float x1[8], x2[8], u1[8], d1[8], u2[8], d2[8];
+    int g1[8], g2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      x1[e] = mn[h * 8 + e] * inv[h];
+      x2[e] = vn[h * 8 + e] * inv[2 + h];
+      g1[e] = q8_guess<true>(x1[e]);
+      g2[e] = q8_guess<false>(x2[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      u1[e] = tb[256 + g1[e]]; d1[e] = tb[256 + (g1[e] > 0 ? g1[e] - 1 : 0)];
+      u2[e] = tb[768 + g2[e]]; d2[e] = tb[768 + (g2[e] > 0 ? g2[e] - 1 : 0)];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = h * 8 + e;
+      int q1 = q8_fix(g1[e], x1[e], u1[e], d1[e]);
+      q1 += ((q1 < 127) != (mn[k] < 0.f)) ? (mn[k] > 0.f ? 1 : -1) : 0;   // m keeps its sign (codes below 127 are the negative ones; the code of 0 counts as positive)
+      const int q2 = q8_fix(g2[e], x2[e], u2[e], d2[e]);
+      if (FULL || (r0 + k * 4 + wave < d.rows && c < d.cols)) { pm[lo + k * rstep] = (uint8_t)q1; pq[lo + k * rstep] = (uint8_t)q2; }
+    }
+  }
+}
+
+// The same tile with 16-byte accesses (interior tiles of tensors whose rows are 16-byte aligned - every tile of the SDXL UNet but the ragged edges): a lane owns four consecutive
+// columns of four rows (row = 16 k + 4 wave + lane / 16), i.e. one float4 of p and g and one dword of codes per row instead of four scalar requests each - 28 memory
+// instructions per lane instead of 112, and a quarter of the address arithmetic.
+__device__ __forceinline__ void adamw8_tile_vec(const sdlt_shadow_desc& d, int r0, int c0, float* arena, const float* g, uint8_t* m8, uint8_t* v8, float* absmax_blk,
+                                                const float* hyper, const float* tb, float (*red)[4], bf16_t (*tile)[72]) {
+  const int thr = threadIdx.x, wave = thr >> 6, lane = thr & 63, cq = lane & 15, rq = lane >> 4;
+  const float4 am = *(const float4*)absmax_blk;
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2 = hyper[6], gs = hyper[8];
+  const float c2 = sqrtf(bc2), step_size = -lr * c2 / bc1, eps2 = c2 * eps, decay = wd > 0.f ? 1.f - lr * wd : 1.f;
+  const int64_t org = d.offset + (int64_t)r0 * d.src_ld + c0;
+  float* pa = arena + org;
+  const float* pg = g + org;
+  uint8_t* pm = m8 + org;
+  uint8_t* pq = v8 + org;
+  const uint32_t lo = (uint32_t)(wave * 4 + rq) * (uint32_t)d.src_ld + 4u * cq, rstep = 16u * (uint32_t)d.src_ld;
+  float4 pv[4], gv[4];
+  uint32_t cm[4], cv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t i = lo + k * rstep;
+    pv[k] = *(const float4*)(pa + i); gv[k] = *(const float4*)(pg + i);
+    cm[k] = *(const uint32_t*)(pm + i); cv[k] = *(const uint32_t*)(pq + i);
+  }
+  __syncthreads();                                                  // the tables are in LDS
+  float mn[16], vn[16], mx[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int h = k >> 1;
+    float val[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gi = gv[k][e] * gs;
+      const float mi = b1 * (tb[(cm[k] >> (8 * e)) & 255u] * (h ? am.y : am.x)) + (1.f - b1) * gi;
+      const float vi = b2 * (tb[512 + ((cv[k] >> (8 * e)) & 255u)] * (h ? am.w : am.z)) + (1.f - b2) * gi * gi;
+      mn[k * 4 + e] = mi; vn[k * 4 + e] = vi;
+      mx[h] = fmaxf(mx[h], fabsf(mi));
+      mx[2 + h] = fmaxf(mx[2 + h], vi);
+      val[e] = (pv[k][e] + step_size * (mi * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vi) + eps2))) * decay;
+    }
+    *(float4*)(pa + lo + k * rstep) = (float4){val[0], val[1], val[2], val[3]};
+    *(uint2*)&tile[k * 16 + wave * 4 + rq][4 * cq] = (uint2){pack2bf(val[0], val[1]), pack2bf(val[2], val[3])};
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) mx[u] = wave_max(mx[u]);
+  if (lane == 0) *(float4*)&red[wave][0] = (float4){mx[0], mx[1], mx[2], mx[3]};
+  __syncthreads();                                                  // (also: the bf16 tile is complete)
+  float inv[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    mx[u] = fmaxf(fmaxf(red[0][u], red[1][u]), fmaxf(red[2][u], red[3][u]));
+    inv[u] = mx[u] > 0.f ? __builtin_amdgcn_rcpf(mx[u]) : 0.f;
+  }
+  if (thr == 0) *(float4*)absmax_blk = (float4){mx[0], mx[1], mx[2], mx[3]};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {                                     // one row (four codes of each moment = one dword each) at a time: guesses, then all eight midpoint reads, then the codes
+    const int h = k >> 1;
+    float x1[4], x2[4], u1[4], d1[4], u2[4], d2[4];
+    int g1[4], g2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      x1[e] = mn[k * 4 + e] * inv[h];
+      x2[e] = vn[k * 4 + e] * inv[2 + h];
+      g1[e] = q8_guess<true>(x1[e]);
+      g2[e] = q8_guess<false>(x2[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      u1[e] = tb[256 + g1[e]]; d1[e] = tb[256 + (g1[e] > 0 ? g1[e] - 1 : 0)];
+      u2[e] = tb[768 + g2[e]]; d2[e] = tb[768 + (g2[e] > 0 ? g2[e] - 1 : 0)];
+    }
+    uint32_t w1 = 0, w2 = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int q1 = q8_fix(g1[e], x1[e], u1[e], d1[e]);
+      q1 += ((q1 < 127) != (mn[k * 4 + e] < 0.f)) ? (mn[k * 4 + e] > 0.f ? 1 : -1) : 0;
+      w1 |= (uint32_t)q1 << (8 * e);
+      w2 |= (uint32_t)q8_fix(g2[e], x2[e], u2[e], d2[e]) << (8 * e);
+    }
+    const uint32_t i = lo + k * rstep;
+    *(uint32_t*)(pm + i) = w1; *(uint32_t*)(pq + i) = w2;
+  }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void shadow_adamw8_kernel(const sdlt_shadow_desc* descs, const int32_t* block_desc, const int32_t* block_first, float* arena, const float* g,
+                                                            uint8_t* m8, uint8_t* v8, float* absmax, const float* tables, const float* hyper) {
+  __shared__ bf16_t tile[64][72];
+  __shared__ float tb[1024];
+  __shared__ float red[4][4];
+  const sdlt_shadow_desc d = descs[block_desc[blockIdx.x]];
+  const int t = blockIdx.x - block_first[block_desc[blockIdx.x]];
+  const int tiles_c = (d.cols + 63) >> 6;
+  const int r0 = (t / tiles_c) << 6, c0 = (t % tiles_c) << 6;
+  const int thr = threadIdx.x;
+  ((uint4*)tb)[thr] = ((const uint4*)tables)[thr];
+  const bool full = r0 + 64 <= d.rows && c0 + 64 <= d.cols;
+  if (full && ((d.offset | d.src_ld) & 3) == 0 && ((((uintptr_t)arena | (uintptr_t)g) & 15) | (((uintptr_t)m8 | (uintptr_t)v8) & 3)) == 0)
+    adamw8_tile_vec(d, r0, c0, arena, g, m8, v8, absmax + 4 * (int64_t)blockIdx.x, hyper, tb, red, tile);
+  else if (full) adamw8_tile<true>(d, r0, c0, arena, g, m8, v8, absmax + 4 * (int64_t)blockIdx.x, hyper, tb, red, tile);
+  else adamw8_tile<false>(d, r0, c0, arena, g, m8, v8, absmax + 4 * (int64_t)blockIdx.x, hyper, tb, red, tile);
+  const int q = thr >> 2, ch = (thr & 3) * 16;
+  if (d.dst) {
+    const int r = r0 + q;
+    if (r < d.rows) {
+      bf16_t* p = (bf16_t*)d.dst + (int64_t)r * d.ld + c0 + ch;
+      if (c0 + ch + 16 <= d.cols && (((uintptr_t)p) & 15) == 0) {
+        *(uint4*)p = *(const uint4*)&tile[q][ch];
+        *(uint4*)(p + 8) = *(const uint4*)&tile[q][ch + 8];
+      } else {
+        for (int j = 0; j < 16 && c0 + ch + j < d.cols; ++j) p[j] = tile[q][ch + j];
+      }
+    }
+  }
+  if (d.dstT) {
+    const int cc = c0 + q;
+    if (cc < d.cols) {
+      bf16_t v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = tile[ch + j][q];
+      bf16_t* p = (bf16_t*)d.dstT + (int64_t)cc * d.ldT + r0 + ch;
+      if (r0 + ch + 16 <= d.rows && (((uintptr_t)p) & 15) == 0) {
+        *(uint4*)p = *(const uint4*)&v[0];
+        *(uint4*)(p + 8) = *(const uint4*)&v[8];
+      } else {
+        for (int j = 0; j < 16 && r0 + ch + j < d.rows; ++j) p[j] = v[j];
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ out = a + b on strided [M,C] views
 __global__ void add2d_kernel(const bf16_t* a, int64_t lda, const bf16_t* b, int64_t ldb, bf16_t* out, int64_t ldo, int M, int C) {
   const int nch = C >> 3;
@@ -451,6 +691,14 @@ extern "C" int sdlt_adamw_shadow_refresh(const sdlt_shadow_desc* descs_dev, cons
                                          int32_t n_blocks, float* p, const float* g, float* m, float* v, const float* hyper, void* stream) {
   if (n_blocks <= 0 || !p || !g || !m || !v || !hyper) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_adamw_shadow_refresh: n_blocks=%d or a null buffer", n_blocks);
   hipLaunchKernelGGL(shadow_kernel<true>, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, block_desc_dev, block_first_dev, p, g, m, v, hyper);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+extern "C" int sdlt_adamw8_shadow_refresh(const sdlt_shadow_desc* descs_dev, const int32_t* block_desc_dev, const int32_t* block_first_dev, int32_t n_blocks, float* p,
+                                          const float* g, uint8_t* m8, uint8_t* v8, float* absmax, const float* tables, const float* hyper, void* stream) {
+  if (n_blocks <= 0 || !p || !g || !m8 || !v8 || !absmax || !tables || !hyper) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_adamw8_shadow_refresh: n_blocks=%d or a null buffer", n_blocks);
+  if ((((uintptr_t)absmax | (uintptr_t)tables) & 15) != 0) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_adamw8_shadow_refresh: absmax / tables must be 16-byte aligned");
+  hipLaunchKernelGGL(shadow_adamw8_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, block_desc_dev, block_first_dev, p, g, m8, v8, absmax, tables, hyper);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }

@@ -34,6 +34,7 @@ class WeightTrainer:
         self._binds = []           # callables run at finalize (point layer attributes at arena views)
         self._shadow = []          # ShadowPlan descriptors (offset, rows, cols, src_ld, dst, dstT)
         self.params = self.grads = self.m = self.v = None
+        self.q8 = None             # AdamW8bit: (m8, v8, absmax, tables), see enable_8bit
         self.registering = False   # True only while the UNet builds its layers (the text encoders share the leaf classes)
         # Deferred, batched weight gradients: the leaf layers only RECORD (weight, inputs, dY) during the first backward; flush()
         # at the end of every backward issues all layers of one shape together - one panel launch per operand and one batched
@@ -126,9 +127,27 @@ class WeightTrainer:
         (sdlt_adamw_shadow_refresh: p, g, m, v -> p, m, v, W, W^T), the vector region (biases, norm affine: used in fp32) with
         sdlt_adamw_fused."""
         ops, nm = self.rt.ops, self.n_mat
+        if self.q8 is not None:           # AdamW8bit: byte moments for the matrices, fp32 moments for the vector region
+            m8, v8, absmax, tables = self.q8
+            self._plan.adamw8(self.params[:nm], self.grads[:nm], m8, v8, absmax, tables, hyper)
+            if self.nv:
+                ops.adamw_fused(self.params[nm:], self.grads[nm:], self.m_vec, self.v_vec, hyper, None)
+            return
         self._plan.adamw(self.params, self.grads, self.m, self.v, hyper)
         if self.nv:
             ops.adamw_fused(self.params[nm:], self.grads[nm:], self.m[nm:], self.v[nm:], hyper, None)
+
+    def enable_8bit(self):
+        """`unet_optimizer_type: AdamW8bit` (trainer/optimizer.py:19-21, full_finetuning_example.json): the moments of every matrix / conv weight as one byte per
+        element + one fp32 absmax per 2048-element block (include/sdlt_kernels.h: sdlt_adamw8_shadow_refresh) - 2 x 10.3 GB of fp32 moments become 2 x 2.6 GB on
+        SDXL and the optimizer pass moves 20 instead of 32 bytes per parameter.  The vector region (biases, norm affine parameters: 0.1 % of the arena) keeps fp32
+        moments: bitsandbytes does the same for every tensor under 4096 elements, and quantises the 140 GEGLU / conv biases above that size, which stay fp32 here."""
+        assert self.params is not None and self.m is not None and self._plan is not None
+        nm, dev = self.n_mat, self.rt.device
+        self.m_vec, self.v_vec = self.m[nm:].clone(), self.v[nm:].clone()
+        self.m = self.v = None
+        self.q8 = (torch.zeros(nm, dtype=torch.uint8, device=dev), torch.zeros(nm, dtype=torch.uint8, device=dev),
+                   torch.zeros(4 * self._plan.n_blocks, dtype=F32, device=dev), self.rt.ops.q8_tables(dev))
 
     # ------------------------------------------------------------------ sharded optimizer state (data parallel, ZeRO-1)
     def enable_zero1(self, rank, world):
@@ -157,6 +176,8 @@ class WeightTrainer:
         return o0 + self.z_rank * c, o0 + (self.z_rank + 1) * c
 
     def opt_state(self):
+        if self.q8 is not None:
+            return [self.q8[0], self.q8[1], self.q8[2], self.m_vec, self.v_vec]
         return [self.m, self.v] if self.m is not None else [self.m_sh, self.v_sh, self.m_vec, self.v_vec]
 
     def adamw_shard_step(self, hyper):

@@ -1232,6 +1232,45 @@ def _shadow_adamw(self, p, g, m, v, hyper):
 ShadowPlan.adamw = _shadow_adamw
 
 
+def dynamic_code_book(signed):
+    """The 256-entry "dynamic" code book of bitsandbytes' 8-bit optimizers (bitsandbytes 0.43.1 functional.create_dynamic_map with its defaults: 7 exponent
+    bits, 8 bits in all), sorted: decade i = 0..6 holds 2^i (signed; 2^(i+1) unsigned) values - the midpoints of an even split of [0.1, 1] - scaled by
+    10^(i-6), mirrored for the signed book, plus 0 and 1.  The fp32 values follow the recipe's own arithmetic (linspace, means and the scaling all in fp32) so that the indices mean the same numbers as in the reference's optimizer state."""
+    vals = []
+    for i in range(7):
+        edges = torch.linspace(0.1, 1, (2 ** i if signed else 2 ** (i + 1)) + 1)
+        scaled = (10 ** (i - 6)) * ((edges[:-1] + edges[1:]) / 2.0)
+        vals += scaled.tolist()
+        if signed:
+            vals += (-scaled).tolist()
+    vals += [0.0, 1.0]
+    assert len(vals) == 256
+    return torch.tensor(sorted(vals), dtype=F32)
+
+
+def q8_tables(device):
+    """q1 | mid1 | q2 | mid2 for sdlt_adamw8_shadow_refresh (mid[k] = (q[k] + q[k+1]) / 2 in fp32, mid[255] = +inf)."""
+    parts = []
+    for signed in (True, False):
+        q = dynamic_code_book(signed)
+        parts += [q, torch.cat([(q[:-1] + q[1:]) * 0.5, torch.tensor([float("inf")])])]
+    return torch.cat(parts).to(device)
+
+
+def _shadow_adamw8(self, p, g, m8, v8, absmax, tables, hyper):
+    """AdamW8bit step fused into the refresh tiles (sdlt_adamw8_shadow_refresh): one block of 2048 moments = half a tile."""
+    lib = _lib.load()
+    for t in (p, g, absmax, tables, hyper):
+        _chk2(t, F32)
+    assert m8.dtype == torch.uint8 and v8.dtype == torch.uint8 and m8.numel() >= p.numel() and v8.numel() >= p.numel()
+    assert absmax.numel() == 4 * self.n_blocks and tables.numel() == 1024 and absmax.is_contiguous() and tables.is_contiguous()
+    _lib.check(lib.sdlt_adamw8_shadow_refresh(_p(self.descs_dev), _p(self.block_desc_dev), _p(self.block_first_dev), self.n_blocks, _p(p), _p(g), _p(m8), _p(v8),
+                                              _p(absmax), _p(tables), _p(hyper), _stream()), "sdlt_adamw8_shadow_refresh")
+
+
+ShadowPlan.adamw8 = _shadow_adamw8
+
+
 def add2d(a, b, out):
     lib = _lib.load()
     _chk2(a), _chk2(b), _chk2(out)

@@ -195,9 +195,11 @@ class TrainStep:
                  cond_reg_w=0.0, tok_cov_reg_w=0.0, cond_target_norm=None, tok_cond_reg_w=0.0, reg_caption_ids=None, ddp_wire_dtype=None, ddp_zero1=None, ddp_force=False):
         """process_group: data-parallel full fine-tune only (`unet.trainer` set) - a torch.distributed group (or True for the
         default one) over which the gradient arena is all-reduced once per optimiser step (RCCL on the GPU)."""
-        if optimizer == "AdamW8bit":
-            # bitsandbytes' AdamW8bit (optimizer.py:19-21, the full fine-tune example) is AdamW with block-quantised moments, a
-            # memory saving for 24 GB cards; with 288 GB the fp32 moments of all 2.57 G parameters fit (31 GB), so it runs as AdamW
+        adam8 = optimizer == "AdamW8bit"
+        if adam8:
+            # bitsandbytes' AdamW8bit (optimizer.py:19-21, the full fine-tune example) is AdamW with block-quantised moments.  Full fine-tune on one GPU (or
+            # data parallel with the all-reduce exchange): the matrices' moments are held that way (fullft.WeightTrainer.enable_8bit - 12 fewer bytes per
+            # parameter and step).  LoRA / TI groups (a few MB) and the sharded optimizer (ZeRO-1: 1 / world of the moments per rank) keep fp32 moments.
             optimizer = "adamw"
         if optimizer not in ("adamw", "prodigy"):
             raise NotImplementedError(f"Invalid optimizer_name for unet: {optimizer}")
@@ -240,6 +242,9 @@ class TrainStep:
             self.zero1 = bool(z) and self.bucketed and optimizer == "adamw"
             if self.zero1:
                 unet.trainer.enable_zero1(dist.get_rank(self.pg), self.world)
+        self.adam8 = adam8 and self.full_ft and not getattr(self, "zero1", False) and os.environ.get("SDLT_ADAM8", "1") != "0"
+        if self.adam8:
+            unet.trainer.enable_8bit()
             # Prodigy under data parallelism: its step-size estimate d is built from sums of g . (p0 - p) and |s| and is not invariant to the
             # gradient's scale, so the SUMMED gradients are turned into the mean (one in-place multiply) before its two passes - the state every
             # rank then holds is the state of one process on the whole batch; AdamW takes the mean through its hyper row instead (no extra pass).

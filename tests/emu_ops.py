@@ -651,6 +651,37 @@ def _shadow_adamw(self, p, g, m, v, hyper):
 ShadowPlan.adamw = _shadow_adamw
 
 
+def q8_tables(device):
+    from oracle import adam8bit_ref as A8
+    parts = []
+    for q in A8.maps():
+        parts += [q, torch.cat([(q[:-1] + q[1:]) * 0.5, torch.tensor([float("inf")])])]
+    return torch.cat(parts).to(device)
+
+
+def _shadow_adamw8(self, p, g, m8, v8, absmax, tables, hyper):
+    """sdlt_adamw8_shadow_refresh through the oracle's AdamW8bit (same block shape and absmax layout), then the refresh."""
+    from oracle import adam8bit_ref as A8
+    lr, b1, b2, eps, wd, bc1, bc2, _, gs = [float(x) for x in hyper[:9]]
+    step = max(1, round(math.log(max(1.0 - bc1, 1e-300)) / math.log(b1)))
+    nb = 0
+    for (off, rows, cols, src_ld, dst, dstT) in self.entries:
+        pv, gv, mv, vv = [torch.as_strided(t, (rows, cols), (src_ld, 1), off) for t in (p, g, m8, v8)]
+        blocks = ((rows + 63) // 64) * ((cols + 63) // 64)
+        st = A8.Adam8State(rows, cols)
+        st.m8, st.v8 = mv.clone(), vv.clone()
+        st.set_tile_absmax(absmax[4 * nb: 4 * (nb + blocks)])
+        pv.copy_(A8.adamw8_step(pv.clone(), gv, st, lr=lr, beta1=b1, beta2=b2, eps=eps, weight_decay=wd, step=step, grad_scale=gs))
+        mv.copy_(st.m8), vv.copy_(st.v8)
+        absmax[4 * nb: 4 * (nb + blocks)] = st.tile_absmax().reshape(-1)
+        nb += blocks
+    self.run(p)
+
+
+ShadowPlan.adamw8 = _shadow_adamw8
+ShadowPlan.n_blocks = property(lambda self: sum(((r + 63) // 64) * ((c + 63) // 64) for (_, r, c, _, _, _) in self.entries))
+
+
 def add2d(a, b, out):
     out.copy_((a.float() + b.float()).to(out.dtype))
     return out

@@ -30,7 +30,7 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tm
 python $R/tools/step_profile.py $T15 $(ls /tmp/pmc15_f/*/*counter_collection.csv | head -1) $(ls /tmp/pmc15_w/*/*counter_collection.csv | head -1) \
   $O/r05_sd15_512_b4_step_profile.json $O/r05_sd15_512_b4_per_kernel.csv $C "python bench.py --config sd15 $B" > /dev/null 2> $O/step_profile_sd15.err
 cd $R
-for v in "--no-ti" "--ti-frozen" "--config sd15" "--full-ft" "--rank 64" "--jobs-per-gpu 2" "--dora" "--config sd15 --full-ft"; do
+for v in "--no-ti" "--ti-frozen" "--config sd15" "--full-ft" "--full-ft --fp32-moments" "--rank 64" "--jobs-per-gpu 2" "--dora" "--config sd15 --full-ft"; do
   timeout 600 python bench.py $v $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', round(d['ms_per_step'],2), round(d['value'],2), round(d['roofline']['frac'],4))" >> $O/r05_bench_variants.txt
 done
 timeout 900 python bench.py --profile-json $O/r05_sdxl1024_ti_step_profile.json > $O/r05_bench_line.json 2> $O/bench_default.err
