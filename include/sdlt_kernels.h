@@ -247,8 +247,19 @@ typedef struct sdlt_groupnorm_params {
   float* ws; int64_t ws_floats;
   int32_t* cnt; int32_t cnt_len;
   int32_t pad_;
+  /* bwd only, optional side output: the column sums over each image's pixels of dx (as stored, bf16-rounded) - the gradient of a per-image bias added in front of
+     this norm (ResnetBlock2D: time_emb_proj(silu(emb)) in front of norm2; was sdlt_colsum over the stored gradient).  Every block leaves its partial sums in
+     colsum_ws[(split * B + b) * C + c], split < nsplit = sdlt_groupnorm_ws_floats(B, HW, C) / (B * C): fp32 [nsplit][B][C], persistent until
+     sdlt_colsum_finish_batch has added the splits (one launch for all norms of a step). */
+  float* colsum_ws;
 } sdlt_groupnorm_params;
 int sdlt_groupnorm_ws_floats(int32_t B, int32_t HW, int32_t C);
+/* out[i] = sum_{split < nsplit} ws[split * n + i] (fixed order: bitwise reproducible) for n_desc reductions in one launch; out32 (fp32) and / or out16 (bf16), max_n = the largest n. */
+typedef struct sdlt_colsum_finish_desc {
+  const float* ws; float* out32; void* out16;
+  int32_t nsplit, n;
+} sdlt_colsum_finish_desc;
+int sdlt_colsum_finish_batch(const sdlt_colsum_finish_desc* descs_dev, int32_t n_desc, int32_t max_n, void* stream);
 int sdlt_groupnorm_fwd(const sdlt_groupnorm_params* p, void* stream);
 int sdlt_groupnorm_bwd(const sdlt_groupnorm_params* p, void* stream);
 

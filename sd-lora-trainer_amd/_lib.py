@@ -109,7 +109,12 @@ class GroupNormParams(C.Structure):
         ("bstats", vp),
         ("ws", vp), ("ws_floats", i64),
         ("cnt", vp), ("cnt_len", i32), ("pad_", i32),
+        ("colsum_ws", vp),
     ]
+
+
+class ColsumFinishDesc(C.Structure):
+    _fields_ = [("ws", vp), ("out32", vp), ("out16", vp), ("nsplit", i32), ("n", i32)]
 
 
 class StripParams(C.Structure):
@@ -151,6 +156,7 @@ SYMBOLS = {
     "sdlt_attn_bwd": (i32, [C.POINTER(AttnParams), vp]),
     "sdlt_attn_splitsum_batch": (i32, [vp, vp, vp, i32, vp]),
     "sdlt_groupnorm_ws_floats": (i32, [i32, i32, i32]),
+    "sdlt_colsum_finish_batch": (i32, [vp, i32, i32, vp]),
     "sdlt_groupnorm_fwd": (i32, [C.POINTER(GroupNormParams), vp]),
     "sdlt_groupnorm_bwd": (i32, [C.POINTER(GroupNormParams), vp]),
     "sdlt_layernorm_fwd": (i32, [vp, i64, i32, i32, vp, vp, f32, vp, i64, vp, vp]),
@@ -235,7 +241,7 @@ def struct_sizes():
     ops.py packs with `struct` (8 / 3 pointers) are listed by their packed size."""
     mirrored = (GemmParams, LoraGradDesc, AttnParams, GroupNormParams, ShadowDesc, GemmBatchItem, DoraDesc, DoraWtDesc, DoraGradDesc, SplitsumDesc, StripParams,
                 TaParams, LnSlabsParams, TaGroup)
-    return [(c.__name__, C.sizeof(c)) for c in mirrored] + [("sdlt_affine_grad_item", 8 * 8), ("sdlt_wgrad_tr_item", 3 * 8), ("LnFoldDesc", C.sizeof(LnFoldDesc))]
+    return [(c.__name__, C.sizeof(c)) for c in mirrored] + [("sdlt_affine_grad_item", 8 * 8), ("sdlt_wgrad_tr_item", 3 * 8), ("LnFoldDesc", C.sizeof(LnFoldDesc)), ("ColsumFinishDesc", C.sizeof(ColsumFinishDesc))]
 
 
 def check(rc, what):

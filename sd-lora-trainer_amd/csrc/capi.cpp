@@ -37,6 +37,7 @@ extern "C" int sdlt_struct_size(int which) {
     case 14: return (int)sizeof(sdlt_affine_grad_item);
     case 15: return (int)sizeof(sdlt_wgrad_tr_item);
     case 16: return (int)sizeof(sdlt_ln_fold_desc);
+    case 17: return (int)sizeof(sdlt_colsum_finish_desc);
   }
   return -1;
 }

@@ -280,7 +280,7 @@ template <bool SILU>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(CatIn in, const bf16_t* dy, int64_t lddy, int HW, int C,
                                                             const float* stats, float* bstats_out, const float* ws, const float* gamma,
                                                             const float* beta, float eps, const bf16_t* dres, int64_t lddres,
-                                                            bf16_t* dx, int64_t lddx) {
+                                                            bf16_t* dx, int64_t lddx, float* csws) {
   __shared__ float bstats[G * 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z;
@@ -310,6 +310,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(CatIn in, const bf16_
     m1[j] = bstats[g * 2] * inv_n;
     m2[j] = bstats[g * 2 + 1] * inv_n;
   }
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   while (r < HW) {
     const uint4 xc = xn, dc = dn, oc = on;
     const int64_t row = (int64_t)b * HW + r;
@@ -332,6 +333,36 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(CatIn in, const bf16_
       o[j] = (dres ? bf2f((j & 1) ? (ow[j >> 1] >> 16) : (ow[j >> 1] & 0xffff)) : 0.f) + rstd[j] * (dxh - m1[j] - xh * m2[j]);
     }
     store8(dx + row * lddx + c0, o);
+    if (csws) {      // column sums of the rows as they were stored (bf16-rounded), see below
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cs[j] += bf2f(f2bf(o[j]));
+    }
+  }
+  // Side output (ResnetBlock2D: the time-embedding projection is added per image in front of norm2, so its gradient is the column sum over the pixels of this
+  // kernel's output): every block leaves the column sums of its rows in csws[(split * B + b) * C + c] - plain stores, no atomics; sdlt_colsum_finish_batch adds
+  // the splits in a fixed order for all resnets of the step in one launch (were two launches per resnet: sdlt_colsum over the stored gradient + its finish).
+  if (csws) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) cs[j] += __shfl_xor(cs[j], o, 64);
+    __shared__ float csh[4][64];
+    if ((lane >> 3) == 0)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) csh[wave][(lane & 7) * 8 + j] = cs[j];
+    __syncthreads();
+    if (tid < 64) csws[((int64_t)blockIdx.y * gridDim.z + b) * C + blockIdx.x * 64 + tid] = (csh[0][tid] + csh[1][tid]) + (csh[2][tid] + csh[3][tid]);
+  }
+}
+
+// one launch for many column-sum reductions: out[i] = sum over the splits (in order) of ws[split * n + i]
+__global__ __launch_bounds__(256) void colsum_finish_batch_kernel(const sdlt_colsum_finish_desc* descs) {
+  const sdlt_colsum_finish_desc d = descs[blockIdx.y];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += gridDim.x * 256) {
+    float a = 0.f;
+    for (int sp = 0; sp < d.nsplit; ++sp) a += d.ws[(int64_t)sp * d.n + i];
+    if (d.out32) d.out32[i] = a;
+    if (d.out16) ((bf16_t*)d.out16)[i] = f2bf(a);
   }
 }
 
@@ -589,11 +620,20 @@ extern "C" int sdlt_groupnorm_bwd(const sdlt_groupnorm_params* pp, void* stream)
   if (rc) return rc;
   if (p.silu) {
     hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.gamma, p.beta, p.eps, p.ws);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.bstats, p.ws, p.gamma, p.beta, p.eps, (const bf16_t*)p.dres, p.lddres, (bf16_t*)p.dx, p.lddx);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.bstats, p.ws, p.gamma, p.beta, p.eps, (const bf16_t*)p.dres, p.lddres, (bf16_t*)p.dx, p.lddx, p.colsum_ws);
   } else {
     hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.gamma, p.beta, p.eps, p.ws);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.bstats, p.ws, p.gamma, p.beta, p.eps, (const bf16_t*)p.dres, p.lddres, (bf16_t*)p.dx, p.lddx);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, grid, dim3(256), 0, s, in, (const bf16_t*)p.dy, p.lddy, p.HW, p.C, p.stats, p.bstats, p.ws, p.gamma, p.beta, p.eps, (const bf16_t*)p.dres, p.lddres, (bf16_t*)p.dx, p.lddx, p.colsum_ws);
   }
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+
+extern "C" int sdlt_colsum_finish_batch(const sdlt_colsum_finish_desc* descs_dev, int32_t n_desc, int32_t max_n, void* stream) {
+  if (n_desc <= 0) return SDLT_OK;
+  if (!descs_dev || max_n <= 0) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_colsum_finish_batch: descs == NULL or max_n=%d", max_n);
+  int gx = (max_n + 255) / 256;
+  hipLaunchKernelGGL(colsum_finish_batch_kernel, dim3(gx > 16 ? 16 : gx, n_desc), dim3(256), 0, (hipStream_t)stream, descs_dev);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }

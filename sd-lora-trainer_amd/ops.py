@@ -840,11 +840,21 @@ def groupnorm_fwd(x1, x2, y, stats, *, B, HW, gamma, beta, eps, silu, stats_zero
     return y
 
 
-def groupnorm_bwd(x1, x2, dy, dx, stats, bstats, *, B, HW, gamma, beta, eps, silu, dres=None, stats_zeroed=False):
+def groupnorm_colsum_splits(B, HW, Cc):
+    """Row splits of the GroupNorm kernels' grid = the number of partial rows sdlt_groupnorm_bwd leaves in `colsum_ws` (fp32 [splits][B][C])."""
+    return int(_lib.load().sdlt_groupnorm_ws_floats(B, HW, Cc)) // (B * Cc)
+
+
+def groupnorm_bwd(x1, x2, dy, dx, stats, bstats, *, B, HW, gamma, beta, eps, silu, dres=None, stats_zeroed=False, colsum_ws=None):
+    """colsum_ws (fp32, groupnorm_colsum_splits(...) * B * C floats, optional): partial column sums of dx per image, finished by ColsumFinishPlan.run()."""
     lib = _lib.load()
     p = _gn_params(x1, x2, B, HW, gamma, beta, eps, silu, stats)
     _chk2(dy), _chk2(dx), _chk2(bstats, F32)
     p.dy, p.lddy, p.dx, p.lddx, p.bstats = _p(dy), _ld(dy), _p(dx), _ld(dx), _p(bstats)
+    if colsum_ws is not None:
+        _chk2(colsum_ws, F32)
+        assert colsum_ws.is_contiguous() and colsum_ws.numel() >= groupnorm_colsum_splits(B, HW, p.C) * B * p.C
+        p.colsum_ws = _p(colsum_ws)
     if dres is not None:
         _chk2(dres)
         p.dres, p.lddres = _p(dres), _ld(dres)
@@ -1285,6 +1295,28 @@ def sum2x2(inp, out, *, B, H, W):
     assert inp.is_contiguous() and out.is_contiguous()
     _lib.check(lib.sdlt_sum2x2(_p(inp), B, H, W, inp.shape[1], _p(out), _stream()), "sdlt_sum2x2")
     return out
+
+
+class ColsumFinishPlan:
+    """Descriptor table of sdlt_colsum_finish_batch: items = [(ws fp32 [nsplit * n], nsplit, out fp32 or bf16 [n])] - all reductions in one launch."""
+
+    def __init__(self, items, device):
+        descs = (_lib.ColsumFinishDesc * len(items))()
+        self.keep, self.max_n = items, 0
+        for d, (ws, nsplit, out) in zip(descs, items):
+            _chk2(ws, F32)
+            assert ws.is_contiguous() and out.is_contiguous() and out.is_cuda and out.dtype in (F32, BF16) and ws.numel() >= nsplit * out.numel()
+            d.ws, d.nsplit, d.n = ws.data_ptr(), nsplit, out.numel()
+            if out.dtype == F32:
+                d.out32 = out.data_ptr()
+            else:
+                d.out16 = out.data_ptr()
+            self.max_n = max(self.max_n, out.numel())
+        self.n = len(items)
+        self.descs_dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(device)
+
+    def run(self):
+        _lib.check(_lib.load().sdlt_colsum_finish_batch(_p(self.descs_dev), self.n, self.max_n, _stream()), "sdlt_colsum_finish_batch")
 
 
 _colsum_scratch = {}

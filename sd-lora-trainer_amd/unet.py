@@ -740,7 +740,8 @@ class GroupNorm(_Module):
         return self.rt.ops.groupnorm_fwd(x1, x2, y, stats, B=B, HW=HW, gamma=self.gamma, beta=self.beta, eps=self.eps, silu=self.silu,
                                          stats_zeroed=self.rt.gn_prezero)
 
-    def backward(self, dy, dres=None, out=None):
+    def backward(self, dy, dres=None, out=None, colsum_ws=None):
+        """colsum_ws: see ops.groupnorm_bwd (the per-image column sums of dx as a side output of the apply kernel)."""
         x1, x2, B, HW = self._in
         dx = out if out is not None else self.buf("dx", B * HW, self.C)
         if self.trainer is not None:
@@ -749,7 +750,8 @@ class GroupNorm(_Module):
         if "bstats" not in self._b:
             self._b["bstats"] = self.rt.gn_stats("bwd", B * 64)
         return self.rt.ops.groupnorm_bwd(x1, x2, dy, dx, self._b["stats"], self._b["bstats"], B=B, HW=HW,
-                                         gamma=self.gamma, beta=self.beta, eps=self.eps, silu=self.silu, dres=dres, stats_zeroed=self.rt.gn_prezero)
+                                         gamma=self.gamma, beta=self.beta, eps=self.eps, silu=self.silu, dres=dres, stats_zeroed=self.rt.gn_prezero,
+                                         **({"colsum_ws": colsum_ws} if colsum_ws is not None else {}))
 
 
 # SDLT_LN_NOOP (bit 0: forward, bit 1: backward): a TIMING-ONLY switch that skips the UNet's LayerNorm launches - the upper bound of what folding
@@ -757,6 +759,7 @@ class GroupNorm(_Module):
 _LN_NOOP = int(os.environ.get("SDLT_LN_NOOP", "0"))
 
 
+COLSUM_FUSED = os.environ.get("SDLT_COLSUM_FUSED", "1") != "0"      # time-embedding column sums as a side output of norm2's backward (A/B switch)
 LN_FOLD = int(os.environ.get("SDLT_LN_FOLD", "7"))      # bit 0: norm1 -> to_q|to_k|to_v, bit 1: norm2 -> attn2.to_q, bit 2: norm3 -> ff.net.0.proj (A/B switch)
 
 
@@ -1075,12 +1078,14 @@ class ResnetBlock(_Module):
         rt = self.rt
         x1, x2, B, H, W = self._in
         dh2 = self.conv2.backward(dout)
-        dc1 = self.norm2.backward(dh2)
-        if rt.want_dpooled or self.temb.trainer is not None:
-            # h = conv1(.) + time_emb_proj(silu(emb))[b]: d(proj output)[b] = column sums of dc1 over the pixels of image b;
-            # accumulated over all resnets into d silu(emb)
-            slot = getattr(self, "_dtp_slot", None)
-            if slot is not None:            # stacked: one GEMM for all resnets at the end of UNet._backward
+        # h = conv1(.) + time_emb_proj(silu(emb))[b]: d(proj output)[b] = column sums of dc1 over the pixels of image b, accumulated over all resnets into
+        # d silu(emb).  Stacked (batch 1): norm2's backward leaves the partial sums as a side output, ONE launch finishes them for all resnets and one GEMM
+        # applies the projection at the end of UNet._backward (were a column-sum launch and its finish per resnet)
+        slot = getattr(self, "_dtp_slot", None) if (rt.want_dpooled or self.temb.trainer is not None) else None
+        fused = slot is not None and COLSUM_FUSED
+        dc1 = self.norm2.backward(dh2, colsum_ws=self._dtp_ws if fused else None)
+        if (rt.want_dpooled or self.temb.trainer is not None) and not fused:
+            if slot is not None:
                 rt.ops.colsum(dc1, slot, B=B, R=H * W)
             else:
                 dtp = rt.ops.colsum(dc1, self.buf("dtp", B, self.cout), B=B, R=H * W)
@@ -1311,8 +1316,15 @@ class UNet(_Module):
             rt.dsemb.zero_()
             if self.temb_W is not None and "dtp_all" not in self._b:
                 dtp_all = self.buf("dtp_all", B, self.temb_W.shape[0], zero=True)
+                items = []
                 for r in self.resnets:      # [B, cout] slices are contiguous only for B == 1 (sdlt_colsum writes a dense [B, C])
                     r._dtp_slot = dtp_all[:, r.temb_off: r.temb_off + r.cout] if B == 1 else None
+                    if B == 1 and COLSUM_FUSED:
+                        _, _, _, Hr, Wr = r._in
+                        ns = rt.ops.groupnorm_colsum_splits(B, Hr * Wr, r.cout)
+                        r._dtp_ws = torch.zeros(ns * B * r.cout, dtype=F32, device=rt.device)
+                        items.append((r._dtp_ws, ns, r._dtp_slot.reshape(-1)))
+                self._dtp_plan = rt.ops.ColsumFinishPlan(items, rt.device) if items else None
         dh = self.norm_out.backward(self.conv_out.backward(dpred64))
         skip_grads = []
         nlev = len(boc)
@@ -1347,6 +1359,8 @@ class UNet(_Module):
         if tr is not None:
             self.conv_in.weight_grad(self._add(dh, pop_skip(), ("cin",)))
         if rt.want_dpooled and self.temb_W is not None and B == 1:
+            if getattr(self, "_dtp_plan", None) is not None:
+                self._dtp_plan.run()
             rt.ops.gemm(self._b["dtp_all"], self.temb_Wt, rt.dsemb)          # dsemb = sum over the resnets of colsum(dc1) . W_temb
         if rt.want_dpooled or tr is not None:
             # emb = time_embedding(t) + add_embedding([pooled | sinusoid(time_ids)]); with LoRA only the pooled text embedding is

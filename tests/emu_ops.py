@@ -374,7 +374,20 @@ def groupnorm_fwd(x1, x2, y, stats, *, B, HW, gamma, beta, eps, silu, stats_zero
     return y
 
 
-def groupnorm_bwd(x1, x2, dy, dx, stats, bstats, *, B, HW, gamma, beta, eps, silu, dres=None, stats_zeroed=False):
+def groupnorm_colsum_splits(B, HW, Cc):
+    return 2          # (the emulation always leaves two partial rows: the sums of the even and of the odd pixels)
+
+
+class ColsumFinishPlan:
+    def __init__(self, items, device):
+        self.items = items
+
+    def run(self):
+        for ws, nsplit, out in self.items:
+            out.copy_(ws[: nsplit * out.numel()].view(nsplit, -1).sum(0).to(out.dtype))
+
+
+def groupnorm_bwd(x1, x2, dy, dx, stats, bstats, *, B, HW, gamma, beta, eps, silu, dres=None, stats_zeroed=False, colsum_ws=None):
     x = _gn_cat(x1, x2).detach().clone().requires_grad_(True)
     C = x.shape[1]
     z = F.group_norm(x.reshape(B, HW, C).permute(0, 2, 1), 32, gamma.float(), beta.float(), eps)
@@ -384,6 +397,9 @@ def groupnorm_bwd(x1, x2, dy, dx, stats, bstats, *, B, HW, gamma, beta, eps, sil
     if dres is not None:
         g = g + dres.float()
     dx.copy_(g.to(dx.dtype))
+    if colsum_ws is not None:      # [split][B][C] partial column sums of the stored rows
+        r = dx.float().reshape(B, HW, C)
+        colsum_ws[: 2 * B * C].view(2, B, C).copy_(torch.stack([r[:, 0::2].sum(1), r[:, 1::2].sum(1)]))
     return dx
 
 

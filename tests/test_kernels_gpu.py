@@ -701,6 +701,22 @@ def test_groupnorm_fwd_bwd(ops, B, HW, C1, C2, silu):
         y2 = ops.groupnorm_fwd(x1d, x2d, torch.empty(B * HW, C, dtype=BF, device="cuda"), st2, gamma=gd, beta=bd, **kw)
         dx2 = ops.groupnorm_bwd(x1d, x2d, dyd, torch.empty(B * HW, C, dtype=BF, device="cuda"), st2, bst2, gamma=gd, beta=bd, dres=drd, **kw)
         assert torch.equal(st2, stats) and torch.equal(bst2, bstats) and torch.equal(y2, y) and torch.equal(dx2, dx), f"GroupNorm not reproducible (rep {rep})"
+    # side output: per-image column sums of the STORED gradient (the time-embedding projection's gradient in a ResnetBlock2D), finished for several norms in one
+    # launch; equal to sdlt_colsum over dx up to the order of the fp32 additions, bitwise reproducible, dx itself unchanged
+    ns = ops.groupnorm_colsum_splits(B, HW, C)
+    ws = torch.full((ns * B * C,), float("nan"), device="cuda")
+    dx3 = ops.groupnorm_bwd(x1d, x2d, dyd, torch.empty(B * HW, C, dtype=BF, device="cuda"), stats, bstats, gamma=gd, beta=bd, dres=drd, colsum_ws=ws, **kw)
+    assert torch.equal(dx3, dx)
+    out16, out32 = torch.zeros(B * C, dtype=BF, device="cuda"), torch.zeros(B * C, device="cuda")
+    ops.ColsumFinishPlan([(ws, ns, out16), (ws, ns, out32)], torch.device("cuda")).run()
+    want = dx.float().reshape(B, HW, C).sum(1).reshape(-1)
+    torch.testing.assert_close(out32, want, rtol=1e-5, atol=1e-4 * float(want.abs().max()))
+    assert torch.equal(out16, out32.to(BF))
+    two = ops.colsum(dx, torch.zeros(B, C, device="cuda"), B=B, R=HW).reshape(-1)
+    torch.testing.assert_close(out32, two, rtol=1e-5, atol=1e-4 * float(want.abs().max()))
+    ws2 = torch.zeros_like(ws)
+    ops.groupnorm_bwd(x1d, x2d, dyd, torch.empty(B * HW, C, dtype=BF, device="cuda"), stats, bstats, gamma=gd, beta=bd, dres=drd, colsum_ws=ws2, **kw)
+    assert torch.equal(ws2, ws)
 
 
 @pytest.mark.parametrize("M,C", [(77, 768), (1000, 320), (256, 1280), (64, 2048)])
