@@ -207,7 +207,9 @@ typedef struct sdlt_attn_params {
   int32_t defer_splitsum;  /* single-pass cross-attention backward only: leave the per-split partial dK / dV slabs in dK32 / dV32
                               (they must then be layer-owned, not scratch); sdlt_attn_splitsum_batch sums the slabs of ALL layers in
                               one launch before their consumer (the batched to_k|to_v input-gradient GEMM) */
-  int32_t pad_;
+  int32_t d_ready;         /* backward, self-attention: D already holds rowsum(dO o O) - sdlt_wsk_gemm_rowdot accumulated it while it produced dO - so the D
+                              pre-pass launch is skipped.  Its slots must start from zero: sdlt_attn_fwd zeroes D when D != NULL (in the forward kernel's
+                              epilogue on the 32-row path, with a memset node otherwise). */
 } sdlt_attn_params;
 int sdlt_attn_fwd(const sdlt_attn_params* p, void* stream);
 int sdlt_attn_bwd(const sdlt_attn_params* p, void* stream);
@@ -538,6 +540,15 @@ int sdlt_layernorm_bwd_slabs_pair(const sdlt_ln_slabs_params* a, const sdlt_ln_s
 int sdlt_wsk_gemm(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t M, int32_t N, int32_t K, const float* bias,
                   const void* R, int64_t ldr, void* Y, int64_t ldy, const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup,
                   float lora_scale, void* T_out, int64_t ld_t, int32_t lora_group_k, void* stream);
+
+/* sdlt_wsk_gemm whose output is the gradient dO of a self-attention with 64-wide heads (the dX of attn1.to_out.0; diffusers Attention under main.py:329-336):
+ * next to Y it accumulates D[(b H + h) Nq + q] += sum over head h's columns of rounded(Y[m, n]) O[m, n] (H = N / 64, m = b Nq + q, O bf16 [M, N] = the forward's
+ * attention output, NOT added to Y) - the row term of the softmax backward, which sdlt_attn_bwd otherwise computes in a pre-pass launch (sdlt_attn_params.d_ready).
+ * D must be zero on entry (sdlt_attn_fwd with D set).  Float atomics, still bitwise reproducible: a slot receives at most two values (a head's 64 columns lie in
+ * at most two 80-column tiles) and x + y == y + x.  N % 64 == 0, M % Nq == 0. */
+int sdlt_wsk_gemm_rowdot(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t M, int32_t N, int32_t K, const float* bias,
+                         const void* O, int64_t ldo, void* Y, int64_t ldy, const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup,
+                         float lora_scale, void* T_out, int64_t ld_t, int32_t lora_group_k, float* D, int32_t Nq, void* stream);
 
 /* FROZEN weights (the UNet under LoRA / textual inversion, main.py:329-336 with trainer/optimizer.py:84-95: only adapters train) can be handed to the three
  * sdlt_wsk_gemm* entry points in fragment-major order: Wp = [N / 80][K / 64][2][5][64 lanes][8 bf16], lane (r = lane % 16, g = lane / 16) of fragment

@@ -90,7 +90,7 @@ class AttnParams(C.Structure):
         ("dQ", vp), ("lddq", i64), ("dK", vp), ("lddk", i64), ("dV", vp), ("lddv", i64),
         ("dK32", vp), ("dV32", vp), ("ld32", i64),
         ("B", i32), ("H", i32), ("Nq", i32), ("Nk", i32), ("Nqp", i32), ("Nkp", i32), ("d", i32),
-        ("scale", f32), ("qsplit", i32), ("causal", i32), ("accumulate_dq", i32), ("accumulate_dk", i32), ("defer_splitsum", i32), ("pad_", i32),
+        ("scale", f32), ("qsplit", i32), ("causal", i32), ("accumulate_dq", i32), ("accumulate_dk", i32), ("defer_splitsum", i32), ("d_ready", i32),
     ]
 
 
@@ -192,6 +192,7 @@ SYMBOLS = {
     "sdlt_attn_bwd_pair": (i32, [C.POINTER(AttnParams), C.POINTER(AttnParams), vp]),
     "sdlt_layernorm_bwd_slabs_pair": (i32, [C.POINTER(LnSlabsParams), C.POINTER(LnSlabsParams), vp]),
     "sdlt_wsk_gemm": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp, i64, vp, i64, vp, i64, vp, i64, f32, vp, i64, i32, vp]),
+    "sdlt_wsk_gemm_rowdot": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp, i64, vp, i64, vp, i64, vp, i64, f32, vp, i64, i32, vp, i32, vp]),
     "sdlt_wsk_pack_weight": (i32, [vp, i64, i32, i32, vp, vp]),
     "sdlt_wsk_conv": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, vp, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, f32, vp, i64, vp, vp]),
     "sdlt_wsk_gemm_parts": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp, i64, vp, i64, vp, i64, vp, i64, f32, vp, i64, i32, vp, vp]),

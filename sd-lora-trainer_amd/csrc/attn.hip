@@ -1154,8 +1154,9 @@ extern "C" int sdlt_attn_fwd(const sdlt_attn_params* pp, void* stream) {
   // 23.8 / 16.7 / 20.6 us, 4096 x 10 90.5 / 80.0 / 84.3, 4 x 256 x 20 8.9 / 7.5 / 11.5, 4 x 1024 x 10 26.2 / 24.5 / 29.7)
   if (attn32_on() && sdlt_attn32_ok(p) && ((uintptr_t)p.O % 8) == 0) {
     static const int ks_env = getenv("SDLT_ATTN32_KS_FWD") ? atoi(getenv("SDLT_ATTN32_KS_FWD")) : 0;
-    return sdlt_attn32_fwd(p, ks_env > 0 ? ks_env : (p.Nk >= 128 ? 2 : 1), s);
+    return sdlt_attn32_fwd(p, ks_env > 0 ? ks_env : (p.Nk >= 128 ? 2 : 1), s);      // (zeroes D in its epilogue)
   }
+  if (p.D) sdlt_zero_async(p.D, sizeof(float) * (size_t)p.B * p.H * p.Nq, s);
 #define NSTRH(D_) ((D_) == 64 ? 128 : (D_) * 2 + 16)
 #define SMEM_FWD(D_) (2 * (2 * 64 * NSTRH(D_)))
   // the key split (two wave groups per workgroup) pays on latency-bound grids only - less than two workgroups per CU and a chain of >= 4
@@ -1221,7 +1222,8 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
     if (groups >= (1 << 22)) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_attn_bwd: B * Nq * H = %lld rows (the D pre-pass indexes < 2^22)", (long long)groups);
     int blocks = (int)((groups * 8 + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(attn_prep_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)p.O, p.ldo, (const bf16_t*)p.dO, p.lddo, p.B, p.H, p.Nq, p.Nqp, p.d, p.D);
+    if (!p.d_ready)      // (d_ready: sdlt_wsk_gemm_rowdot left D while it produced dO)
+      hipLaunchKernelGGL(attn_prep_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)p.O, p.ldo, (const bf16_t*)p.dO, p.lddo, p.B, p.H, p.Nq, p.Nqp, p.d, p.D);
     if (attn32_on() && sdlt_attn32_ok(p) && ((uintptr_t)p.L % 16) == 0 && ((uintptr_t)p.D % 16) == 0) {
       static const int ks_env = getenv("SDLT_ATTN32_KS_BWD") ? atoi(getenv("SDLT_ATTN32_KS_BWD")) : 0;
       // (1 / 2 / 4 groups: 1024 x 20 44.0 / 38.1 / 46.4 us, 4096 x 10 219.9 / 203.3 / 201.5, 4 x 1024 x 10 72.0 / 60.1 / 75.1)

@@ -325,6 +325,9 @@ __global__ __launch_bounds__(128 * KS) void attn32_fwd_kernel(const sdlt_attn_pa
   }
   const float inv = 1.f / lsum;
   if (hl == 0 && p.L) p.L[((int64_t)b * p.H + h) * p.Nq + q] = (m + log2f(lsum)) / LOG2E;
+#ifndef SDLT_ATTN32_TRACE
+  if (hl == 0 && p.D) p.D[((int64_t)b * p.H + h) * p.Nq + q] = 0.f;      // the slots sdlt_wsk_gemm_rowdot accumulates rowsum(dO o O) into during the backward pass
+#endif
   bf16_t* op = (bf16_t*)p.O + ((int64_t)b * p.Nqp + q) * p.ldo + hc + 4 * hl;
 #pragma unroll
   for (int db = 0; db < 2; ++db)

@@ -59,6 +59,11 @@ struct wsk_params {
   int Hc, Wc, Cin, flip;
   const bf16_t* zero;
   const bf16_t* rowbias; int64_t ld_rowbias;
+  // row dots for the attention backward that reads Y next (Y = dO of a self-attention with 64-wide heads, R = the forward's O instead of a residual: it is NOT added):
+  // dotD[(b H + h) dot_nq + q] += sum over head h's columns of this tile of rounded(Y[m, n]) O[m, n], H = N / 64, m = b dot_nq + q.  A head's 64 columns lie in at
+  // most TWO 80-column tiles and every tile adds ONE value per (row, head): onto a zeroed slot the result does not depend on the order (x + y == y + x), so the float
+  // atomics stay bitwise reproducible.  Replaces the D pre-pass of the attention backward (sdlt_attn_params.d_ready).
+  float* dotD; int dot_nq;
 };
 
 // -DSDLT_WSK_TRACE (tools/wsk_trace.py): thread 0 of workgroup 0 stamps clock64() at the phase boundaries; sdlt_wsk_trace_read copies them out
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   // each behind an s_waitcnt lgkmcnt(0), in the prologue and in front of the epilogue)
   asm volatile("" ::"s"(p.X), "s"(p.ldx), "s"(p.W), "s"(p.ldw), "s"(p.bias), "s"(p.R), "s"(p.ldr), "s"(p.Y), "s"(p.ldy), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.map2d));
   asm volatile("" ::"s"(p.Adown), "s"(p.ld_adown), "s"(p.Bup), "s"(p.ld_bup), "s"(p.T_out), "s"(p.ld_t), "s"(p.lora_scale), "s"(p.group_k), "s"(p.stagger));
-  asm volatile("" ::"s"(p.ln_c1), "s"(p.ln_stats), "s"(p.ln_adapter), "s"(p.ln_eps), "s"(p.ln_parts), "s"(p.Wp));
+  asm volatile("" ::"s"(p.ln_c1), "s"(p.ln_stats), "s"(p.ln_adapter), "s"(p.ln_eps), "s"(p.ln_parts), "s"(p.Wp), "s"(p.dotD), "s"(p.dot_nq));
   if constexpr (CONV) asm volatile("" ::"s"(p.Hc), "s"(p.Wc), "s"(p.Cin), "s"(p.flip), "s"(p.zero), "s"(p.rowbias), "s"(p.ld_rowbias));
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
@@ -482,6 +487,7 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   }
   WTR(10);
   float ps4[JN], pm2[JN];     // ln_parts: (sum, centred sum of squares) of this lane's four columns of every unit
+  [[maybe_unused]] float dq4[JN];      // dotD: rounded output . O over this lane's four columns of every unit
 #pragma unroll
   for (int q = 0; q < JN; ++q) {
     f32x4 v = red[(mb * JN + q) * 64 + lane];
@@ -502,12 +508,16 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
         v[0] += bf2f(rv.x & 0xffff); v[1] += bf2f(rv.x >> 16); v[2] += bf2f(rv.y & 0xffff); v[3] += bf2f(rv.y >> 16);
       }
     }
-    if (p.R) {
+    if (p.R && !p.dotD) {
       const uint2 rv = rpre[q];
       v[0] += bf2f(rv.x & 0xffff); v[1] += bf2f(rv.x >> 16); v[2] += bf2f(rv.y & 0xffff); v[3] += bf2f(rv.y >> 16);
     }
     const uint2 ov = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
     *(uint2*)(p.Y + (int64_t)m * p.ldy + n0 + 16 * q + 4 * g) = ov;
+    if constexpr (!LN && !CONV) {
+      const uint2 rv = rpre[q];
+      dq4[q] = (bf2f(ov.x & 0xffff) * bf2f(rv.x & 0xffff) + bf2f(ov.x >> 16) * bf2f(rv.x >> 16)) + (bf2f(ov.y & 0xffff) * bf2f(rv.y & 0xffff) + bf2f(ov.y >> 16) * bf2f(rv.y >> 16));
+    }
     // (sum, CENTRED sum of squares) of the four ROUNDED columns: the slots of a row are merged below around the tile's row mean (the update of Chan et al.), so
     // the variance never comes out of a difference of two large numbers (rows whose mean dwarfs their spread)
     const float y0 = bf2f(ov.x & 0xffff), y1 = bf2f(ov.x >> 16), y2 = bf2f(ov.y & 0xffff), y3 = bf2f(ov.y >> 16);
@@ -526,6 +536,22 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
     for (int q = 0; q < JN; ++q) { const float d = ps4[q] * 0.25f - mt; m2 += pm2[q] + 4.f * d * d; }
     m2 = ln_sum_fk(m2);
     if (g == 0) p.ln_parts[(int64_t)m * ntn + tn] = make_float2(sx, m2);
+  }
+  if constexpr (!LN && !CONV) {
+    if (p.dotD) {      // (wave-uniform) units 0 .. nA - 1 of this tile belong to head hA = n0 / 64, the rest to head hA + 1; the row's four lanes are summed like the LayerNorm partials
+      const int hA = n0 >> 6, nA = ((hA + 1) * 64 - n0) >> 4;
+      float sA = 0.f, sB = 0.f;
+#pragma unroll
+      for (int q = 0; q < JN; ++q) { sA += q < nA ? dq4[q] : 0.f; sB += q < nA ? 0.f : dq4[q]; }
+      sA = ln_sum_fk(sA);
+      sB = ln_sum_fk(sB);
+      if (g == 0) {
+        const int b = div_small(m, p.dot_nq), qrow = m - b * p.dot_nq, H = p.N >> 6;
+        float* dst = p.dotD + ((int64_t)b * H + hA) * p.dot_nq + qrow;
+        atomicAdd(dst, sA);
+        if (nA < JN && hA + 1 < H) atomicAdd(dst + p.dot_nq, sB);
+      }
+    }
   }
   WTR(11);
 }
@@ -578,7 +604,7 @@ extern "C" int sdlt_wsk_trace_read(long long* out16) { return (int)hipMemcpyFrom
 static int wsk_gemm_impl(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t M, int32_t N, int32_t K, const float* bias,
                          const void* R, int64_t ldr, void* Y, int64_t ldy, const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup,
                          float lora_scale, void* T_out, int64_t ld_t, int32_t lora_group_k, const float* ln_c1, float* ln_stats, float ln_eps,
-                         const float* ln_adapter, void* ln_parts, void* stream) {
+                         const float* ln_adapter, void* ln_parts, void* stream, float* dotD = nullptr, int32_t dot_nq = 0) {
   if (M <= 0 || N <= 0 || K <= 0 || (M % 64) || (N % 80) || ((N / 80) % 8) || (K % 256))
     SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wsk_gemm: M=%d N=%d K=%d (M %% 64, N %% 640, K %% 256 == 0)", M, N, K);
   const bool packed = ldw == 0;          // W is sdlt_wsk_pack_weight's output
@@ -592,8 +618,10 @@ static int wsk_gemm_impl(const void* X, int64_t ldx, const void* W, int64_t ldw,
   static const int stagger_env = getenv("SDLT_WSK_STAGGER") ? atoi(getenv("SDLT_WSK_STAGGER")) : 1;   // (read once: A/B switch)
   wsk_params p{(const bf16_t*)X, ldx, (const bf16_t*)W, ldw, bias, (const bf16_t*)R, ldr, (bf16_t*)Y, ldy, M, N, K, 1,
                (const bf16_t*)Adown, ld_adown, (const bf16_t*)Bup, ld_bup, (bf16_t*)T_out, ld_t, lora_scale, lora_group_k, stagger_env,
-               ln_c1, ln_stats, ln_adapter, ln_eps, (float2*)ln_parts, packed ? (const bf16_t*)W : nullptr, 0, 0, 0, 0, nullptr, nullptr, 0};
+               ln_c1, ln_stats, ln_adapter, ln_eps, (float2*)ln_parts, packed ? (const bf16_t*)W : nullptr, 0, 0, 0, 0, nullptr, nullptr, 0, dotD, dot_nq};
   if (((uintptr_t)ln_parts) & 7) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_gemm: ln_parts must be 8-byte aligned");
+  if (dotD && (!R || ln_c1 || (N % 64) || dot_nq <= 0 || (M % dot_nq) || ((uintptr_t)dotD & 3)))
+    SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wsk_gemm_rowdot: O is required, N %% 64 == 0 (64-wide heads), M = B * Nq, no folded LayerNorm");
   hipStream_t s = (hipStream_t)stream;
   if (packed) {          // register ring of 3 stages (probed 2 / 3 / 4 in round 5: 3 wins on every shape; 4 runs out of registers with an adapter)
 #define WSK_WP(KG_, LN_) launch_wsk<4, 5, 3, KG_, LN_, true>(p, s)
@@ -618,6 +646,14 @@ extern "C" int sdlt_wsk_gemm(const void* X, int64_t ldx, const void* W, int64_t 
                              float lora_scale, void* T_out, int64_t ld_t, int32_t lora_group_k, void* stream) {
   return wsk_gemm_impl(X, ldx, W, ldw, M, N, K, bias, R, ldr, Y, ldy, Adown, ld_adown, Bup, ld_bup, lora_scale, T_out, ld_t, lora_group_k,
                        nullptr, nullptr, 0.f, nullptr, nullptr, stream);
+}
+
+extern "C" int sdlt_wsk_gemm_rowdot(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t M, int32_t N, int32_t K, const float* bias,
+                                    const void* O, int64_t ldo, void* Y, int64_t ldy, const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup,
+                                    float lora_scale, void* T_out, int64_t ld_t, int32_t lora_group_k, float* D, int32_t Nq, void* stream) {
+  if (!D) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wsk_gemm_rowdot: D == NULL");
+  return wsk_gemm_impl(X, ldx, W, ldw, M, N, K, bias, O, ldo, Y, ldy, Adown, ld_adown, Bup, ld_bup, lora_scale, T_out, ld_t, lora_group_k,
+                       nullptr, nullptr, 0.f, nullptr, nullptr, stream, D, Nq);
 }
 
 extern "C" int sdlt_wsk_gemm_parts(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t M, int32_t N, int32_t K, const float* bias,

@@ -139,6 +139,14 @@ def wsk_shape(M, N, K, lora=False):
     return 2560 <= K <= WSK_KMAX
 
 
+ROWDOT = os.environ.get("SDLT_ROWDOT", "1") != "0"          # the attention backward's row term D from the GEMM that produces dO (A/B switch)
+
+
+def wsk_rowdot_shape(M, N, K, lora, d):
+    """Will gemm(rowdot=) apply to the dX of a to_out.0 of this shape?  (The caller only uses it to decide whether the forward zeroes D; gemm() itself reports what it did.)"""
+    return ROWDOT and WSK and not THROUGHPUT_HINT and d == 64 and N % 64 == 0 and wsk_shape(M, N, K, lora)
+
+
 WSK_PACK = os.environ.get("SDLT_WSK_PACK", "1") != "0"
 _WSK_FROZEN = {}         # data_ptr of a weight declared frozen -> weakref of the tensor
 _WSK_PACKED = {}         # data_ptr -> (fragment-major copy (sdlt_wsk_pack_weight's layout), N, K, ld, weakref of the tensor)
@@ -204,7 +212,7 @@ def gemm_emits_parts(M, N, K, lora_rank_pad=0):
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
          residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0, batch=None,
-         geglu_out=None, geglu_bwd=None, act_out=None, dact_in=None, col_scale=None, ln=None, ln_parts_out=None):
+         geglu_out=None, geglu_bwd=None, act_out=None, dact_in=None, col_scale=None, ln=None, ln_parts_out=None, rowdot=None):
     """out[M,N] = alpha*col_scale[n]*(X.W^T [+ X2.W2^T] [+ s*(X.Adown^T).Bup^T]) + bias + rowbias[m//rows_per_batch] + residual.
     col_scale fp32 [N]: DoRA's magnitude / norm factor (adapter launches only; DoraPlan keeps it up to date).
     act_out = (kind, A [M,N]): also writes A = act(out), kind "gelu" | "quick_gelu" (the CLIP MLP's fc1).
@@ -222,6 +230,9 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
     ... optionally followed by (parts fp32 [M, P, 2], P): the row partials the PRODUCER of X left (ln_parts_out of that call).
     ln_parts_out fp32 [M, N / 80, 2]: also leave the row partials (sum, centred sum of squares of the rounded output row per 80-column tile) for the
     LayerNorm that reads `out` next - only where this call runs on the wave-split-K kernel (gemm_emits_parts says so; asserted).
+    rowdot = dict(O bf16 [M, N], D fp32 [B * N / 64 * Nq], Nq): `out` is the gradient dO of a self-attention with 64-wide heads; where this call runs on the wave-split-K
+    kernel it also accumulates D[b, h, q] += sum_n rounded(out[m, n]) O[m, n] over each head's columns and sets rowdot["done"] = True (attn_bwd(d_ready=True) then skips its
+    D pre-pass); otherwise the dict is left alone and the caller keeps the pre-pass.  D must be zero on entry (attn_fwd(zero_D=)).
     batch: a GemmBatch - the launch runs len(batch) problems of identical shape / leading dimensions; the tensor arguments
     describe problem 0 (shapes, strides, options), every problem's operand pointers come from the batch."""
     lib = _lib.load()
@@ -264,6 +275,16 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
                                                _p(out), _ld(out), _p(A_), _ld(A_) if A_ is not None else 0, _p(B_), _ld(B_) if B_ is not None else 0, float(scale_),
                                                _p(T_), _ld(T_) if T_ is not None else 0, int(lora_group_k) if lora is not None else 0, _p(ln_parts_out), _stream()),
                        "sdlt_wsk_gemm_parts")
+            return out
+        if rowdot is not None and ROWDOT and residual is None and N_ % 64 == 0 and M_ % rowdot["Nq"] == 0:
+            O_, D_ = rowdot["O"], rowdot["D"]
+            _chk2(O_), _chk2(D_, F32)
+            assert tuple(O_.shape) == (M_, N_) and D_.is_contiguous() and D_.numel() >= M_ * (N_ // 64)
+            _lib.check(lib.sdlt_wsk_gemm_rowdot(_p(X), _ld(X), Wptr, Wld, M_, N_, K_, _p(bias), _p(O_), _ld(O_), _p(out), _ld(out), _p(A_),
+                                                _ld(A_) if A_ is not None else 0, _p(B_), _ld(B_) if B_ is not None else 0, float(scale_), _p(T_),
+                                                _ld(T_) if T_ is not None else 0, int(lora_group_k) if lora is not None else 0, _p(D_), int(rowdot["Nq"]), _stream()),
+                       "sdlt_wsk_gemm_rowdot")
+            rowdot["done"] = True
             return out
         _lib.check(lib.sdlt_wsk_gemm(_p(X), _ld(X), Wptr, Wld, M_, N_, K_, _p(bias), _p(residual), _ld(residual) if residual is not None else 0,
                                      _p(out), _ld(out), _p(A_), _ld(A_) if A_ is not None else 0, _p(B_), _ld(B_) if B_ is not None else 0, float(scale_),
@@ -744,22 +765,29 @@ def _attn_params(Q, K, V, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=False):
     return p
 
 
-def attn_fwd(Q, K, V, Vt, O, L, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=False):
+def attn_fwd(Q, K, V, Vt, O, L, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=False, zero_D=None):
+    """zero_D (fp32 [B * H * Nq], optional): cleared by the launch - the slots gemm(rowdot=) accumulates the backward's row term into."""
     lib = _lib.load()
     p = _attn_params(Q, K, V, B=B, H=H, Nq=Nq, Nk=Nk, Nqp=Nqp, Nkp=Nkp, d=d, scale=scale, causal=causal)
     _chk2(O), _chk2(L, F32)      # Vt is accepted for call compatibility and ignored: the kernel transposes V tiles in LDS
     p.O, p.ldo, p.L = _p(O), _ld(O), _p(L)
+    if zero_D is not None:
+        _chk2(zero_D, F32)
+        assert zero_D.is_contiguous() and zero_D.numel() >= B * H * Nq
+        p.D = _p(zero_D)
     _issue("attn_fwd", p)
     return O
 
 
 def attn_bwd(Q, K, V, Kt, Qt, O, L, dO, dOt, D, dQ, dK, dV, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=False,
-             qsplit=1, dK32=None, dV32=None, accumulate_dq=False, accumulate_dk=False, defer_splitsum=False):
+             qsplit=1, dK32=None, dV32=None, accumulate_dq=False, accumulate_dk=False, defer_splitsum=False, d_ready=False):
     """defer_splitsum (single-pass cross-attention backward): dK / dV stay as per-split fp32 slabs in dK32 / dV32 (layer-owned buffers);
-    a SplitsumPlan over all layers sums them in one launch later."""
+    a SplitsumPlan over all layers sums them in one launch later.
+    d_ready (self-attention): D already holds rowsum(dO o O) - the GEMM that produced dO left it (gemm(rowdot=)) - and the pre-pass launch is skipped."""
     lib = _lib.load()
     p = _attn_params(Q, K, V, B=B, H=H, Nq=Nq, Nk=Nk, Nqp=Nqp, Nkp=Nkp, d=d, scale=scale, causal=causal)
     p.defer_splitsum = int(defer_splitsum)
+    p.d_ready = int(d_ready)
     for t in (O, dO, dQ, dK, dV):      # Kt / Qt / dOt: accepted and ignored (see attn_fwd)
         _chk2(t)
     _chk2(L, F32), _chk2(D, F32)

@@ -406,7 +406,8 @@ class Linear(_Module):
             self.rt.ops.gemm(x, W, y, lora=lora, bias=bias, residual=residual, Ct=Ct, **kw)
         return y
 
-    def backward(self, dy, *, dres=None, Ct=None, key="dx", out=None, dact_in=None):
+    def backward(self, dy, *, dres=None, Ct=None, key="dx", out=None, dact_in=None, rowdot=None):
+        """rowdot: see ops.gemm (attn1.to_out.0: the attention backward's row term as a side output of this dX product)."""
         M = dy.shape[0]
         dx = out if out is not None else self.buf(key, M, self.K)
         lora = None
@@ -427,6 +428,8 @@ class Linear(_Module):
         Wt = self.Wt_d if self.dora else self.Wt
         if dact_in is not None:
             self.rt.ops.gemm(dy, Wt, dx, lora=lora, residual=dres, Ct=Ct, dact_in=dact_in)
+        elif rowdot is not None:
+            self.rt.ops.gemm(dy, Wt, dx, lora=lora, residual=dres, Ct=Ct, rowdot=rowdot)
         else:
             self.rt.ops.gemm(dy, Wt, dx, lora=lora, residual=dres, Ct=Ct)
         return dx
@@ -853,7 +856,12 @@ class Attention(_Module):
         O = self.buf("O", Mq, C)
         L = self.buf("L", B * self.heads * N, dtype=F32)
         self._dims = (B, N, Nk, Nkp)
-        rt.ops.attn_fwd(q, k, v, None, O, L, B=B, H=self.heads, Nq=N, Nk=Nk, Nqp=N, Nkp=Nkp, d=self.d, scale=self.scale)
+        # self-attention whose to_out.0 input gradient runs on the wave-split-K kernel: that product leaves the backward's row term D = rowsum(dO o O) as a side output
+        # (no D pre-pass launch); its slots are cleared here, by the forward kernel's epilogue
+        self._rowdot = (not self.cross and getattr(self, "_rowdot_ok", True) and self.to_out.trainer is None and not self.to_out.dora
+                        and getattr(rt.ops, "wsk_rowdot_shape", None) is not None and rt.ops.wsk_rowdot_shape(Mq, C, C, self.to_out.lora is not None, self.d))
+        kwz = {"zero_D": self.buf("D", B * self.heads * N, dtype=F32)} if self._rowdot else {}
+        rt.ops.attn_fwd(q, k, v, None, O, L, B=B, H=self.heads, Nq=N, Nk=Nk, Nqp=N, Nkp=Nkp, d=self.d, scale=self.scale, **kwz)
         if self.cross and self.hooked:
             # DAAM side output (ti_cross_attn_loss.py:201-212): sum over heads of Q_h K_h^T / sqrt(d) = Q K^T / sqrt(d).
             # The token-attention loss only ever uses the MEAN over layers of these maps (loss.py:23-52), so the layers
@@ -881,7 +889,11 @@ class Attention(_Module):
         rt, C = self.rt, self.C
         B, N, Nk, Nkp = self._dims
         Mq, Mk = B * N, B * Nkp
-        dO = self.to_out.backward(dout)
+        D = self.buf("D", B * self.heads * N, dtype=F32)
+        rd = dict(O=self._b["O"], D=D, Nq=N, done=False) if getattr(self, "_rowdot", False) else None
+        dO = self.to_out.backward(dout, **({"rowdot": rd} if rd is not None else {}))
+        if rd is not None and not rd["done"]:
+            self._rowdot_ok = False      # (this product does not run where the side output exists: the next forward stops clearing D)
         q, k, v = self.to_q._b["y"], self.to_k._b["y"], self.to_v._b["y"]
         fused = self.stack.has_lora and self.stack.kgrouped or not self.stack.has_lora
         if fused and self.cross:
@@ -891,8 +903,7 @@ class Attention(_Module):
             dqkv, (dq, dk, dv) = self.stack.grad_slices(Mq)
         else:
             dq, dk, dv = self.buf("dq", Mq, C), self.buf("dk", Mk, C), self.buf("dv", Mk, C)
-        D = self.buf("D", B * self.heads * N, dtype=F32)
-        kw = {}
+        kw = {"d_ready": True} if (rd is not None and rd["done"]) else {}
         if self.cross:
             # cross-attention: ~160 workgroups, each owning all 77 keys of one head and a range of query tiles; the fp32
             # dK/dV accumulators are adjacent so the kernel side zeroes / converts them with one launch each

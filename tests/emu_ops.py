@@ -48,7 +48,17 @@ def set_throughput_hint(flag):
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
          residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0, batch=None,
-         geglu_out=None, geglu_bwd=None, act_out=None, dact_in=None, col_scale=None, ln=None, ln_parts_out=None):
+         geglu_out=None, geglu_bwd=None, act_out=None, dact_in=None, col_scale=None, ln=None, ln_parts_out=None, rowdot=None):
+    if rowdot is not None:      # sdlt_wsk_gemm_rowdot: the product, then D[b, h, q] += sum over head h's columns of rounded(out) o O
+        assert residual is None and conv is None and ln is None and ln_parts_out is None and not accumulate
+        gemm(X, W, out, lora=lora, bias=bias, alpha=alpha, Ct=Ct, lora_group_k=lora_group_k)
+        M, N = out.shape
+        O_, D_, Nq = rowdot["O"], rowdot["D"], rowdot["Nq"]
+        H = D_.numel() // M
+        prod = (out.float() * O_.float()).reshape(M // Nq, Nq, H, N // H).sum(-1)           # [B, Nq, H]
+        D_.view(M // Nq, H, Nq).add_(prod.permute(0, 2, 1))
+        rowdot["done"] = True
+        return out
     if ln is not None:      # folded LayerNorm (sdlt_gemm_params.ln_c1): raw rows in, W = W o gamma, bias = c2
         c1, stats_, eps_, lnad = ln[:4]
         assert conv is None and X2 is None and alpha == 1.0 and col_scale is None and not lora_group_k and batch is None
@@ -310,7 +320,13 @@ def _attn_core(q, k, v, Nq, Nk, scale, causal):
     return s
 
 
-def attn_fwd(Q, K, V, Vt, O, L, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=False):
+def wsk_rowdot_shape(M, N, K, lora, d):
+    return True          # (the emulation takes the side output everywhere, so that the CPU tests exercise the plumbing on the tiny topologies)
+
+
+def attn_fwd(Q, K, V, Vt, O, L, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=False, zero_D=None):
+    if zero_D is not None:
+        zero_D.zero_()
     C = H * d
     q, k, v = _heads(Q[:, :C], B, Nqp, H, d), _heads(K[:, :C], B, Nkp, H, d), _heads(V[:, :C], B, Nkp, H, d)
     s = _attn_core(q, k, v, Nq, Nk, scale, causal)
@@ -322,8 +338,12 @@ def attn_fwd(Q, K, V, Vt, O, L, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=Fals
 
 
 def attn_bwd(Q, K, V, Kt, Qt, O, L, dO, dOt, D, dQ, dK, dV, *, B, H, Nq, Nk, Nqp, Nkp, d, scale, causal=False,
-             qsplit=1, dK32=None, dV32=None, accumulate_dq=False, accumulate_dk=False, defer_splitsum=False):
+             qsplit=1, dK32=None, dV32=None, accumulate_dq=False, accumulate_dk=False, defer_splitsum=False, d_ready=False):
     C = H * d
+    if d_ready:      # the producer of dO left the row term: it must be what the pre-pass would have computed
+        assert Nq == Nqp
+        want = (dO[:, :C].float() * O[:, :C].float()).reshape(B, Nq, H, d).sum(-1).permute(0, 2, 1).reshape(-1)
+        torch.testing.assert_close(D[: want.numel()], want, rtol=1e-4, atol=1e-5 * float(want.abs().max() + 1e-30))
     q = _heads(Q[:, :C], B, Nqp, H, d).detach().clone().requires_grad_(True)
     k = _heads(K[:, :C], B, Nkp, H, d).detach().clone().requires_grad_(True)
     v = _heads(V[:, :C], B, Nkp, H, d).detach().clone().requires_grad_(True)

@@ -673,6 +673,19 @@ def test_attention_fwd_bwd(ops, c):
     close(dQ.cpu() * vq, dQr * vq, tol=2.5e-2, what=f"attn dQ {c}")
     close(dK, dKr, tol=2.5e-2, what=f"attn dK {c}")
     close(dV, dVr, tol=2.5e-2, what=f"attn dV {c}")
+    if c["qsplit"] == 1 and not acc and not c["causal"] and Nq == Nqp:
+        # d_ready: the row term D = rowsum(dO o O) comes from outside (sdlt_wsk_gemm_rowdot leaves it while it produces dO) - with the pre-pass's own D handed back in,
+        # skipping the pre-pass launch must not change a bit; and a forward that is given D clears it (the slots the side output accumulates into)
+        D2 = D.clone()
+        D.fill_(float("nan"))
+        dQ2, dK2, dV2 = (torch.full_like(t, 3.0) for t in (Qd, Kd, Vd))
+        ops.attn_bwd(Qd, Kd, Vd, Kt, Qt, O, L, dOd, dOt, D2, dQ2, dK2, dV2, **kw, d_ready=True)
+        assert torch.equal(dQ2, dQ) and torch.equal(dK2, dK) and torch.equal(dV2, dV)
+        want = (dOd.float() * O.float()).reshape(B, Nq, H, d).sum(-1).permute(0, 2, 1).reshape(-1)
+        torch.testing.assert_close(D2, want, rtol=1e-4, atol=1e-5 * float(want.abs().max()))
+        O3, L3 = torch.zeros_like(O), torch.zeros_like(L)
+        ops.attn_fwd(Qd, Kd, Vd, Vt, O3, L3, **kw, zero_D=D)
+        assert torch.equal(O3, O) and torch.equal(L3, L) and float(D.abs().max()) == 0.0
 
 
 # --------------------------------------------------------------------------------------------- norms / element-wise
@@ -1403,6 +1416,53 @@ def test_wsk_gemm_packed_weight_is_bit_identical(ops, M, N, K, mode):
         ops.gemm(x, w, y2, bias=b, residual=r, **(dict(lora=(A, Bu, 0.75, T2), lora_group_k=K // G if kgroup else 0) if lora else {}))
         assert w.data_ptr() in ops._WSK_PACKED and torch.equal(ops._WSK_PACKED[w.data_ptr()][0], wp)
         assert torch.equal(y2, base[0]) and (not lora or torch.equal(T2, base[1]))
+
+
+@pytest.mark.parametrize("B,Nq,N,K,lora,packed", [(1, 1024, 1280, 1280, True, True), (1, 1024, 1280, 1280, True, False), (4, 256, 1280, 1280, True, True), (1, 1024, 1280, 2560, False, True),
+                                                  (2, 256, 640, 1280, True, False), (1, 4096, 640, 2560, False, True)])
+def test_wsk_gemm_rowdot(ops, B, Nq, N, K, lora, packed):
+    """sdlt_wsk_gemm_rowdot: Y = the plain wave-split-K product (same bits) and D[b, h, q] = sum over head h's 64 columns of rounded(Y) o O on a zeroed D - what the
+    attention backward's D pre-pass computes from the stored dO.  A head's columns lie in at most two 80-column tiles, so the two float atomics per slot commute: bitwise
+    reproducible.  O is NOT added to Y."""
+    M, H = B * Nq, N // 64
+    g = torch.Generator().manual_seed(M + N + K + int(lora))
+    x, w = rnd(M, K, g=g).cuda(), rnd(N, K, g=g, scale=K ** -0.5).cuda()
+    o = rnd(M, N, g=g).cuda()
+    A, Bu = rnd(16, K, g=g, scale=1.0 / 16).cuda(), rnd(N, 16, g=g, scale=0.05).cuda()
+    lib = ops._lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    wptr, ldw = w.data_ptr(), K
+    if packed:
+        wp = torch.empty(N * K, dtype=BF, device="cuda")
+        ops._lib.check(lib.sdlt_wsk_pack_weight(w.data_ptr(), K, N, K, wp.data_ptr(), st), "sdlt_wsk_pack_weight")
+        wptr, ldw = wp.data_ptr(), 0
+
+    def run(dot):
+        y, T = torch.full((M, N), 7.0, dtype=BF, device="cuda"), torch.full((M, 16), 7.0, dtype=BF, device="cuda")
+        D = torch.zeros(B * H * Nq, device="cuda")
+        la = (A.data_ptr(), K, Bu.data_ptr(), 16, 0.75, T.data_ptr(), 16) if lora else (None, 0, None, 0, 0.0, None, 0)
+        if dot:
+            rc = lib.sdlt_wsk_gemm_rowdot(x.data_ptr(), K, wptr, ldw, M, N, K, None, o.data_ptr(), N, y.data_ptr(), N, *la, 0, D.data_ptr(), Nq, st)
+        else:
+            rc = lib.sdlt_wsk_gemm(x.data_ptr(), K, wptr, ldw, M, N, K, None, None, 0, y.data_ptr(), N, *la, 0, st)
+        assert rc == 0, lib.sdlt_last_error()
+        torch.cuda.synchronize()
+        return y, T, D
+    y0, T0, _ = run(False)
+    y1, T1, D1 = run(True)
+    assert torch.equal(y0, y1) and torch.equal(T0, T1)
+    want = (y1.double() * o.double()).reshape(B, Nq, H, 64).sum(-1).permute(0, 2, 1).reshape(-1)
+    torch.testing.assert_close(D1.double(), want, rtol=1e-5, atol=2e-6 * float(want.abs().max()))
+    for _ in range(3):
+        assert torch.equal(run(True)[2], D1)
+    # through ops.gemm: reports the side output, D accumulates onto what is there (the forward zeroes it)
+    rd = dict(O=o, D=torch.zeros(B * H * Nq, device="cuda"), Nq=Nq, done=False)
+    y2 = torch.empty(M, N, dtype=BF, device="cuda")
+    ops.gemm(x, w, y2, **(dict(lora=(A, Bu, 0.75, torch.empty(M, 16, dtype=BF, device="cuda"))) if lora else {}), rowdot=rd)
+    if ops.wsk_shape(M, N, K, lora):
+        assert rd["done"] and torch.equal(y2, y1) and torch.equal(rd["D"], D1)
+    else:
+        assert not rd["done"] and float(rd["D"].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("B,sizes,ratio,has", [(1, [(64, 64, 10), (32, 32, 50)], 1.0, [1]), (2, [(64, 64, 3), (32, 32, 6), (16, 16, 6)], 1.0, [1, 0]),
