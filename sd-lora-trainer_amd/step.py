@@ -192,8 +192,10 @@ class TrainStep:
                  weight_decay=0.004, grad_accum=1, betas=(0.9, 0.999), eps=1e-8, text: TextStack = None, n_tokens=3,
                  token_attention_loss_w=3e-7, ti_weight_decay=0.0, ti_std_loss_w=0.01, optimizer="adamw", ti_optimizer="adamw",
                  prodigy_d_coef=1.0, prodigy_growth_rate=1.05, text_lora_weight_decay=1e-5, process_group=None,
-                 cond_reg_w=0.0, tok_cov_reg_w=0.0, cond_target_norm=None, tok_cond_reg_w=0.0, reg_caption_ids=None, ddp_wire_dtype=None, ddp_zero1=None, ddp_force=False):
-        """process_group: data-parallel full fine-tune only (`unet.trainer` set) - a torch.distributed group (or True for the
+                 cond_reg_w=0.0, tok_cov_reg_w=0.0, cond_target_norm=None, tok_cond_reg_w=0.0, reg_caption_ids=None, ddp_wire_dtype=None, ddp_zero1=None, ddp_force=False, ti_trainable=True):
+        """ti_trainable=False (disable_ti with text-encoder LoRA, main.py:116-133): the text encoders run inside the step for their adapters' gradients, the token
+        rows never move (their learning rate is forced to 0) and the logged total leaves the token regularisers out.
+        process_group: data-parallel full fine-tune only (`unet.trainer` set) - a torch.distributed group (or True for the
         default one) over which the gradient arena is all-reduced once per optimiser step (RCCL on the GPU)."""
         adam8 = optimizer == "AdamW8bit"
         if adam8:
@@ -206,6 +208,7 @@ class TrainStep:
         if ti_optimizer not in ("adamw", "prodigy"):
             raise NotImplementedError(f"Invalid optimizer_name: '{ti_optimizer}'")
         self.rt, self.unet = rt, unet
+        self.ti_trainable = bool(ti_trainable)
         # the trained parameter group of the UNet: the LoRA arena, or every weight (full fine-tune, main.py:144-149)
         self.full_ft = getattr(unet, "trainer", None) is not None
         self.group = unet.trainer if self.full_ft else unet.arena
@@ -839,6 +842,8 @@ class TrainStep:
                     self.body_micro()
                 return
             self._micro = 0
+        if not self.ti_trainable:
+            lr_ti = 0.0
         self.set_hyper(lr, lr_ti, lr_te)
         # frozen-TI fast path (Prodigy with lr 0 is a no-op as well: sdlt_prodigy_step); never with text-encoder LoRA, whose
         # gradients need the text backward for the whole run
@@ -880,7 +885,7 @@ class TrainStep:
         tot = float(self.loss) + self.l1_penalty * float(self.l1_sum) / self.group.n
         if self.text is not None:
             tot += self.ta_w * float(self.ta.loss)
-            if not getattr(self, "_frozen_last", False):       # main.py:358: the regularisers only while the TI learning rate is > 0
+            if not getattr(self, "_frozen_last", False) and self.ti_trainable:       # main.py:358: the regularisers only while the TI learning rate is > 0
                 tot += float(self.ti.reg_loss)
                 if self.cond_reg_w > 0.0:
                     tot += float(self.cond_reg_loss)

@@ -110,9 +110,7 @@ class Models:
         del sd
         # ---- text encoders: always built (the reference encodes the captions through them even with disable_ti, main.py:306-308)
         te_arena = None
-        if config.text_encoder_lora_optimizer is not None:
-            if config.disable_ti:
-                raise NotImplementedError("text-encoder LoRA without textual inversion: the step's text stack is only built for TI runs")
+        if config.text_encoder_lora_optimizer is not None:      # built independently of disable_ti, like main.py:116-131
             te_arena = M.LoraArena(rt, config.text_encoder_lora_rank, config.lora_alpha_multiplier, problems=[], dora=config.use_dora)      # a21
         self.encoders = []
         for i, kd in enumerate(self.kinds):
@@ -398,17 +396,22 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
     config.num_train_epochs = math.ceil(config.max_train_steps / steps_per_epoch)
 
     ti_on = not config.disable_ti
+    # The text encoders are part of the step when the token rows train OR when they carry adapters (main.py:116-131 builds the text-encoder LoRA whether or not
+    # disable_ti is set).  disable_ti with adapters: the step of a TI run whose token rows never move - no TI optimizer (main.py:133), no token-attention loss
+    # (main.py:342) and none of the token regularisers (main.py:357: they need a TI optimizer with lr > 0); the text backward runs for the adapters' gradients.
+    text_in_step = ti_on or config.text_encoder_lora_optimizer is not None
     ts = S.TrainStep(rt, unet, latent_hw=(h, w), process_group=True if ddp else None, snr_gamma=config.snr_gamma, l1_penalty=config.l1_penalty, weight_decay=config.lora_weight_decay,
-                     grad_accum=config.gradient_accumulation_steps, text=models.text if ti_on else None, n_tokens=config.n_tokens,
-                     token_attention_loss_w=config.token_attention_loss_w, ti_weight_decay=config.ti_weight_decay,
-                     optimizer=config.unet_optimizer_type, ti_optimizer=config.ti_optimizer,
+                     grad_accum=config.gradient_accumulation_steps, text=models.text if text_in_step else None, n_tokens=config.n_tokens,
+                     token_attention_loss_w=config.token_attention_loss_w if ti_on else 0.0, ti_weight_decay=config.ti_weight_decay if ti_on else 0.0,
+                     optimizer=config.unet_optimizer_type, ti_optimizer=config.ti_optimizer if ti_on else "adamw",
                      prodigy_d_coef=config.prodigy_d_coef, prodigy_growth_rate=config.unet_prodigy_growth_factor,
                      text_lora_weight_decay=config.text_encoder_lora_weight_decay,
-                     cond_reg_w=config.cond_reg_w, tok_cov_reg_w=config.tok_cov_reg_w, tok_cond_reg_w=config.tok_cond_reg_w,
+                     cond_reg_w=config.cond_reg_w if ti_on else 0.0, tok_cov_reg_w=config.tok_cov_reg_w if ti_on else 0.0,
+                     tok_cond_reg_w=config.tok_cond_reg_w if ti_on else 0.0, ti_trainable=ti_on,
                      reg_caption_ids=reg_caption_ids(config, models, cache) if (ti_on and config.tok_cond_reg_w > 0.0) else None)
     # main.py:92-101: the new token rows are initialised whether or not they are trained (with disable_ti they stay as drawn)
     from .ti import TiState
-    ti_state = ts.ti if ti_on else TiState(rt, models.encoders, config.n_tokens)
+    ti_state = ts.ti if text_in_step else TiState(rt, models.encoders, config.n_tokens)
     handler = TokenEmbeddingsHandler(ti_state, config.inserting_list_tokens)
     handler.initialize_new_tokens(seed=config.seed)
     # a20 token warm-up (main.py -> embedding_handler.pre_optimize_token_embeddings, :321-399): only with token_warmup_steps > 0
@@ -453,7 +456,7 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
             if pooled is not None:
                 pools.append(pooled.clone())
         return torch.cat(ctxs)[:n], (torch.cat(pools)[:n] if pools else None)
-    if not ti_on:
+    if not text_in_step:
         with torch.no_grad():
             cond = encode_rows(cache["input_ids"])
             cond_tok = encode_rows([t.view(1, 77) for t in cache["tok_ids"]]) if cache.get("tok_ids") is not None else None
@@ -488,7 +491,7 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
     has_tok = cache.get("tok_ids") is not None
     N_TOK_ROW = n_img                                                    # row n_img of the per-caption tables = the caption-dropout caption
     ids_tab = lists_all = cap_table = None
-    if ti_on:
+    if text_in_step:
         ids_tab = [torch.cat([t, (tok.view(1, 77) if has_tok else t[:1])]).to(dev) for t, tok in zip(cache["input_ids"], cache["tok_ids"] if has_tok else cache["input_ids"])]
         lists_all = list(cache["token_lists"]) + [list(cache["tok_list"]) if has_tok else list(cache["token_lists"][0])]
         cap_table = ts.ta.caption_table(lists_all, models.encoders[0].train_ids.tolist())
@@ -499,7 +502,7 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
         # dataset.DiagonalGaussian's clamp / exp on the whole table once instead of on the batch's rows every step (same values)
         g_all = DiagonalGaussian(data_d)
         post_mean, post_std = g_all.mean.contiguous(), g_all.std.contiguous()
-    if ti_on:
+    if text_in_step:
         pool_tab = ts.text.pool_position_table(ids_tab[-1])
 
     def cond_rows(cnd, cnd_tok):
@@ -533,8 +536,8 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
             if ts.te_arena is not None:
                 optimizers.optimizers["text_encoders"].param_groups[0]["lr"] = lrs["text_encoders"]
             optimizers.optimizers["unet"].param_groups[0]["lr"] = lrs["unet"]
-            if ti_on:
-                optimizers.optimizers["textual_inversion"].param_groups[0]["lr"] = lrs["textual_inversion"]
+            if text_in_step:      # (token rows frozen from the first step with disable_ti)
+                optimizers.optimizers["textual_inversion"].param_groups[0]["lr"] = lrs["textual_inversion"] if ti_on else 0.0
             idx, sel = order_d[step_in_epoch], sel_d[step_in_epoch]
             # the batch is written straight into the step's buffers (set_batch skips `x is self.x`): ~25 small launches between two graph
             # replays instead of 53 (tools/train_loop_gaps.py); same draws from the generator in the same order, same arithmetic
@@ -549,9 +552,9 @@ def train(config: TrainingConfig, runtime=None, every_step=False):
             if config.noise_offset > 0.0:                                                # main.py:313-317
                 noise += config.noise_offset * torch.randn((B, 4, 1, 1), generator=gd, device=dev)
             timesteps = torch.randint(0, 1000, (B,), generator=gd, device=dev, out=ts.timesteps)
-            if ti_on:
+            if text_in_step:
                 kw = {}
-                if lrs["textual_inversion"] == 0.0 and ts.te_arena is None and ts.prodigy_ti is None and (captured or dev.type != "cuda") and ts._acc is None \
+                if ti_on and lrs["textual_inversion"] == 0.0 and ts.te_arena is None and ts.prodigy_ti is None and (captured or dev.type != "cuda") and ts._acc is None \
                         and completion_f > config.freeze_ti_after_completion_f:
                     # f4: the token rows are frozen for the rest of the run (main.py:273-274) -> every caption's conditioning is a
                     # constant; encode each caption (and the dropout caption) once with the final rows, then skip the text encoders

@@ -111,6 +111,39 @@ def test_train_from_folder_with_tokenizer(tmp_path, monkeypatch, version, disabl
         assert set(emb) == {"clip_l", "clip_g"} and not torch.equal(emb["clip_l"], e0["clip_l"])     # the token rows were trained
 
 
+def test_text_encoder_lora_without_textual_inversion(tmp_path, monkeypatch):
+    """`text_encoder_lora_optimizer` with `disable_ti` (main.py:116-133: the adapters are built whether or not the token rows train): the text encoders stay inside the
+    step for the adapters' gradients, the token rows keep the values they were initialised with, no token-attention loss, no token regularisers in the logged total."""
+    monkeypatch.chdir(tmp_path)
+    from safetensors.torch import load_file
+    from sd_lora_trainer_amd import train as T
+    import sd_lora_trainer_amd.step as S
+    cfg = TrainingConfig(lora_training_urls="synthetic:4", concept_mode="object", name="te only", seed=4, resolution=128, train_batch_size=1, max_train_steps=30,
+                         checkpointing_steps=100, lora_rank=4, disable_ti=True, text_encoder_lora_optimizer="adamw", text_encoder_lora_lr=2e-2, text_encoder_lora_rank=4,
+                         txt_encoders_lr_warmup_steps=0, unet_lr=1e-3, pretrained_model={"path": "synthetic:tinyxl"})
+    seen = []
+    real_run = S.TrainStep._run
+
+    def spy(self, lr, lr_ti=0.0, lr_te=0.0, last_batch=False):
+        seen.append((lr_ti, lr_te, self.text is not None, self.ti_trainable, self.ta_w, self.te_arena is not None))
+        return real_run(self, lr, lr_ti, lr_te, last_batch)
+    monkeypatch.setattr(S.TrainStep, "_run", spy)
+    rt = unet_mod.Runtime("cpu", 1, act_dtype=torch.float32, ops=emu_ops)
+    progress, (config, out_dir) = _run(T.train(cfg, runtime=rt))
+    assert progress[-1] == 1.0 and len(seen) >= 30 and out_dir.endswith("checkpoint-31")      # (checkpoint-0, then the final one: the loop runs max_train_steps + 1 steps, main.py:462-470)
+    assert all(s[0] == 0.0 and s[2] and not s[3] and s[4] == 0.0 and s[5] for s in seen) and any(s[1] > 0.0 for s in seen)
+    ck = os.path.dirname(out_dir)
+    emb0 = load_file(os.path.join(ck, "checkpoint-0", "te_only_tinyxl_embeddings.safetensors"))
+    emb1 = load_file(os.path.join(out_dir, "te_only_tinyxl_embeddings.safetensors"))
+    assert all(torch.equal(emb0[k], emb1[k]) for k in emb0)                      # the token rows never moved
+    a0, a1 = load_file(os.path.join(ck, "checkpoint-0", "te_only_tinyxl_lora.safetensors")), load_file(os.path.join(out_dir, "te_only_tinyxl_lora.safetensors"))
+    te_keys = [k for k in a0 if k.startswith("lora_te") and not k.endswith("alpha")]
+    assert te_keys, sorted(a0)[:8]
+    assert sum(int(not torch.equal(a0[k], a1[k])) for k in te_keys) > len(te_keys) // 2      # ... the text-encoder adapters did
+    ta = json.load(open(os.path.join(out_dir, "training_args.json")))
+    assert all(np.isfinite(ta["training_attributes"]["losses"]["tot_loss"]))
+
+
 @pytest.mark.parametrize("kw", [dict(aspect_ratio_bucketing=True), dict(tok_cond_reg_w=0.1, text_encoder_lora_optimizer="adamw", use_dora=True)])
 def test_unbuilt_fields_raise(tmp_path, monkeypatch, kw):
     monkeypatch.chdir(tmp_path)

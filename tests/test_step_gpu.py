@@ -138,7 +138,8 @@ def test_prodigy_step_in_graph():
 
 @pytest.mark.parametrize("extra", [{}, dict(is_lora=False, disable_ti=True, unet_optimizer_type="AdamW8bit", unet_lr=2e-4), dict(text_encoder_lora_optimizer="adamw", text_encoder_lora_lr=1e-4, text_encoder_lora_rank=8, ti_optimizer="prodigy", token_warmup_steps=5, training_attributes={"gpt_description": "a synthetic concept"},
                                                cond_reg_w=1e-4, tok_cov_reg_w=1.0, tok_cond_reg_w=1e-4, gradient_accumulation_steps=2),
-                                   dict(tok_cond_reg_w=1e-4, cond_reg_w=1e-4), dict(use_dora=True, lora_rank=16)])
+                                   dict(tok_cond_reg_w=1e-4, cond_reg_w=1e-4), dict(use_dora=True, lora_rank=16),
+                                   dict(disable_ti=True, text_encoder_lora_optimizer="adamw", text_encoder_lora_lr=1e-4, text_encoder_lora_rank=8)])
 def test_train_generator_on_gpu(tmp_path, monkeypatch, extra):
     """main.py-style driver: config -> train() generator -> kohya checkpoint, on the HIP path with hipGraph replay.
     Second case: text-encoder LoRA (a21) next to the UNet LoRA, Prodigy on the token rows (a17)."""
