@@ -1,21 +1,20 @@
-"""Largest idle gaps between consecutive kernels of the LAST step of a rocprofv3 kernel trace (who ends, how long nothing runs, who starts).
-  python tools/step_gaps.py trace_kernel_trace.csv [top]"""
+"""Idle holes inside the LAST training step of a rocprofv3 kernel trace: every gap of more than 15 us between the end of everything launched so far and the next
+kernel's start, with its offset from the step's first kernel and its position in the launch order.  python tools/step_gaps.py trace_kernel_trace.csv"""
 import csv
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-top = int(sys.argv[2]) if len(sys.argv) > 2 else 15
 marks = [i for i, r in enumerate(rows) if "mse_reduce_kernel" in r["Kernel_Name"]]
-step = rows[marks[-2] + 1: marks[-1] + 1]
-nm = lambda r: r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:60]  # noqa: E731
-gaps = []
-end = int(step[0]["End_Timestamp"])
-for i in range(1, len(step)):
-    st = int(step[i]["Start_Timestamp"])
-    gaps.append(((st - end) / 1e3, i))
-    end = max(end, int(step[i]["End_Timestamp"]))
-tot = sum(g for g, _ in gaps if g > 0)
-print(f"{len(step)} kernels, idle between kernels {tot / 1e3:.3f} ms; gaps > 3 us: {sum(1 for g, _ in gaps if g > 3)} summing {sum(g for g, _ in gaps if g > 3) / 1e3:.3f} ms; median gap {sorted(g for g, _ in gaps)[len(gaps) // 2]:.2f} us")
-for g, i in sorted(gaps, reverse=True)[:top]:
-    print(f"{g:9.1f} us   #{i:5d}  after {nm(step[i - 1])}   before {nm(step[i])}")
+n = marks[-1] - marks[-2]
+for back in (2, 1):          # the last two whole steps (marker to marker)
+    seg = rows[marks[-back - 1]: marks[-back]]
+    t0, hi = int(seg[0]["Start_Timestamp"]), int(seg[0]["End_Timestamp"])
+    busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg) / 1e6
+    print(f"step -{back}: {len(seg)} launches, span {(int(seg[-1]['End_Timestamp']) - t0) / 1e6:.3f} ms, busy {busy:.3f} ms")
+    for i, (a, b) in enumerate(zip(seg, seg[1:])):
+        hi = max(hi, int(a["End_Timestamp"]))
+        g = (int(b["Start_Timestamp"]) - hi) / 1e3
+        if g > 15:
+            nm = lambda r: r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:50]  # noqa: E731
+            print(f"   hole {g:7.1f} us at +{(hi - t0) / 1e3:9.1f} us, after launch {i} ({nm(a)}) before ({nm(b)})")

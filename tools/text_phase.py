@@ -31,6 +31,22 @@ def report(title, seg):
     print(f"{title}: {len(seg)} launches, span {span / 1e3:.3f} ms, busy {sum(v[1] for v in agg.values()) / 1e3:.3f} ms")
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
         print(f"   {k:90s} {c:5d} {t / 1e3:7.3f} ms  avg {t / c:6.1f} us")
+    # where the idle time of the phase sits: the gaps between the end of everything launched so far and the next start
+    gaps, hi = [], int(seg[0]["End_Timestamp"])
+    for a, b in zip(seg, seg[1:]):
+        hi = max(hi, int(a["End_Timestamp"]))
+        g = (int(b["Start_Timestamp"]) - hi) / 1e3
+        if g > 0:
+            gaps.append((g, name(a)[:40], name(b)[:40]))
+    if gaps:      # the launches around the largest hole, with their durations
+        gi = max(range(len(seg) - 1), key=lambda i: int(seg[i + 1]["Start_Timestamp"]) - max(int(x["End_Timestamp"]) for x in seg[max(0, i - 8): i + 1]))
+        t0 = int(seg[0]["Start_Timestamp"])
+        for x in seg[max(0, gi - 6): gi + 4]:
+            print(f"      @{(int(x['Start_Timestamp']) - t0) / 1e3:9.1f} us  {dur(x):7.1f} us  q{x.get('Queue_Id', '?')} s{x.get('Stream_Id', '?')}  grid {x.get('Grid_Size_X', x.get('Grid_Size', '?'))}  {name(x)[:70]}")
+    tot = sum(g for g, _, _ in gaps)
+    big = sorted(gaps, reverse=True)[:6]
+    print(f"   idle {tot / 1e3:.3f} ms in {len(gaps)} gaps (median {sorted(g for g, _, _ in gaps)[len(gaps) // 2] if gaps else 0:.2f} us); largest: " +
+          "; ".join(f"{g:.1f} us after {a} before {b}" for g, a, b in big))
 
 
 report("text forward", step[:an])
