@@ -29,6 +29,10 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tm
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc15_w -- python $R/bench.py --config sd15 --no-graph $B --steps 2 --warmup 1 > /dev/null 2>&1
 python $R/tools/step_profile.py $T15 $(ls /tmp/pmc15_f/*/*counter_collection.csv | head -1) $(ls /tmp/pmc15_w/*/*counter_collection.csv | head -1) \
   $O/r05_sd15_512_b4_step_profile.json $O/r05_sd15_512_b4_per_kernel.csv $C "python bench.py --config sd15 $B" > /dev/null 2> $O/step_profile_sd15.err
+# cfg5 (SDXL 512 px batch 4 full fine-tune, AdamW8bit): last-step table
+cd /tmp; rm -rf /tmp/pf5
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/pf5 -- python $R/bench.py --full-ft --no-cpu-baseline --steps 6 --warmup 3 > /dev/null 2>&1
+python $R/tools/last_step_auto.py $(ls /tmp/pf5/*/*kernel_trace.csv | head -1) 45 > $O/r05_fullft_sdxl512_b4_last_step_kernels.txt 2>&1
 cd $R
 for v in "--no-ti" "--ti-frozen" "--config sd15" "--full-ft" "--full-ft --fp32-moments" "--rank 64" "--jobs-per-gpu 2" "--dora" "--config sd15 --full-ft"; do
   timeout 600 python bench.py $v $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', round(d['ms_per_step'],2), round(d['value'],2), round(d['roofline']['frac'],4))" >> $O/r05_bench_variants.txt
