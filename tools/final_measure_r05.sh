@@ -43,5 +43,5 @@ timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --mast
 # round 5 extras: the bound experiments of the wave-split-K kernels' K walk, the convolution probe, the GEMM fetch-ratio table, the dry run of the data-parallel exchange step on one RCCL rank
 timeout 600 python tools/wsk_pack_probe.py 2>&1 | grep -v "Warning\|amdgpu.ids" > $O/r05_wsk_pack_probe.txt
 timeout 600 python tools/wsk_conv_probe.py 2>&1 | grep -v "Warning\|amdgpu.ids" > $O/r05_wsk_conv_probe.txt
-timeout 900 python bench.py --full-ft --dry-collectives --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | head -1 > $O/r05_fullft_dry_collectives.json
+timeout 900 python bench.py --full-ft --dry-collectives --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | grep "^{" | tail -1 > $O/r05_fullft_dry_collectives.json
 timeout 1500 bash $R/tools/gemm_fetch_ratio.sh $O/r05_gemm_fetch_ratio.txt > $O/r05_gemm_fetch_ratio.log 2>&1
