@@ -57,3 +57,48 @@ def test_fullft_gpu_matches_oracle(version, B):
     att = next(a for a in unet.cross_attns)
     w = tr.view(att.to_q.went)
     assert torch.equal(att.to_q.W, w.to(torch.bfloat16)) and torch.equal(att.to_q.Wt, w.t().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("version", ["tinyxl"])
+def test_fullft_adamw8bit_step_follows_fp32_moments(version):
+    """`unet_optimizer_type: AdamW8bit` through the whole captured step (TrainStep(optimizer="AdamW8bit"): sdlt_adamw8_shadow_refresh inside the graph) against the same
+    step with fp32 moments: the first step moves the masters identically (the update uses the unquantised moments; only the order of step and decay differs), after 12
+    steps on a fixed batch the two runs are within 8 % of the displacement, both train, and the operands the GEMMs read are the bf16 rounding of the 8-bit run's masters."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import unet_ref as U
+    from sd_lora_trainer_amd import fullft, topology
+    import sd_lora_trainer_amd.step as S
+    import sd_lora_trainer_amd.unet as M
+    cfg, h, B = U.CONFIGS[version], 16, 2
+    latent, noise, mask, t, ctx, pooled, tid, add = _inputs(cfg, B, h)
+    dv = lambda x: x.cuda() if x is not None else None  # noqa: E731
+    runs = {}
+    for opt in ("adamw", "AdamW8bit"):
+        sd = {k: v.to(torch.bfloat16).float() for k, v in U.init_unet_state(cfg, seed=0).items()}
+        rt = M.Runtime("cuda:0", B)
+        tr = fullft.WeightTrainer(rt)
+        unet = M.UNet(rt, topology.CONFIGS[version], sd, trainer=tr)
+        ts = S.TrainStep(rt, unet, latent_hw=(h, h), snr_gamma=5.0, optimizer=opt)
+        assert ts.adam8 == (opt == "AdamW8bit")
+        ts.set_batch(dv(latent), dv(noise), dv(t), dv(mask), dv(ctx), dv(pooled), dv(tid))
+        ts.capture(warmup=1)
+        p0 = tr.params.clone()
+        traj, losses = [], []
+        for i in range(12):
+            ts.run(2e-4)
+            losses.append(float(ts.loss))
+            if i in (0, 11):
+                traj.append(tr.params.clone())
+        runs[opt] = (tr, unet, p0, traj, losses)
+    tr8, unet8, p0, t8, l8 = runs["AdamW8bit"]
+    _, _, q0, t32, l32 = runs["adamw"]
+    assert torch.equal(p0, q0) and tr8.m is None and tr8.q8[0].dtype == torch.uint8 and int(tr8.q8[0].max()) > 0
+    d1 = float((t32[0] - q0).norm())
+    assert float((t8[0] - t32[0]).norm()) <= 2e-3 * d1, (float((t8[0] - t32[0]).norm()), d1)
+    d12 = float((t32[1] - q0).norm())
+    assert float((t8[1] - t32[1]).norm()) <= 0.08 * d12, (float((t8[1] - t32[1]).norm()), d12)
+    assert l8[-1] < l8[0] and l32[-1] < l32[0] and abs(l8[-1] - l32[-1]) <= 0.05 * abs(l32[0]), (l8, l32)
+    att = next(a for a in unet8.cross_attns)
+    w = tr8.view(att.to_q.went)
+    assert torch.equal(att.to_q.W, w.to(torch.bfloat16)) and torch.equal(att.to_q.Wt, w.t().to(torch.bfloat16))
