@@ -121,7 +121,7 @@ __device__ __forceinline__ void sstore_nat(const TileRegs<DP>& t, char* dst, int
 // state and K / V buffers; the groups' (m, l, O) meet through LDS at the end.  A 1024-token layer is 16 dependent tile steps per
 // workgroup and 1.25 workgroups per CU: with one wave per SIMD the softmax VALU work and the MFMAs of a step run one after the other -
 // two waves per SIMD on half the chain each overlap them (and halve the chain).
-template <int DP, int KS>
+template <int DP, int KS, int DV = DP>
 __device__ __forceinline__ void attn_fwd_body(const sdlt_attn_params& p, char* smem, const WgId wg) {
   constexpr int NSTR = tile_stride<DP>();
   const int b = wg.z, h = wg.y, q0 = wg.x * 64;
@@ -136,9 +136,9 @@ __device__ __forceinline__ void attn_fwd_body(const sdlt_attn_params& p, char* s
     qf[kk] = ld_frag_global((const bf16_t*)p.Q + ((int64_t)b * p.Nqp + q) * p.ldq + hc + col, q < p.Nq && col < d);
   }
   float m = -1e30f, lsum = 0.f;
-  f32x4 o[DP / 16];
+  f32x4 o[DV / 16];
 #pragma unroll
-  for (int df = 0; df < DP / 16; ++df) o[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int df = 0; df < DV / 16; ++df) o[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float sl2 = p.scale * LOG2E;
   const int kend = p.causal ? min(p.Nk, q0 + 64) : p.Nk;
 
@@ -219,14 +219,14 @@ __device__ __forceinline__ void attn_fwd_body(const sdlt_attn_params& p, char* s
     lsum = lsum * alpha + rs;
     TR();
 #pragma unroll
-    for (int df = 0; df < DP / 16; ++df) o[df] *= alpha;
+    for (int df = 0; df < DV / 16; ++df) o[df] *= alpha;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       float a4[4] = {s[2 * kb][0], s[2 * kb][1], s[2 * kb][2], s[2 * kb][3]};
       float b4[4] = {s[2 * kb + 1][0], s[2 * kb + 1][1], s[2 * kb + 1][2], s[2 * kb + 1][3]};
       bf16x8 pf = pack8(a4, b4);
 #pragma unroll
-      for (int df = 0; df < DP / 16; ++df) {
+      for (int df = 0; df < DV / 16; ++df) {
         bf16x8 vf = lds_tr_frag(Vs + troff + kb * 32 * NSTR + ((df ^ tsw) << 5), NSTR);   // V[key block kb][columns df*16..]^T
         o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[df], 0, 0, 0);
       }
@@ -250,7 +250,7 @@ __device__ __forceinline__ void attn_fwd_body(const sdlt_attn_params& p, char* s
       mg[0] = m;
       mg[1] = lsum;
 #pragma unroll
-      for (int df = 0; df < DP / 16; ++df) *(f32x4*)(mg + 4 + df * 4) = o[df];
+      for (int df = 0; df < DV / 16; ++df) *(f32x4*)(mg + 4 + df * 4) = o[df];
     }
     __syncthreads();
     if (grp == 1) return;
@@ -259,7 +259,7 @@ __device__ __forceinline__ void attn_fwd_body(const sdlt_attn_params& p, char* s
     m = mn;
     lsum = lsum * a0 + l1 * a1;
 #pragma unroll
-    for (int df = 0; df < DP / 16; ++df) {
+    for (int df = 0; df < DV / 16; ++df) {
       const f32x4 o1 = *(const f32x4*)(mg + 4 + df * 4);
       o[df] = o[df] * a0 + o1 * a1;
     }
@@ -268,7 +268,7 @@ __device__ __forceinline__ void attn_fwd_body(const sdlt_attn_params& p, char* s
     const float inv = 1.f / lsum;
     if (g == 0 && p.L && q < p.Nq) p.L[((int64_t)b * p.H + h) * p.Nq + q] = (m + log2f(lsum)) / LOG2E;
 #pragma unroll
-    for (int df = 0; df < DP / 16; ++df) {
+    for (int df = 0; df < DV / 16; ++df) {
       int col = df * 16 + g * 4;
       if (col < d) {
         uint2 w;
@@ -280,10 +280,13 @@ __device__ __forceinline__ void attn_fwd_body(const sdlt_attn_params& p, char* s
   }
 }
 
-template <int DP, int KS = 1>
+// DV: width of the OUTPUT column blocks (O, dQ, dK, dV accumulators and the products that feed them).  Heads of 40 columns (SD1.5's 320-wide blocks: 4096 tokens x 8 heads)
+// sit in the 64-column tiles of DP = 64 - the contraction over d keeps its two 32-wide steps - but need only three of the four 16-column output blocks: DV = 48 drops a quarter
+// of the P V / dS K / P^T dO / dS^T Q MFMAs and of the accumulator registers.
+template <int DP, int KS = 1, int DV = DP>
 __global__ __launch_bounds__(256 * KS) __attribute__((amdgpu_waves_per_eu(DP == 64 ? 4 : 1, DP == 64 ? 4 : 8))) void attn_fwd_kernel(const sdlt_attn_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  attn_fwd_body<DP, KS>(p, smem, xcd_wg());
+  attn_fwd_body<DP, KS, DV>(p, smem, xcd_wg());
 }
 // Two independent attention problems of the same head width in ONE launch: the heads of p1 follow the heads of p0 along grid y (the text
 // encoders' layer i of CLIP-L and of OpenCLIP-bigG; see strip_pair_kernel).
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DP == 64 ? 
 }
 
 // =============================================================================== backward dQ (per 64-query tile)
-template <int DP, bool WRITE_D>
+template <int DP, bool WRITE_D, int DV = DP>
 __device__ __forceinline__ void attn_bwd_dq_body(const sdlt_attn_params& p, char* smem, const int bx, const WgId wg) {
   constexpr int NSTR = tile_stride<DP>();
   const int b = wg.z, h = wg.y, q0 = bx * 64;
@@ -329,9 +332,9 @@ __device__ __forceinline__ void attn_bwd_dq_body(const sdlt_attn_params& p, char
   Dq += __shfl_xor(Dq, 16, 64);
   Dq += __shfl_xor(Dq, 32, 64);
   if (WRITE_D && g == 0 && qok) p.D[((int64_t)b * p.H + h) * p.Nq + q] = Dq;   // (merged launch: written by attn_prep_kernel instead)
-  f32x4 dq[DP / 16];
+  f32x4 dq[DV / 16];
 #pragma unroll
-  for (int df = 0; df < DP / 16; ++df) dq[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int df = 0; df < DV / 16; ++df) dq[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float sl2 = p.scale * LOG2E;
   const int kend = p.causal ? min(p.Nk, q0 + 64) : p.Nk;
 
@@ -398,7 +401,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const sdlt_attn_params& p, char
       float b4[4] = {s[2 * kb + 1][0], s[2 * kb + 1][1], s[2 * kb + 1][2], s[2 * kb + 1][3]};
       bf16x8 dsf = pack8(a4, b4);
 #pragma unroll
-      for (int df = 0; df < DP / 16; ++df) {
+      for (int df = 0; df < DV / 16; ++df) {
         bf16x8 ktf = lds_tr_frag(Ks + troff + kb * 32 * NSTR + ((df ^ tsw) << 5), NSTR);
         dq[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dq[df], 0, 0, 0);
       }
@@ -412,7 +415,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const sdlt_attn_params& p, char
   }
   if (q < p.Nqp) {   // pad rows: dq == 0
 #pragma unroll
-    for (int df = 0; df < DP / 16; ++df) {
+    for (int df = 0; df < DV / 16; ++df) {
       int col = df * 16 + g * 4;
       if (col < d) {
         uint2 w;
@@ -425,7 +428,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const sdlt_attn_params& p, char
 }
 
 // =============================================================================== backward dK,dV (per 64-key tile, optional query split)
-template <int DP>
+template <int DP, int DV = DP>
 __device__ __forceinline__ void attn_bwd_dkdv_body(const sdlt_attn_params& p, char* smem, const int bx, const WgId wg) {
   constexpr int NSTR = tile_stride<DP>();
   const int b = wg.z, h = wg.y;
@@ -442,9 +445,9 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const sdlt_attn_params& p, ch
     kf[kk] = ld_frag_global((const bf16_t*)p.K + ((int64_t)b * p.Nkp + key) * p.ldk + hc + col, kok && col < d);
     vf[kk] = ld_frag_global((const bf16_t*)p.V + ((int64_t)b * p.Nkp + key) * p.ldv + hc + col, kok && col < d);
   }
-  f32x4 dk[DP / 16], dv[DP / 16];
+  f32x4 dk[DV / 16], dv[DV / 16];
 #pragma unroll
-  for (int df = 0; df < DP / 16; ++df) {
+  for (int df = 0; df < DV / 16; ++df) {
     dk[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
     dv[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
@@ -543,7 +546,7 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const sdlt_attn_params& p, ch
       float e4[4] = {dp[2 * qb + 1][0], dp[2 * qb + 1][1], dp[2 * qb + 1][2], dp[2 * qb + 1][3]};
       bf16x8 dsf = pack8(c4, e4);
 #pragma unroll
-      for (int df = 0; df < DP / 16; ++df) {
+      for (int df = 0; df < DV / 16; ++df) {
         bf16x8 gtf = lds_tr_frag(Gs + troff + qb * 32 * NSTR + ((df ^ tsw) << 5), NSTR);
         dv[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gtf, pf, dv[df], 0, 0, 0);
         bf16x8 qtf = lds_tr_frag(Qs + troff + qb * 32 * NSTR + ((df ^ tsw) << 5), NSTR);
@@ -559,7 +562,7 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const sdlt_attn_params& p, ch
   if (key < p.Nkp) {   // pad rows [Nk, Nkp) receive zeros (their accumulators are zero: p == 0 there)
     const int64_t row = (int64_t)b * p.Nkp + key;
 #pragma unroll
-    for (int df = 0; df < DP / 16; ++df) {
+    for (int df = 0; df < DV / 16; ++df) {
       int col = df * 16 + g * 4;
       if (col < d) {
         if (p.qsplit > 1) {
@@ -582,17 +585,17 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const sdlt_attn_params& p, ch
 }
 
 // =============================================================================== backward launch forms
-template <int DP>
+template <int DP, int DV = DP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DP == 64 ? 3 : 1, DP == 64 ? 3 : 8))) void attn_bwd_dq_kernel(const sdlt_attn_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const WgId wg = xcd_wg();
-  attn_bwd_dq_body<DP, true>(p, smem, wg.x, wg);
+  attn_bwd_dq_body<DP, true, DV>(p, smem, wg.x, wg);
 }
-template <int DP>
+template <int DP, int DV = DP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DP == 64 ? 3 : 1, DP == 64 ? 3 : 8))) void attn_bwd_dkdv_kernel(const sdlt_attn_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const WgId wg = xcd_wg();
-  attn_bwd_dkdv_body<DP>(p, smem, wg.x, wg);
+  attn_bwd_dkdv_body<DP, DV>(p, smem, wg.x, wg);
 }
 // Self-attention: the dQ tiles and the dK/dV tiles of one layer in ONE launch (blockIdx.x < #query tiles: dQ role).  At
 // 1024 tokens x 20 heads either pass alone is 320 workgroups of 16 dependent steps - latency-bound, the chip half empty;
@@ -1169,6 +1172,13 @@ extern "C" int sdlt_attn_fwd(const sdlt_attn_params* pp, void* stream) {
     SDLT_CHECK_LAUNCH();
     return SDLT_OK;
   }
+  static const bool dv48 = !(getenv("SDLT_ATTN_DV48") && atoi(getenv("SDLT_ATTN_DV48")) == 0);      // (A/B switch: 0 = four output blocks for heads of <= 48 columns too)
+  if (dv48 && dp == 64 && p.d <= 48) {
+    set_smem((attn_fwd_kernel<64, 1, 48>), SMEM_FWD(64));
+    hipLaunchKernelGGL((attn_fwd_kernel<64, 1, 48>), grid, dim3(256), SMEM_FWD(64), s, p);
+    SDLT_CHECK_LAUNCH();
+    return SDLT_OK;
+  }
   ATTN_DISPATCH(dp, attn_fwd_kernel, grid, SMEM_FWD)
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
@@ -1238,12 +1248,16 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
   if (p.accumulate_dq || p.accumulate_dk) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_attn_bwd: accumulate_dq/dk exist for the single-pass cross-attention kernel only");
   dim3 gq((p.Nq + 63) / 64, p.H, p.B);
 #define SMEM_DQ(D_) (2 * (2 * 64 * NSTRH(D_)))
-  ATTN_DISPATCH(dp, attn_bwd_dq_kernel, gq, SMEM_DQ)
+  static const bool dv48 = !(getenv("SDLT_ATTN_DV48") && atoi(getenv("SDLT_ATTN_DV48")) == 0);
+  const bool v48 = dv48 && dp == 64 && p.d <= 48;
+  if (v48) { set_smem((attn_bwd_dq_kernel<64, 48>), SMEM_DQ(64)); hipLaunchKernelGGL((attn_bwd_dq_kernel<64, 48>), gq, dim3(256), SMEM_DQ(64), s, p); }
+  else { ATTN_DISPATCH(dp, attn_bwd_dq_kernel, gq, SMEM_DQ) }
   if (p.qsplit > 1 && (((uintptr_t)p.dK32 | (uintptr_t)p.dV32) & 15 || (p.ld32 & 3) || (C & 3)))
     SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_attn_bwd: the dK / dV slabs of a query-split backward need 16-byte rows (ld32 %% 4, C %% 4)");
   dim3 gk(((p.Nk + 63) / 64) * p.qsplit, p.H, p.B);
 #define SMEM_DKV(D_) (2 * (2 * 64 * NSTRH(D_) + 512))
-  ATTN_DISPATCH(dp, attn_bwd_dkdv_kernel, gk, SMEM_DKV)
+  if (v48) { set_smem((attn_bwd_dkdv_kernel<64, 48>), SMEM_DKV(64)); hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, 48>), gk, dim3(256), SMEM_DKV(64), s, p); }
+  else { ATTN_DISPATCH(dp, attn_bwd_dkdv_kernel, gk, SMEM_DKV) }
   if (p.qsplit > 1) {      // [qsplit][B * Nkp][ld32] partial slabs -> bf16 dK / dV, summed in slab order (bitwise reproducible)
     int blocks = (int)(((int64_t)krows * C / 2 + 255) / 256);
     if (blocks > 4096) blocks = 4096;

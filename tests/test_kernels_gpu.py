@@ -652,6 +652,8 @@ ATTN_CASES = [
     dict(B=1, H=10, Nq=4096, Nk=4096, Nkp=4096, d=64, causal=False, qsplit=1),      # the 64 x 64 level of SDXL at 1024 px (attn32: 4096 tokens x 10 heads)
     # SD1.5's 160-wide cross-attention heads with a query split: the generic dQ + dK / dV launches, partial dK / dV in per-split slabs (ordered sum; float atomics until round 5)
     dict(B=2, H=2, Nq=320, Nk=77, Nkp=128, d=160, causal=False, qsplit=4),
+    # SD1.5's 40-wide heads on a grid large enough for the separate dQ and dK / dV launches (> 2048 workgroups): three 16-column output blocks (DV = 48) in 64-column tiles
+    dict(B=5, H=8, Nq=2048, Nk=2048, Nkp=2048, d=40, causal=False, qsplit=1),
 ]
 
 
