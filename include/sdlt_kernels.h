@@ -403,6 +403,11 @@ int sdlt_adamw_shadow_refresh(const sdlt_shadow_desc* descs_dev, const int32_t* 
 int sdlt_adamw8_shadow_refresh(const sdlt_shadow_desc* descs_dev, const int32_t* block_desc_dev, const int32_t* block_first_dev, int32_t n_blocks, float* p,
                                const float* g, uint8_t* m8, uint8_t* v8, float* absmax, const float* tables, const float* hyper, void* stream);
 
+/* The AdamW8bit update of sdlt_adamw8_shadow_refresh on a flat range of n elements (n % 4 == 0): blocks of 2048 CONSECUTIVE elements counted from p - bitsandbytes' own
+ * partition - with absmax fp32 [ceil(n / 2048)][2] = {m, v} (8-byte aligned, zero before the first step), no operand refresh.  The owned slices of the sharded optimizer
+ * (data-parallel full fine-tune, ZeRO-1): their masters are all-gathered before the refresh. */
+int sdlt_adamw8_flat(float* p, const float* g, uint8_t* m8, uint8_t* v8, float* absmax, int64_t n, const float* tables, const float* hyper, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ DoRA
  * Weight-decomposed adapters: peft `LoraConfig(use_dora=True)` as the reference requests it (trainer/optimizer.py:86-95; L1 penalty
  * and weight decay are switched off with it, config.py:153-157).  [3P-unverified: peft 0.10.0 LoraLayer._apply_dora / Conv2d]

@@ -8,10 +8,16 @@ percentile_clipping=100, min_8bit_size=4096)`:
     in fp32, take the block's new absmax, step the parameter from the UNquantised moments (`p += step_size * m / (sqrt(v) + correction2 * eps)`, then
     `p *= 1 - lr * weight_decay`), requantise to the nearest code; a first-moment code whose sign differs from m's moves one step towards m.
 
+A property of the algorithm as restated (worth knowing when reading a parity report): an element whose first moment is below ~2.7e-7 of its block's largest rounds to the code
+of 0 and, when NEGATIVE, is moved one step further by the sign rule (the code of 0 counts as positive) - to -5.5e-7 x absmax, away from its value; its second moment has long been
+rounded to 0 (that happens below 1.6e-7 of the block's largest v, i.e. gradients below 4e-4 of the block's largest).  Its next update is then ~lr x 5.5e-7 x absmax_m / (eps + ...):
+negligible while 5.5e-7 x absmax_m stays below eps = 1e-8 (gradients up to ~1e-2, every real training run), large on synthetic gradients of order 1.
+
 PARITY UNPINNED: bitsandbytes is a third-party dependency that is absent from /root/reference and from this image (`import bitsandbytes` fails), the reference
 holds no golden vector of its optimizer state, so this restatement follows the published algorithm as read and is pinned by structure only (256 distinct sorted
 codes, symmetry, the decade layout).  One deliberate difference, shared with the HIP kernel it checks (include/sdlt_kernels.h: sdlt_adamw8_shadow_refresh): a
 quantisation block is 32 rows x 64 columns of the weight's [N, K] view (2048 elements, bnb's block size) instead of 2048 consecutive elements of the flattened tensor.
+(sdlt_adamw8_flat, the sharded optimizer's slices, uses consecutive elements: checked with the range viewed as a [n / 64, 64] matrix, whose 32 x 64 blocks are exactly that.)
 """
 import math
 

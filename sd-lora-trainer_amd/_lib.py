@@ -182,6 +182,7 @@ SYMBOLS = {
     "sdlt_lora_shadow_refresh": (i32, [vp, vp, vp, i32, vp, vp]),
     "sdlt_adamw_shadow_refresh": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
     "sdlt_adamw8_shadow_refresh": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "sdlt_adamw8_flat": (i32, [vp, vp, vp, vp, vp, i64, vp, vp, vp]),
     "sdlt_dora_refresh": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "sdlt_dora_scale_wt": (i32, [vp, vp, vp, i32, vp]),
     "sdlt_dora_mag_grad": (i32, [vp, vp, vp, i32, vp, vp, i32, vp, vp]),

@@ -497,6 +497,82 @@ __device__ __forceinline__ void adamw8_tile_vec(const sdlt_shadow_desc& d, int r
   }
 }
 
+// The same update on a FLAT range (the owned slices of the sharded optimizer, data-parallel full fine-tune): one workgroup per block of 2048 CONSECUTIVE elements - bitsandbytes' own
+// partition, counted from the start of the range -, eight elements per lane (two float4 of p and g, two dwords of codes), no operand refresh (the masters are all-gathered first).
+// absmax: fp32 [ceil(n / 2048)][2] = {m, v}.  n % 4 == 0; the last block may be short.
+__global__ __launch_bounds__(256) void adamw8_flat_kernel(float* p, const float* g, uint8_t* m8, uint8_t* v8, float* absmax, int64_t n, const float* tables, const float* hyper) {
+  __shared__ float tb[1024];
+  __shared__ float red[4][2];
+  const int thr = threadIdx.x, wave = thr >> 6, lane = thr & 63;
+  ((uint4*)tb)[thr] = ((const uint4*)tables)[thr];
+  const int64_t e0 = (int64_t)blockIdx.x * 2048 + thr * 8;
+  const float2 am = *(const float2*)(absmax + 2 * (int64_t)blockIdx.x);
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2 = hyper[6], gs = hyper[8];
+  const float c2 = sqrtf(bc2), step_size = -lr * c2 / bc1, eps2 = c2 * eps, decay = wd > 0.f ? 1.f - lr * wd : 1.f;
+  float4 pv[2], gv[2];
+  uint32_t cm[2], cv[2];
+  bool ok[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {      // (unconditional requests; a quad past the end reads the range's first elements and is dropped)
+    ok[k] = e0 + 4 * k < n;
+    const int64_t i = ok[k] ? e0 + 4 * k : 0;
+    pv[k] = *(const float4*)(p + i); gv[k] = *(const float4*)(g + i);
+    cm[k] = *(const uint32_t*)(m8 + i); cv[k] = *(const uint32_t*)(v8 + i);
+  }
+  __syncthreads();
+  float mn[8], vn[8], mxm = 0.f, mxv = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    float val[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gi = gv[k][e] * gs;
+      float mi = b1 * (tb[(cm[k] >> (8 * e)) & 255u] * am.x) + (1.f - b1) * gi;
+      float vi = b2 * (tb[512 + ((cv[k] >> (8 * e)) & 255u)] * am.y) + (1.f - b2) * gi * gi;
+      if (!ok[k]) mi = vi = 0.f;
+      mn[k * 4 + e] = mi; vn[k * 4 + e] = vi;
+      mxm = fmaxf(mxm, fabsf(mi));
+      mxv = fmaxf(mxv, vi);
+      val[e] = (pv[k][e] + step_size * (mi * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vi) + eps2))) * decay;
+    }
+    if (ok[k]) *(float4*)(p + e0 + 4 * k) = (float4){val[0], val[1], val[2], val[3]};
+  }
+  mxm = wave_max(mxm);
+  mxv = wave_max(mxv);
+  if (lane == 0) { red[wave][0] = mxm; red[wave][1] = mxv; }
+  __syncthreads();
+  mxm = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
+  mxv = fmaxf(fmaxf(red[0][1], red[1][1]), fmaxf(red[2][1], red[3][1]));
+  if (thr == 0) *(float2*)(absmax + 2 * (int64_t)blockIdx.x) = make_float2(mxm, mxv);
+  const float im = mxm > 0.f ? __builtin_amdgcn_rcpf(mxm) : 0.f, iv = mxv > 0.f ? __builtin_amdgcn_rcpf(mxv) : 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    float x1[4], x2[4], u1[4], d1[4], u2[4], d2[4];
+    int g1[4], g2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      x1[e] = mn[k * 4 + e] * im;
+      x2[e] = vn[k * 4 + e] * iv;
+      g1[e] = q8_guess<true>(x1[e]);
+      g2[e] = q8_guess<false>(x2[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      u1[e] = tb[256 + g1[e]]; d1[e] = tb[256 + (g1[e] > 0 ? g1[e] - 1 : 0)];
+      u2[e] = tb[768 + g2[e]]; d2[e] = tb[768 + (g2[e] > 0 ? g2[e] - 1 : 0)];
+    }
+    uint32_t w1 = 0, w2 = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int q1 = q8_fix(g1[e], x1[e], u1[e], d1[e]);
+      q1 += ((q1 < 127) != (mn[k * 4 + e] < 0.f)) ? (mn[k * 4 + e] > 0.f ? 1 : -1) : 0;
+      w1 |= (uint32_t)q1 << (8 * e);
+      w2 |= (uint32_t)q8_fix(g2[e], x2[e], u2[e], d2[e]) << (8 * e);
+    }
+    if (ok[k]) { *(uint32_t*)(m8 + e0 + 4 * k) = w1; *(uint32_t*)(v8 + e0 + 4 * k) = w2; }
+  }
+}
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void shadow_adamw8_kernel(const sdlt_shadow_desc* descs, const int32_t* block_desc, const int32_t* block_first, float* arena, const float* g,
                                                             uint8_t* m8, uint8_t* v8, float* absmax, const float* tables, const float* hyper) {
   __shared__ bf16_t tile[64][72];
@@ -699,6 +775,14 @@ extern "C" int sdlt_adamw8_shadow_refresh(const sdlt_shadow_desc* descs_dev, con
   if (n_blocks <= 0 || !p || !g || !m8 || !v8 || !absmax || !tables || !hyper) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_adamw8_shadow_refresh: n_blocks=%d or a null buffer", n_blocks);
   if ((((uintptr_t)absmax | (uintptr_t)tables) & 15) != 0) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_adamw8_shadow_refresh: absmax / tables must be 16-byte aligned");
   hipLaunchKernelGGL(shadow_adamw8_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, block_desc_dev, block_first_dev, p, g, m8, v8, absmax, tables, hyper);
+  SDLT_CHECK_LAUNCH();
+  return SDLT_OK;
+}
+extern "C" int sdlt_adamw8_flat(float* p, const float* g, uint8_t* m8, uint8_t* v8, float* absmax, int64_t n, const float* tables, const float* hyper, void* stream) {
+  if (n <= 0 || (n & 3) || !p || !g || !m8 || !v8 || !absmax || !tables || !hyper) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_adamw8_flat: n=%lld (n %% 4 == 0) or a null buffer", (long long)n);
+  if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)tables) & 15) || (((uintptr_t)m8 | (uintptr_t)v8) & 3) || ((uintptr_t)absmax & 7))
+    SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_adamw8_flat: p / g / tables 16-byte, codes 4-byte, absmax 8-byte aligned");
+  hipLaunchKernelGGL(adamw8_flat_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m8, v8, absmax, n, tables, hyper);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }

@@ -35,6 +35,7 @@ class WeightTrainer:
         self._shadow = []          # ShadowPlan descriptors (offset, rows, cols, src_ld, dst, dstT)
         self.params = self.grads = self.m = self.v = None
         self.q8 = None             # AdamW8bit: (m8, v8, absmax, tables), see enable_8bit
+        self.q8_sh = None          # AdamW8bit under ZeRO-1: ([absmax of this rank's slice of bucket b], tables), see enable_zero1
         self.registering = False   # True only while the UNet builds its layers (the text encoders share the leaf classes)
         # Deferred, batched weight gradients: the leaf layers only RECORD (weight, inputs, dY) during the first backward; flush()
         # at the end of every backward issues all layers of one shape together - one panel launch per operand and one batched
@@ -150,7 +151,7 @@ class WeightTrainer:
                    torch.zeros(4 * self._plan.n_blocks, dtype=F32, device=dev), self.rt.ops.q8_tables(dev))
 
     # ------------------------------------------------------------------ sharded optimizer state (data parallel, ZeRO-1)
-    def enable_zero1(self, rank, world):
+    def enable_zero1(self, rank, world, adam8=False):
         """Data-parallel full fine-tune with the optimizer sharded over the ranks (the reference has no data parallelism to cite:
         full_finetuning_example.json names the workload).  Rank r owns the r-th of `world` equal slices of EVERY gradient bucket: the exchange
         step becomes reduce-scatter (each rank receives the summed gradients of its slices only) -> AdamW over the owned slices (p, g, m, v of
@@ -166,7 +167,13 @@ class WeightTrainer:
         for c in self.z_chunk:
             self.z_soff.append(self.z_soff[-1] + c)
         ns, nm, dev = self.z_soff[-1], self.n_mat, self.rt.device
-        self.m_sh, self.v_sh = torch.zeros(ns, dtype=F32, device=dev), torch.zeros(ns, dtype=F32, device=dev)
+        if adam8:
+            # AdamW8bit with the optimizer sharded: the owned slices' moments as byte codes + one fp32 absmax pair per 2048 consecutive elements of a slice
+            # (sdlt_adamw8_flat: bitsandbytes' own flat partition, counted from the slice's start); the vector region keeps fp32 moments as in enable_8bit
+            self.m_sh, self.v_sh = torch.zeros(ns, dtype=torch.uint8, device=dev), torch.zeros(ns, dtype=torch.uint8, device=dev)
+            self.q8_sh = ([torch.zeros(2 * ((c + 2047) // 2048), dtype=F32, device=dev) for c in self.z_chunk], self.rt.ops.q8_tables(dev))
+        else:
+            self.m_sh, self.v_sh = torch.zeros(ns, dtype=F32, device=dev), torch.zeros(ns, dtype=F32, device=dev)
         self.m_vec, self.v_vec = self.m[nm:].clone(), self.v[nm:].clone()
         self.m = self.v = None           # the full-size moments are released
 
@@ -178,6 +185,8 @@ class WeightTrainer:
     def opt_state(self):
         if self.q8 is not None:
             return [self.q8[0], self.q8[1], self.q8[2], self.m_vec, self.v_vec]
+        if self.m is None and self.q8_sh is not None:
+            return [self.m_sh, self.v_sh, self.m_vec, self.v_vec] + list(self.q8_sh[0])
         return [self.m, self.v] if self.m is not None else [self.m_sh, self.v_sh, self.m_vec, self.v_vec]
 
     def adamw_shard_step(self, hyper):
@@ -187,7 +196,10 @@ class WeightTrainer:
         for b in range(len(self.buckets)):
             s0, s1 = self.shard_range(b)
             so = self.z_soff[b]
-            ops.adamw_fused(self.params[s0:s1], self.grads[s0:s1], self.m_sh[so:so + s1 - s0], self.v_sh[so:so + s1 - s0], hyper, None)
+            if self.q8_sh is not None:
+                ops.adamw8_flat(self.params[s0:s1], self.grads[s0:s1], self.m_sh[so:so + s1 - s0], self.v_sh[so:so + s1 - s0], self.q8_sh[0][b], self.q8_sh[1], hyper)
+            else:
+                ops.adamw_fused(self.params[s0:s1], self.grads[s0:s1], self.m_sh[so:so + s1 - s0], self.v_sh[so:so + s1 - s0], hyper, None)
         if self.nv:
             ops.adamw_fused(self.params[nm:], self.grads[nm:], self.m_vec, self.v_vec, hyper, None)
 

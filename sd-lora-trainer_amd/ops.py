@@ -1309,6 +1309,18 @@ def _shadow_adamw8(self, p, g, m8, v8, absmax, tables, hyper):
 ShadowPlan.adamw8 = _shadow_adamw8
 
 
+def adamw8_flat(p, g, m8, v8, absmax, tables, hyper):
+    """AdamW8bit on a flat fp32 range (sdlt_adamw8_flat): blocks of 2048 consecutive elements, absmax fp32 [ceil(n / 2048), 2]."""
+    lib = _lib.load()
+    for t in (p, g, absmax, tables, hyper):
+        _chk2(t, F32)
+        assert t.is_contiguous()
+    n = p.numel()
+    assert g.numel() == n and m8.dtype == torch.uint8 and v8.dtype == torch.uint8 and m8.numel() == n and v8.numel() == n and m8.is_contiguous() and v8.is_contiguous()
+    assert absmax.numel() == 2 * ((n + 2047) // 2048) and tables.numel() == 1024
+    _lib.check(lib.sdlt_adamw8_flat(_p(p), _p(g), _p(m8), _p(v8), _p(absmax), n, _p(tables), _p(hyper), _stream()), "sdlt_adamw8_flat")
+
+
 def add2d(a, b, out):
     lib = _lib.load()
     _chk2(a), _chk2(b), _chk2(out)

@@ -201,7 +201,8 @@ class TrainStep:
         if adam8:
             # bitsandbytes' AdamW8bit (optimizer.py:19-21, the full fine-tune example) is AdamW with block-quantised moments.  Full fine-tune on one GPU (or
             # data parallel with the all-reduce exchange): the matrices' moments are held that way (fullft.WeightTrainer.enable_8bit - 12 fewer bytes per
-            # parameter and step).  LoRA / TI groups (a few MB) and the sharded optimizer (ZeRO-1: 1 / world of the moments per rank) keep fp32 moments.
+            # parameter and step); with the sharded optimizer (ZeRO-1) the owned slices' moments, in blocks of 2048 consecutive elements (enable_zero1(adam8=True)).
+            # LoRA / TI groups (a few MB) keep fp32 moments.
             optimizer = "adamw"
         if optimizer not in ("adamw", "prodigy"):
             raise NotImplementedError(f"Invalid optimizer_name for unet: {optimizer}")
@@ -244,9 +245,9 @@ class TrainStep:
             z = ddp_zero1 if ddp_zero1 is not None else (_os.environ.get("SDLT_DDP_ZERO1", "1") != "0")
             self.zero1 = bool(z) and self.bucketed and optimizer == "adamw"
             if self.zero1:
-                unet.trainer.enable_zero1(dist.get_rank(self.pg), self.world)
-        self.adam8 = adam8 and self.full_ft and not getattr(self, "zero1", False) and os.environ.get("SDLT_ADAM8", "1") != "0"
-        if self.adam8:
+                unet.trainer.enable_zero1(dist.get_rank(self.pg), self.world, adam8=adam8 and os.environ.get("SDLT_ADAM8", "1") != "0")
+        self.adam8 = adam8 and self.full_ft and os.environ.get("SDLT_ADAM8", "1") != "0"
+        if self.adam8 and not getattr(self, "zero1", False):
             unet.trainer.enable_8bit()
             # Prodigy under data parallelism: its step-size estimate d is built from sums of g . (p0 - p) and |s| and is not invariant to the
             # gradient's scale, so the SUMMED gradients are turned into the mean (one in-place multiply) before its two passes - the state every

@@ -715,6 +715,26 @@ def _shadow_adamw8(self, p, g, m8, v8, absmax, tables, hyper):
 
 
 ShadowPlan.adamw8 = _shadow_adamw8
+
+
+def adamw8_flat(p, g, m8, v8, absmax, tables, hyper):
+    """sdlt_adamw8_flat through the oracle: the range as a [n / 64, 64] matrix - a block of 32 rows x 64 columns IS 2048 consecutive elements."""
+    from oracle import adam8bit_ref as A8
+    lr, b1, b2, eps, wd, bc1, bc2, _, gs = [float(x) for x in hyper[:9]]
+    step = max(1, round(math.log(max(1.0 - bc1, 1e-300)) / math.log(b1)))
+    n = p.numel()
+    rows = (n + 63) // 64
+    pad = lambda t, dt, fill=0: torch.cat([t.reshape(-1).to(dt), torch.full((rows * 64 - n,), fill, dtype=dt)]).view(rows, 64)  # noqa: E731
+    st = A8.Adam8State(rows, 64)
+    st.m8, st.v8 = pad(m8, torch.uint8, 127), pad(v8, torch.uint8)          # (the padding decodes to 0: code 127 of the signed book, code 0 of the unsigned one)
+    nb = (n + 2047) // 2048
+    st.am, st.av = absmax.view(nb, 2)[:, 0:1].clone(), absmax.view(nb, 2)[:, 1:2].clone()
+    gp = pad(g, torch.float32)
+    pn = A8.adamw8_step(pad(p, torch.float32), gp, st, lr=lr, beta1=b1, beta2=b2, eps=eps, weight_decay=wd, step=step, grad_scale=gs)
+    p.copy_(pn.reshape(-1)[:n])
+    m8.copy_(st.m8.reshape(-1)[:n]), v8.copy_(st.v8.reshape(-1)[:n])
+    absmax.view(nb, 2)[:, 0:1].copy_(st.am)
+    absmax.view(nb, 2)[:, 1:2].copy_(st.av)
 ShadowPlan.n_blocks = property(lambda self: sum(((r + 63) // 64) * ((c + 63) // 64) for (_, r, c, _, _, _) in self.entries))
 
 

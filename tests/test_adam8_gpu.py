@@ -107,3 +107,42 @@ def test_adamw8_follows_fp32_adamw():
     assert rel(got, p32) <= 0.05 and rel(pref, p32) <= 0.05, (rel(got, p32), rel(pref, p32))
     mo, vo = A8.moments(st)
     assert float((mo - m32).norm() / m32.norm()) <= 0.05 and float((vo - v32).norm() / v32.norm()) <= 0.05
+
+
+@pytest.mark.parametrize("n", [2048 * 3, 2048 * 5 + 4 * 100, 4 * 7, 2048 * 64 + 1024])
+def test_adamw8_flat_matches_oracle(n):
+    """sdlt_adamw8_flat (the sharded optimizer's slices): blocks of 2048 consecutive elements, the last one short - against the oracle on the range viewed as a
+    [n / 64, 64] matrix (a 32 x 64 block of it IS 2048 consecutive elements), every step from the oracle's state."""
+    from sd_lora_trainer_amd import ops
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(n)
+    lr, b1, b2, eps, wd = 1e-3, 0.9, 0.999, 1e-8, 0.01
+    rows = (n + 63) // 64
+    pad = rows * 64 - n
+    p0 = torch.randn(n, generator=gen) * 0.05
+    p, g = torch.zeros(n + 64, device=dev), torch.zeros(n + 64, device=dev)          # (16 floats of guard behind the range)
+    m8, v8 = torch.zeros(n + 64, dtype=torch.uint8, device=dev), torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+    nb = (n + 2047) // 2048
+    absmax, tables = torch.zeros(2 * nb, device=dev), ops.q8_tables(dev)
+    st = A8.Adam8State(rows, 64)
+    st.m8[-1, 64 - pad:] = 127          # the padding of the last row decodes to 0
+    pref = torch.cat([p0, torch.zeros(pad)]).view(rows, 64)
+    worst = 0.0
+    for step in range(1, 6):
+        gi = torch.cat([_grad(gen, (n,), 1e-3 * (1 + step % 3), "outliers" if step % 2 else "sparse".replace("sparse", "plain")), torch.zeros(pad)]).view(rows, 64)
+        g[:n] = gi.reshape(-1)[:n].to(dev)
+        p[:n] = pref.reshape(-1)[:n].to(dev)
+        m8[:n] = st.m8.reshape(-1)[:n].to(dev)
+        v8[:n] = st.v8.reshape(-1)[:n].to(dev)
+        absmax.copy_(torch.stack([st.am[:, 0], st.av[:, 0]], 1).reshape(-1).to(dev))
+        ops.adamw8_flat(p[:n], g[:n], m8[:n], v8[:n], absmax, tables, _hyper(dev, lr, b1, b2, eps, wd, step))
+        pref = A8.adamw8_step(pref, gi, st, lr=lr, beta1=b1, beta2=b2, eps=eps, weight_decay=wd, step=step)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(p[:n].cpu(), pref.reshape(-1)[:n], rtol=2e-6, atol=1e-7)
+        torch.testing.assert_close(absmax.cpu().view(nb, 2), torch.stack([st.am[:, 0], st.av[:, 0]], 1), rtol=2e-6, atol=0)
+        for got, ref in ((m8, st.m8), (v8, st.v8)):
+            d = (got[:n].cpu().int() - ref.reshape(-1)[:n].int()).abs()
+            assert int(d.max()) <= 1
+            worst = max(worst, float((d > 0).float().mean()))
+        assert float(p[n:].abs().max()) == 0.0 and int(m8[n:].max()) == 0 and int(v8[n:].max()) == 0          # nothing behind the range moved
+    assert worst <= 2e-3, worst
