@@ -396,7 +396,8 @@ int sdlt_adamw_shadow_refresh(const sdlt_shadow_desc* descs_dev, const int32_t* 
 
 /* bitsandbytes 0.43.1 `AdamW8bit` (trainer/optimizer.py:19-21; unet_optimizer_type of train_configs/full_finetuning_example.json), restated from its published
  * blockwise 8-bit Adam [3P-unverified: bitsandbytes is absent from /root/reference and from this image]: the same tiles as sdlt_adamw_shadow_refresh with
- * the moments held as one byte per element (m8, v8: indices into the signed / unsigned "dynamic" code books, addressed like the fp32 arena) times one fp32
+ * the moments held as one byte per element (m8, v8: indices into the signed / unsigned "dynamic" code books; TILE-MAJOR, uint8 [n_blocks][64][64]: element (r, c) of tile b
+ * of the descriptor table at 4096 b + 64 r + c, positions outside the tensor unused - whole 128-byte lines per wave whatever the tensor's row stride) times one fp32
  * absmax per block of 2048 elements.  A block is one half of a 64 x 64 tile (rows 0-31 | rows 32-63) - absmax: fp32 [n_blocks][4] = {m lo, m hi, v lo, v hi},
  * 16-byte aligned, zero before the first step (m8 / v8 zero too).  tables: fp32 [1024], 16-byte aligned = q1[256] | mid1[256] | q2[256] | mid2[256] with
  * q the sorted code book and mid[k] = (q[k] + q[k + 1]) / 2, mid[255] = +inf.  hyper as sdlt_adamw_fused.  Update order as bnb: p += step, then p *= 1 - lr wd. */

@@ -312,6 +312,7 @@ __global__ __launch_bounds__(256) void shadow_kernel(const sdlt_shadow_desc* des
 // Here a block is one half of a 64 x 64 refresh tile (32 rows x 64 columns = 2048 elements of the weight's [N, K] view) instead of 2048 consecutive elements of
 // the flattened tensor: the tile is the unit this pass already owns (fp32 master in, W and W^T bf16 out), so the whole optimizer step stays ONE pass
 // - p, g 4 B + m, v 1 B in, p 4 B + m, v 1 B + two bf16 copies out = 20 B per parameter instead of 32 B with fp32 moments.
+// m8 / v8: tile-major, uint8 [n_blocks][64][64] (tile b of the descriptor table, element (r, c) of the tile at 4096 b + 64 r + c; positions outside the tensor unused).
 // tables (fp32, device): q1[256] | mid1[256] | q2[256] | mid2[256], mid[k] = (q[k] + q[k + 1]) / 2, mid[255] = +inf.  absmax: [n_blocks][4] = {m rows 0-31, m rows 32-63,
 // v rows 0-31, v rows 32-63}.  The nearest code is found from the code book's structure (decade i holds 2^i (signed) / 2^(i+1) (unsigned) equally spaced values in
 // 10^(i-6) [0.1, 1]: q8_guess) and corrected by at most one step against the two neighbouring midpoints (q8_fix): two LDS reads instead of bnb's eight-step search.
@@ -346,9 +347,11 @@ __device__ __forceinline__ void adamw8_tile(const sdlt_shadow_desc& d, int r0, i
   const int64_t org = d.offset + (int64_t)r0 * d.src_ld + c0;
   float* pa = arena + org;
   const float* pg = g + org;
-  uint8_t* pm = m8 + org;
-  uint8_t* pq = v8 + org;
+  // codes: tile-major (4096 per tile, row r of the tile at 64 r): a wave's requests are whole 128-byte lines whatever the tensor's row stride
+  uint8_t* pm = m8 + (int64_t)blockIdx.x * 4096;
+  uint8_t* pq = v8 + (int64_t)blockIdx.x * 4096;
   const uint32_t lo = (uint32_t)wave * (uint32_t)d.src_ld + lane, rstep = 4u * (uint32_t)d.src_ld;
+  const uint32_t clo = (uint32_t)wave * 64u + lane;          // (element (4 k + wave, lane) of the tile)
   // all 64 requests of the lane first (unconditional; ragged tiles read element 0 of the tensor instead), then the arithmetic
   float pv[16], gv[16];
   uint8_t cm[16], cv[16];
@@ -356,7 +359,7 @@ __device__ __forceinline__ void adamw8_tile(const sdlt_shadow_desc& d, int r0, i
   for (int k = 0; k < 16; ++k) {
     const bool ok = FULL || (r0 + k * 4 + wave < d.rows && c < d.cols);
     const uint32_t i = ok ? lo + k * rstep : 0u;
-    pv[k] = pa[i]; gv[k] = pg[i]; cm[k] = pm[i]; cv[k] = pq[i];
+    pv[k] = pa[i]; gv[k] = pg[i]; cm[k] = pm[clo + k * 256]; cv[k] = pq[clo + k * 256];
   }
   __syncthreads();                                                  // the tables are in LDS
   float mn[16], vn[16], mx[4] = {0.f, 0.f, 0.f, 0.f};
@@ -409,7 +412,7 @@ __device__ __forceinline__ void adamw8_tile(const sdlt_shadow_desc& d, int r0, i
       int q1 = q8_fix(g1[e], x1[e], u1[e], d1[e]);
       q1 += ((q1 < 127) != (mn[k] < 0.f)) ? (mn[k] > 0.f ? 1 : -1) : 0;   // m keeps its sign (codes below 127 are the negative ones; the code of 0 counts as positive)
       const int q2 = q8_fix(g2[e], x2[e], u2[e], d2[e]);
-      if (FULL || (r0 + k * 4 + wave < d.rows && c < d.cols)) { pm[lo + k * rstep] = (uint8_t)q1; pq[lo + k * rstep] = (uint8_t)q2; }
+      if (FULL || (r0 + k * 4 + wave < d.rows && c < d.cols)) { pm[clo + k * 256] = (uint8_t)q1; pq[clo + k * 256] = (uint8_t)q2; }
     }
   }
 }
@@ -426,16 +429,17 @@ __device__ __forceinline__ void adamw8_tile_vec(const sdlt_shadow_desc& d, int r
   const int64_t org = d.offset + (int64_t)r0 * d.src_ld + c0;
   float* pa = arena + org;
   const float* pg = g + org;
-  uint8_t* pm = m8 + org;
-  uint8_t* pq = v8 + org;
+  uint8_t* pm = m8 + (int64_t)blockIdx.x * 4096;      // tile-major codes: row r of the tile at 64 r (a wave's four rows are 256 contiguous bytes)
+  uint8_t* pq = v8 + (int64_t)blockIdx.x * 4096;
   const uint32_t lo = (uint32_t)(wave * 4 + rq) * (uint32_t)d.src_ld + 4u * cq, rstep = 16u * (uint32_t)d.src_ld;
+  const uint32_t clo = (uint32_t)(wave * 4 + rq) * 64u + 4u * cq;
   float4 pv[4], gv[4];
   uint32_t cm[4], cv[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const uint32_t i = lo + k * rstep;
     pv[k] = *(const float4*)(pa + i); gv[k] = *(const float4*)(pg + i);
-    cm[k] = *(const uint32_t*)(pm + i); cv[k] = *(const uint32_t*)(pq + i);
+    cm[k] = *(const uint32_t*)(pm + clo + k * 1024); cv[k] = *(const uint32_t*)(pq + clo + k * 1024);
   }
   __syncthreads();                                                  // the tables are in LDS
   float mn[16], vn[16], mx[4] = {0.f, 0.f, 0.f, 0.f};
@@ -492,8 +496,7 @@ __device__ __forceinline__ void adamw8_tile_vec(const sdlt_shadow_desc& d, int r
       w1 |= (uint32_t)q1 << (8 * e);
       w2 |= (uint32_t)q8_fix(g2[e], x2[e], u2[e], d2[e]) << (8 * e);
     }
-    const uint32_t i = lo + k * rstep;
-    *(uint32_t*)(pm + i) = w1; *(uint32_t*)(pq + i) = w2;
+    *(uint32_t*)(pm + clo + k * 1024) = w1; *(uint32_t*)(pq + clo + k * 1024) = w2;
   }
 }
 

@@ -147,8 +147,9 @@ class WeightTrainer:
         nm, dev = self.n_mat, self.rt.device
         self.m_vec, self.v_vec = self.m[nm:].clone(), self.v[nm:].clone()
         self.m = self.v = None
-        self.q8 = (torch.zeros(nm, dtype=torch.uint8, device=dev), torch.zeros(nm, dtype=torch.uint8, device=dev),
-                   torch.zeros(4 * self._plan.n_blocks, dtype=F32, device=dev), self.rt.ops.q8_tables(dev))
+        nb = self._plan.n_blocks          # codes are tile-major: 4096 per 64 x 64 tile of the refresh plan (ragged tiles leave positions unused)
+        self.q8 = (torch.zeros(4096 * nb, dtype=torch.uint8, device=dev), torch.zeros(4096 * nb, dtype=torch.uint8, device=dev),
+                   torch.zeros(4 * nb, dtype=F32, device=dev), self.rt.ops.q8_tables(dev))
 
     # ------------------------------------------------------------------ sharded optimizer state (data parallel, ZeRO-1)
     def enable_zero1(self, rank, world, adam8=False):

@@ -1296,11 +1296,11 @@ def q8_tables(device):
 
 
 def _shadow_adamw8(self, p, g, m8, v8, absmax, tables, hyper):
-    """AdamW8bit step fused into the refresh tiles (sdlt_adamw8_shadow_refresh): one block of 2048 moments = half a tile."""
+    """AdamW8bit step fused into the refresh tiles (sdlt_adamw8_shadow_refresh): one block of 2048 moments = half a tile; m8 / v8 tile-major, uint8 [n_blocks * 4096]."""
     lib = _lib.load()
     for t in (p, g, absmax, tables, hyper):
         _chk2(t, F32)
-    assert m8.dtype == torch.uint8 and v8.dtype == torch.uint8 and m8.numel() >= p.numel() and v8.numel() >= p.numel()
+    assert m8.dtype == torch.uint8 and v8.dtype == torch.uint8 and m8.numel() >= 4096 * self.n_blocks and v8.numel() >= 4096 * self.n_blocks      # tile-major codes
     assert absmax.numel() == 4 * self.n_blocks and tables.numel() == 1024 and absmax.is_contiguous() and tables.is_contiguous()
     _lib.check(lib.sdlt_adamw8_shadow_refresh(_p(self.descs_dev), _p(self.block_desc_dev), _p(self.block_first_dev), self.n_blocks, _p(p), _p(g), _p(m8), _p(v8),
                                               _p(absmax), _p(tables), _p(hyper), _stream()), "sdlt_adamw8_shadow_refresh")

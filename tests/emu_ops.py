@@ -702,13 +702,19 @@ def _shadow_adamw8(self, p, g, m8, v8, absmax, tables, hyper):
     step = max(1, round(math.log(max(1.0 - bc1, 1e-300)) / math.log(b1)))
     nb = 0
     for (off, rows, cols, src_ld, dst, dstT) in self.entries:
-        pv, gv, mv, vv = [torch.as_strided(t, (rows, cols), (src_ld, 1), off) for t in (p, g, m8, v8)]
-        blocks = ((rows + 63) // 64) * ((cols + 63) // 64)
+        pv, gv = [torch.as_strided(t, (rows, cols), (src_ld, 1), off) for t in (p, g)]
+        tr, tc = (rows + 63) // 64, (cols + 63) // 64
+        blocks = tr * tc
+        # codes are tile-major: [blocks][64][64] -> the [rows, cols] matrix and back
+        from_tiles = lambda t: t[4096 * nb: 4096 * (nb + blocks)].view(tr, tc, 64, 64).permute(0, 2, 1, 3).reshape(tr * 64, tc * 64)[:rows, :cols].clone()  # noqa: E731
         st = A8.Adam8State(rows, cols)
-        st.m8, st.v8 = mv.clone(), vv.clone()
+        st.m8, st.v8 = from_tiles(m8), from_tiles(v8)
         st.set_tile_absmax(absmax[4 * nb: 4 * (nb + blocks)])
         pv.copy_(A8.adamw8_step(pv.clone(), gv, st, lr=lr, beta1=b1, beta2=b2, eps=eps, weight_decay=wd, step=step, grad_scale=gs))
-        mv.copy_(st.m8), vv.copy_(st.v8)
+        for dst8, src8 in ((m8, st.m8), (v8, st.v8)):
+            full = torch.zeros(tr * 64, tc * 64, dtype=torch.uint8)
+            full[:rows, :cols] = src8
+            dst8[4096 * nb: 4096 * (nb + blocks)] = full.view(tr, 64, tc, 64).permute(0, 2, 1, 3).reshape(-1)
         absmax[4 * nb: 4 * (nb + blocks)] = st.tile_absmax().reshape(-1)
         nb += blocks
     self.run(p)

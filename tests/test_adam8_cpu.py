@@ -89,7 +89,7 @@ def test_trainstep_adamw8bit_host_logic():
         runs[opt] = (tr, traj)
     tr8, t8 = runs["AdamW8bit"]
     tr32, t32 = runs["adamw"]
-    assert tr8.m is None and tr8.q8[0].dtype == torch.uint8 and tr8.q8[0].numel() == tr8.n_mat and tr8.m_vec.numel() == tr8.nv
+    assert tr8.m is None and tr8.q8[0].dtype == torch.uint8 and tr8.q8[0].numel() == 4096 * tr8._plan.n_blocks and tr8.m_vec.numel() == tr8.nv
     assert int(tr8.q8[0].max()) > 0 and float(tr8.q8[2].max()) > 0
     torch.testing.assert_close(t8[0], t32[0], rtol=1e-5, atol=1e-7)
     d32 = float((t32[2] - t32[0]).norm())
