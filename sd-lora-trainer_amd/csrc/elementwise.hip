@@ -228,9 +228,16 @@ __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, int64
     upd(pi, g[i], mi, vi);
     p[i] = pi; m[i] = mi; v[i] = vi;
   }
-  if (l1_partial) {
+  if (l1_partial) {      // one atomic per workgroup (16384 wave-level atomics onto one address took longer than the kernel's HBM traffic: 235 us for 713 MB)
+    __shared__ float l1w[4];
     l1 = wave_sum(l1);
-    if ((threadIdx.x & 63) == 0) atomicAdd(l1_partial, l1);
+    if ((threadIdx.x & 63) == 0) l1w[threadIdx.x >> 6] = l1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += l1w[w];
+      atomicAdd(l1_partial, t);
+    }
   }
 }
 
