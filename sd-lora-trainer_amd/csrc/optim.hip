@@ -56,14 +56,24 @@ __global__ void prodigy_accum_kernel(const float* p, const float* g, const float
     }
   }
   // per-thread partial sums cover n / (grid * 256) elements in fp32; everything above that is accumulated in fp64
+  // (one set of atomics per WORKGROUP: per wave they were up to 3 x 16384 serialised updates of three addresses - see adamw_kernel)
+  __shared__ double accw[4][2];
+  __shared__ float l1w[4];
   double dd = wave_sum_d((double)dot), de = wave_sum_d((double)den);
+  l1 = wave_sum(l1);
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&acc[0], dd);
-    atomicAdd(&acc[1], de);
+    accw[threadIdx.x >> 6][0] = dd;
+    accw[threadIdx.x >> 6][1] = de;
+    l1w[threadIdx.x >> 6] = l1;
   }
-  if (l1_partial) {
-    l1 = wave_sum(l1);
-    if ((threadIdx.x & 63) == 0) atomicAdd(l1_partial, l1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a += accw[w][0]; b += accw[w][1]; t += l1w[w]; }
+    atomicAdd(&acc[0], a);
+    atomicAdd(&acc[1], b);
+    if (l1_partial) atomicAdd(l1_partial, t);
   }
 }
 
