@@ -448,7 +448,9 @@ typedef struct sdlt_dora_grad_desc {
   float* gB;                         /* fp32 [N, rank], scaled in place */
   int64_t ws_off;
   int32_t M, N, rank, splits;
-  float grad_scale; int32_t pad_;
+  float grad_scale;
+  int32_t accumulate;                /* 0: gmag = the layer's gradient and gB rows *= scale; 1: gmag += it and gB is left alone - a SECOND pass through
+                                        the same adapters (the tok_cond_reg_w captions), run in its own launch after the first pass's */
 } sdlt_dora_grad_desc;
 int sdlt_dora_refresh(const sdlt_dora_desc* descs_dev, const int32_t* block_desc_dev, const int32_t* block_first_dev, int32_t n_blocks,
                       int32_t Rp, int32_t init, void* stream);

@@ -67,7 +67,7 @@ class DoraWtDesc(C.Structure):
 
 class DoraGradDesc(C.Structure):
     _fields_ = [("dY", vp), ("lddy", i64), ("Y", vp), ("ldy", i64), ("bias", vp), ("mag", vp), ("scale", vp), ("gmag", vp), ("gB", vp),
-                ("ws_off", i64), ("M", i32), ("N", i32), ("rank", i32), ("splits", i32), ("grad_scale", f32), ("pad_", i32)]
+                ("ws_off", i64), ("M", i32), ("N", i32), ("rank", i32), ("splits", i32), ("grad_scale", f32), ("accumulate", i32)]
 
 
 class LoraGradDesc(C.Structure):

@@ -191,7 +191,12 @@ __global__ __launch_bounds__(256) void dora_mag_grad_finish_kernel(const sdlt_do
   }
   const float b = d.bias ? d.bias[n] : 0.f;
   // y - bias = scale * z, scale = m / norm:  d m = sum dY * z / norm = sum dY * (y - bias) / m
-  d.gmag[n] = d.grad_scale * (sy - b * sd) / d.mag[n];
+  const float gm = d.grad_scale * (sy - b * sd) / d.mag[n];
+  if (d.accumulate) {      // second pass through the same adapters: its own launch behind the first pass's (which also scaled the summed dB rows)
+    d.gmag[n] += gm;
+    return;
+  }
+  d.gmag[n] = gm;
   const float sc = d.scale[n];
   float* gb = d.gB + (size_t)n * d.rank;
   for (int r = 0; r < d.rank; ++r) gb[r] *= sc;

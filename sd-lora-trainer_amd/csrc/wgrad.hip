@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void norm_affine_grad_kernel(CatIn2 in, const 
         const int64_t rr = r + 4 * u < r1 ? r + 4 * u : r;
         xs[u] = in.at(rr, c);
         ds[u] = bf2f(dy[rr * lddy + c]);
-        st[u] = MODE == 0 ? *(const float2*)(stats + rr * 2) : *(const float2*)(stats + (div_small((int)rr, HW) * 32 + grp) * 2);      // (M < 2^31: the launchers check)
+        st[u] = MODE == 0 ? *(const float2*)(stats + rr * 2) : *(const float2*)(stats + (div_small((int)rr, HW) * 32 + grp) * 2);      // (div_small is exact below 2^22 rows: both GroupNorm launchers check B * HW)
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -246,6 +246,7 @@ extern "C" int sdlt_groupnorm_affine_grad(const sdlt_groupnorm_params* pp, float
   const sdlt_groupnorm_params& p = *pp;
   if (p.B <= 0 || p.HW <= 0 || p.C <= 0 || (p.C % 32) || !p.stats || !p.dy || !dgamma || !dbeta)
     SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_groupnorm_affine_grad: B=%d HW=%d C=%d", p.B, p.HW, p.C);
+  if ((int64_t)p.B * p.HW >= (1 << 22)) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_groupnorm_affine_grad: B * HW = %lld rows >= 2^22 (row -> image division)", (long long)p.B * p.HW);
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate) zero_pair(dgamma, dbeta, p.C, s);
   CatIn2 in{(const bf16_t*)p.x1, p.ldx1, p.x2 ? p.C1 : p.C, (const bf16_t*)p.x2, p.ldx2};
@@ -261,6 +262,7 @@ extern "C" int sdlt_affine_grad_batch(const sdlt_affine_grad_item* items_dev, in
                                       int64_t ldx2, int64_t lddy, int32_t B, int32_t HW, int32_t C, float eps, int32_t silu, void* stream) {
   if (!items_dev || n <= 0 || n > 65535 || B <= 0 || HW <= 0 || C <= 0 || (groupnorm && (C % 32)))
     SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_affine_grad_batch: n=%d B=%d HW=%d C=%d", n, B, HW, C);
+  if (groupnorm && (int64_t)B * HW >= (1 << 22)) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_affine_grad_batch: B * HW = %lld rows >= 2^22 (row -> image division)", (long long)B * HW);
   CatIn2 in{nullptr, ldx1, C1 > 0 ? C1 : C, nullptr, ldx2};
   const int cb = (C + 63) / 64;
   const int64_t M = (int64_t)B * HW;

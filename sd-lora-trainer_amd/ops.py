@@ -149,19 +149,41 @@ def wsk_rowdot_shape(M, N, K, lora, d):
 
 WSK_PACK = os.environ.get("SDLT_WSK_PACK", "1") != "0"
 _WSK_FROZEN = {}         # data_ptr of a weight declared frozen -> weakref of the tensor
-_WSK_PACKED = {}         # data_ptr -> (fragment-major copy (sdlt_wsk_pack_weight's layout), N, K, ld, weakref of the tensor)
+_WSK_PACKED = {}         # data_ptr -> (fragment-major copy (sdlt_wsk_pack_weight's layout), N, K, ld, weakref of the tensor, W._version at pack time)
+
+
+def _wsk_forget(key, ref):
+    """weakref callback of a frozen weight: the tensor died - drop its registration and its packed copy (1-2 GB per SDXL model) with it, unless the
+    address already belongs to a newer registration."""
+    f = _WSK_FROZEN.get(key)
+    if f is ref or (f is not None and f() is None):
+        _WSK_FROZEN.pop(key, None)
+    e = _WSK_PACKED.get(key)
+    if e is not None and (e[4] is ref or e[4]() is None):
+        _WSK_PACKED.pop(key, None)
 
 
 def wsk_mark_frozen(W):
     """Declare a bf16 weight [N, K] FROZEN: nothing rewrites it for as long as the tensor lives (the UNet under LoRA / textual inversion; NOT the full
     fine-tune's refreshed operands, NOT DoRA's per-step W^T).  The first gemm(X, W, ...) that runs on the wave-split-K kernel then makes the
-    fragment-major copy of include/sdlt_kernels.h (sdlt_wsk_pack_weight) once and every such call reads the weight through it."""
+    fragment-major copy of include/sdlt_kernels.h (sdlt_wsk_pack_weight) once and every such call reads the weight through it.  The copy lives as
+    long as the tensor (a weakref callback drops it); code that DOES rewrite a marked weight in place (loading a checkpoint into the same tensors,
+    merging adapters) calls wsk_invalidate(W) - eager calls also notice the tensor's version counter and re-pack, a captured graph cannot."""
     if WSK and WSK_PACK and W is not None and W.dim() == 2 and W.dtype == BF16 and W.is_cuda and W.stride(1) == 1:
         key = W.data_ptr()
         e = _WSK_PACKED.get(key)
         if e is not None and e[4]() is not W:          # a copy made for an earlier tensor at this address
             del _WSK_PACKED[key]
-        _WSK_FROZEN[key] = weakref.ref(W)
+        _WSK_FROZEN[key] = weakref.ref(W, lambda r, key=key: _wsk_forget(key, r))
+
+
+def wsk_invalidate(W=None):
+    """Drop the packed copy of one marked weight (it is re-made on the next eager use) or, with no argument, of all of them; call it after writing a
+    marked weight in place and before re-capturing a graph that reads it (a captured launch holds the OLD copy's pointer)."""
+    if W is None:
+        _WSK_PACKED.clear()
+    else:
+        _WSK_PACKED.pop(W.data_ptr(), None)
 
 
 def _wsk_operand(W):
@@ -169,7 +191,7 @@ def _wsk_operand(W):
     key = W.data_ptr()
     e = _WSK_PACKED.get(key)
     if e is not None:
-        if e[4]() is None:          # the registered tensor is gone (its address may have been reused): drop the copy
+        if e[4]() is None or e[5] != W._version:      # the registered tensor is gone (its address may have been reused), or it was rewritten in place: drop the copy
             del _WSK_PACKED[key]
         elif e[1] == W.shape[0] and e[2] == W.shape[1] and e[3] == _ld(W):
             return _p(e[0]), 0
@@ -183,7 +205,7 @@ def _wsk_operand(W):
         N, K = W.shape
         Wp = torch.empty(N * K, device=W.device, dtype=BF16)
         _lib.check(_lib.load().sdlt_wsk_pack_weight(_p(W), _ld(W), N, K, _p(Wp), _stream()), "sdlt_wsk_pack_weight")
-        _WSK_PACKED[key] = (Wp, N, K, _ld(W), f)
+        _WSK_PACKED[key] = (Wp, N, K, _ld(W), f, W._version)
         return _p(Wp), 0
     return _p(W), _ld(W)
 
@@ -1180,7 +1202,8 @@ class DoraPlan:
     """Descriptor tables of the three batched DoRA launches (sdlt_dora_refresh / _scale_wt / _mag_grad) over every adapted layer.
     layers: dict(W [N,K] bf16, A_s [Rp,K], B_s [N,Rp], B32 fp32 [N,rank], mag fp32 [N], scale fp32 [N], Bt bf16 [Rp,N] view or None, s)
     wts   : dict(src, dst bf16 [rows, cols] (same strides), scale fp32 [period'], period, nvalid)
-    grads : dict(dY, Y bf16 [M,N], bias fp32 [N] or None, mag, scale, gmag fp32 [N], gB fp32 [N,rank])"""
+    grads : dict(dY, Y bf16 [M,N], bias fp32 [N] or None, mag, scale, gmag fp32 [N], gB fp32 [N,rank][, accumulate: gmag += and gB untouched - the
+            second pass of step.TrainStep._tok_cond_reg, whose plan holds no layers / wts and runs behind the first pass's mag_grad])"""
 
     def __init__(self, layers, wts, grads, rank, Rp, device):
         self.rank, self.Rp, self.device = rank, Rp, device
@@ -1231,6 +1254,7 @@ class DoraPlan:
                 d.bias = _p(g["bias"])
             d.mag, d.scale, d.gmag, d.gB = _p(g["mag"]), _p(g["scale"]), _p(g["gmag"]), _p(g["gB"])
             d.M, d.N, d.rank, d.splits, d.grad_scale = M, N, self.rank, max(1, min(64, (M + 2047) // 2048)), 1.0
+            d.accumulate = int(bool(g.get("accumulate")))
             d.ws_off = off
             off += d.splits * 2 * N
             c1.append(((N + 63) // 64) * d.splits)

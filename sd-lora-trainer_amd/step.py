@@ -139,7 +139,8 @@ class TextStack:
             if self._grad_plan is None:
                 self._grad_plan = self.rt.ops.LoraGradPlan(self.arena.problems, self.arena.Rp, self.rt.device)
             self._grad_plan.run()
-            self.arena.dora_mag_grad()
+            if not getattr(self, "defer_dora_mag_grad", False):      # (TrainStep._tok_cond_reg runs it behind its second pass)
+                self.arena.dora_mag_grad()
 
 
 def ddpm_alphas_cumprod(n=1000, beta_start=0.00085, beta_end=0.012):
@@ -226,8 +227,7 @@ class TrainStep:
             assert self.full_ft, "LoRA / TI jobs are independent per GPU (no collective); only the full fine-tune is data parallel"
             self.pg = None if process_group is True else process_group
             self.world = dist.get_world_size(self.pg)
-            import os as _os0
-            self.ddp = self.world > 1 or bool(ddp_force) or _os0.environ.get("SDLT_DDP_FORCE", "0") == "1"
+            self.ddp = self.world > 1 or bool(ddp_force) or os.environ.get("SDLT_DDP_FORCE", "0") == "1"
             # bucketed, overlapped gradient exchange: the weight gradients are produced bucket by bucket at the end of the
             # backward (fullft.WeightTrainer.flush(bucket=i)), each bucket's all-reduce starts as soon as its gradients exist
             self.bucketed = self.ddp and grad_accum == 1
@@ -236,23 +236,18 @@ class TrainStep:
             # instead of 10.3 GB for SDXL) for two more HBM passes per bucket (pack after its weight-gradient GEMMs, unpack after its
             # all-reduce: ~15 GB of traffic each way per step) and a bf16 sum over the ranks; the vector region (biases, norm affine)
             # and the token rows stay fp32.  Default fp32: exact, and no multi-GPU box was available to measure which side wins.
-            import os as _os
-            wire = ddp_wire_dtype or _os.environ.get("SDLT_DDP_WIRE", "fp32")
+            wire = ddp_wire_dtype or os.environ.get("SDLT_DDP_WIRE", "fp32")
             assert wire in ("fp32", "bf16"), wire
             self.wire = torch.empty(unet.trainer.n_mat, dtype=torch.bfloat16, device=rt.device) if (wire == "bf16" and self.bucketed) else None
             # the exchange step: reduce-scatter -> AdamW on this rank's 1 / world of every bucket -> all-gather of the masters -> operand refresh
             # (fullft.WeightTrainer.enable_zero1); ddp_zero1=False / SDLT_DDP_ZERO1=0: all-reduce + the full AdamW on every rank (A/B)
-            z = ddp_zero1 if ddp_zero1 is not None else (_os.environ.get("SDLT_DDP_ZERO1", "1") != "0")
+            z = ddp_zero1 if ddp_zero1 is not None else (os.environ.get("SDLT_DDP_ZERO1", "1") != "0")
             self.zero1 = bool(z) and self.bucketed and optimizer == "adamw"
             if self.zero1:
                 unet.trainer.enable_zero1(dist.get_rank(self.pg), self.world, adam8=adam8 and os.environ.get("SDLT_ADAM8", "1") != "0")
         self.adam8 = adam8 and self.full_ft and os.environ.get("SDLT_ADAM8", "1") != "0"
         if self.adam8 and not getattr(self, "zero1", False):
             unet.trainer.enable_8bit()
-            # Prodigy under data parallelism: its step-size estimate d is built from sums of g . (p0 - p) and |s| and is not invariant to the
-            # gradient's scale, so the SUMMED gradients are turned into the mean (one in-place multiply) before its two passes - the state every
-            # rank then holds is the state of one process on the whole batch; AdamW takes the mean through its hyper row instead (no extra pass).
-            # Text-encoder LoRA: the adapter gradients are exchanged like the token rows (the ranks see different captions).
         self.text, self.ta_w, self.ti_wd = text, token_attention_loss_w, ti_weight_decay
         self.ti = TiState(rt, text.encoders, n_tokens, ti_std_loss_w) if text is not None else None
         self.ta = TokenAttentionLoss(rt, n_tokens) if text is not None else None
@@ -304,8 +299,11 @@ class TrainStep:
         if self.tok_cond_reg_w > 0.0:
             from .unet import ArenaView, clone_plan
             assert reg_caption_ids is not None, "tok_cond_reg_w > 0 needs the token ids of the regularisation captions"
-            if text.arena is not None and text.arena.dora:
-                raise NotImplementedError("tok_cond_reg_w together with DoRA text-encoder adapters")
+            # DoRA text-encoder adapters: the first pass's magnitude-gradient launch also scales the dB rows by m / norm, so it has to see the SUM of both passes'
+            # dB - it is deferred behind the second pass's accumulating dA / dB launch, and the second pass adds its own magnitude gradients in one more launch
+            # (sdlt_dora_grad_desc.accumulate); optimizer.py:157-202 + loss.py:207-211
+            self._reg_dora_plan = None
+            text.defer_dora_mag_grad = text.arena is not None and text.arena.dora
             nreg = reg_caption_ids[0].shape[0]
             self.reg_rt = Runtime(dev, nreg, act_dtype=rt.act, ops=rt.ops)
             # text-encoder LoRA: the second pass differentiates through the adapters too - its dA / dB problems live in a view of the arena
@@ -482,6 +480,12 @@ class TrainStep:
                 self._reg_grad_plan = self.rt.ops.LoraGradPlan(self.reg_arena.problems, self.reg_arena.Rp, self.rt.device)
                 self._reg_grad_plan.set_accumulate(True)
             self._reg_grad_plan.run()
+            if self.text.arena.dora:
+                self.text.arena.dora_mag_grad()          # first pass: its magnitude gradients, and the column factor onto the summed dB rows
+                if self._reg_dora_plan is None:
+                    grads = [dict(g, accumulate=True) for g in self.reg_arena.dora_grads]
+                    self._reg_dora_plan = self.rt.ops.DoraPlan([], [], grads, self.text.arena.rank, self.text.arena.Rp, self.rt.device)
+                self._reg_dora_plan.mag_grad()
 
     def forward_backward(self):
         self._phase_text_fwd()
@@ -496,6 +500,10 @@ class TrainStep:
             a.adamw_step(self.hyper)           # optimizer step and operand refresh in one tiled pass over the matrices
             return
         if self.prodigy is not None:
+            # Prodigy under data parallelism: its step-size estimate d is built from sums of g . (p0 - p) and |s| and is not invariant to the
+            # gradient's scale, so the SUMMED gradients are turned into the mean (one in-place multiply) before its two passes - the state every
+            # rank then holds is the state of one process on the whole batch; AdamW takes the mean through its hyper row instead (no extra pass).
+            # (Text-encoder LoRA: the adapter gradients are exchanged like the token rows - the ranks see different captions.)
             if self.world > 1:
                 a.grads.mul_(1.0 / self.world)
             self.prodigy.step(a.grads, a.m, a.v, self.hyper, l1)
@@ -714,7 +722,9 @@ class TrainStep:
         return losses
 
     def grad_norm(self):
-        """Global L2 norm of the LoRA gradients, the reference's debug read-out (loss.py:108-125, main.py:373-379)."""
+        """Global L2 norm of the LoRA gradients, the reference's debug read-out (loss.py:108-125, main.py:373-379).
+        COLLECTIVE under the sharded data-parallel optimizer (ZeRO-1): every rank must call it (one scalar all-reduce) - a rank-0-only call, the way
+        the reference guards its logging, would hang the job; with the all-reduce exchange or on one GPU it is a local read."""
         return self._unet_grad_norm()
 
     def _unet_grad_norm(self):
@@ -741,7 +751,8 @@ class TrainStep:
         """The whole debug read-out of main.py:373-379: {'unet': ..., 'text_encoder_0': ..., 'text_encoder_1': ...} - `compute_grad_norm` over
         every parameter that has a gradient.  For a text encoder that is its token table AFTER the rows of the frozen vocabulary were zeroed
         (main.py:368-371: only the trained rows count - this engine never forms the other rows' gradients) plus, with
-        text_encoder_lora_optimizer, that encoder's adapters.  One device sync per entry; not part of the step's graph."""
+        text_encoder_lora_optimizer, that encoder's adapters.  One device sync per entry; not part of the step's graph.  Like grad_norm(): a
+        collective under ZeRO-1 - call it on every rank or on none."""
         out = {"unet": self._unet_grad_norm()}
         if self.ti is not None:
             sq = [float(r.float().pow(2).sum()) for r in self.ti.grad_rows]

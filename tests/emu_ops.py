@@ -276,7 +276,11 @@ class DoraPlan:
         for g in self.grads:
             N = g["Y"].shape[1]
             z = g["Y"].float() - (g["bias"].float() if g.get("bias") is not None else 0.0)
-            g["gmag"].copy_((g["dY"][:, :N].float() * z).sum(0) / g["mag"])
+            gm = (g["dY"][:, :N].float() * z).sum(0) / g["mag"]
+            if g.get("accumulate"):
+                g["gmag"].add_(gm)
+                continue
+            g["gmag"].copy_(gm)
             g["gB"].mul_(g["scale"][:, None])
 
 

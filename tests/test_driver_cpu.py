@@ -144,7 +144,7 @@ def test_text_encoder_lora_without_textual_inversion(tmp_path, monkeypatch):
     assert all(np.isfinite(ta["training_attributes"]["losses"]["tot_loss"]))
 
 
-@pytest.mark.parametrize("kw", [dict(aspect_ratio_bucketing=True), dict(tok_cond_reg_w=0.1, text_encoder_lora_optimizer="adamw", use_dora=True)])
+@pytest.mark.parametrize("kw", [dict(aspect_ratio_bucketing=True)])
 def test_unbuilt_fields_raise(tmp_path, monkeypatch, kw):
     monkeypatch.chdir(tmp_path)
     from sd_lora_trainer_amd import train as T
@@ -152,6 +152,20 @@ def test_unbuilt_fields_raise(tmp_path, monkeypatch, kw):
                          train_batch_size=1, max_train_steps=3, **kw)
     with pytest.raises(NotImplementedError):
         next(T.train(cfg, runtime=unet_mod.Runtime("cpu", 1, act_dtype=torch.float32, ops=emu_ops)))
+
+
+def test_tok_cond_reg_with_dora_text_encoder_adapters_trains(tmp_path, monkeypatch):
+    """The last refused combination of optional switches (round 5: NotImplementedError): `tok_cond_reg_w` + `use_dora` + `text_encoder_lora_optimizer`
+    (loss.py:207-211 over optimizer.py:157-202) - the regularisation captions' second pass through the weight-decomposed adapters."""
+    monkeypatch.chdir(tmp_path)
+    from sd_lora_trainer_amd import train as T
+    cfg = TrainingConfig(lora_training_urls="synthetic:4", concept_mode="object", pretrained_model={"path": "synthetic:tiny15"}, seed=1, resolution=128,
+                         train_batch_size=1, max_train_steps=3, tok_cond_reg_w=0.1, text_encoder_lora_optimizer="adamw", use_dora=True,
+                         checkpointing_steps=1000, validation_img_size=[128, 128], n_sample_imgs=1)
+    progress, (config, out_dir) = _run(T.train(cfg, runtime=unet_mod.Runtime("cpu", 1, act_dtype=torch.float32, ops=emu_ops)))
+    assert progress[-1] == 1.0
+    ta = json.load(open(os.path.join(out_dir, "training_args.json")))
+    assert all(np.isfinite(ta["training_attributes"]["losses"]["tot_loss"]))
 
 
 def test_real_unet_without_text_encoder_weights_is_an_error(tmp_path, monkeypatch):

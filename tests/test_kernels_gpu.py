@@ -1444,6 +1444,23 @@ def test_wsk_gemm_packed_weight_is_bit_identical(ops, M, N, K, mode):
         ops.gemm(x, w, y2, bias=b, residual=r, **(dict(lora=(A, Bu, 0.75, T2), lora_group_k=K // G if kgroup else 0) if lora else {}))
         assert w.data_ptr() in ops._WSK_PACKED and torch.equal(ops._WSK_PACKED[w.data_ptr()][0], wp)
         assert torch.equal(y2, base[0]) and (not lora or torch.equal(T2, base[1]))
+        if mode == "plain":
+            # the copy follows the tensor: an in-place rewrite is noticed by the next eager call (version counter) and re-packed, wsk_invalidate() drops it,
+            # and the registration + copy die with the tensor (a long-lived worker must not keep every model's packed weights alive)
+            w.mul_(-1.0)
+            ops.gemm(x, w, y2, bias=b, residual=r)
+            y3 = torch.empty_like(y2)
+            ops._lib.check(lib.sdlt_wsk_gemm(x.data_ptr(), K, w.data_ptr(), K, M, N, K, b.data_ptr(), r.data_ptr(), N, y3.data_ptr(), N, None, 0, None, 0, 0.0, None, 0, 0, st), "sdlt_wsk_gemm")
+            assert torch.equal(y2, y3) and not torch.equal(y2, base[0])
+            key = w.data_ptr()
+            ops.wsk_invalidate(w)
+            assert key not in ops._WSK_PACKED and key in ops._WSK_FROZEN
+            ops.gemm(x, w, y2, bias=b, residual=r)
+            assert key in ops._WSK_PACKED
+            del w
+            import gc
+            gc.collect()
+            assert key not in ops._WSK_PACKED and key not in ops._WSK_FROZEN
 
 
 @pytest.mark.parametrize("B,Nq,N,K,lora,packed", [(1, 1024, 1280, 1280, True, True), (1, 1024, 1280, 1280, True, False), (4, 256, 1280, 1280, True, True), (1, 1024, 1280, 2560, False, True),

@@ -123,7 +123,8 @@ def test_ti_step_matches_oracle(version, B):
 
 @pytest.mark.parametrize("version,B,rank,dora,w_tok", [("tiny15", 2, 4, False, 0.0), ("tinyxl", 1, 16, False, 0.0), ("tiny15", 1, 24, False, 0.0),
                                                        ("tinyxl", 1, 16, True, 0.0), ("tiny15", 2, 24, True, 0.0),
-                                                       ("tinyxl", 1, 16, False, 2e-3), ("tiny15", 2, 24, False, 2e-3)])    # + tok_cond_reg_w: a second pass through the adapters
+                                                       ("tinyxl", 1, 16, False, 2e-3), ("tiny15", 2, 24, False, 2e-3),     # + tok_cond_reg_w: a second pass through the adapters
+                                                       ("tinyxl", 1, 16, True, 2e-3), ("tiny15", 2, 24, True, 2e-3)])      # ... through weight-decomposed ones (round 6)
 def test_text_encoder_lora_matches_oracle(version, B, rank, dora, w_tok):
     """a21 (`text_encoder_lora_optimizer`, trainer/optimizer.py:157-202): peft LoRA on q/k/v/out_proj of every text-encoder
     layer, trained by its own AdamW next to TI and the UNet LoRA.  Oracle: Hugging Face CLIP called functionally with

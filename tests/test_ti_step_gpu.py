@@ -134,7 +134,8 @@ def test_ti_step_gpu_matches_oracle(version, B, concurrent):
 
 
 @pytest.mark.parametrize("version,B,rank,dora,w_tok", [("tiny15", 2, 16, False, 0.0), ("tinyxl", 2, 8, False, 0.0), ("tinyxl", 2, 16, True, 0.0), ("tiny15", 2, 24, True, 0.0),
-                                                       ("tinyxl", 2, 16, False, 2e-3)])       # + tok_cond_reg_w: second pass through the adapters, accumulating dA / dB launch
+                                                       ("tinyxl", 2, 16, False, 2e-3),        # + tok_cond_reg_w: second pass through the adapters, accumulating dA / dB launch
+                                                       ("tinyxl", 2, 16, True, 2e-3)])        # ... through weight-decomposed adapters: the magnitude gradients accumulate too (round 6)
 def test_text_encoder_lora_gpu_matches_oracle(version, B, rank, dora, w_tok):
     """a21: LoRA on q/k/v/out_proj of the text encoders (trainer/optimizer.py:157-202) on the HIP path - fused into the
     stacked q|k|v GEMM (N-grouped forward, K-grouped dX) and the out_proj GEMM - against autograd through Hugging Face
