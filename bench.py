@@ -685,7 +685,16 @@ def main():
                 ms = prof.get("family_ms", {}).get(fam)
                 if ms:
                     families[fam] = {"ms": ms, "tflop": fpt / 1e12, "frac": fpt / (ms * 1e-3) / PEAK_BF16_DENSE, "launches": prof.get("family_launches", {}).get(fam)}
-        elif default_workload:
+        # the per-launch floor model of the step (tools/step_floor.py): what the step's SHAPE allows on this chip
+        shape_floor = None
+        floors = sorted(glob.glob(os.path.join(pdir, "r[0-9][0-9]_step_floor.json")))
+        if default_workload and floors:
+            with open(floors[-1]) as fh:
+                sf = json.load(fh)
+            shape_floor = {"shape_floor_ms": sf.get("shape_floor_ms"), "measured_ms_replayed_per_signature": sf.get("measured_ms"), "calls_per_step": sf.get("calls_per_step"),
+                           "commit": sf.get("commit"), "families": sf.get("families"), "largest_gaps": [{k: g[k] for k in ("sig", "calls", "us", "floor_us", "bound", "gap_ms") if k in g} for g in (sf.get("top_gaps") or [])[:8]],
+                           "model": (sf.get("model") or {}).get("note"), "source": os.path.basename(floors[-1])}
+        if default_workload and not (ppath and os.path.exists(ppath)):
             tpath = os.path.join(pdir, "r02_sdxl1024_ti_hbm_traffic_pmc.json")
             if os.path.exists(tpath):
                 with open(tpath) as fh:
@@ -719,6 +728,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_DENSE, "traffic": traffic, "traffic_commit": traffic_commit, "traffic_sources_match": traffic_sources_match,
                          "traffic_GB_per_s": (traffic / (ev_ms * 1e-3 / args.steps) / 1e9) if traffic else None, "hbm_kernels": hbm_kernels, "families": families,
+                         "shape_floor_ms": (shape_floor or {}).get("shape_floor_ms"), "shape_floor": shape_floor,
                          "note": f"algorithmic {J} x {f_step / 1e12:.3f} TFLOP per step (2 x fwd census) / {ev_ms / args.steps:.3f} ms "
                                  "per step (HIP events on the replay stream); traffic = HBM-side bytes per step (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, "
                                  f"separate passes) of this command at commit `traffic_commit` (--profile-json, here {os.path.basename(ppath) if ppath else None}: the newest committed profiles/rNN_sdxl1024_ti_step_profile.json by default); "

@@ -587,6 +587,35 @@ int sdlt_wsk_gemm_ln(const void* X, int64_t ldx, const void* W, int64_t ldw, int
                      float lora_scale, void* T_out, int64_t ld_t, const float* ln_c1, float* ln_stats, float ln_eps,
                      const float* ln_adapter, void* stream);
 
+/* The wave-split-K product with every option as one parameter block - what sdlt_wsk_gemm / _rowdot / _ln / _parts take as arguments, plus the two that only
+ * exist here:
+ *   lora_rp   padded adapter rank: 16 (0 = 16), or 32 - the sweep's rank 24 (scripts/create_hyperparam_sweep.py:76) - with ONE adapter and a packed
+ *             weight (ldw == 0), no folded LayerNorm: Adown [lora_rp, K], Bup [N, lora_rp], T_out [M, lora_rp];
+ *   col_scale fp32 [N] or NULL: DoRA's column factor m / ||W + s B A|| (use_dora, trainer/optimizer.py:86-95) applied to product + adapter before the bias -
+ *             sdlt_gemm_params.col_scale's contract; adapter launches only, not with a folded LayerNorm;
+ *   Y0        bf16 [M, N] or NULL: the layer's own output BEFORE the residual, rounded(col_scale (X W^T + adapter) + bias), written next to Y (= that value in fp32 + R):
+ *             DoRA's magnitude gradient reads it (sdlt_dora_mag_grad), and the product + residual add stay one launch.
+ * R: residual [M, N], or (dotD != NULL) the attention output O of sdlt_wsk_gemm_rowdot, which is not added. */
+typedef struct sdlt_wsk_gemm_params {
+  const void* X; int64_t ldx;
+  const void* W; int64_t ldw;
+  const float* bias;
+  const void* R; int64_t ldr;
+  void* Y; int64_t ldy;
+  const void* Adown; int64_t ld_adown;
+  const void* Bup; int64_t ld_bup;
+  void* T_out; int64_t ld_t;
+  const float* col_scale;
+  void* Y0; int64_t ldy0;
+  const float* ln_c1; float* ln_stats; const float* ln_adapter;
+  void* ln_parts;
+  float* dotD;
+  int32_t M, N, K;
+  int32_t lora_group_k, lora_rp, dot_nq;
+  float lora_scale, ln_eps;
+} sdlt_wsk_gemm_params;
+int sdlt_wsk_gemm_p(const sdlt_wsk_gemm_params* p, void* stream);
+
 /* sdlt_wsk_gemm that also leaves, for the LayerNorm that reads its output next, ln_parts fp32 [M, N / 80, 2] = (sum y, sum (y - tile mean)^2) of every ROUNDED
  * output row over each 80-column tile (to_out.0 + residual -> norm2 / norm3, ff.net.2 + residual -> the next block's norm1): the consumer
  * (sdlt_gemm_params.ln_parts) adds N / 80 partials per row instead of reducing the row in its K walk. */

@@ -117,6 +117,13 @@ class ColsumFinishDesc(C.Structure):
     _fields_ = [("ws", vp), ("out32", vp), ("out16", vp), ("nsplit", i32), ("n", i32)]
 
 
+class WskGemmParams(C.Structure):
+    _fields_ = [("X", vp), ("ldx", i64), ("W", vp), ("ldw", i64), ("bias", vp), ("R", vp), ("ldr", i64), ("Y", vp), ("ldy", i64),
+                ("Adown", vp), ("ld_adown", i64), ("Bup", vp), ("ld_bup", i64), ("T_out", vp), ("ld_t", i64), ("col_scale", vp), ("Y0", vp), ("ldy0", i64),
+                ("ln_c1", vp), ("ln_stats", vp), ("ln_adapter", vp), ("ln_parts", vp), ("dotD", vp),
+                ("M", i32), ("N", i32), ("K", i32), ("lora_group_k", i32), ("lora_rp", i32), ("dot_nq", i32), ("lora_scale", f32), ("ln_eps", f32)]
+
+
 class StripParams(C.Structure):
     _fields_ = [("X", vp), ("ldx", i64), ("W", vp), ("ldw", i64), ("bias", vp), ("R", vp), ("ldr", i64), ("Y", vp), ("ldy", i64),
                 ("Y2", vp), ("ldy2", i64), ("Z", vp), ("ldz", i64), ("c1", vp), ("c2", vp), ("stats", vp),
@@ -197,6 +204,7 @@ SYMBOLS = {
     "sdlt_wsk_pack_weight": (i32, [vp, i64, i32, i32, vp, vp]),
     "sdlt_wsk_conv": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, vp, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, f32, vp, i64, vp, vp]),
     "sdlt_wsk_gemm_parts": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp, i64, vp, i64, vp, i64, vp, i64, f32, vp, i64, i32, vp, vp]),
+    "sdlt_wsk_gemm_p": (i32, [C.POINTER(WskGemmParams), vp]),
     "sdlt_wsk_gemm_ln": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp, i64, vp, i64, vp, i64, vp, i64, f32, vp, i64, vp, vp, f32, vp, vp]),
     "sdlt_token_attention_ws_floats": (i64, [C.POINTER(TaParams)]),
     "sdlt_token_attention_loss": (i32, [C.POINTER(TaParams), vp]),
@@ -243,7 +251,8 @@ def struct_sizes():
     ops.py packs with `struct` (8 / 3 pointers) are listed by their packed size."""
     mirrored = (GemmParams, LoraGradDesc, AttnParams, GroupNormParams, ShadowDesc, GemmBatchItem, DoraDesc, DoraWtDesc, DoraGradDesc, SplitsumDesc, StripParams,
                 TaParams, LnSlabsParams, TaGroup)
-    return [(c.__name__, C.sizeof(c)) for c in mirrored] + [("sdlt_affine_grad_item", 8 * 8), ("sdlt_wgrad_tr_item", 3 * 8), ("LnFoldDesc", C.sizeof(LnFoldDesc)), ("ColsumFinishDesc", C.sizeof(ColsumFinishDesc))]
+    return [(c.__name__, C.sizeof(c)) for c in mirrored] + [("sdlt_affine_grad_item", 8 * 8), ("sdlt_wgrad_tr_item", 3 * 8), ("LnFoldDesc", C.sizeof(LnFoldDesc)), ("ColsumFinishDesc", C.sizeof(ColsumFinishDesc)),
+                                                               ("WskGemmParams", C.sizeof(WskGemmParams))]
 
 
 def check(rc, what):

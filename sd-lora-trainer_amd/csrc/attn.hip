@@ -1155,7 +1155,7 @@ extern "C" int sdlt_attn_fwd(const sdlt_attn_params* pp, void* stream) {
   // head width 64, whole 64-row tiles, no mask: 32 rows per wave on the 32x32x16 MFMA (attn32.hip).  SDLT_ATTN_R32=0 keeps the 16-row kernels (A/B).
   // Two wave groups per workgroup split the key tiles wherever there are >= 2 of them (tools/attn32_probe.sh, 1 / 2 / 4 groups: 1024 tokens x 20 heads
   // 23.8 / 16.7 / 20.6 us, 4096 x 10 90.5 / 80.0 / 84.3, 4 x 256 x 20 8.9 / 7.5 / 11.5, 4 x 1024 x 10 26.2 / 24.5 / 29.7)
-  if (attn32_on() && sdlt_attn32_ok(p) && ((uintptr_t)p.O % 8) == 0) {
+  if (attn32_on() && sdlt_attn32_ok(p) && ((uintptr_t)p.O % 16) == 0 && (p.ldo % 8) == 0) {      // (16-byte epilogue stores)
     static const int ks_env = getenv("SDLT_ATTN32_KS_FWD") ? atoi(getenv("SDLT_ATTN32_KS_FWD")) : 0;
     return sdlt_attn32_fwd(p, ks_env > 0 ? ks_env : (p.Nk >= 128 ? 2 : 1), s);      // (zeroes D in its epilogue)
   }
@@ -1234,7 +1234,8 @@ extern "C" int sdlt_attn_bwd(const sdlt_attn_params* pp, void* stream) {
     if (blocks > 4096) blocks = 4096;
     if (!p.d_ready)      // (d_ready: sdlt_wsk_gemm_rowdot left D while it produced dO)
       hipLaunchKernelGGL(attn_prep_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)p.O, p.ldo, (const bf16_t*)p.dO, p.lddo, p.B, p.H, p.Nq, p.Nqp, p.d, p.D);
-    if (attn32_on() && sdlt_attn32_ok(p) && ((uintptr_t)p.L % 16) == 0 && ((uintptr_t)p.D % 16) == 0) {
+    if (attn32_on() && sdlt_attn32_ok(p) && ((uintptr_t)p.L % 16) == 0 && ((uintptr_t)p.D % 16) == 0 &&
+        (((uintptr_t)p.dQ | (uintptr_t)p.dK | (uintptr_t)p.dV) % 16) == 0 && ((p.lddq | p.lddk | p.lddv) % 8) == 0) {      // (16-byte epilogue stores)
       static const int ks_env = getenv("SDLT_ATTN32_KS_BWD") ? atoi(getenv("SDLT_ATTN32_KS_BWD")) : 0;
       // (1 / 2 / 4 groups: 1024 x 20 44.0 / 38.1 / 46.4 us, 4096 x 10 219.9 / 203.3 / 201.5, 4 x 1024 x 10 72.0 / 60.1 / 75.1)
       return sdlt_attn32_bwd_both(p, ks_env > 0 ? ks_env : (p.Nk >= 128 && p.Nq >= 128 ? 2 : 1), s);

@@ -125,6 +125,26 @@ __device__ __forceinline__ float half_sum(float v) {
   auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// Epilogue stores as 16-byte pieces: lane (hl, c) holds, for every 8-column group j of an output block, the four columns 8 j + 4 hl .. + 3 of row c - an 8-byte
+// store per group, 32 rows x 16 bytes per wave instruction, and the store tail of a launch is store-ISSUE-bound (MI355X_MICROARCH.md: 16 x dwordx2 per lane ~ 9.3 k
+// cycles, halved by 8 x dwordx4).  One v_permlane32_swap per dword hands the lane pair (c, c + 32) each other's halves: the lower lane ends up with the even group's
+// eight columns, the upper lane with the odd group's - half as many stores, twice as wide.  ev / od: the packed groups 2 jp / 2 jp + 1 of this lane.
+// -DSDLT_A32_STORE16=0 builds the 8-byte form (A/B).
+#ifndef SDLT_A32_STORE16
+#define SDLT_A32_STORE16 1
+#endif
+// p = the row's pointer at column 8 hl of the output block's 16-column pair jp (elements)
+__device__ __forceinline__ void store_pair(bf16_t* p, int hl, uint2 ev, uint2 od) {
+#if SDLT_A32_STORE16
+  auto x = __builtin_amdgcn_permlane32_swap(ev.x, od.x, false, false);       // -> {ev.lo | od.lo}, {ev.hi | od.hi} over (lower | upper) half-wave
+  auto y = __builtin_amdgcn_permlane32_swap(ev.y, od.y, false, false);
+  *(uint4*)p = make_uint4(x[0], y[0], x[1], y[1]);
+#else
+  *(uint2*)(p - 4 * hl) = ev;
+  *(uint2*)(p - 4 * hl + 8) = od;
+#endif
+}
+
 __device__ __forceinline__ void wait_dma_barrier() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -328,15 +348,19 @@ __global__ __launch_bounds__(128 * KS) void attn32_fwd_kernel(const sdlt_attn_pa
 #ifndef SDLT_ATTN32_TRACE
   if (hl == 0 && p.D) p.D[((int64_t)b * p.H + h) * p.Nq + q] = 0.f;      // the slots sdlt_wsk_gemm_rowdot accumulates rowsum(dO o O) into during the backward pass
 #endif
-  bf16_t* op = (bf16_t*)p.O + ((int64_t)b * p.Nqp + q) * p.ldo + hc + 4 * hl;
+  bf16_t* op = (bf16_t*)p.O + ((int64_t)b * p.Nqp + q) * p.ldo + hc + 8 * hl;
 #pragma unroll
   for (int db = 0; db < 2; ++db)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      uint2 w;
-      w.x = pack2bf(o[db][4 * j] * inv, o[db][4 * j + 1] * inv);
-      w.y = pack2bf(o[db][4 * j + 2] * inv, o[db][4 * j + 3] * inv);
-      *(uint2*)(op + 32 * db + 8 * j) = w;
+    for (int jp = 0; jp < 2; ++jp) {
+      uint2 w[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int j = 2 * jp + e;
+        w[e].x = pack2bf(o[db][4 * j] * inv, o[db][4 * j + 1] * inv);
+        w[e].y = pack2bf(o[db][4 * j + 2] * inv, o[db][4 * j + 3] * inv);
+      }
+      store_pair(op + 32 * db + 16 * jp, hl, w[0], w[1]);
     }
 }
 
@@ -474,15 +498,19 @@ __device__ __forceinline__ void attn32_dq_body(const sdlt_attn_params& p, char* 
         }
     }
   }
-  bf16_t* op = (bf16_t*)p.dQ + ((int64_t)b * p.Nqp + q) * p.lddq + hc + 4 * hl;
+  bf16_t* op = (bf16_t*)p.dQ + ((int64_t)b * p.Nqp + q) * p.lddq + hc + 8 * hl;
 #pragma unroll
   for (int db = 0; db < 2; ++db)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      uint2 w;
-      w.x = pack2bf(dq[db][4 * j] * p.scale, dq[db][4 * j + 1] * p.scale);
-      w.y = pack2bf(dq[db][4 * j + 2] * p.scale, dq[db][4 * j + 3] * p.scale);
-      *(uint2*)(op + 32 * db + 8 * j) = w;
+    for (int jp = 0; jp < 2; ++jp) {
+      uint2 w[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int j = 2 * jp + e;
+        w[e].x = pack2bf(dq[db][4 * j] * p.scale, dq[db][4 * j + 1] * p.scale);
+        w[e].y = pack2bf(dq[db][4 * j + 2] * p.scale, dq[db][4 * j + 3] * p.scale);
+      }
+      store_pair(op + 32 * db + 16 * jp, hl, w[0], w[1]);
     }
 }
 
@@ -659,19 +687,23 @@ __device__ __forceinline__ void attn32_dkdv_body(const sdlt_attn_params& p, char
     }
   }
   const int64_t row = (int64_t)b * p.Nkp + key;
-  bf16_t* kp2 = (bf16_t*)p.dK + row * p.lddk + hc + 4 * hl;
-  bf16_t* vp2 = (bf16_t*)p.dV + row * p.lddv + hc + 4 * hl;
+  bf16_t* kp2 = (bf16_t*)p.dK + row * p.lddk + hc + 8 * hl;
+  bf16_t* vp2 = (bf16_t*)p.dV + row * p.lddv + hc + 8 * hl;
 #pragma unroll
   for (int db = 0; db < 2; ++db)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      uint2 w;
-      w.x = pack2bf(dk[db][4 * j] * p.scale, dk[db][4 * j + 1] * p.scale);
-      w.y = pack2bf(dk[db][4 * j + 2] * p.scale, dk[db][4 * j + 3] * p.scale);
-      *(uint2*)(kp2 + 32 * db + 8 * j) = w;
-      w.x = pack2bf(dv[db][4 * j], dv[db][4 * j + 1]);
-      w.y = pack2bf(dv[db][4 * j + 2], dv[db][4 * j + 3]);
-      *(uint2*)(vp2 + 32 * db + 8 * j) = w;
+    for (int jp = 0; jp < 2; ++jp) {
+      uint2 wk[2], wv[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int j = 2 * jp + e;
+        wk[e].x = pack2bf(dk[db][4 * j] * p.scale, dk[db][4 * j + 1] * p.scale);
+        wk[e].y = pack2bf(dk[db][4 * j + 2] * p.scale, dk[db][4 * j + 3] * p.scale);
+        wv[e].x = pack2bf(dv[db][4 * j], dv[db][4 * j + 1]);
+        wv[e].y = pack2bf(dv[db][4 * j + 2], dv[db][4 * j + 3]);
+      }
+      store_pair(kp2 + 32 * db + 16 * jp, hl, wk[0], wk[1]);
+      store_pair(vp2 + 32 * db + 16 * jp, hl, wv[0], wv[1]);
     }
 }
 

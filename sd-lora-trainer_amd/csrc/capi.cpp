@@ -38,6 +38,7 @@ extern "C" int sdlt_struct_size(int which) {
     case 15: return (int)sizeof(sdlt_wgrad_tr_item);
     case 16: return (int)sizeof(sdlt_ln_fold_desc);
     case 17: return (int)sizeof(sdlt_colsum_finish_desc);
+    case 18: return (int)sizeof(sdlt_wsk_gemm_params);
   }
   return -1;
 }

@@ -64,6 +64,11 @@ struct wsk_params {
   // most TWO 80-column tiles and every tile adds ONE value per (row, head): onto a zeroed slot the result does not depend on the order (x + y == y + x), so the float
   // atomics stay bitwise reproducible.  Replaces the D pre-pass of the attention backward (sdlt_attn_params.d_ready).
   float* dotD; int dot_nq;
+  // DoRA (LORA kernels): per-column factor m / ||W + s B A|| applied to the product + adapter before the bias (sdlt_gemm_params.col_scale's contract), fp32 [N] or NULL
+  const float* col_scale;
+  // ... and the layer's own output before the residual (DoRA's magnitude gradient needs it: d m = sum_rows dY (y0 - bias) / m): Y0 [M, N] = rounded(col_scale (X W^T + adapter) + bias),
+  // written next to Y = Y0's fp32 value + R - one launch instead of the product + an add2d launch.  NULL: not written.
+  bf16_t* Y0; int64_t ldy0;
 };
 
 // -DSDLT_WSK_TRACE (tools/wsk_trace.py): thread 0 of workgroup 0 stamps clock64() at the phase boundaries; sdlt_wsk_trace_read copies them out
@@ -82,12 +87,15 @@ __device__ long long g_wsk_tr[16];
 //     that path, and its layout conversion to pack time, is what this variant is for.
 // CONV: implicit-GEMM 3 x 3 convolution (wsk_params::Hc ...): the activation pieces are gathered per tap (per-lane addresses, zero page for the halo), everything else is
 //     the same walk.  Replaces the tiled kernel's split-K (fp32 slabs through HBM: 23.6 MB written for a 2.6 MB output) for the 32 x 32 level of the UNet.
-template <int MBK, int JN, int R, int KG = 0, bool LN = false, bool WP = false, bool CONV = false>
+// RG (KG == 1 only): the adapter's padded rank as RG groups of 16 rows - rank pad 32 (the hyper-parameter sweep's rank 24, create_hyperparam_sweep.py:76; instantiated for
+//     RG = 2): RG x 16 LoRA-down rows ride the K walk, T is RG tiles of 16 ranks, the LoRA-up RG MFMAs of 16x16x16 per output block.  Packed weights only (the row-major ring has no room).
+template <int MBK, int JN, int R, int KG = 0, bool LN = false, bool WP = false, bool CONV = false, int RG = 1>
 __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   constexpr bool LORA = KG > 0;
   static_assert(!LN || KG <= 1, "the folded LayerNorm belongs to forward products (no K-grouped adapters)");
   static_assert(!CONV || (!LN && KG <= 1), "convolutions: plain or with one rank-16 adapter");
-  constexpr int XR = 16 * MBK, WR = 16 * JN, AOFF = XR + (WP ? 0 : WR), SROWS = AOFF + (LORA ? 16 : 0), SLOT = SROWS * ROWB,
+  static_assert(RG == 1 || (KG == 1 && WP && !CONV), "rank pads above 16: one adapter, packed weights, no convolution");
+  constexpr int XR = 16 * MBK, WR = 16 * JN, AOFF = XR + (WP ? 0 : WR), SROWS = AOFF + (LORA ? 16 * RG : 0), SLOT = SROWS * ROWB,
                 PIECES = SROWS / 8 + (WP ? 2 * JN : 0);      // vector-memory operations of one K step of one wave (what the counted waits count)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   WTR(0);
@@ -97,6 +105,7 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   asm volatile("" ::"s"(p.Adown), "s"(p.ld_adown), "s"(p.Bup), "s"(p.ld_bup), "s"(p.T_out), "s"(p.ld_t), "s"(p.lora_scale), "s"(p.group_k), "s"(p.stagger));
   asm volatile("" ::"s"(p.ln_c1), "s"(p.ln_stats), "s"(p.ln_adapter), "s"(p.ln_eps), "s"(p.ln_parts), "s"(p.Wp), "s"(p.dotD), "s"(p.dot_nq));
   if constexpr (CONV) asm volatile("" ::"s"(p.Hc), "s"(p.Wc), "s"(p.Cin), "s"(p.flip), "s"(p.zero), "s"(p.rowbias), "s"(p.ld_rowbias));
+  if constexpr (LORA) asm volatile("" ::"s"(p.col_scale), "s"(p.Y0), "s"(p.ldy0));
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int ntn = p.N / WR, ntm = p.M / XR;
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
     }
     if constexpr (LORA) {
 #pragma unroll
-      for (int q = 0; q < 2; ++q) glds16(asrc + q * a8 + k0, dst + AOFF * ROWB + q * 1024);
+      for (int q = 0; q < 2 * RG; ++q) glds16(asrc + q * a8 + k0, dst + AOFF * ROWB + q * 1024);
     }
     return k0;
   };
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   };
   const int foff0 = r * ROWB + (((0 * 4 + g) ^ (r & 7)) << 4), foff1 = r * ROWB + (((1 * 4 + g) ^ (r & 7)) << 4);
 
-  constexpr int TG = KG > 0 ? KG : 1;
+  constexpr int TG = KG > 1 ? KG : (KG == 1 ? RG : 1);      // T tiles of 16 ranks: the K groups' adapters, or the rank groups of one adapter
   f32x4 acc[JN][MBK], tacc[TG][MBK];
 #pragma unroll
   for (int mb = 0; mb < MBK; ++mb) {
@@ -251,11 +260,18 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   const float* bsrc = (p.bias ? p.bias : (const float*)p.X) + n0 + 4 * g;       // (N floats <= 64 rows of X: K >= 256 columns)
   uint2 rpre[JN];
   f32x4 bpre[JN], c1pre[LN ? JN : 1];
-  uint2 bupf[JN][KG > 0 ? KG : 1];
+  // RG = 4 (rank pad 64): the LoRA-up fragments and the column factors (60 registers) would not fit beside the K walk's 512 - they are requested behind it, in front of the
+  // reduction's first barrier, which covers most of their round trip
+  constexpr bool LATE = RG >= 4;
+  uint2 bupf[JN][TG];
+  [[maybe_unused]] f32x4 cspre[LORA ? JN : 1];
+  [[maybe_unused]] const float* cssrc = nullptr;
+  if constexpr (LORA) cssrc = (p.col_scale ? p.col_scale : (const float*)p.X) + n0 + 4 * g;
 #pragma unroll
   for (int q = 0; q < JN; ++q) {
     rpre[q] = *(const uint2*)(rsrc + 16 * q);
     bpre[q] = *(const f32x4*)(bsrc + 16 * q);
+    if constexpr (LORA && !LATE) cspre[q] = *(const f32x4*)(cssrc + 16 * q);
     if constexpr (LN) c1pre[q] = *(const f32x4*)(p.ln_c1 + n0 + 16 * q + 4 * g);
   }
   [[maybe_unused]] uint2 rbpre[JN];
@@ -265,17 +281,21 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
 #pragma unroll
     for (int q = 0; q < JN; ++q) rbpre[q] = *(const uint2*)(rb + 16 * q);
   }
-  if constexpr (LORA) {
-    const int ngrp0 = KG > 1 ? p.K / p.group_k : 1;
+  auto load_bup = [&]() {
+    const int ngrp0 = KG > 1 ? p.K / p.group_k : TG;
     const bf16_t* bu = p.Bup + (int64_t)(n0 + r) * p.ld_bup + 4 * g;
 #pragma unroll
     for (int q = 0; q < JN; ++q)
 #pragma unroll
-      for (int tg = 0; tg < KG; ++tg) bupf[q][tg] = *(const uint2*)(bu + (int64_t)(16 * q) * p.ld_bup + (tg < ngrp0 ? 16 * tg : 0));
-  }
+      for (int tg = 0; tg < TG; ++tg) bupf[q][tg] = *(const uint2*)(bu + (int64_t)(16 * q) * p.ld_bup + (tg < ngrp0 ? 16 * tg : 0));
+  };
+  if constexpr (LORA && !LATE) load_bup();
   WTR(14);
-  f32x4 lnca = (f32x4){0.f, 0.f, 0.f, 0.f}, lnab = lnca;      // adapter constants of this lane's four rank rows 4g .. 4g+3
-  if constexpr (LN && LORA) { lnca = *(const f32x4*)(p.ln_adapter + 4 * g); lnab = *(const f32x4*)(p.ln_adapter + 16 + 4 * g); }
+  [[maybe_unused]] f32x4 lnca[TG], lnab[TG];      // adapter constants of this lane's four rank rows 4g .. 4g+3 of every rank group (cA[16] | abeta[16] per group)
+  if constexpr (LN && LORA) {
+#pragma unroll
+    for (int tg = 0; tg < TG; ++tg) { lnca[tg] = *(const f32x4*)(p.ln_adapter + 32 * tg + 4 * g); lnab[tg] = *(const f32x4*)(p.ln_adapter + 32 * tg + 16 + 4 * g); }
+  }
   static_assert(WP || R == 2 || KG <= 1, "the K-grouped bookkeeping below tracks a 2-slot ring");
 
   if constexpr (WP) {
@@ -300,13 +320,16 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
           else wait_vmcnt<0>();
           if (i < 6) WTR(2 + i);
           const char* base = ring + s * SLOT;
-          bf16x8 xf[2][MBK], af[2];
+          bf16x8 xf[2][MBK], af[RG][2];
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk) {
             const int fo = kk ? foff1 : foff0;
 #pragma unroll
             for (int mb = 0; mb < MBK; ++mb) xf[kk][mb] = *(const bf16x8*)(base + mb * 16 * ROWB + fo);
-            if constexpr (LORA) af[kk] = *(const bf16x8*)(base + AOFF * ROWB + fo);
+            if constexpr (LORA) {
+#pragma unroll
+              for (int rg = 0; rg < RG; ++rg) af[rg][kk] = *(const bf16x8*)(base + (AOFF + 16 * rg) * ROWB + fo);
+            }
           }
           if (refill_first && i + R < nsteps) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -329,16 +352,23 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
             for (int j = 0; j < JN; ++j)
 #pragma unroll
               for (int mb = 0; mb < MBK; ++mb) acc[j][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[s][kk][j], xf[kk][mb], acc[j][mb], 0, 0, 0);
-          if constexpr (LORA) {
-            const int tgrp = KG > 1 ? kcur / p.group_k : 0;
+          if constexpr (KG > 1) {
+            const int tgrp = kcur / p.group_k;
 #pragma unroll
             for (int tg = 0; tg < TG; ++tg)
               if (tg == tgrp) {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                  for (int mb = 0; mb < MBK; ++mb) tacc[tg][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk], xf[kk][mb], tacc[tg][mb], 0, 0, 0);
+                  for (int mb = 0; mb < MBK; ++mb) tacc[tg][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][kk], xf[kk][mb], tacc[tg][mb], 0, 0, 0);
               }
+          } else if constexpr (LORA) {      // one adapter: every rank group rides every step
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+              for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int mb = 0; mb < MBK; ++mb) tacc[rg][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[rg][kk], xf[kk][mb], tacc[rg][mb], 0, 0, 0);
           }
           if constexpr (LN) {
 #pragma unroll
@@ -425,6 +455,11 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   // round-3 assignment (units w, w + 4, ... per wave)
   constexpr int UNITS = MBK * JN, TUN = LORA ? TG * MBK : 0, SMU = UNITS + TUN, UALL = UNITS + TUN + (LN ? 1 : 0);
   WTR(8);
+  if constexpr (LORA && LATE) {
+    load_bup();
+#pragma unroll
+    for (int q = 0; q < JN; ++q) cspre[q] = *(const f32x4*)(cssrc + 16 * q);
+  }
   __syncthreads();
   WTR(9);
   f32x4* red = (f32x4*)smem;                                  // [NW][UALL][64 lanes]
@@ -445,7 +480,7 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
       if (g == 0) ((float2*)(red + (wave * UALL + SMU) * 64))[mb * 16 + r] = make_float2(a, b);   // one unit: [MBK * 16 rows] (sum x, sum x^2)
     }
   }
-  const int ngrp = KG > 1 ? p.K / p.group_k : 1;            // groups in use (<= TG; the unused accumulators stay zero)
+  const int ngrp = KG > 1 ? p.K / p.group_k : TG;           // groups in use (<= TG; the unused accumulators stay zero)
   __syncthreads();
   WTR(12);
   const int mb = wave;                                       // this wave's row block; lane (r, g): row m, columns 16 j + 4 g .. + 3 of unit j
@@ -478,7 +513,7 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
         for (int w = 1; w < NW; ++w) t += red[(w * UALL + UNITS + tg * MBK + mb) * 64 + lane];
         if constexpr (LN) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) t[i] = rstd * (t[i] - mean * lnca[i]) + lnab[i];
+          for (int i = 0; i < 4; ++i) t[i] = rstd * (t[i] - mean * lnca[tg][i]) + lnab[tg][i];
         }
         tb[tg] = make_uint2(pack2bf(t[0] * p.lora_scale, t[1] * p.lora_scale), pack2bf(t[2] * p.lora_scale, t[3] * p.lora_scale));
         if (p.T_out && tn == 0) *(uint2*)(p.T_out + (int64_t)m * p.ld_t + 16 * tg + 4 * g) = tb[tg];
@@ -501,12 +536,18 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
         v = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, bupf[q][tg]), __builtin_bit_cast(s16x4, tb[tg]), v, 0, 0, 0);
       }
     }
+    if constexpr (LORA) {
+      if (p.col_scale) v *= cspre[q];
+    }
     if (p.bias) v += bpre[q];
     if constexpr (CONV) {
       if (p.rowbias) {
         const uint2 rv = rbpre[q];
         v[0] += bf2f(rv.x & 0xffff); v[1] += bf2f(rv.x >> 16); v[2] += bf2f(rv.y & 0xffff); v[3] += bf2f(rv.y >> 16);
       }
+    }
+    if constexpr (LORA) {
+      if (p.Y0) *(uint2*)(p.Y0 + (int64_t)m * p.ldy0 + n0 + 16 * q + 4 * g) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
     }
     if (p.R && !p.dotD) {
       const uint2 rv = rpre[q];
@@ -556,16 +597,17 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   WTR(11);
 }
 
-template <int MBK, int JN, int R, int KG, bool LN = false, bool WP = false, bool CONV = false>
+template <int MBK, int JN, int R, int KG, bool LN = false, bool WP = false, bool CONV = false, int RG = 1>
 int launch_wsk(const wsk_params& p, hipStream_t s) {
   constexpr bool LORA = KG > 0;
-  constexpr int SLOT = (16 * MBK + (WP ? 0 : 16 * JN) + (LORA ? 16 : 0)) * ROWB;
-  constexpr int RED = NW * (MBK * JN + KG * MBK + (LN ? 1 : 0)) * 1024;           // the four partial tiles (+ adapter tiles, + row sums) of the reduction
+  constexpr int TGN = KG > 1 ? KG : (KG == 1 ? RG : 0);
+  constexpr int SLOT = (16 * MBK + (WP ? 0 : 16 * JN) + (LORA ? 16 * RG : 0)) * ROWB;
+  constexpr int RED = NW * (MBK * JN + TGN * MBK + (LN ? 1 : 0)) * 1024;          // the four partial tiles (+ adapter tiles, + row sums) of the reduction
   constexpr int smem = NW * R * SLOT > RED ? NW * R * SLOT : RED;
   static_assert(smem <= 160 * 1024, "LDS budget");
-  if (sdlt_raise_smem((const void*)wsk_kernel<MBK, JN, R, KG, LN, WP, CONV>, smem)) SDLT_FAIL(SDLT_ERR_LAUNCH, "sdlt_wsk_gemm: cannot raise the dynamic LDS limit to %d bytes", smem);
+  if (sdlt_raise_smem((const void*)wsk_kernel<MBK, JN, R, KG, LN, WP, CONV, RG>, smem)) SDLT_FAIL(SDLT_ERR_LAUNCH, "sdlt_wsk_gemm: cannot raise the dynamic LDS limit to %d bytes", smem);
   const int tiles = (p.M / (16 * MBK)) * (p.N / (16 * JN));
-  hipLaunchKernelGGL((wsk_kernel<MBK, JN, R, KG, LN, WP, CONV>), dim3(tiles), dim3(64 * NW), smem, s, p);
+  hipLaunchKernelGGL((wsk_kernel<MBK, JN, R, KG, LN, WP, CONV, RG>), dim3(tiles), dim3(64 * NW), smem, s, p);
   SDLT_CHECK_LAUNCH();
   return SDLT_OK;
 }
@@ -604,7 +646,8 @@ extern "C" int sdlt_wsk_trace_read(long long* out16) { return (int)hipMemcpyFrom
 static int wsk_gemm_impl(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t M, int32_t N, int32_t K, const float* bias,
                          const void* R, int64_t ldr, void* Y, int64_t ldy, const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup,
                          float lora_scale, void* T_out, int64_t ld_t, int32_t lora_group_k, const float* ln_c1, float* ln_stats, float ln_eps,
-                         const float* ln_adapter, void* ln_parts, void* stream, float* dotD = nullptr, int32_t dot_nq = 0) {
+                         const float* ln_adapter, void* ln_parts, void* stream, float* dotD = nullptr, int32_t dot_nq = 0, int32_t lora_rp = 16,
+                         const float* col_scale = nullptr, void* Y0 = nullptr, int64_t ldy0 = 0) {
   if (M <= 0 || N <= 0 || K <= 0 || (M % 64) || (N % 80) || ((N / 80) % 8) || (K % 256))
     SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wsk_gemm: M=%d N=%d K=%d (M %% 64, N %% 640, K %% 256 == 0)", M, N, K);
   const bool packed = ldw == 0;          // W is sdlt_wsk_pack_weight's output
@@ -613,18 +656,28 @@ static int wsk_gemm_impl(const void* X, int64_t ldx, const void* W, int64_t ldw,
     SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_gemm: operand alignment");
   if (Adown && (!Bup || (ld_adown % 8) || ((uintptr_t)Adown & 15) || (ld_bup % 4) || ((uintptr_t)Bup & 7) || (T_out && ((ld_t % 4) || ((uintptr_t)T_out & 7)))))
     SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_gemm: adapter operands (Adown [16, K] 16-byte rows, Bup [N, 16] / T_out [M, 16] 8-byte rows)");
+  if (lora_rp <= 0) lora_rp = 16;
+  // (rank pad 64 - four groups - was built and dropped in round 6: with 64 T accumulators beside the 80 of the tile and the weight ring the kernel needs all 512 registers, hipcc
+  // starts moving values between VGPRs and AGPRs around the hand-issued weight loads - whose destinations it believes to be ready at once - and the launch faults; the tiled
+  // kernel keeps those products)
+  if (Adown && lora_rp != 16 && (lora_rp != 32 || lora_group_k > 0 || ldw != 0))
+    SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_wsk_gemm_p: lora_rp=%d (16; 32 with ONE adapter and a packed weight, ldw == 0)", lora_rp);
+  if (Adown && lora_rp != 16 && ln_c1) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_wsk_gemm_p: the folded LayerNorm exists for rank pad 16 only");
+  if (col_scale && (!Adown || ((uintptr_t)col_scale & 15) || ln_c1)) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_wsk_gemm_p: col_scale (DoRA) needs an adapter, 16-byte alignment and no folded LayerNorm");
+  if (Y0 && (!Adown || (ldy0 % 4) || ((uintptr_t)Y0 & 7))) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_wsk_gemm_p: Y0 (the output before the residual) exists for adapter launches; 8-byte aligned rows");
   if (ln_c1 && (((uintptr_t)ln_c1 & 15) || ((uintptr_t)ln_stats & 7) || lora_group_k > 0 || (Adown && (!ln_adapter || ((uintptr_t)ln_adapter & 15)))))
     SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_gemm_ln: c1 [N] / ln_adapter [32] 16-byte aligned, stats [M, 2] 8-byte aligned, no K-grouped adapters");
   static const int stagger_env = getenv("SDLT_WSK_STAGGER") ? atoi(getenv("SDLT_WSK_STAGGER")) : 1;   // (read once: A/B switch)
   wsk_params p{(const bf16_t*)X, ldx, (const bf16_t*)W, ldw, bias, (const bf16_t*)R, ldr, (bf16_t*)Y, ldy, M, N, K, 1,
                (const bf16_t*)Adown, ld_adown, (const bf16_t*)Bup, ld_bup, (bf16_t*)T_out, ld_t, lora_scale, lora_group_k, stagger_env,
-               ln_c1, ln_stats, ln_adapter, ln_eps, (float2*)ln_parts, packed ? (const bf16_t*)W : nullptr, 0, 0, 0, 0, nullptr, nullptr, 0, dotD, dot_nq};
+               ln_c1, ln_stats, ln_adapter, ln_eps, (float2*)ln_parts, packed ? (const bf16_t*)W : nullptr, 0, 0, 0, 0, nullptr, nullptr, 0, dotD, dot_nq, col_scale, (bf16_t*)Y0, ldy0};
   if (((uintptr_t)ln_parts) & 7) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_gemm: ln_parts must be 8-byte aligned");
   if (dotD && (!R || ln_c1 || (N % 64) || dot_nq <= 0 || (M % dot_nq) || ((uintptr_t)dotD & 3)))
     SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wsk_gemm_rowdot: O is required, N %% 64 == 0 (64-wide heads), M = B * Nq, no folded LayerNorm");
   hipStream_t s = (hipStream_t)stream;
   if (packed) {          // register ring of 3 stages (probed 2 / 3 / 4 in round 5: 3 wins on every shape; 4 runs out of registers with an adapter)
 #define WSK_WP(KG_, LN_) launch_wsk<4, 5, 3, KG_, LN_, true>(p, s)
+    if (Adown && lora_rp == 32) return launch_wsk<4, 5, 3, 1, false, true, false, 2>(p, s);
     if (ln_c1) return Adown ? WSK_WP(1, true) : WSK_WP(0, true);
     if (!Adown) return WSK_WP(0, false);
     if (lora_group_k <= 0) return WSK_WP(1, false);
@@ -670,6 +723,13 @@ extern "C" int sdlt_wsk_gemm_ln(const void* X, int64_t ldx, const void* W, int64
   if (!ln_c1) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wsk_gemm_ln: c1 is required");
   return wsk_gemm_impl(X, ldx, W, ldw, M, N, K, c2, R, ldr, Y, ldy, Adown, ld_adown, Bup, ld_bup, lora_scale, T_out, ld_t, 0,
                        ln_c1, ln_stats, ln_eps, ln_adapter, nullptr, stream);
+}
+
+extern "C" int sdlt_wsk_gemm_p(const sdlt_wsk_gemm_params* q, void* stream) {
+  if (!q) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wsk_gemm_p: params == NULL");
+  if (q->dotD && (q->ln_c1 || q->ln_parts)) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_wsk_gemm_p: the row-dot side output excludes the folded LayerNorm / row partials");
+  return wsk_gemm_impl(q->X, q->ldx, q->W, q->ldw, q->M, q->N, q->K, q->bias, q->R, q->ldr, q->Y, q->ldy, q->Adown, q->ld_adown, q->Bup, q->ld_bup, q->lora_scale,
+                       q->T_out, q->ld_t, q->lora_group_k, q->ln_c1, q->ln_stats, q->ln_eps, q->ln_adapter, q->ln_parts, stream, q->dotD, q->dot_nq, q->lora_rp, q->col_scale, q->Y0, q->ldy0);
 }
 
 extern "C" int sdlt_wsk_conv(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t B, int32_t H, int32_t Wd, int32_t Cin, int32_t N, int32_t flip,

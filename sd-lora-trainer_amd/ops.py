@@ -148,6 +148,8 @@ def wsk_rowdot_shape(M, N, K, lora, d):
 
 
 WSK_PACK = os.environ.get("SDLT_WSK_PACK", "1") != "0"
+WSK_DORA = os.environ.get("SDLT_WSK_DORA", "1") != "0"        # DoRA's column factor in the wave-split-K epilogue (A/B switch: 0 = the tiled kernel, round 5)
+WSK_RANKS = tuple(int(x) for x in os.environ.get("SDLT_WSK_RANKS", "16,32").split(","))      # padded adapter ranks the wave-split-K kernel takes (A/B switch: "16" = round 5; 64 does not exist: csrc/wsk.hip says why)
 _WSK_FROZEN = {}         # data_ptr of a weight declared frozen -> weakref of the tensor
 _WSK_PACKED = {}         # data_ptr -> (fragment-major copy (sdlt_wsk_pack_weight's layout), N, K, ld, weakref of the tensor, W._version at pack time)
 
@@ -184,6 +186,12 @@ def wsk_invalidate(W=None):
         _WSK_PACKED.clear()
     else:
         _WSK_PACKED.pop(W.data_ptr(), None)
+
+
+def _wsk_is_frozen(W):
+    """Is W a weight wsk_mark_frozen() knows (so that _wsk_operand hands out its packed copy)?"""
+    f = _WSK_FROZEN.get(W.data_ptr())
+    return f is not None and f() is not None and tuple(f().shape) == tuple(W.shape) and f().stride(0) == W.stride(0)
 
 
 def _wsk_operand(W):
@@ -225,17 +233,20 @@ def wsk_conv_shape(conv, N, lora_rank_pad=0):
     return 200 <= (M // 64) * (N // 80) <= 256
 
 
-def gemm_emits_parts(M, N, K, lora_rank_pad=0):
+def gemm_emits_parts(M, N, K, lora_rank_pad=0, W=None, dora=False):
     """Number of row partials per row (0: none) a plain / rank-16-adapter product [M, K] x [N, K]^T (+ bias, residual) runs on the wave-split-K kernel and can therefore leave row
     partials for the next LayerNorm (gemm(..., ln_parts_out=)): the to_out.0 and ff.net.2 products of the 1280-wide blocks at batch 1."""
-    ok = WSK and not THROUGHPUT_HINT and lora_rank_pad in (0, 16) and wsk_shape(M, N, K, lora_rank_pad > 0) and (N // 80) % 2 == 0 and N // 80 <= 16
+    ok = (WSK and not THROUGHPUT_HINT and (WSK_DORA or not dora) and (lora_rank_pad in (0, 16) or (lora_rank_pad in WSK_RANKS and WSK_PACK and W is not None and _wsk_is_frozen(W))) and wsk_shape(M, N, K, lora_rank_pad > 0)
+          and (N // 80) % 2 == 0 and N // 80 <= 16)
     return N // 80 if ok else 0
 
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
          residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0, batch=None,
-         geglu_out=None, geglu_bwd=None, act_out=None, dact_in=None, col_scale=None, ln=None, ln_parts_out=None, rowdot=None):
+         geglu_out=None, geglu_bwd=None, act_out=None, dact_in=None, col_scale=None, ln=None, ln_parts_out=None, rowdot=None, out0=None):
     """out[M,N] = alpha*col_scale[n]*(X.W^T [+ X2.W2^T] [+ s*(X.Adown^T).Bup^T]) + bias + rowbias[m//rows_per_batch] + residual.
+    out0 [M,N] (with residual, adapter launches): ALSO the value before the residual (DoRA: the magnitude gradient reads the layer's own output) - one launch where the
+    product runs on the wave-split-K kernel (sdlt_wsk_gemm_params.Y0), otherwise the product into out0 and an add2d launch.
     col_scale fp32 [N]: DoRA's magnitude / norm factor (adapter launches only; DoraPlan keeps it up to date).
     act_out = (kind, A [M,N]): also writes A = act(out), kind "gelu" | "quick_gelu" (the CLIP MLP's fc1).
     dact_in = (kind, P [M,N]): out = (...) * act'(P), P = the forward pre-activation (the dX of the CLIP MLP's fc2).
@@ -258,11 +269,15 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
     batch: a GemmBatch - the launch runs len(batch) problems of identical shape / leading dimensions; the tensor arguments
     describe problem 0 (shapes, strides, options), every problem's operand pointers come from the batch."""
     lib = _lib.load()
+    rp_ = lora[0].shape[0] if lora is not None else 0
+    if out0 is not None:
+        assert residual is not None and lora is not None and Ct is None and ln is None and geglu_out is None and act_out is None and tuple(out0.shape) == tuple(out.shape)
     if (WSK and conv is None and X2 is None and rowbias is None and alpha == 1.0 and Ct is None and batch is None and geglu_out is None
-            and geglu_bwd is None and act_out is None and dact_in is None and col_scale is None and not accumulate and tile == 0 and splitk == 0
+            and geglu_bwd is None and act_out is None and dact_in is None and (col_scale is None or (lora is not None and ln is None and WSK_DORA)) and not accumulate and tile == 0 and splitk == 0
             and not lora_group_n and out is not None and out.dtype == BF16 and not THROUGHPUT_HINT and (ln is None or not lora_group_k)
-            and (lora is None or (lora[0].shape[0] == 16 and ((not lora_group_k and lora[1].shape[1] == 16) or
-                                                                (lora_group_k and lora_group_k % 64 == 0 and W.shape[1] // lora_group_k in (2, 3)))))
+            and (lora is None or (rp_ == 16 and ((not lora_group_k and lora[1].shape[1] == 16) or
+                                                 (lora_group_k and lora_group_k % 64 == 0 and W.shape[1] // lora_group_k in (2, 3))))
+                 or (rp_ in WSK_RANKS and rp_ > 16 and not lora_group_k and ln is None and lora[1].shape[1] == rp_ and WSK_PACK and _wsk_is_frozen(W)))      # rank pads 32 / 64: packed weights only
             and wsk_shape(X.shape[0], W.shape[0], W.shape[1], lora is not None)):
         # 1280-wide product at batch 1 with exactly one 64 x 80 tile per CU: K split over the waves, rank-16 adapter fused (sdlt_wsk_gemm)
         _chk2(X), _chk2(W), _chk2(out)
@@ -278,11 +293,47 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
             A_, B_, scale_, T_ = lora
             _chk2(A_), _chk2(B_)
             G_ = K_ // lora_group_k if lora_group_k else 1
-            assert tuple(A_.shape) == (16, K_) and tuple(B_.shape) == (N_, 16 * G_)
+            assert tuple(A_.shape) == (rp_, K_) and tuple(B_.shape) == (N_, rp_ * G_)
             if T_ is not None:
                 _chk2(T_)
-                assert tuple(T_.shape) == (M_, 16 * G_)
+                assert tuple(T_.shape) == (M_, rp_ * G_)
         Wptr, Wld = _wsk_operand(W)
+        if rp_ > 16 or col_scale is not None or out0 is not None:
+            # the parameter-block entry point: rank pads 32 / 64 (packed weights) and DoRA's column factor exist only there
+            q = _lib.WskGemmParams()
+            q.X, q.ldx, q.W, q.ldw, q.M, q.N, q.K = _p(X), _ld(X), Wptr, Wld, M_, N_, K_
+            q.bias, q.Y, q.ldy = _p(bias), _p(out), _ld(out)
+            q.Adown, q.ld_adown, q.Bup, q.ld_bup, q.lora_scale, q.lora_rp = _p(A_), _ld(A_), _p(B_), _ld(B_), float(scale_), rp_
+            if T_ is not None:
+                q.T_out, q.ld_t = _p(T_), _ld(T_)
+            q.lora_group_k = int(lora_group_k)
+            if col_scale is not None:
+                _chk2(col_scale, F32)
+                assert col_scale.numel() == N_
+                q.col_scale = _p(col_scale)
+            if residual is not None:
+                q.R, q.ldr = _p(residual), _ld(residual)
+            if out0 is not None:
+                _chk2(out0)
+                q.Y0, q.ldy0 = _p(out0), _ld(out0)
+            if ln is not None:
+                c1, stats_, eps_, lnad = ln[:4]
+                _chk2(c1, F32)
+                assert Wld == 0 or rp_ == 16
+                assert c1.numel() == N_ and (stats_ is None or (stats_.dtype == F32 and stats_.numel() >= 2 * M_)) and lnad is not None and lnad.numel() >= 2 * rp_
+                q.ln_c1, q.ln_stats, q.ln_eps, q.ln_adapter = _p(c1), _p(stats_), float(eps_), _p(lnad)
+            elif ln_parts_out is not None:
+                assert ln_parts_out.dtype == F32 and ln_parts_out.is_contiguous() and ln_parts_out.numel() >= M_ * (N_ // 80) * 2
+                q.ln_parts = _p(ln_parts_out)
+            elif rowdot is not None and ROWDOT and residual is None and N_ % 64 == 0 and M_ % rowdot["Nq"] == 0:
+                O_, D_ = rowdot["O"], rowdot["D"]
+                _chk2(O_), _chk2(D_, F32)
+                assert tuple(O_.shape) == (M_, N_) and D_.is_contiguous() and D_.numel() >= M_ * (N_ // 64)
+                q.R, q.ldr, q.dotD, q.dot_nq = _p(O_), _ld(O_), _p(D_), int(rowdot["Nq"])
+                rowdot["done"] = True
+            assert rp_ == 16 or Wld == 0, "rank pads 32 / 64 run on the packed copy of a frozen weight"
+            _lib.check(lib.sdlt_wsk_gemm_p(C.byref(q), _stream()), "sdlt_wsk_gemm_p")
+            return out
         if ln is not None:
             c1, stats_, eps_, lnad = ln[:4]
             _chk2(c1, F32)
@@ -313,6 +364,9 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
                                      _p(T_), _ld(T_) if T_ is not None else 0, int(lora_group_k) if lora is not None else 0, _stream()), "sdlt_wsk_gemm")
         return out
     assert ln_parts_out is None, "ln_parts_out: this product does not run on the wave-split-K kernel (ops.gemm_emits_parts)"
+    if out0 is not None:          # (no wave-split-K shape: the product without the residual, then the add as its own launch)
+        gemm(X, W, out0, lora=lora, bias=bias, col_scale=col_scale, tile=tile, splitk=splitk, stages=stages, lora_group_n=lora_group_n, lora_group_k=lora_group_k)
+        return add2d(out0, residual, out)
     if (conv is not None and X2 is None and alpha == 1.0 and Ct is None and batch is None and geglu_out is None and geglu_bwd is None and act_out is None
             and dact_in is None and col_scale is None and not accumulate and tile == 0 and splitk == 0 and not lora_group_n and not lora_group_k and ln is None
             and out is not None and out.dtype == BF16 and not THROUGHPUT_HINT and (lora is None or (lora[0].shape[0] == 16 and lora[1].shape[1] == 16))

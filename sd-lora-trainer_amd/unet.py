@@ -386,15 +386,29 @@ class Linear(_Module):
             # y = scale * (x W^T + s x A^T B^T) + bias; the residual is added by a second launch because the magnitude gradient
             # needs the layer's own output (DoraPlan.mag_grad)
             assert geglu_out is None and act_out is None and not (residual is not None and Ct is not None)
-            y0 = y if residual is None else self.buf(key + "0", M, self.N)
-            self.rt.ops.gemm(x, self.W, y0, lora=lora, bias=self.bias, Ct=Ct, col_scale=self.lora["scale"])
+            if residual is None:
+                self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, Ct=Ct, col_scale=self.lora["scale"])
+                self._y0 = y
+                return y
+            # round 6: the product, the layer's own output y0 and y = y0 + residual in ONE launch where the wave-split-K kernel takes it (ops.gemm out0=; otherwise gemm + add2d inside
+            # ops.gemm), and then also the row partials of the LayerNorm that reads y next
+            y0 = self.buf(key + "0", M, self.N)
+            kwd = {}
+            if parts_for is not None:
+                parts_for._parts = None
+                if parts_for.folded and PARTS and hasattr(self.rt.ops, "gemm_emits_parts") and self.ln is None:
+                    P = self.rt.ops.gemm_emits_parts(M, self.N, self.K, self.arena.Rp, self.W, dora=True)
+                    if P:
+                        parts_for._parts = (parts_for.buf("parts", M * P * 2, dtype=F32), P)
+                        kwd["ln_parts_out"] = parts_for._parts[0]
+            self.rt.ops.gemm(x, self.W, y, lora=lora, bias=self.bias, residual=residual, col_scale=self.lora["scale"], out0=y0, **kwd)
             self._y0 = y0
-            return y if residual is None else self.rt.ops.add2d(y0, residual, y)
+            return y
         kw = {} if ln is None else {"ln": ln}
         if parts_for is not None:
             parts_for._parts = None
             if (parts_for.folded and PARTS and hasattr(self.rt.ops, "gemm_emits_parts") and self.ln is None and Ct is None and geglu_out is None and act_out is None):
-                P = self.rt.ops.gemm_emits_parts(M, self.N, self.K, self.arena.Rp if self.lora is not None else 0)
+                P = self.rt.ops.gemm_emits_parts(M, self.N, self.K, self.arena.Rp if self.lora is not None else 0, W)
                 if P:
                     parts_for._parts = (parts_for.buf("parts", M * P * 2, dtype=F32), P)
                     kw["ln_parts_out"] = parts_for._parts[0]
@@ -858,7 +872,7 @@ class Attention(_Module):
         self._dims = (B, N, Nk, Nkp)
         # self-attention whose to_out.0 input gradient runs on the wave-split-K kernel: that product leaves the backward's row term D = rowsum(dO o O) as a side output
         # (no D pre-pass launch); its slots are cleared here, by the forward kernel's epilogue
-        self._rowdot = (not self.cross and getattr(self, "_rowdot_ok", True) and self.to_out.trainer is None and not self.to_out.dora
+        self._rowdot = (not self.cross and getattr(self, "_rowdot_ok", True) and self.to_out.trainer is None
                         and getattr(rt.ops, "wsk_rowdot_shape", None) is not None and rt.ops.wsk_rowdot_shape(Mq, C, C, self.to_out.lora is not None, self.d))
         kwz = {"zero_D": self.buf("D", B * self.heads * N, dtype=F32)} if self._rowdot else {}
         rt.ops.attn_fwd(q, k, v, None, O, L, B=B, H=self.heads, Nq=N, Nk=Nk, Nqp=N, Nkp=Nkp, d=self.d, scale=self.scale, **kwz)
@@ -984,17 +998,17 @@ class TransformerBlock(_Module):
             self.ff1.bias = self.ff1.bias[perm].contiguous()
         # LayerNorm forward folded into the GEMM behind it (sdlt_gemm_params.ln_c1): norm1 -> to_q|to_k|to_v, norm2 -> attn2.to_q,
         # norm3 -> ff.net.0.proj (with the fused GEGLU epilogue only).  Not with the full fine-tune (gamma / beta / W are trained), DoRA (the
-        # column factor needs the unfolded rows) or rank pads above 16.  SDLT_LN_FOLD=0: the LayerNorm launches (bit mask per norm).
-        lin = (self.attn1.to_q, self.attn2.to_q, self.ff1)
-        if (LN_FOLD and hasattr(rt.ops, "LnFoldPlan") and all(l.trainer is None and not l.dora for l in lin) and self.norm1.trainer is None
-                and arena is not None and arena.Rp == 16 and self.attn1.C % LN_FOLD_WIDTH == 0):      # (the folded kernel variants exist for rank-16 adapter products and for ff.net.0.proj + GEGLU)
+        # column factor needs the unfolded rows); rank pads above 16 fold norm3 only (round 6: ff.net.0.proj carries no adapter - the folded ADAPTER products exist for
+        # rank pad 16).  SDLT_LN_FOLD=0: the LayerNorm launches (bit mask per norm).
+        if (LN_FOLD and hasattr(rt.ops, "LnFoldPlan") and self.norm1.trainer is None and arena is not None and self.attn1.C % LN_FOLD_WIDTH == 0):
             w = lambda n: sd[n + ".weight"].float()
             a1 = self.attn1
-            if LN_FOLD & 1:
+            ok = lambda l: l.trainer is None and not l.dora        # (the folded kernel variants exist for rank-16 adapter products and for ff.net.0.proj + GEGLU)
+            if (LN_FOLD & 1) and arena.Rp == 16 and ok(a1.to_q):
                 a1.stack.fold_ln(self.norm1, [w(m.name) for m in a1.stack.members])
-            if LN_FOLD & 2:
+            if (LN_FOLD & 2) and arena.Rp == 16 and ok(self.attn2.to_q):
                 self.attn2.to_q.fold_ln(self.norm2, w(self.attn2.to_q.name))
-            if self.fused_geglu and (LN_FOLD & 4):
+            if self.fused_geglu and (LN_FOLD & 4) and ok(self.ff1):      # (no adapter on ff.net.0.proj: any rank, DoRA too - round 6)
                 w3 = w(self.ff1.name).to(rt.device)
                 self.ff1.fold_ln(self.norm3, w3[perm], keep_plain=True)
 

@@ -48,7 +48,11 @@ def set_throughput_hint(flag):
 
 def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbias=None, rows_per_batch=0,
          residual=None, alpha=1.0, Ct=None, tile=0, splitk=0, stages=0, accumulate=False, lora_group_n=0, lora_group_k=0, batch=None,
-         geglu_out=None, geglu_bwd=None, act_out=None, dact_in=None, col_scale=None, ln=None, ln_parts_out=None, rowdot=None):
+         geglu_out=None, geglu_bwd=None, act_out=None, dact_in=None, col_scale=None, ln=None, ln_parts_out=None, rowdot=None, out0=None):
+    if out0 is not None:        # sdlt_wsk_gemm_params.Y0: the layer's own output (rounded) before the residual, and out = its unrounded value + residual
+        gemm(X, W, out0, lora=lora, bias=bias, col_scale=col_scale, lora_group_n=lora_group_n, lora_group_k=lora_group_k)
+        gemm(X, W, out, lora=lora, bias=bias, col_scale=col_scale, residual=residual, lora_group_n=lora_group_n, lora_group_k=lora_group_k, ln_parts_out=ln_parts_out)
+        return out
     if rowdot is not None:      # sdlt_wsk_gemm_rowdot: the product, then D[b, h, q] += sum over head h's columns of rounded(out) o O
         assert residual is None and conv is None and ln is None and ln_parts_out is None and not accumulate
         gemm(X, W, out, lora=lora, bias=bias, alpha=alpha, Ct=Ct, lora_group_k=lora_group_k)
@@ -212,7 +216,7 @@ def _part_width(N):
     return 80 if (N % 160 == 0 and N // 80 <= 16) else N // 2
 
 
-def gemm_emits_parts(M, N, K, lora_rank_pad=0):
+def gemm_emits_parts(M, N, K, lora_rank_pad=0, W=None, dora=False):
     """(the emulation leaves partials for every even width - two per row where the 80-column tiling does not apply - so that the CPU tests
     exercise the producer / consumer plumbing on the tiny topologies too)"""
     return N // _part_width(N) if N % 2 == 0 else 0

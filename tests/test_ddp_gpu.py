@@ -18,16 +18,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out, zero1=True):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    import torch.distributed as dist
+def _worker(rank, world, zero1=True):
     from oracle import unet_ref as U
     from sd_lora_trainer_amd import fullft, topology
     from sd_lora_trainer_amd import step as step_mod
     from sd_lora_trainer_amd import unet as unet_mod
     from tests.test_fullft_cpu import _inputs
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
     cfg, h = U.CONFIGS["tinyxl"], 16
     sd = U.init_unet_state(cfg, seed=0)
     latent, noise, mask, t, ctx, pooled, tid, _ = _inputs(cfg, 2, h)
@@ -48,27 +44,73 @@ def _worker(rank, world, port, out, zero1=True):
         ts.run(2e-4)
         losses.append(float(ts.loss))
     torch.cuda.synchronize()
-    out.put((rank, tr.params.cpu().numpy().copy(), losses))
-    dist.barrier()
+    return (rank, tr.params.cpu().numpy().copy(), losses)
+
+
+SCENARIOS = [("plain", True), ("plain", False), ("ti", True), ("ti", False)]
+
+
+def _rank_main(rank, world, port, out, threads):
+    """One process per rank for the whole module: the four scenarios run back to back on one gloo group (round 5 spawned a fresh pair of processes -
+    torch import, HIP context, 256 default OpenMP threads on a 16-CPU quota - for each: 290 s of the suite)."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import traceback
+    import torch.distributed as dist
+    torch.set_num_threads(threads)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    for kind, zero1 in SCENARIOS:
+        try:
+            res = (_worker if kind == "plain" else _worker_ti)(rank, world, zero1)
+            out.put((kind, zero1, rank, res, None))
+        except Exception:                     # reported per scenario; the other rank would hang in its next collective, so this rank stops here
+            out.put((kind, zero1, rank, None, traceback.format_exc()))
+            break
+        dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("zero1", [True, False])
-def test_bucketed_ddp_two_ranks_on_one_gpu(zero1):
-    """zero1 (default): reduce-scatter per bucket -> AdamW on the owned slices -> all-gather of the masters -> operand refresh;
-    zero1 = False: all-reduce per bucket -> the full AdamW on every rank."""
+@pytest.fixture(scope="module")
+def ddp_results():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    from tests.conftest import _usable_cores
     ctx_mp = mp.get_context("spawn")
     q = ctx_mp.Queue()
     port = _free_port()
-    procs = [ctx_mp.Process(target=_worker, args=(r, 2, port, q, zero1)) for r in range(2)]
+    procs = [ctx_mp.Process(target=_rank_main, args=(r, 2, port, q, max(1, _usable_cores() // 2))) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=600) for _ in procs), key=lambda x: x[0])
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    got = {}
+    try:
+        while len(got) < 2 * len(SCENARIOS):
+            kind, zero1, rank, res, err = q.get(timeout=600)
+            got[(kind, zero1, rank)] = (res, err)
+            if err is not None:
+                break
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    return got
+
+
+def _scenario(ddp_results, kind, zero1):
+    out = []
+    for rank in range(2):
+        assert (kind, zero1, rank) in ddp_results, f"rank {rank} never reported scenario {kind} zero1={zero1}: {[v[1] for v in ddp_results.values() if v[1]]}"
+        res, err = ddp_results[(kind, zero1, rank)]
+        assert err is None, err
+        out.append(res)
+    return out
+
+
+@pytest.mark.parametrize("zero1", [True, False])
+def test_bucketed_ddp_two_ranks_on_one_gpu(ddp_results, zero1):
+    """zero1 (default): reduce-scatter per bucket -> AdamW on the owned slices -> all-gather of the masters -> operand refresh;
+    zero1 = False: all-reduce per bucket -> the full AdamW on every rank."""
+    res = _scenario(ddp_results, "plain", zero1)
     p0, p1 = torch.from_numpy(res[0][1]), torch.from_numpy(res[1][1])
     assert torch.equal(p0, p1), "data-parallel replicas diverged"
     for _, _, losses in res:
@@ -77,20 +119,16 @@ def test_bucketed_ddp_two_ranks_on_one_gpu(zero1):
     assert mean[-1] < mean[0], mean
 
 
-def _worker_ti(rank, world, port, out, zero1=True):
+def _worker_ti(rank, world, zero1=True):
     """Full fine-tune + textual inversion under data parallelism, CAPTURED (the default workload of full_finetuning_example.json: ti_lr > 0).
     Round 4 crashed here inside torch.cuda.graph: the frozen-TI graph variants were captured also for world > 1 and recorded the full-arena
     AdamW, whose moments ZeRO-1 has released."""
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    import torch.distributed as dist
     import sd_lora_trainer_amd.clip as clip_mod
     from oracle import unet_ref as U
     from sd_lora_trainer_amd import fullft, topology
     from sd_lora_trainer_amd import step as step_mod
     from sd_lora_trainer_amd import unet as unet_mod
     from tests.test_ti_step_cpu import EOS, NTOK, _captions, _hf
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
     cfg, h = U.CONFIGS["tinyxl"], 32
     sd = U.init_unet_state(cfg, seed=0)
     hf = [_hf("quick_gelu", False, 64, 1, 11), _hf("gelu", True, 64, 1, 12, proj=cfg["proj_class_in"] - 6 * cfg["addition_time_embed_dim"])]
@@ -124,25 +162,12 @@ def _worker_ti(rank, world, port, out, zero1=True):
     ts.run(2e-4, lr_ti=0.0)                  # frozen token rows under DDP: the full graphs with lr 0 (no fast path), the exchange still runs
     gn = ts.grad_norms()
     torch.cuda.synchronize()
-    out.put((rank, tr.params.cpu().numpy().copy(), losses, ts.ti.params.cpu().numpy().copy(), bool((ts.ti.params != rows0).any()), gn))
-    dist.barrier()
-    dist.destroy_process_group()
+    return (rank, tr.params.cpu().numpy().copy(), losses, ts.ti.params.cpu().numpy().copy(), bool((ts.ti.params != rows0).any()), gn)
 
 
 @pytest.mark.parametrize("zero1", [True, False])
-def test_ddp_full_finetune_with_textual_inversion_captured(zero1):
-    if not torch.cuda.is_available():
-        pytest.skip("needs a GPU")
-    ctx_mp = mp.get_context("spawn")
-    q = ctx_mp.Queue()
-    port = _free_port()
-    procs = [ctx_mp.Process(target=_worker_ti, args=(r, 2, port, q, zero1)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted((q.get(timeout=600) for _ in procs), key=lambda x: x[0])
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+def test_ddp_full_finetune_with_textual_inversion_captured(ddp_results, zero1):
+    res = _scenario(ddp_results, "ti", zero1)
     assert torch.equal(torch.from_numpy(res[0][1]), torch.from_numpy(res[1][1])), "UNet replicas diverged"
     assert torch.equal(torch.from_numpy(res[0][3]), torch.from_numpy(res[1][3])), "token rows diverged"
     assert res[0][4] and res[1][4], "token rows did not train"

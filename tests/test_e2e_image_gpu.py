@@ -164,6 +164,16 @@ def test_train_render_decode_sdxl_real_topology():
     run_e2e("sdxl", ["clip_l", "clip_g"], "sd", 32, 16)
 
 
+@pytest.mark.skipif(os.environ.get("SDLT_E2E_1024") != "1", reason="the metric's own size (128 x 128 latent = 1024 px): ~60 fp32 oracle UNet passes at 13.7 TFLOP each take ~10 minutes "
+                    "of host time - run as a report (SDLT_E2E_1024=1 python -m pytest tests/test_e2e_image_gpu.py -k 1024px; profiles/r06_parity_report_e2e_1024.json), not in the driver's suite")
+def test_train_render_decode_sdxl_real_topology_1024px():
+    """north_star's image clause AT THE METRIC'S SIZE: the real SDXL / CLIP / AutoencoderKL topologies, 128 x 128 latent = a 1024 x 1024 image:
+    4 training steps, the full 25 trailing Euler steps at guidance 8, VAE decode, uint8 image against the oracle pipeline - same bars as the 256 px case."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    run_e2e("sdxl", ["clip_l", "clip_g"], "sd", 128, 16, n_train=4)
+
+
 def test_train_render_decode_sd15_real_topology():
     """the REAL SD1.5 UNet / CLIP-L / AutoencoderKL topologies (cfg2's model; head widths 40 / 80 / 160, one text tower, `first_eos` pooling, no
     add-embedding) at a 32 x 32 latent, batch 2 in training"""

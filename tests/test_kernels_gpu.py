@@ -1392,6 +1392,108 @@ def test_wsk_gemm_k_grouped_lora(ops, M, N, gk, G, res):
         assert torch.equal(y3, y) and torch.equal(T3, T)
 
 
+@pytest.mark.parametrize("M,N,K,rank,dora,side", [(1024, 1280, 1280, 24, False, "res"), (1024, 1280, 1280, 32, False, "parts"), (1024, 1280, 1280, 24, False, "rowdot"),
+                                                  (512, 1280, 2560, 20, False, "none"), (128, 640, 256, 32, False, "res"), (1024, 1280, 5120, 24, False, "res"),
+                                                  (1024, 1280, 1280, 16, True, "none"), (1024, 1280, 1280, 24, True, "none"), (256, 640, 1024, 8, True, "none"),
+                                                  (1024, 1280, 1280, 16, True, "y0"), (1024, 1280, 1280, 24, True, "y0parts")])
+def test_wsk_gemm_rank_groups_and_dora(ops, M, N, K, rank, dora, side):
+    """sdlt_wsk_gemm_p (round 6): adapter rank pad 32 - the sweep's rank 24, scripts/create_hyperparam_sweep.py:76 - as 2 groups of 16 LoRA-down rows on the
+    packed-weight kernel (rank pad 64 is refused: csrc/wsk.hip says why), and DoRA's column factor in the epilogue, against the emulation of the tiled kernel's contract and against sdlt_gemm_bf16 itself; the row-partial and
+    row-dot side outputs ride along unchanged; ops.gemm must select this kernel for a frozen weight (asserted through the packed-copy registry and bit equality)."""
+    Rp = 16 if rank <= 16 else (32 if rank <= 32 else 64)
+    g = torch.Generator().manual_seed(M + N + K + rank + int(dora))
+    x, w = rnd(M, K, g=g), rnd(N, K, g=g, scale=K ** -0.5)
+    A, Bu = torch.zeros(Rp, K, dtype=BF), torch.zeros(N, Rp, dtype=BF)
+    A[:rank], Bu[:, :rank] = rnd(rank, K, g=g, scale=1.0 / rank), rnd(N, rank, g=g, scale=0.05)
+    b = torch.randn(N, generator=g)
+    r = rnd(M, N, g=g) if side in ("res", "parts", "y0", "y0parts") else None
+    cs = (1.0 + 0.2 * torch.randn(N, generator=g)) if dora else None
+    want_y0 = side.startswith("y0")
+    scale = 1.5
+    ref, tref = torch.empty(M, N, dtype=BF), torch.empty(M, Rp, dtype=BF)
+    E.gemm(x, w, ref, lora=(A, Bu, scale, tref), bias=b, residual=r, **({"col_scale": cs} if dora else {}))
+    lib = ops._lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    xd, wd, Ad, Bd, bd = x.cuda(), w.cuda(), A.cuda(), Bu.cuda(), b.cuda()
+    rd, csd = (r.cuda() if r is not None else None), (cs.cuda() if dora else None)
+    wp = torch.empty(N * K, dtype=BF, device="cuda")
+    ops._lib.check(lib.sdlt_wsk_pack_weight(wd.data_ptr(), K, N, K, wp.data_ptr(), st), "sdlt_wsk_pack_weight")
+    Nq = 256 if M % 256 == 0 else M
+    o = rnd(M, N, g=g).cuda()
+
+    def run(packed=True):
+        y, T = torch.full((M, N), 7.0, dtype=BF, device="cuda"), torch.full((M, Rp), 7.0, dtype=BF, device="cuda")
+        parts, D = torch.zeros(M, N // 80, 2, device="cuda"), torch.zeros(M * (N // 64), device="cuda")
+        y0 = torch.full((M, N), 7.0, dtype=BF, device="cuda")
+        q = ops._lib.WskGemmParams()
+        q.X, q.ldx, q.W, q.ldw, q.M, q.N, q.K = xd.data_ptr(), K, (wp if packed else wd).data_ptr(), 0 if packed else K, M, N, K
+        q.bias, q.Y, q.ldy = bd.data_ptr(), y.data_ptr(), N
+        q.Adown, q.ld_adown, q.Bup, q.ld_bup, q.lora_scale, q.lora_rp, q.T_out, q.ld_t = Ad.data_ptr(), K, Bd.data_ptr(), Rp, scale, Rp, T.data_ptr(), Rp
+        if rd is not None:
+            q.R, q.ldr = rd.data_ptr(), N
+        if dora:
+            q.col_scale = csd.data_ptr()
+        if side in ("parts", "y0parts"):
+            q.ln_parts = parts.data_ptr()
+        if want_y0:
+            q.Y0, q.ldy0 = y0.data_ptr(), N
+        if side == "rowdot":
+            q.R, q.ldr, q.dotD, q.dot_nq = o.data_ptr(), N, D.data_ptr(), Nq
+        rc = lib.sdlt_wsk_gemm_p(C.byref(q), st)
+        assert rc == 0, lib.sdlt_last_error()
+        torch.cuda.synchronize()
+        run.y0 = y0
+        return y, T, parts, D
+    import ctypes as C
+    y, T, parts, D = run()
+    close(y, ref, what="wsk gemm_p")
+    if want_y0:        # the layer's own output before the residual, from the same launch
+        ref0 = torch.empty(M, N, dtype=BF)
+        E.gemm(x, w, ref0, lora=(A, Bu, scale, None), bias=b, col_scale=cs)
+        close(run.y0, ref0, what="wsk gemm_p Y0")
+    close(T, tref, what="wsk gemm_p T_out")
+    y1 = run()
+    assert all(torch.equal(a_, b_) for a_, b_ in zip((y, T, parts, D), y1)), "not reproducible"
+    if Rp == 16:          # the row-major ring gives the same bits (rank pads above 16 exist for packed weights only, and say so)
+        assert torch.equal(run(packed=False)[0], y)
+    else:
+        q = ops._lib.WskGemmParams()
+        q.X, q.ldx, q.W, q.ldw, q.M, q.N, q.K, q.Y, q.ldy = xd.data_ptr(), K, wd.data_ptr(), K, M, N, K, y1[0].data_ptr(), N
+        q.Adown, q.ld_adown, q.Bup, q.ld_bup, q.lora_scale, q.lora_rp = Ad.data_ptr(), K, Bd.data_ptr(), Rp, scale, Rp
+        assert lib.sdlt_wsk_gemm_p(C.byref(q), st) != 0 and b"packed" in lib.sdlt_last_error()
+        q.W, q.ldw, q.lora_rp, q.ld_bup = wp.data_ptr(), 0, 64, 64
+        assert lib.sdlt_wsk_gemm_p(C.byref(q), st) != 0 and b"lora_rp=64" in lib.sdlt_last_error()
+    y2, T2 = torch.empty(M, N, dtype=BF, device="cuda"), torch.empty(M, Rp, dtype=BF, device="cuda")
+    ops.gemm(xd, wd, y2, lora=(Ad, Bd, scale, T2), bias=bd, residual=rd, tile=2, **({"col_scale": csd} if dora else {}))      # the tiled kernel (an explicit tile keeps it there)
+    close(y, y2, tol=1e-2, what="wsk_p vs tiled kernel")
+    close(T, T2, tol=1e-2, what="wsk_p vs tiled T_out")
+    if side in ("parts", "y0parts"):
+        yf = y.float().view(M, N // 80, 80)
+        close(parts[:, :, 0], yf.sum(-1), tol=1e-3, what="row partial sums")
+        close(parts[:, :, 1], ((yf - yf.mean(-1, keepdim=True)) ** 2).sum(-1), tol=2e-3, what="row partial centred squares")
+    if side == "rowdot":
+        Dref = (y.float() * o.float()).view(M // Nq, Nq, N // 64, 64).sum(-1).permute(0, 2, 1).reshape(-1)
+        close(D, Dref, tol=2e-3, what="row dots")
+    if ops.wsk_shape(M, N, K, True):      # ops.gemm: a frozen weight takes this kernel (same bits), an unmarked one stays on the tiled kernel for rank pads above 16
+        ops.wsk_mark_frozen(wd)
+        y3, T3 = torch.empty(M, N, dtype=BF, device="cuda"), torch.empty(M, Rp, dtype=BF, device="cuda")
+        kw = {"col_scale": csd} if dora else {}
+        if side in ("parts", "y0parts"):
+            assert ops.gemm_emits_parts(M, N, K, Rp, wd, dora=dora) == N // 80
+            kw["ln_parts_out"] = torch.zeros(M, N // 80, 2, device="cuda")
+        if want_y0:
+            kw["out0"] = torch.empty(M, N, dtype=BF, device="cuda")
+        rdot = dict(O=o, D=torch.zeros_like(D), Nq=Nq, done=False) if side == "rowdot" else None
+        ops.gemm(xd, wd, y3, lora=(Ad, Bd, scale, T3), bias=bd, residual=rd, rowdot=rdot, **kw)
+        assert wd.data_ptr() in ops._WSK_PACKED and torch.equal(y3, y) and torch.equal(T3, T), "ops.gemm did not select the wave-split-K kernel"
+        if side == "rowdot":
+            assert rdot["done"] and torch.equal(rdot["D"], D)
+        if side in ("parts", "y0parts"):
+            assert torch.equal(kw["ln_parts_out"], parts)
+        if want_y0:
+            assert torch.equal(kw["out0"], run.y0)
+
+
 @pytest.mark.parametrize("M,N,K,mode", [(1024, 1280, 1280, "plain"), (1024, 1280, 5120, "plain"), (1024, 1280, 10240, "plain"), (64, 1280, 256, "plain"), (128, 640, 512, "plain"),
                                         (128, 640, 768, "lora"), (256, 640, 1024, "plain"), (2048, 640, 4096, "plain"), (1024, 1280, 1280, "lora"), (512, 1280, 2560, "lora"),
                                         (1024, 1280, 3840, "kgroup"), (256, 640, 768, "kgroup"), (1024, 1280, 1280, "ln"), (1024, 1280, 1280, "ln_lora"), (1024, 1280, 5120, "parts"),

@@ -74,6 +74,30 @@ def _unet_state(version):
     return _CACHE[version]
 
 
+def _trained_like(sd, seed=17):
+    """fan-in-scaled random weights give attention logits of unit spread - softmax near uniform over 1024 - 4096 keys, the q / k
+    gradients numerically nothing (rms 1 % of the median adapter's), no outlier channels.  This is the same state pushed towards what a trained SDXL / SD1.5 looks
+    like, for BOTH sides of the comparison: to_q and to_k of every attention doubled (logit spread x 4: a peaked softmax, q / k gradients that carry signal),
+    1 % of the channels of every transformer's residual stream amplified 10 - 30 x (proj_in rows: the massive-activation channels of trained transformers),
+    LayerNorm / GroupNorm gains 1 +- 0.3 with biases of 0.1.  bf16-exact like the state it starts from."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for n, t in sd.items():
+        if n.endswith((".to_q.weight", ".to_k.weight")):
+            t = t * 2.0
+        elif n.endswith(".proj_in.weight") and t.dim() == 2:
+            C = t.shape[0]
+            idx = torch.randperm(C, generator=g)[: max(1, C // 100)]
+            f = torch.ones(C)
+            f[idx] = 10.0 + 20.0 * torch.rand(idx.numel(), generator=g)
+            t = t * f[:, None]
+        elif t.dim() == 1 and (".norm" in n or n.startswith("conv_norm_out")):
+            r = torch.randn(t.shape, generator=g)
+            t = (1.0 + 0.3 * r).clamp_min(0.2) if n.endswith(".weight") else 0.1 * r
+        out[n] = t.to(torch.bfloat16).float() if t is not sd[n] else t
+    return out
+
+
 _HF = {}
 
 
@@ -181,6 +205,9 @@ TOL_BF16 = dict(pred=3e-2, loss=2e-2, ta=5e-2, reg=5e-2, cos=0.9995, rel=3e-2, r
 TOL_FAITHFUL = dict(pred=3e-2, loss=8e-3, cos=0.9995, rel=3e-2, rows_cos=0.999, rows_rel=5e-2, ada_rel=0.12, ada_normal_rel=0.10, ada_small_abs=0.02)
 TOL_FP32 = dict(pred=2e-3, loss=1e-3, ta=2e-3, reg=2e-3, cos=0.9999, rel=5e-3, rows_cos=0.9999, rows_rel=1e-2, disp_cos=0.99, rows_final=1e-3, ada_rel=2e-2)
 TOL_FP32_FAITHFUL = dict(pred=3e-2, loss=2e-2, cos=0.99, rel=8e-2, rows_cos=0.985, rows_rel=0.2, ada_rel=0.45)     # (fp32 engine vs rounded oracle: the bf16 bars)
+# the "trained-like" weight mode (_trained_like): no adapter is allowed to hide behind "its gradient is numerically nothing" - every adapter tensor's cosine is bounded
+TRAINED_LIKE_EXTRA = dict(ada_min_cos=0.99)
+TOL_TRAINED_LIKE = dict(TOL_BF16, **TRAINED_LIKE_EXTRA)
 REPORT = {}        # case -> worst adapters etc., written to gpurun_out/parity_report.json when that directory exists
 
 
@@ -223,8 +250,13 @@ def _check_first_step(tag, tol, names, lora, pred, got, rows, o, dora):
     if not (cos >= tol["cos"] and rel <= tol["rel"]):
         fails.append(f"[{tag}] LoRA grads cos {cos} rel {rel}")
     per = _per_adapter(names, lora, got, o["lora_grads"])
+    by_cos = sorted(per, key=lambda x: x[1])
     rep = dict(pred_err=err, lora_cos=cos, lora_rel=rel, worst_adapters=[dict(adj_rel=round(r, 4), cos=round(c, 5), name=n, rms_over_median=round(w, 4)) for r, c, n, w in per[:5]],
-               median_adapter_rel=per[len(per) // 2][0], n_adapter_tensors=len(per), adapter_classes=dict(_per_adapter.classes))
+               median_adapter_rel=per[len(per) // 2][0], n_adapter_tensors=len(per), adapter_classes=dict(_per_adapter.classes),
+               min_adapter_cos=by_cos[0][1], adapters_below_cos_0_99=sum(1 for x in per if x[1] < 0.99), smallest_rms_over_median=min(x[3] for x in per),
+               lowest_cos_adapters=[dict(cos=round(c, 5), name=n, rms_over_median=round(w, 4), adj_rel=round(r, 4)) for r, c, n, w in by_cos[:5]])
+    if "ada_min_cos" in tol and by_cos[0][1] < tol["ada_min_cos"]:
+        fails.append(f"[{tag}] adapters below cos {tol['ada_min_cos']}: {by_cos[:5]}")
     if per[0][0] > tol["ada_rel"]:
         fails.append(f"[{tag}] worst adapter gradients (adjusted rel, cos, name, rms / median) {per[:5]}")
     cl = _per_adapter.classes
@@ -372,14 +404,15 @@ def run_step_and_trajectory(version, B, h, sd, kinds, *, device, ops=None, act_d
     return traj
 
 
-def _case_step_and_trajectory(version, B, dora=False, h=32, n_steps=6, rank=16, case=None):
+def _case_step_and_trajectory(version, B, dora=False, h=32, n_steps=6, rank=16, case=None, trained_like=False, **kw):
     """(a) + (b): first step in detail, then 5 more optimizer steps; batches alternate between two injected ones so that the
     effect of training on a revisited batch is part of what is compared."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from oracle import unet_ref as U
     kinds = ["clip_l", "clip_g"] if U.CONFIGS[version]["addition"] else ["clip_l"]
-    run_step_and_trajectory(version, B, h, _unet_state(version), kinds, device="cuda:0", dora=dora, n_steps=n_steps, rank=rank, case=case)
+    sd = _unet_state(version)
+    run_step_and_trajectory(version, B, h, _trained_like(sd) if trained_like else sd, kinds, device="cuda:0", dora=dora, n_steps=n_steps, rank=rank, case=case, **kw)
 
 
 def _case_full_size_properties(version, B, h):
@@ -564,12 +597,14 @@ def _case_fullft_baseline_size():
 
 
 # Ordered so that each 10 GB weight state is built once: all SDXL cases, then all SD1.5 cases.
-@pytest.mark.parametrize("case", ["sdxl-step-trajectory", "sdxl-dora-step-trajectory", "sdxl-rank24-step", "sdxl-full-size", "sdxl-full-size-step-parity",
+@pytest.mark.parametrize("case", ["sdxl-step-trajectory", "sdxl-trained-like-step", "sdxl-dora-step-trajectory", "sdxl-rank24-step", "sdxl-full-size", "sdxl-full-size-step-parity",
                                   "sdxl-fullft-gradients", "sdxl-fullft-baseline-size", "sd15-step-trajectory", "sd15-dora-step-trajectory", "sd15-rank64-step", "sd15-full-size",
                                   "sd15-full-size-step-parity"])
 def test_real_topology(case):
     if case == "sdxl-step-trajectory":
         _case_step_and_trajectory("sdxl", 1, case=case)
+    elif case == "sdxl-trained-like-step":         # peaked softmax, outlier channels, non-trivial norm gains: every adapter's gradient carries signal
+        _case_step_and_trajectory("sdxl", 1, n_steps=2, case=case, trained_like=True, tol=TOL_TRAINED_LIKE, tol_faithful=dict(TOL_FAITHFUL, **TRAINED_LIKE_EXTRA))
     elif case == "sdxl-full-size-step-parity":     # cfg3 at its FULL size (1024 px: 128 x 128 latent, batch 1): one whole step against the fp32 oracle
         _case_step_and_trajectory("sdxl", 1, h=128, n_steps=1, case=case)
     elif case == "sd15-full-size-step-parity":     # cfg2 at its FULL size (512 px: 64 x 64 latent, batch 4)
