@@ -980,11 +980,12 @@ int launch(const sdlt_gemm_params& p, hipStream_t stream) {
 }
 
 // tile ids: 1 = 128x128 (8 waves), 2 = 64x128 (8 waves), 3 = 64x64 (4 waves), 4 = 256x128 (8 waves), 5 = 128x128 (4 waves),
-//           6 = 256x256 (8 waves), 7 = 256x160 (8 waves, 4x2), 8 = 128x160 (8 waves, 4x2)
+//           6 = 256x256 (8 waves), 7 = 256x160 (8 waves, 4x2), 8 = 128x160 (8 waves, 4x2), 9 = 128x80 (4 waves, 4x1; convolutions only)
 void tile_dims(int tile, int& bm, int& bn) {
   switch (tile) {
     case 7: bm = 256; bn = 160; break;
     case 8: bm = 128; bn = 160; break;
+    case 9: bm = 128; bn = 80; break;
     case 1: case 5: bm = 128; bn = 128; break;
     case 2: bm = 64; bn = 128; break;
     case 4: bm = 256; bn = 128; break;
@@ -1114,6 +1115,7 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
     case 6: return launch<8, 4, 4, MODE, R16, NSV>(p, s);            \
     case 7: if constexpr (R16 <= 1) return launch<4, 5, 2, MODE, R16, NSV, 0, 0, 4>(p, s); else break; \
     case 8: if constexpr (R16 <= 1) return launch<2, 5, 2, MODE, R16, NSV, 0, 0, 4>(p, s); else break; \
+    case 9: if constexpr (R16 <= 1 && MODE == 1) return launch<2, 5, 1, MODE, R16, NSV, 0, 0, 4>(p, s); else break; \
   }
   // (stages == 1, the register-staged loader, is kept in the kernel source but not instantiated: hipcc places its
   //  staging registers in scratch - measured 3-6x slower than the LDS-DMA ring on every SDXL shape.)

@@ -206,7 +206,9 @@ TOL_FAITHFUL = dict(pred=3e-2, loss=8e-3, cos=0.9995, rel=3e-2, rows_cos=0.999, 
 TOL_FP32 = dict(pred=2e-3, loss=1e-3, ta=2e-3, reg=2e-3, cos=0.9999, rel=5e-3, rows_cos=0.9999, rows_rel=1e-2, disp_cos=0.99, rows_final=1e-3, ada_rel=2e-2)
 TOL_FP32_FAITHFUL = dict(pred=3e-2, loss=2e-2, cos=0.99, rel=8e-2, rows_cos=0.985, rows_rel=0.2, ada_rel=0.45)     # (fp32 engine vs rounded oracle: the bf16 bars)
 # the "trained-like" weight mode (_trained_like): no adapter is allowed to hide behind "its gradient is numerically nothing" - every adapter tensor's cosine is bounded
-TRAINED_LIKE_EXTRA = dict(ada_min_cos=0.99)
+# (measured, round 6, profiles/r06_parity_report.json: all 1154 adapter tensors cos >= 0.9960 against the fp32 oracle / 0.9928 against the bf16-faithful one, the smallest gradient 1.8 % of
+# the median adapter's rms; the peaked softmax amplifies what bf16 storage leaves on the flat vector - rel-L2 3.1 / 3.8 %, prediction 2.2 / 2.4 % of max-abs - so those bars sit wider here)
+TRAINED_LIKE_EXTRA = dict(ada_min_cos=0.99, pred=4e-2, cos=0.998, rel=6e-2, ada_rel=0.2, ada_normal_rel=0.2)
 TOL_TRAINED_LIKE = dict(TOL_BF16, **TRAINED_LIKE_EXTRA)
 REPORT = {}        # case -> worst adapters etc., written to gpurun_out/parity_report.json when that directory exists
 
@@ -597,7 +599,7 @@ def _case_fullft_baseline_size():
 
 
 # Ordered so that each 10 GB weight state is built once: all SDXL cases, then all SD1.5 cases.
-@pytest.mark.parametrize("case", ["sdxl-step-trajectory", "sdxl-trained-like-step", "sdxl-dora-step-trajectory", "sdxl-rank24-step", "sdxl-full-size", "sdxl-full-size-step-parity",
+@pytest.mark.parametrize("case", ["sdxl-step-trajectory", "sdxl-trained-like-step", "sdxl-trained-like-full-size-step-parity", "sdxl-dora-step-trajectory", "sdxl-rank24-step", "sdxl-full-size", "sdxl-full-size-step-parity",
                                   "sdxl-fullft-gradients", "sdxl-fullft-baseline-size", "sd15-step-trajectory", "sd15-dora-step-trajectory", "sd15-rank64-step", "sd15-full-size",
                                   "sd15-full-size-step-parity"])
 def test_real_topology(case):
@@ -605,6 +607,10 @@ def test_real_topology(case):
         _case_step_and_trajectory("sdxl", 1, case=case)
     elif case == "sdxl-trained-like-step":         # peaked softmax, outlier channels, non-trivial norm gains: every adapter's gradient carries signal
         _case_step_and_trajectory("sdxl", 1, n_steps=2, case=case, trained_like=True, tol=TOL_TRAINED_LIKE, tol_faithful=dict(TOL_FAITHFUL, **TRAINED_LIKE_EXTRA))
+    elif case == "sdxl-trained-like-full-size-step-parity":      # the same mode at cfg3's full size: a report run (~50 s of oracle time), not in the driver's suite
+        if os.environ.get("SDLT_PARITY_EXTRA") != "1":
+            pytest.skip("report run: SDLT_PARITY_EXTRA=1 (profiles/r06_parity_report.json)")
+        _case_step_and_trajectory("sdxl", 1, h=128, n_steps=1, case=case, trained_like=True, tol=TOL_TRAINED_LIKE, tol_faithful=dict(TOL_FAITHFUL, **TRAINED_LIKE_EXTRA))
     elif case == "sdxl-full-size-step-parity":     # cfg3 at its FULL size (1024 px: 128 x 128 latent, batch 1): one whole step against the fp32 oracle
         _case_step_and_trajectory("sdxl", 1, h=128, n_steps=1, case=case)
     elif case == "sd15-full-size-step-parity":     # cfg2 at its FULL size (512 px: 64 x 64 latent, batch 4)

@@ -263,7 +263,7 @@ def main():
         elif name.startswith("sdlt_wsk"):
             a = cs[0][1]
             label += (f" M{a[4]} N{a[5]} K{a[6]}" if name != "sdlt_wsk_conv" else f" M{a[4] * a[5] * a[6]} N{a[8]} K{9 * a[7]}") + (" lora16" if a[12 if name != "sdlt_wsk_conv" else 17] else "") + (" R" if a[8 if name != "sdlt_wsk_conv" else 13] else "")
-        elif name.startswith(("sdlt_attn", "sdlt_strip")):
+        elif name.startswith(("sdlt_attn", "sdlt_strip")) and hasattr(cs[0][1][0], "_obj"):
             p = cs[0][1][0]._obj
             label += (f" B{p.B} H{p.H} Nq{p.Nq} Nk{p.Nk} d{p.d}" if name.startswith("sdlt_attn") else f" N{p.N} K{p.K}")
         rows.append(dict(sig=label, entry=name, family=fam, calls=len(cs), us=us, floor_us=floor, bound=bound, flop=fl, bytes=by, gap_ms=(us - floor) * len(cs) / 1e3,
