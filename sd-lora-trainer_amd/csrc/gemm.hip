@@ -980,12 +980,14 @@ int launch(const sdlt_gemm_params& p, hipStream_t stream) {
 }
 
 // tile ids: 1 = 128x128 (8 waves), 2 = 64x128 (8 waves), 3 = 64x64 (4 waves), 4 = 256x128 (8 waves), 5 = 128x128 (4 waves),
-//           6 = 256x256 (8 waves), 7 = 256x160 (8 waves, 4x2), 8 = 128x160 (8 waves, 4x2), 9 = 128x80 (4 waves, 4x1; convolutions only)
+//           6 = 256x256 (8 waves), 7 = 256x160 (8 waves, 4x2), 8 = 128x160 (8 waves, 4x2)
+// (round 6, measured and dropped - tools/conv_tile_probe.py, profiles/r06_conv_tile_probe.txt: 128 x 80 tiles of 4 waves (4 x 1) that cut a 4096 x 640 convolution into exactly
+//  256 workgroups WITHOUT a K split - no fp32 slabs, no last-arriver seam - run 47-76 % SLOWER than the 128 x 160 tiles with their 2-3 splits (64 x 64 x 640 -> 640: 88.0 vs
+//  59.9 us); 128 x 160 unsplit: +27-48 %.  The slabs' traffic is not what bounds these launches, the 8-wave K loop's DMA / MFMA staggering is what makes them fast.)
 void tile_dims(int tile, int& bm, int& bn) {
   switch (tile) {
     case 7: bm = 256; bn = 160; break;
     case 8: bm = 128; bn = 160; break;
-    case 9: bm = 128; bn = 80; break;
     case 1: case 5: bm = 128; bn = 128; break;
     case 2: bm = 64; bn = 128; break;
     case 4: bm = 256; bn = 128; break;
@@ -1115,7 +1117,6 @@ int dispatch_tile(const sdlt_gemm_params& pin, hipStream_t s) {
     case 6: return launch<8, 4, 4, MODE, R16, NSV>(p, s);            \
     case 7: if constexpr (R16 <= 1) return launch<4, 5, 2, MODE, R16, NSV, 0, 0, 4>(p, s); else break; \
     case 8: if constexpr (R16 <= 1) return launch<2, 5, 2, MODE, R16, NSV, 0, 0, 4>(p, s); else break; \
-    case 9: if constexpr (R16 <= 1 && MODE == 1) return launch<2, 5, 1, MODE, R16, NSV, 0, 0, 4>(p, s); else break; \
   }
   // (stages == 1, the register-staged loader, is kept in the kernel source but not instantiated: hipcc places its
   //  staging registers in scratch - measured 3-6x slower than the LDS-DMA ring on every SDXL shape.)

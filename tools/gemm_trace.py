@@ -23,6 +23,36 @@ def run(name, M, N, K, lora=False, res=False, geglu=False, **kw):
     rel = [x - t[0] for x in t[:12]]
     r2 = [t[12] - t[0], t[13] - t[0], t[14] - t[0]]
     print(f"{name:34s} tile-coords {r2[0]:5d} geometry {r2[1]:5d} epi-prefetch {r2[2]:5d} index {rel[1]:6d} prefill {rel[2]:6d} steps {rel[3:7]} loop end {rel[8]:7d} splitk {rel[9]:7d} lora-up {rel[10]:7d} end {rel[11]:7d}")
+def run_ff(name, M, N, K, mode):
+    """the feed-forward products with their fused GEGLU epilogues (round 6: the three largest gaps of tools/step_floor.py are the FF chain)"""
+    X = torch.randn(M, K, device="cuda").to(BF); W = (torch.randn(N, K, device="cuda") * 0.02).to(BF)
+    bias = torch.randn(N, device="cuda")
+    kw = {}
+    if mode == "geglu":            # ff.net.0.proj: F1 [M, N] and hidden * gelu(gate) [M, N / 2]
+        Y = torch.empty(M, N, device="cuda", dtype=BF)
+        kw = dict(geglu_out=torch.empty(M, N // 2, device="cuda", dtype=BF), bias=bias)
+    elif mode == "geglu_bwd":      # dX of ff.net.2 with GEGLU's backward in the epilogue: reads F1 [M, 2N], writes dF1 [M, 2N]
+        Y = None
+        kw = dict(geglu_bwd=(torch.randn(M, 2 * N, device="cuda").to(BF), torch.empty(M, 2 * N, device="cuda", dtype=BF)))
+    else:
+        Y = torch.empty(M, N, device="cuda", dtype=BF)
+        kw = dict(bias=bias)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for rep in range(4):
+        e0.record(); ops.gemm(X, W, Y, **kw); e1.record()
+        torch.cuda.synchronize()
+    out = (ctypes.c_longlong * 16)()
+    lib.sdlt_gemm_trace_read(out)
+    t = list(out)
+    rel = [x - t[0] for x in t[:12]]
+    print(f"{name:34s} eager launch {e0.elapsed_time(e1) * 1e3:6.1f} us | index {rel[1]:6d} prefill {rel[2]:6d} steps {rel[3:7]} loop end {rel[8]:7d} splitk {rel[9]:7d} lora-up {rel[10]:7d} end {rel[11]:7d} (ticks of workgroup 0)")
+if os.environ.get("SDLT_TRACE_FF") == "1":
+    run_ff("ff.net.0 1024x10240x1280 plain", 1024, 10240, 1280, "plain")
+    run_ff("ff.net.0 1024x10240x1280 geglu", 1024, 10240, 1280, "geglu")
+    run_ff("ff.net.2 dX 1024x5120x1280 plain", 1024, 5120, 1280, "plain")
+    run_ff("ff.net.2 dX 1024x5120x1280 geglu-bwd", 1024, 5120, 1280, "geglu_bwd")
+    run_ff("4096x5120x640 geglu", 4096, 5120, 640, "geglu")
+    sys.exit(0)
 run("1024x1280x1280 lora", 1024, 1280, 1280, lora=True)
 run("1024x1280x1280 lora res", 1024, 1280, 1280, lora=True, res=True)
 run("1024x3840x1280", 1024, 3840, 1280)
