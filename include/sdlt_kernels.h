@@ -610,9 +610,11 @@ typedef struct sdlt_wsk_gemm_params {
   const float* ln_c1; float* ln_stats; const float* ln_adapter;
   void* ln_parts;
   float* dotD;
-  int32_t M, N, K;
+  const void* pf_next_w;             /* hint (may be NULL): the PACKED weight [pf_next_n, pf_next_k] of the wave-split-K product that follows in the step - this launch */
+  int32_t M, N, K;                   /* touches the first pf_steps K steps of it into the L2s that will read them (never an error if it does not fit the scheme) */
   int32_t lora_group_k, lora_rp, dot_nq;
   float lora_scale, ln_eps;
+  int32_t pf_next_n, pf_next_k, pf_steps, pad_;
 } sdlt_wsk_gemm_params;
 int sdlt_wsk_gemm_p(const sdlt_wsk_gemm_params* p, void* stream);
 

@@ -120,8 +120,9 @@ class ColsumFinishDesc(C.Structure):
 class WskGemmParams(C.Structure):
     _fields_ = [("X", vp), ("ldx", i64), ("W", vp), ("ldw", i64), ("bias", vp), ("R", vp), ("ldr", i64), ("Y", vp), ("ldy", i64),
                 ("Adown", vp), ("ld_adown", i64), ("Bup", vp), ("ld_bup", i64), ("T_out", vp), ("ld_t", i64), ("col_scale", vp), ("Y0", vp), ("ldy0", i64),
-                ("ln_c1", vp), ("ln_stats", vp), ("ln_adapter", vp), ("ln_parts", vp), ("dotD", vp),
-                ("M", i32), ("N", i32), ("K", i32), ("lora_group_k", i32), ("lora_rp", i32), ("dot_nq", i32), ("lora_scale", f32), ("ln_eps", f32)]
+                ("ln_c1", vp), ("ln_stats", vp), ("ln_adapter", vp), ("ln_parts", vp), ("dotD", vp), ("pf_next_w", vp),
+                ("M", i32), ("N", i32), ("K", i32), ("lora_group_k", i32), ("lora_rp", i32), ("dot_nq", i32), ("lora_scale", f32), ("ln_eps", f32),
+                ("pf_next_n", i32), ("pf_next_k", i32), ("pf_steps", i32), ("pad_", i32)]
 
 
 class StripParams(C.Structure):

@@ -69,6 +69,11 @@ struct wsk_params {
   // ... and the layer's own output before the residual (DoRA's magnitude gradient needs it: d m = sum_rows dY (y0 - bias) / m): Y0 [M, N] = rounded(col_scale (X W^T + adapter) + bias),
   // written next to Y = Y0's fp32 value + R - one launch instead of the product + an add2d launch.  NULL: not written.
   bf16_t* Y0; int64_t ldy0;
+  // next-weight prefetch (round 6, lab): pf_ptr = the PACKED weight of the wave-split-K product that follows this launch in the step (sdlt_wsk_pack_weight's layout, N_next / 80 column-tile
+  // blocks of pf_tile_bytes each); behind its K walk every workgroup touches - one lane per 128-byte line - its share of the first pf_head_bytes of the pf_ntn / 4 column tiles
+  // the SAME XCD will walk in that launch (the 2 x 4 XCD map: XCD x owns column quarter x & 3), so that the next launch's first K steps hit in this XCD's L2 instead of paying
+  // the fabric's first-touch burst (the launches are bound by it: DESIGN 4.14).  NULL: off.
+  const char* pf_ptr; int pf_tile_bytes, pf_head_bytes, pf_ntn;
 };
 
 // -DSDLT_WSK_TRACE (tools/wsk_trace.py): thread 0 of workgroup 0 stamps clock64() at the phase boundaries; sdlt_wsk_trace_read copies them out
@@ -106,6 +111,7 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   asm volatile("" ::"s"(p.ln_c1), "s"(p.ln_stats), "s"(p.ln_adapter), "s"(p.ln_eps), "s"(p.ln_parts), "s"(p.Wp), "s"(p.dotD), "s"(p.dot_nq));
   if constexpr (CONV) asm volatile("" ::"s"(p.Hc), "s"(p.Wc), "s"(p.Cin), "s"(p.flip), "s"(p.zero), "s"(p.rowbias), "s"(p.ld_rowbias));
   if constexpr (LORA) asm volatile("" ::"s"(p.col_scale), "s"(p.Y0), "s"(p.ldy0));
+  asm volatile("" ::"s"(p.pf_ptr), "s"(p.pf_tile_bytes), "s"(p.pf_head_bytes), "s"(p.pf_ntn));
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int ntn = p.N / WR, ntm = p.M / XR;
@@ -455,6 +461,18 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
   // round-3 assignment (units w, w + 4, ... per wave)
   constexpr int UNITS = MBK * JN, TUN = LORA ? TG * MBK : 0, SMU = UNITS + TUN, UALL = UNITS + TUN + (LN ? 1 : 0);
   WTR(8);
+  // next-weight prefetch: the touches go out behind this wave's last operand load (nothing of the K walk waits for them) and are waited for at the very end of the kernel, beside
+  // the output stores; ONE destination register kept alive until then ("+v": hipcc must not hand it to anything else while loads into it are in flight)
+  uint32_t pf_tmp = 0;
+  if (p.pf_ptr) {
+    const int xcdp = blockIdx.x & 7, idxp = blockIdx.x >> 3, nxp = gridDim.x >> 3;
+    const int pcp = p.pf_ntn >> 2, lpt = p.pf_head_bytes >> 7, totalp = pcp * lpt;
+    for (int l = idxp * (64 * NW) + (int)threadIdx.x; l < totalp; l += nxp * (64 * NW)) {
+      const int t = div_small(l, lpt), o = l - t * lpt;
+      const char* a = p.pf_ptr + (int64_t)((xcdp & 3) * pcp + t) * p.pf_tile_bytes + (int64_t)o * 128;
+      asm volatile("global_load_dword %0, %1, off" : "+v"(pf_tmp) : "v"(a) : "memory");
+    }
+  }
   if constexpr (LORA && LATE) {
     load_bup();
 #pragma unroll
@@ -595,6 +613,10 @@ __global__ __launch_bounds__(64 * NW) void wsk_kernel(const wsk_params p) {
     }
   }
   WTR(11);
+  if (p.pf_ptr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::"v"(pf_tmp));
+  }
 }
 
 template <int MBK, int JN, int R, int KG, bool LN = false, bool WP = false, bool CONV = false, int RG = 1>
@@ -647,7 +669,8 @@ static int wsk_gemm_impl(const void* X, int64_t ldx, const void* W, int64_t ldw,
                          const void* R, int64_t ldr, void* Y, int64_t ldy, const void* Adown, int64_t ld_adown, const void* Bup, int64_t ld_bup,
                          float lora_scale, void* T_out, int64_t ld_t, int32_t lora_group_k, const float* ln_c1, float* ln_stats, float ln_eps,
                          const float* ln_adapter, void* ln_parts, void* stream, float* dotD = nullptr, int32_t dot_nq = 0, int32_t lora_rp = 16,
-                         const float* col_scale = nullptr, void* Y0 = nullptr, int64_t ldy0 = 0) {
+                         const float* col_scale = nullptr, void* Y0 = nullptr, int64_t ldy0 = 0,
+                         const void* pf_w = nullptr, int32_t pf_n = 0, int32_t pf_k = 0, int32_t pf_steps = 0) {
   if (M <= 0 || N <= 0 || K <= 0 || (M % 64) || (N % 80) || ((N / 80) % 8) || (K % 256))
     SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wsk_gemm: M=%d N=%d K=%d (M %% 64, N %% 640, K %% 256 == 0)", M, N, K);
   const bool packed = ldw == 0;          // W is sdlt_wsk_pack_weight's output
@@ -670,7 +693,13 @@ static int wsk_gemm_impl(const void* X, int64_t ldx, const void* W, int64_t ldw,
   static const int stagger_env = getenv("SDLT_WSK_STAGGER") ? atoi(getenv("SDLT_WSK_STAGGER")) : 1;   // (read once: A/B switch)
   wsk_params p{(const bf16_t*)X, ldx, (const bf16_t*)W, ldw, bias, (const bf16_t*)R, ldr, (bf16_t*)Y, ldy, M, N, K, 1,
                (const bf16_t*)Adown, ld_adown, (const bf16_t*)Bup, ld_bup, (bf16_t*)T_out, ld_t, lora_scale, lora_group_k, stagger_env,
-               ln_c1, ln_stats, ln_adapter, ln_eps, (float2*)ln_parts, packed ? (const bf16_t*)W : nullptr, 0, 0, 0, 0, nullptr, nullptr, 0, dotD, dot_nq, col_scale, (bf16_t*)Y0, ldy0};
+               ln_c1, ln_stats, ln_adapter, ln_eps, (float2*)ln_parts, packed ? (const bf16_t*)W : nullptr, 0, 0, 0, 0, nullptr, nullptr, 0, dotD, dot_nq, col_scale, (bf16_t*)Y0, ldy0, nullptr, 0, 0, 0};
+  if (pf_w && pf_steps > 0) {      // (a hint: anything that does not fit the scheme is ignored, never an error)
+    if (pf_n > 0 && pf_k > 0 && (pf_n % 320) == 0 && (pf_k % 64) == 0 && !((uintptr_t)pf_w & 127)) {
+      const int steps = pf_steps < (pf_k >> 6) ? pf_steps : (pf_k >> 6);
+      p.pf_ptr = (const char*)pf_w; p.pf_tile_bytes = (pf_k >> 6) * 10240; p.pf_head_bytes = steps * 10240; p.pf_ntn = pf_n / 80;
+    }
+  }
   if (((uintptr_t)ln_parts) & 7) SDLT_FAIL(SDLT_ERR_ALIGN, "sdlt_wsk_gemm: ln_parts must be 8-byte aligned");
   if (dotD && (!R || ln_c1 || (N % 64) || dot_nq <= 0 || (M % dot_nq) || ((uintptr_t)dotD & 3)))
     SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wsk_gemm_rowdot: O is required, N %% 64 == 0 (64-wide heads), M = B * Nq, no folded LayerNorm");
@@ -729,7 +758,7 @@ extern "C" int sdlt_wsk_gemm_p(const sdlt_wsk_gemm_params* q, void* stream) {
   if (!q) SDLT_FAIL(SDLT_ERR_SHAPE, "sdlt_wsk_gemm_p: params == NULL");
   if (q->dotD && (q->ln_c1 || q->ln_parts)) SDLT_FAIL(SDLT_ERR_UNSUPPORTED, "sdlt_wsk_gemm_p: the row-dot side output excludes the folded LayerNorm / row partials");
   return wsk_gemm_impl(q->X, q->ldx, q->W, q->ldw, q->M, q->N, q->K, q->bias, q->R, q->ldr, q->Y, q->ldy, q->Adown, q->ld_adown, q->Bup, q->ld_bup, q->lora_scale,
-                       q->T_out, q->ld_t, q->lora_group_k, q->ln_c1, q->ln_stats, q->ln_eps, q->ln_adapter, q->ln_parts, stream, q->dotD, q->dot_nq, q->lora_rp, q->col_scale, q->Y0, q->ldy0);
+                       q->T_out, q->ld_t, q->lora_group_k, q->ln_c1, q->ln_stats, q->ln_eps, q->ln_adapter, q->ln_parts, stream, q->dotD, q->dot_nq, q->lora_rp, q->col_scale, q->Y0, q->ldy0, q->pf_next_w, q->pf_next_n, q->pf_next_k, q->pf_steps);
 }
 
 extern "C" int sdlt_wsk_conv(const void* X, int64_t ldx, const void* W, int64_t ldw, int32_t B, int32_t H, int32_t Wd, int32_t Cin, int32_t N, int32_t flip,

@@ -218,6 +218,52 @@ def _wsk_operand(W):
     return _p(W), _ld(W)
 
 
+# ---- next-weight prefetch (round 6): a wave-split-K launch is bound by the fabric's first-touch burst of its operands; the launch in front of it can touch the
+# first K steps of its packed weight into the L2s that will read them (sdlt_wsk_gemm_params.pf_next_w).  The plan is static, so the "next weight" of every launch is known from
+# one eager pass: step.TrainStep records the sequence of wave-split-K products of each graph it captures (pf_record_*) and replays it while capturing (pf_replay_*); a launch
+# whose (weight, N, K) differs from the recorded pass switches the hints off for the rest of that capture.  Hints never change a result.  SDLT_WSK_PREFETCH=0: off (A/B).
+WSK_PREFETCH = os.environ.get("SDLT_WSK_PREFETCH", "1") != "0"
+WSK_PREFETCH_STEPS = int(os.environ.get("SDLT_WSK_PREFETCH_STEPS", "40"))      # K steps of 64 columns touched per column tile (tools/wsk_prefetch_probe.py)
+_PF = {"mode": None, "seq": None, "idx": 0}
+
+
+def pf_record_begin():
+    _PF.update(mode="record", seq=[], idx=0)
+
+
+def pf_record_end():
+    seq = _PF["seq"]
+    _PF.update(mode=None, seq=None, idx=0)
+    return seq
+
+
+def pf_replay_begin(seq):
+    _PF.update(mode="replay" if (WSK_PREFETCH and seq) else None, seq=seq, idx=0)
+
+
+def pf_replay_end():
+    _PF.update(mode=None, seq=None, idx=0)
+
+
+def _pf_hint(Wptr, Wld, N, K):
+    """The (pointer, N, K) of the packed weight the NEXT wave-split-K product of the recorded plan reads, or None."""
+    m = _PF["mode"]
+    if m is None:
+        return None
+    ent = ((Wptr.value or 0) if Wld == 0 else 0, int(N), int(K))
+    if m == "record":
+        _PF["seq"].append(ent)
+        return None
+    seq, i = _PF["seq"], _PF["idx"]
+    if i >= len(seq) or seq[i] != ent:          # not the plan that was recorded: no hints from here on
+        _PF["mode"] = None
+        return None
+    _PF["idx"] = i + 1
+    if i + 1 < len(seq) and seq[i + 1][0] and seq[i + 1][0] != ent[0] and seq[i + 1][1] % 320 == 0:
+        return seq[i + 1]
+    return None
+
+
 WSK_CONV = os.environ.get("SDLT_WSK_CONV", "1") != "0"
 
 
@@ -298,12 +344,16 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
                 _chk2(T_)
                 assert tuple(T_.shape) == (M_, rp_ * G_)
         Wptr, Wld = _wsk_operand(W)
-        if rp_ > 16 or col_scale is not None or out0 is not None:
+        hint = _pf_hint(Wptr, Wld, N_, K_)
+        if rp_ > 16 or col_scale is not None or out0 is not None or hint is not None:
             # the parameter-block entry point: rank pads 32 / 64 (packed weights) and DoRA's column factor exist only there
             q = _lib.WskGemmParams()
             q.X, q.ldx, q.W, q.ldw, q.M, q.N, q.K = _p(X), _ld(X), Wptr, Wld, M_, N_, K_
             q.bias, q.Y, q.ldy = _p(bias), _p(out), _ld(out)
-            q.Adown, q.ld_adown, q.Bup, q.ld_bup, q.lora_scale, q.lora_rp = _p(A_), _ld(A_), _p(B_), _ld(B_), float(scale_), rp_
+            if hint is not None:
+                q.pf_next_w, q.pf_next_n, q.pf_next_k, q.pf_steps = hint[0], hint[1], hint[2], min(hint[2] // 64, WSK_PREFETCH_STEPS)
+            if lora is not None:
+                q.Adown, q.ld_adown, q.Bup, q.ld_bup, q.lora_scale, q.lora_rp = _p(A_), _ld(A_), _p(B_), _ld(B_), float(scale_), rp_
             if T_ is not None:
                 q.T_out, q.ld_t = _p(T_), _ld(T_)
             q.lora_group_k = int(lora_group_k)
@@ -319,8 +369,7 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
             if ln is not None:
                 c1, stats_, eps_, lnad = ln[:4]
                 _chk2(c1, F32)
-                assert Wld == 0 or rp_ == 16
-                assert c1.numel() == N_ and (stats_ is None or (stats_.dtype == F32 and stats_.numel() >= 2 * M_)) and lnad is not None and lnad.numel() >= 2 * rp_
+                assert c1.numel() == N_ and (stats_ is None or (stats_.dtype == F32 and stats_.numel() >= 2 * M_)) and (lora is None or (lnad is not None and lnad.numel() >= 2 * rp_))
                 q.ln_c1, q.ln_stats, q.ln_eps, q.ln_adapter = _p(c1), _p(stats_), float(eps_), _p(lnad)
             elif ln_parts_out is not None:
                 assert ln_parts_out.dtype == F32 and ln_parts_out.is_contiguous() and ln_parts_out.numel() >= M_ * (N_ // 80) * 2
@@ -331,7 +380,7 @@ def gemm(X, W, out, *, X2=None, W2=None, conv=None, lora=None, bias=None, rowbia
                 assert tuple(O_.shape) == (M_, N_) and D_.is_contiguous() and D_.numel() >= M_ * (N_ // 64)
                 q.R, q.ldr, q.dotD, q.dot_nq = _p(O_), _ld(O_), _p(D_), int(rowdot["Nq"])
                 rowdot["done"] = True
-            assert rp_ == 16 or Wld == 0, "rank pads 32 / 64 run on the packed copy of a frozen weight"
+            assert rp_ <= 16 or Wld == 0, "rank pad 32 runs on the packed copy of a frozen weight"
             _lib.check(lib.sdlt_wsk_gemm_p(C.byref(q), _stream()), "sdlt_wsk_gemm_p")
             return out
         if ln is not None:

@@ -795,11 +795,32 @@ class TrainStep:
             for _ in range(warmup):
                 self.body()
         torch.cuda.current_stream().wait_stream(s)
+        ops = self.rt.ops
+        prefetch = hasattr(ops, "pf_record_begin") and getattr(ops, "WSK_PREFETCH", False) and not self.ddp and not self.full_ft      # (frozen, packed weights only: LoRA / TI jobs)
+
         def cap(fns, pool):
+            # next-weight prefetch (ops.pf_*): one more eager pass of exactly these phases records the sequence of wave-split-K products, the capture replays it so that every
+            # such launch knows the packed weight of the one behind it (the optimizer state this pass moves is restored below, like the warm-up's)
+            seq = None
+            if prefetch:
+                with torch.cuda.stream(s):
+                    ops.pf_record_begin()
+                    try:
+                        for fn in fns:
+                            fn()
+                    finally:
+                        seq = ops.pf_record_end()
+                torch.cuda.current_stream().wait_stream(s)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool):
-                for fn in fns:
-                    fn()
+                if seq:
+                    ops.pf_replay_begin(seq)
+                try:
+                    for fn in fns:
+                        fn()
+                finally:
+                    if seq:
+                        ops.pf_replay_end()
             return g
         phases = self._phases()
         split = (self.text is not None and self.text.concurrent) or self.ddp      # one graph per phase when the encoders fork / DDP
@@ -830,6 +851,10 @@ class TrainStep:
                 acc_buf.zero_()
         for t, c in zip(state, snap):
             t.copy_(c)
+        if not self.full_ft:
+            # the logged sum of |p| (a read-out the optimizer kernel leaves; the capture passes ran it on parameters that are restored above - with more than one eager pass on a
+            # zero hyper row they are not even finite): what a gradient-accumulation micro-step logs before the first optimizer step is the restored parameters' own sum
+            self.l1_sum.copy_(a.params.abs().sum().reshape(1))
         a.refresh_shadows()
         if self.ti is not None:
             self.ti.refresh_tables()
