@@ -143,6 +143,8 @@ class WeightTrainer:
         element + one fp32 absmax per 2048-element block (include/sdlt_kernels.h: sdlt_adamw8_shadow_refresh) - 2 x 10.3 GB of fp32 moments become 2 x 2.6 GB on
         SDXL and the optimizer pass moves 20 instead of 32 bytes per parameter.  The vector region (biases, norm affine parameters: 0.1 % of the arena) keeps fp32
         moments: bitsandbytes does the same for every tensor under 4096 elements, and quantises the 140 GEGLU / conv biases above that size, which stay fp32 here."""
+        if getattr(self, "q8", None) is not None:          # (idempotent: a second TrainStep on the same trainer finds the 8-bit state in place)
+            return
         assert self.params is not None and self.m is not None and self._plan is not None
         nm, dev = self.n_mat, self.rt.device
         self.m_vec, self.v_vec = self.m[nm:].clone(), self.v[nm:].clone()
