@@ -473,6 +473,8 @@ def main():
                     "(TrainStep(ddp_wire_dtype=); default fp32 = exact)")
     ap.add_argument("--profile-json", default=None, help="step profile of THIS command (tools/step_profile.py over the rocprofv3 kernel trace + FETCH_SIZE / "
                     "WRITE_SIZE passes): source of roofline.traffic and roofline.hbm_kernels; default: the newest profiles/rNN_sdxl1024_ti_step_profile.json for the default workload")
+    ap.add_argument("--families-only", action="store_true", help=argparse.SUPPRESS)          # child mode: per-family kernel time of THIS process's replayed steps (torch.profiler)
+    ap.add_argument("--no-families", action="store_true", help="skip the extra in-run measurement of the per-family kernel times (roofline.families_this_run)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the extra sustained-rate measurement behind the timed region")
     ap.add_argument("--sustained-steps", type=int, default=100)
     ap.add_argument("--launch-test", action="store_true", help=argparse.SUPPRESS)            # tests/test_parallel_cpu.py: launcher + timing protocol on CPU
@@ -640,6 +642,40 @@ def main():
     loss = losses[0]
     assert all(math.isfinite(x) for x in losses), "non-finite loss in the timed region"
 
+    if args.families_only:
+        # per-family kernel time of the replayed step IN THIS PROCESS (the families of the bench line used to come from a committed profile of another box):
+        # three more steps under torch.profiler (roctracer kernel records), folded with the family rules of tools/step_profile.py
+        import re
+        from torch.profiler import ProfilerActivity, profile
+        nprof = 3
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for i in range(nprof):
+                step_all(args.warmup + (i % max(1, args.steps)))
+            torch.cuda.synchronize()
+
+        def fam_of(k):
+            k = re.sub(r"\(anonymous namespace\)::", "", k).replace("void ", "")
+            if k.startswith(("gemm_kernel", "wsk_kernel")): return "gemm"
+            if k.startswith("strip_"): return "text_gemm"
+            if k.startswith("attn"): return "attention"
+            if "lora_grad" in k: return "lora_grad"
+            if k.startswith("gn_"): return "groupnorm"
+            if k.startswith("ln_"): return "layernorm"
+            if k.startswith("geglu"): return "geglu"
+            if k.startswith(("adamw_kernel", "shadow_kernel")): return "adamw"
+            if "at::" in k or "rocclr" in k or "Memcpy" in k or "Memset" in k: return "torch"
+            return "other"
+        fam_us, fam_n, seen = {}, {}, 0
+        for e in prof.events():
+            if str(getattr(e, "device_type", "")).endswith("CUDA") and getattr(e, "device_time", 0) > 0:
+                f = fam_of(e.name)
+                fam_us[f] = fam_us.get(f, 0.0) + float(e.device_time)
+                fam_n[f] = fam_n.get(f, 0) + 1
+                seen += int("mse_reduce_kernel" in e.name)          # (once per step: the tracer does not always deliver the first replay's records)
+        nprof = max(1, seen // J) if seen else nprof
+        print(json.dumps({"steps_profiled": nprof, "ms_per_step_timed": elapsed / args.steps * 1e3, "family_ms": {f: v / nprof / 1e3 for f, v in fam_us.items()},
+                          "family_launches": {f: n / nprof for f, n in fam_n.items()}, "busy_ms": sum(fam_us.values()) / nprof / 1e3}), flush=True)
+        return
     if rank == 0:
         # LoRA: dX only (+ small adapter terms) = 2 x forward; full fine-tune: dX and dW = 3 x forward
         f_step = (3.0 * topology.fwd_flops(cfg, B, h, h, 0)["total"]) if full_ft else 2.0 * topology.fwd_flops(cfg, B, h, h, args.rank)["total"]
@@ -801,6 +837,23 @@ def main():
                     out["library_gpu_baseline"] = child[-1]
                     out["library_gpu_baseline"]["speedup_of_value"] = out["value"] / child[-1]["value"]
                 print("[bench] library GPU baseline done", file=sys.stderr, flush=True)
+        if world == 1 and J == 1 and not args.no_graph and not args.no_families and not args.no_cpu_baseline:
+            # Extra measurement (never `value`), child process with a wall-clock limit: the per-family kernel times of THIS box and THIS code (torch.profiler over three replayed steps of
+            # the same workload) next to the families of the committed rocprofv3 profile above; fractions against the same algorithmic FLOPs
+            argv = ["--families-only", "--config", version, "--res", str(res), "--rank", str(args.rank), "--steps", "5", "--warmup", "3", "--no-cpu-baseline", "--no-sustained"] \
+                + (["--batch", str(args.batch)] if args.batch else []) + (["--no-ti"] if args.no_ti else []) + (["--ti-frozen"] if args.ti_frozen else []) + (["--dora"] if args.dora else []) \
+                + (["--full-ft"] if full_ft else []) + (["--fp32-moments"] if args.fp32_moments else [])
+            child = run_guarded(argv, 300)
+            if child and isinstance(child[-1], dict) and "family_ms" in child[-1]:
+                fr = child[-1]
+                if not full_ft:
+                    fl2 = topology.fwd_flops(cfg, B, h, h, args.rank)
+                    for fam, fpt in (("gemm", 2.0 * (fl2["total"] - fl2["attn_core"] - fl2["daam"])), ("attention", 2.0 * fl2["attn_core"])):
+                        if fr["family_ms"].get(fam):
+                            fr.setdefault("frac_of_peak", {})[fam] = fpt / (fr["family_ms"][fam] * 1e-3) / PEAK_BF16_DENSE
+                fr["note"] = "torch.profiler (roctracer kernel records) over three replayed steps in a child process of this run: kernel time per family and step on THIS box with THIS code"
+                out["roofline"]["families_this_run"] = fr
+            print("[bench] in-run family times done", file=sys.stderr, flush=True)
         if world == 1 and J == 1 and not full_ft and not args.no_graph and not args.no_train_loop and text is not None:
             # Extra measurement (never `value`), in a child process with a wall-clock limit (see train_loop_measure)
             child = run_guarded(["--train-loop-only", "--config", version, "--res", str(res), "--rank", str(args.rank), "--steps", str(args.steps)]
