@@ -7,10 +7,6 @@ mkdir -p $O
 timeout 900 python -m pytest tests/test_kernels_gpu.py -q -x -k "rank_groups_and_dora or packed_weight or wsk_gemm" > $O/tests_wsk.log 2>&1; tail -3 $O/tests_wsk.log
 timeout 900 python -m pytest tests/test_ti_step_gpu.py -q -x -k "text_encoder_lora" > $O/tests_te.log 2>&1; tail -3 $O/tests_te.log
 B="--no-cpu-baseline --no-concurrent --no-train-loop --no-sustained --steps 30 --warmup 5"
-run() { # label, env..., -- args
-  L=$1; shift
-  ( env "$@" 2>/dev/null | true ) ; 
-}
 ab() { # label "ENV=.." args...
   L=$1; EV=$2; shift; shift
   env $EV timeout 600 python bench.py $B "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$L', '$EV', round(d['ms_per_step'],3), 'loss', d['config']['final_loss'])" | tee -a $O/ab.txt
