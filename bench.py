@@ -647,7 +647,8 @@ def main():
         # three more steps under torch.profiler (roctracer kernel records), folded with the family rules of tools/step_profile.py
         import re
         from torch.profiler import ProfilerActivity, profile
-        nprof = 3
+        nprof = 4
+        torch.cuda.synchronize()                 # (nothing of the timed region may still be draining when the tracer starts)
         with profile(activities=[ProfilerActivity.CUDA]) as prof:
             for i in range(nprof):
                 step_all(args.warmup + (i % max(1, args.steps)))
@@ -665,14 +666,18 @@ def main():
             if k.startswith(("adamw_kernel", "shadow_kernel")): return "adamw"
             if "at::" in k or "rocclr" in k or "Memcpy" in k or "Memset" in k: return "torch"
             return "other"
-        fam_us, fam_n, seen = {}, {}, 0
-        for e in prof.events():
-            if str(getattr(e, "device_type", "")).endswith("CUDA") and getattr(e, "device_time", 0) > 0:
-                f = fam_of(e.name)
-                fam_us[f] = fam_us.get(f, 0.0) + float(e.device_time)
-                fam_n[f] = fam_n.get(f, 0) + 1
-                seen += int("mse_reduce_kernel" in e.name)          # (once per step: the tracer does not always deliver the first replay's records)
-        nprof = max(1, seen // J) if seen else nprof
+        # whole steps only: the kernel records between the first and the last once-per-step loss kernel (the tracer does not always deliver the first replay's records)
+        evs = sorted(((e.time_range.start, e.name, float(e.device_time)) for e in prof.events()
+                      if str(getattr(e, "device_type", "")).endswith("CUDA") and getattr(e, "device_time", 0) > 0), key=lambda t: t[0])
+        marks = [i for i, (_, n, _) in enumerate(evs) if "mse_reduce_kernel" in n]
+        assert len(marks) >= 1 + J, f"torch.profiler delivered {len(marks)} step markers"
+        evs = evs[marks[0] + 1: marks[-1] + 1]
+        nprof = (len(marks) - 1) // J
+        fam_us, fam_n = {}, {}
+        for _, name, dur in evs:
+            f = fam_of(name)
+            fam_us[f] = fam_us.get(f, 0.0) + dur
+            fam_n[f] = fam_n.get(f, 0) + 1
         print(json.dumps({"steps_profiled": nprof, "ms_per_step_timed": elapsed / args.steps * 1e3, "family_ms": {f: v / nprof / 1e3 for f, v in fam_us.items()},
                           "family_launches": {f: n / nprof for f, n in fam_n.items()}, "busy_ms": sum(fam_us.values()) / nprof / 1e3}), flush=True)
         return
